@@ -1,0 +1,198 @@
+/*
+ * sparta_amd.h -- C-ABI of the MI355X-native block-sparse SpMM path
+ * (Jaccard row-clustering reorder -> VBS build -> VBS A x dense B on gfx950).
+ *
+ * This is the drop-in boundary for the ONE hot path of HicrestLaboratory/SPARTA.  Every entry
+ * point below cites the reference interface it replaces (paths relative to the reference tree).
+ * Plain pointers and sizes only; no C++/torch types; no exceptions cross the boundary.
+ * All functions return SPARTA_OK (0) or a negative status; sparta_last_error() returns a
+ * thread-local message for the last failure on the calling thread.
+ *
+ * Conventions kept from the reference:
+ *   - `intT` is 64-bit (include/definitions.h:4) -> every VBS index array is int64_t here.
+ *   - A VBS block is column-major h x w, blocks of a block-row are consecutive, block-rows are
+ *     consecutive (include/matrices.h:95-104).
+ *   - B is column-major cols x N with ld = cols, C is column-major rows x N with ld = rows, the
+ *     rows of C are in REORDERED order, and C is accumulated into (src/general/vbr.cpp:323-372).
+ *     Both layouts and the accumulate flag are explicit arguments here.
+ *   - `dt` is the device time of the multiply only, in milliseconds, excluding host<->device
+ *     copies (src/cuda/cuda_utilities.cpp:828,872-875).
+ */
+#ifndef SPARTA_AMD_H
+#define SPARTA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define SPARTA_OK               0
+#define SPARTA_ERR_INVALID     -1   /* bad argument (null pointer, negative size, unsorted row, ...) */
+#define SPARTA_ERR_ALLOC       -2   /* host or device allocation failed */
+#define SPARTA_ERR_HIP         -3   /* a HIP runtime call failed (message has the HIP error string) */
+#define SPARTA_ERR_UNSUPPORTED -4   /* valid request this build does not implement */
+#define SPARTA_ERR_IO          -5   /* file could not be read / parsed */
+#define SPARTA_ERR_NO_DEVICE   -6   /* no gfx950 device visible: the product path has NO CPU fallback */
+
+/* ---- enums -------------------------------------------------------------------------------- */
+/* storage/compute type of the VBS values on the device; accumulation is always fp32 */
+#define SPARTA_F32  0
+#define SPARTA_F16  1
+#define SPARTA_BF16 2
+
+#define SPARTA_COL_MAJOR 0          /* the reference's layout for B and C */
+#define SPARTA_ROW_MAJOR 1
+
+#define SPARTA_PTR_HOST   0         /* B and C are host buffers: copied in/out, dt excludes the copies */
+#define SPARTA_PTR_DEVICE 1         /* B and C are device buffers: stream-ordered, nothing is copied */
+
+/* BlockingType of the reference, same numeric values (include/definitions.h:17; flag -a) */
+#define SPARTA_BLOCKING_ITERATIVE            0
+#define SPARTA_BLOCKING_ITERATIVE_STRUCTURED 1   /* m:n structured variant -- not on the hot path: UNSUPPORTED */
+#define SPARTA_BLOCKING_FIXED_SIZE           2
+#define SPARTA_BLOCKING_ITERATIVE_CLOCKED    3   /* the reference's default (include/input.h:27) */
+#define SPARTA_BLOCKING_ITERATIVE_QUEUE      4
+#define SPARTA_BLOCKING_ITERATIVE_MAX_SIZE   5   /* dispatches to IterativeBlockingKeeper (blocking.cpp:655) */
+#define SPARTA_BLOCKING_SCRAMBLE             6
+
+/* similarity measure, flag -m (include/input.h:29, src/general/blocking.cpp:699-717) */
+#define SPARTA_SIM_HAMMING 0
+#define SPARTA_SIM_JACCARD 1
+
+/* kernel selection for sparta_vbs_spmm (`algo` argument) */
+#define SPARTA_SPMM_MFMA  0   /* hand-written MFMA kernels (the product path) */
+#define SPARTA_SPMM_EXACT 1   /* fp32 only: unfused mul+add in the reference's summation order,
+                                 bit-identical to VBR::multiply on finite inputs (slow; for parity) */
+
+/* ---- reorder (host-side C++) -------------------------------------------------------------- */
+/* replaces the configuration fields of class BlockingEngine (include/blocking.h:12-23) as filled
+ * from the command line by BlockingEngine(CLineReader&) (src/general/blocking.cpp:678-688). */
+typedef struct sparta_reorder_cfg {
+    int32_t blocking_algo;     /* SPARTA_BLOCKING_*            (-a, default 3)    */
+    int32_t sim_measure;       /* SPARTA_SIM_*                 (-m, default 1)    */
+    float   tau;               /* merge threshold, dist <= tau (-t, default 0.1)  */
+    int32_t use_groups;        /* weight distances by cluster size (-g, default 0)*/
+    int64_t col_block_size;    /* w                            (-b, default 3)    */
+    int64_t row_block_size;    /* max / fixed block-row height (-B, default 3)    */
+    int32_t use_pattern;       /* merge rows into the pattern  (-p, default 1)    */
+    int32_t force_fixed_size;  /* re-chunk into equal heights  (-F, default 0)    */
+} sparta_reorder_cfg;
+
+/* replaces the measuring fields of BlockingEngine (include/blocking.h:28-42) */
+typedef struct sparta_reorder_stats {
+    int64_t comparison_counter;
+    int64_t merge_counter;
+    float   average_row_distance;
+    float   average_merge_tau;
+    float   timer_total;        /* microseconds, as in the reference (blocking.cpp:236-238) */
+    float   timer_comparisons;
+    float   timer_merges;
+    int32_t reserved;
+} sparta_reorder_stats;
+
+/* fills *cfg with the reference's command-line defaults (include/input.h:15-42) */
+void sparta_reorder_cfg_default(sparta_reorder_cfg* cfg);
+
+/* replaces std::vector<intT> BlockingEngine::GetGrouping(const CSR&)  (include/blocking.h:47,
+ * src/general/blocking.cpp:633-676).  The CSR is flat: rowptr[rows+1], colidx ascending within each
+ * row.  grouping_out[rows] receives one group id per row (the reference's convention: the id is the
+ * seed row; algo 5 numbers incomplete clusters seed+rows).  stats may be NULL. */
+int sparta_reorder(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx,
+                   const sparta_reorder_cfg* cfg, int64_t* grouping_out, sparta_reorder_stats* stats);
+
+/* replaces get_permutation / get_partition / get_fixed_size_grouping (src/general/utilities.cpp:8-54).
+ * perm_out[new_row] = old_row.  part_out needs room for n+1 entries; *n_part_out receives the count
+ * (block_rows + 1). */
+int sparta_get_permutation(const int64_t* grouping, int64_t n, int64_t* perm_out);
+int sparta_get_partition(const int64_t* grouping, int64_t n, int64_t* part_out, int64_t* n_part_out);
+int sparta_get_fixed_size_grouping(const int64_t* grouping, int64_t n, int64_t row_block_size, int64_t* grouping_out);
+
+/* replaces HammingDistanceGroup / JaccardDistanceGroup (src/general/blocking.cpp:859-994): distance
+ * between a cluster pattern row_a (column ids, weight group_a) and a row row_b (weight group_b) on
+ * column blocks of width block_size. */
+int sparta_row_distance(int32_t sim_measure, const int64_t* row_a, int64_t size_a, int64_t group_a,
+                        const int64_t* row_b, int64_t size_b, int64_t group_b, int64_t block_size, float* dist_out);
+
+/* replaces merge_rows (src/general/utilities.cpp:145-173), including its lossy behaviour.
+ * out needs room for size_a + size_b entries. */
+int sparta_merge_rows(const int64_t* row_a, int64_t size_a, const int64_t* row_b, int64_t size_b,
+                      int64_t* out, int64_t* size_out);
+
+/* ---- VBS build (host-side C++) ------------------------------------------------------------- */
+/* the five arrays + scalars of struct VBR (include/matrices.h:93-104), owned by the library */
+typedef struct sparta_vbs_host {
+    int64_t rows, cols;           /* padded up to block multiples when force_fixed_size */
+    int64_t block_rows, block_cols;
+    int64_t block_col_size;
+    int64_t nztot;                /* number of stored values = sum h*w over nonzero blocks */
+    int64_t nblocks;              /* number of nonzero blocks = sum nzcount */
+    int64_t* row_part;            /* [block_rows + 1] */
+    int64_t* nzcount;             /* [block_rows]     */
+    int64_t* jab;                 /* [nblocks]        */
+    float*   mab;                 /* [nztot]          */
+} sparta_vbs_host;
+
+/* replaces VBR::fill_from_CSR_inplace(cmat, grouping, col_block_size, row_block_size, force_fixed_size)
+ * (include/matrices.h:118, src/general/vbr.cpp:135-237).  vals == NULL means pattern-only (every
+ * stored nonzero is 1, vbr.cpp:217).  The caller releases *out with sparta_vbs_host_free. */
+int sparta_vbs_build(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals,
+                     const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, int32_t force_fixed_size,
+                     sparta_vbs_host* out);
+void sparta_vbs_host_free(sparta_vbs_host* v);
+
+/* replaces BlockingEngine::CollectBlockingInfo (src/general/blocking.cpp:576-631): statistics of
+ * the VBS a grouping would give, without building it. info_out: [VBR_nzcount, VBR_nzblocks_count,
+ * VBR_longest_row]; avg_height_out: VBR_average_height. */
+int sparta_blocking_info(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx,
+                         const int64_t* grouping, int64_t col_block_size, int64_t* info_out, float* avg_height_out);
+
+/* ---- device: VBS A x dense B (hand-written HIP, gfx950) ---------------------------------------- */
+typedef struct sparta_vbs sparta_vbs_t;   /* opaque; owns the device image of A and the launch plan */
+
+/* Uploads a VBS matrix (the reference's arrays, host pointers) to `device` once and builds the tile
+ * plan.  Replaces the per-call cudaMalloc + H2D of A that every reference back-end performs
+ * (src/cuda/cuda_utilities.cpp:779-789).  dtype conversion (f32 -> f16/bf16) happens here. */
+int sparta_vbs_create(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t block_col_size,
+                      const int64_t* row_part, const int64_t* nzcount, const int64_t* jab, const float* mab,
+                      int32_t dtype, int32_t device);
+
+/* Same, restricted to block-rows [block_row_begin, block_row_end): the row-range partition used for
+ * multi-GPU runs.  C of the resulting handle has row_part[end]-row_part[begin] rows (local numbering). */
+int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t block_col_size,
+                            const int64_t* row_part, const int64_t* nzcount, const int64_t* jab, const float* mab,
+                            int64_t block_row_begin, int64_t block_row_end, int32_t dtype, int32_t device);
+
+/* C (+)= A * B.  Replaces VBR::multiply(B, B_cols, C) (include/matrices.h:121) and the GPU back-ends
+ *   cublas_fixed_blocks_multiply / cublas_blockmat_batched / cutlas_* (const VBR&, DataT* B, int B_cols,
+ *   DataT_C* C, float& dt[, int n_streams])            (include/cuda_utilities.h:38-44,
+ *                                                        include/cutlass_bellpack_lib.h:19-25).
+ * B: `cols` x n_cols, C: `rows` x n_cols (rows of this handle), element type fp32 for dtype F32,
+ * and the handle's 16-bit type for B with fp32 C otherwise.  accumulate = 1 is the reference's
+ * semantics (C += A*B); 0 overwrites C (every row of C is written).  ptr_space HOST: buffers are
+ * copied to/from the device around the kernel and *dt_ms (may be NULL) covers the kernel only;
+ * DEVICE: launched on `stream` (a hipStream_t, NULL = default stream); if dt_ms != NULL the call
+ * records events and synchronises on them, otherwise it returns without synchronising. */
+int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int32_t n_cols,
+                    void* C, int64_t ldc, int32_t c_layout, int32_t accumulate,
+                    int32_t ptr_space, void* stream, int32_t algo, float* dt_ms);
+
+int sparta_vbs_destroy(sparta_vbs_t* A);
+
+/* plan / roofline introspection. info_out (int64[16]):
+ *  [0] rows [1] cols [2] block_rows [3] block_col_size [4] nblocks [5] nztot (area)
+ *  [6] tiles of class 16 [7] class 32 [8] class 64 [9] class 128 [10] device bytes of A
+ *  [11] padded MFMA rows summed over (tile, block) pairs x w (executed area) [12..15] reserved */
+int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info_out);
+
+/* number of visible HIP devices (0 when none); never initialises a device context */
+int sparta_device_count(void);
+
+const char* sparta_last_error(void);
+const char* sparta_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARTA_AMD_H */

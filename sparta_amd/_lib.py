@@ -1,0 +1,92 @@
+"""ctypes binding of libsparta_amd.so (the C-ABI declared in include/sparta_amd.h).
+
+The shared library is built in-tree by `make -C sparta_amd/csrc` (see __graft_entry__.build()).
+There is NO Python/CPU fallback: if the library is missing, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsparta_amd.so")
+
+# status codes (include/sparta_amd.h)
+OK, ERR_INVALID, ERR_ALLOC, ERR_HIP, ERR_UNSUPPORTED, ERR_IO, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
+F32, F16, BF16 = 0, 1, 2
+COL_MAJOR, ROW_MAJOR = 0, 1
+PTR_HOST, PTR_DEVICE = 0, 1
+SPMM_MFMA, SPMM_EXACT = 0, 1
+
+# every symbol include/sparta_amd.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "sparta_reorder_cfg_default", "sparta_reorder", "sparta_get_permutation", "sparta_get_partition",
+    "sparta_get_fixed_size_grouping", "sparta_row_distance", "sparta_merge_rows", "sparta_vbs_build",
+    "sparta_vbs_host_free", "sparta_blocking_info", "sparta_vbs_create", "sparta_vbs_create_range",
+    "sparta_vbs_spmm", "sparta_vbs_destroy", "sparta_vbs_info", "sparta_device_count", "sparta_last_error",
+    "sparta_version",
+]
+
+
+class ReorderCfg(C.Structure):
+    _fields_ = [("blocking_algo", C.c_int32), ("sim_measure", C.c_int32), ("tau", C.c_float), ("use_groups", C.c_int32),
+                ("col_block_size", C.c_int64), ("row_block_size", C.c_int64), ("use_pattern", C.c_int32),
+                ("force_fixed_size", C.c_int32)]
+
+
+class ReorderStats(C.Structure):
+    _fields_ = [("comparison_counter", C.c_int64), ("merge_counter", C.c_int64), ("average_row_distance", C.c_float),
+                ("average_merge_tau", C.c_float), ("timer_total", C.c_float), ("timer_comparisons", C.c_float),
+                ("timer_merges", C.c_float), ("reserved", C.c_int32)]
+
+
+class VbsHost(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("cols", C.c_int64), ("block_rows", C.c_int64), ("block_cols", C.c_int64),
+                ("block_col_size", C.c_int64), ("nztot", C.c_int64), ("nblocks", C.c_int64),
+                ("row_part", C.POINTER(C.c_int64)), ("nzcount", C.POINTER(C.c_int64)), ("jab", C.POINTER(C.c_int64)),
+                ("mab", C.POINTER(C.c_float))]
+
+
+class SpartaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sparta_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("sparta_amd: %s is missing -- build it with `make -C sparta_amd/csrc` "
+                          "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    i64p, i32p, f32p, vp = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.c_void_p
+    L.sparta_reorder_cfg_default.argtypes = [C.POINTER(ReorderCfg)]
+    L.sparta_reorder_cfg_default.restype = None
+    L.sparta_reorder.argtypes = [C.c_int64, C.c_int64, i64p, i32p, C.POINTER(ReorderCfg), i64p, C.POINTER(ReorderStats)]
+    L.sparta_get_permutation.argtypes = [i64p, C.c_int64, i64p]
+    L.sparta_get_partition.argtypes = [i64p, C.c_int64, i64p, i64p]
+    L.sparta_get_fixed_size_grouping.argtypes = [i64p, C.c_int64, C.c_int64, i64p]
+    L.sparta_row_distance.argtypes = [C.c_int32, i64p, C.c_int64, C.c_int64, i64p, C.c_int64, C.c_int64, C.c_int64, f32p]
+    L.sparta_merge_rows.argtypes = [i64p, C.c_int64, i64p, C.c_int64, i64p, i64p]
+    L.sparta_vbs_build.argtypes = [C.c_int64, C.c_int64, i64p, i32p, f32p, i64p, C.c_int64, C.c_int64, C.c_int32,
+                                   C.POINTER(VbsHost)]
+    L.sparta_vbs_host_free.argtypes = [C.POINTER(VbsHost)]
+    L.sparta_vbs_host_free.restype = None
+    L.sparta_blocking_info.argtypes = [C.c_int64, C.c_int64, i64p, i32p, i64p, C.c_int64, i64p, f32p]
+    L.sparta_vbs_create.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, C.c_int64, C.c_int64, i64p, i64p, i64p, f32p,
+                                    C.c_int32, C.c_int32]
+    L.sparta_vbs_create_range.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, C.c_int64, C.c_int64, i64p, i64p, i64p, f32p,
+                                          C.c_int64, C.c_int64, C.c_int32, C.c_int32]
+    L.sparta_vbs_spmm.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp,
+                                  C.c_int32, f32p]
+    L.sparta_vbs_destroy.argtypes = [vp]
+    L.sparta_vbs_info.argtypes = [vp, i64p]
+    L.sparta_device_count.argtypes = []
+    L.sparta_last_error.restype = C.c_char_p
+    L.sparta_version.restype = C.c_char_p
+    return L
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != OK:
+        raise SpartaError(rc, lib.sparta_last_error().decode(errors="replace"))

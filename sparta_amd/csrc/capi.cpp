@@ -1,0 +1,144 @@
+// capi.cpp -- extern "C" glue for the host-side part of include/sparta_amd.h
+// (the device part lives in vbs_spmm.hip).  No exception leaves this file.
+#include <cstring>
+#include <exception>
+#include <new>
+
+#include "host_core.hpp"
+
+namespace sparta {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+
+int validate_csr(const CsrView& a, bool need_sorted) {
+    if (a.rows < 0 || a.cols < 0) return fail(SPARTA_ERR_INVALID, "CSR: negative dimension");
+    if (a.rows > 0 && (!a.rowptr)) return fail(SPARTA_ERR_INVALID, "CSR: rowptr is NULL");
+    if (a.rows == 0) return SPARTA_OK;
+    if (a.rowptr[0] != 0) return fail(SPARTA_ERR_INVALID, "CSR: rowptr[0] must be 0");
+    for (int64_t i = 0; i < a.rows; i++) {
+        int64_t n = a.rowptr[i + 1] - a.rowptr[i];
+        if (n < 0) return fail(SPARTA_ERR_INVALID, "CSR: rowptr must be non-decreasing (row " + std::to_string(i) + ")");
+        if (n > 0 && !a.colidx) return fail(SPARTA_ERR_INVALID, "CSR: colidx is NULL");
+        const int32_t* r = a.colidx + a.rowptr[i];
+        for (int64_t k = 0; k < n; k++) {
+            if (r[k] < 0 || (int64_t)r[k] >= a.cols)
+                return fail(SPARTA_ERR_INVALID, "CSR: column index out of range in row " + std::to_string(i));
+            // the reference's distance/merge code assumes ascending rows (its readers throw on unsorted
+            // row ids, csr.cpp:259-260, and never sort columns); duplicates make merge_rows ill-defined.
+            if (need_sorted && k > 0 && r[k] <= r[k - 1])
+                return fail(SPARTA_ERR_INVALID, "CSR: columns must be strictly ascending within a row (row " + std::to_string(i) + ")");
+        }
+    }
+    return SPARTA_OK;
+}
+
+}  // namespace sparta
+
+using namespace sparta;
+
+#define SPARTA_TRY try {
+#define SPARTA_CATCH                                                                  \
+    }                                                                                 \
+    catch (const std::bad_alloc&) { return fail(SPARTA_ERR_ALLOC, "out of host memory"); } \
+    catch (const std::exception& e) { return fail(SPARTA_ERR_INVALID, e.what()); }    \
+    catch (...) { return fail(SPARTA_ERR_INVALID, "unknown C++ exception"); }
+
+extern "C" {
+
+const char* sparta_last_error(void) { return g_last_error.c_str(); }
+const char* sparta_version(void) { return "sparta_amd 0.1 (gfx950)"; }
+
+void sparta_reorder_cfg_default(sparta_reorder_cfg* c) {
+    if (!c) return;
+    std::memset(c, 0, sizeof(*c));
+    c->blocking_algo = SPARTA_BLOCKING_ITERATIVE_CLOCKED;   // include/input.h:27
+    c->sim_measure = SPARTA_SIM_JACCARD;                    // :29
+    c->tau = 0.1f;                                          // :33
+    c->use_groups = 0;                                      // :21
+    c->col_block_size = 3;                                  // :31
+    c->row_block_size = 3;                                  // :32
+    c->use_pattern = 1;                                     // :22
+    c->force_fixed_size = 0;                                // :24
+}
+
+int sparta_reorder(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const sparta_reorder_cfg* cfg,
+                   int64_t* grouping_out, sparta_reorder_stats* stats) {
+    SPARTA_TRY
+    if (!cfg || (!grouping_out && rows > 0)) return fail(SPARTA_ERR_INVALID, "sparta_reorder: NULL argument");
+    CsrView a; a.rows = rows; a.cols = cols; a.rowptr = rowptr; a.colidx = colidx;
+    return reorder(a, *cfg, grouping_out, stats);
+    SPARTA_CATCH
+}
+
+int sparta_get_permutation(const int64_t* grouping, int64_t n, int64_t* perm_out) {
+    SPARTA_TRY
+    if (n < 0 || (n > 0 && (!grouping || !perm_out))) return fail(SPARTA_ERR_INVALID, "sparta_get_permutation: bad argument");
+    std::vector<int64_t> p = get_permutation(grouping, n);
+    std::copy(p.begin(), p.end(), perm_out);
+    return SPARTA_OK;
+    SPARTA_CATCH
+}
+
+int sparta_get_partition(const int64_t* grouping, int64_t n, int64_t* part_out, int64_t* n_part_out) {
+    SPARTA_TRY
+    if (n < 0 || !part_out || !n_part_out || (n > 0 && !grouping)) return fail(SPARTA_ERR_INVALID, "sparta_get_partition: bad argument");
+    std::vector<int64_t> p = get_partition(grouping, n);
+    std::copy(p.begin(), p.end(), part_out);
+    *n_part_out = (int64_t)p.size();
+    return SPARTA_OK;
+    SPARTA_CATCH
+}
+
+int sparta_get_fixed_size_grouping(const int64_t* grouping, int64_t n, int64_t row_block_size, int64_t* grouping_out) {
+    SPARTA_TRY
+    if (n < 0 || row_block_size <= 0 || (n > 0 && (!grouping || !grouping_out)))
+        return fail(SPARTA_ERR_INVALID, "sparta_get_fixed_size_grouping: bad argument");
+    std::vector<int64_t> g = get_fixed_size_grouping(grouping, n, row_block_size);
+    std::copy(g.begin(), g.end(), grouping_out);
+    return SPARTA_OK;
+    SPARTA_CATCH
+}
+
+int sparta_row_distance(int32_t sim_measure, const int64_t* row_a, int64_t size_a, int64_t group_a, const int64_t* row_b,
+                        int64_t size_b, int64_t group_b, int64_t block_size, float* dist_out) {
+    SPARTA_TRY
+    if (size_a < 0 || size_b < 0 || block_size <= 0 || !dist_out || (size_a > 0 && !row_a) || (size_b > 0 && !row_b))
+        return fail(SPARTA_ERR_INVALID, "sparta_row_distance: bad argument");
+    *dist_out = row_distance(sim_measure, row_a, size_a, group_a, row_b, size_b, group_b, block_size);
+    return SPARTA_OK;
+    SPARTA_CATCH
+}
+
+int sparta_merge_rows(const int64_t* row_a, int64_t size_a, const int64_t* row_b, int64_t size_b, int64_t* out, int64_t* size_out) {
+    SPARTA_TRY
+    if (size_a < 0 || size_b < 0 || !size_out || (size_a > 0 && !row_a) || (size_b > 0 && !row_b) || (size_a + size_b > 0 && !out))
+        return fail(SPARTA_ERR_INVALID, "sparta_merge_rows: bad argument");
+    std::vector<int64_t> r = merge_rows(row_a, size_a, row_b, size_b);
+    std::copy(r.begin(), r.end(), out);
+    *size_out = (int64_t)r.size();
+    return SPARTA_OK;
+    SPARTA_CATCH
+}
+
+int sparta_vbs_build(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals,
+                     const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, int32_t force_fixed_size,
+                     sparta_vbs_host* out) {
+    SPARTA_TRY
+    CsrView a; a.rows = rows; a.cols = cols; a.rowptr = rowptr; a.colidx = colidx; a.vals = vals;
+    int rc = vbs_build(a, grouping, col_block_size, row_block_size, force_fixed_size != 0, out);
+    return rc;
+    SPARTA_CATCH
+}
+
+int sparta_blocking_info(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const int64_t* grouping,
+                         int64_t col_block_size, int64_t* info_out, float* avg_height_out) {
+    SPARTA_TRY
+    CsrView a; a.rows = rows; a.cols = cols; a.rowptr = rowptr; a.colidx = colidx;
+    return blocking_info(a, grouping, col_block_size, info_out, avg_height_out);
+    SPARTA_CATCH
+}
+
+}  // extern "C"

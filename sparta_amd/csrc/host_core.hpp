@@ -1,0 +1,44 @@
+// host_core.hpp -- internal declarations shared by the host-side C++ of libsparta_amd.so
+// (reorder engine, VBS builder, C-ABI glue).  Not installed; the public surface is
+// include/sparta_amd.h (C-ABI) and include/sparta_compat.hpp (reference-shaped C++ API).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "sparta_amd.h"
+
+namespace sparta {
+
+// Flat CSR view (the reference keeps one heap array per row: include/matrices.h:22-28; we use the
+// flat form everywhere and adapt at the compat layer).
+struct CsrView {
+    int64_t rows = 0, cols = 0;
+    const int64_t* rowptr = nullptr;
+    const int32_t* colidx = nullptr;
+    const float* vals = nullptr;   // nullptr == pattern only
+    int64_t nnz_of(int64_t i) const { return rowptr[i + 1] - rowptr[i]; }
+    const int32_t* row(int64_t i) const { return colidx + rowptr[i]; }
+};
+
+// thread-local error message behind sparta_last_error()
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+// validates rowptr monotonicity, column range and strictly ascending columns per row
+int validate_csr(const CsrView& a, bool need_sorted);
+
+// ---- reorder engine (reorder.cpp) ----------------------------------------------------------
+int reorder(const CsrView& a, const sparta_reorder_cfg& cfg, int64_t* grouping_out, sparta_reorder_stats* stats);
+std::vector<int64_t> get_permutation(const int64_t* grouping, int64_t n);
+std::vector<int64_t> get_partition(const int64_t* grouping, int64_t n);
+std::vector<int64_t> get_fixed_size_grouping(const int64_t* grouping, int64_t n, int64_t row_block_size);
+float row_distance(int sim_measure, const int64_t* a, int64_t na, int64_t ga, const int64_t* b, int64_t nb, int64_t gb,
+                   int64_t block_size);
+std::vector<int64_t> merge_rows(const int64_t* a, int64_t na, const int64_t* b, int64_t nb);
+
+// ---- VBS builder (vbs_build.cpp) -------------------------------------------------------------
+int vbs_build(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t row_block_size,
+              bool force_fixed_size, sparta_vbs_host* out);
+int blocking_info(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t* info_out, float* avg_height_out);
+
+}  // namespace sparta

@@ -1,0 +1,455 @@
+// reorder.cpp -- host-side row-clustering reorder engine (Jaccard / Hamming on column blocks).
+//
+// Reproduces the OBSERVABLE result (the grouping vector and the counters) of the reference's
+// BlockingEngine::GetGrouping (src/general/blocking.cpp:633-676) for the algorithms its
+// experiments use, with a different internal design:
+//   * every row is pre-reduced once to its sorted list of distinct column-block ids, and the
+//     cluster pattern carries both its column-level content (needed by the lossy merge) and its
+//     block-level content (all the distance functions ever look at) -- a comparison is a merge-count
+//     of two short int32 arrays instead of a by-value std::vector<long> copy plus a division per
+//     element (blocking.cpp:923-994, definitions.h:13);
+//   * the inner scan walks a compacted list of still-ungrouped rows;
+//   * the per-row `distances` scratch lives on the heap (the reference uses a stack VLA,
+//     blocking.cpp:159, which overflows the stack above ~2M rows) but is initialised the way the
+//     reference's `float distances[rows] = {-1}` really is: element 0 = -1, all others 0.
+// Behaviours that define parity are called out inline with the reference line they mirror.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <numeric>
+#include <random>
+#include <set>
+#include <utility>
+
+#include "host_core.hpp"
+
+namespace sparta {
+namespace {
+
+using clk = std::chrono::high_resolution_clock;
+inline float us_since(clk::time_point t0) {
+    return (float)std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count();
+}
+
+// distinct column-block ids per row, CSR-of-blocks
+struct RowBlocks {
+    std::vector<int64_t> ptr;
+    std::vector<int32_t> idx;
+    const int32_t* row(int64_t i) const { return idx.data() + ptr[i]; }
+    int64_t n(int64_t i) const { return ptr[i + 1] - ptr[i]; }
+};
+
+RowBlocks build_row_blocks(const CsrView& a, int64_t w) {
+    RowBlocks rb;
+    rb.ptr.resize(a.rows + 1);
+    rb.idx.reserve((size_t)std::min<int64_t>(a.rowptr[a.rows], (int64_t)1 << 40));
+    rb.ptr[0] = 0;
+    for (int64_t i = 0; i < a.rows; i++) {
+        const int32_t* r = a.row(i);
+        int64_t n = a.nnz_of(i);
+        int64_t last = -1;
+        for (int64_t k = 0; k < n; k++) {
+            int64_t b = (int64_t)r[k] / w;
+            if (b != last) { rb.idx.push_back((int32_t)b); last = b; }
+        }
+        rb.ptr[i + 1] = (int64_t)rb.idx.size();
+    }
+    return rb;
+}
+
+// |A ∩ B| for two strictly ascending int32 lists
+inline int64_t intersect_count(const int32_t* a, int64_t na, const int32_t* b, int64_t nb) {
+    int64_t i = 0, j = 0, c = 0;
+    while (i < na && j < nb) {
+        int32_t x = a[i], y = b[j];
+        c += (x == y);
+        i += (x <= y);
+        j += (y <= x);
+    }
+    return c;
+}
+
+// Distance from block-level quantities.  size_*: column-level lengths (only used by the empty-row
+// rules), n*: number of distinct blocks, g*: cluster weights, inter: common blocks.
+// Mirrors HammingDistanceGroup (blocking.cpp:859-921) and JaccardDistanceGroup (:923-994), whose
+// `count_zeros = 1` makes a block present only in A weigh group_size_B and vice versa (:929-941).
+inline float distance_from_counts(int sim, int64_t size_a, int64_t na, int64_t ga, int64_t size_b, int64_t nb, int64_t gb,
+                                  int64_t inter) {
+    if (sim == SPARTA_SIM_JACCARD) {
+        if (size_a == 0 && size_b == 0) return 0.0f;           // :926
+        if (size_a == 0 || size_b == 0) return 1.0f;           // :927
+        int64_t count = (na - inter) * gb + (nb - inter) * ga;
+        return (float)((2.0 * (double)count) / (double)(na * ga + nb * gb + count));   // :993
+    }
+    if (size_a == 0 && size_b == 0) return 0.0f;               // :863
+    if (size_a == 0 || size_b == 0) return (float)std::max(size_a * ga, size_b * gb);   // :864 (column-level sizes)
+    int64_t count = (na - inter) * gb + (nb - inter) * ga;
+    return (float)count;                                       // :920
+}
+
+// Cluster pattern.  The reference keeps a std::vector of COLUMN ids and "unions" each merged row into
+// it with merge_rows (src/general/utilities.cpp:145-173), which is lossy.  Closed form of what that
+// loop computes for strictly ascending inputs A (pattern) and B (row):
+//     B empty                      -> {}                      (the loop never runs, only B's tail is appended)
+//     no element of B is <= max(A) -> B                       (breaks at j = 0 before copying anything of A)
+//     otherwise, with b* = the largest element of B that is <= max(A):
+//                                     {a in A : a < b*}  U  B (A's elements above b* are never copied)
+struct Pattern {
+    std::vector<int64_t> cols;
+    std::vector<int32_t> blks;
+    std::vector<int64_t> tmp;
+
+    void rebuild_blocks(int64_t w) {
+        blks.clear();
+        int64_t last = -1;
+        for (int64_t c : cols) {
+            int64_t b = c / w;
+            if (b != last) { blks.push_back((int32_t)b); last = b; }
+        }
+    }
+    void assign(const int32_t* row, int64_t n, int64_t w) {
+        cols.assign(row, row + n);
+        rebuild_blocks(w);
+    }
+    template <typename T>
+    static void merge_into(std::vector<int64_t>& out, const int64_t* a, int64_t na, const T* b, int64_t nb) {
+        out.clear();
+        if (nb == 0) return;
+        if (na == 0 || (int64_t)b[0] > a[na - 1]) { out.assign(b, b + nb); return; }
+        const int64_t max_a = a[na - 1];
+        // b* = last element of B that is <= max(A)
+        const T* ub = std::upper_bound(b, b + nb, max_a, [](int64_t v, const T& e) { return v < (int64_t)e; });
+        const int64_t bstar = (int64_t) * (ub - 1);
+        const int64_t keep = std::lower_bound(a, a + na, bstar) - a;   // elements of A strictly below b*
+        out.reserve((size_t)(keep + nb));
+        int64_t i = 0, j = 0;
+        while (i < keep && j < nb) {
+            int64_t x = a[i], y = (int64_t)b[j];
+            if (x < y) { out.push_back(x); i++; }
+            else if (y < x) { out.push_back(y); j++; }
+            else { out.push_back(x); i++; j++; }
+        }
+        while (i < keep) out.push_back(a[i++]);
+        while (j < nb) out.push_back((int64_t)b[j++]);
+    }
+    void merge(const int32_t* row, int64_t n, int64_t w) {
+        merge_into(tmp, cols.data(), (int64_t)cols.size(), row, n);
+        cols.swap(tmp);
+        rebuild_blocks(w);
+    }
+};
+
+struct Ctx {
+    const CsrView& a;
+    const sparta_reorder_cfg& cfg;
+    RowBlocks rb;
+    int sim;
+    int64_t w;
+    int64_t comparisons = 0, merges = 0;
+    float total_merge_tau = 0, total_row_distance = 0;   // float accumulators as in blocking.cpp:162-163
+    float t_cmp = 0, t_merge = 0;
+
+    Ctx(const CsrView& a_, const sparta_reorder_cfg& c) : a(a_), cfg(c) {
+        w = c.col_block_size;
+        sim = (c.sim_measure & 1) ? SPARTA_SIM_JACCARD : SPARTA_SIM_HAMMING;   // 2,3 are the 'OPENMP' twins of 0,1
+        rb = build_row_blocks(a, w);
+    }
+    inline float dist(const Pattern& p, int64_t gsize, int64_t j) const {
+        int64_t inter = intersect_count(p.blks.data(), (int64_t)p.blks.size(), rb.row(j), rb.n(j));
+        return distance_from_counts(sim, (int64_t)p.cols.size(), (int64_t)p.blks.size(), gsize, a.nnz_of(j), rb.n(j), 1, inter);
+    }
+};
+
+// the reference's `float distances[cmat.rows] = {-1};` (blocking.cpp:159,255,436): a VLA with a
+// one-element initialiser -> element 0 is -1, every other element is 0.
+std::vector<float> make_distances(int64_t rows) {
+    std::vector<float> d((size_t)rows, 0.0f);
+    if (rows > 0) d[0] = -1.0f;
+    return d;
+}
+
+// Algorithms 3 (IterativeBlockingPatternCLOCKED, blocking.cpp:156-243) and 4 (IterativeBlockingQueue,
+// :245-338).  Both visit the still-ungrouped rows after the seed in ascending order and differ only in
+// bookkeeping that cannot change the result: CLOCKED also runs its prune test on already-grouped rows,
+// whose `distances` entry is never read again.
+void clocked(Ctx& c, int64_t* grouping) {
+    const int64_t rows = c.a.rows;
+    const float tau = c.cfg.tau;
+    std::fill(grouping, grouping + rows, (int64_t)-1);
+    std::vector<float> dist = make_distances(rows);
+    std::vector<int64_t> alive((size_t)rows), next;
+    std::iota(alive.begin(), alive.end(), (int64_t)0);
+    next.reserve((size_t)rows);
+    Pattern pat;
+
+    size_t head = 0;   // alive[head] is the next seed
+    while (head < alive.size()) {
+        const int64_t i = alive[head];
+        grouping[i] = i;                                           // :172 group id = seed row
+        pat.assign(c.a.row(i), c.a.nnz_of(i), c.w);                // :173
+        int64_t gsize = 1;
+        const float di = dist[(size_t)i];
+        auto t0 = clk::now();
+        next.clear();
+        for (size_t q = head + 1; q < alive.size(); q++) {
+            const int64_t j = alive[q];
+            float& dj = dist[(size_t)j];
+            // triangle-inequality prune (:192-196); note it resets distances[j]
+            if (di != -1.0f && dj != -1.0f && std::fabs(di - dj) > tau) {
+                dj = -1.0f;
+                next.push_back(j);
+                continue;
+            }
+            c.comparisons++;
+            const float d = c.dist(pat, gsize, j);
+            dj = d;
+            if (d <= tau) {                                        // :207 (<=)
+                c.total_merge_tau += d;
+                c.total_row_distance += (float)(j - i);
+                c.merges++;
+                grouping[j] = i;
+                if (c.cfg.use_pattern) {
+                    auto tm = clk::now();
+                    pat.merge(c.a.row(j), c.a.nnz_of(j), c.w);     // :217
+                    c.t_merge += us_since(tm);
+                }
+                if (c.cfg.use_groups) gsize++;                     // :221-224
+            } else {
+                next.push_back(j);
+            }
+        }
+        c.t_cmp += us_since(t0);
+        // compact: rows before `head` are done; keep the survivors
+        alive.swap(next);
+        head = 0;
+    }
+}
+
+// Algorithm 0 (IterativeBlockingPattern, blocking.cpp:89-154): no prune, strict `<`, and -- because the
+// `if (use_pattern)` there guards only a timer macro -- the pattern merge ALWAYS runs (:128-132).
+void plain(Ctx& c, int64_t* grouping) {
+    const int64_t rows = c.a.rows;
+    const float tau = c.cfg.tau;
+    std::fill(grouping, grouping + rows, (int64_t)-1);
+    std::vector<int64_t> alive((size_t)rows), next;
+    std::iota(alive.begin(), alive.end(), (int64_t)0);
+    Pattern pat;
+    while (!alive.empty()) {
+        const int64_t i = alive[0];
+        grouping[i] = i;
+        pat.assign(c.a.row(i), c.a.nnz_of(i), c.w);
+        int64_t gsize = 1;
+        next.clear();
+        for (size_t q = 1; q < alive.size(); q++) {
+            const int64_t j = alive[q];
+            c.comparisons++;
+            const float d = c.dist(pat, gsize, j);
+            if (d < tau) {                                         // :124 (<)
+                c.merges++;
+                grouping[j] = i;
+                pat.merge(c.a.row(j), c.a.nnz_of(j), c.w);
+                if (c.cfg.use_groups) gsize++;
+            } else {
+                next.push_back(j);
+            }
+        }
+        alive.swap(next);
+    }
+}
+
+// Algorithm 5 (-a 5 dispatches to IterativeBlockingKeeper, blocking.cpp:655, :433-549): clusters are
+// capped at row_block_size rows; the best rejected candidates are kept in an ordered set and used to
+// pad short clusters; complete clusters are numbered `seed`, incomplete ones `seed + rows` (:450,527-533).
+//
+// The candidate set is trimmed in the reference with
+//       auto it = best.end(); advance(it, k); best.erase(it, best.end());          (:509-511)
+// i.e. by incrementing PAST end().  On libstdc++ that walk is deterministic: incrementing the header
+// node lands on the right-most node (or its left child) and the walk wraps around.  Which elements
+// are dropped therefore depends on the red-black tree's shape.  To give the same grouping we perform
+// the very same iterator walk on the same container type; this relies on libstdc++ and is guarded.
+#if !defined(__GLIBCXX__)
+#error "IterativeBlockingKeeper parity relies on libstdc++'s std::set iterator behaviour"
+#endif
+void keeper(Ctx& c, int64_t* grouping) {
+    const int64_t rows = c.a.rows;
+    const float tau = c.cfg.tau;
+    const int64_t max_h = c.cfg.row_block_size;
+    std::fill(grouping, grouping + rows, (int64_t)-1);
+    std::vector<float> dist = make_distances(rows);
+    Pattern pat;
+    std::vector<int64_t> merged;
+
+    for (int64_t i = 0; i < rows; i++) {
+        if (grouping[i] != -1) continue;
+        std::set<std::pair<float, int64_t>> best;
+        merged.clear();
+        const int64_t group_number = i + rows;                     // :450
+        grouping[i] = group_number;
+        merged.push_back(i);
+        pat.assign(c.a.row(i), c.a.nnz_of(i), c.w);
+        int64_t gsize = 1;
+        const float di = dist[(size_t)i];
+        auto t0 = clk::now();
+        for (int64_t j = i + 1; j < rows; j++) {
+            if (gsize == max_h) break;                             // :463-466
+            float& dj = dist[(size_t)j];
+            if (di != -1.0f && dj != -1.0f && std::fabs(di - dj) > tau) { dj = -1.0f; continue; }   // :469-473
+            if (grouping[j] != -1) continue;
+            c.comparisons++;
+            const float d = c.dist(pat, gsize, j);                 // :480 weight is ALWAYS the cluster size
+            dj = d;
+            if (d <= tau) {
+                c.total_merge_tau += d;
+                c.total_row_distance += (float)(j - i);
+                c.merges++;
+                grouping[j] = group_number;
+                merged.push_back(j);
+                if (c.cfg.use_pattern) {
+                    auto tm = clk::now();
+                    pat.merge(c.a.row(j), c.a.nnz_of(j), c.w);
+                    c.t_merge += us_since(tm);
+                }
+                gsize++;                                           // :501 unconditional
+            } else {
+                best.insert({d, j});
+                // (:507) size_t comparison in the reference; the right-hand side is >= 1 here
+                if (best.size() > (size_t)(max_h - (int64_t)merged.size())) {
+                    auto it = best.end();
+                    std::advance(it, max_h - (int64_t)merged.size());   // walks past end(): see note above
+                    best.erase(it, best.end());
+                }
+            }
+        }
+        if (gsize < max_h) {                                       // :517-525 pad from the kept candidates
+            for (auto it = best.begin(); it != best.end() && gsize != max_h; ++it) {
+                grouping[it->second] = group_number;
+                merged.push_back(it->second);
+                gsize++;
+            }
+        }
+        if (gsize == max_h)                                        // :527-533 complete blocks sort first
+            for (int64_t r : merged) grouping[r] -= rows;
+        c.t_cmp += us_since(t0);
+    }
+}
+
+}  // namespace
+
+// ---- public helpers ---------------------------------------------------------------------------
+
+// src/general/utilities.cpp:8-20.  The reference sorts row indices with std::sort (introsort, NOT
+// stable) under `grouping[i] < grouping[j]`; the order of rows inside one group is therefore whatever
+// libstdc++'s introsort leaves.  Calling the same standard algorithm with the same strict-weak order
+// on the same initial sequence (iota) gives the same permutation on the same standard library.
+std::vector<int64_t> get_permutation(const int64_t* grouping, int64_t n) {
+    std::vector<int64_t> v((size_t)n);
+    std::iota(v.begin(), v.end(), (int64_t)0);
+    std::sort(v.begin(), v.end(), [grouping](int64_t x, int64_t y) { return grouping[x] < grouping[y]; });
+    return v;
+}
+
+// src/general/utilities.cpp:22-43: start offset of every distinct id in the sorted grouping + sentinel n
+std::vector<int64_t> get_partition(const int64_t* grouping, int64_t n) {
+    std::vector<int64_t> s(grouping, grouping + n);
+    std::sort(s.begin(), s.end());
+    std::vector<int64_t> part;
+    for (int64_t i = 0; i < n; i++)
+        if (i == 0 ? (s[0] != -1) : (s[i] != s[i - 1])) part.push_back(i);
+    // the reference starts from current_group = -1 (:29): a leading run of -1 ids opens no partition
+    part.push_back(n);
+    return part;
+}
+
+// src/general/utilities.cpp:45-54
+std::vector<int64_t> get_fixed_size_grouping(const int64_t* grouping, int64_t n, int64_t row_block_size) {
+    std::vector<int64_t> perm = get_permutation(grouping, n);
+    std::vector<int64_t> out((size_t)n, -1);
+    for (int64_t i = 0; i < n; i++) out[(size_t)perm[(size_t)i]] = i / row_block_size;
+    return out;
+}
+
+float row_distance(int sim_measure, const int64_t* a, int64_t na, int64_t ga, const int64_t* b, int64_t nb, int64_t gb,
+                   int64_t block_size) {
+    auto blocks = [block_size](const int64_t* r, int64_t n) {
+        std::vector<int32_t> out;
+        int64_t last = -1;
+        for (int64_t k = 0; k < n; k++) {
+            int64_t q = r[k] / block_size;
+            if (q != last) { out.push_back((int32_t)q); last = q; }
+        }
+        return out;
+    };
+    std::vector<int32_t> ba = blocks(a, na), bb = blocks(b, nb);
+    int64_t inter = intersect_count(ba.data(), (int64_t)ba.size(), bb.data(), (int64_t)bb.size());
+    int sim = (sim_measure & 1) ? SPARTA_SIM_JACCARD : SPARTA_SIM_HAMMING;
+    return distance_from_counts(sim, na, (int64_t)ba.size(), ga, nb, (int64_t)bb.size(), gb, inter);
+}
+
+std::vector<int64_t> merge_rows(const int64_t* a, int64_t na, const int64_t* b, int64_t nb) {
+    std::vector<int64_t> out;
+    Pattern::merge_into(out, a, na, b, nb);
+    return out;
+}
+
+// BlockingEngine::GetGrouping (src/general/blocking.cpp:633-676)
+int reorder(const CsrView& a, const sparta_reorder_cfg& cfg, int64_t* grouping_out, sparta_reorder_stats* stats) {
+    if (cfg.col_block_size <= 0) return fail(SPARTA_ERR_INVALID, "sparta_reorder: col_block_size must be > 0");
+    const bool needs_rbs = cfg.blocking_algo == SPARTA_BLOCKING_FIXED_SIZE || cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_MAX_SIZE ||
+                           cfg.force_fixed_size;
+    if (needs_rbs && cfg.row_block_size <= 0) return fail(SPARTA_ERR_INVALID, "sparta_reorder: row_block_size must be > 0");
+    const bool iterative = cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE || cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_CLOCKED ||
+                           cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_QUEUE || cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_MAX_SIZE;
+    if (int rc = validate_csr(a, iterative)) return rc;
+
+    auto t0 = clk::now();
+    sparta_reorder_stats st{};
+    switch (cfg.blocking_algo) {
+        case SPARTA_BLOCKING_ITERATIVE_CLOCKED:
+        case SPARTA_BLOCKING_ITERATIVE_QUEUE: {
+            Ctx c(a, cfg);
+            clocked(c, grouping_out);
+            st.comparison_counter = c.comparisons; st.merge_counter = c.merges;
+            st.average_merge_tau = c.total_merge_tau / (float)c.merges;          // :239-240 (NaN when no merge, as in the reference)
+            st.average_row_distance = c.total_row_distance / (float)c.merges;
+            st.timer_comparisons = c.t_cmp; st.timer_merges = c.t_merge;
+            break;
+        }
+        case SPARTA_BLOCKING_ITERATIVE_MAX_SIZE: {
+            Ctx c(a, cfg);
+            keeper(c, grouping_out);
+            st.comparison_counter = c.comparisons; st.merge_counter = c.merges;
+            st.average_merge_tau = c.total_merge_tau / (float)c.merges;
+            st.average_row_distance = c.total_row_distance / (float)c.merges;
+            st.timer_comparisons = c.t_cmp; st.timer_merges = c.t_merge;
+            break;
+        }
+        case SPARTA_BLOCKING_ITERATIVE: {
+            Ctx c(a, cfg);
+            plain(c, grouping_out);
+            st.comparison_counter = c.comparisons; st.merge_counter = c.merges;
+            break;
+        }
+        case SPARTA_BLOCKING_FIXED_SIZE:                                         // :554-562
+            for (int64_t i = 0; i < a.rows; i++) grouping_out[i] = i / cfg.row_block_size;
+            break;
+        case SPARTA_BLOCKING_SCRAMBLE: {                                         // :565-574, seed 123
+            std::vector<int64_t> g((size_t)a.rows);
+            std::iota(g.begin(), g.end(), (int64_t)0);
+            std::shuffle(g.begin(), g.end(), std::default_random_engine(123));
+            std::copy(g.begin(), g.end(), grouping_out);
+            break;
+        }
+        default:
+            return fail(SPARTA_ERR_UNSUPPORTED, "sparta_reorder: blocking_algo " + std::to_string(cfg.blocking_algo) +
+                                                    " (m:n structured) is outside the hot path");
+    }
+    if (cfg.force_fixed_size && cfg.blocking_algo != SPARTA_BLOCKING_FIXED_SIZE) {   // :670-673
+        std::vector<int64_t> g = get_fixed_size_grouping(grouping_out, a.rows, cfg.row_block_size);
+        std::copy(g.begin(), g.end(), grouping_out);
+    }
+    st.timer_total = us_since(t0);
+    if (stats) *stats = st;
+    return SPARTA_OK;
+}
+
+}  // namespace sparta

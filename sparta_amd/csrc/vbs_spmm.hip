@@ -1,0 +1,603 @@
+// vbs_spmm.hip -- VBS A x dense B on MI355X (gfx950 / CDNA4): device image, tile plan and the
+// hand-written kernels behind sparta_vbs_create / sparta_vbs_spmm (include/sparta_amd.h).
+//
+// What it replaces in the reference: the CPU triple loop VBR::multiply (src/general/vbr.cpp:323-372)
+// and the "one library GEMM per nonzero block" GPU back-ends (src/cuda/cuda_utilities.cpp:39-887,
+// src/cuda/cutlass_bellpack_lib.cu:380-1019).  Not a translation of either: there is ONE fused kernel
+// family, no vendor BLAS/SPARSE call, no per-block launch.
+//
+// Design (see DESIGN.md §3 for the long form):
+//   * A keeps the reference's VBS layout in HBM (column-major h x w blocks, blocks of a block-row
+//     back to back), so a block-row IS a dense column-major h x (nb*w) matrix with lda = h.
+//   * The host cuts every block-row into ROW TILES of <=128 / <=64 / <=32 / <=16 rows ("classes");
+//     one 256-thread workgroup owns one (row tile, 128-column slab of C) and walks the block-row's
+//     nonzero blocks.  Per block ("panel step") the workgroup stages the w x 128 panel of B
+//     (gathered through jab) and the tile's slice of the A block through LDS, then every wave runs
+//     fp32 MFMAs on it: v_mfma_f32_32x32x2_f32 for tiles >16 rows, v_mfma_f32_16x16x4_f32 for thin
+//     (<=16 row) tiles so ragged clusters do not pay 32-row padding.
+//   * The product is computed TRANSPOSED inside the MFMA (D = Bpanel^T * Atile^T): the accumulator
+//     then holds, per register, 32 (16) consecutive ROWS of one column of C, so the column-major C
+//     of the reference is written in 128-byte (64-byte) contiguous runs.
+//   * Global->LDS staging is register-prefetched one panel ahead (loads for step s+1 are issued
+//     before the MFMAs of step s), so HBM/L2 latency hides under the fp32 MFMAs (64 cycles each).
+//   * The workgroup->tile map is XCD-aware: the 8 XCDs each get a contiguous range of the tile list,
+//     so neighbouring block-rows (which gather the same B panels) share one L2.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "host_core.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned: global_load_dwordx4 on any float address
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int kTN = 128;   // columns of C per workgroup
+constexpr int kKP = 64;    // k-depth of one panel step
+
+// one row tile of one block-row
+struct TileDesc {
+    int64_t a_off;     // element offset into A of (first block of the block-row) + r0
+    int64_t jab_off;   // offset into jab of the block-row's first block-column id
+    int32_t nb;        // nonzero blocks in the block-row
+    int32_t h;         // block-row height = leading dimension of each of its blocks
+    int32_t c_row;     // first row of C written by this tile
+    int32_t mt;        // rows in this tile (<= class height)
+};
+static_assert(sizeof(TileDesc) == 32, "TileDesc must stay 32 bytes");
+
+struct SpmmParams {
+    const TileDesc* tiles;
+    const int32_t* jab;
+    const float* A;
+    const float* B;
+    float* C;
+    int64_t ldb, ldc;
+    int64_t cols;      // valid rows of B
+    int32_t n_tiles, n_ntiles;
+    int32_t N, w;
+    int32_t b_row_major, c_row_major;
+    int32_t accumulate, vec_ok;
+};
+
+// bijective XCD-aware remap (workgroups are dealt round-robin over the 8 XCDs: b and b+8 share one)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+template <int MF>
+struct Acc;
+template <>
+struct Acc<32> { typedef f32x16 type; };
+template <>
+struct Acc<16> { typedef f32x4 type; };
+
+// MF: MFMA tile (32 -> 32x32x2, 16 -> 16x16x4).  WM x WN waves, each MI x NI MFMA tiles.
+template <int MF, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(kThreads) void vbs_spmm_f32_kernel(const SpmmParams p) {
+    constexpr int TM = WM * MI * MF;
+    constexpr int TN = WN * NI * MF;
+    static_assert(TN == kTN, "workgroup covers 128 columns");
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int KP = kKP;
+    constexpr int LDBS = KP + 4;                    // floats per staged B column: 16-B aligned rows, conflict-free ds_read_b128
+    constexpr int LDAS = (TM == 16) ? 20 : TM;      // 16-row tiles: shift the upper k-quarters onto the other 16 banks
+    constexpr int NBV = TN * KP / 4 / kThreads;     // float4 B chunks staged per thread
+    constexpr int NAV = TM * KP / kThreads;         // A floats staged per thread
+    constexpr int KG = (MF == 32) ? 8 : 16;         // k consumed per fragment round
+    typedef typename Acc<MF>::type acc_t;
+
+    __shared__ __attribute__((aligned(16))) float lds[TN * LDBS + KP * LDAS];
+    float* Bs = lds;
+    float* As = lds + TN * LDBS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_id = logical / p.n_ntiles;
+    const int n0 = (logical % p.n_ntiles) * TN;
+    const TileDesc td = p.tiles[tile_id];
+    const int w = p.w, N = p.N;
+    const int spb = (w + KP - 1) / KP;              // panel steps per block
+    const int nsteps = td.nb * spb;
+
+    acc_t acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++)
+#pragma unroll
+            for (int r = 0; r < (MF == 32 ? 16 : 4); r++) acc[mi][ni][r] = 0.0f;
+
+    f32x4 breg[NBV];
+    float areg[NAV];
+
+    // ---- stage loader: global -> registers ------------------------------------------------------
+    auto load_step = [&](int s) {
+        const int b = s / spb;
+        const int ks = (s - b * spb) * KP;
+        const int64_t jb = p.jab[td.jab_off + b];
+        const int64_t gk0 = jb * (int64_t)w + ks;                 // first B row of this panel
+        if (!p.b_row_major) {
+            // column-major B (the reference's layout): a panel column is `kp` contiguous floats
+#pragma unroll
+            for (int q = 0; q < NBV; q++) {
+                const int c = tid + kThreads * q;
+                const int j = c / (KP / 4), k = (c % (KP / 4)) * 4;
+                const int col = n0 + j;
+                const float* src = p.B + (gk0 + k) + (int64_t)col * p.ldb;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (col < N) {
+                    if (p.vec_ok && ks + k + 3 < w && gk0 + k + 3 < p.cols) {
+                        const f32x4u t = *reinterpret_cast<const f32x4u*>(src);
+                        v = (f32x4){t.x, t.y, t.z, t.w};
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (ks + k + e < w && gk0 + k + e < p.cols) v[e] = src[e];
+                    }
+                }
+                breg[q] = v;
+            }
+        } else {
+            // row-major B: a panel row is 128 contiguous floats; transposed on the way into LDS
+#pragma unroll
+            for (int q = 0; q < NBV; q++) {
+                const int c = tid + kThreads * q;
+                const int k = c / (TN / 4), j = (c % (TN / 4)) * 4;
+                const int col = n0 + j;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (ks + k < w && gk0 + k < p.cols) {
+                    const float* src = p.B + (gk0 + k) * p.ldb + col;
+                    if (p.vec_ok && col + 3 < N) {
+                        const f32x4u t = *reinterpret_cast<const f32x4u*>(src);
+                        v = (f32x4){t.x, t.y, t.z, t.w};
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (col + e < N) v[e] = src[e];
+                    }
+                }
+                breg[q] = v;
+            }
+        }
+        // A: rows [r0, r0+mt) x k [ks, ks+KP) of block b; column-major, lda = h
+        const float* ablk = p.A + td.a_off + ((int64_t)b * w + ks) * td.h;
+#pragma unroll
+        for (int q = 0; q < NAV; q++) {
+            const int e = tid + kThreads * q;
+            const int i = e % TM, k = e / TM;
+            areg[q] = (i < td.mt && ks + k < w) ? ablk[(int64_t)k * td.h + i] : 0.0f;
+        }
+    };
+
+    // ---- registers -> LDS -----------------------------------------------------------------------
+    auto store_step = [&]() {
+        if (!p.b_row_major) {
+#pragma unroll
+            for (int q = 0; q < NBV; q++) {
+                const int c = tid + kThreads * q;
+                const int j = c / (KP / 4), k = (c % (KP / 4)) * 4;
+                *reinterpret_cast<f32x4*>(&Bs[j * LDBS + k]) = breg[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NBV; q++) {
+                const int c = tid + kThreads * q;
+                const int k = c / (TN / 4), j = (c % (TN / 4)) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; e++) Bs[(j + e) * LDBS + k] = breg[q][e];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NAV; q++) {
+            const int e = tid + kThreads * q;
+            As[(e / TM) * LDAS + (e % TM)] = areg[q];
+        }
+    };
+
+    // ---- MFMA over one staged panel -----------------------------------------------------------------
+    // Fragment k-mapping: one ds_read_b128 gives a lane 4 consecutive k of its B column; MFMA number m of
+    // the round consumes element m, so lane-group g (half for 32x32x2, quarter for 16x16x4) contributes
+    // k = kb + 4g + m.  The A fragment uses the same k for the same lane group.  Any bijection works:
+    // an MFMA just sums over its k slots.
+    auto compute_step = [&](int kp) {
+        const int lm = lane & (MF - 1);             // row/col inside the MFMA tile
+        const int g = lane / MF;                    // k lane-group
+        for (int kb = 0; kb < kp; kb += KG) {
+            float a[MI][4];
+            f32x4 bf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                for (int m = 0; m < 4; m++) a[mi][m] = As[(kb + 4 * g + m) * LDAS + (wm * MI + mi) * MF + lm];
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++)
+                bf[ni] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NI + ni) * MF + lm) * LDBS + kb + 4 * g]);
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ni++) {
+                        if constexpr (MF == 32)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[ni][m], a[mi][m], acc[mi][ni], 0, 0, 0);
+                        else
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[ni][m], a[mi][m], acc[mi][ni], 0, 0, 0);
+                    }
+        }
+    };
+
+    if (nsteps > 0) load_step(0);
+    for (int s = 0; s < nsteps; s++) {
+        __syncthreads();                            // everyone finished reading the previous panel
+        store_step();
+        __syncthreads();
+        if (s + 1 < nsteps) load_step(s + 1);       // in flight while the MFMAs below run
+        const int ks = (s % spb) * KP;
+        const int kp = min(KP, w - ks);
+        compute_step(kp);
+    }
+
+    // ---- epilogue: D[j][i] -> C[i][j] -----------------------------------------------------------------
+    {
+        const int lm = lane & (MF - 1);
+        const int g = lane / MF;
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++) {
+            const int row = (wm * MI + mi) * MF + lm;
+            if (row >= td.mt) continue;
+#pragma unroll
+            for (int ni = 0; ni < NI; ni++) {
+#pragma unroll
+                for (int r = 0; r < (MF == 32 ? 16 : 4); r++) {
+                    const int j = (MF == 32) ? ((r & 3) + 8 * (r >> 2) + 4 * g) : (4 * g + r);
+                    const int col = n0 + (wn * NI + ni) * MF + j;
+                    if (col >= N) continue;
+                    float* dst = p.c_row_major ? p.C + (int64_t)(td.c_row + row) * p.ldc + col
+                                               : p.C + (int64_t)(td.c_row + row) + (int64_t)col * p.ldc;
+                    float v = acc[mi][ni][r];
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- exact-order kernel (parity aid) -----------------------------------------------------------------
+// One thread per element of C; the sum runs block by block, k ascending, with an UNFUSED multiply and
+// add -- the operation order and rounding of the reference's loop nest (src/general/vbr.cpp:358-363,
+// compiled for baseline x86-64: no FMA).  Bit-identical to VBR::multiply for finite inputs.
+struct BlockRowDesc {
+    int64_t a_off, jab_off;
+    int32_t nb, h, c_row, pad;
+};
+
+__global__ __launch_bounds__(kThreads) void vbs_spmm_f32_exact_kernel(const BlockRowDesc* rows, const int32_t* jab, const float* A,
+                                                                      const float* B, float* C, int64_t ldb, int64_t ldc,
+                                                                      int64_t cols, int N, int w, int b_row_major, int c_row_major,
+                                                                      int accumulate) {
+#pragma clang fp contract(off)
+    const BlockRowDesc br = rows[blockIdx.x];
+    const int64_t total = (int64_t)br.h * N;
+    for (int64_t idx = threadIdx.x; idx < total; idx += kThreads) {
+        const int i = (int)(idx % br.h);
+        const int j = (int)(idx / br.h);
+        float* dst = c_row_major ? C + (int64_t)(br.c_row + i) * ldc + j : C + (int64_t)(br.c_row + i) + (int64_t)j * ldc;
+        float c = accumulate ? *dst : 0.0f;
+        for (int b = 0; b < br.nb; b++) {
+            const int64_t gk0 = (int64_t)jab[br.jab_off + b] * w;
+            const float* ablk = A + br.a_off + (int64_t)b * w * br.h + i;
+            for (int k = 0; k < w; k++) {
+                const int64_t gk = gk0 + k;
+                // the reference reads B out of bounds here when cols % w != 0 (vbr.cpp:351,362) and relies on
+                // the matching A entry being a stored zero; we define that product as 0 * 0.
+                const float bv = gk < cols ? (b_row_major ? B[gk * ldb + j] : B[gk + (int64_t)j * ldb]) : 0.0f;
+                const float prod = ablk[(int64_t)k * br.h] * bv;
+                c = c + prod;
+            }
+        }
+        *dst = c;
+    }
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return sparta::fail(SPARTA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+struct sparta_vbs {
+    int device = 0, dtype = SPARTA_F32;
+    int64_t rows = 0, cols = 0, block_rows = 0, w = 0, nblocks = 0, nztot = 0;
+    float* d_A = nullptr;
+    int32_t* d_jab = nullptr;
+    TileDesc* d_tiles[4] = {nullptr, nullptr, nullptr, nullptr};   // classes 16, 32, 64, 128
+    int64_t n_tiles[4] = {0, 0, 0, 0};
+    BlockRowDesc* d_brows = nullptr;
+    int64_t n_brows = 0;
+    int64_t exec_area = 0;
+    int64_t a_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void* d_B = nullptr;
+    size_t d_B_bytes = 0;
+    void* d_C = nullptr;
+    size_t d_C_bytes = 0;
+};
+
+namespace {
+
+template <int MF, int WM, int WN, int MI, int NI>
+void launch_class(const SpmmParams& p, hipStream_t st) {
+    if (p.n_tiles == 0) return;
+    const int64_t grid = (int64_t)p.n_tiles * p.n_ntiles;
+    hipLaunchKernelGGL((vbs_spmm_f32_kernel<MF, WM, WN, MI, NI>), dim3((unsigned)grid), dim3(kThreads), 0, st, p);
+}
+
+int ensure_scratch(void** ptr, size_t* have, size_t need) {
+    if (*have >= need) return SPARTA_OK;
+    if (*ptr) { (void)hipFree(*ptr); *ptr = nullptr; *have = 0; }
+    HIP_TRY(hipMalloc(ptr, need));
+    *have = need;
+    return SPARTA_OK;
+}
+
+void destroy_impl(sparta_vbs* v) {
+    if (!v) return;
+    DeviceGuard g(v->device);
+    if (v->d_A) (void)hipFree(v->d_A);
+    if (v->d_jab) (void)hipFree(v->d_jab);
+    for (int c = 0; c < 4; c++)
+        if (v->d_tiles[c]) (void)hipFree(v->d_tiles[c]);
+    if (v->d_brows) (void)hipFree(v->d_brows);
+    if (v->d_B) (void)hipFree(v->d_B);
+    if (v->d_C) (void)hipFree(v->d_C);
+    if (v->ev0) (void)hipEventDestroy(v->ev0);
+    if (v->ev1) (void)hipEventDestroy(v->ev1);
+    delete v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sparta_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
+                            const int64_t* nzcount, const int64_t* jab, const float* mab, int64_t br0, int64_t br1, int32_t dtype,
+                            int32_t device) {
+    using sparta::fail;
+    if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: out is NULL");
+    *out = nullptr;
+    if (rows <= 0 || cols <= 0 || block_rows <= 0 || w <= 0 || !row_part || !nzcount)
+        return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad dimensions or NULL index array");
+    if (br0 < 0 || br1 > block_rows || br0 >= br1) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad block-row range");
+    if (dtype != SPARTA_F32) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: only SPARTA_F32 is implemented in this build");
+    if (rows > INT32_MAX || w > (1 << 20)) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: rows >= 2^31 or w > 2^20");
+    const int64_t block_cols = (cols - 1) / w + 1;
+
+    // validate the partition and locate the range inside jab / mab
+    if (row_part[0] != 0 || row_part[block_rows] != rows) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: row_part must span [0, rows]");
+    int64_t jab_lo = 0, mab_lo = 0, jab_hi = 0, mab_hi = 0, jo = 0, mo = 0;
+    for (int64_t ib = 0; ib < block_rows; ib++) {
+        const int64_t h = row_part[ib + 1] - row_part[ib];
+        if (h < 0 || nzcount[ib] < 0 || nzcount[ib] > block_cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: invalid row_part / nzcount");
+        if (h > INT32_MAX / 2 || nzcount[ib] > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: block-row too large");
+        if (ib == br0) { jab_lo = jo; mab_lo = mo; }
+        jo += nzcount[ib];
+        mo += nzcount[ib] * h * w;
+        if (ib == br1 - 1) { jab_hi = jo; mab_hi = mo; }
+    }
+    const int64_t nblocks = jab_hi - jab_lo, nztot = mab_hi - mab_lo;
+    if (nblocks > 0 && (!jab || !mab)) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: jab / mab is NULL");
+
+    int ndev = sparta_device_count();
+    if (ndev <= 0) return fail(SPARTA_ERR_NO_DEVICE, "sparta_vbs_create: no HIP device visible (this path has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: device index out of range");
+
+    // ---- plan: row tiles per class -----------------------------------------------------------------
+    std::vector<TileDesc> tiles[4];
+    std::vector<BlockRowDesc> brows;
+    std::vector<int32_t> jab32((size_t)std::max<int64_t>(nblocks, 1));
+    for (int64_t q = 0; q < nblocks; q++) {
+        const int64_t jb = jab[jab_lo + q];
+        if (jb < 0 || jb >= block_cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: jab entry out of range");
+        jab32[(size_t)q] = (int32_t)jb;
+    }
+    int64_t exec_area = 0;
+    {
+        int64_t jo2 = 0, mo2 = 0;
+        const int64_t row0 = row_part[br0];
+        for (int64_t ib = br0; ib < br1; ib++) {
+            const int64_t h = row_part[ib + 1] - row_part[ib];
+            const int64_t nb = nzcount[ib];
+            if (h > 0) {
+                BlockRowDesc br{mo2, jo2, (int32_t)nb, (int32_t)h, (int32_t)(row_part[ib] - row0), 0};
+                brows.push_back(br);
+                int64_t r0 = 0;
+                while (r0 < h) {
+                    const int64_t rem = h - r0;
+                    int cls;
+                    int64_t mt;
+                    if (rem > 64) { cls = 3; mt = std::min<int64_t>(rem, 128); }
+                    else if (rem > 32) { cls = 2; mt = rem; }
+                    else if (rem > 16) { cls = 1; mt = rem; }
+                    else { cls = 0; mt = rem; }
+                    TileDesc t{mo2 + r0, jo2, (int32_t)nb, (int32_t)h, (int32_t)(row_part[ib] - row0 + r0), (int32_t)mt};
+                    tiles[cls].push_back(t);
+                    const int64_t padded = cls == 0 ? 16 : ((mt + 31) / 32) * 32;
+                    exec_area += padded * w * nb;
+                    r0 += mt;
+                }
+            }
+            jo2 += nb;
+            mo2 += nb * h * w;
+        }
+    }
+
+    sparta_vbs* v = new (std::nothrow) sparta_vbs;
+    if (!v) return fail(SPARTA_ERR_ALLOC, "sparta_vbs_create: out of host memory");
+    v->device = device; v->dtype = dtype;
+    v->rows = row_part[br1] - row_part[br0]; v->cols = cols; v->block_rows = br1 - br0; v->w = w;
+    v->nblocks = nblocks; v->nztot = nztot; v->exec_area = exec_area;
+
+    DeviceGuard guard(device);
+    if (!guard.ok) { delete v; return fail(SPARTA_ERR_HIP, "sparta_vbs_create: hipSetDevice failed"); }
+#define CREATE_TRY(expr)                                                                                     \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e_);                              \
+            destroy_impl(v);                                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? SPARTA_ERR_ALLOC : SPARTA_ERR_HIP, m_);                  \
+        }                                                                                                    \
+    } while (0)
+    // A is padded by 128 floats so that no (masked-off) lane ever forms an address past the allocation
+    v->a_bytes = (nztot + 128) * (int64_t)sizeof(float);
+    CREATE_TRY(hipMalloc((void**)&v->d_A, (size_t)v->a_bytes));
+    CREATE_TRY(hipMemset(v->d_A, 0, (size_t)v->a_bytes));
+    if (nztot > 0) CREATE_TRY(hipMemcpy(v->d_A, mab + mab_lo, (size_t)nztot * sizeof(float), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc((void**)&v->d_jab, jab32.size() * sizeof(int32_t)));
+    CREATE_TRY(hipMemcpy(v->d_jab, jab32.data(), jab32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    for (int c = 0; c < 4; c++) {
+        v->n_tiles[c] = (int64_t)tiles[c].size();
+        if (tiles[c].empty()) continue;
+        CREATE_TRY(hipMalloc((void**)&v->d_tiles[c], tiles[c].size() * sizeof(TileDesc)));
+        CREATE_TRY(hipMemcpy(v->d_tiles[c], tiles[c].data(), tiles[c].size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    }
+    v->n_brows = (int64_t)brows.size();
+    if (!brows.empty()) {
+        CREATE_TRY(hipMalloc((void**)&v->d_brows, brows.size() * sizeof(BlockRowDesc)));
+        CREATE_TRY(hipMemcpy(v->d_brows, brows.data(), brows.size() * sizeof(BlockRowDesc), hipMemcpyHostToDevice));
+    }
+    CREATE_TRY(hipEventCreate(&v->ev0));
+    CREATE_TRY(hipEventCreate(&v->ev1));
+#undef CREATE_TRY
+    *out = v;
+    return SPARTA_OK;
+}
+
+int sparta_vbs_create(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
+                      const int64_t* nzcount, const int64_t* jab, const float* mab, int32_t dtype, int32_t device) {
+    return sparta_vbs_create_range(out, rows, cols, block_rows, w, row_part, nzcount, jab, mab, 0, block_rows, dtype, device);
+}
+
+int sparta_vbs_destroy(sparta_vbs_t* A) {
+    destroy_impl(A);
+    return SPARTA_OK;
+}
+
+int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info) {
+    if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_info: NULL argument");
+    std::memset(info, 0, 16 * sizeof(int64_t));
+    info[0] = A->rows; info[1] = A->cols; info[2] = A->block_rows; info[3] = A->w; info[4] = A->nblocks; info[5] = A->nztot;
+    for (int c = 0; c < 4; c++) info[6 + c] = A->n_tiles[c];
+    info[10] = A->a_bytes; info[11] = A->exec_area;
+    return SPARTA_OK;
+}
+
+int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int32_t n_cols, void* C, int64_t ldc,
+                    int32_t c_layout, int32_t accumulate, int32_t ptr_space, void* stream, int32_t algo, float* dt_ms) {
+    using sparta::fail;
+    if (!A || !B || !C) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: NULL argument");
+    if (n_cols <= 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: n_cols must be > 0");
+    if (b_layout != SPARTA_COL_MAJOR && b_layout != SPARTA_ROW_MAJOR) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: bad b_layout");
+    if (c_layout != SPARTA_COL_MAJOR && c_layout != SPARTA_ROW_MAJOR) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: bad c_layout");
+    if (ldb < (b_layout == SPARTA_COL_MAJOR ? A->cols : (int64_t)n_cols)) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: ldb too small");
+    if (ldc < (c_layout == SPARTA_COL_MAJOR ? A->rows : (int64_t)n_cols)) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: ldc too small");
+    if (algo != SPARTA_SPMM_MFMA && algo != SPARTA_SPMM_EXACT) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: bad algo");
+    if (ptr_space != SPARTA_PTR_HOST && ptr_space != SPARTA_PTR_DEVICE) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: bad ptr_space");
+
+    DeviceGuard guard(A->device);
+    if (!guard.ok) return fail(SPARTA_ERR_HIP, "sparta_vbs_spmm: hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+
+    const float* dB = (const float*)B;
+    float* dC = (float*)C;
+    const size_t b_elems = (size_t)ldb * (size_t)(b_layout == SPARTA_COL_MAJOR ? n_cols : A->cols);
+    const size_t c_elems = (size_t)ldc * (size_t)(c_layout == SPARTA_COL_MAJOR ? n_cols : A->rows);
+    if (ptr_space == SPARTA_PTR_HOST) {
+        // the reference's back-end contract: host in, host out, dt excludes the copies
+        if (int rc = ensure_scratch(&A->d_B, &A->d_B_bytes, b_elems * sizeof(float))) return rc;
+        if (int rc = ensure_scratch(&A->d_C, &A->d_C_bytes, c_elems * sizeof(float))) return rc;
+        HIP_TRY(hipMemcpyAsync(A->d_B, B, b_elems * sizeof(float), hipMemcpyHostToDevice, st));
+        if (accumulate) HIP_TRY(hipMemcpyAsync(A->d_C, C, c_elems * sizeof(float), hipMemcpyHostToDevice, st));
+        else if (c_elems > 0) HIP_TRY(hipMemsetAsync(A->d_C, 0, c_elems * sizeof(float), st));   // ld padding stays defined
+        dB = (const float*)A->d_B;
+        dC = (float*)A->d_C;
+    }
+
+    if (dt_ms) HIP_TRY(hipEventRecord(A->ev0, st));
+    if (algo == SPARTA_SPMM_EXACT) {
+        if (A->d_brows) {
+            hipLaunchKernelGGL(vbs_spmm_f32_exact_kernel, dim3((unsigned)A->n_brows), dim3(kThreads), 0, st, A->d_brows, A->d_jab,
+                               A->d_A, dB, dC, ldb, ldc, A->cols, (int)n_cols, (int)A->w, (int)(b_layout == SPARTA_ROW_MAJOR),
+                               (int)(c_layout == SPARTA_ROW_MAJOR), (int)accumulate);
+        }
+    } else {
+        SpmmParams p;
+        p.jab = A->d_jab; p.A = A->d_A; p.B = dB; p.C = dC; p.ldb = ldb; p.ldc = ldc; p.cols = A->cols;
+        p.n_ntiles = (n_cols + kTN - 1) / kTN; p.N = n_cols; p.w = (int32_t)A->w;
+        p.b_row_major = b_layout == SPARTA_ROW_MAJOR; p.c_row_major = c_layout == SPARTA_ROW_MAJOR;
+        p.accumulate = accumulate != 0;
+        const char* nv = std::getenv("SPARTA_NO_VEC");
+        p.vec_ok = (nv && nv[0] == '1') ? 0 : 1;
+        for (int c = 3; c >= 0; c--) {              // heavy classes first
+            if (A->n_tiles[c] == 0) continue;
+            if (A->n_tiles[c] * (int64_t)p.n_ntiles > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: grid too large");
+            p.tiles = A->d_tiles[c]; p.n_tiles = (int32_t)A->n_tiles[c];
+            switch (c) {
+                case 0: launch_class<16, 1, 4, 1, 2>(p, st); break;   //  16 x 128
+                case 1: launch_class<32, 1, 4, 1, 1>(p, st); break;   //  32 x 128
+                case 2: launch_class<32, 2, 2, 1, 2>(p, st); break;   //  64 x 128
+                default: launch_class<32, 2, 2, 2, 2>(p, st); break;  // 128 x 128
+            }
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    if (dt_ms) {
+        HIP_TRY(hipEventRecord(A->ev1, st));
+        HIP_TRY(hipEventSynchronize(A->ev1));
+        HIP_TRY(hipEventElapsedTime(dt_ms, A->ev0, A->ev1));
+    }
+    if (ptr_space == SPARTA_PTR_HOST) {
+        HIP_TRY(hipMemcpyAsync(C, A->d_C, c_elems * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SPARTA_OK;
+}
+
+}  // extern "C"

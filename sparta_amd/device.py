@@ -1,0 +1,95 @@
+"""Device side: VBS image on one MI355X and the fused SpMM (sparta_vbs_create / sparta_vbs_spmm)."""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+
+_i64p = C.POINTER(C.c_int64)
+_f32p = C.POINTER(C.c_float)
+
+
+def device_count():
+    return int(lib.sparta_device_count())
+
+
+class DeviceVBS:
+    """Opaque device image of a VBS matrix + its tile plan (sparta_vbs_t)."""
+
+    def __init__(self, vbmat, device=0, dtype=_lib.F32, block_row_range=None):
+        self.device = int(device)
+        self.dtype = dtype
+        self.h = C.c_void_p(None)
+        rp = np.ascontiguousarray(vbmat.row_part, np.int64)
+        nz = np.ascontiguousarray(vbmat.nzcount, np.int64)
+        jab = np.ascontiguousarray(vbmat.jab, np.int64)
+        mab = np.ascontiguousarray(vbmat.mab, np.float32)
+        b0, b1 = (0, vbmat.block_rows) if block_row_range is None else block_row_range
+        check(lib.sparta_vbs_create_range(C.byref(self.h), vbmat.rows, vbmat.cols, vbmat.block_rows, vbmat.block_col_size,
+                                          rp.ctypes.data_as(_i64p), nz.ctypes.data_as(_i64p), jab.ctypes.data_as(_i64p),
+                                          mab.ctypes.data_as(_f32p), int(b0), int(b1), int(dtype), self.device))
+        info = self.info()
+        self.rows, self.cols = info["rows"], info["cols"]
+
+    def info(self):
+        a = np.zeros(16, np.int64)
+        check(lib.sparta_vbs_info(self.h, a.ctypes.data_as(_i64p)))
+        keys = ["rows", "cols", "block_rows", "block_col_size", "nblocks", "nztot", "tiles16", "tiles32", "tiles64",
+                "tiles128", "a_bytes", "exec_area"]
+        return {k: int(a[i]) for i, k in enumerate(keys)}
+
+    def spmm_host(self, B, n_cols, C_out, accumulate=True, algo=_lib.SPMM_MFMA, b_layout=_lib.COL_MAJOR,
+                  c_layout=_lib.COL_MAJOR):
+        """Host buffers in, host buffers out (the reference back-ends' contract). Returns kernel ms."""
+        B = np.ascontiguousarray(B, np.float32).reshape(-1)
+        if not (isinstance(C_out, np.ndarray) and C_out.dtype == np.float32 and C_out.flags.c_contiguous):
+            raise ValueError("C must be a contiguous float32 numpy array (it is written in place)")
+        ldb = self.cols if b_layout == _lib.COL_MAJOR else n_cols
+        ldc = self.rows if c_layout == _lib.COL_MAJOR else n_cols
+        if B.size < self.cols * n_cols or C_out.size < self.rows * n_cols:
+            raise ValueError("B or C too small")
+        dt = C.c_float(0)
+        check(lib.sparta_vbs_spmm(self.h, B.ctypes.data_as(C.c_void_p), ldb, b_layout, int(n_cols),
+                                  C_out.ctypes.data_as(C.c_void_p), ldc, c_layout, int(bool(accumulate)), _lib.PTR_HOST, None,
+                                  int(algo), C.byref(dt)))
+        return dt.value
+
+    def spmm(self, B, C_out, n_cols, accumulate=False, algo=_lib.SPMM_MFMA, b_layout=_lib.COL_MAJOR, c_layout=_lib.COL_MAJOR,
+             ldb=None, ldc=None, timed=False, stream=None):
+        """Device tensors (torch, on this device): stream-ordered on torch's current stream, no copies.
+        B: cols x n_cols, C: rows x n_cols in the given layouts. Returns kernel ms if timed else None."""
+        import torch
+        if not (B.is_cuda and C_out.is_cuda and B.dtype == torch.float32 and C_out.dtype == torch.float32):
+            raise ValueError("B and C must be float32 tensors on the GPU")
+        if B.device.index != self.device or C_out.device.index != self.device:
+            raise ValueError("B and C must live on device %d" % self.device)
+        ldb = (self.cols if b_layout == _lib.COL_MAJOR else n_cols) if ldb is None else ldb
+        ldc = (self.rows if c_layout == _lib.COL_MAJOR else n_cols) if ldc is None else ldc
+        need_b = ldb * (n_cols if b_layout == _lib.COL_MAJOR else self.cols)
+        need_c = ldc * (n_cols if c_layout == _lib.COL_MAJOR else self.rows)
+        if B.numel() < need_b or C_out.numel() < need_c or not B.is_contiguous() or not C_out.is_contiguous():
+            raise ValueError("B or C too small / not contiguous for the stated leading dimensions")
+        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        dt = C.c_float(0)
+        check(lib.sparta_vbs_spmm(self.h, C.c_void_p(B.data_ptr()), int(ldb), b_layout, int(n_cols), C.c_void_p(C_out.data_ptr()),
+                                  int(ldc), c_layout, int(bool(accumulate)), _lib.PTR_DEVICE, C.c_void_p(st), int(algo),
+                                  C.byref(dt) if timed else None))
+        return dt.value if timed else None
+
+    def close(self):
+        if self.h:
+            lib.sparta_vbs_destroy(self.h)
+            self.h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def vbs_multiply(vbmat, B, B_cols, C_out, n_streams=None, device=0):
+    """Drop-in for the reference's GPU back-ends `f(const VBR&, DataT* B, int B_cols, DataT_C* C, float& dt[, n_streams])`
+    (include/cuda_utilities.h:38-44): host B/C, C += A*B, returns dt in ms (kernel only). `n_streams` is accepted and
+    ignored (there is one fused launch per tile class, not one GEMM per block)."""
+    return vbmat.multiply(B, B_cols, C_out, device=device)

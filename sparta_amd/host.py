@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference's CSR / BlockingEngine / VBR interface (same names, argument
+meaning and defaults), implemented by the host C++ in libsparta_amd.so."""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+
+# BlockingType (include/definitions.h:17) -- values of the `-a` flag
+BLOCKING_ALGOS = dict(iterative=0, iterative_structured=1, fixed_size=2, iterative_clocked=3, iterative_queue=4,
+                      iterative_max_size=5, scramble=6)
+
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+
+
+def _p64(a):
+    return a.ctypes.data_as(_i64p)
+
+
+def _p32(a):
+    return a.ctypes.data_as(_i32p)
+
+
+def _pf(a):
+    return a.ctypes.data_as(_f32p) if a is not None else None
+
+
+class CSR:
+    """Sparse input matrix.  The reference keeps one heap array per row (`nzcount[i]`, `ja[i][]`, `ma[i][]`,
+    include/matrices.h:22-28); here the same content is flat: rowptr[rows+1] (int64), colidx (int32, ascending
+    within a row), vals (float32 or None == `pattern_only`)."""
+
+    def __init__(self, rows, cols, rowptr, colidx, vals=None):
+        self.rows, self.cols = int(rows), int(cols)
+        self.rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        self.colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+        self.vals = None if vals is None else np.ascontiguousarray(vals, dtype=np.float32)
+        if self.rowptr.shape != (self.rows + 1,):
+            raise ValueError("rowptr must have rows+1 entries")
+        if self.vals is not None and self.vals.shape != self.colidx.shape:
+            raise ValueError("vals and colidx differ in length")
+
+    @property
+    def pattern_only(self):
+        return self.vals is None
+
+    @property
+    def nzcount(self):
+        return np.diff(self.rowptr)
+
+    def nztot(self):
+        return int(self.rowptr[-1])
+
+    def ja(self, i):
+        return self.colidx[self.rowptr[i]:self.rowptr[i + 1]]
+
+    def ma(self, i):
+        return None if self.vals is None else self.vals[self.rowptr[i]:self.rowptr[i + 1]]
+
+    @classmethod
+    def from_scipy(cls, m, pattern_only=False):
+        m = m.tocsr()
+        m.sort_indices()
+        return cls(m.shape[0], m.shape[1], m.indptr, m.indices, None if pattern_only else m.data)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        v = np.ones(len(self.colidx), np.float32) if self.vals is None else self.vals
+        return sp.csr_matrix((v, self.colidx, self.rowptr), shape=(self.rows, self.cols))
+
+
+class BlockingEngine:
+    """Row-clustering reorder engine; field names and defaults of the reference's BlockingEngine
+    (include/blocking.h:9-56)."""
+
+    def __init__(self, tau=0.5, col_block_size=1, row_block_size=1, use_groups=False, use_pattern=True,
+                 force_fixed_size=False, blocking_algo=3, sim_measure=1):
+        self.tau = tau
+        self.col_block_size = col_block_size
+        self.row_block_size = row_block_size
+        self.use_groups = use_groups
+        self.use_pattern = use_pattern
+        self.force_fixed_size = force_fixed_size
+        self.blocking_algo = BLOCKING_ALGOS.get(blocking_algo, blocking_algo)
+        self.sim_measure = sim_measure          # SetComparator(choice): 0 Hamming, 1 Jaccard (blocking.cpp:699-717)
+        self.comparison_counter = 0
+        self.merge_counter = 0
+        self.timer_total = 0.0
+        self.timer_comparisons = 0.0
+        self.timer_merges = 0.0
+        self.average_row_distance = 0.0
+        self.average_merge_tau = 0.0
+        self.multiplication_timer_avg = 0.0
+        self.multiplication_timer_std = 0.0
+        self.VBR_nzcount = 0
+        self.VBR_nzblocks_count = 0
+        self.VBR_average_height = 0.0
+        self.VBR_longest_row = 0
+        self.grouping_result = None
+
+    def SetComparator(self, choice):
+        self.sim_measure = choice
+
+    def _cfg(self):
+        c = _lib.ReorderCfg()
+        c.blocking_algo = int(self.blocking_algo)
+        c.sim_measure = int(self.sim_measure)
+        c.tau = float(self.tau)
+        c.use_groups = int(bool(self.use_groups))
+        c.col_block_size = int(self.col_block_size)
+        c.row_block_size = int(self.row_block_size)
+        c.use_pattern = int(bool(self.use_pattern))
+        c.force_fixed_size = int(bool(self.force_fixed_size))
+        return c
+
+    def GetGrouping(self, cmat):
+        """std::vector<intT> BlockingEngine::GetGrouping(const CSR&)  (blocking.cpp:633-676)"""
+        g = np.empty(cmat.rows, np.int64)
+        st = _lib.ReorderStats()
+        cfg = self._cfg()
+        check(lib.sparta_reorder(cmat.rows, cmat.cols, _p64(cmat.rowptr), _p32(cmat.colidx), C.byref(cfg), _p64(g), C.byref(st)))
+        self.comparison_counter = st.comparison_counter
+        self.merge_counter = st.merge_counter
+        self.average_row_distance = st.average_row_distance
+        self.average_merge_tau = st.average_merge_tau
+        self.timer_total = st.timer_total
+        self.timer_comparisons = st.timer_comparisons
+        self.timer_merges = st.timer_merges
+        self.grouping_result = g
+        return g
+
+    def CollectBlockingInfo(self, cmat):
+        """BlockingEngine::CollectBlockingInfo (blocking.cpp:576-631)"""
+        info = np.zeros(3, np.int64)
+        avg = C.c_float(0)
+        g = np.ascontiguousarray(self.grouping_result, np.int64)
+        check(lib.sparta_blocking_info(cmat.rows, cmat.cols, _p64(cmat.rowptr), _p32(cmat.colidx), _p64(g),
+                                       int(self.col_block_size), _p64(info), C.byref(avg)))
+        self.VBR_nzcount, self.VBR_nzblocks_count = int(info[0]), int(info[1])
+        self.VBR_longest_row = max(self.VBR_longest_row, int(info[2]))
+        self.VBR_average_height = avg.value
+
+
+class VBR:
+    """Variable-block-sparse matrix: the fields of the reference's struct VBR (include/matrices.h:93-104)."""
+
+    def __init__(self):
+        self.rows = self.cols = self.block_rows = self.block_cols = 0
+        self.block_col_size = 0
+        self.nztot = 0
+        self.nzcount = self.jab = self.row_part = self.mab = None
+        self._dev = None
+
+    def fill_from_CSR_inplace(self, cmat, grouping, col_block_size, row_block_size=0, force_fixed_size=False):
+        """VBR::fill_from_CSR_inplace (include/matrices.h:118, vbr.cpp:135-237)"""
+        g = np.ascontiguousarray(grouping, np.int64)
+        if g.shape != (cmat.rows,):
+            raise ValueError("grouping must have one entry per row")
+        h = _lib.VbsHost()
+        check(lib.sparta_vbs_build(cmat.rows, cmat.cols, _p64(cmat.rowptr), _p32(cmat.colidx), _pf(cmat.vals), _p64(g),
+                                   int(col_block_size), int(row_block_size), int(bool(force_fixed_size)), C.byref(h)))
+        try:
+            self.rows, self.cols = h.rows, h.cols
+            self.block_rows, self.block_cols = h.block_rows, h.block_cols
+            self.block_col_size, self.nztot = h.block_col_size, h.nztot
+            self.row_part = np.ctypeslib.as_array(h.row_part, (h.block_rows + 1,)).copy()
+            self.nzcount = np.ctypeslib.as_array(h.nzcount, (h.block_rows,)).copy()
+            self.jab = np.ctypeslib.as_array(h.jab, (max(h.nblocks, 1),))[:h.nblocks].copy()
+            self.mab = np.ctypeslib.as_array(h.mab, (max(h.nztot, 1),))[:h.nztot].copy()
+        finally:
+            lib.sparta_vbs_host_free(C.byref(h))
+        self._dev = None
+        return self
+
+    def fill_from_CSR_inplace_fixed(self, cmat, row_block_size, col_block_size, force_fixed_size=False):
+        """the fixed-grid overload (vbr.cpp:121-132): grouping[i] = i / row_block_size"""
+        g = np.arange(cmat.rows, dtype=np.int64) // int(row_block_size)
+        return self.fill_from_CSR_inplace(cmat, g, col_block_size, row_block_size, force_fixed_size)
+
+    @classmethod
+    def from_arrays(cls, rows, cols, block_col_size, row_part, nzcount, jab, mab):
+        v = cls()
+        v.rows, v.cols, v.block_col_size = int(rows), int(cols), int(block_col_size)
+        v.row_part = np.ascontiguousarray(row_part, np.int64)
+        v.nzcount = np.ascontiguousarray(nzcount, np.int64)
+        v.jab = np.ascontiguousarray(jab, np.int64)
+        v.mab = np.ascontiguousarray(mab, np.float32)
+        v.block_rows = len(v.nzcount)
+        v.block_cols = (v.cols - 1) // v.block_col_size + 1
+        v.nztot = len(v.mab)
+        return v
+
+    def to_device(self, device=0, dtype=_lib.F32, block_row_range=None):
+        from .device import DeviceVBS
+        return DeviceVBS(self, device=device, dtype=dtype, block_row_range=block_row_range)
+
+    def multiply(self, B, B_cols, C_out, device=0, algo=_lib.SPMM_MFMA):
+        """void VBR::multiply(DataT* B, int B_cols, DataT_C* C)  (include/matrices.h:121): C += A*B with host
+        buffers, column-major, ld(B) = cols, ld(C) = rows -- executed on the GPU.  Returns the kernel time in ms."""
+        if self._dev is None or self._dev.device != device:
+            self._dev = self.to_device(device)
+        return self._dev.spmm_host(B, B_cols, C_out, accumulate=True, algo=algo)
+
+
+def get_permutation(grouping):
+    g = np.ascontiguousarray(grouping, np.int64)
+    out = np.empty(len(g), np.int64)
+    check(lib.sparta_get_permutation(_p64(g), len(g), _p64(out)))
+    return out
+
+
+def get_partition(grouping):
+    g = np.ascontiguousarray(grouping, np.int64)
+    out = np.empty(len(g) + 1, np.int64)
+    n = C.c_int64(0)
+    check(lib.sparta_get_partition(_p64(g), len(g), _p64(out), C.byref(n)))
+    return out[:n.value].copy()
+
+
+def get_fixed_size_grouping(grouping, row_block_size):
+    g = np.ascontiguousarray(grouping, np.int64)
+    out = np.empty(len(g), np.int64)
+    check(lib.sparta_get_fixed_size_grouping(_p64(g), len(g), int(row_block_size), _p64(out)))
+    return out
+
+
+def row_distance(sim_measure, row_a, group_a, row_b, group_b, block_size):
+    a = np.ascontiguousarray(row_a, np.int64)
+    b = np.ascontiguousarray(row_b, np.int64)
+    d = C.c_float(0)
+    check(lib.sparta_row_distance(int(sim_measure), _p64(a), len(a), int(group_a), _p64(b), len(b), int(group_b),
+                                  int(block_size), C.byref(d)))
+    return d.value
+
+
+def merge_rows(row_a, row_b):
+    a = np.ascontiguousarray(row_a, np.int64)
+    b = np.ascontiguousarray(row_b, np.int64)
+    out = np.empty(len(a) + len(b) + 1, np.int64)
+    n = C.c_int64(0)
+    check(lib.sparta_merge_rows(_p64(a), len(a), _p64(b), len(b), _p64(out), C.byref(n)))
+    return out[:n.value].copy()
