@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the block-sparse SpMM path (BASELINE.json: "Block-sparse SpMM GFLOP/s +
+%HBM/MFMA roofline").
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: C = A_vbs * B with A already reordered
+(Jaccard row clustering), built into VBS and resident in HBM, B and C resident in HBM.
+
+  N = 1  : BASELINE.json configs[1] -- SuiteSparse `cant` shape (62 451^2, 3-dof FEM, ~4.3 M nnz; generated, there is no
+           network), B = 128 dense columns, fp32, reference layouts (B, C column-major).
+  N > 1  : weak scaling of the same workload: the mesh grows N x along z, rank r owns row slab r of A and the matching
+           row shard of B; each step = ONE all-gather of B over RCCL/xGMI + the local SpMM; no collective on C.
+
+value = useful GFLOP/s of the whole job = 2 * nnz * n_cols * n_gpus_units / time (dense-block padding is NOT counted).
+The JSON line also carries the roofline of the dominant kernel and a CPU baseline (the reference's own
+VBR::multiply, compiled from its sources into oracle/_ref, timed on this box's host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
+
+
+def mixed_roofline_seconds(row_part, nzcount, w, n_cols, cols, accumulate=False):
+    """T_lb = sum over block-rows of max(bytes_alg / BW, flops_exec / P) + |B| / BW."""
+    h = np.diff(np.asarray(row_part, np.int64)).astype(np.float64)
+    nb = np.asarray(nzcount, np.float64)
+    flops = 2.0 * nb * h * w * n_cols
+    byts = nb * h * w * 4.0 + nb * 4.0 + 16.0 + h * n_cols * 4.0 * (2.0 if accumulate else 1.0)
+    t = np.maximum(byts / (PEAK_HBM_GBS * 1e9), flops / (PEAK_MFMA_F32_TFLOPS * 1e12)).sum()
+    t += cols * n_cols * 4.0 / (PEAK_HBM_GBS * 1e9)
+    return float(t), float(flops.sum()), float(byts.sum() + cols * n_cols * 4.0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--tau", type=float, default=0.2)
+    ap.add_argument("--col-block", type=int, default=64)
+    ap.add_argument("--ncols", type=int, default=128)
+    ap.add_argument("--fixed-height", type=int, default=0, help="reorder OFF: fixed block-row height instead of clustering")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import sparta_amd as sa
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    n_gpus = max(args.gpus, 1)
+    if n_gpus > 1 and world == 1:
+        raise SystemExit("for --gpus > 1 launch with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the SpMM path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    w, N = args.col_block, args.ncols
+    t0 = time.time()
+    # ---- workload ------------------------------------------------------------------------------------------------
+    if world == 1:
+        m = sa.gen.cant_like(seed=2)
+        n_local, shard_rows = m.rows, None
+    else:
+        m, n_local, shard_rows = sa.gen.fem3d_slab(9, 9, 257, rank, world, dof=3, pad_to=w, seed=2)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    if args.fixed_height:
+        eng = sa.BlockingEngine(blocking_algo="fixed_size", row_block_size=args.fixed_height, col_block_size=w)
+    else:
+        eng = sa.BlockingEngine(blocking_algo="iterative_clocked", tau=args.tau, col_block_size=w, sim_measure=1)
+    grouping = eng.GetGrouping(m)
+    t_reorder = time.time() - t0
+    t0 = time.time()
+    vb = sa.VBR().fill_from_CSR_inplace(m, grouping, w)
+    t_build = time.time() - t0
+    d = vb.to_device(local_rank)
+    info = d.info()
+
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    if world == 1:
+        B = (torch.rand(vb.cols * N, generator=g, dtype=torch.float32) - 0.5).to(dev)      # column-major, ld = cols
+        B_shard = B_gath = None
+    else:
+        B_shard = (torch.rand(shard_rows * N, generator=g, dtype=torch.float32) - 0.5).to(dev)   # column-major, ld = shard_rows
+        B_gath = torch.empty(world * shard_rows * N, dtype=torch.float32, device=dev)
+    C = torch.zeros(vb.rows * N, dtype=torch.float32, device=dev)
+
+    def step():
+        if world == 1:
+            d.spmm(B, C, N, accumulate=False)
+        else:
+            dist.all_gather_into_tensor(B_gath, B_shard)          # the one exchange step (RCCL over xGMI)
+            d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- per-kernel device time (HIP events on the launch stream, one class per kernel instantiation) ----------
+    d.set_class_timing(True)
+    cls_ms = {16: [], 32: [], 64: [], 128: []}
+    for _ in range(min(args.steps, 50)):
+        step()
+        ct = d.class_times()
+        for k in cls_ms:
+            cls_ms[k].append(ct[k])
+    d.set_class_timing(False)
+    cls_avg = {k: float(np.mean(v)) for k, v in cls_ms.items()}
+
+    nnz_local = m.nztot()
+    nnz_total = nnz_local
+    if world > 1:
+        tt = torch.tensor([float(nnz_local)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt)
+        nnz_total = float(tt.item())
+    useful_gflops = 2.0 * nnz_total * N / (ms_per_step * 1e-3) / 1e9
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (rank 0's launch) ------------------------------------------------------
+    h = np.diff(vb.row_part)
+    heights = {16: 16, 32: 32, 64: 64, 128: 128}
+    dom = max(cls_avg, key=lambda k: cls_avg[k])
+    # algorithmic flops of the dominant class = 2 * (stored area of its tiles) * N.  Tiles are cut from block-rows by
+    # height: rows beyond multiples of 128 fall into the class of the remainder (mirrors the plan in vbs_spmm.hip).
+    area_by_cls = {16: 0.0, 32: 0.0, 64: 0.0, 128: 0.0}
+    for hh, nb in zip(h, vb.nzcount):
+        r = int(hh)
+        while r > 0:
+            if r > 64:
+                mt, c = min(r, 128), 128
+            elif r > 32:
+                mt, c = r, 64
+            elif r > 16:
+                mt, c = r, 32
+            else:
+                mt, c = r, 16
+            area_by_cls[c] += float(mt) * w * float(nb)
+            r -= mt
+    t_lb, flops_exec, bytes_alg = mixed_roofline_seconds(vb.row_part, vb.nzcount, w, N, vb.cols)
+    kernel_ms_total = sum(cls_avg.values())
+    dom_tflops = 2.0 * area_by_cls[dom] * N / (cls_avg[dom] * 1e-3) / 1e12 if cls_avg[dom] > 0 else 0.0
+    roofline = {
+        "bound": "mfma", "achieved": round(dom_tflops, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(dom_tflops / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+        "kernel": "vbs_spmm_f32_kernel<class %d>" % dom, "kernel_ms": round(cls_avg[dom], 5),
+        "class_ms": {str(k): round(v, 5) for k, v in cls_avg.items()},
+        "all_kernels_tflops_exec": round(flops_exec / (kernel_ms_total * 1e-3) / 1e12, 3) if kernel_ms_total > 0 else 0.0,
+        "mixed_roofline_frac": round(t_lb / (kernel_ms_total * 1e-3), 4) if kernel_ms_total > 0 else 0.0,
+        "algorithmic_gbs": round(bytes_alg / (kernel_ms_total * 1e-3) / 1e9, 1) if kernel_ms_total > 0 else 0.0,
+    }
+
+    # ---- CPU baseline: the reference's own VBR::multiply on this host, 1 thread -----------------------------------
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            from oracle import ref, oracle as O
+            Bh = (B if world == 1 else None)
+            if world == 1:
+                Bh = B.cpu().numpy()
+            else:
+                Bh = sa.dist.gathered_to_colmajor(B_gath.cpu().numpy(), world, shard_rows, N)
+            # bounded sample: a prefix of block-rows worth <= ~2e10 executed flops (about 10-20 s of scalar CPU work)
+            per_row = 2.0 * np.diff(vb.row_part) * w * vb.nzcount * N
+            cum = np.cumsum(per_row)
+            nbr = int(np.searchsorted(cum, 2.0e10, side="right"))
+            nbr = max(1, min(nbr, vb.block_rows))
+            rows_s = int(vb.row_part[nbr])
+            # useful flops of the sample: nnz of the (reordered) rows it covers
+            perm = sa.get_permutation(grouping)
+            nnz_s = int(np.diff(m.rowptr)[perm[:rows_s]].sum())
+            if ref.available():
+                kind = "reference"
+                rc = ref.RefCSR(m.rows, m.cols, m.rowptr, m.colidx.astype(np.int64), m.vals)
+                if nbr == vb.block_rows:
+                    rv = ref.RefVBR(rc, grouping, w)
+                    t1 = time.perf_counter()
+                    rv.multiply(Bh, N)
+                    t_cpu = time.perf_counter() - t1
+                else:
+                    kind = "port"
+                    rv = None
+            else:
+                kind = "port"
+                rv = None
+            if rv is None:
+                t1 = time.perf_counter()
+                O.vbr_multiply(vb.rows, vb.cols, w, vb.row_part, vb.nzcount, vb.jab, vb.mab, Bh, N, block_row_range=(0, nbr))
+                t_cpu = time.perf_counter() - t1
+            cpu = {"value": round(2.0 * nnz_s * N / t_cpu / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": kind,
+                   "sample": "block-rows [0,%d) of %d (%d rows, %d nnz), 1 repetition, %.2f s; executed dense-block rate %.2f GFLOP/s"
+                             % (nbr, vb.block_rows, rows_s, nnz_s, t_cpu, float(cum[nbr - 1]) / t_cpu / 1e9)}
+        except Exception as e:  # the baseline is a report, never a reason to lose the measurement
+            cpu = {"value": None, "unit": "GFLOP/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+
+    out = {
+        "metric": "Block-sparse SpMM GFLOP/s", "value": round(useful_gflops, 2), "unit": "GFLOP/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": ("cant-like FEM 9x9x257 mesh x 3 dof (62451^2, %d nnz), B = %d cols, fp32" % (nnz_local, N)) if world == 1 else
+                        ("row-partitioned FEM 9x9x%d mesh x 3 dof (%d^2 padded, %d nnz), B = %d cols, fp32, 1 all-gather of B per step"
+                         % (257 * world, world * shard_rows, int(nnz_total), N)),
+            "reorder": ("fixed height %d (reorder off)" % args.fixed_height) if args.fixed_height else
+                       ("Jaccard iterative_clocked tau=%.2f" % args.tau),
+            "col_block_size": w, "n_cols": N, "block_rows": int(vb.block_rows), "nonzero_blocks": int(len(vb.jab)),
+            "vbs_area": int(vb.nztot), "fill": round(nnz_local / max(vb.nztot, 1), 4),
+            "mean_block_row_height": round(float(h.mean()), 2),
+            "tiles": {"16": info["tiles16"], "32": info["tiles32"], "64": info["tiles64"], "128": info["tiles128"]},
+            "executed_gflops": round(flops_exec * (n_gpus if world > 1 else 1) / (ms_per_step * 1e-3) / 1e9, 1),
+            "host_seconds": {"generate": round(t_gen, 2), "reorder": round(t_reorder, 2), "vbs_build": round(t_build, 2)},
+            "parallelism": "row-partition x%d, B all-gather" % world if world > 1 else "single GPU",
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -178,6 +178,20 @@ int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layou
                     void* C, int64_t ldc, int32_t c_layout, int32_t accumulate,
                     int32_t ptr_space, void* stream, int32_t algo, float* dt_ms);
 
+/* Multi-GPU entry point: B_gathered is what ONE ncclAllGather (RCCL) of the ranks' row shards of B leaves on
+ * every GPU: n_shards consecutive column-major slabs of shard_rows x n_cols (ld = shard_rows), slab s holding
+ * rows [s*shard_rows, (s+1)*shard_rows) of B, consecutive slabs shard_stride elements apart.  shard_rows must
+ * be a multiple of block_col_size (so that no B panel straddles two slabs) and cols == n_shards * shard_rows.
+ * Device pointers only.  No reference counterpart (the reference is single-GPU: SURVEY.md section 2.1). */
+int sparta_vbs_spmm_gathered(sparta_vbs_t* A, const void* B_gathered, int64_t shard_rows, int64_t shard_stride, int32_t n_cols,
+                             void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, void* stream, int32_t algo, float* dt_ms);
+
+/* Per-tile-class device timing for roofline reports: when enabled, sparta_vbs_spmm brackets each class
+ * launch with HIP events on the launch stream; sparta_vbs_class_times waits for them and writes the last
+ * call's milliseconds for classes {16, 32, 64, 128} (0 for a class with no tiles) into ms_out[4]. */
+int sparta_vbs_set_class_timing(sparta_vbs_t* A, int32_t enable);
+int sparta_vbs_class_times(sparta_vbs_t* A, float* ms_out);
+
 int sparta_vbs_destroy(sparta_vbs_t* A);
 
 /* plan / roofline introspection. info_out (int64[16]):

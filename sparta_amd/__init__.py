@@ -18,7 +18,7 @@ from ._lib import (SpartaError, LIB_PATH, F32, F16, BF16, COL_MAJOR, ROW_MAJOR, 
 from .host import (CSR, BlockingEngine, VBR, get_permutation, get_partition, get_fixed_size_grouping,  # noqa: F401
                    row_distance, merge_rows, BLOCKING_ALGOS)
 from .device import DeviceVBS, vbs_multiply, device_count  # noqa: F401
-from . import gen  # noqa: F401
+from . import gen, dist  # noqa: F401
 
 # names of the reference's GPU back-ends this path replaces (include/cuda_utilities.h:38-44,
 # include/cutlass_bellpack_lib.h:19-25): all map onto the single fused kernel family.

@@ -66,6 +66,8 @@ struct SpmmParams {
     int32_t N, w;
     int32_t b_row_major, c_row_major;
     int32_t accumulate, vec_ok;
+    int64_t shard_stride; // elements between consecutive slabs of a gathered B
+    int64_t shard_rows;   // 0: B is one matrix; >0: B is an all-gather result of column-major shard_rows x N slabs
 };
 
 // bijective XCD-aware remap (workgroups are dealt round-robin over the 8 XCDs: b and b+8 share one)
@@ -129,7 +131,17 @@ __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_kernel(const SpmmParams
         const int b = s / spb;
         const int ks = (s - b * spb) * KP;
         const int64_t jb = p.jab[td.jab_off + b];
-        const int64_t gk0 = jb * (int64_t)w + ks;                 // first B row of this panel
+        int64_t gk0 = jb * (int64_t)w + ks;                       // first B row of this panel
+        const float* Bbase = p.B;
+        int64_t bvalid = p.cols;                                  // rows of B that exist (panel rows past it read as 0)
+        if (p.shard_rows > 0) {
+            // gathered B: rank s contributed rows [s*shard_rows, (s+1)*shard_rows) as its own column-major slab;
+            // shard_rows is a multiple of w, so a panel never straddles two slabs (wave-uniform arithmetic)
+            const int64_t sh = gk0 / p.shard_rows;
+            Bbase += sh * p.shard_stride;
+            gk0 -= sh * p.shard_rows;
+            bvalid = p.shard_rows;
+        }
         if (!p.b_row_major) {
             // column-major B (the reference's layout): a panel column is `kp` contiguous floats
 #pragma unroll
@@ -137,16 +149,16 @@ __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_kernel(const SpmmParams
                 const int c = tid + kThreads * q;
                 const int j = c / (KP / 4), k = (c % (KP / 4)) * 4;
                 const int col = n0 + j;
-                const float* src = p.B + (gk0 + k) + (int64_t)col * p.ldb;
+                const float* src = Bbase + (gk0 + k) + (int64_t)col * p.ldb;
                 f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (col < N) {
-                    if (p.vec_ok && ks + k + 3 < w && gk0 + k + 3 < p.cols) {
+                    if (p.vec_ok && ks + k + 3 < w && gk0 + k + 3 < bvalid) {
                         const f32x4u t = *reinterpret_cast<const f32x4u*>(src);
                         v = (f32x4){t.x, t.y, t.z, t.w};
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; e++)
-                            if (ks + k + e < w && gk0 + k + e < p.cols) v[e] = src[e];
+                            if (ks + k + e < w && gk0 + k + e < bvalid) v[e] = src[e];
                     }
                 }
                 breg[q] = v;
@@ -159,8 +171,8 @@ __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_kernel(const SpmmParams
                 const int k = c / (TN / 4), j = (c % (TN / 4)) * 4;
                 const int col = n0 + j;
                 f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (ks + k < w && gk0 + k < p.cols) {
-                    const float* src = p.B + (gk0 + k) * p.ldb + col;
+                if (ks + k < w && gk0 + k < bvalid) {
+                    const float* src = Bbase + (gk0 + k) * p.ldb + col;
                     if (p.vec_ok && col + 3 < N) {
                         const f32x4u t = *reinterpret_cast<const f32x4u*>(src);
                         v = (f32x4){t.x, t.y, t.z, t.w};
@@ -289,7 +301,7 @@ struct BlockRowDesc {
 __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_exact_kernel(const BlockRowDesc* rows, const int32_t* jab, const float* A,
                                                                       const float* B, float* C, int64_t ldb, int64_t ldc,
                                                                       int64_t cols, int N, int w, int b_row_major, int c_row_major,
-                                                                      int accumulate) {
+                                                                      int accumulate, int64_t shard_rows, int64_t shard_stride) {
 #pragma clang fp contract(off)
     const BlockRowDesc br = rows[blockIdx.x];
     const int64_t total = (int64_t)br.h * N;
@@ -305,7 +317,11 @@ __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_exact_kernel(const Bloc
                 const int64_t gk = gk0 + k;
                 // the reference reads B out of bounds here when cols % w != 0 (vbr.cpp:351,362) and relies on
                 // the matching A entry being a stored zero; we define that product as 0 * 0.
-                const float bv = gk < cols ? (b_row_major ? B[gk * ldb + j] : B[gk + (int64_t)j * ldb]) : 0.0f;
+                float bv = 0.0f;
+                if (gk < cols) {
+                    if (shard_rows > 0) bv = B[(gk / shard_rows) * shard_stride + (gk % shard_rows) + (int64_t)j * ldb];
+                    else bv = b_row_major ? B[gk * ldb + j] : B[gk + (int64_t)j * ldb];
+                }
                 const float prod = ablk[(int64_t)k * br.h] * bv;
                 c = c + prod;
             }
@@ -348,6 +364,9 @@ struct sparta_vbs {
     int64_t exec_area = 0;
     int64_t a_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t cev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    bool class_timing = false;
+    bool class_ran[4] = {false, false, false, false};
     void* d_B = nullptr;
     size_t d_B_bytes = 0;
     void* d_C = nullptr;
@@ -383,6 +402,9 @@ void destroy_impl(sparta_vbs* v) {
     if (v->d_C) (void)hipFree(v->d_C);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
     if (v->ev1) (void)hipEventDestroy(v->ev1);
+    for (int c = 0; c < 4; c++)
+        for (int e = 0; e < 2; e++)
+            if (v->cev[c][e]) (void)hipEventDestroy(v->cev[c][e]);
     delete v;
 }
 
@@ -529,14 +551,21 @@ int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info) {
     return SPARTA_OK;
 }
 
-int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int32_t n_cols, void* C, int64_t ldc,
-                    int32_t c_layout, int32_t accumulate, int32_t ptr_space, void* stream, int32_t algo, float* dt_ms) {
+}  // extern "C"
+
+namespace {
+
+// shared implementation of sparta_vbs_spmm / sparta_vbs_spmm_gathered
+int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int64_t shard_rows, int64_t shard_stride, int32_t n_cols,
+              void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, int32_t ptr_space, void* stream, int32_t algo,
+              float* dt_ms) {
     using sparta::fail;
     if (!A || !B || !C) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: NULL argument");
     if (n_cols <= 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: n_cols must be > 0");
     if (b_layout != SPARTA_COL_MAJOR && b_layout != SPARTA_ROW_MAJOR) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: bad b_layout");
     if (c_layout != SPARTA_COL_MAJOR && c_layout != SPARTA_ROW_MAJOR) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: bad c_layout");
-    if (ldb < (b_layout == SPARTA_COL_MAJOR ? A->cols : (int64_t)n_cols)) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: ldb too small");
+    if (shard_rows == 0 && ldb < (b_layout == SPARTA_COL_MAJOR ? A->cols : (int64_t)n_cols))
+        return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: ldb too small");
     if (ldc < (c_layout == SPARTA_COL_MAJOR ? A->rows : (int64_t)n_cols)) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: ldc too small");
     if (algo != SPARTA_SPMM_MFMA && algo != SPARTA_SPMM_EXACT) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: bad algo");
     if (ptr_space != SPARTA_PTR_HOST && ptr_space != SPARTA_PTR_DEVICE) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: bad ptr_space");
@@ -562,10 +591,10 @@ int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layou
 
     if (dt_ms) HIP_TRY(hipEventRecord(A->ev0, st));
     if (algo == SPARTA_SPMM_EXACT) {
-        if (A->d_brows) {
+        if (A->n_brows > 0) {
             hipLaunchKernelGGL(vbs_spmm_f32_exact_kernel, dim3((unsigned)A->n_brows), dim3(kThreads), 0, st, A->d_brows, A->d_jab,
                                A->d_A, dB, dC, ldb, ldc, A->cols, (int)n_cols, (int)A->w, (int)(b_layout == SPARTA_ROW_MAJOR),
-                               (int)(c_layout == SPARTA_ROW_MAJOR), (int)accumulate);
+                               (int)(c_layout == SPARTA_ROW_MAJOR), (int)accumulate, shard_rows, shard_stride);
         }
     } else {
         SpmmParams p;
@@ -573,18 +602,23 @@ int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layou
         p.n_ntiles = (n_cols + kTN - 1) / kTN; p.N = n_cols; p.w = (int32_t)A->w;
         p.b_row_major = b_layout == SPARTA_ROW_MAJOR; p.c_row_major = c_layout == SPARTA_ROW_MAJOR;
         p.accumulate = accumulate != 0;
+        p.shard_rows = shard_rows; p.shard_stride = shard_stride;
         const char* nv = std::getenv("SPARTA_NO_VEC");
         p.vec_ok = (nv && nv[0] == '1') ? 0 : 1;
+        const bool prof = A->class_timing;
         for (int c = 3; c >= 0; c--) {              // heavy classes first
+            A->class_ran[c] = false;
             if (A->n_tiles[c] == 0) continue;
             if (A->n_tiles[c] * (int64_t)p.n_ntiles > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: grid too large");
             p.tiles = A->d_tiles[c]; p.n_tiles = (int32_t)A->n_tiles[c];
+            if (prof) HIP_TRY(hipEventRecord(A->cev[c][0], st));
             switch (c) {
                 case 0: launch_class<16, 1, 4, 1, 2>(p, st); break;   //  16 x 128
                 case 1: launch_class<32, 1, 4, 1, 1>(p, st); break;   //  32 x 128
                 case 2: launch_class<32, 2, 2, 1, 2>(p, st); break;   //  64 x 128
                 default: launch_class<32, 2, 2, 2, 2>(p, st); break;  // 128 x 128
             }
+            if (prof) { HIP_TRY(hipEventRecord(A->cev[c][1], st)); A->class_ran[c] = true; }
         }
     }
     HIP_TRY(hipGetLastError());
@@ -596,6 +630,52 @@ int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layou
     if (ptr_space == SPARTA_PTR_HOST) {
         HIP_TRY(hipMemcpyAsync(C, A->d_C, c_elems * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SPARTA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int32_t n_cols, void* C, int64_t ldc,
+                    int32_t c_layout, int32_t accumulate, int32_t ptr_space, void* stream, int32_t algo, float* dt_ms) {
+    return spmm_impl(A, B, ldb, b_layout, 0, 0, n_cols, C, ldc, c_layout, accumulate, ptr_space, stream, algo, dt_ms);
+}
+
+int sparta_vbs_spmm_gathered(sparta_vbs_t* A, const void* B_gathered, int64_t shard_rows, int64_t shard_stride, int32_t n_cols,
+                             void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, void* stream, int32_t algo, float* dt_ms) {
+    using sparta::fail;
+    if (!A) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: NULL handle");
+    if (shard_rows <= 0 || shard_rows % A->w != 0)
+        return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: shard_rows must be a positive multiple of block_col_size");
+    if (shard_stride < shard_rows * (int64_t)n_cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: shard_stride too small");
+    if (A->cols % shard_rows != 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: cols must be n_shards * shard_rows");
+    return spmm_impl(A, B_gathered, shard_rows, SPARTA_COL_MAJOR, shard_rows, shard_stride, n_cols, C, ldc, c_layout, accumulate,
+                     SPARTA_PTR_DEVICE, stream, algo, dt_ms);
+}
+
+int sparta_vbs_set_class_timing(sparta_vbs_t* A, int32_t enable) {
+    using sparta::fail;
+    if (!A) return fail(SPARTA_ERR_INVALID, "sparta_vbs_set_class_timing: NULL handle");
+    DeviceGuard guard(A->device);
+    if (enable && !A->cev[0][0]) {
+        for (int c = 0; c < 4; c++)
+            for (int e = 0; e < 2; e++) HIP_TRY(hipEventCreate(&A->cev[c][e]));
+    }
+    A->class_timing = enable != 0;
+    return SPARTA_OK;
+}
+
+int sparta_vbs_class_times(sparta_vbs_t* A, float* ms_out) {
+    using sparta::fail;
+    if (!A || !ms_out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_class_times: NULL argument");
+    DeviceGuard guard(A->device);
+    for (int c = 0; c < 4; c++) {
+        ms_out[c] = 0.0f;
+        if (!A->class_timing || !A->class_ran[c]) continue;
+        HIP_TRY(hipEventSynchronize(A->cev[c][1]));
+        HIP_TRY(hipEventElapsedTime(&ms_out[c], A->cev[c][0], A->cev[c][1]));
     }
     return SPARTA_OK;
 }

@@ -76,6 +76,32 @@ class DeviceVBS:
                                   C.byref(dt) if timed else None))
         return dt.value if timed else None
 
+    def spmm_gathered(self, B_gathered, shard_rows, C_out, n_cols, accumulate=False, algo=_lib.SPMM_MFMA,
+                      c_layout=_lib.COL_MAJOR, shard_stride=None, timed=False, stream=None):
+        """Multi-GPU entry: B_gathered is the all-gather result (n_shards column-major slabs of shard_rows x n_cols)."""
+        import torch
+        if not (B_gathered.is_cuda and C_out.is_cuda and B_gathered.dtype == torch.float32 and C_out.dtype == torch.float32):
+            raise ValueError("B_gathered and C must be float32 tensors on the GPU")
+        shard_stride = shard_rows * n_cols if shard_stride is None else shard_stride
+        if B_gathered.numel() < (self.cols // shard_rows) * shard_stride:
+            raise ValueError("B_gathered too small")
+        ldc = self.rows if c_layout == _lib.COL_MAJOR else n_cols
+        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        dt = C.c_float(0)
+        check(lib.sparta_vbs_spmm_gathered(self.h, C.c_void_p(B_gathered.data_ptr()), int(shard_rows), int(shard_stride), int(n_cols),
+                                           C.c_void_p(C_out.data_ptr()), int(ldc), c_layout, int(bool(accumulate)), C.c_void_p(st),
+                                           int(algo), C.byref(dt) if timed else None))
+        return dt.value if timed else None
+
+    def set_class_timing(self, enable=True):
+        check(lib.sparta_vbs_set_class_timing(self.h, int(bool(enable))))
+
+    def class_times(self):
+        """ms of the last spmm per tile class {16, 32, 64, 128} (needs set_class_timing(True))"""
+        a = np.zeros(4, np.float32)
+        check(lib.sparta_vbs_class_times(self.h, a.ctypes.data_as(_f32p)))
+        return {16: float(a[0]), 32: float(a[1]), 64: float(a[2]), 128: float(a[3])}
+
     def close(self):
         if self.h:
             lib.sparta_vbs_destroy(self.h)

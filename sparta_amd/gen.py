@@ -106,3 +106,35 @@ def dense_rhs(n_rows, n_cols, seed=7, lo=-0.5, hi=0.5):
     """Dense operand B, column-major flat (ld = n_rows), U(lo, hi)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     return rng.uniform(lo, hi, size=n_rows * n_cols).astype(np.float32)
+
+
+def fem3d_slab(nx, ny, nz_per_rank, rank, world, dof=3, pad_to=64, seed=2, pattern_only=False):
+    """Row slab `rank` of the fem3d matrix of an nx x ny x (world*nz_per_rank) mesh, for row-partitioned multi-GPU
+    runs.  Rows are the slab's own unknowns (local numbering); columns are GLOBAL in the padded numbering
+    col = owner_rank * n_pad + local_index, n_pad = ceil(n_local / pad_to) * pad_to, so that every rank's shard of B
+    has n_pad rows (a multiple of the column-block width: sparta_vbs_spmm_gathered) and the slab couples to its
+    z-neighbours' shards through the 27-point stencil.  Returns (CSR, n_local, n_pad)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 1000 * rank))
+    n_local = nx * ny * nz_per_rank * dof
+    n_pad = -(-n_local // pad_to) * pad_to
+    nz_tot = nz_per_rank * world
+    x, y, z = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz_per_rank), indexing="ij")
+    x, y, z = x.ravel(), y.ravel(), z.ravel()
+    node_local = x + nx * (y + ny * z)
+    zg = z + rank * nz_per_rank
+    rr, cc = [], []
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                ok = (x + dx >= 0) & (x + dx < nx) & (y + dy >= 0) & (y + dy < ny) & (zg + dz >= 0) & (zg + dz < nz_tot)
+                a = node_local[ok]
+                z2 = zg[ok] + dz
+                owner = z2 // nz_per_rank
+                b_local = (x[ok] + dx) + nx * ((y[ok] + dy) + ny * (z2 % nz_per_rank))
+                for di in range(dof):
+                    for dj in range(dof):
+                        rr.append(a * dof + di)
+                        cc.append(owner * n_pad + b_local * dof + dj)
+    r, c = np.concatenate(rr), np.concatenate(cc)
+    v = None if pattern_only else rng.uniform(-1.0, 1.0, size=len(r)).astype(np.float32)
+    return _csr_from_coo(n_local, world * n_pad, r, c, v), n_local, n_pad
