@@ -139,26 +139,97 @@ struct Pattern {
     }
 };
 
-struct Ctx {
+// Shared counters / configuration of one GetGrouping run.
+struct CtxBase {
     const CsrView& a;
     const sparta_reorder_cfg& cfg;
-    RowBlocks rb;
     int sim;
     int64_t w;
     int64_t comparisons = 0, merges = 0;
     float total_merge_tau = 0, total_row_distance = 0;   // float accumulators as in blocking.cpp:162-163
     float t_cmp = 0, t_merge = 0;
-
-    Ctx(const CsrView& a_, const sparta_reorder_cfg& c) : a(a_), cfg(c) {
+    CtxBase(const CsrView& a_, const sparta_reorder_cfg& c) : a(a_), cfg(c) {
         w = c.col_block_size;
         sim = (c.sim_measure & 1) ? SPARTA_SIM_JACCARD : SPARTA_SIM_HAMMING;   // 2,3 are the 'OPENMP' twins of 0,1
-        rb = build_row_blocks(a, w);
-    }
-    inline float dist(const Pattern& p, int64_t gsize, int64_t j) const {
-        int64_t inter = intersect_count(p.blks.data(), (int64_t)p.blks.size(), rb.row(j), rb.n(j));
-        return distance_from_counts(sim, (int64_t)p.cols.size(), (int64_t)p.blks.size(), gsize, a.nnz_of(j), rb.n(j), 1, inter);
     }
 };
+
+// FAST policy -- valid when every row's columns are strictly ascending (the normal case): rows and the
+// cluster pattern are compared as lists of distinct column-block ids, the merge uses the closed form above.
+struct Ctx : CtxBase {
+    RowBlocks rb;
+    Pattern pat;
+    Ctx(const CsrView& a_, const sparta_reorder_cfg& c) : CtxBase(a_, c) { rb = build_row_blocks(a, w); }
+    inline void assign(int64_t i) { pat.assign(a.row(i), a.nnz_of(i), w); }
+    inline void merge(int64_t j) { pat.merge(a.row(j), a.nnz_of(j), w); }
+    inline float dist(int64_t gsize, int64_t j) const {
+        int64_t inter = intersect_count(pat.blks.data(), (int64_t)pat.blks.size(), rb.row(j), rb.n(j));
+        return distance_from_counts(sim, (int64_t)pat.cols.size(), (int64_t)pat.blks.size(), gsize, a.nnz_of(j), rb.n(j), 1, inter);
+    }
+};
+
+// LITERAL policy -- used when some row is NOT strictly ascending.  The reference never sorts or checks
+// the columns of a row (its readers append them in file order, csr.cpp:262; two of its own data/minitest
+// matrices have out-of-order rows), and then its two-pointer distance walk and its binary-search merge
+// do whatever they do on unsorted data.  To return the same grouping on the same input we run the same
+// walks on the column-level data: a run-compressed two-pointer merge-count (blocking.cpp:951-991) and the
+// lower_bound-driven copy loop (utilities.cpp:152-171).  std::lower_bound is the same library routine the
+// reference calls, so even its probes into unsorted data coincide.
+struct LiteralCtx : CtxBase {
+    std::vector<int64_t> pat, tmp;
+    LiteralCtx(const CsrView& a_, const sparta_reorder_cfg& c) : CtxBase(a_, c) {}
+    inline void assign(int64_t i) { pat.assign(a.row(i), a.row(i) + a.nnz_of(i)); }
+    inline void merge(int64_t j) {
+        const int32_t* b = a.row(j);
+        const int64_t nb = a.nnz_of(j);
+        tmp.clear();
+        auto i = pat.begin();
+        int64_t q = 0;
+        while (q < nb) {
+            const int64_t bv = b[q];
+            auto ni = std::lower_bound(i, pat.end(), bv);
+            if (ni == pat.end()) break;              // nothing of the pattern from `i` on is kept
+            tmp.insert(tmp.end(), i, ni);
+            tmp.push_back(bv);
+            if (*ni == bv) ++ni;
+            i = ni;
+            q++;
+        }
+        for (; q < nb; q++) tmp.push_back(b[q]);
+        pat.swap(tmp);
+    }
+    inline float dist(int64_t gsize, int64_t j) const {
+        const int64_t* ra = pat.data();
+        const int32_t* rb_ = a.row(j);
+        const int64_t na = (int64_t)pat.size(), nb = a.nnz_of(j);
+        const int64_t ga = gsize, gb = 1;
+        if (na == 0 && nb == 0) return 0.0f;
+        if (na == 0 || nb == 0) return sim == SPARTA_SIM_JACCARD ? 1.0f : (float)std::max(na * ga, nb * gb);
+        int64_t i = 0, q = 0, count = 0, blocks_a = 0, blocks_b = 0;
+        auto skip_a = [&](int64_t pos) { while (i < na && ra[i] / w == pos) i++; };
+        auto skip_b = [&](int64_t pos) { while (q < nb && (int64_t)rb_[q] / w == pos) q++; };
+        while (i < na && q < nb) {
+            const int64_t pa = ra[i] / w, pb = (int64_t)rb_[q] / w;
+            if (pa < pb) { count += gb; blocks_a++; skip_a(pa); }
+            else if (pa > pb) { count += ga; blocks_b++; skip_b(pb); }
+            else { blocks_a++; blocks_b++; skip_a(pa); skip_b(pb); }
+        }
+        while (i < na) { const int64_t pa = ra[i] / w; count += gb; blocks_a++; skip_a(pa); }
+        while (q < nb) { const int64_t pb = (int64_t)rb_[q] / w; count += ga; blocks_b++; skip_b(pb); }
+        if (sim == SPARTA_SIM_JACCARD) return (float)((2.0 * (double)count) / (double)(blocks_a * ga + blocks_b * gb + count));
+        return (float)count;
+    }
+};
+
+bool all_rows_strictly_ascending(const CsrView& a) {
+    for (int64_t i = 0; i < a.rows; i++) {
+        const int32_t* r = a.row(i);
+        const int64_t n = a.nnz_of(i);
+        for (int64_t k = 1; k < n; k++)
+            if (r[k] <= r[k - 1]) return false;
+    }
+    return true;
+}
 
 // the reference's `float distances[cmat.rows] = {-1};` (blocking.cpp:159,255,436): a VLA with a
 // one-element initialiser -> element 0 is -1, every other element is 0.
@@ -172,7 +243,8 @@ std::vector<float> make_distances(int64_t rows) {
 // :245-338).  Both visit the still-ungrouped rows after the seed in ascending order and differ only in
 // bookkeeping that cannot change the result: CLOCKED also runs its prune test on already-grouped rows,
 // whose `distances` entry is never read again.
-void clocked(Ctx& c, int64_t* grouping) {
+template <class C>
+void clocked(C& c, int64_t* grouping) {
     const int64_t rows = c.a.rows;
     const float tau = c.cfg.tau;
     std::fill(grouping, grouping + rows, (int64_t)-1);
@@ -180,13 +252,12 @@ void clocked(Ctx& c, int64_t* grouping) {
     std::vector<int64_t> alive((size_t)rows), next;
     std::iota(alive.begin(), alive.end(), (int64_t)0);
     next.reserve((size_t)rows);
-    Pattern pat;
 
     size_t head = 0;   // alive[head] is the next seed
     while (head < alive.size()) {
         const int64_t i = alive[head];
         grouping[i] = i;                                           // :172 group id = seed row
-        pat.assign(c.a.row(i), c.a.nnz_of(i), c.w);                // :173
+        c.assign(i);                // :173
         int64_t gsize = 1;
         const float di = dist[(size_t)i];
         auto t0 = clk::now();
@@ -201,7 +272,7 @@ void clocked(Ctx& c, int64_t* grouping) {
                 continue;
             }
             c.comparisons++;
-            const float d = c.dist(pat, gsize, j);
+            const float d = c.dist(gsize, j);
             dj = d;
             if (d <= tau) {                                        // :207 (<=)
                 c.total_merge_tau += d;
@@ -210,7 +281,7 @@ void clocked(Ctx& c, int64_t* grouping) {
                 grouping[j] = i;
                 if (c.cfg.use_pattern) {
                     auto tm = clk::now();
-                    pat.merge(c.a.row(j), c.a.nnz_of(j), c.w);     // :217
+                    c.merge(j);     // :217
                     c.t_merge += us_since(tm);
                 }
                 if (c.cfg.use_groups) gsize++;                     // :221-224
@@ -227,27 +298,27 @@ void clocked(Ctx& c, int64_t* grouping) {
 
 // Algorithm 0 (IterativeBlockingPattern, blocking.cpp:89-154): no prune, strict `<`, and -- because the
 // `if (use_pattern)` there guards only a timer macro -- the pattern merge ALWAYS runs (:128-132).
-void plain(Ctx& c, int64_t* grouping) {
+template <class C>
+void plain(C& c, int64_t* grouping) {
     const int64_t rows = c.a.rows;
     const float tau = c.cfg.tau;
     std::fill(grouping, grouping + rows, (int64_t)-1);
     std::vector<int64_t> alive((size_t)rows), next;
     std::iota(alive.begin(), alive.end(), (int64_t)0);
-    Pattern pat;
     while (!alive.empty()) {
         const int64_t i = alive[0];
         grouping[i] = i;
-        pat.assign(c.a.row(i), c.a.nnz_of(i), c.w);
+        c.assign(i);
         int64_t gsize = 1;
         next.clear();
         for (size_t q = 1; q < alive.size(); q++) {
             const int64_t j = alive[q];
             c.comparisons++;
-            const float d = c.dist(pat, gsize, j);
+            const float d = c.dist(gsize, j);
             if (d < tau) {                                         // :124 (<)
                 c.merges++;
                 grouping[j] = i;
-                pat.merge(c.a.row(j), c.a.nnz_of(j), c.w);
+                c.merge(j);
                 if (c.cfg.use_groups) gsize++;
             } else {
                 next.push_back(j);
@@ -270,13 +341,13 @@ void plain(Ctx& c, int64_t* grouping) {
 #if !defined(__GLIBCXX__)
 #error "IterativeBlockingKeeper parity relies on libstdc++'s std::set iterator behaviour"
 #endif
-void keeper(Ctx& c, int64_t* grouping) {
+template <class C>
+void keeper(C& c, int64_t* grouping) {
     const int64_t rows = c.a.rows;
     const float tau = c.cfg.tau;
     const int64_t max_h = c.cfg.row_block_size;
     std::fill(grouping, grouping + rows, (int64_t)-1);
     std::vector<float> dist = make_distances(rows);
-    Pattern pat;
     std::vector<int64_t> merged;
 
     for (int64_t i = 0; i < rows; i++) {
@@ -286,7 +357,7 @@ void keeper(Ctx& c, int64_t* grouping) {
         const int64_t group_number = i + rows;                     // :450
         grouping[i] = group_number;
         merged.push_back(i);
-        pat.assign(c.a.row(i), c.a.nnz_of(i), c.w);
+        c.assign(i);
         int64_t gsize = 1;
         const float di = dist[(size_t)i];
         auto t0 = clk::now();
@@ -296,7 +367,7 @@ void keeper(Ctx& c, int64_t* grouping) {
             if (di != -1.0f && dj != -1.0f && std::fabs(di - dj) > tau) { dj = -1.0f; continue; }   // :469-473
             if (grouping[j] != -1) continue;
             c.comparisons++;
-            const float d = c.dist(pat, gsize, j);                 // :480 weight is ALWAYS the cluster size
+            const float d = c.dist(gsize, j);                 // :480 weight is ALWAYS the cluster size
             dj = d;
             if (d <= tau) {
                 c.total_merge_tau += d;
@@ -306,7 +377,7 @@ void keeper(Ctx& c, int64_t* grouping) {
                 merged.push_back(j);
                 if (c.cfg.use_pattern) {
                     auto tm = clk::now();
-                    pat.merge(c.a.row(j), c.a.nnz_of(j), c.w);
+                    c.merge(j);
                     c.t_merge += us_since(tm);
                 }
                 gsize++;                                           // :501 unconditional
@@ -399,34 +470,31 @@ int reorder(const CsrView& a, const sparta_reorder_cfg& cfg, int64_t* grouping_o
     if (needs_rbs && cfg.row_block_size <= 0) return fail(SPARTA_ERR_INVALID, "sparta_reorder: row_block_size must be > 0");
     const bool iterative = cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE || cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_CLOCKED ||
                            cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_QUEUE || cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_MAX_SIZE;
-    if (int rc = validate_csr(a, iterative)) return rc;
+    if (int rc = validate_csr(a, false)) return rc;
 
     auto t0 = clk::now();
     sparta_reorder_stats st{};
-    switch (cfg.blocking_algo) {
-        case SPARTA_BLOCKING_ITERATIVE_CLOCKED:
-        case SPARTA_BLOCKING_ITERATIVE_QUEUE: {
-            Ctx c(a, cfg);
-            clocked(c, grouping_out);
-            st.comparison_counter = c.comparisons; st.merge_counter = c.merges;
+    const bool fast = iterative && all_rows_strictly_ascending(a);
+    auto run = [&](auto& c) {
+        switch (cfg.blocking_algo) {
+            case SPARTA_BLOCKING_ITERATIVE_MAX_SIZE: keeper(c, grouping_out); break;
+            case SPARTA_BLOCKING_ITERATIVE: plain(c, grouping_out); break;
+            default: clocked(c, grouping_out); break;
+        }
+        st.comparison_counter = c.comparisons; st.merge_counter = c.merges;
+        if (cfg.blocking_algo != SPARTA_BLOCKING_ITERATIVE) {
             st.average_merge_tau = c.total_merge_tau / (float)c.merges;          // :239-240 (NaN when no merge, as in the reference)
             st.average_row_distance = c.total_row_distance / (float)c.merges;
-            st.timer_comparisons = c.t_cmp; st.timer_merges = c.t_merge;
-            break;
         }
-        case SPARTA_BLOCKING_ITERATIVE_MAX_SIZE: {
-            Ctx c(a, cfg);
-            keeper(c, grouping_out);
-            st.comparison_counter = c.comparisons; st.merge_counter = c.merges;
-            st.average_merge_tau = c.total_merge_tau / (float)c.merges;
-            st.average_row_distance = c.total_row_distance / (float)c.merges;
-            st.timer_comparisons = c.t_cmp; st.timer_merges = c.t_merge;
-            break;
-        }
+        st.timer_comparisons = c.t_cmp; st.timer_merges = c.t_merge;
+    };
+    switch (cfg.blocking_algo) {
+        case SPARTA_BLOCKING_ITERATIVE_CLOCKED:
+        case SPARTA_BLOCKING_ITERATIVE_QUEUE:
+        case SPARTA_BLOCKING_ITERATIVE_MAX_SIZE:
         case SPARTA_BLOCKING_ITERATIVE: {
-            Ctx c(a, cfg);
-            plain(c, grouping_out);
-            st.comparison_counter = c.comparisons; st.merge_counter = c.merges;
+            if (fast) { Ctx c(a, cfg); run(c); }
+            else { LiteralCtx c(a, cfg); run(c); }
             break;
         }
         case SPARTA_BLOCKING_FIXED_SIZE:                                         // :554-562

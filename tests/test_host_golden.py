@@ -1,0 +1,74 @@
+"""CPU: the product's host-side C++ (reorder engine + VBS builder, through the C-ABI / sparta_amd mirror classes)
+against the golden vectors from the compiled reference -- including algorithm 5 (IterativeBlockingKeeper) and 6."""
+import numpy as np
+import pytest
+
+import sparta_amd as sa
+import _util as U
+
+
+def test_similarity_and_merge_kat():
+    A, B = [1, 2, 5, 10, 12, 20], [0, 2, 4, 10, 16]
+    assert sa.row_distance(0, A, 1, B, 1, 1) == 7.0
+    assert sa.row_distance(1, A, 1, B, 1, 1) == pytest.approx(0.777778, abs=1e-6)
+    assert sa.row_distance(0, A, 1, B, 1, 3) == 3.0 and sa.row_distance(1, A, 1, B, 1, 4) == 0.5
+    assert sa.merge_rows([1, 2, 3], [5]).tolist() == [5]
+    assert sa.merge_rows([1, 4, 9], [2, 4, 7]).tolist() == [1, 2, 4, 7]
+    assert sa.merge_rows([1, 4, 9], [2, 4, 7, 12]).tolist() == [1, 2, 4, 7, 12]
+
+
+def test_appendix_b_kat():
+    k = U.load("kat9.npz")
+    m = sa.CSR(9, 9, k["rowptr"], k["colidx"], k["vals"])
+    e = sa.BlockingEngine(tau=0.6, col_block_size=3, row_block_size=3)
+    g = e.GetGrouping(m)
+    assert g.tolist() == [0, 1, 1, 1, 0, 5, 0, 0, 8]
+    assert (e.comparison_counter, e.merge_counter) == (13, 5)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, 3)
+    assert (v.rows, v.cols, v.block_rows, v.block_cols, v.nztot) == (9, 9, 4, 3, 33)
+    assert v.row_part.tolist() == [0, 4, 7, 8, 9] and v.nzcount.tolist() == [0, 3, 1, 1] and v.jab.tolist() == [0, 1, 2, 2, 0]
+    assert np.array_equal(v.mab, k["mab"])
+    e.CollectBlockingInfo(m)
+    assert (e.VBR_nzcount, e.VBR_nzblocks_count, e.VBR_longest_row) == (33, 5, 3)
+    assert e.VBR_average_height == pytest.approx(2.2)
+    assert sa.BlockingEngine(tau=0.6, col_block_size=3, row_block_size=3, force_fixed_size=True).GetGrouping(m).tolist() == \
+        [0, 1, 1, 2, 0, 2, 0, 1, 2]
+    assert sa.BlockingEngine(tau=0.6, col_block_size=3, row_block_size=3, force_fixed_size=True, blocking_algo=5).GetGrouping(m).tolist() == \
+        [0, 1, 1, 1, 0, 2, 0, 2, 2] == k["g_a5_B3_F1"].tolist()
+
+
+def test_primitives_golden():
+    p = U.load("prims.npz")
+    for t in range(int(p["n"])):
+        A, B = p["%d/A" % t], p["%d/B" % t]
+        ga, gb, bs = map(int, p["%d/par" % t])
+        assert np.array_equal(sa.merge_rows(A, B), p["%d/merged" % t]), t
+        d = p["%d/dist" % t]
+        assert np.float32(sa.row_distance(0, A, ga, B, gb, bs)) == d[0] and np.float32(sa.row_distance(1, A, ga, B, gb, bs)) == d[1], t
+    for t in range(int(p["nperm"])):
+        g = p["perm%d/g" % t]
+        assert np.array_equal(sa.get_permutation(g), p["perm%d/perm" % t])
+        assert np.array_equal(sa.get_partition(g), p["perm%d/part" % t])
+        assert np.array_equal(sa.get_fixed_size_grouping(g, 5), p["perm%d/fixed5" % t])
+
+
+@pytest.mark.parametrize("key,name,cfg", U.case_list(), ids=[c[0] for c in U.case_list()])
+def test_case_golden(key, name, cfg):
+    m = U.matrices()[name]
+    f = U.case_fields(key)
+    w, rbs, ff = cfg["w"], cfg.get("rbs", 1), cfg.get("ff", False)
+    e = sa.BlockingEngine(tau=cfg["tau"], col_block_size=w, row_block_size=rbs, use_groups=cfg.get("use_groups", False),
+                          use_pattern=cfg.get("use_pattern", True), force_fixed_size=ff, blocking_algo=cfg["algo"],
+                          sim_measure=cfg.get("sim", 1))
+    g = e.GetGrouping(m)
+    assert np.array_equal(g, f["grouping"]), "grouping differs from the reference"
+    if cfg["algo"] in (0, 3, 4, 5):
+        assert [e.comparison_counter, e.merge_counter] == f["counters"].tolist()
+    assert np.array_equal(sa.get_permutation(g), f["perm"])
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w, rbs, ff)
+    assert [v.rows, v.cols, v.block_rows, v.block_cols, v.nztot] == f["dims"].tolist()
+    assert np.array_equal(v.row_part, f["row_part"]) and np.array_equal(v.nzcount, f["nzcount"]) and np.array_equal(v.jab, f["jab"])
+    assert U.sha(v.mab) == str(f["mab_sha"]), "mab differs from the reference"
+    e.CollectBlockingInfo(m)
+    assert [e.VBR_nzcount, e.VBR_nzblocks_count, e.VBR_longest_row] == f["info"].tolist()
+    assert np.float32(e.VBR_average_height) == f["avg_height"]

@@ -1,0 +1,281 @@
+"""GPU (-m gpu): parity of the hand-written HIP SpMM (through the C-ABI) with the oracle and the golden vectors.
+
+Bars: SPARTA_SPMM_EXACT -> bit-identical to the reference's VBR::multiply (golden C);
+      SPARTA_SPMM_MFMA  -> |C - C_oracle| <= 1e-5 * sum_k |a||b| per element (fp32; the MFMA sums k in another order
+                           and fuses multiply-add) -- the tolerance BASELINE.md section 3 states."""
+import numpy as np
+import pytest
+
+import sparta_amd as sa
+from oracle import oracle as O
+import _util as U
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU test on a box without a GPU"
+    return torch
+
+
+def _check(C, Co, bound, what=""):
+    err = np.abs(C - Co)
+    bad = err > TOL * bound + 1e-30
+    assert not bad.any(), "%s: %d elements outside tolerance, max err %.3e" % (what, int(bad.sum()), float(err.max()))
+
+
+def _oracle_c(v, B, n, C_in=None):
+    return O.vbr_multiply(v.rows, v.cols, v.block_col_size, v.row_part, v.nzcount, v.jab, v.mab, B, n, C_in)
+
+
+def test_native_library_is_loaded_and_sees_the_gpu():
+    assert sa.device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libsparta_amd.so" in maps
+
+
+def test_appendix_b_kat_on_gpu():
+    k = U.load("kat9.npz")
+    v = sa.VBR.from_arrays(9, 9, 3, k["row_part"], k["nzcount"], k["jab"], k["mab"])
+    B = np.arange(1, 19, dtype=np.float32)
+    for algo in (sa.SPMM_MFMA, sa.SPMM_EXACT):
+        C = np.zeros(18, np.float32)
+        v.multiply(B, 2, C, algo=algo)            # VBR::multiply(B, B_cols, C): C += A*B, host buffers
+        assert C.tolist() == [0, 0, 0, 0, 126, 22, 102, 14, 10, 0, 0, 0, 0, 306, 49, 219, 32, 55]   # small integers: exact either way
+
+
+@pytest.mark.parametrize("key,name,cfg", U.case_list(), ids=[c[0] for c in U.case_list()])
+def test_golden_cases(key, name, cfg):
+    m = U.matrices()[name]
+    f = U.case_fields(key)
+    w, rbs, ff = cfg["w"], cfg.get("rbs", 1), cfg.get("ff", False)
+    v = sa.VBR().fill_from_CSR_inplace(m, f["grouping"].astype(np.int64), w, rbs, ff)
+    assert U.sha(v.mab) == str(f["mab_sha"])
+    n = f["C"].size // v.rows
+    B = sa.gen.dense_rhs(v.cols, n, seed=77)
+    d = v.to_device(0)
+    Cx = np.zeros(v.rows * n, np.float32)
+    d.spmm_host(B, n, Cx, accumulate=True, algo=sa.SPMM_EXACT)
+    assert np.array_equal(Cx, f["C"]), "exact-order kernel is not bit-identical to the reference's VBR::multiply"
+    Cm = np.zeros(v.rows * n, np.float32)
+    d.spmm_host(B, n, Cm, accumulate=True, algo=sa.SPMM_MFMA)
+    _check(Cm, f["C"], U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n), key)
+
+
+SHAPES = [
+    # rows, cols, nnz, w, blocking, N   -- ragged everything: w not a multiple of 4, cols % w != 0, N % 32 != 0, N > 128
+    (257, 391, 5000, 13, ("tau", 0.6), 37),
+    (1000, 777, 30000, 48, ("tau", 0.7), 100),
+    (1000, 777, 30000, 100, ("fixed", 200), 33),
+    (640, 640, 20000, 64, ("fixed", 64), 128),
+    (640, 640, 20000, 64, ("fixed", 128), 300),
+    (500, 2000, 9000, 200, ("tau", 0.9), 64),
+    (333, 65, 3000, 1, ("tau", 0.5), 5),
+    (70, 70, 70 * 70 // 2, 16, ("fixed", 70), 129),
+    (2048, 2048, 40000, 32, ("keeper", 16), 64),
+]
+
+
+@pytest.mark.parametrize("rows,cols,nnz,w,blk,n", SHAPES)
+def test_ragged_shapes_vs_oracle(rows, cols, nnz, w, blk, n):
+    m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + cols + w)
+    if blk[0] == "tau":
+        g = sa.BlockingEngine(tau=blk[1], col_block_size=w).GetGrouping(m)
+    elif blk[0] == "keeper":
+        g = sa.BlockingEngine(tau=0.5, col_block_size=w, row_block_size=blk[1], blocking_algo=5).GetGrouping(m)
+    else:
+        g = np.arange(rows) // blk[1]
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=3)
+    Co = _oracle_c(v, B, n)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+    d = v.to_device(0)
+    for algo in (sa.SPMM_MFMA, sa.SPMM_EXACT):
+        C = np.zeros(v.rows * n, np.float32)
+        d.spmm_host(B, n, C, accumulate=True, algo=algo)
+        if algo == sa.SPMM_EXACT:
+            assert np.array_equal(C, Co)
+        else:
+            _check(C, Co, bound, "mfma")
+    # independent check through the permutation: C_vbs[r] == C_csr[perm[r]]  
+    perm = sa.get_permutation(g)
+    Cc = O.csr_multiply(m.rows, m.rowptr, m.colidx, m.vals, B, m.cols, n).reshape(n, m.rows)
+    C = np.zeros(v.rows * n, np.float32)
+    d.spmm_host(B, n, C, accumulate=False)
+    _check(C.reshape(n, v.rows), Cc[:, perm], bound.reshape(n, v.rows), "vs CSR through perm")
+
+
+def test_accumulate_overwrite_layouts_and_pointer_spaces():
+    torch = _torch()
+    m = sa.gen.uniform_random(900, 700, 25000, seed=5)
+    w, n = 40, 72
+    g = sa.BlockingEngine(tau=0.6, col_block_size=w).GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=8)
+    C0 = sa.gen.dense_rhs(v.rows, n, seed=9)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n) + np.abs(C0)
+    Co_acc = _oracle_c(v, B, n, C0)            # reference semantics: C += A*B
+    Co = _oracle_c(v, B, n)
+    d = v.to_device(0)
+    C = C0.copy(); d.spmm_host(B, n, C, accumulate=True); _check(C, Co_acc, bound, "host accumulate")
+    C = C0.copy(); d.spmm_host(B, n, C, accumulate=True, algo=sa.SPMM_EXACT); assert np.array_equal(C, Co_acc)
+    C = np.full(v.rows * n, 3.25, np.float32); d.spmm_host(B, n, C, accumulate=False); _check(C, Co, bound, "host overwrite")
+    # device pointers, all four layout combinations, both kernels
+    Bcm = torch.from_numpy(B).cuda()
+    Brm = torch.from_numpy(np.ascontiguousarray(B.reshape(n, v.cols).T).reshape(-1)).cuda()
+    for bl, Bt in ((sa.COL_MAJOR, Bcm), (sa.ROW_MAJOR, Brm)):
+        for cl in (sa.COL_MAJOR, sa.ROW_MAJOR):
+            for algo in (sa.SPMM_MFMA, sa.SPMM_EXACT):
+                Ct = torch.full((v.rows * n,), -1.0, dtype=torch.float32, device="cuda")
+                d.spmm(Bt, Ct, n, accumulate=False, algo=algo, b_layout=bl, c_layout=cl)
+                torch.cuda.synchronize()
+                got = Ct.cpu().numpy()
+                if cl == sa.ROW_MAJOR:
+                    got = np.ascontiguousarray(got.reshape(v.rows, n).T).reshape(-1)
+                if algo == sa.SPMM_EXACT:
+                    assert np.array_equal(got, Co), (bl, cl)
+                else:
+                    _check(got, Co, bound, "layouts %d %d" % (bl, cl))
+    # leading dimensions larger than the matrix
+    ldb, ldc = v.cols + 5, v.rows + 3
+    Bp = np.zeros(ldb * n, np.float32); Bp.reshape(n, ldb)[:, :v.cols] = B.reshape(n, v.cols)
+    Bt = torch.from_numpy(Bp).cuda()
+    Ct = torch.zeros(ldc * n, dtype=torch.float32, device="cuda")
+    dt = d.spmm(Bt, Ct, n, accumulate=False, ldb=ldb, ldc=ldc, timed=True)
+    assert dt > 0
+    _check(Ct.cpu().numpy().reshape(n, ldc)[:, :v.rows].reshape(-1), Co, bound, "padded ld")
+    # a non-default stream
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        Ct2 = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
+        d.spmm(Bcm, Ct2, n, accumulate=False)
+    s.synchronize()
+    _check(Ct2.cpu().numpy(), Co, bound, "side stream")
+
+
+def test_special_block_rows():
+    """empty block-rows (zero blocks), 1-row clusters, one huge block-row, an all-empty matrix row range"""
+    torch = _torch()
+    rows, cols, w, n = 300, 256, 32, 48
+    rng = np.random.Generator(np.random.PCG64(3))
+    dense = (rng.random((rows, cols)) < 0.08).astype(np.float32) * rng.uniform(-1, 1, (rows, cols)).astype(np.float32)
+    dense[10:60] = 0           # 50 empty rows -> cluster into one block-row with nzcount = 0
+    dense[200] = 0
+    import scipy.sparse as sp
+    m = sa.CSR.from_scipy(sp.csr_matrix(dense))
+    for eng in (sa.BlockingEngine(tau=0.4, col_block_size=w), sa.BlockingEngine(tau=1.0, col_block_size=w),
+                sa.BlockingEngine(tau=0.0, col_block_size=w)):
+        g = eng.GetGrouping(m)
+        v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+        assert (v.nzcount == 0).any()
+        B = sa.gen.dense_rhs(v.cols, n, seed=2)
+        Co = _oracle_c(v, B, n)
+        bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+        d = v.to_device(0)
+        C = np.full(v.rows * n, 9.0, np.float32)
+        d.spmm_host(B, n, C, accumulate=False)      # overwrite must zero the rows of empty block-rows
+        _check(C, Co, bound)
+        Cx = np.zeros(v.rows * n, np.float32)
+        d.spmm_host(B, n, Cx, accumulate=True, algo=sa.SPMM_EXACT)
+        assert np.array_equal(Cx, Co)
+
+
+def test_non_finite_b_outside_the_matrix_does_not_leak():
+    """cols % w != 0: the reference multiplies stored zeros with whatever lies past B's column end (vbr.cpp:351,362).
+    We must not read it: put NaNs right after every column of B (ld > cols) and expect a clean result."""
+    torch = _torch()
+    m = sa.gen.uniform_random(200, 150, 3000, seed=12)
+    w, n = 64, 40                    # 150 = 2*64 + 22: last block column is padded
+    v = sa.VBR().fill_from_CSR_inplace_fixed(m, 32, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=1)
+    ldb = v.cols + 64
+    Bp = np.full(ldb * n, np.nan, np.float32)
+    Bp.reshape(n, ldb)[:, :v.cols] = B.reshape(n, v.cols)
+    Co = _oracle_c(v, B, n)
+    d = v.to_device(0)
+    for algo in (sa.SPMM_MFMA, sa.SPMM_EXACT):
+        Ct = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
+        d.spmm(torch.from_numpy(Bp).cuda(), Ct, n, ldb=ldb, algo=algo)
+        torch.cuda.synchronize()
+        got = Ct.cpu().numpy()
+        assert np.isfinite(got).all()
+        _check(got, Co, U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n))
+
+
+def test_block_row_range_handles_and_gathered_b():
+    """the multi-GPU pieces on one GPU: row-range handles (sparta_vbs_create_range) reproduce the rows of the full
+    product, and the gathered-B entry point reads an all-gather-shaped B"""
+    torch = _torch()
+    world, w, n = 3, 16, 40
+    slabs = [sa.gen.fem3d_slab(3, 3, 5, r, world, dof=3, pad_to=w, seed=4) for r in range(world)]
+    n_pad = slabs[0][2]
+    shards = [sa.gen.dense_rhs(n_pad, n, seed=50 + r) for r in range(world)]
+    gathered = np.concatenate(shards)                                   # what all_gather_into_tensor leaves
+    Bfull = sa.dist.gathered_to_colmajor(gathered, world, n_pad, n)     # one column-major (world*n_pad) x n matrix
+    for r, (m, n_local, _) in enumerate(slabs):
+        g = sa.BlockingEngine(tau=0.4, col_block_size=w).GetGrouping(m)
+        v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+        Co = _oracle_c(v, Bfull, n)
+        bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, Bfull, n)
+        d = v.to_device(0)
+        Ct = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
+        d.spmm_gathered(torch.from_numpy(gathered).cuda(), n_pad, Ct, n)
+        torch.cuda.synchronize()
+        _check(Ct.cpu().numpy(), Co, bound, "gathered B rank %d" % r)
+        d.spmm_gathered(torch.from_numpy(gathered).cuda(), n_pad, Ct, n, algo=sa.SPMM_EXACT)
+        torch.cuda.synchronize()
+        assert np.array_equal(Ct.cpu().numpy(), Co)
+        # row-range handles
+        parts = sa.dist.partition_block_rows(v.row_part, v.nzcount, w, 4)
+        assert parts[0][0] == 0 and parts[-1][1] == v.block_rows and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        Cfull = Co.reshape(n, v.rows)
+        for b0, b1 in parts:
+            if b0 == b1:
+                continue
+            dr = v.to_device(0, block_row_range=(b0, b1))
+            r0, r1 = int(v.row_part[b0]), int(v.row_part[b1])
+            assert dr.rows == r1 - r0
+            Cr = torch.zeros(dr.rows * n, dtype=torch.float32, device="cuda")
+            dr.spmm(torch.from_numpy(Bfull).cuda(), Cr, n, algo=sa.SPMM_EXACT)
+            torch.cuda.synchronize()
+            assert np.array_equal(Cr.cpu().numpy().reshape(n, dr.rows), Cfull[:, r0:r1])
+
+
+def test_full_size_properties_config2():
+    """BASELINE.json configs[1] at full size (cant-like 62 451^2, N = 128): size-independent properties instead of a
+    full CPU product -- (i) linearity in B, (ii) column checksum 1^T C == (1^T A) B, (iii) sampled block-rows against the
+    oracle, (iv) idempotence of overwrite mode (two runs bit-identical)."""
+    torch = _torch()
+    m = sa.gen.cant_like()
+    w, n = 64, 128
+    g = sa.BlockingEngine(tau=0.2, col_block_size=w).GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    d = v.to_device(0)
+    B1 = torch.from_numpy(sa.gen.dense_rhs(v.cols, n, seed=1)).cuda()
+    B2 = torch.from_numpy(sa.gen.dense_rhs(v.cols, n, seed=2)).cuda()
+
+    def run(Bt):
+        Ct = torch.empty(v.rows * n, dtype=torch.float32, device="cuda")
+        d.spmm(Bt, Ct, n, accumulate=False)
+        torch.cuda.synchronize()
+        return Ct
+    C1, C2, C12 = run(B1), run(B2), run(0.5 * B1 + B2)
+    assert torch.equal(C1, run(B1))                                            # (iv)
+    scale = float(C1.abs().max())
+    assert float((C12 - (0.5 * C1 + C2)).abs().max()) <= 2e-5 * scale * 4      # (i)
+    colsum = np.zeros(v.cols, np.float64)                                      # (ii) 1^T A over the stored nonzeros
+    np.add.at(colsum, m.colidx, m.vals.astype(np.float64))
+    want = colsum @ B1.cpu().numpy().astype(np.float64).reshape(n, v.cols).T
+    got = C1.cpu().numpy().astype(np.float64).reshape(n, v.rows).sum(axis=1)
+    assert np.allclose(got, want, rtol=0, atol=1e-3 * max(1.0, float(np.abs(want).max())))
+    rng = np.random.Generator(np.random.PCG64(0))                              # (iii)
+    B1h = B1.cpu().numpy()
+    C1h = C1.cpu().numpy().reshape(n, v.rows)
+    absA, absB = np.abs(v.mab), np.abs(B1h)
+    for ib in rng.choice(v.block_rows, size=12, replace=False):
+        r0, r1 = int(v.row_part[ib]), int(v.row_part[ib + 1])
+        Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B1h, n, block_row_range=(int(ib), int(ib) + 1)).reshape(n, v.rows)
+        bd = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, absA, absB, n, block_row_range=(int(ib), int(ib) + 1)).reshape(n, v.rows)
+        _check(C1h[:, r0:r1], Co[:, r0:r1], bd[:, r0:r1], "block-row %d" % ib)
