@@ -1,0 +1,242 @@
+// sparta_compat.hpp -- the reference's C++ call shapes for the reorder-and-multiply path, implemented on
+// the C-ABI of include/sparta_amd.h (header-only; link with -lsparta_amd).
+//
+// A driver written against the reference (e.g. test/cuda/cuda_multiply.cpp:250-269,
+// test/general/TEST_blocking_VBR.cpp) keeps its calls:
+//
+//     BlockingEngine bEngine; bEngine.tau = ...; bEngine.col_block_size = ...;
+//     bEngine.GetGrouping(cmat);                                             // include/blocking.h:47
+//     VBR vbmat; vbmat.fill_from_CSR_inplace(cmat, bEngine.grouping_result, col_block_size, row_block_size, force_fixed);
+//                                                                            // include/matrices.h:118
+//     cublas_blockmat_batched(vbmat, mat_B, B_cols, mat_C, dt);              // include/cuda_utilities.h:42
+//     vbmat.multiply(mat_B, B_cols, mat_C);                                  // include/matrices.h:121  (runs on the GPU here)
+//
+// Same type names, field names, argument order and semantics (C is accumulated into; B, C column-major host
+// buffers; `dt` in ms covers the device multiply only).  What is NOT here: the file readers / CLineReader (a driver
+// concern; build a CSR from arrays with CSR::from_flat or fill nzcount/ja/ma yourself) and the CPU CSR::multiply.
+// Errors: the reference prints and continues; these shims throw std::runtime_error carrying sparta_last_error().
+#pragma once
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "sparta_amd.h"
+
+typedef long int intT;   // include/definitions.h:4
+typedef float DataT;     // :5
+typedef float DataT_C;   // :6
+
+enum BlockingType { iterative, iterative_structured, fixed_size, iterative_clocked, iterative_queue, iterative_max_size, scramble };   // :17
+
+namespace sparta_compat_detail {
+inline void check(int rc, const char* what) {
+    if (rc != SPARTA_OK) throw std::runtime_error(std::string(what) + ": " + sparta_last_error());
+}
+}  // namespace sparta_compat_detail
+
+// include/matrices.h:10-91 -- one heap array per row, exactly as in the reference
+struct CSR {
+    intT rows = 0, cols = 0;
+    intT* nzcount = nullptr;
+    intT** ja = nullptr;
+    DataT** ma = nullptr;
+    bool pattern_only = false;
+
+    CSR() = default;
+    CSR(const CSR&) = delete;
+    CSR& operator=(const CSR&) = delete;
+    ~CSR() { clean(); }
+
+    void clean() {
+        if (ja) for (intT i = 0; i < rows; i++) delete[] ja[i];
+        if (ma) for (intT i = 0; i < rows; i++) delete[] ma[i];
+        delete[] ja; delete[] ma; delete[] nzcount;
+        ja = nullptr; ma = nullptr; nzcount = nullptr; rows = cols = 0;
+    }
+    intT nztot() const { intT n = 0; for (intT i = 0; i < rows; i++) n += nzcount[i]; return n; }
+
+    // build from flat CSR arrays (vals == nullptr -> pattern_only)
+    static void from_flat(CSR& out, intT rows, intT cols, const intT* rowptr, const intT* colidx, const DataT* vals) {
+        out.clean();
+        out.rows = rows; out.cols = cols; out.pattern_only = (vals == nullptr);
+        out.nzcount = new intT[rows];
+        out.ja = new intT*[rows];
+        out.ma = vals ? new DataT*[rows] : nullptr;
+        for (intT i = 0; i < rows; i++) {
+            intT n = rowptr[i + 1] - rowptr[i];
+            out.nzcount[i] = n;
+            out.ja[i] = new intT[n];
+            std::memcpy(out.ja[i], colidx + rowptr[i], sizeof(intT) * (size_t)n);
+            if (vals) { out.ma[i] = new DataT[n]; std::memcpy(out.ma[i], vals + rowptr[i], sizeof(DataT) * (size_t)n); }
+        }
+    }
+    // flatten for the C-ABI (rowptr int64, colidx int32)
+    void to_flat(std::vector<int64_t>& rowptr, std::vector<int32_t>& colidx, std::vector<float>& vals) const {
+        rowptr.assign((size_t)rows + 1, 0);
+        for (intT i = 0; i < rows; i++) rowptr[(size_t)i + 1] = rowptr[(size_t)i] + nzcount[i];
+        colidx.resize((size_t)rowptr[(size_t)rows]);
+        vals.clear();
+        if (!pattern_only) vals.resize(colidx.size());
+        for (intT i = 0; i < rows; i++)
+            for (intT k = 0; k < nzcount[i]; k++) {
+                colidx[(size_t)(rowptr[(size_t)i] + k)] = (int32_t)ja[i][k];
+                if (!pattern_only) vals[(size_t)(rowptr[(size_t)i] + k)] = ma[i][k];
+            }
+    }
+};
+
+// src/general/utilities.cpp:8-54,145-173 and src/general/blocking.cpp:859-994 -- same signatures
+inline std::vector<intT> get_permutation(const std::vector<intT>& grouping) {
+    std::vector<intT> p(grouping.size());
+    sparta_compat_detail::check(sparta_get_permutation((const int64_t*)grouping.data(), (int64_t)grouping.size(), (int64_t*)p.data()), "get_permutation");
+    return p;
+}
+inline std::vector<intT> get_partition(const std::vector<intT>& grouping) {
+    std::vector<intT> p(grouping.size() + 1);
+    int64_t n = 0;
+    sparta_compat_detail::check(sparta_get_partition((const int64_t*)grouping.data(), (int64_t)grouping.size(), (int64_t*)p.data(), &n), "get_partition");
+    p.resize((size_t)n);
+    return p;
+}
+inline std::vector<intT> get_fixed_size_grouping(const std::vector<intT>& grouping, intT row_block_size) {
+    std::vector<intT> g(grouping.size());
+    sparta_compat_detail::check(sparta_get_fixed_size_grouping((const int64_t*)grouping.data(), (int64_t)grouping.size(), row_block_size, (int64_t*)g.data()), "get_fixed_size_grouping");
+    return g;
+}
+inline std::vector<intT> merge_rows(std::vector<intT> A, intT* B, intT sizeB) {
+    std::vector<intT> out(A.size() + (size_t)sizeB + 1);
+    int64_t n = 0;
+    sparta_compat_detail::check(sparta_merge_rows((const int64_t*)A.data(), (int64_t)A.size(), (const int64_t*)B, sizeB, (int64_t*)out.data(), &n), "merge_rows");
+    out.resize((size_t)n);
+    return out;
+}
+inline float HammingDistanceGroup(std::vector<intT> row_A, intT group_size_A, intT* row_B, intT size_B, intT group_size_B, intT block_size) {
+    float d = 0;
+    sparta_compat_detail::check(sparta_row_distance(SPARTA_SIM_HAMMING, (const int64_t*)row_A.data(), (int64_t)row_A.size(), group_size_A, (const int64_t*)row_B, size_B, group_size_B, block_size, &d), "HammingDistanceGroup");
+    return d;
+}
+inline float JaccardDistanceGroup(std::vector<intT> row_A, intT group_size_A, intT* row_B, intT size_B, intT group_size_B, intT block_size) {
+    float d = 0;
+    sparta_compat_detail::check(sparta_row_distance(SPARTA_SIM_JACCARD, (const int64_t*)row_A.data(), (int64_t)row_A.size(), group_size_A, (const int64_t*)row_B, size_B, group_size_B, block_size, &d), "JaccardDistanceGroup");
+    return d;
+}
+
+// include/blocking.h:9-56
+class BlockingEngine {
+   public:
+    float tau = 0.5;
+    intT col_block_size = 1;
+    intT row_block_size = 1;
+    bool use_groups = false;
+    bool use_pattern = true;
+    bool force_fixed_size = false;
+    int structured_m = 2, structured_n = 4;
+    BlockingType blocking_algo = iterative_clocked;
+
+    intT comparison_counter = 0, merge_counter = 0;
+    float timer_total = 0, timer_comparisons = 0, timer_merges = 0;
+    float average_row_distance = 0, average_merge_tau = 0;
+    float multiplication_timer_avg = 0, multiplication_timer_std = 0;
+    intT VBR_nzcount = 0, VBR_nzblocks_count = 0;
+    float VBR_average_height = 0;
+    intT VBR_longest_row = 0;
+    std::vector<intT> grouping_result;
+
+    void SetComparator(int choice) { sim_measure_ = choice; }   // src/general/blocking.cpp:699-717
+
+    std::vector<intT> GetGrouping(const CSR& cmat) {             // src/general/blocking.cpp:633-676
+        std::vector<int64_t> rp; std::vector<int32_t> ci; std::vector<float> v;
+        cmat.to_flat(rp, ci, v);
+        sparta_reorder_cfg cfg;
+        sparta_reorder_cfg_default(&cfg);
+        cfg.blocking_algo = (int32_t)blocking_algo; cfg.sim_measure = sim_measure_; cfg.tau = tau;
+        cfg.use_groups = use_groups; cfg.col_block_size = col_block_size; cfg.row_block_size = row_block_size;
+        cfg.use_pattern = use_pattern; cfg.force_fixed_size = force_fixed_size;
+        sparta_reorder_stats st;
+        grouping_result.assign((size_t)cmat.rows, 0);
+        sparta_compat_detail::check(sparta_reorder(cmat.rows, cmat.cols, rp.data(), ci.data(), &cfg, (int64_t*)grouping_result.data(), &st), "GetGrouping");
+        comparison_counter = st.comparison_counter; merge_counter = st.merge_counter;
+        timer_total = st.timer_total; timer_comparisons = st.timer_comparisons; timer_merges = st.timer_merges;
+        average_row_distance = st.average_row_distance; average_merge_tau = st.average_merge_tau;
+        return grouping_result;
+    }
+    void CollectBlockingInfo(const CSR& cmat) {                  // src/general/blocking.cpp:576-631
+        std::vector<int64_t> rp; std::vector<int32_t> ci; std::vector<float> v;
+        cmat.to_flat(rp, ci, v);
+        int64_t info[3]; float avg = 0;
+        sparta_compat_detail::check(sparta_blocking_info(cmat.rows, cmat.cols, rp.data(), ci.data(), (const int64_t*)grouping_result.data(), col_block_size, info, &avg), "CollectBlockingInfo");
+        VBR_nzcount = info[0]; VBR_nzblocks_count = info[1];
+        if (info[2] > VBR_longest_row) VBR_longest_row = info[2];
+        VBR_average_height = avg;
+    }
+
+   private:
+    int sim_measure_ = 1;
+};
+
+// include/matrices.h:93-125
+struct VBR {
+    intT rows = 0, cols = 0, block_rows = 0, block_cols = 0;
+    intT* nzcount = nullptr;
+    intT* jab = nullptr;
+    intT* row_part = nullptr;
+    DataT* mab = nullptr;
+    intT block_col_size = 0;
+    intT nztot = 0;
+
+    VBR() = default;
+    VBR(const VBR&) = delete;
+    VBR& operator=(const VBR&) = delete;
+    ~VBR() { clean(); }
+
+    void clean() {
+        if (dev_) { sparta_vbs_destroy(dev_); dev_ = nullptr; }
+        delete[] nzcount; delete[] jab; delete[] row_part; delete[] mab;
+        nzcount = jab = row_part = nullptr; mab = nullptr;
+        rows = cols = block_rows = block_cols = nztot = block_col_size = 0;
+    }
+
+    // src/general/vbr.cpp:135-237
+    void fill_from_CSR_inplace(const CSR& cmat, const std::vector<intT>& grouping, intT col_block_size, intT row_block_size = 0,
+                               bool force_fixed_size = false) {
+        clean();
+        std::vector<int64_t> rp; std::vector<int32_t> ci; std::vector<float> v;
+        cmat.to_flat(rp, ci, v);
+        sparta_vbs_host h;
+        sparta_compat_detail::check(sparta_vbs_build(cmat.rows, cmat.cols, rp.data(), ci.data(), cmat.pattern_only ? nullptr : v.data(),
+                                                     (const int64_t*)grouping.data(), col_block_size, row_block_size, force_fixed_size, &h),
+                                    "VBR::fill_from_CSR_inplace");
+        rows = h.rows; cols = h.cols; block_rows = h.block_rows; block_cols = h.block_cols; block_col_size = h.block_col_size; nztot = h.nztot;
+        row_part = new intT[h.block_rows + 1]; std::memcpy(row_part, h.row_part, sizeof(intT) * (size_t)(h.block_rows + 1));
+        nzcount = new intT[h.block_rows > 0 ? h.block_rows : 1]; std::memcpy(nzcount, h.nzcount, sizeof(intT) * (size_t)h.block_rows);
+        jab = new intT[h.nblocks > 0 ? h.nblocks : 1]; std::memcpy(jab, h.jab, sizeof(intT) * (size_t)h.nblocks);
+        mab = new DataT[h.nztot > 0 ? h.nztot : 1]; std::memcpy(mab, h.mab, sizeof(DataT) * (size_t)h.nztot);
+        sparta_vbs_host_free(&h);
+    }
+    // src/general/vbr.cpp:121-132
+    void fill_from_CSR_inplace(const CSR& cmat, intT row_block_size, intT col_block_size, bool force_fixed_size = false) {
+        std::vector<intT> grouping((size_t)cmat.rows);
+        for (intT i = 0; i < cmat.rows; i++) grouping[(size_t)i] = i / row_block_size;
+        fill_from_CSR_inplace(cmat, grouping, col_block_size, row_block_size, force_fixed_size);
+    }
+
+    // include/matrices.h:121 -- C += A*B, host buffers, column-major; runs the MFMA kernels on `device`
+    void multiply(DataT* B, int B_cols, DataT_C* C, float* dt = nullptr, int device = 0) const {
+        if (!dev_)
+            sparta_compat_detail::check(sparta_vbs_create(&dev_, rows, cols, block_rows, block_col_size, (const int64_t*)row_part,
+                                                          (const int64_t*)nzcount, (const int64_t*)jab, mab, SPARTA_F32, device), "VBR::multiply (upload)");
+        sparta_compat_detail::check(sparta_vbs_spmm(dev_, B, cols, SPARTA_COL_MAJOR, B_cols, C, rows, SPARTA_COL_MAJOR, 1, SPARTA_PTR_HOST, nullptr,
+                                                    SPARTA_SPMM_MFMA, dt), "VBR::multiply");
+    }
+
+   private:
+    mutable sparta_vbs_t* dev_ = nullptr;   // device image, created on first multiply, released by clean()
+};
+
+// include/cuda_utilities.h:38,42 and include/cutlass_bellpack_lib.h:21,25 -- one fused kernel family behind all of them.
+// n_streams is accepted for source compatibility and ignored (there is no per-block launch to spread over streams).
+inline void cublas_fixed_blocks_multiply(const VBR& vbmatA, DataT* B, int B_cols, DataT_C* C, float& dt, int n_streams = 4) { (void)n_streams; vbmatA.multiply(B, B_cols, C, &dt); }
+inline void cublas_blockmat_batched(const VBR& vbmatA, DataT* B, int B_cols, DataT_C* C, float& dt) { vbmatA.multiply(B, B_cols, C, &dt); }
+inline void cutlas_fixed_blocks_multiply(const VBR& vbmatA, DataT* B, int B_cols, DataT_C* C, float& dt) { vbmatA.multiply(B, B_cols, C, &dt); }
+inline void cutlas_blockmat_batched(const VBR& vbmatA, DataT* B, int B_cols, DataT_C* C, float& dt) { vbmatA.multiply(B, B_cols, C, &dt); }

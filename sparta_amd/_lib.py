@@ -6,6 +6,14 @@ There is NO Python/CPU fallback: if the library is missing, importing this modul
 import ctypes as C
 import os
 
+try:
+    # PyTorch-ROCm wheels bundle their own libamdhip64; a process must end up with ONE HIP runtime.  Loading torch
+    # first makes libsparta_amd.so (NEEDED libamdhip64.so.7) bind to the runtime torch uses, so torch tensors,
+    # torch streams and our kernels share one device context.  Without torch the system ROCm runtime is used.
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover - torch is optional for the pure C-ABI user
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsparta_amd.so")
 

@@ -1,0 +1,51 @@
+// tests/cpp/compat_driver.cpp -- a driver written the way the reference's drivers are (test/general/TEST_blocking_VBR.cpp,
+// test/cuda/cuda_multiply.cpp:250-269), compiled against include/sparta_compat.hpp instead of the reference's headers.
+// argv[1] = "host" (reorder + build only, no GPU needed) or "gpu" (also multiplies and prints a checksum).
+// Prints the README example's results so the test can compare text.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "sparta_compat.hpp"
+
+int main(int argc, char** argv) {
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    // data/TEST_matrix_weighted.el as the reference's reader parses it (first data line dropped)
+    intT rowptr[] = {0, 0, 3, 6, 10, 10, 11, 11, 11, 12};
+    intT colidx[] = {2, 5, 8, 5, 6, 8, 1, 3, 7, 8, 6, 1};
+    DataT vals[] = {5, 8, 7, 1, 1, 1, 1, 1, 3, 8, 2, 5};
+    CSR cmat;
+    CSR::from_flat(cmat, 9, 9, rowptr, colidx, vals);
+
+    BlockingEngine bEngine;
+    bEngine.tau = 0.6f; bEngine.col_block_size = 3; bEngine.row_block_size = 3;
+    bEngine.blocking_algo = iterative_clocked; bEngine.SetComparator(1);
+    bEngine.GetGrouping(cmat);
+    std::printf("grouping:");
+    for (intT g : bEngine.grouping_result) std::printf(" %ld", g);
+    std::printf("\ncounters: %ld %ld\n", bEngine.comparison_counter, bEngine.merge_counter);
+
+    VBR vbmat;
+    vbmat.fill_from_CSR_inplace(cmat, bEngine.grouping_result, 3);
+    std::printf("dims: %ld %ld %ld %ld %ld\n", vbmat.rows, vbmat.cols, vbmat.block_rows, vbmat.block_cols, vbmat.nztot);
+    std::printf("jab:");
+    for (intT i = 0, n = 0; i < vbmat.block_rows; i++) for (intT k = 0; k < vbmat.nzcount[i]; k++) std::printf(" %ld", vbmat.jab[n++]);
+    std::printf("\n");
+    bEngine.CollectBlockingInfo(cmat);
+    std::printf("info: %ld %ld %ld\n", bEngine.VBR_nzcount, bEngine.VBR_nzblocks_count, bEngine.VBR_longest_row);
+
+    if (gpu) {
+        std::vector<DataT> B(18);
+        for (int i = 0; i < 18; i++) B[(size_t)i] = (DataT)(i + 1);
+        std::vector<DataT_C> C(18, 0.0f);
+        float dt = 0;
+        cublas_blockmat_batched(vbmat, B.data(), 2, C.data(), dt);       // include/cuda_utilities.h:42
+        std::printf("C:");
+        for (float c : C) std::printf(" %g", c);
+        std::printf("\n");
+        vbmat.multiply(B.data(), 2, C.data());                           // accumulates: C doubles
+        std::printf("C2:");
+        for (float c : C) std::printf(" %g", c);
+        std::printf("\n");
+    }
+    return 0;
+}

@@ -1,0 +1,40 @@
+"""The reference-shaped C++ API (include/sparta_compat.hpp): a driver written like the reference's own drivers is
+compiled against it with g++, linked to libsparta_amd.so, and must print the README example's numbers."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "compat_driver")
+
+
+def _build():
+    src = os.path.join(ROOT, "tests", "cpp", "compat_driver.cpp")
+    libdir = os.path.join(ROOT, "sparta_amd")
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
+                               "-L", libdir, "-lsparta_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return EXE
+
+
+def _run(mode):
+    out = subprocess.check_output([_build(), mode], text=True)
+    return dict(line.split(":", 1) for line in out.strip().splitlines())
+
+
+def test_compat_driver_host_side():
+    r = _run("host")
+    assert r["grouping"].split() == "0 1 1 1 0 5 0 0 8".split()
+    assert r["counters"].split() == ["13", "5"]
+    assert r["dims"].split() == "9 9 4 3 33".split()
+    assert r["jab"].split() == "0 1 2 2 0".split()
+    assert r["info"].split() == ["33", "5", "3"]
+
+
+@pytest.mark.gpu
+def test_compat_driver_multiplies_on_gpu():
+    r = _run("gpu")
+    want = [0, 0, 0, 0, 126, 22, 102, 14, 10, 0, 0, 0, 0, 306, 49, 219, 32, 55]
+    assert [float(x) for x in r["C"].split()] == want
+    assert [float(x) for x in r["C2"].split()] == [2 * x for x in want]

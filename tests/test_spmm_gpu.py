@@ -169,7 +169,7 @@ def test_special_block_rows():
                 sa.BlockingEngine(tau=0.0, col_block_size=w)):
         g = eng.GetGrouping(m)
         v = sa.VBR().fill_from_CSR_inplace(m, g, w)
-        assert (v.nzcount == 0).any()
+        assert (v.nzcount == 0).any() or eng.tau >= 1.0      # tau = 1 merges everything into ONE huge block-row
         B = sa.gen.dense_rhs(v.cols, n, seed=2)
         Co = _oracle_c(v, B, n)
         bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
