@@ -50,8 +50,9 @@ struct TileDesc {
     int32_t nb;        // nonzero blocks in the block-row
     int32_t h;         // block-row height = leading dimension of each of its blocks
     int32_t c_row;     // first row of C written by this tile
-    int32_t mt;        // rows in this tile (<= class height)
+    int32_t mt_flags;  // low 16 bits: rows in this tile (<= class height); TILE_* flags above
 };
+constexpr int32_t TILE_TAIL = 1 << 16;   // the block-row's last block lies in the zero-padded last block column (cols % w != 0)
 static_assert(sizeof(TileDesc) == 32, "TileDesc must stay 32 bytes");
 
 struct SpmmParams {
@@ -70,13 +71,6 @@ struct SpmmParams {
     int64_t shard_rows;   // 0: B is one matrix; >0: B is an all-gather result of column-major shard_rows x N slabs
 };
 
-// bijective XCD-aware remap (workgroups are dealt round-robin over the 8 XCDs: b and b+8 share one)
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (bid >> 3);
-}
-
 template <int MF>
 struct Acc;
 template <>
@@ -84,36 +78,56 @@ struct Acc<32> { typedef f32x16 type; };
 template <>
 struct Acc<16> { typedef f32x4 type; };
 
-// MF: MFMA tile (32 -> 32x32x2, 16 -> 16x16x4).  WM x WN waves, each MI x NI MFMA tiles.
-template <int MF, int WM, int WN, int MI, int NI>
+// MF: MFMA tile (32 -> 32x32x2, 16 -> 16x16x4).  WM x WN waves, each MI x NI MFMA tiles.  KP: k-depth of a
+// panel step.  BRM: B is row-major.  GENERIC: any w / N / alignment (slow, branchy staging); the non-GENERIC
+// instantiation requires w % KP == 0, N % 128 == 0 (checked on the host) and keeps its main loop free of
+// any data-dependent branch: every load of a step is an unconditional 16-byte load, so the loads of step
+// s+1 stay in flight under the MFMAs of step s.  The one irregular case it still meets -- the zero-padded
+// LAST block column when cols % w != 0, which can only be the last block of a block-row because jab is
+// ascending -- is peeled out of the loop into a single slow step (TILE_TAIL flag of the tile).
+template <int MF, int WM, int WN, int MI, int NI, int KP, bool BRM, bool GENERIC>
 __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_kernel(const SpmmParams p) {
     constexpr int TM = WM * MI * MF;
     constexpr int TN = WN * NI * MF;
     static_assert(TN == kTN, "workgroup covers 128 columns");
     static_assert(WM * WN == 4, "4 waves");
-    constexpr int KP = kKP;
-    constexpr int LDBS = KP + 4;                    // floats per staged B column: 16-B aligned rows, conflict-free ds_read_b128
-    constexpr int LDAS = (TM == 16) ? 20 : TM;      // 16-row tiles: shift the upper k-quarters onto the other 16 banks
-    constexpr int NBV = TN * KP / 4 / kThreads;     // float4 B chunks staged per thread
-    constexpr int NAV = TM * KP / kThreads;         // A floats staged per thread
+    // LDS image of the B panel: column-major B -> Bs[j][k] (k contiguous, +4 pad: conflict-free ds_read_b128);
+    //                           row-major B    -> Bs[k][j] (j contiguous: conflict-free ds_read_b32)
+    constexpr int LDBS = BRM ? TN : KP + 4;
+    constexpr int BS_FLOATS = BRM ? KP * TN : TN * (KP + 4);
+    constexpr int LDAS = (TM == 16) ? 20 : TM;      // As[k][i]; 16-row tiles: shift the upper k-quarters onto the other banks
+    constexpr int NBV = TN * KP / 4 / kThreads;     // 16-byte B chunks staged per thread
+    constexpr int NAV = TM * KP / 4 / kThreads;     // 16-byte A chunks staged per thread
+    constexpr int KC = KP / 4;                      // col-major B: chunks per panel column
+    constexpr int BJ_STEP = kThreads / KC;          // col-major B: columns between a thread's consecutive chunks
+    constexpr int BK_STEP = kThreads / (TN / 4);    // row-major B: k rows between a thread's consecutive chunks
+    constexpr int AC = TM / 4;                      // A: chunks per k column
+    constexpr int AK_STEP = kThreads / AC;          // A: k between a thread's consecutive chunks
     constexpr int KG = (MF == 32) ? 8 : 16;         // k consumed per fragment round
+    constexpr int NACC = (MF == 32) ? 16 : 4;
+    static_assert(KP % KG == 0 && NBV >= 1 && NAV >= 1 && kThreads % AC == 0, "bad tile configuration");
     typedef typename Acc<MF>::type acc_t;
 
-    __shared__ __attribute__((aligned(16))) float lds[TN * LDBS + KP * LDAS];
+    __shared__ __attribute__((aligned(16))) float lds[BS_FLOATS + KP * LDAS];
     float* Bs = lds;
-    float* As = lds + TN * LDBS;
+    float* As = lds + BS_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    const int lm = lane & (MF - 1);                 // row/col inside the MFMA tile
+    const int g = lane / MF;                        // k lane-group (half for 32x32x2, quarter for 16x16x4)
 
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_id = logical / p.n_ntiles;
-    const int n0 = (logical % p.n_ntiles) * TN;
+    // tile list is pre-arranged on the host (see sparta_vbs_create): entry t belongs to XCD t % 8 (workgroups are
+    // dealt round-robin over the 8 XCDs), each XCD owning a contiguous range of block-rows sorted by descending cost
+    const int tile_id = blockIdx.x % p.n_tiles;
+    const int n0 = (blockIdx.x / p.n_tiles) * TN;
     const TileDesc td = p.tiles[tile_id];
+    const int mt = td.mt_flags & 0xffff;
+    const bool tail_partial = !GENERIC && (td.mt_flags & TILE_TAIL) != 0 && p.shard_rows == 0;
     const int w = p.w, N = p.N;
     const int spb = (w + KP - 1) / KP;              // panel steps per block
-    const int nsteps = td.nb * spb;
+    const int nsteps = (td.nb - (tail_partial ? 1 : 0)) * spb;   // steps of the regular loop
 
     acc_t acc[MI][NI];
 #pragma unroll
@@ -121,135 +135,174 @@ __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_kernel(const SpmmParams
 #pragma unroll
         for (int ni = 0; ni < NI; ni++)
 #pragma unroll
-            for (int r = 0; r < (MF == 32 ? 16 : 4); r++) acc[mi][ni][r] = 0.0f;
+            for (int r = 0; r < NACC; r++) acc[mi][ni][r] = 0.0f;
 
     f32x4 breg[NBV];
-    float areg[NAV];
+    f32x4 areg[NAV];
+
+    // per-thread staging coordinates (constant over the whole tile)
+    const int bj0 = tid / KC, bk = (tid % KC) * 4;                  // col-major B: column bj0 + BJ_STEP*q, k = bk..bk+3
+    const int rj = (tid % (TN / 4)) * 4, rk0 = tid / (TN / 4);      // row-major B: k = rk0 + BK_STEP*q, columns rj..rj+3
+    const int ai = (tid % AC) * 4, ak0 = tid / AC;                  // A: rows ai..ai+3, k = ak0 + AK_STEP*q
+
+    // where panel step (b, ks) finds its B rows: base pointer, first row, number of rows that exist
+    struct PanelSrc { const float* base; int64_t gk0; int64_t bvalid; };
+    auto panel_src = [&](int b, int ks) {
+        PanelSrc ps;
+        const int64_t jb = p.jab[td.jab_off + b];
+        ps.gk0 = jb * (int64_t)w + ks;
+        ps.base = p.B;
+        ps.bvalid = p.cols;
+        if (p.shard_rows > 0) {
+            // gathered B: rank s contributed rows [s*shard_rows, (s+1)*shard_rows) as its own column-major slab;
+            // shard_rows is a multiple of w, so a panel never straddles two slabs (wave-uniform arithmetic)
+            const int64_t sh = ps.gk0 / p.shard_rows;
+            ps.base += sh * p.shard_stride;
+            ps.gk0 -= sh * p.shard_rows;
+            ps.bvalid = p.shard_rows;
+        }
+        return ps;
+    };
+
+    // A slice of block b, k in [ks, ks+KP): 16-byte loads along the rows of a column.  Rows past the tile (mt < TM)
+    // read the following rows / the next column / the 128-float pad behind A: finite garbage that only reaches
+    // accumulator rows which are never stored.  Needs no mask when the k range is full (w % KP == 0).
+    auto load_a_fast = [&](int b, int ks) {
+        const float* asrc = p.A + td.a_off + ((int64_t)b * w + ks + ak0) * td.h + ai;
+#pragma unroll
+        for (int q = 0; q < NAV; q++) {
+            const f32x4u t = *reinterpret_cast<const f32x4u*>(asrc + (int64_t)(q * AK_STEP) * td.h);
+            areg[q] = (f32x4){t.x, t.y, t.z, t.w};
+        }
+    };
 
     // ---- stage loader: global -> registers ------------------------------------------------------
     auto load_step = [&](int s) {
         const int b = s / spb;
         const int ks = (s - b * spb) * KP;
-        const int64_t jb = p.jab[td.jab_off + b];
-        int64_t gk0 = jb * (int64_t)w + ks;                       // first B row of this panel
-        const float* Bbase = p.B;
-        int64_t bvalid = p.cols;                                  // rows of B that exist (panel rows past it read as 0)
-        if (p.shard_rows > 0) {
-            // gathered B: rank s contributed rows [s*shard_rows, (s+1)*shard_rows) as its own column-major slab;
-            // shard_rows is a multiple of w, so a panel never straddles two slabs (wave-uniform arithmetic)
-            const int64_t sh = gk0 / p.shard_rows;
-            Bbase += sh * p.shard_stride;
-            gk0 -= sh * p.shard_rows;
-            bvalid = p.shard_rows;
-        }
-        if (!p.b_row_major) {
-            // column-major B (the reference's layout): a panel column is `kp` contiguous floats
+        const PanelSrc ps = panel_src(b, ks);
+        if constexpr (!GENERIC) {
+            if constexpr (!BRM) {
+                const float* src = ps.base + ps.gk0 + bk + (int64_t)(n0 + bj0) * p.ldb;
 #pragma unroll
-            for (int q = 0; q < NBV; q++) {
-                const int c = tid + kThreads * q;
-                const int j = c / (KP / 4), k = (c % (KP / 4)) * 4;
-                const int col = n0 + j;
-                const float* src = Bbase + (gk0 + k) + (int64_t)col * p.ldb;
-                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (col < N) {
-                    if (p.vec_ok && ks + k + 3 < w && gk0 + k + 3 < bvalid) {
-                        const f32x4u t = *reinterpret_cast<const f32x4u*>(src);
-                        v = (f32x4){t.x, t.y, t.z, t.w};
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (ks + k + e < w && gk0 + k + e < bvalid) v[e] = src[e];
-                    }
+                for (int q = 0; q < NBV; q++) {
+                    const f32x4u t = *reinterpret_cast<const f32x4u*>(src + (int64_t)(q * BJ_STEP) * p.ldb);
+                    breg[q] = (f32x4){t.x, t.y, t.z, t.w};
                 }
-                breg[q] = v;
+            } else {
+                const float* src = ps.base + (ps.gk0 + rk0) * p.ldb + n0 + rj;
+#pragma unroll
+                for (int q = 0; q < NBV; q++) {
+                    const f32x4u t = *reinterpret_cast<const f32x4u*>(src + (int64_t)(q * BK_STEP) * p.ldb);
+                    breg[q] = (f32x4){t.x, t.y, t.z, t.w};
+                }
             }
+            load_a_fast(b, ks);
         } else {
-            // row-major B: a panel row is 128 contiguous floats; transposed on the way into LDS
+            const int kp_a = min(KP, w - ks);                                         // k that exist in the block
+            const int kp_b = (int)min((int64_t)kp_a, ps.bvalid - ps.gk0);             // ... and in B
+            if constexpr (!BRM) {
 #pragma unroll
-            for (int q = 0; q < NBV; q++) {
-                const int c = tid + kThreads * q;
-                const int k = c / (TN / 4), j = (c % (TN / 4)) * 4;
-                const int col = n0 + j;
-                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (ks + k < w && gk0 + k < bvalid) {
-                    const float* src = Bbase + (gk0 + k) * p.ldb + col;
-                    if (p.vec_ok && col + 3 < N) {
-                        const f32x4u t = *reinterpret_cast<const f32x4u*>(src);
-                        v = (f32x4){t.x, t.y, t.z, t.w};
-                    } else {
+                for (int q = 0; q < NBV; q++) {
+                    const int col = n0 + bj0 + BJ_STEP * q;
+                    const float* src = ps.base + ps.gk0 + bk + (int64_t)col * p.ldb;
+                    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (col < N) {
+                        if (p.vec_ok && bk + 3 < kp_b) {
+                            const f32x4u t = *reinterpret_cast<const f32x4u*>(src);
+                            v = (f32x4){t.x, t.y, t.z, t.w};
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (col + e < N) v[e] = src[e];
+                            for (int e = 0; e < 4; e++)
+                                if (bk + e < kp_b) v[e] = src[e];
+                        }
                     }
+                    breg[q] = v;
                 }
-                breg[q] = v;
-            }
-        }
-        // A: rows [r0, r0+mt) x k [ks, ks+KP) of block b; column-major, lda = h
-        const float* ablk = p.A + td.a_off + ((int64_t)b * w + ks) * td.h;
+            } else {
 #pragma unroll
-        for (int q = 0; q < NAV; q++) {
-            const int e = tid + kThreads * q;
-            const int i = e % TM, k = e / TM;
-            areg[q] = (i < td.mt && ks + k < w) ? ablk[(int64_t)k * td.h + i] : 0.0f;
+                for (int q = 0; q < NBV; q++) {
+                    const int k = rk0 + BK_STEP * q;
+                    const int col = n0 + rj;
+                    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (k < kp_b) {
+                        const float* src = ps.base + (ps.gk0 + k) * p.ldb + col;
+                        if (p.vec_ok && col + 3 < N) {
+                            const f32x4u t = *reinterpret_cast<const f32x4u*>(src);
+                            v = (f32x4){t.x, t.y, t.z, t.w};
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                if (col + e < N) v[e] = src[e];
+                        }
+                    }
+                    breg[q] = v;
+                }
+            }
+            const float* asrc = p.A + td.a_off + ((int64_t)b * w + ks) * td.h;
+#pragma unroll
+            for (int q = 0; q < NAV; q++) {
+                const int k = ak0 + AK_STEP * q;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (k < kp_a) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (ai + e < mt) v[e] = asrc[(int64_t)k * td.h + ai + e];
+                }
+                areg[q] = v;
+            }
         }
     };
 
     // ---- registers -> LDS -----------------------------------------------------------------------
-    auto store_step = [&]() {
-        if (!p.b_row_major) {
+    auto store_a = [&]() {
 #pragma unroll
-            for (int q = 0; q < NBV; q++) {
-                const int c = tid + kThreads * q;
-                const int j = c / (KP / 4), k = (c % (KP / 4)) * 4;
-                *reinterpret_cast<f32x4*>(&Bs[j * LDBS + k]) = breg[q];
-            }
+        for (int q = 0; q < NAV; q++) *reinterpret_cast<f32x4*>(&As[(ak0 + AK_STEP * q) * LDAS + ai]) = areg[q];
+    };
+    auto store_step = [&]() {
+        if constexpr (!BRM) {
+#pragma unroll
+            for (int q = 0; q < NBV; q++) *reinterpret_cast<f32x4*>(&Bs[(bj0 + BJ_STEP * q) * LDBS + bk]) = breg[q];
         } else {
 #pragma unroll
-            for (int q = 0; q < NBV; q++) {
-                const int c = tid + kThreads * q;
-                const int k = c / (TN / 4), j = (c % (TN / 4)) * 4;
-#pragma unroll
-                for (int e = 0; e < 4; e++) Bs[(j + e) * LDBS + k] = breg[q][e];
-            }
+            for (int q = 0; q < NBV; q++) *reinterpret_cast<f32x4*>(&Bs[(rk0 + BK_STEP * q) * LDBS + rj]) = breg[q];
         }
-#pragma unroll
-        for (int q = 0; q < NAV; q++) {
-            const int e = tid + kThreads * q;
-            As[(e / TM) * LDAS + (e % TM)] = areg[q];
-        }
+        store_a();
     };
 
     // ---- MFMA over one staged panel -----------------------------------------------------------------
-    // Fragment k-mapping: one ds_read_b128 gives a lane 4 consecutive k of its B column; MFMA number m of
-    // the round consumes element m, so lane-group g (half for 32x32x2, quarter for 16x16x4) contributes
-    // k = kb + 4g + m.  The A fragment uses the same k for the same lane group.  Any bijection works:
-    // an MFMA just sums over its k slots.
-    auto compute_step = [&](int kp) {
-        const int lm = lane & (MF - 1);             // row/col inside the MFMA tile
-        const int g = lane / MF;                    // k lane-group
-        for (int kb = 0; kb < kp; kb += KG) {
-            float a[MI][4];
-            f32x4 bf[NI];
+    // Fragment k-mapping: MFMA number m of a round takes, from lane-group g, k = kb + 4g + m for BOTH operands
+    // (any bijection works: an MFMA just sums over its k slots).  Column-major B: one ds_read_b128 gives a lane the
+    // 4 consecutive k of its column; row-major B: four ds_read_b32, each conflict-free across the 32 columns.
+    const float* a_frag = As + (4 * g) * LDAS + wm * MI * MF + lm;
+    const float* b_frag = BRM ? Bs + (4 * g) * LDBS + wn * NI * MF + lm : Bs + (wn * NI * MF + lm) * LDBS + 4 * g;
+    auto mfma_round = [&](int kb) {
+        float a[MI][4];
+        f32x4 bf[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) a[mi][m] = a_frag[(kb + m) * LDAS + mi * MF];
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {
+            if constexpr (!BRM) {
+                bf[ni] = *reinterpret_cast<const f32x4*>(&b_frag[ni * MF * LDBS + kb]);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; m++) bf[ni][m] = b_frag[(kb + m) * LDBS + ni * MF];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-                for (int m = 0; m < 4; m++) a[mi][m] = As[(kb + 4 * g + m) * LDAS + (wm * MI + mi) * MF + lm];
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++)
-                bf[ni] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NI + ni) * MF + lm) * LDBS + kb + 4 * g]);
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-#pragma unroll
-                for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ni++) {
-                        if constexpr (MF == 32)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[ni][m], a[mi][m], acc[mi][ni], 0, 0, 0);
-                        else
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[ni][m], a[mi][m], acc[mi][ni], 0, 0, 0);
-                    }
-        }
+                for (int ni = 0; ni < NI; ni++) {
+                    if constexpr (MF == 32)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[ni][m], a[mi][m], acc[mi][ni], 0, 0, 0);
+                    else
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[ni][m], a[mi][m], acc[mi][ni], 0, 0, 0);
+                }
     };
 
     if (nsteps > 0) load_step(0);
@@ -258,32 +311,62 @@ __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_kernel(const SpmmParams
         store_step();
         __syncthreads();
         if (s + 1 < nsteps) load_step(s + 1);       // in flight while the MFMAs below run
-        const int ks = (s % spb) * KP;
-        const int kp = min(KP, w - ks);
-        compute_step(kp);
+        if constexpr (!GENERIC) {
+#pragma unroll
+            for (int kb = 0; kb < KP; kb += KG) mfma_round(kb);
+        } else {
+            const int kp = min(KP, w - (s % spb) * KP);
+            for (int kb = 0; kb < kp; kb += KG) mfma_round(kb);   // short block: the staged tail is zero-filled
+        }
+    }
+
+    if constexpr (!GENERIC) {
+        if (tail_partial) {
+            // peeled step: the block in the zero-padded last block column.  B rows >= cols do not exist: staged as
+            // zeros by a plain bounds-checked loop (slow, once per block-row at most); A is full width as stored.
+            const int b = td.nb - 1;
+            for (int ks = 0; ks < w; ks += KP) {
+                const PanelSrc ps = panel_src(b, ks);
+                load_a_fast(b, ks);
+                __syncthreads();
+#pragma unroll 1
+                for (int idx = tid; idx < TN * KP; idx += kThreads) {
+                    float v = 0.0f;
+                    if constexpr (!BRM) {
+                        const int j = idx / KP, k = idx % KP;
+                        if (ps.gk0 + k < ps.bvalid) v = ps.base[ps.gk0 + k + (int64_t)(n0 + j) * p.ldb];
+                        Bs[j * LDBS + k] = v;
+                    } else {
+                        const int k = idx / TN, j = idx % TN;
+                        if (ps.gk0 + k < ps.bvalid) v = ps.base[(ps.gk0 + k) * p.ldb + n0 + j];
+                        Bs[k * LDBS + j] = v;
+                    }
+                }
+                store_a();
+                __syncthreads();
+#pragma unroll
+                for (int kb = 0; kb < KP; kb += KG) mfma_round(kb);
+            }
+        }
     }
 
     // ---- epilogue: D[j][i] -> C[i][j] -----------------------------------------------------------------
-    {
-        const int lm = lane & (MF - 1);
-        const int g = lane / MF;
 #pragma unroll
-        for (int mi = 0; mi < MI; mi++) {
-            const int row = (wm * MI + mi) * MF + lm;
-            if (row >= td.mt) continue;
+    for (int mi = 0; mi < MI; mi++) {
+        const int row = (wm * MI + mi) * MF + lm;
+        if (row >= mt) continue;
 #pragma unroll
-            for (int ni = 0; ni < NI; ni++) {
+        for (int ni = 0; ni < NI; ni++) {
 #pragma unroll
-                for (int r = 0; r < (MF == 32 ? 16 : 4); r++) {
-                    const int j = (MF == 32) ? ((r & 3) + 8 * (r >> 2) + 4 * g) : (4 * g + r);
-                    const int col = n0 + (wn * NI + ni) * MF + j;
-                    if (col >= N) continue;
-                    float* dst = p.c_row_major ? p.C + (int64_t)(td.c_row + row) * p.ldc + col
-                                               : p.C + (int64_t)(td.c_row + row) + (int64_t)col * p.ldc;
-                    float v = acc[mi][ni][r];
-                    if (p.accumulate) v += *dst;
-                    *dst = v;
-                }
+            for (int r = 0; r < NACC; r++) {
+                const int j = (MF == 32) ? ((r & 3) + 8 * (r >> 2) + 4 * g) : (4 * g + r);
+                const int col = n0 + (wn * NI + ni) * MF + j;
+                if (GENERIC && col >= N) continue;
+                float* dst = p.c_row_major ? p.C + (int64_t)(td.c_row + row) * p.ldc + col
+                                           : p.C + (int64_t)(td.c_row + row) + (int64_t)col * p.ldc;
+                float v = acc[mi][ni][r];
+                if (p.accumulate) v += *dst;
+                *dst = v;
             }
         }
     }
@@ -358,7 +441,8 @@ struct sparta_vbs {
     float* d_A = nullptr;
     int32_t* d_jab = nullptr;
     TileDesc* d_tiles[4] = {nullptr, nullptr, nullptr, nullptr};   // classes 16, 32, 64, 128
-    int64_t n_tiles[4] = {0, 0, 0, 0};
+    int64_t n_tiles[4] = {0, 0, 0, 0};       // launch entries (real tiles + padding)
+    int64_t n_real_tiles[4] = {0, 0, 0, 0};
     BlockRowDesc* d_brows = nullptr;
     int64_t n_brows = 0;
     int64_t exec_area = 0;
@@ -375,11 +459,22 @@ struct sparta_vbs {
 
 namespace {
 
-template <int MF, int WM, int WN, int MI, int NI>
+template <int MF, int WM, int WN, int MI, int NI, int KP, bool BRM, bool GENERIC>
 void launch_class(const SpmmParams& p, hipStream_t st) {
     if (p.n_tiles == 0) return;
     const int64_t grid = (int64_t)p.n_tiles * p.n_ntiles;
-    hipLaunchKernelGGL((vbs_spmm_f32_kernel<MF, WM, WN, MI, NI>), dim3((unsigned)grid), dim3(kThreads), 0, st, p);
+    hipLaunchKernelGGL((vbs_spmm_f32_kernel<MF, WM, WN, MI, NI, KP, BRM, GENERIC>), dim3((unsigned)grid), dim3(kThreads), 0, st, p);
+}
+
+bool force_generic() { const char* e = std::getenv("SPARTA_FORCE_GENERIC"); return e && e[0] == '1'; }
+
+template <bool BRM, bool GENERIC>
+void launch_tile_class(int c, const SpmmParams& p, hipStream_t st) {
+    switch (c) {
+        case 0: launch_class<16, 1, 4, 1, 2, kKP, BRM, GENERIC>(p, st); break;   // <=16 x 128, 16x16x4 MFMA
+        case 1: launch_class<32, 1, 4, 1, 1, kKP, BRM, GENERIC>(p, st); break;   // <=32 x 128
+        default: launch_class<32, 2, 2, 1, 2, kKP, BRM, GENERIC>(p, st); break;  // <=64 x 128
+    }
 }
 
 int ensure_scratch(void** ptr, size_t* have, size_t need) {
@@ -474,11 +569,12 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
                     const int64_t rem = h - r0;
                     int cls;
                     int64_t mt;
-                    if (rem > 64) { cls = 3; mt = std::min<int64_t>(rem, 128); }
-                    else if (rem > 32) { cls = 2; mt = rem; }
+                    if (rem > 32) { cls = 2; mt = std::min<int64_t>(rem, 64); }
                     else if (rem > 16) { cls = 1; mt = rem; }
                     else { cls = 0; mt = rem; }
-                    TileDesc t{mo2 + r0, jo2, (int32_t)nb, (int32_t)h, (int32_t)(row_part[ib] - row0 + r0), (int32_t)mt};
+                    const bool tail = (cols % w != 0) && nb > 0 && jab[jab_lo + jo2 + nb - 1] == block_cols - 1;
+                    TileDesc t{mo2 + r0, jo2, (int32_t)nb, (int32_t)h, (int32_t)(row_part[ib] - row0 + r0),
+                               (int32_t)mt | (tail ? TILE_TAIL : 0)};
                     tiles[cls].push_back(t);
                     const int64_t padded = cls == 0 ? 16 : ((mt + 31) / 32) * 32;
                     exec_area += padded * w * nb;
@@ -487,6 +583,41 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
             }
             jo2 += nb;
             mo2 += nb * h * w;
+        }
+    }
+
+    // ---- schedule: per class, 8 contiguous chunks of ~equal cost (one per XCD: neighbouring block-rows gather the
+    // same B panels, so they should share an L2), each chunk sorted by descending cost (the hardware hands workgroups
+    // to free slots in blockIdx order => longest-processing-time-first per XCD), interleaved so that entry t is XCD
+    // t % 8's (t / 8)-th item; short chunks are padded with empty tiles (nb = 0, mt = 0: nothing loaded or stored).
+    int64_t n_real[4];
+    for (int c = 0; c < 4; c++) n_real[c] = (int64_t)tiles[c].size();
+    {
+        const char* ord = std::getenv("SPARTA_TILE_ORDER");
+        const bool natural = ord && std::strcmp(ord, "natural") == 0;
+        for (int c = 0; c < 4; c++) {
+            std::vector<TileDesc>& L = tiles[c];
+            if (L.empty()) continue;
+            const int64_t rows_pad = c == 0 ? 16 : (c == 1 ? 32 : 64);
+            auto cost = [&](const TileDesc& t) { return (int64_t)t.nb * rows_pad + rows_pad / 4; };
+            int64_t total = 0;
+            for (const TileDesc& t : L) total += cost(t);
+            std::vector<std::vector<TileDesc>> chunk(8);
+            int64_t acc_cost = 0;
+            for (const TileDesc& t : L) {
+                int x = (int)std::min<int64_t>(7, (acc_cost * 8) / std::max<int64_t>(total, 1));
+                chunk[(size_t)x].push_back(t);
+                acc_cost += cost(t);
+            }
+            size_t maxlen = 0;
+            for (auto& ch : chunk) {
+                if (!natural) std::stable_sort(ch.begin(), ch.end(), [&](const TileDesc& a, const TileDesc& b) { return cost(a) > cost(b); });
+                maxlen = std::max(maxlen, ch.size());
+            }
+            std::vector<TileDesc> arranged(maxlen * 8, TileDesc{0, 0, 0, 1, 0, 0});
+            for (size_t x = 0; x < 8; x++)
+                for (size_t j = 0; j < chunk[x].size(); j++) arranged[j * 8 + x] = chunk[x][j];
+            L.swap(arranged);
         }
     }
 
@@ -516,6 +647,7 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
     CREATE_TRY(hipMemcpy(v->d_jab, jab32.data(), jab32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     for (int c = 0; c < 4; c++) {
         v->n_tiles[c] = (int64_t)tiles[c].size();
+        v->n_real_tiles[c] = n_real[c];
         if (tiles[c].empty()) continue;
         CREATE_TRY(hipMalloc((void**)&v->d_tiles[c], tiles[c].size() * sizeof(TileDesc)));
         CREATE_TRY(hipMemcpy(v->d_tiles[c], tiles[c].data(), tiles[c].size() * sizeof(TileDesc), hipMemcpyHostToDevice));
@@ -546,7 +678,7 @@ int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info) {
     if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_info: NULL argument");
     std::memset(info, 0, 16 * sizeof(int64_t));
     info[0] = A->rows; info[1] = A->cols; info[2] = A->block_rows; info[3] = A->w; info[4] = A->nblocks; info[5] = A->nztot;
-    for (int c = 0; c < 4; c++) info[6 + c] = A->n_tiles[c];
+    for (int c = 0; c < 4; c++) info[6 + c] = A->n_real_tiles[c];
     info[10] = A->a_bytes; info[11] = A->exec_area;
     return SPARTA_OK;
 }
@@ -606,18 +738,16 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
         const char* nv = std::getenv("SPARTA_NO_VEC");
         p.vec_ok = (nv && nv[0] == '1') ? 0 : 1;
         const bool prof = A->class_timing;
+        // the branch-free kernels need full panels: w a multiple of the panel depth, N a multiple of the slab width
+        const bool generic = !p.vec_ok || (A->w % kKP) != 0 || (n_cols % kTN) != 0 || force_generic();
         for (int c = 3; c >= 0; c--) {              // heavy classes first
             A->class_ran[c] = false;
             if (A->n_tiles[c] == 0) continue;
             if (A->n_tiles[c] * (int64_t)p.n_ntiles > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: grid too large");
             p.tiles = A->d_tiles[c]; p.n_tiles = (int32_t)A->n_tiles[c];
             if (prof) HIP_TRY(hipEventRecord(A->cev[c][0], st));
-            switch (c) {
-                case 0: launch_class<16, 1, 4, 1, 2>(p, st); break;   //  16 x 128
-                case 1: launch_class<32, 1, 4, 1, 1>(p, st); break;   //  32 x 128
-                case 2: launch_class<32, 2, 2, 1, 2>(p, st); break;   //  64 x 128
-                default: launch_class<32, 2, 2, 2, 2>(p, st); break;  // 128 x 128
-            }
+            if (generic) { if (p.b_row_major) launch_tile_class<true, true>(c, p, st); else launch_tile_class<false, true>(c, p, st); }
+            else { if (p.b_row_major) launch_tile_class<true, false>(c, p, st); else launch_tile_class<false, false>(c, p, st); }
             if (prof) { HIP_TRY(hipEventRecord(A->cev[c][1], st)); A->class_ran[c] = true; }
         }
     }
