@@ -19,6 +19,7 @@ for tau, fixed in cfgs:
     d.set_class_timing(True)
     ts, cls = [], []
     for _ in range(30):
-        ts.append(d.spmm(B, C, N, timed=True)); cls.append(list(d.class_times().values()))
+        ts.append(d.spmm(B, C, N, timed=True)); cls.append(list(d.class_times().values())[:2])
     t = float(np.median(ts)); c = np.median(np.array(cls), axis=0)
-    print('tau=%s fixed=%s: %.1f us exec %.1f TF useful %.2f TF | class us %s' % (tau, fixed, t * 1e3, 2 * vb.nztot * N / t / 1e9, 2 * m.nztot() * N / t / 1e9, np.round(c * 1e3, 1)))
+    i = d.info()
+    print('tau=%s fixed=%s: %.1f us exec %.1f TF useful %.2f TF | kernels us %s | steps %d workers %d split %d path %d' % (tau, fixed, t * 1e3, 2 * vb.nztot * N / t / 1e9, 2 * m.nztot() * N / t / 1e9, np.round(c * 1e3, 1), i['stream_steps'], i['stream_workers'], i['split_tiles'], i['last_path']))

@@ -29,6 +29,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "host_core.hpp"
@@ -38,6 +39,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned: global_load_dwordx4 on any float address
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
 constexpr int kTN = 128;   // columns of C per workgroup
@@ -372,6 +374,337 @@ __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_kernel(const SpmmParams
     }
 }
 
+// =====================================================================================================
+// Persistent "stream" kernel -- the product path for w % 32 == 0, N % 128 == 0.
+//
+// Why: a VBS multiply on one MI355X is a few thousand short tiles (a block-row tile has ~10 nonzero blocks).
+// Launching one workgroup per tile loses a third of the machine to (i) the exposed descriptor -> jab ->
+// first-panel latency chain at the start of every tile and (ii) quantisation (4 tiles of uneven length per CU).
+// Here the host flattens all tiles into ONE sequence of 32-deep "steps" (tile after tile, block after
+// block) and cuts it into P = 2 x #CU contiguous ranges of equal modelled cost; worker p (a persistent
+// 256-thread workgroup) streams through its range with a software pipeline that never drains at a tile
+// boundary:
+//        G(i+3): global -> registers (2 register sets, ~2 steps of latency budget)
+//        W(i+1): registers -> LDS stage (i+1)&1        (interleaved between the MFMAs of step i)
+//        C(i)  : ds_read fragments (one round ahead) + v_mfma_f32_32x32x2_f32 from LDS stage i&1
+//        one s_barrier per step.
+// A tile whose steps straddle a range boundary is "split": each worker stores its partial accumulator to a
+// workspace slot and a small fix-up kernel adds the (<= P-1) split tiles' slots in a fixed order -- no
+// atomics, bit-reproducible.  Workers of one XCD get a contiguous range, so neighbouring block-rows (which
+// gather the same B panels) share an L2; A is streamed with non-temporal loads so it does not evict B.
+// Wave v owns columns [32v, 32v+32) of the 128-column slab and one or two 32-row MFMA tiles (rows 0-31,
+// 32-63 when the tile has more than 32 rows).
+// =====================================================================================================
+constexpr int SK_KP = 32;                 // k depth of a step
+constexpr int SK_TM = 64;                 // max rows of a tile
+constexpr int32_t STEP_FIRST = 1 << 16;   // first step of a (segment of a) tile: accumulators start at zero
+constexpr int32_t STEP_LAST = 1 << 17;    // last step of a (segment of a) tile: run the epilogue
+constexpr int32_t STEP_SPLIT = 1 << 18;   // the tile is shared with another worker: epilogue goes to the workspace
+constexpr int32_t STEP_TAIL = 1 << 19;    // panel of the zero-padded last block column: read from StreamParams::B_tail, b_row = k offset in it
+constexpr int SK_SLOT_FLOATS = 32 * kThreads;   // one partial accumulator image: 32 registers x 256 threads
+
+struct StepRec {                          // 32 bytes, one per (block, 32-deep k slice), in execution order
+    int64_t a_off;                        // element offset into A of (tile row 0, first k of this step)
+    int32_t b_row;                        // first row of B of this step's panel (jb * w + ks)
+    int32_t h;                            // leading dimension of the A block (block-row height)
+    int32_t c_row;                        // first row of C of the tile
+    int32_t mt_flags;                     // rows of the tile (low 16 bits) | STEP_* flags
+    int32_t slot;                         // workspace slot for STEP_LAST|STEP_SPLIT, else -1
+    int32_t pad;
+};
+static_assert(sizeof(StepRec) == 32, "StepRec must stay 32 bytes");
+
+struct FixRec {                           // one per split tile
+    int32_t c_row, mt;
+    int32_t slot_begin, n_slots;          // its partial images: fix_slots[slot_begin .. slot_begin + n_slots)
+};
+
+struct StreamParams {
+    const StepRec* steps;
+    const int32_t* worker_range;          // [2 * P]: begin, end step of every worker
+    const float* A;
+    const float* B;
+    const float* B_tail;                  // zero-padded copy of B's last (partial) block row: w x N, ld = w (col-major) / N (row-major)
+    float* C;
+    float* ws;                            // partial images: [n_ntiles][2 * P][SK_SLOT_FLOATS]
+    int64_t ldb, ldc, cols;
+    int64_t shard_rows, shard_stride;
+    int64_t ws_slab_stride;               // floats between the workspaces of consecutive 128-column slabs
+    int32_t accumulate, c_row_major;
+    int32_t N, w;
+};
+
+// D[j][i] register image -> C.  lane: i = lane & 31 (row), g = lane >> 5; register r: j = (r&3) + 8(r>>2) + 4g.
+__device__ __forceinline__ void sk_store_tile(const f32x16& acc0, const f32x16& acc1, int mt, int c_row, int col0, float* C,
+                                              int64_t ldc, int c_row_major, int accumulate, int lm, int g) {
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++) {
+        const int row = mi * 32 + lm;
+        if (row >= mt) continue;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int col = col0 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            float* dst = c_row_major ? C + (int64_t)(c_row + row) * ldc + col : C + (int64_t)(c_row + row) + (int64_t)col * ldc;
+            float v = mi == 0 ? acc0[r] : acc1[r];
+            if (accumulate) v += *dst;
+            *dst = v;
+        }
+    }
+}
+
+// Instruction budget of the loop.  On gfx950 v_mfma_f32_32x32x2_f32 runs on the SIMD's fp32 vector datapath (it has
+// exactly the fp32 VALU rate): LDS and vector-memory instructions issue underneath a running MFMA, ordinary VALU
+// instructions do NOT -- every v_add/v_cndmask/v_readlane of either co-resident wave takes the pipe away from the
+// MFMAs (measured: scripts/ubench/mfma_overlap.hip, 8 VALU ops per 2 MFMAs = +23 %).  So the steady state keeps
+// VALU work near zero: all per-step quantities live in SGPRs (records arrive through v_readlane, cursors advance on
+// the scalar unit), global loads are buffer loads (per-thread byte offset computed once, per-step base in the
+// scalar descriptor / soffset), LDS addresses are per-thread constants plus immediates (stage parity is a template
+// argument), and the B-tail / gathered-B variations are scalar selects.
+template <bool BRM, bool GATHERED>
+__global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const StreamParams p) {
+    constexpr int KP = SK_KP, TN = kTN, TM = SK_TM;
+    constexpr int LDB = BRM ? TN : KP + 4;          // col-major B: Bs[j][k] (+4: conflict-free ds_read_b128); row-major: Bs[k][j]
+    constexpr int BSZ = BRM ? KP * TN : TN * (KP + 4);
+    constexpr int STAGE = BSZ + KP * TM;            // floats per LDS stage (B panel + A slice As[k][i])
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 31, g = lane >> 5;
+    const int n0 = blockIdx.y * TN;
+    const int s_begin = p.worker_range[2 * blockIdx.x];
+    const int n = p.worker_range[2 * blockIdx.x + 1] - s_begin;
+    if (n <= 0) return;
+    float* ws = p.ws + (int64_t)blockIdx.y * p.ws_slab_stride;
+
+    // ---- step records, read COALESCED and kept in registers -----------------------------------------------
+    // A record is 8 dwords; one 256-byte wave load brings 8 consecutive records into one VGPR (lane = 8*rec + field)
+    // and v_readlane hands a field to the scalar unit when its step comes up.  Two such VGPRs (batches b, b+1) cover
+    // the pipeline's look-ahead of 3 steps; a batch is requested 5+ steps before its first use, so the control stream
+    // never waits on memory and issues no scalar load (SMEM shares lgkmcnt with LDS and returns out of order: one
+    // pending s_load turns every fragment wait into lgkmcnt(0)).
+    const int32_t* srec = reinterpret_cast<const int32_t*>(p.steps + s_begin);
+    int vrec0 = srec[lane];
+    int vrec1 = srec[64 + lane];
+    auto field = [&](int s, int f) -> int32_t {
+        const int ln = ((s & 7) << 3) + f;
+        const int32_t x0 = __builtin_amdgcn_readlane(vrec0, ln), x1 = __builtin_amdgcn_readlane(vrec1, ln);
+        return ((s >> 3) & 1) ? x1 : x0;
+    };
+    enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6 };
+
+    // per-thread constant byte offsets (the only vector part of any address in the loop)
+    const int bj0 = tid >> 3, bk = (tid & 7) * 4;       // col-major B: column bj0 + 32q, k = bk..bk+3   (q = 0..3)
+    const int rk0 = tid >> 5, rj = (tid & 31) * 4;      // row-major B: k = rk0 + 8q, columns rj..rj+3
+    const int ak0 = tid >> 4, ai = (tid & 15) * 4;      // A: k = ak0 + 16q (q = 0..1), rows ai..ai+3
+    const int64_t ld_t = BRM ? (int64_t)p.N : (int64_t)p.w;                      // leading dimension of B_tail
+    const uint32_t voffB = BRM ? (uint32_t)((rk0 * p.ldb + rj) * 4) : (uint32_t)((bk + bj0 * p.ldb) * 4);
+    const uint32_t voffBt = BRM ? (uint32_t)((rk0 * ld_t + n0 + rj) * 4) : (uint32_t)((bk + (n0 + bj0) * ld_t) * 4);
+    const uint32_t qstepB = (uint32_t)((BRM ? 8 : 32) * p.ldb * 4), qstepBt = (uint32_t)((BRM ? 8 : 32) * ld_t * 4);
+    const int64_t n0off = BRM ? (int64_t)n0 : (int64_t)n0 * p.ldb;               // slab offset folded into the scalar base
+    const uint32_t lwB = BRM ? (uint32_t)((rk0 * LDB + rj) * 4) : (uint32_t)((bj0 * LDB + bk) * 4);   // LDS write offsets (bytes)
+    const uint32_t lwA = (uint32_t)((BSZ + ak0 * TM + ai) * 4);
+    const uint32_t lrA = (uint32_t)((BSZ + 4 * g * TM + lm) * 4);                                    // LDS read offsets
+    const uint32_t lrB = BRM ? (uint32_t)((4 * g * LDB + 32 * wave + lm) * 4) : (uint32_t)(((32 * wave + lm) * LDB + 4 * g) * 4);
+    const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 32 * wave + 4 * g) * 4) : (uint32_t)((lm + (32 * wave + 4 * g) * p.ldc) * 4);
+    char* const ldsb = reinterpret_cast<char*>(lds);
+
+    u32x4 b0[4], a0[2], b1[4], a1[2];                   // register sets 0 / 1 of the staging pipeline (raw bits)
+
+    // ---- G: global -> registers; steps are requested strictly in order s = 0, 1, 2, ... ----------------------
+    int64_t g_aoff = 0;                                  // scalar cursor of the G stage
+    int32_t g_h = 1;
+    auto issue_loads = [&](int s, u32x4 (&rb)[4], u32x4 (&ra)[2]) {
+        const int32_t flags = field(s, F_FLAGS);
+        if (flags & STEP_FIRST) {                        // tile (segment) start: re-seat the cursor, else it just advances
+            g_aoff = (int64_t)(uint32_t)field(s, F_AOFF_LO) | ((int64_t)field(s, F_AOFF_HI) << 32);
+            g_h = field(s, F_H);
+        } else {
+            g_aoff += (int64_t)KP * g_h;                 // consecutive steps of a block-row are contiguous in A (column-major blocks back to back)
+        }
+        const bool tail = (flags & STEP_TAIL) != 0;
+        int64_t gk0 = field(s, F_BROW);
+        const float* Bbase = tail ? p.B_tail : p.B;
+        if constexpr (GATHERED) {                        // slab index is wave-uniform; a panel never straddles slabs (shard_rows % w == 0)
+            const int64_t sh = gk0 / p.shard_rows;
+            Bbase += sh * p.shard_stride;
+            gk0 -= sh * p.shard_rows;
+        }
+        const float* bptr = tail ? Bbase + (BRM ? gk0 * ld_t : gk0) : Bbase + (BRM ? gk0 * p.ldb : gk0) + n0off;
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bptr), 0, 0x7ffffff0, 0x00020000);
+        const uint32_t vo = tail ? voffBt : voffB, qs = tail ? qstepBt : qstepB;
+#pragma unroll
+        for (int q = 0; q < 4; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo, qs * q, 0);
+        // A slice: 16-byte loads along the rows of a column, streamed (nt: read exactly once).  Rows past the tile read
+        // what follows in memory (next rows / next column / the pad behind A): never stored.
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + g_aoff), 0, 0x7ffffff0, 0x00020000);
+        const uint32_t voA = (uint32_t)(ak0 * g_h + ai) * 4u;
+        ra[0] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA, 0, 2);
+        ra[1] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA, (uint32_t)(16 * g_h) * 4u, 2);
+    };
+
+    // ---- W: registers -> LDS stage (compile-time stage => immediate offsets) -----------------------------------
+    auto write_b = [&](auto stage_tag, const u32x4 (&rb)[4], int q) {
+        constexpr int ST = decltype(stage_tag)::value;
+        *reinterpret_cast<u32x4*>(ldsb + lwB + (ST * STAGE + (BRM ? 8 * q * LDB : 32 * q * LDB)) * 4) = rb[q];
+    };
+    auto write_a = [&](auto stage_tag, const u32x4 (&ra)[2], int q) {
+        constexpr int ST = decltype(stage_tag)::value;
+        *reinterpret_cast<u32x4*>(ldsb + lwA + (ST * STAGE + 16 * q * TM) * 4) = ra[q];
+    };
+
+    // ---- C: fragments + MFMA ------------------------------------------------------------------------------
+    struct Frag { float a[2][4]; f32x4 b; };
+    auto read_frag = [&](auto stage_tag, int kb, const bool mi2) {
+        constexpr int ST = decltype(stage_tag)::value;
+        Frag f;
+        const float* as = reinterpret_cast<const float*>(ldsb + lrA + (ST * STAGE + kb * TM) * 4);
+#pragma unroll
+        for (int m = 0; m < 4; m++) f.a[0][m] = as[m * TM];
+        if (mi2) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) f.a[1][m] = as[m * TM + 32];
+        }
+        if constexpr (!BRM) {
+            f.b = *reinterpret_cast<const f32x4*>(ldsb + lrB + (ST * STAGE + kb) * 4);
+        } else {
+            const float* bs = reinterpret_cast<const float*>(ldsb + lrB + (ST * STAGE + kb * LDB) * 4);
+#pragma unroll
+            for (int m = 0; m < 4; m++) f.b[m] = bs[m * LDB];
+        }
+        return f;
+    };
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    auto mfma4 = [&](const Frag& f, const bool mi2) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[m], f.a[0][m], acc0, 0, 0, 0);
+            if (mi2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[m], f.a[1][m], acc1, 0, 0, 0);
+        }
+    };
+
+    // one pipeline iteration: compute step i from stage PAR; write step i+1 (register set wb/wa) into stage 1-PAR
+    // between the MFMA rounds; refill that register set with step i+3.  The step list is padded on the host, so steps
+    // i+1 .. i+3 always exist (at a range end they are the next worker's: loaded, never multiplied).
+    auto iteration_t = [&](int i, int32_t flags, u32x4 (&wb)[4], u32x4 (&wa)[2], auto par_tag, auto mi2_tag) {
+        constexpr bool mi2 = decltype(mi2_tag)::value;
+        constexpr int PAR = decltype(par_tag)::value;
+        using cur_t = std::integral_constant<int, PAR>;
+        using nxt_t = std::integral_constant<int, 1 - PAR>;
+        Frag f0 = read_frag(cur_t{}, 0, mi2);
+        Frag f1 = read_frag(cur_t{}, 8, mi2);
+        write_b(nxt_t{}, wb, 0); write_b(nxt_t{}, wb, 1);
+        mfma4(f0, mi2);
+        f0 = read_frag(cur_t{}, 16, mi2);
+        write_b(nxt_t{}, wb, 2); write_b(nxt_t{}, wb, 3);
+        mfma4(f1, mi2);
+        f1 = read_frag(cur_t{}, 24, mi2);
+        write_a(nxt_t{}, wa, 0); write_a(nxt_t{}, wa, 1);
+        mfma4(f0, mi2);
+        issue_loads(i + 3, wb, wa);
+        mfma4(f1, mi2);
+        if (flags & STEP_LAST) {
+            // epilogue: scalar descriptor + scalar per-register offsets, the per-thread part is a kernel-lifetime constant.
+            // The accumulators are cleared HERE (every segment start follows a segment end), not at STEP_FIRST: a
+            // conditional clear at the top of the step is if-converted into 32 v_cndmask per step.
+            if (flags & STEP_SPLIT) {
+                const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_SLOT) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc0[q]), rW, (uint32_t)tid * 4u, (uint32_t)(q * kThreads * 4), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1[q]), rW, (uint32_t)tid * 4u, (uint32_t)((16 + q) * kThreads * 4), 0);
+                }
+            } else {
+                const int mt = flags & 0xffff;
+                const int64_t c_row = field(i, F_CROW);
+                float* cbase = p.c_row_major ? p.C + c_row * p.ldc + n0 : p.C + c_row + (int64_t)n0 * p.ldc;
+                const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
+                const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;          // bytes per output column
+                const uint32_t mistep = p.c_row_major ? (uint32_t)p.ldc * 128u : 128u;     // bytes per 32 rows
+#pragma unroll
+                for (int mi = 0; mi < (mi2 ? 2 : 1); mi++) {
+                    if (mi * 32 + lm < mt) {
+#pragma unroll
+                        for (int q = 0; q < 16; q++) {
+                            const uint32_t so = (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep;
+                            float v = mi == 0 ? acc0[q] : acc1[q];
+                            if (p.accumulate) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rC, voffC, so, 0));
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rC, voffC, so, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
+        }
+        __syncthreads();
+    };
+    auto iteration = [&](int i, u32x4 (&wb)[4], u32x4 (&wa)[2], auto par_tag) {
+        const int32_t flags = field(i, F_FLAGS);
+        if ((flags & 0xffff) > 32) iteration_t(i, flags, wb, wa, par_tag, std::true_type{});
+        else iteration_t(i, flags, wb, wa, par_tag, std::false_type{});
+    };
+
+    // ---- prologue: G(0) G(1) | W(0) | G(2) ------------------------------------------------------------------
+    using st0 = std::integral_constant<int, 0>;
+    using st1 = std::integral_constant<int, 1>;
+    issue_loads(0, b0, a0);
+    issue_loads(1, b1, a1);
+#pragma unroll
+    for (int q = 0; q < 4; q++) write_b(st0{}, b0, q);
+#pragma unroll
+    for (int q = 0; q < 2; q++) write_a(st0{}, a0, q);
+    issue_loads(2, b0, a0);
+    __syncthreads();
+    // step i computes from stage i&1; the register set that holds step i+1 is set (i+1)&1
+    for (int i = 0; i < n; i += 2) {
+        if ((i & 7) == 0 && i > 0) {
+            // steps 8k .. 8k+7 begin: batch k+1 replaces batch k-1 (last touched 5 steps ago: look-ahead is 3)
+            const int nb = (i >> 3) + 1;
+            const int v = srec[(int64_t)nb * 64 + lane];
+            if (nb & 1) vrec1 = v; else vrec0 = v;
+        }
+        iteration(i, b1, a1, st0{});
+        if (i + 1 >= n) break;
+        iteration(i + 1, b0, a0, st1{});
+    }
+}
+
+// adds the partial images of every split tile (fixed order: worker order) and writes the tile
+__global__ __launch_bounds__(kThreads) void vbs_spmm_f32_fixup_kernel(const FixRec* fix, const int32_t* fix_slots, const float* ws_all,
+                                                                      int64_t ws_slab_stride, float* C, int64_t ldc, int c_row_major,
+                                                                      int accumulate) {
+    const FixRec fr = fix[blockIdx.x];
+    const float* ws = ws_all + (int64_t)blockIdx.y * ws_slab_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 31, g = lane >> 5;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int q = 0; q < 16; q++) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
+    for (int s = 0; s < fr.n_slots; s++) {
+        const float* img = ws + (int64_t)fix_slots[fr.slot_begin + s] * SK_SLOT_FLOATS + tid;
+#pragma unroll
+        for (int q = 0; q < 16; q++) { acc0[q] += img[q * kThreads]; acc1[q] += img[(16 + q) * kThreads]; }
+    }
+    sk_store_tile(acc0, acc1, fr.mt, fr.c_row, blockIdx.y * kTN + 32 * wave, C, ldc, c_row_major, accumulate, lm, g);
+}
+
+// zero-padded copy of the rows of B that face the last (partial) block column: B_tail[k][j], k < w
+__global__ __launch_bounds__(kThreads) void vbs_tail_copy_kernel(const float* B, int64_t ldb, int b_row_major, int64_t row0, int64_t cols,
+                                                                 int w, int N, float* B_tail) {
+    const int64_t total = (int64_t)w * N;
+    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kThreads) {
+        if (b_row_major) {
+            const int64_t k = idx / N, j = idx % N;
+            B_tail[idx] = row0 + k < cols ? B[(row0 + k) * ldb + j] : 0.0f;
+        } else {
+            const int64_t j = idx / w, k = idx % w;
+            B_tail[idx] = row0 + k < cols ? B[row0 + k + j * ldb] : 0.0f;
+        }
+    }
+}
+
 // ---- exact-order kernel (parity aid) -----------------------------------------------------------------
 // One thread per element of C; the sum runs block by block, k ascending, with an UNFUSED multiply and
 // add -- the operation order and rounding of the reference's loop nest (src/general/vbr.cpp:358-363,
@@ -451,6 +784,19 @@ struct sparta_vbs {
     hipEvent_t cev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     bool class_timing = false;
     bool class_ran[4] = {false, false, false, false};
+    // stream plan (w % 32 == 0): see vbs_spmm_f32_stream_kernel
+    StepRec* d_steps = nullptr;
+    int32_t* d_wrange = nullptr;
+    FixRec* d_fix = nullptr;
+    int32_t* d_fix_slots = nullptr;
+    int64_t n_steps = 0;
+    int32_t n_workers = 0, n_fix = 0, n_split = 0;
+    void* d_ws = nullptr;
+    size_t d_ws_bytes = 0;
+    bool has_tail = false;                 // cols % w != 0: the stream path needs B_tail
+    void* d_btail = nullptr;
+    size_t d_btail_bytes = 0;
+    int last_path = 0;                     // 1: stream kernel, 2: per-class generic kernels
     void* d_B = nullptr;
     size_t d_B_bytes = 0;
     void* d_C = nullptr;
@@ -493,6 +839,12 @@ void destroy_impl(sparta_vbs* v) {
     for (int c = 0; c < 4; c++)
         if (v->d_tiles[c]) (void)hipFree(v->d_tiles[c]);
     if (v->d_brows) (void)hipFree(v->d_brows);
+    if (v->d_steps) (void)hipFree(v->d_steps);
+    if (v->d_wrange) (void)hipFree(v->d_wrange);
+    if (v->d_fix) (void)hipFree(v->d_fix);
+    if (v->d_fix_slots) (void)hipFree(v->d_fix_slots);
+    if (v->d_ws) (void)hipFree(v->d_ws);
+    if (v->d_btail) (void)hipFree(v->d_btail);
     if (v->d_B) (void)hipFree(v->d_B);
     if (v->d_C) (void)hipFree(v->d_C);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -621,6 +973,116 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
         }
     }
 
+    // ---- stream plan (persistent kernel): flatten tiles into 32-deep steps, cut into equal-cost worker ranges ----
+    std::vector<StepRec> steps;
+    std::vector<int32_t> wrange;
+    std::vector<FixRec> fix;
+    std::vector<int32_t> fix_slots;
+    int n_workers = 0, n_split = 0;
+    if (w % SK_KP == 0) {
+        hipDeviceProp_t prop;
+        int cus = 256;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        int per_cu = 2;
+        if (const char* e = std::getenv("SPARTA_WORKERS_PER_CU")) per_cu = std::max(1, std::min(3, atoi(e)));
+        n_workers = ((cus * per_cu + 7) / 8) * 8;
+        // modelled cost of a step (two / one 32-row MFMA tile per wave) and of a tile's epilogue
+        int c2 = 20, c1 = 13, ct = 6;
+        if (const char* e = std::getenv("SPARTA_COST_MODEL")) sscanf(e, "%d,%d,%d", &c2, &c1, &ct);
+        struct TileSpan { int64_t first, last; int32_t c_row, mt; };     // step range of a tile
+        std::vector<TileSpan> spans;
+        std::vector<int64_t> cum;                                        // cumulative cost BEFORE step s
+        int64_t total_cost = 0;
+        {
+            int64_t jo2 = 0, mo2 = 0;
+            const int64_t row0 = row_part[br0];
+            for (int64_t ib = br0; ib < br1; ib++) {
+                const int64_t h = row_part[ib + 1] - row_part[ib];
+                const int64_t nb = nzcount[ib];
+                for (int64_t r0 = 0; r0 < h; r0 += SK_TM) {
+                    const int32_t mt = (int32_t)std::min<int64_t>(SK_TM, h - r0);
+                    const int32_t c_row = (int32_t)(row_part[ib] - row0 + r0);
+                    if (nb == 0) {                                      // nothing to multiply: the fix-up kernel writes the zeros
+                        fix.push_back(FixRec{c_row, mt, 0, 0});
+                        continue;
+                    }
+                    TileSpan sp{(int64_t)steps.size(), 0, c_row, mt};
+                    for (int64_t b = 0; b < nb; b++) {
+                        const int64_t jb = jab[jab_lo + jo2 + b];
+                        for (int64_t ks = 0; ks < w; ks += SK_KP) {
+                            StepRec r;
+                            r.a_off = mo2 + r0 + (b * w + ks) * h;
+                            r.b_row = (int32_t)(jb * w + ks);
+                            r.h = (int32_t)h;
+                            r.c_row = c_row;
+                            r.mt_flags = mt;
+                            if ((jb + 1) * w > cols) { r.mt_flags |= STEP_TAIL; r.b_row = (int32_t)ks; }   // read from the zero-padded B_tail
+                            r.slot = -1;
+                            r.pad = 0;
+                            cum.push_back(total_cost);
+                            total_cost += mt > 32 ? c2 : c1;
+                            steps.push_back(r);
+                        }
+                    }
+                    total_cost += ct;
+                    sp.last = (int64_t)steps.size() - 1;
+                    steps[(size_t)sp.first].mt_flags |= STEP_FIRST;
+                    steps[(size_t)sp.last].mt_flags |= STEP_LAST;
+                    spans.push_back(sp);
+                }
+                jo2 += nb;
+                mo2 += nb * h * w;
+            }
+        }
+        if ((int64_t)cols * 1 > INT32_MAX || (int64_t)steps.size() > INT32_MAX)
+            return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: matrix too large for 32-bit step indexing");
+        const int64_t S = (int64_t)steps.size();
+        cum.push_back(total_cost);
+        // boundaries: worker (x, j) = the j-th of the P/8 sub-ranges of XCD x's eighth; workgroup id = x + 8 j
+        const int per_x = n_workers / 8;
+        std::vector<int64_t> bnd((size_t)n_workers + 1, S);
+        bnd[0] = 0;
+        for (int k = 1; k < n_workers; k++) {
+            const int64_t target = total_cost * k / n_workers;
+            int64_t pos = std::lower_bound(cum.begin(), cum.end(), target) - cum.begin();
+            bnd[(size_t)k] = std::min<int64_t>(std::max(pos, bnd[(size_t)k - 1]), S);
+        }
+        wrange.assign((size_t)n_workers * 2, 0);
+        std::vector<int32_t> wid_of_pos((size_t)n_workers);
+        for (int pos = 0; pos < n_workers; pos++) {
+            const int x = pos / per_x, j = pos % per_x;
+            const int wid = x + 8 * j;
+            wid_of_pos[(size_t)pos] = wid;
+            wrange[(size_t)wid * 2] = (int32_t)bnd[(size_t)pos];
+            wrange[(size_t)wid * 2 + 1] = (int32_t)bnd[(size_t)pos + 1];
+        }
+        // segments: a tile cut by a boundary is split; every segment writes one workspace image
+        size_t ti = 0;
+        for (int pos = 0; pos < n_workers; pos++) {
+            const int64_t s0 = bnd[(size_t)pos], s1 = bnd[(size_t)pos + 1];
+            if (s0 >= s1) continue;
+            const int wid = wid_of_pos[(size_t)pos];
+            while (ti < spans.size() && spans[ti].last < s0) ti++;
+            for (size_t t = ti; t < spans.size() && spans[t].first < s1; t++) {
+                const int64_t a = std::max(spans[t].first, s0), b = std::min(spans[t].last, s1 - 1);
+                const bool whole = a == spans[t].first && b == spans[t].last;
+                steps[(size_t)a].mt_flags |= STEP_FIRST;
+                steps[(size_t)b].mt_flags |= STEP_LAST;
+                if (!whole) {
+                    const int32_t slot = 2 * wid + (a == s0 ? 0 : 1);
+                    steps[(size_t)b].mt_flags |= STEP_SPLIT;
+                    steps[(size_t)b].slot = slot;
+                    if (a == spans[t].first) {                          // first segment of the tile opens its fix-up record
+                        fix.push_back(FixRec{spans[t].c_row, spans[t].mt, (int32_t)fix_slots.size(), 0});
+                        n_split++;
+                    }
+                    fix_slots.push_back(slot);
+                    fix.back().n_slots++;
+                }
+            }
+        }
+    }
+
     sparta_vbs* v = new (std::nothrow) sparta_vbs;
     if (!v) return fail(SPARTA_ERR_ALLOC, "sparta_vbs_create: out of host memory");
     v->device = device; v->dtype = dtype;
@@ -657,6 +1119,25 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
         CREATE_TRY(hipMalloc((void**)&v->d_brows, brows.size() * sizeof(BlockRowDesc)));
         CREATE_TRY(hipMemcpy(v->d_brows, brows.data(), brows.size() * sizeof(BlockRowDesc), hipMemcpyHostToDevice));
     }
+    if (!steps.empty() || !fix.empty()) {
+        v->n_steps = (int64_t)steps.size();
+        v->has_tail = (cols % w) != 0;
+        if (!steps.empty())                      // the pipeline prefetches up to 5 records past a range end: pad with harmless copies
+            for (int k = 0; k < 24; k++) { StepRec d = steps[(size_t)v->n_steps - 1]; d.mt_flags = (d.mt_flags & ~(STEP_LAST | STEP_SPLIT)) | STEP_FIRST; steps.push_back(d); }
+        v->n_workers = n_workers; v->n_fix = (int32_t)fix.size(); v->n_split = n_split;
+        if (!steps.empty()) {
+            CREATE_TRY(hipMalloc((void**)&v->d_steps, steps.size() * sizeof(StepRec)));
+            CREATE_TRY(hipMemcpy(v->d_steps, steps.data(), steps.size() * sizeof(StepRec), hipMemcpyHostToDevice));
+        }
+        CREATE_TRY(hipMalloc((void**)&v->d_wrange, std::max<size_t>(wrange.size(), 2) * sizeof(int32_t)));
+        if (!wrange.empty()) CREATE_TRY(hipMemcpy(v->d_wrange, wrange.data(), wrange.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (!fix.empty()) {
+            CREATE_TRY(hipMalloc((void**)&v->d_fix, fix.size() * sizeof(FixRec)));
+            CREATE_TRY(hipMemcpy(v->d_fix, fix.data(), fix.size() * sizeof(FixRec), hipMemcpyHostToDevice));
+        }
+        CREATE_TRY(hipMalloc((void**)&v->d_fix_slots, std::max<size_t>(fix_slots.size(), 1) * sizeof(int32_t)));
+        if (!fix_slots.empty()) CREATE_TRY(hipMemcpy(v->d_fix_slots, fix_slots.data(), fix_slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     CREATE_TRY(hipEventCreate(&v->ev0));
     CREATE_TRY(hipEventCreate(&v->ev1));
 #undef CREATE_TRY
@@ -680,6 +1161,7 @@ int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info) {
     info[0] = A->rows; info[1] = A->cols; info[2] = A->block_rows; info[3] = A->w; info[4] = A->nblocks; info[5] = A->nztot;
     for (int c = 0; c < 4; c++) info[6 + c] = A->n_real_tiles[c];
     info[10] = A->a_bytes; info[11] = A->exec_area;
+    info[12] = A->n_steps; info[13] = A->n_workers; info[14] = A->n_split; info[15] = A->last_path;
     return SPARTA_OK;
 }
 
@@ -728,7 +1210,44 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                                A->d_A, dB, dC, ldb, ldc, A->cols, (int)n_cols, (int)A->w, (int)(b_layout == SPARTA_ROW_MAJOR),
                                (int)(c_layout == SPARTA_ROW_MAJOR), (int)accumulate, shard_rows, shard_stride);
         }
+    } else if (A->n_workers > 0 && (n_cols % kTN) == 0 && !force_generic() && !(std::getenv("SPARTA_NO_VEC") && std::getenv("SPARTA_NO_VEC")[0] == '1')) {
+        // ---- product path: persistent stream kernel + fix-up of the split tiles -------------------------------
+        const int n_nt = n_cols / kTN;
+        const size_t slab = (size_t)2 * A->n_workers * SK_SLOT_FLOATS;
+        if (A->n_split > 0)
+            if (int rc = ensure_scratch(&A->d_ws, &A->d_ws_bytes, slab * n_nt * sizeof(float))) return rc;
+        StreamParams sp;
+        sp.steps = A->d_steps; sp.worker_range = A->d_wrange; sp.A = A->d_A; sp.B = dB; sp.C = dC; sp.ws = (float*)A->d_ws;
+        sp.ldb = ldb; sp.ldc = ldc; sp.cols = A->cols; sp.shard_rows = shard_rows; sp.shard_stride = shard_stride;
+        sp.ws_slab_stride = (int64_t)slab; sp.accumulate = accumulate != 0; sp.c_row_major = c_layout == SPARTA_ROW_MAJOR;
+        const bool prof = A->class_timing;
+        for (int c = 0; c < 4; c++) A->class_ran[c] = false;
+        sp.N = n_cols; sp.w = (int32_t)A->w; sp.B_tail = nullptr;
+        if (A->n_steps > 0) {
+            if (prof) HIP_TRY(hipEventRecord(A->cev[0][0], st));
+            if (A->has_tail && shard_rows == 0) {
+                if (int rc = ensure_scratch(&A->d_btail, &A->d_btail_bytes, (size_t)A->w * n_cols * sizeof(float))) return rc;
+                const int64_t row0 = ((A->cols - 1) / A->w) * A->w;
+                hipLaunchKernelGGL(vbs_tail_copy_kernel, dim3(32), dim3(kThreads), 0, st, dB, ldb, (int)(b_layout == SPARTA_ROW_MAJOR), row0,
+                                   A->cols, (int)A->w, (int)n_cols, (float*)A->d_btail);
+                sp.B_tail = (const float*)A->d_btail;
+            }
+            const dim3 grid((unsigned)A->n_workers, (unsigned)n_nt);
+            if (shard_rows > 0) hipLaunchKernelGGL((vbs_spmm_f32_stream_kernel<false, true>), grid, dim3(kThreads), 0, st, sp);
+            else if (b_layout == SPARTA_ROW_MAJOR) hipLaunchKernelGGL((vbs_spmm_f32_stream_kernel<true, false>), grid, dim3(kThreads), 0, st, sp);
+            else hipLaunchKernelGGL((vbs_spmm_f32_stream_kernel<false, false>), grid, dim3(kThreads), 0, st, sp);
+            if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
+        }
+        if (A->n_fix > 0) {
+            if (prof) HIP_TRY(hipEventRecord(A->cev[1][0], st));
+            hipLaunchKernelGGL(vbs_spmm_f32_fixup_kernel, dim3((unsigned)A->n_fix, (unsigned)n_nt), dim3(kThreads), 0, st, A->d_fix,
+                               A->d_fix_slots, (const float*)A->d_ws, (int64_t)slab, dC, ldc, (int)(c_layout == SPARTA_ROW_MAJOR),
+                               (int)(accumulate != 0));
+            if (prof) { HIP_TRY(hipEventRecord(A->cev[1][1], st)); A->class_ran[1] = true; }
+        }
+        A->last_path = 1;
     } else {
+        A->last_path = 2;
         SpmmParams p;
         p.jab = A->d_jab; p.A = A->d_A; p.B = dB; p.C = dC; p.ldb = ldb; p.ldc = ldc; p.cols = A->cols;
         p.n_ntiles = (n_cols + kTN - 1) / kTN; p.N = n_cols; p.w = (int32_t)A->w;
@@ -739,15 +1258,15 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
         p.vec_ok = (nv && nv[0] == '1') ? 0 : 1;
         const bool prof = A->class_timing;
         // the branch-free kernels need full panels: w a multiple of the panel depth, N a multiple of the slab width
-        const bool generic = !p.vec_ok || (A->w % kKP) != 0 || (n_cols % kTN) != 0 || force_generic();
+        const bool generic = true;   // the branch-free fast path is the stream kernel above
         for (int c = 3; c >= 0; c--) {              // heavy classes first
             A->class_ran[c] = false;
             if (A->n_tiles[c] == 0) continue;
             if (A->n_tiles[c] * (int64_t)p.n_ntiles > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: grid too large");
             p.tiles = A->d_tiles[c]; p.n_tiles = (int32_t)A->n_tiles[c];
             if (prof) HIP_TRY(hipEventRecord(A->cev[c][0], st));
-            if (generic) { if (p.b_row_major) launch_tile_class<true, true>(c, p, st); else launch_tile_class<false, true>(c, p, st); }
-            else { if (p.b_row_major) launch_tile_class<true, false>(c, p, st); else launch_tile_class<false, false>(c, p, st); }
+            (void)generic;
+            if (p.b_row_major) launch_tile_class<true, true>(c, p, st); else launch_tile_class<false, true>(c, p, st);
             if (prof) { HIP_TRY(hipEventRecord(A->cev[c][1], st)); A->class_ran[c] = true; }
         }
     }
