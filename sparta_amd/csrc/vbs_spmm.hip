@@ -30,6 +30,7 @@
 #include <new>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "host_core.hpp"
@@ -593,18 +594,29 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
         constexpr int PAR = decltype(par_tag)::value;
         using cur_t = std::integral_constant<int, PAR>;
         using nxt_t = std::integral_constant<int, 1 - PAR>;
+        // The order below is pinned with sched_barrier: left alone, the scheduler sinks every fragment read next to its
+        // MFMA and the loop pays one LDS round trip per MFMA pair.  Pinned, the fragments of round r+1 are requested
+        // before the MFMAs of round r are issued, and the LDS writes / global loads ride in the same gaps.
         Frag f0 = read_frag(cur_t{}, 0, mi2);
         Frag f1 = read_frag(cur_t{}, 8, mi2);
         write_b(nxt_t{}, wb, 0); write_b(nxt_t{}, wb, 1);
+        __builtin_amdgcn_sched_barrier(0);
         mfma4(f0, mi2);
+        __builtin_amdgcn_sched_barrier(0);
         f0 = read_frag(cur_t{}, 16, mi2);
         write_b(nxt_t{}, wb, 2); write_b(nxt_t{}, wb, 3);
+        __builtin_amdgcn_sched_barrier(0);
         mfma4(f1, mi2);
+        __builtin_amdgcn_sched_barrier(0);
         f1 = read_frag(cur_t{}, 24, mi2);
         write_a(nxt_t{}, wa, 0); write_a(nxt_t{}, wa, 1);
+        __builtin_amdgcn_sched_barrier(0);
         mfma4(f0, mi2);
+        __builtin_amdgcn_sched_barrier(0);
         issue_loads(i + 3, wb, wa);
+        __builtin_amdgcn_sched_barrier(0);
         mfma4(f1, mi2);
+        __builtin_amdgcn_sched_barrier(0);
         if (flags & STEP_LAST) {
             // epilogue: scalar descriptor + scalar per-register offsets, the per-thread part is a kernel-lifetime constant.
             // The accumulators are cleared HERE (every segment start follows a segment end), not at STEP_FIRST: a
@@ -796,7 +808,12 @@ struct sparta_vbs {
     bool has_tail = false;                 // cols % w != 0: the stream path needs B_tail
     void* d_btail = nullptr;
     size_t d_btail_bytes = 0;
-    int last_path = 0;                     // 1: stream kernel, 2: per-class generic kernels
+    int last_path = 0;                     // 1: stream kernel, 2: per-class branch-free kernels, 3: per-class generic kernels
+    std::vector<std::pair<int64_t, int>> tuned;   // (n_cols/layout key) -> measured best path
+    float tune_ms[2] = {0.0f, 0.0f};
+    void* d_tune = nullptr;
+    size_t d_tune_bytes = 0;
+    hipEvent_t tev0 = nullptr, tev1 = nullptr;
     void* d_B = nullptr;
     size_t d_B_bytes = 0;
     void* d_C = nullptr;
@@ -845,6 +862,9 @@ void destroy_impl(sparta_vbs* v) {
     if (v->d_fix_slots) (void)hipFree(v->d_fix_slots);
     if (v->d_ws) (void)hipFree(v->d_ws);
     if (v->d_btail) (void)hipFree(v->d_btail);
+    if (v->d_tune) (void)hipFree(v->d_tune);
+    if (v->tev0) (void)hipEventDestroy(v->tev0);
+    if (v->tev1) (void)hipEventDestroy(v->tev1);
     if (v->d_B) (void)hipFree(v->d_B);
     if (v->d_C) (void)hipFree(v->d_C);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -1140,6 +1160,8 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
     }
     CREATE_TRY(hipEventCreate(&v->ev0));
     CREATE_TRY(hipEventCreate(&v->ev1));
+    CREATE_TRY(hipEventCreate(&v->tev0));
+    CREATE_TRY(hipEventCreate(&v->tev1));
 #undef CREATE_TRY
     *out = v;
     return SPARTA_OK;
@@ -1210,65 +1232,108 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                                A->d_A, dB, dC, ldb, ldc, A->cols, (int)n_cols, (int)A->w, (int)(b_layout == SPARTA_ROW_MAJOR),
                                (int)(c_layout == SPARTA_ROW_MAJOR), (int)accumulate, shard_rows, shard_stride);
         }
-    } else if (A->n_workers > 0 && (n_cols % kTN) == 0 && !force_generic() && !(std::getenv("SPARTA_NO_VEC") && std::getenv("SPARTA_NO_VEC")[0] == '1')) {
-        // ---- product path: persistent stream kernel + fix-up of the split tiles -------------------------------
-        const int n_nt = n_cols / kTN;
-        const size_t slab = (size_t)2 * A->n_workers * SK_SLOT_FLOATS;
-        if (A->n_split > 0)
-            if (int rc = ensure_scratch(&A->d_ws, &A->d_ws_bytes, slab * n_nt * sizeof(float))) return rc;
-        StreamParams sp;
-        sp.steps = A->d_steps; sp.worker_range = A->d_wrange; sp.A = A->d_A; sp.B = dB; sp.C = dC; sp.ws = (float*)A->d_ws;
-        sp.ldb = ldb; sp.ldc = ldc; sp.cols = A->cols; sp.shard_rows = shard_rows; sp.shard_stride = shard_stride;
-        sp.ws_slab_stride = (int64_t)slab; sp.accumulate = accumulate != 0; sp.c_row_major = c_layout == SPARTA_ROW_MAJOR;
+    } else {
+        const char* nv = std::getenv("SPARTA_NO_VEC");
+        const bool novec = nv && nv[0] == '1';
+        const int n_nt = (n_cols + kTN - 1) / kTN;
+        const bool full_slabs = (n_cols % kTN) == 0;
+        // two product paths (both branch-free, both need full panels) + the generic fallback for odd shapes
+        const bool can_stream = A->n_workers > 0 && full_slabs && !novec && !force_generic();
+        const bool can_class = (A->w % kKP) == 0 && full_slabs && !novec && !force_generic();
+
+        // persistent stream kernel + fix-up of the split tiles
+        auto run_stream = [&](float* Cout, bool prof) -> int {
+            const size_t slab = (size_t)2 * A->n_workers * SK_SLOT_FLOATS;
+            if (A->n_split > 0)
+                if (int rc = ensure_scratch(&A->d_ws, &A->d_ws_bytes, slab * n_nt * sizeof(float))) return rc;
+            StreamParams sp;
+            sp.steps = A->d_steps; sp.worker_range = A->d_wrange; sp.A = A->d_A; sp.B = dB; sp.C = Cout; sp.ws = (float*)A->d_ws;
+            sp.ldb = ldb; sp.ldc = ldc; sp.cols = A->cols; sp.shard_rows = shard_rows; sp.shard_stride = shard_stride;
+            sp.ws_slab_stride = (int64_t)slab; sp.accumulate = accumulate != 0; sp.c_row_major = c_layout == SPARTA_ROW_MAJOR;
+            sp.N = n_cols; sp.w = (int32_t)A->w; sp.B_tail = nullptr;
+            if (A->n_steps > 0) {
+                if (prof) HIP_TRY(hipEventRecord(A->cev[0][0], st));
+                if (A->has_tail && shard_rows == 0) {
+                    if (int rc = ensure_scratch(&A->d_btail, &A->d_btail_bytes, (size_t)A->w * n_cols * sizeof(float))) return rc;
+                    const int64_t row0 = ((A->cols - 1) / A->w) * A->w;
+                    hipLaunchKernelGGL(vbs_tail_copy_kernel, dim3(32), dim3(kThreads), 0, st, dB, ldb, (int)(b_layout == SPARTA_ROW_MAJOR),
+                                       row0, A->cols, (int)A->w, (int)n_cols, (float*)A->d_btail);
+                    sp.B_tail = (const float*)A->d_btail;
+                }
+                const dim3 grid((unsigned)A->n_workers, (unsigned)n_nt);
+                if (shard_rows > 0) hipLaunchKernelGGL((vbs_spmm_f32_stream_kernel<false, true>), grid, dim3(kThreads), 0, st, sp);
+                else if (b_layout == SPARTA_ROW_MAJOR) hipLaunchKernelGGL((vbs_spmm_f32_stream_kernel<true, false>), grid, dim3(kThreads), 0, st, sp);
+                else hipLaunchKernelGGL((vbs_spmm_f32_stream_kernel<false, false>), grid, dim3(kThreads), 0, st, sp);
+                if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
+            }
+            if (A->n_fix > 0) {
+                if (prof) HIP_TRY(hipEventRecord(A->cev[1][0], st));
+                hipLaunchKernelGGL(vbs_spmm_f32_fixup_kernel, dim3((unsigned)A->n_fix, (unsigned)n_nt), dim3(kThreads), 0, st, A->d_fix,
+                                   A->d_fix_slots, (const float*)A->d_ws, (int64_t)slab, Cout, ldc, (int)(c_layout == SPARTA_ROW_MAJOR),
+                                   (int)(accumulate != 0));
+                if (prof) { HIP_TRY(hipEventRecord(A->cev[1][1], st)); A->class_ran[1] = true; }
+            }
+            return SPARTA_OK;
+        };
+        // one launch per tile class (<=16 / <=32 / <=64 rows), one workgroup per tile
+        auto run_class = [&](float* Cout, bool generic, bool prof) -> int {
+            SpmmParams p;
+            p.jab = A->d_jab; p.A = A->d_A; p.B = dB; p.C = Cout; p.ldb = ldb; p.ldc = ldc; p.cols = A->cols;
+            p.n_ntiles = n_nt; p.N = n_cols; p.w = (int32_t)A->w;
+            p.b_row_major = b_layout == SPARTA_ROW_MAJOR; p.c_row_major = c_layout == SPARTA_ROW_MAJOR;
+            p.accumulate = accumulate != 0;
+            p.shard_rows = shard_rows; p.shard_stride = shard_stride;
+            p.vec_ok = novec ? 0 : 1;
+            for (int c = 3; c >= 0; c--) {              // heavy classes first
+                if (A->n_tiles[c] == 0) continue;
+                if (A->n_tiles[c] * (int64_t)p.n_ntiles > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: grid too large");
+                p.tiles = A->d_tiles[c]; p.n_tiles = (int32_t)A->n_tiles[c];
+                if (prof) HIP_TRY(hipEventRecord(A->cev[c][0], st));
+                if (generic) { if (p.b_row_major) launch_tile_class<true, true>(c, p, st); else launch_tile_class<false, true>(c, p, st); }
+                else { if (p.b_row_major) launch_tile_class<true, false>(c, p, st); else launch_tile_class<false, false>(c, p, st); }
+                if (prof) { HIP_TRY(hipEventRecord(A->cev[c][1], st)); A->class_ran[c] = true; }
+            }
+            return SPARTA_OK;
+        };
+
+        // ---- choose the path: forced by SPARTA_PATH, else measured once per (n_cols, layouts, gathered) on this handle -------
+        int path = 3;                                   // 1 stream, 2 per-class fast, 3 generic
+        const char* pe = std::getenv("SPARTA_PATH");
+        const std::string forced = pe ? pe : "auto";
+        if (forced == "stream") path = can_stream ? 1 : 3;
+        else if (forced == "class") path = can_class ? 2 : 3;
+        else if (forced == "generic") path = 3;
+        else if (can_stream && can_class) {
+            const int64_t key = ((int64_t)n_cols << 8) | (b_layout << 2) | (c_layout << 1) | (shard_rows > 0 ? 1 : 0);
+            path = 0;
+            for (const auto& kv : A->tuned) if (kv.first == key) path = kv.second;
+            if (path == 0) {
+                // plan-time autotune: both paths write a scratch C (the caller's C must not be accumulated into twice)
+                if (int rc = ensure_scratch(&A->d_tune, &A->d_tune_bytes, c_elems * sizeof(float))) return rc;
+                float best[3] = {0.0f, 1e30f, 1e30f};
+                for (int cand = 1; cand <= 2; cand++) {
+                    for (int rep = 0; rep < 4; rep++) {
+                        HIP_TRY(hipEventRecord(A->tev0, st));
+                        if (int rc = cand == 1 ? run_stream((float*)A->d_tune, false) : run_class((float*)A->d_tune, false, false)) return rc;
+                        HIP_TRY(hipEventRecord(A->tev1, st));
+                        HIP_TRY(hipEventSynchronize(A->tev1));
+                        float ms = 0.0f;
+                        HIP_TRY(hipEventElapsedTime(&ms, A->tev0, A->tev1));
+                        if (rep > 0) best[cand] = std::min(best[cand], ms);
+                    }
+                }
+                path = best[1] <= best[2] ? 1 : 2;
+                A->tuned.emplace_back(key, path);
+                A->tune_ms[0] = best[1]; A->tune_ms[1] = best[2];
+            }
+        } else if (can_stream) path = 1;
+        else if (can_class) path = 2;
+
         const bool prof = A->class_timing;
         for (int c = 0; c < 4; c++) A->class_ran[c] = false;
-        sp.N = n_cols; sp.w = (int32_t)A->w; sp.B_tail = nullptr;
-        if (A->n_steps > 0) {
-            if (prof) HIP_TRY(hipEventRecord(A->cev[0][0], st));
-            if (A->has_tail && shard_rows == 0) {
-                if (int rc = ensure_scratch(&A->d_btail, &A->d_btail_bytes, (size_t)A->w * n_cols * sizeof(float))) return rc;
-                const int64_t row0 = ((A->cols - 1) / A->w) * A->w;
-                hipLaunchKernelGGL(vbs_tail_copy_kernel, dim3(32), dim3(kThreads), 0, st, dB, ldb, (int)(b_layout == SPARTA_ROW_MAJOR), row0,
-                                   A->cols, (int)A->w, (int)n_cols, (float*)A->d_btail);
-                sp.B_tail = (const float*)A->d_btail;
-            }
-            const dim3 grid((unsigned)A->n_workers, (unsigned)n_nt);
-            if (shard_rows > 0) hipLaunchKernelGGL((vbs_spmm_f32_stream_kernel<false, true>), grid, dim3(kThreads), 0, st, sp);
-            else if (b_layout == SPARTA_ROW_MAJOR) hipLaunchKernelGGL((vbs_spmm_f32_stream_kernel<true, false>), grid, dim3(kThreads), 0, st, sp);
-            else hipLaunchKernelGGL((vbs_spmm_f32_stream_kernel<false, false>), grid, dim3(kThreads), 0, st, sp);
-            if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
-        }
-        if (A->n_fix > 0) {
-            if (prof) HIP_TRY(hipEventRecord(A->cev[1][0], st));
-            hipLaunchKernelGGL(vbs_spmm_f32_fixup_kernel, dim3((unsigned)A->n_fix, (unsigned)n_nt), dim3(kThreads), 0, st, A->d_fix,
-                               A->d_fix_slots, (const float*)A->d_ws, (int64_t)slab, dC, ldc, (int)(c_layout == SPARTA_ROW_MAJOR),
-                               (int)(accumulate != 0));
-            if (prof) { HIP_TRY(hipEventRecord(A->cev[1][1], st)); A->class_ran[1] = true; }
-        }
-        A->last_path = 1;
-    } else {
-        A->last_path = 2;
-        SpmmParams p;
-        p.jab = A->d_jab; p.A = A->d_A; p.B = dB; p.C = dC; p.ldb = ldb; p.ldc = ldc; p.cols = A->cols;
-        p.n_ntiles = (n_cols + kTN - 1) / kTN; p.N = n_cols; p.w = (int32_t)A->w;
-        p.b_row_major = b_layout == SPARTA_ROW_MAJOR; p.c_row_major = c_layout == SPARTA_ROW_MAJOR;
-        p.accumulate = accumulate != 0;
-        p.shard_rows = shard_rows; p.shard_stride = shard_stride;
-        const char* nv = std::getenv("SPARTA_NO_VEC");
-        p.vec_ok = (nv && nv[0] == '1') ? 0 : 1;
-        const bool prof = A->class_timing;
-        // the branch-free kernels need full panels: w a multiple of the panel depth, N a multiple of the slab width
-        const bool generic = true;   // the branch-free fast path is the stream kernel above
-        for (int c = 3; c >= 0; c--) {              // heavy classes first
-            A->class_ran[c] = false;
-            if (A->n_tiles[c] == 0) continue;
-            if (A->n_tiles[c] * (int64_t)p.n_ntiles > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: grid too large");
-            p.tiles = A->d_tiles[c]; p.n_tiles = (int32_t)A->n_tiles[c];
-            if (prof) HIP_TRY(hipEventRecord(A->cev[c][0], st));
-            (void)generic;
-            if (p.b_row_major) launch_tile_class<true, true>(c, p, st); else launch_tile_class<false, true>(c, p, st);
-            if (prof) { HIP_TRY(hipEventRecord(A->cev[c][1], st)); A->class_ran[c] = true; }
-        }
+        if (path == 1) { if (int rc = run_stream(dC, prof)) return rc; }
+        else if (int rc = run_class(dC, path == 3, prof)) return rc;
+        A->last_path = path;
     }
     HIP_TRY(hipGetLastError());
     if (dt_ms) {

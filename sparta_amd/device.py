@@ -103,7 +103,7 @@ class DeviceVBS:
         check(lib.sparta_vbs_class_times(self.h, a.ctypes.data_as(_f32p)))
         if self.info()["last_path"] == 1:
             return {"stream": float(a[0]), "fixup": float(a[1])}
-        return {16: float(a[0]), 32: float(a[1]), 64: float(a[2]), 128: float(a[3])}
+        return {"class16": float(a[0]), "class32": float(a[1]), "class64": float(a[2])}
 
     def close(self):
         if self.h:

@@ -279,3 +279,101 @@ def test_full_size_properties_config2():
         Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B1h, n, block_row_range=(int(ib), int(ib) + 1)).reshape(n, v.rows)
         bd = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, absA, absB, n, block_row_range=(int(ib), int(ib) + 1)).reshape(n, v.rows)
         _check(C1h[:, r0:r1], Co[:, r0:r1], bd[:, r0:r1], "block-row %d" % ib)
+
+
+# ---- the two branch-free product paths, forced one at a time (SPARTA_PATH), on shapes that qualify for them ----------
+PRODUCT_SHAPES = [
+    # rows, cols, nnz, w, blocking, N          (w % 64 == 0 or w % 32 == 0, N % 128 == 0)
+    (1500, 1500, 60000, 64, ("tau", 0.5), 128),        # clustered, ragged heights, cols % w != 0 (tail block column)
+    (1500, 1500, 60000, 64, ("fixed", 64), 256),       # two 128-column slabs
+    (1000, 2077, 50000, 64, ("tau", 0.7), 128),        # rectangular, tail
+    (2000, 1024, 40000, 128, ("fixed", 100), 128),     # w = 128: two panel steps per block (stream: four)
+    (900, 960, 30000, 32, ("tau", 0.6), 128),          # w = 32: stream path only
+    (3000, 640, 20000, 64, ("keeper", 48), 128),
+    (64, 6400, 30000, 64, ("fixed", 64), 128),         # ONE tile with 100 blocks: split across many stream workers
+]
+
+
+@pytest.mark.parametrize("path", ["stream", "class"])
+@pytest.mark.parametrize("rows,cols,nnz,w,blk,n", PRODUCT_SHAPES)
+def test_product_paths_vs_oracle(monkeypatch, path, rows, cols, nnz, w, blk, n):
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_PATH", path)
+    m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + cols + w + n)
+    if blk[0] == "tau":
+        g = sa.BlockingEngine(tau=blk[1], col_block_size=w).GetGrouping(m)
+    elif blk[0] == "keeper":
+        g = sa.BlockingEngine(tau=0.5, col_block_size=w, row_block_size=blk[1], blocking_algo=5).GetGrouping(m)
+    else:
+        g = np.arange(rows) // blk[1]
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=3)
+    Co = _oracle_c(v, B, n)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+    d = v.to_device(0)
+    Bcm = torch.from_numpy(B).cuda()
+    Brm = torch.from_numpy(np.ascontiguousarray(B.reshape(n, v.cols).T).reshape(-1)).cuda()
+    want_path = {"stream": 1, "class": 2}[path]
+    if path == "class" and w % 64 != 0:
+        want_path = 3                      # the per-class branch-free kernels need w % 64 == 0: falls back to generic
+    for bl, Bt in ((sa.COL_MAJOR, Bcm), (sa.ROW_MAJOR, Brm)):
+        for cl in (sa.COL_MAJOR, sa.ROW_MAJOR):
+            Ct = torch.full((v.rows * n,), 5.0, dtype=torch.float32, device="cuda")
+            d.spmm(Bt, Ct, n, accumulate=False, b_layout=bl, c_layout=cl)
+            torch.cuda.synchronize()
+            assert d.info()["last_path"] == want_path
+            got = Ct.cpu().numpy()
+            if cl == sa.ROW_MAJOR:
+                got = np.ascontiguousarray(got.reshape(v.rows, n).T).reshape(-1)
+            _check(got, Co, bound, "%s layouts %d %d" % (path, bl, cl))
+    # reference semantics: accumulate onto a non-zero C
+    C0 = sa.gen.dense_rhs(v.rows, n, seed=9)
+    Ct = torch.from_numpy(C0).cuda()
+    d.spmm(Bcm, Ct, n, accumulate=True)
+    torch.cuda.synchronize()
+    _check(Ct.cpu().numpy(), C0 + Co, bound + np.abs(C0), path + " accumulate")
+    # bit-reproducible (no atomics anywhere, split tiles are summed in a fixed order)
+    C1 = torch.empty(v.rows * n, dtype=torch.float32, device="cuda"); d.spmm(Bcm, C1, n)
+    C2 = torch.empty(v.rows * n, dtype=torch.float32, device="cuda"); d.spmm(Bcm, C2, n)
+    torch.cuda.synchronize()
+    assert torch.equal(C1, C2)
+
+
+@pytest.mark.parametrize("path", ["stream", "class", "auto"])
+def test_gathered_b_product_paths(monkeypatch, path):
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_PATH", path)
+    world, w, n = 4, 64, 128
+    slabs = [sa.gen.fem3d_slab(4, 4, 12, r, world, dof=3, pad_to=w, seed=4) for r in range(world)]
+    n_pad = slabs[0][2]
+    gathered = np.concatenate([sa.gen.dense_rhs(n_pad, n, seed=50 + r) for r in range(world)])
+    Bfull = sa.dist.gathered_to_colmajor(gathered, world, n_pad, n)
+    for r, (m, n_local, _) in enumerate(slabs):
+        g = sa.BlockingEngine(tau=0.4, col_block_size=w).GetGrouping(m)
+        v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+        Co = _oracle_c(v, Bfull, n)
+        d = v.to_device(0)
+        Ct = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
+        d.spmm_gathered(torch.from_numpy(gathered).cuda(), n_pad, Ct, n)
+        torch.cuda.synchronize()
+        _check(Ct.cpu().numpy(), Co, U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, Bfull, n), "gathered %s rank %d" % (path, r))
+        assert d.info()["last_path"] in (1, 2)
+
+
+def test_autotune_picks_a_product_path_and_is_stable():
+    torch = _torch()
+    m = sa.gen.fem3d(6, 6, 40, 3, seed=3)
+    v = sa.VBR().fill_from_CSR_inplace_fixed(m, 64, 64)
+    d = v.to_device(0)
+    n = 128
+    B = torch.from_numpy(sa.gen.dense_rhs(v.cols, n, seed=1)).cuda()
+    C = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
+    C[:] = 1.0
+    d.spmm(B, C, n, accumulate=True)            # first call measures both paths on a SCRATCH C: ours is accumulated once
+    torch.cuda.synchronize()
+    p1 = d.info()["last_path"]
+    assert p1 in (1, 2)
+    Co = _oracle_c(v, B.cpu().numpy(), n) + 1.0
+    _check(C.cpu().numpy(), Co, U.abs_bound(v.rows, v.cols, 64, v.row_part, v.nzcount, v.jab, v.mab, B.cpu().numpy(), n) + 1.0, "autotune")
+    d.spmm(B, C, n)
+    assert d.info()["last_path"] == p1
