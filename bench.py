@@ -49,7 +49,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--tau", type=float, default=0.2)
+    ap.add_argument("--tau", type=float, default=0.6)
+    ap.add_argument("--algo", type=int, default=5, help="reference BlockingType: 3 iterative_clocked, 5 iterative_max_size (Keeper)")
+    ap.add_argument("--row-block", type=int, default=32, help="max / fixed block-row height (-B)")
+    ap.add_argument("--force-fixed", type=int, default=1, help="-F: re-chunk clusters into equal heights")
     ap.add_argument("--col-block", type=int, default=64)
     ap.add_argument("--ncols", type=int, default=128)
     ap.add_argument("--fixed-height", type=int, default=0, help="reorder OFF: fixed block-row height instead of clustering")
@@ -90,11 +93,12 @@ def main():
     if args.fixed_height:
         eng = sa.BlockingEngine(blocking_algo="fixed_size", row_block_size=args.fixed_height, col_block_size=w)
     else:
-        eng = sa.BlockingEngine(blocking_algo="iterative_clocked", tau=args.tau, col_block_size=w, sim_measure=1)
+        eng = sa.BlockingEngine(blocking_algo=args.algo, tau=args.tau, col_block_size=w, row_block_size=args.row_block,
+                                force_fixed_size=bool(args.force_fixed), sim_measure=1)
     grouping = eng.GetGrouping(m)
     t_reorder = time.time() - t0
     t0 = time.time()
-    vb = sa.VBR().fill_from_CSR_inplace(m, grouping, w)
+    vb = sa.VBR().fill_from_CSR_inplace(m, grouping, w, args.row_block, bool(args.force_fixed) and not args.fixed_height)
     t_build = time.time() - t0
     d = vb.to_device(local_rank)
     info = d.info()
@@ -134,16 +138,16 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
 
-    # ---- per-kernel device time (HIP events on the launch stream, one class per kernel instantiation) ----------
+    # ---- per-kernel device time (HIP events on the launch stream, one pair per kernel launch) ----------------------
     d.set_class_timing(True)
-    cls_ms = {16: [], 32: [], 64: [], 128: []}
+    kt = {}
     for _ in range(min(args.steps, 50)):
         step()
-        ct = d.class_times()
-        for k in cls_ms:
-            cls_ms[k].append(ct[k])
+        for k, v in d.class_times().items():
+            kt.setdefault(k, []).append(v)
     d.set_class_timing(False)
-    cls_avg = {k: float(np.mean(v)) for k, v in cls_ms.items()}
+    kernel_ms = {k: float(np.mean(v)) for k, v in kt.items()}
+    path = {1: "stream", 2: "class", 3: "generic"}.get(d.info()["last_path"], "?")
 
     nnz_local = m.nztot()
     nnz_total = nnz_local
@@ -160,35 +164,42 @@ def main():
 
     # ---- roofline of the dominant kernel (rank 0's launch) ------------------------------------------------------
     h = np.diff(vb.row_part)
-    heights = {16: 16, 32: 32, 64: 64, 128: 128}
-    dom = max(cls_avg, key=lambda k: cls_avg[k])
-    # algorithmic flops of the dominant class = 2 * (stored area of its tiles) * N.  Tiles are cut from block-rows by
-    # height: rows beyond multiples of 128 fall into the class of the remainder (mirrors the plan in vbs_spmm.hip).
-    area_by_cls = {16: 0.0, 32: 0.0, 64: 0.0, 128: 0.0}
+    # stored area handled by each kernel: the stream kernel takes everything; the per-class kernels take the tiles of
+    # their height class (block-rows are cut into <=64-row tiles; a remainder <=32 / <=16 rows goes to the thinner class)
+    area = {"stream": float(vb.nztot), "fixup": 0.0, "class16": 0.0, "class32": 0.0, "class64": 0.0}
     for hh, nb in zip(h, vb.nzcount):
         r = int(hh)
         while r > 0:
-            if r > 64:
-                mt, c = min(r, 128), 128
-            elif r > 32:
-                mt, c = r, 64
-            elif r > 16:
-                mt, c = r, 32
-            else:
-                mt, c = r, 16
-            area_by_cls[c] += float(mt) * w * float(nb)
+            mt = min(r, 64) if r > 32 else r
+            c = "class64" if r > 32 else ("class32" if r > 16 else "class16")
+            area[c] += float(mt) * w * float(nb)
             r -= mt
     t_lb, flops_exec, bytes_alg = mixed_roofline_seconds(vb.row_part, vb.nzcount, w, N, vb.cols)
-    kernel_ms_total = sum(cls_avg.values())
-    dom_tflops = 2.0 * area_by_cls[dom] * N / (cls_avg[dom] * 1e-3) / 1e12 if cls_avg[dom] > 0 else 0.0
+    kernel_ms_total = sum(kernel_ms.values())
+    dom = max(kernel_ms, key=lambda k: kernel_ms[k]) if kernel_ms else "stream"
+    dom_tflops = 2.0 * area.get(dom, 0.0) * N / (kernel_ms[dom] * 1e-3) / 1e12 if kernel_ms.get(dom, 0) > 0 else 0.0
+    kname = {"stream": "vbs_spmm_f32_stream_kernel", "fixup": "vbs_spmm_f32_fixup_kernel", "class16": "vbs_spmm_f32_kernel<16,...>",
+             "class32": "vbs_spmm_f32_kernel<32,1,4,1,1,...>", "class64": "vbs_spmm_f32_kernel<32,2,2,1,2,...>"}.get(dom, dom)
+    # HBM bytes per launch of that kernel from rocprofv3 PMC passes (profiles/traffic.json, produced by
+    # scripts/profile_bench.sh on the same command; FETCH_SIZE doubled per MI355X_MICROARCH.md) -- only reported when the
+    # profiled workload is the one running now
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        wk = tj.get("workload", {})
+        if wk.get("vbs_area") == int(vb.nztot) and wk.get("n_cols") == N and wk.get("kernel_path") == path and world == 1:
+            traffic = round(float(tj["hbm_bytes_per_launch"]))
+    except Exception:
+        traffic = None
     roofline = {
         "bound": "mfma", "achieved": round(dom_tflops, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(dom_tflops / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
-        "kernel": "vbs_spmm_f32_kernel<class %d>" % dom, "kernel_ms": round(cls_avg[dom], 5),
-        "class_ms": {str(k): round(v, 5) for k, v in cls_avg.items()},
+        "frac": round(dom_tflops / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
+        "kernel": kname, "kernel_ms": round(kernel_ms.get(dom, 0.0), 5), "path": path,
+        "kernels_ms": {k: round(v, 5) for k, v in kernel_ms.items()},
         "all_kernels_tflops_exec": round(flops_exec / (kernel_ms_total * 1e-3) / 1e12, 3) if kernel_ms_total > 0 else 0.0,
         "mixed_roofline_frac": round(t_lb / (kernel_ms_total * 1e-3), 4) if kernel_ms_total > 0 else 0.0,
         "algorithmic_gbs": round(bytes_alg / (kernel_ms_total * 1e-3) / 1e9, 1) if kernel_ms_total > 0 else 0.0,
+        "algorithmic_bytes": round(bytes_alg),
     }
 
     # ---- CPU baseline: the reference's own VBR::multiply on this host, 1 thread -----------------------------------
@@ -214,7 +225,7 @@ def main():
                 kind = "reference"
                 rc = ref.RefCSR(m.rows, m.cols, m.rowptr, m.colidx.astype(np.int64), m.vals)
                 if nbr == vb.block_rows:
-                    rv = ref.RefVBR(rc, grouping, w)
+                    rv = ref.RefVBR(rc, grouping, w, args.row_block, bool(args.force_fixed) and not args.fixed_height)
                     t1 = time.perf_counter()
                     rv.multiply(Bh, N)
                     t_cpu = time.perf_counter() - t1
@@ -243,11 +254,13 @@ def main():
                         ("row-partitioned FEM 9x9x%d mesh x 3 dof (%d^2 padded, %d nnz), B = %d cols, fp32, 1 all-gather of B per step"
                          % (257 * world, world * shard_rows, int(nnz_total), N)),
             "reorder": ("fixed height %d (reorder off)" % args.fixed_height) if args.fixed_height else
-                       ("Jaccard iterative_clocked tau=%.2f" % args.tau),
+                       ("Jaccard %s tau=%.2f row_block=%d force_fixed=%d (reference flags -a %d -t %.2f -B %d -F %d -b %d)"
+                        % ({3: "iterative_clocked", 5: "iterative_max_size/Keeper"}.get(args.algo, str(args.algo)), args.tau, args.row_block,
+                           args.force_fixed, args.algo, args.tau, args.row_block, args.force_fixed, w)),
             "col_block_size": w, "n_cols": N, "block_rows": int(vb.block_rows), "nonzero_blocks": int(len(vb.jab)),
             "vbs_area": int(vb.nztot), "fill": round(nnz_local / max(vb.nztot, 1), 4),
             "mean_block_row_height": round(float(h.mean()), 2),
-            "tiles": {"16": info["tiles16"], "32": info["tiles32"], "64": info["tiles64"], "128": info["tiles128"]},
+            "tiles": {"16": info["tiles16"], "32": info["tiles32"], "64": info["tiles64"]}, "kernel_path": path,
             "executed_gflops": round(flops_exec * (n_gpus if world > 1 else 1) / (ms_per_step * 1e-3) / 1e9, 1),
             "host_seconds": {"generate": round(t_gen, 2), "reorder": round(t_reorder, 2), "vbs_build": round(t_build, 2)},
             "parallelism": "row-partition x%d, B all-gather" % world if world > 1 else "single GPU",

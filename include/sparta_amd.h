@@ -61,7 +61,8 @@ extern "C" {
 #define SPARTA_SIM_HAMMING 0
 #define SPARTA_SIM_JACCARD 1
 
-/* kernel selection for sparta_vbs_spmm (`algo` argument) */
+/* kernel selection for sparta_vbs_spmm (`algo` argument).  Within SPARTA_SPMM_MFMA the library picks between its
+ * product paths by measuring them once per (n_cols, layouts) on the handle; env SPARTA_PATH=stream|class|generic forces one. */
 #define SPARTA_SPMM_MFMA  0   /* hand-written MFMA kernels (the product path) */
 #define SPARTA_SPMM_EXACT 1   /* fp32 only: unfused mul+add in the reference's summation order,
                                  bit-identical to VBR::multiply on finite inputs (slow; for parity) */
@@ -188,7 +189,8 @@ int sparta_vbs_spmm_gathered(sparta_vbs_t* A, const void* B_gathered, int64_t sh
 
 /* Per-tile-class device timing for roofline reports: when enabled, sparta_vbs_spmm brackets each class
  * launch with HIP events on the launch stream; sparta_vbs_class_times waits for them and writes the last
- * call's milliseconds for classes {16, 32, 64, 128} (0 for a class with no tiles) into ms_out[4]. */
+ * call's milliseconds into ms_out[4]: stream path -> {stream kernel, fix-up kernel, 0, 0};
+ * per-class / generic path -> {<=16-row class, <=32-row class, <=64-row class, 0}. */
 int sparta_vbs_set_class_timing(sparta_vbs_t* A, int32_t enable);
 int sparta_vbs_class_times(sparta_vbs_t* A, float* ms_out);
 
@@ -196,8 +198,10 @@ int sparta_vbs_destroy(sparta_vbs_t* A);
 
 /* plan / roofline introspection. info_out (int64[16]):
  *  [0] rows [1] cols [2] block_rows [3] block_col_size [4] nblocks [5] nztot (area)
- *  [6] tiles of class 16 [7] class 32 [8] class 64 [9] class 128 [10] device bytes of A
- *  [11] padded MFMA rows summed over (tile, block) pairs x w (executed area) [12..15] reserved */
+ *  [6] tiles of <=16 rows [7] <=32 rows [8] <=64 rows [9] 0 [10] device bytes of A
+ *  [11] padded MFMA rows summed over (tile, block) pairs x w (executed area)
+ *  [12] steps of the stream plan [13] stream workers [14] split tiles
+ *  [15] kernel path of the last sparta_vbs_spmm: 1 stream, 2 per-class, 3 generic */
 int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info_out);
 
 /* number of visible HIP devices (0 when none); never initialises a device context */

@@ -487,6 +487,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
     const int32_t* srec = reinterpret_cast<const int32_t*>(p.steps + s_begin);
     int vrec0 = srec[lane];
     int vrec1 = srec[64 + lane];
+    int vnext = 0;
     auto field = [&](int s, int f) -> int32_t {
         const int ln = ((s & 7) << 3) + f;
         const int32_t x0 = __builtin_amdgcn_readlane(vrec0, ln), x1 = __builtin_amdgcn_readlane(vrec1, ln);
@@ -672,11 +673,12 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
     __syncthreads();
     // step i computes from stage i&1; the register set that holds step i+1 is set (i+1)&1
     for (int i = 0; i < n; i += 2) {
-        if ((i & 7) == 0 && i > 0) {
-            // steps 8k .. 8k+7 begin: batch k+1 replaces batch k-1 (last touched 5 steps ago: look-ahead is 3)
-            const int nb = (i >> 3) + 1;
-            const int v = srec[(int64_t)nb * 64 + lane];
-            if (nb & 1) vrec1 = v; else vrec0 = v;
+        if ((i & 7) == 0 && i > 0) vnext = srec[(int64_t)((i >> 3) + 1) * 64 + lane];   // request batch k+1 at step 8k ...
+        if ((i & 7) == 4 && i > 4) {
+            // ... and only TOUCH it at step 8k+4 (first needed at 8k+5 by the look-ahead of 3): the register it replaces
+            // (batch k-1) is dead by then, and the wait the compiler puts in front of this copy finds the data long landed.
+            // Copying at request time would park the wave on a cold global load every 8 steps.
+            if (((i >> 3) + 1) & 1) vrec1 = vnext; else vrec0 = vnext;
         }
         iteration(i, b1, a1, st0{});
         if (i + 1 >= n) break;
