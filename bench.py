@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--ncols", type=int, default=128)
     ap.add_argument("--fixed-height", type=int, default=0, help="reorder OFF: fixed block-row height instead of clustering")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-path", action="store_true", help="run the multi-GPU code path (slab + all-gather + gathered SpMM) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -75,15 +76,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    distributed = world > 1 or args.dist_path
+    if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     w, N = args.col_block, args.ncols
     t0 = time.time()
     # ---- workload ------------------------------------------------------------------------------------------------
-    if world == 1:
+    if not distributed:
         m = sa.gen.cant_like(seed=2)
         n_local, shard_rows = m.rows, None
     else:
@@ -104,7 +107,7 @@ def main():
     info = d.info()
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    if world == 1:
+    if not distributed:
         B = (torch.rand(vb.cols * N, generator=g, dtype=torch.float32) - 0.5).to(dev)      # column-major, ld = cols
         B_shard = B_gath = None
     else:
@@ -113,14 +116,14 @@ def main():
     C = torch.zeros(vb.rows * N, dtype=torch.float32, device=dev)
 
     def step():
-        if world == 1:
+        if not distributed:
             d.spmm(B, C, N, accumulate=False)
         else:
             dist.all_gather_into_tensor(B_gath, B_shard)          # the one exchange step (RCCL over xGMI)
             d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False)
 
     def fence():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,7 +135,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -151,14 +154,14 @@ def main():
 
     nnz_local = m.nztot()
     nnz_total = nnz_local
-    if world > 1:
+    if distributed:
         tt = torch.tensor([float(nnz_local)], dtype=torch.float64, device=dev)
         dist.all_reduce(tt)
         nnz_total = float(tt.item())
     useful_gflops = 2.0 * nnz_total * N / (ms_per_step * 1e-3) / 1e9
 
     if rank != 0:
-        if world > 1:
+        if distributed:
             dist.destroy_process_group()
         return
 
@@ -187,7 +190,7 @@ def main():
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         wk = tj.get("workload", {})
-        if wk.get("vbs_area") == int(vb.nztot) and wk.get("n_cols") == N and wk.get("kernel_path") == path and world == 1:
+        if wk.get("vbs_area") == int(vb.nztot) and wk.get("n_cols") == N and wk.get("kernel_path") == path and not distributed:
             traffic = round(float(tj["hbm_bytes_per_launch"]))
     except Exception:
         traffic = None
@@ -207,8 +210,7 @@ def main():
     if not args.no_cpu_baseline:
         try:
             from oracle import ref, oracle as O
-            Bh = (B if world == 1 else None)
-            if world == 1:
+            if not distributed:
                 Bh = B.cpu().numpy()
             else:
                 Bh = sa.dist.gathered_to_colmajor(B_gath.cpu().numpy(), world, shard_rows, N)
@@ -250,7 +252,7 @@ def main():
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": ("cant-like FEM 9x9x257 mesh x 3 dof (62451^2, %d nnz), B = %d cols, fp32" % (nnz_local, N)) if world == 1 else
+            "workload": ("cant-like FEM 9x9x257 mesh x 3 dof (62451^2, %d nnz), B = %d cols, fp32" % (nnz_local, N)) if not distributed else
                         ("row-partitioned FEM 9x9x%d mesh x 3 dof (%d^2 padded, %d nnz), B = %d cols, fp32, 1 all-gather of B per step"
                          % (257 * world, world * shard_rows, int(nnz_total), N)),
             "reorder": ("fixed height %d (reorder off)" % args.fixed_height) if args.fixed_height else
@@ -261,15 +263,15 @@ def main():
             "vbs_area": int(vb.nztot), "fill": round(nnz_local / max(vb.nztot, 1), 4),
             "mean_block_row_height": round(float(h.mean()), 2),
             "tiles": {"16": info["tiles16"], "32": info["tiles32"], "64": info["tiles64"]}, "kernel_path": path,
-            "executed_gflops": round(flops_exec * (n_gpus if world > 1 else 1) / (ms_per_step * 1e-3) / 1e9, 1),
+            "executed_gflops": round(flops_exec * world / (ms_per_step * 1e-3) / 1e9, 1),
             "host_seconds": {"generate": round(t_gen, 2), "reorder": round(t_reorder, 2), "vbs_build": round(t_build, 2)},
-            "parallelism": "row-partition x%d, B all-gather" % world if world > 1 else "single GPU",
+            "parallelism": "row-partition x%d, B all-gather" % world if distributed else "single GPU",
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
     print(json.dumps(out))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 
