@@ -14,6 +14,9 @@
  * insertion sort).  The reference's get_permutation (src/general/utilities.cpp:8-20) sorts row indices with
  * it under a comparator that only looks at the group id, so the order of rows INSIDE a group -- and with it
  * the row order of every VBS block -- is whatever that exact algorithm leaves.
+ * Likewise std::set of libstdc++ (bits/stl_tree.h, src/c++98/tree.cc: red-black tree with a header node):
+ * IterativeBlockingKeeper (blocking.cpp:509-511) increments an iterator past end(), so the elements it erases
+ * depend on the tree's shape; the insert / erase rebalancing and the iterator increment are restated below.
  */
 #include "sparta_oracle.h"
 
@@ -453,6 +456,274 @@ static void blocking_plain(long rows, const long* rowptr, const long* colidx, fl
     free(pattern.data); free(merged.data);
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* std::set<std::pair<float,long>> of libstdc++ 11 (bits/stl_tree.h, src/c++98/tree.cc), restated   */
+/* ------------------------------------------------------------------------------------------------ */
+/* IterativeBlockingKeeper trims its candidate set with
+ *       auto it = best.end(); advance(it, k); best.erase(it, best.end());     (blocking.cpp:509-511)
+ * i.e. it increments an iterator PAST end().  That is undefined by the standard but deterministic on
+ * libstdc++: incrementing the header node lands on the right-most node (or its left child) and the walk wraps.
+ * Which elements get erased depends on the SHAPE of the red-black tree, so the oracle has to rebuild the tree
+ * exactly: _Rb_tree_insert_and_rebalance, _Rb_tree_rebalance_for_erase, _Rb_tree_increment as published. */
+typedef struct rbn {
+    int red;
+    struct rbn *parent, *left, *right;
+    float d;
+    long row;
+} rbn;
+typedef struct { rbn header; long count; rbn* pool; long pool_n, pool_cap; rbn* free_list; } rbset;
+
+static int key_less(float d1, long r1, float d2, long r2) { return d1 < d2 || (!(d2 < d1) && r1 < r2); }   /* std::pair operator< */
+
+static void rb_init(rbset* s, long cap)
+{
+    s->header.red = 1; s->header.parent = 0; s->header.left = &s->header; s->header.right = &s->header;
+    s->count = 0; s->pool = (rbn*)malloc(sizeof(rbn) * (size_t)(cap + 1)); s->pool_n = 0; s->pool_cap = cap + 1; s->free_list = 0;
+}
+static void rb_clear(rbset* s)
+{
+    s->header.parent = 0; s->header.left = &s->header; s->header.right = &s->header; s->count = 0; s->pool_n = 0; s->free_list = 0;
+}
+static rbn* rb_alloc(rbset* s)
+{
+    if (s->free_list) { rbn* n = s->free_list; s->free_list = n->parent; return n; }
+    return &s->pool[s->pool_n++];
+}
+static void rb_free_node(rbset* s, rbn* n) { n->parent = s->free_list; s->free_list = n; }
+
+static rbn* rb_increment(rbn* x)                         /* _Rb_tree_increment; also what ++end() does */
+{
+    if (x->right != 0) { x = x->right; while (x->left != 0) x = x->left; }
+    else { rbn* y = x->parent; while (x == y->right) { x = y; y = y->parent; } if (x->right != y) x = y; }
+    return x;
+}
+static rbn* rb_decrement(rbn* x)                         /* _Rb_tree_decrement */
+{
+    if (x->red && x->parent->parent == x) x = x->right;  /* x is the header */
+    else if (x->left != 0) { rbn* y = x->left; while (y->right != 0) y = y->right; x = y; }
+    else { rbn* y = x->parent; while (x == y->left) { x = y; y = y->parent; } x = y; }
+    return x;
+}
+static void rb_rotate_left(rbn* x, rbn** root)
+{
+    rbn* y = x->right;
+    x->right = y->left;
+    if (y->left != 0) y->left->parent = x;
+    y->parent = x->parent;
+    if (x == *root) *root = y; else if (x == x->parent->left) x->parent->left = y; else x->parent->right = y;
+    y->left = x; x->parent = y;
+}
+static void rb_rotate_right(rbn* x, rbn** root)
+{
+    rbn* y = x->left;
+    x->left = y->right;
+    if (y->right != 0) y->right->parent = x;
+    y->parent = x->parent;
+    if (x == *root) *root = y; else if (x == x->parent->right) x->parent->right = y; else x->parent->left = y;
+    y->right = x; x->parent = y;
+}
+static void rb_insert_and_rebalance(int insert_left, rbn* x, rbn* p, rbn* header)
+{
+    rbn** root = &header->parent;
+    x->parent = p; x->left = 0; x->right = 0; x->red = 1;
+    if (insert_left) {
+        p->left = x;
+        if (p == header) { header->parent = x; header->right = x; }
+        else if (p == header->left) header->left = x;
+    } else {
+        p->right = x;
+        if (p == header->right) header->right = x;
+    }
+    while (x != *root && x->parent->red) {
+        rbn* const xpp = x->parent->parent;
+        if (x->parent == xpp->left) {
+            rbn* const y = xpp->right;
+            if (y && y->red) { x->parent->red = 0; y->red = 0; xpp->red = 1; x = xpp; }
+            else {
+                if (x == x->parent->right) { x = x->parent; rb_rotate_left(x, root); }
+                x->parent->red = 0; xpp->red = 1; rb_rotate_right(xpp, root);
+            }
+        } else {
+            rbn* const y = xpp->left;
+            if (y && y->red) { x->parent->red = 0; y->red = 0; xpp->red = 1; x = xpp; }
+            else {
+                if (x == x->parent->left) { x = x->parent; rb_rotate_right(x, root); }
+                x->parent->red = 0; xpp->red = 1; rb_rotate_left(xpp, root);
+            }
+        }
+    }
+    (*root)->red = 0;
+}
+static rbn* rb_rebalance_for_erase(rbn* const z, rbn* header)
+{
+    rbn** root = &header->parent;
+    rbn** leftmost = &header->left;
+    rbn** rightmost = &header->right;
+    rbn* y = z; rbn* x = 0; rbn* x_parent = 0;
+    if (y->left == 0) x = y->right;
+    else if (y->right == 0) x = y->left;
+    else { y = y->right; while (y->left != 0) y = y->left; x = y->right; }
+    if (y != z) {
+        z->left->parent = y; y->left = z->left;
+        if (y != z->right) {
+            x_parent = y->parent;
+            if (x) x->parent = y->parent;
+            y->parent->left = x;
+            y->right = z->right; z->right->parent = y;
+        } else x_parent = y;
+        if (*root == z) *root = y; else if (z->parent->left == z) z->parent->left = y; else z->parent->right = y;
+        y->parent = z->parent;
+        { int t = y->red; y->red = z->red; z->red = t; }
+        y = z;
+    } else {
+        x_parent = y->parent;
+        if (x) x->parent = y->parent;
+        if (*root == z) *root = x; else if (z->parent->left == z) z->parent->left = x; else z->parent->right = x;
+        if (*leftmost == z) {
+            if (z->right == 0) *leftmost = z->parent;
+            else { rbn* m = x; while (m->left != 0) m = m->left; *leftmost = m; }
+        }
+        if (*rightmost == z) {
+            if (z->left == 0) *rightmost = z->parent;
+            else { rbn* m = x; while (m->right != 0) m = m->right; *rightmost = m; }
+        }
+    }
+    if (!y->red) {
+        while (x != *root && (x == 0 || !x->red)) {
+            if (x == x_parent->left) {
+                rbn* w = x_parent->right;
+                if (w->red) { w->red = 0; x_parent->red = 1; rb_rotate_left(x_parent, root); w = x_parent->right; }
+                if ((w->left == 0 || !w->left->red) && (w->right == 0 || !w->right->red)) { w->red = 1; x = x_parent; x_parent = x_parent->parent; }
+                else {
+                    if (w->right == 0 || !w->right->red) { w->left->red = 0; w->red = 1; rb_rotate_right(w, root); w = x_parent->right; }
+                    w->red = x_parent->red; x_parent->red = 0;
+                    if (w->right) w->right->red = 0;
+                    rb_rotate_left(x_parent, root);
+                    break;
+                }
+            } else {
+                rbn* w = x_parent->left;
+                if (w->red) { w->red = 0; x_parent->red = 1; rb_rotate_right(x_parent, root); w = x_parent->left; }
+                if ((w->right == 0 || !w->right->red) && (w->left == 0 || !w->left->red)) { w->red = 1; x = x_parent; x_parent = x_parent->parent; }
+                else {
+                    if (w->left == 0 || !w->left->red) { w->right->red = 0; w->red = 1; rb_rotate_left(w, root); w = x_parent->left; }
+                    w->red = x_parent->red; x_parent->red = 0;
+                    if (w->left) w->left->red = 0;
+                    rb_rotate_right(x_parent, root);
+                    break;
+                }
+            }
+        }
+        if (x) x->red = 0;
+    }
+    return y;
+}
+/* std::set::insert (unique): _M_get_insert_unique_pos + _M_insert_ */
+static void rb_insert_unique(rbset* s, float d, long row)
+{
+    rbn* header = &s->header;
+    rbn* x = header->parent;
+    rbn* y = header;
+    int comp = 1;
+    while (x != 0) { y = x; comp = key_less(d, row, x->d, x->row); x = comp ? x->left : x->right; }
+    rbn* j = y;
+    if (comp) {
+        if (j == header->left) goto do_insert;           /* j == begin() */
+        j = rb_decrement(j);
+    }
+    if (!key_less(j->d, j->row, d, row)) return;          /* equivalent key present */
+do_insert:
+    {
+        const int insert_left = (y == header) || key_less(d, row, y->d, y->row);
+        rbn* z = rb_alloc(s);
+        z->d = d; z->row = row;
+        rb_insert_and_rebalance(insert_left, z, y, header);
+        s->count++;
+    }
+}
+/* std::set::erase(first, end()) : _M_erase_aux(first, last) */
+static void rb_erase_to_end(rbset* s, rbn* first)
+{
+    rbn* header = &s->header;
+    if (first == header->left && s->count > 0 && first != header) {   /* first == begin() && last == end() -> clear() */
+        rb_clear(s);
+        return;
+    }
+    while (first != header) {
+        rbn* cur = first;
+        first = rb_increment(first);
+        rbn* y = rb_rebalance_for_erase(cur, header);
+        rb_free_node(s, y);
+        s->count--;
+    }
+}
+
+/* IterativeBlockingKeeper, src/general/blocking.cpp:433-549 (what `-a 5` runs: dispatch at :655) */
+static void blocking_keeper(long rows, const long* rowptr, const long* colidx, float tau, dist_fn distance, long col_block_size,
+                            long max_row_block_size, int use_pattern, long* grouping, long* comparison_counter, long* merge_counter)
+{
+    for (long i = 0; i < rows; i++) grouping[i] = -1;                                       /* :435 */
+    float* distances = make_distances(rows);                                                /* :436 */
+    lvec pattern = {0, 0, 0}, merged = {0, 0, 0}, merged_rows = {0, 0, 0};
+    rbset best;
+    rb_init(&best, rows);
+    for (long i = 0; i < rows; i++) {                                                       /* :443 */
+        if (grouping[i] != -1) continue;
+        rb_clear(&best);                                                                    /* :447 fresh set per seed */
+        merged_rows.size = 0;
+        const long group_number = i + rows;                                                 /* :450 */
+        long current_group_size = 1;
+        grouping[i] = group_number;
+        lvec_reserve(&merged_rows, 1); merged_rows.data[merged_rows.size++] = i;
+        long ni = rowptr[i + 1] - rowptr[i];
+        lvec_reserve(&pattern, ni);
+        memcpy(pattern.data, colidx + rowptr[i], sizeof(long) * (size_t)ni);
+        pattern.size = ni;
+        for (long j = i + 1; j < rows; j++) {                                               /* :460 */
+            if (current_group_size == max_row_block_size) break;                            /* :463 */
+            if (distances[i] != -1 && distances[j] != -1 && fabsf(distances[i] - distances[j]) > tau) {   /* :469 */
+                distances[j] = -1;
+                continue;
+            }
+            if (grouping[j] != -1) continue;                                                /* :476 */
+            (*comparison_counter)++;
+            const long* row_j = colidx + rowptr[j];
+            long nj = rowptr[j + 1] - rowptr[j];
+            float dist = distance(pattern.data, pattern.size, current_group_size, row_j, nj, 1, col_block_size);   /* :480 */
+            distances[j] = dist;
+            if (dist <= tau) {                                                              /* :484 */
+                (*merge_counter)++;
+                grouping[j] = group_number;
+                lvec_reserve(&merged_rows, merged_rows.size + 1); merged_rows.data[merged_rows.size++] = j;
+                if (use_pattern) {
+                    lvec_reserve(&merged, pattern.size + nj);
+                    merged.size = oracle_merge_rows(pattern.data, pattern.size, row_j, nj, merged.data);
+                    lvec t = pattern; pattern = merged; merged = t;
+                }
+                current_group_size++;                                                       /* :501 */
+            } else {
+                rb_insert_unique(&best, dist, j);                                           /* :505-506 */
+                const unsigned long room = (unsigned long)max_row_block_size - (unsigned long)merged_rows.size;
+                if ((unsigned long)best.count > room) {                                     /* :507 */
+                    rbn* it = &best.header;                                                 /* end() */
+                    for (unsigned long t = 0; t < room; t++) it = rb_increment(it);         /* :510 advance PAST end() */
+                    rb_erase_to_end(&best, it);                                             /* :511 */
+                }
+            }
+        }
+        if (current_group_size < max_row_block_size) {                                      /* :517-525 */
+            for (rbn* it = best.header.left; best.count > 0 && it != &best.header && current_group_size != max_row_block_size; it = rb_increment(it)) {
+                grouping[it->row] = group_number;
+                lvec_reserve(&merged_rows, merged_rows.size + 1); merged_rows.data[merged_rows.size++] = it->row;
+                current_group_size++;
+            }
+        }
+        if (current_group_size == max_row_block_size)                                       /* :527-533 */
+            for (long t = 0; t < merged_rows.size; t++) grouping[merged_rows.data[t]] -= rows;
+    }
+    free(distances); free(pattern.data); free(merged.data); free(merged_rows.data); free(best.pool);
+}
+
 /* BlockingEngine::GetGrouping, src/general/blocking.cpp:633-676 */
 int oracle_get_grouping(long rows, const long* rowptr, const long* colidx, int blocking_algo, int sim_measure, float tau,
                         long col_block_size, long row_block_size, int use_groups, int use_pattern, int force_fixed_size,
@@ -466,6 +737,7 @@ int oracle_get_grouping(long rows, const long* rowptr, const long* colidx, int b
         case 4: blocking_queue(rows, rowptr, colidx, tau, distance, col_block_size, use_groups, use_pattern, grouping, &cmp, &mrg); break;
         case 0: blocking_plain(rows, rowptr, colidx, tau, distance, col_block_size, use_groups, grouping, &cmp, &mrg); break;
         case 2: for (long i = 0; i < rows; i++) grouping[i] = i / row_block_size; break;   /* FixedBlocking :554-562 */
+        case 5: blocking_keeper(rows, rowptr, colidx, tau, distance, col_block_size, row_block_size, use_pattern, grouping, &cmp, &mrg); break;
         default: return -1;
     }
     if (force_fixed_size && blocking_algo != 2) {                                           /* :670-673 */

@@ -38,9 +38,10 @@ long oracle_get_partition(const long* grouping, long n, long* partition);
 void oracle_get_fixed_size_grouping(const long* grouping, long n, long row_block_size, long* result);
 
 /* BlockingEngine::GetGrouping, src/general/blocking.cpp:633-676, for blocking_algo in
- *   0 iterative (:89-154), 2 fixed_size (:554-562), 3 iterative_clocked (:156-243), 4 iterative_queue (:245-338).
+ *   0 iterative (:89-154), 2 fixed_size (:554-562), 3 iterative_clocked (:156-243), 4 iterative_queue (:245-338),
+ *   5 iterative_max_size == IterativeBlockingKeeper (:433-549; needs libstdc++'s red-black tree, restated in the .c).
  * sim_measure: 0 Hamming, 1 Jaccard.  counters (may be NULL): [comparison_counter, merge_counter].
- * Returns 0, or -1 for an algorithm the oracle does not restate (1 structured, 5 keeper, 6 scramble). */
+ * Returns 0, or -1 for an algorithm the oracle does not restate (1 structured, 6 scramble). */
 int oracle_get_grouping(long rows, const long* rowptr, const long* colidx, int blocking_algo, int sim_measure, float tau,
                         long col_block_size, long row_block_size, int use_groups, int use_pattern, int force_fixed_size,
                         long* grouping, long* counters);

@@ -6,7 +6,7 @@ import pytest
 from oracle import oracle as O
 import _util as U
 
-ORACLE_ALGOS = (0, 2, 3, 4)
+ORACLE_ALGOS = (0, 2, 3, 4, 5)
 
 
 def test_similarity_kat():
@@ -52,6 +52,8 @@ def test_appendix_b_inline_kat():
     assert info["VBR_average_height"] == pytest.approx(2.2)
     gF, _ = O.get_grouping(rows, k["rowptr"], k["colidx"], 3, 1, 0.6, 3, 3, force_fixed_size=True)
     assert gF.tolist() == [0, 1, 1, 2, 0, 2, 0, 1, 2] == k["g_F1_B3"].tolist()
+    gK, _ = O.get_grouping(rows, k["rowptr"], k["colidx"], 5, 1, 0.6, 3, 3, force_fixed_size=True)     # -a 5 -B 3 -F 1
+    assert gK.tolist() == [0, 1, 1, 1, 0, 2, 0, 2, 2] == k["g_a5_B3_F1"].tolist()
 
 
 def test_vbr_equals_csr_multiply_fixed_blocking():

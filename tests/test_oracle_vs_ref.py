@@ -29,7 +29,7 @@ def test_random_matrices_three_way(seed):
             e = sa.BlockingEngine(tau=tau, col_block_size=w, row_block_size=rbs, force_fixed_size=ff, blocking_algo=algo, use_groups=bool(seed & 1))
             gp = e.GetGrouping(m)
             assert np.array_equal(gp, gr), (algo, ff)
-            if algo != 5:
+            if True:
                 go, _ = O.get_grouping(m.rows, m.rowptr, m.colidx, algo, 1, tau, w, rbs, bool(seed & 1), True, ff)
                 assert np.array_equal(go, gr), (algo, ff)
             rv = ref.RefVBR(rc, gr, w, rbs, ff)
