@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
+PEAK_CLOCK_MHZ = 2400.0        # the clock that peak is quoted at (256 CUs x 4 SIMD x 64 lanes x 2 flop x 2.4 GHz)
 
 
 def mixed_roofline_seconds(row_part, nzcount, w, n_cols, cols, accumulate=False):
@@ -143,13 +144,17 @@ def main():
 
     # ---- per-kernel device time (HIP events on the launch stream, one pair per kernel launch) ----------------------
     d.set_class_timing(True)
-    kt = {}
+    kt, kc = {}, {}
     for _ in range(min(args.steps, 50)):
         step()
         for k, v in d.class_times().items():
             kt.setdefault(k, []).append(v)
+        for k, v in d.clock_mhz().items():        # s_memtime / s_memrealtime over the kernel: the clock the pipes really ran at
+            if v > 0:
+                kc.setdefault(k, []).append(v)
     d.set_class_timing(False)
     kernel_ms = {k: float(np.mean(v)) for k, v in kt.items()}
+    kernel_mhz = {k: float(np.mean(v)) for k, v in kc.items()}
     path = {1: "stream", 2: "class", 3: "generic"}.get(d.info()["last_path"], "?")
 
     nnz_local = m.nztot()
@@ -204,6 +209,11 @@ def main():
         "algorithmic_gbs": round(bytes_alg / (kernel_ms_total * 1e-3) / 1e9, 1) if kernel_ms_total > 0 else 0.0,
         "algorithmic_bytes": round(bytes_alg),
     }
+    # `peak` is the 2.4 GHz figure of MI355X_MICROARCH.md; under this load the board does not hold 2.4 GHz (power), so the
+    # measured shader clock and the fraction of the matrix peak AT THAT CLOCK are reported next to it (informational)
+    if kernel_mhz.get(dom, 0) > 0:
+        roofline["shader_clock_mhz"] = round(kernel_mhz[dom], 0)
+        roofline["frac_at_measured_clock"] = round(dom_tflops / (PEAK_MFMA_F32_TFLOPS * kernel_mhz[dom] / PEAK_CLOCK_MHZ), 4)
 
     # ---- CPU baseline: the reference's own VBR::multiply on this host, 1 thread -----------------------------------
     cpu = None

@@ -194,6 +194,13 @@ int sparta_vbs_spmm_gathered(sparta_vbs_t* A, const void* B_gathered, int64_t sh
 int sparta_vbs_set_class_timing(sparta_vbs_t* A, int32_t enable);
 int sparta_vbs_class_times(sparta_vbs_t* A, float* ms_out);
 
+/* Shader clock of the last timed call, per launch slot as in sparta_vbs_class_times (mhz_out[4], 0 where no probe ran).
+ * With class timing enabled, workgroup 0 of each product kernel reads s_memtime (shader-clock cycles) and s_memrealtime
+ * (constant 100 MHz) at entry and exit; the ratio is the clock the MFMA pipes really ran at.  Under a dense fp32 MFMA
+ * load on random data MI355X settles well below its 2.4 GHz peak clock (power limit), which scales the attainable
+ * fraction of the 157.3 TFLOP/s fp32 matrix peak: bench.py reports it next to the roofline.  No reference counterpart. */
+int sparta_vbs_clock_mhz(sparta_vbs_t* A, double* mhz_out);
+
 int sparta_vbs_destroy(sparta_vbs_t* A);
 
 /* plan / roofline introspection. info_out (int64[16]):

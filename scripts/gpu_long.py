@@ -16,4 +16,6 @@ for rows, cols, dens in ((65536, 8192, 0.01), (65536, 2048, 0.02), (262144, 1024
     torch.cuda.synchronize()
     ts = [d.spmm(B, C, N, timed=True) for _ in range(10)]
     t = float(np.median(ts))
+    d.set_class_timing(True); d.spmm(B, C, N); kt = d.class_times(); mhz = d.clock_mhz(); d.set_class_timing(False)
+    print(kt, mhz)
     print('%dx%d blocks/tile %.1f tiles %d: %.1f us exec %.1f TF' % (rows, cols, len(vb.jab) / vb.block_rows, vb.block_rows, t * 1e3, 2 * vb.nztot * N / t / 1e9))

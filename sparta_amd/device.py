@@ -105,6 +105,15 @@ class DeviceVBS:
             return {"stream": float(a[0]), "fixup": float(a[1])}
         return {"class16": float(a[0]), "class32": float(a[1]), "class64": float(a[2])}
 
+    def clock_mhz(self):
+        """Shader clock (MHz) the product kernels of the last timed spmm ran at, keyed like class_times()
+        (needs set_class_timing(True); 0.0 where no probe ran, e.g. the fix-up kernel)."""
+        a = np.zeros(4, np.float64)
+        check(lib.sparta_vbs_clock_mhz(self.h, a.ctypes.data_as(C.POINTER(C.c_double))))
+        if self.info()["last_path"] == 1:
+            return {"stream": float(a[0])}
+        return {"class16": float(a[0]), "class32": float(a[1]), "class64": float(a[2])}
+
     def close(self):
         if self.h:
             lib.sparta_vbs_destroy(self.h)
