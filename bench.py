@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--algo", type=int, default=5, help="reference BlockingType: 3 iterative_clocked, 5 iterative_max_size (Keeper)")
     ap.add_argument("--row-block", type=int, default=32, help="max / fixed block-row height (-B)")
     ap.add_argument("--force-fixed", type=int, default=1, help="-F: re-chunk clusters into equal heights")
-    ap.add_argument("--col-block", type=int, default=64)
+    ap.add_argument("--col-block", type=int, default=32)
     ap.add_argument("--ncols", type=int, default=128)
     ap.add_argument("--fixed-height", type=int, default=0, help="reorder OFF: fixed block-row height instead of clustering")
     ap.add_argument("--no-cpu-baseline", action="store_true")

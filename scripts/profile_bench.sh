@@ -30,6 +30,22 @@ for k, d in agg.items():
     if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
         # MI355X_MICROARCH.md section HBM: FETCH_SIZE (KB) reports exactly 1/2 of a wide coalesced read on gfx950 -> x2; WRITE_SIZE (KB) exact
         p["hbm_bytes_per_launch_corrected"] = (2.0 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0
+# traffic.json for bench.py: HBM bytes per launch of the kernel with the largest total time in the trace, tied to the workload
+try:
+    line = [l for l in open(out + "/bench_trace.log") if l.startswith("{")][-1]
+    bj = json.loads(line)
+    dom = max(res["kernel_stats"], key=lambda k: k["calls"] * k["avg_ns"])
+    key = re.search(r"vbs_\w+(<[^>]*>)?", dom["name"]).group(0)
+    p = res["pmc"][key]
+    json.dump({
+        "note": "HBM bytes per launch of the dominant kernel of the default bench.py workload, from rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, counters only). Correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE (KB) reports 1/2 of a wide coalesced read on gfx950 -> doubled; WRITE_SIZE (KB) exact.",
+        "command": "scripts/profile_bench.sh <tag>  (rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -- python3 bench.py ...; rocprofv3 --pmc WRITE_SIZE TCC_HIT TCC_MISS -- python3 bench.py ...)",
+        "workload": {"vbs_area": bj["config"]["vbs_area"], "n_cols": bj["config"]["n_cols"], "kernel_path": bj["config"]["kernel_path"]},
+        "kernel": key, "kernel_avg_ns_in_trace": dom["avg_ns"],
+        "FETCH_SIZE_KB": p["FETCH_SIZE"], "WRITE_SIZE_KB": p["WRITE_SIZE"], "hbm_bytes_per_launch": p["hbm_bytes_per_launch_corrected"],
+    }, open(out + "/traffic.json", "w"), indent=1)
+except Exception as e:
+    print("traffic.json not written:", e)
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
 PY

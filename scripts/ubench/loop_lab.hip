@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int steps, const f32x4* 
             f32x4 b = w0;
             if (FLAGS & 1) {
 #pragma unroll
-                for (int m = 0; m < 4; m++) { a0[m] = aF[cur + (8 * r + m) * 64]; a1[m] = aF[cur + (8 * r + m) * 64 + 32]; }
+                for (int m = 0; m < 4; m++) { a0[m] = aF[cur + (8 * r + m) * 64]; if (!(FLAGS & 8192)) a1[m] = aF[cur + (8 * r + m) * 64 + 32]; }
                 b = *reinterpret_cast<const f32x4*>(bF + cur + 8 * r);
             }
             if (FLAGS & 2) {
@@ -77,7 +77,10 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int steps, const f32x4* 
             if (FLAGS & 128) asm volatile("s_branch .Ltb%=\n\t.rept 16\n\ts_nop 0\n\t.endr\n.Ltb%=:" ::: "memory");                  // one TAKEN branch per round
             if (FLAGS & 256) { asm volatile("s_branch .Ltc%=\n\t.rept 16\n\ts_nop 0\n\t.endr\n.Ltc%=:" ::: "memory"); asm volatile("s_branch .Ltd%=\n\t.rept 16\n\ts_nop 0\n\t.endr\n.Ltd%=:" ::: "memory"); }
             if (FLAGS & 8) __builtin_amdgcn_sched_barrier(0);
-            if (FLAGS & 4096) {                                   // 4 dependent MFMAs on acc0, then 4 on acc1 (behind a uniform branch)
+            if (FLAGS & 8192) {                                   // MI1 emulation: one accumulator, 16 MFMAs per step
+#pragma unroll
+                for (int m = 0; m < 4; m++) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[m], a0[m], acc0, 0, 0, 0);
+            } else if (FLAGS & 4096) {                                   // 4 dependent MFMAs on acc0, then 4 on acc1 (behind a uniform branch)
 #pragma unroll
                 for (int m = 0; m < 4; m++) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[m], a0[m], acc0, 0, 0, 0);
                 if (gmask != 12345) {
@@ -151,6 +154,14 @@ int main() {
         printf("  r+w+barrier+loads SPREAD + group-barrier %.3f\n", run<7 | 16 | 512 | 1024>(blocks, steps));
         printf("  mfma only, 4xacc0 then branch 4xacc1    %.3f\n", run<4096>(blocks, steps));
         printf("  r+w+barrier+BUFFER loads, 4+4 order     %.3f\n", run<7 | 16 | 2048 | 4096>(blocks, steps));
+        printf("  MI1 (16 MFMA/step) mfma only  [ideal = half] %.3f\n", run<8192>(blocks, steps));
+        printf("  MI1 r+w+barrier                          %.3f\n", run<7 | 8192>(blocks, steps));
+        printf("  MI1 r+w+barrier+BUFFER loads             %.3f\n", run<7 | 16 | 2048 | 8192>(blocks, steps));
+        printf("  MI1 r+w+barrier+BUFFER loads, 1 MB set   %.3f\n", run<7 | 16 | 2048 | 8192>(blocks, steps, (1L << 16) - 1));
+        printf("  MI1 r+w+barrier+BUFFER loads, 32 MB set  %.3f\n", run<7 | 16 | 2048 | 8192>(blocks, steps, (1L << 21) - 1));
+        printf("  MI1 r+w+barrier+BUFFER loads, 128 MB set %.3f\n", run<7 | 16 | 2048 | 8192>(blocks, steps, (1L << 23) - 1));
+        printf("  MI2 r+w+barrier+BUFFER loads, 32 MB set  %.3f\n", run<7 | 16 | 2048>(blocks, steps, (1L << 21) - 1));
+        printf("  MI1 r+w+barrier+BUFFER loads+control+br  %.3f\n", run<7 | 16 | 32 | 64 | 2048 | 8192>(blocks, steps));
         printf("  r+w+barrier+BUFFER loads clumped        %.3f\n", run<7 | 16 | 2048>(blocks, steps));
         printf("  r+w+barrier+BUFFER loads spread         %.3f\n", run<7 | 16 | 512 | 2048>(blocks, steps));
         printf("  r+w+barrier+BUFFER loads spread+grpbar  %.3f\n", run<7 | 16 | 512 | 1024 | 2048>(blocks, steps));

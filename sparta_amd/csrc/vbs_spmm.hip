@@ -476,10 +476,13 @@ __device__ __forceinline__ void sk_store_tile(const f32x16& acc0, const f32x16& 
 // argument), and the B-tail / gathered-B variations are scalar selects.
 template <bool BRM, bool GATHERED, bool MI2>
 __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const StreamParams p) {
-    constexpr int KP = SK_KP, TN = kTN, TM = SK_TM;
+    constexpr int KP = SK_KP, TN = kTN;
+    // rows of the A slice staged per step: a one-MFMA-tile launch stages 32 rows, not 64.  Its tiles are bound by the
+    // L2 -> CU load path, not by MFMA (16 KB of B panel per 2 x 32 x 128 x 32 flop): every byte not loaded counts.
+    constexpr int TM = MI2 ? SK_TM : 32;
     constexpr int LDB = BRM ? TN : KP + 4;          // col-major B: Bs[j][k] (+4: conflict-free ds_read_b128); row-major: Bs[k][j]
     constexpr int BSZ = BRM ? KP * TN : TN * (KP + 4);
-    constexpr int STAGE = BSZ + KP * TM;            // floats per LDS stage (B panel + A slice As[k][i])
+    constexpr int STAGE = BSZ + KP * SK_TM;         // floats per LDS stage (B panel + A slice As[k][i]; sized for 64 rows in both instantiations)
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
     const int tid = threadIdx.x;
@@ -512,7 +515,8 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
     // per-thread constant byte offsets (the only vector part of any address in the loop)
     const int bj0 = tid >> 3, bk = (tid & 7) * 4;       // col-major B: column bj0 + 32q, k = bk..bk+3   (q = 0..3)
     const int rk0 = tid >> 5, rj = (tid & 31) * 4;      // row-major B: k = rk0 + 8q, columns rj..rj+3
-    const int ak0 = tid >> 4, ai = (tid & 15) * 4;      // A: k = ak0 + 16q (q = 0..1), rows ai..ai+3
+    // A: MI2: k = ak0 + 16q (q = 0..1), rows ai..ai+3 of 64;  else: k = ak0 (0..31), rows ai..ai+3 of 32 -- one load per lane
+    const int ak0 = MI2 ? tid >> 4 : tid >> 3, ai = MI2 ? (tid & 15) * 4 : (tid & 7) * 4;
     const int64_t ld_t = BRM ? (int64_t)p.N : (int64_t)p.w;                      // leading dimension of B_tail
     const uint32_t voffB = BRM ? (uint32_t)((rk0 * p.ldb + rj) * 4) : (uint32_t)((bk + bj0 * p.ldb) * 4);
     const uint32_t voffBt = BRM ? (uint32_t)((rk0 * ld_t + n0 + rj) * 4) : (uint32_t)((bk + (n0 + bj0) * ld_t) * 4);
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
         const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + g_aoff), 0, 0x7ffffff0, 0x00020000);
         const uint32_t voA = (uint32_t)(ak0 * g_h + ai) * 4u;
         ra[0] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA, 0, 2);
-        ra[1] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA, (uint32_t)(16 * g_h) * 4u, 2);
+        if constexpr (MI2) ra[1] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA, (uint32_t)(16 * g_h) * 4u, 2);
     };
 
     // ---- W: registers -> LDS stage (compile-time stage => immediate offsets) -----------------------------------
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
     };
     auto write_a = [&](auto stage_tag, const u32x4 (&ra)[2], int q) __attribute__((always_inline)) {
         constexpr int ST = decltype(stage_tag)::value;
-        *reinterpret_cast<u32x4*>(ldsb + lwA + (ST * STAGE + 16 * q * TM) * 4) = ra[q];
+        if (MI2 || q == 0) *reinterpret_cast<u32x4*>(ldsb + lwA + (ST * STAGE + 16 * q * TM) * 4) = ra[q];
     };
 
     // ---- C: fragments + MFMA ------------------------------------------------------------------------------
@@ -1047,6 +1051,7 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
     std::vector<FixRec> fix;
     std::vector<int32_t> fix_slots;
     int n_workers = 0, n_split = 0;
+    int plan_aligned[2] = {0, 0};
     if (w % SK_KP == 0) {
         hipDeviceProp_t prop;
         int cus = 256;
@@ -1057,6 +1062,10 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
         // modelled cost of a step and of a tile's epilogue, per type
         int c2 = 20, c1 = 13, ct = 6;
         if (const char* e = std::getenv("SPARTA_COST_MODEL")) sscanf(e, "%d,%d,%d", &c2, &c1, &ct);
+        int64_t split_penalty = 120;                     // cost units (~0.11 us each) the fix-up launch adds to a split plan
+        if (const char* e = std::getenv("SPARTA_SPLIT_PENALTY")) split_penalty = atoll(e);
+        int align_mode = -1;                             // SPARTA_STREAM_ALIGN=0 always split, 1 never split, unset: cheaper one
+        if (const char* e = std::getenv("SPARTA_STREAM_ALIGN")) align_mode = atoi(e) ? 1 : 0;
         if ((int64_t)cols > INT32_MAX)
             return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: matrix too large for 32-bit step indexing");
         for (int ty = 0; ty < 2; ty++) {
@@ -1120,6 +1129,41 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
                 const int64_t target = total_cost * k / n_workers;
                 int64_t pos = std::lower_bound(cum.begin(), cum.end(), target) - cum.begin();
                 bnd[(size_t)k] = std::min<int64_t>(std::max(pos, bnd[(size_t)k - 1]), S);
+            }
+            // Alternative: ranges that end on tile boundaries (no split tile, no fix-up launch).  Splitting balances to one
+            // step but pays the fix-up (a second launch that re-reads the partial images: ~10 us measured, `split_penalty`
+            // cost units); whole tiles cost at most one tile of imbalance.  Many short tiles -> aligned; few long -> split.
+            {
+                const int64_t step_cost = ty ? c2 : c1;
+                auto tile_cost = [&](size_t t) { return (spans[t].last - spans[t].first + 1) * step_cost + ct; };
+                int64_t lo = 0, hi = total_cost;
+                for (size_t t = 0; t < spans.size(); t++) lo = std::max(lo, tile_cost(t));
+                auto bins_needed = [&](int64_t L) {
+                    int64_t bins = 1, cur = 0;
+                    for (size_t t = 0; t < spans.size(); t++) {
+                        const int64_t c = tile_cost(t);
+                        if (cur > 0 && cur + c > L) { bins++; cur = 0; }
+                        cur += c;
+                    }
+                    return bins;
+                };
+                while (lo < hi) {                                   // smallest makespan L that fits n_workers contiguous bins
+                    const int64_t mid = lo + (hi - lo) / 2;
+                    if (bins_needed(mid) <= n_workers) hi = mid; else lo = mid + 1;
+                }
+                const int64_t split_makespan = (total_cost + n_workers - 1) / n_workers + split_penalty;
+                const bool aligned = align_mode == 1 || (align_mode < 0 && lo <= split_makespan);
+                if (aligned) {
+                    std::fill(bnd.begin(), bnd.end(), S);
+                    bnd[0] = 0;
+                    int64_t bin = 0, cur = 0;
+                    for (size_t t = 0; t < spans.size(); t++) {
+                        const int64_t c = tile_cost(t);
+                        if (cur > 0 && cur + c > lo) { bin++; bnd[(size_t)bin] = spans[t].first; cur = 0; }
+                        cur += c;
+                    }
+                }
+                plan_aligned[ty] = aligned ? 1 : 0;
             }
             wrange[ty].assign((size_t)n_workers * 2, 0);
             std::vector<int32_t> wid_of_pos((size_t)n_workers);

@@ -377,3 +377,61 @@ def test_autotune_picks_a_product_path_and_is_stable():
     _check(C.cpu().numpy(), Co, U.abs_bound(v.rows, v.cols, 64, v.row_part, v.nzcount, v.jab, v.mab, B.cpu().numpy(), n) + 1.0, "autotune")
     d.spmm(B, C, n)
     assert d.info()["last_path"] == p1
+
+
+@pytest.mark.parametrize("align", ["0", "1"])
+@pytest.mark.parametrize("rows,cols,nnz,w,blk,n", [
+    (1500, 1500, 60000, 64, ("tau", 0.5), 128),        # one 1500-row cluster: 64-row tiles + a 28-row tile (both tile types)
+    (3000, 640, 20000, 32, ("keeper", 32), 128),       # many short 32-row tiles, w = 32: one step per block
+    (64, 6400, 30000, 64, ("fixed", 64), 128),         # ONE long tile: aligned = one worker, split = many segments
+    (2000, 1024, 40000, 128, ("fixed", 100), 256),     # 64 + 36-row tiles, two column slabs
+])
+def test_stream_plan_modes(monkeypatch, align, rows, cols, nnz, w, blk, n):
+    """The stream plan either cuts worker ranges anywhere (split tiles + fix-up kernel) or on tile boundaries (no
+    fix-up); SPARTA_STREAM_ALIGN forces one or the other.  Both must give the oracle's product, bit-reproducibly."""
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_PATH", "stream")
+    monkeypatch.setenv("SPARTA_STREAM_ALIGN", align)
+    m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + w)
+    if blk[0] == "tau":
+        g = sa.BlockingEngine(tau=blk[1], col_block_size=w).GetGrouping(m)
+    elif blk[0] == "keeper":
+        g = sa.BlockingEngine(tau=0.5, col_block_size=w, row_block_size=blk[1], blocking_algo=5).GetGrouping(m)
+    else:
+        g = np.arange(rows) // blk[1]
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=4)
+    Co = _oracle_c(v, B, n)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+    d = v.to_device(0)
+    info = d.info()
+    if align == "1":
+        assert info["split_tiles"] == 0
+    Bt = torch.from_numpy(B).cuda()
+    C1 = torch.full((v.rows * n,), -3.0, dtype=torch.float32, device="cuda")
+    d.spmm(Bt, C1, n)
+    torch.cuda.synchronize()
+    assert d.info()["last_path"] == 1
+    _check(C1.cpu().numpy(), Co, bound, "stream align=" + align)
+    C2 = torch.empty_like(C1)
+    d.spmm(Bt, C2, n)
+    torch.cuda.synchronize()
+    assert torch.equal(C1, C2)
+
+
+def test_clock_probe_reports_a_plausible_shader_clock():
+    torch = _torch()
+    m = sa.gen.fem3d(6, 6, 40, 3, seed=3)
+    v = sa.VBR().fill_from_CSR_inplace_fixed(m, 64, 64)
+    d = v.to_device(0)
+    n = 128
+    B = torch.from_numpy(sa.gen.dense_rhs(v.cols, n, seed=1)).cuda()
+    C = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
+    d.set_class_timing(True)
+    for _ in range(3):
+        d.spmm(B, C, n)
+    ms = d.class_times()
+    mhz = d.clock_mhz()
+    d.set_class_timing(False)
+    assert sum(ms.values()) > 0
+    assert any(500.0 < x < 3000.0 for x in mhz.values()), mhz
