@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int steps, const f32x4* 
             if (FLAGS & 128) asm volatile("s_branch .Ltb%=\n\t.rept 16\n\ts_nop 0\n\t.endr\n.Ltb%=:" ::: "memory");                  // one TAKEN branch per round
             if (FLAGS & 256) { asm volatile("s_branch .Ltc%=\n\t.rept 16\n\ts_nop 0\n\t.endr\n.Ltc%=:" ::: "memory"); asm volatile("s_branch .Ltd%=\n\t.rept 16\n\ts_nop 0\n\t.endr\n.Ltd%=:" ::: "memory"); }
             if (FLAGS & 8) __builtin_amdgcn_sched_barrier(0);
-            if (FLAGS & 8192) {                                   // MI1 emulation: one accumulator, 16 MFMAs per step
+            if (FLAGS & 16384) {                                  // no MFMA at all: what the staging path alone can move
+                acc0[r] += b[0] + a0[0];
+            } else if (FLAGS & 8192) {                            // MI1 emulation: one accumulator, 16 MFMAs per step
 #pragma unroll
                 for (int m = 0; m < 4; m++) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[m], a0[m], acc0, 0, 0, 0);
             } else if (FLAGS & 4096) {                                   // 4 dependent MFMAs on acc0, then 4 on acc1 (behind a uniform branch)
@@ -161,6 +163,10 @@ int main() {
         printf("  MI1 r+w+barrier+BUFFER loads, 32 MB set  %.3f\n", run<7 | 16 | 2048 | 8192>(blocks, steps, (1L << 21) - 1));
         printf("  MI1 r+w+barrier+BUFFER loads, 128 MB set %.3f\n", run<7 | 16 | 2048 | 8192>(blocks, steps, (1L << 23) - 1));
         printf("  MI2 r+w+barrier+BUFFER loads, 32 MB set  %.3f\n", run<7 | 16 | 2048>(blocks, steps, (1L << 21) - 1));
+        for (long set : {1L << 16, 1L << 21, 1L << 25}) {
+            const float ms = run<7 | 16 | 2048 | 16384>(blocks, steps, set - 1);
+            printf("  NO MFMA: r+w+barrier+BUFFER loads, %4ld MB set: %.3f ms = %.1f B/clk/CU @2.4GHz, %.2f TB/s\n", set * 16 >> 20, ms, (double)blocks * steps * 24576.0 / (ms * 1e-3) / 256 / 2.4e9, (double)blocks * steps * 24576.0 / (ms * 1e-3) / 1e12);
+        }
         printf("  MI1 r+w+barrier+BUFFER loads+control+br  %.3f\n", run<7 | 16 | 32 | 64 | 2048 | 8192>(blocks, steps));
         printf("  r+w+barrier+BUFFER loads clumped        %.3f\n", run<7 | 16 | 2048>(blocks, steps));
         printf("  r+w+barrier+BUFFER loads spread         %.3f\n", run<7 | 16 | 512 | 2048>(blocks, steps));

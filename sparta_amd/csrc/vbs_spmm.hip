@@ -1064,6 +1064,8 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
         if (const char* e = std::getenv("SPARTA_COST_MODEL")) sscanf(e, "%d,%d,%d", &c2, &c1, &ct);
         int64_t split_penalty = 120;                     // cost units (~0.11 us each) the fix-up launch adds to a split plan
         if (const char* e = std::getenv("SPARTA_SPLIT_PENALTY")) split_penalty = atoll(e);
+        bool interleave = false;                         // SPARTA_STREAM_INTERLEAVE=1: deal whole tiles round-robin inside an XCD (measured: +-2 %, L2 locality is not the limit)
+        if (const char* e = std::getenv("SPARTA_STREAM_INTERLEAVE")) interleave = atoi(e) != 0;
         int align_mode = -1;                             // SPARTA_STREAM_ALIGN=0 always split, 1 never split, unset: cheaper one
         if (const char* e = std::getenv("SPARTA_STREAM_ALIGN")) align_mode = atoi(e) ? 1 : 0;
         if ((int64_t)cols > INT32_MAX)
@@ -1161,6 +1163,46 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
                         const int64_t c = tile_cost(t);
                         if (cur > 0 && cur + c > lo) { bin++; bnd[(size_t)bin] = spans[t].first; cur = 0; }
                         cur += c;
+                    }
+                    if (interleave) {
+                        // Whole tiles can go to any worker.  Keep the 64 workers of an XCD close together in the matrix at every
+                        // moment: the XCD takes a contiguous eighth of the tiles (by cost) and deals them, in matrix order, to
+                        // its least-loaded worker (uniform tiles: worker j gets tiles j, j+64, ...).  The B rows the XCD
+                        // touches at one time are then a narrow moving window that stays in its 4 MB L2, instead of 64
+                        // windows spread over the whole eighth.  The step list is rebuilt in worker order.
+                        std::vector<std::vector<size_t>> mine((size_t)n_workers);
+                        size_t t = 0;
+                        int64_t seen = 0;
+                        for (int x = 0; x < 8; x++) {
+                            const int64_t upto = total_cost * (x + 1) / 8;
+                            std::vector<int64_t> load((size_t)per_x, 0);
+                            while (t < spans.size() && (x == 7 || seen + tile_cost(t) / 2 <= upto)) {
+                                size_t best = 0;
+                                for (size_t j = 1; j < load.size(); j++) if (load[j] < load[best]) best = j;
+                                mine[(size_t)x * per_x + best].push_back(t);
+                                load[best] += tile_cost(t);
+                                seen += tile_cost(t);
+                                t++;
+                            }
+                        }
+                        std::vector<StepRec> ns;
+                        std::vector<TileSpan> nspans;
+                        ns.reserve(st.size());
+                        nspans.reserve(spans.size());
+                        for (int pos = 0; pos < n_workers; pos++) {
+                            bnd[(size_t)pos] = (int64_t)ns.size();
+                            for (size_t tt : mine[(size_t)pos]) {
+                                TileSpan sp = spans[tt];
+                                const int64_t len = sp.last - sp.first + 1;
+                                ns.insert(ns.end(), st.begin() + sp.first, st.begin() + sp.last + 1);
+                                sp.first = (int64_t)ns.size() - len;
+                                sp.last = (int64_t)ns.size() - 1;
+                                nspans.push_back(sp);
+                            }
+                        }
+                        bnd[(size_t)n_workers] = S;
+                        st.swap(ns);
+                        spans.swap(nspans);
                     }
                 }
                 plan_aligned[ty] = aligned ? 1 : 0;
