@@ -121,6 +121,65 @@ int sparta_row_distance(int32_t sim_measure, const int64_t* row_a, int64_t size_
 int sparta_merge_rows(const int64_t* row_a, int64_t size_a, const int64_t* row_b, int64_t size_b,
                       int64_t* out, int64_t* size_out);
 
+/* ---- on-disk formats either side of the path (host-side C++, sparta_amd/csrc/io.cpp) ------- */
+#define SPARTA_FMT_EL  0            /* MatrixFormat::el  (include/definitions.h:15; flag -R 0) */
+#define SPARTA_FMT_MTX 1            /* MatrixFormat::mtx (flag -R 1) */
+#define SPARTA_IO_COMPAT 0          /* what the reference's readers do, quirks included */
+#define SPARTA_IO_STRICT 1          /* the formats as documented: no dropped line, MatrixMarket banner/values/symmetry honoured */
+
+/* a CSR in flat arrays, owned by the library (release with sparta_csr_host_free) */
+typedef struct sparta_csr_host {
+    int64_t rows, cols, nnz;
+    int32_t pattern_only;         /* 1: vals == NULL, every stored entry counts as 1 (include/matrices.h:28) */
+    int64_t* rowptr;              /* [rows + 1] */
+    int32_t* colidx;              /* [nnz], in file order inside a row (the reference never sorts a row) */
+    float*   vals;                /* [nnz] or NULL */
+} sparta_csr_host;
+
+/* replaces CSR::read_from_edgelist(infile, delimiter, pattern_only, mat_fmt, symmetrize)
+ * (include/matrices.h:63, src/general/csr.cpp:183-365).  SPARTA_IO_COMPAT: `.el` -- leading '#'/'%' lines skipped, THE
+ * FIRST REMAINING LINE IS DISCARDED (csr.cpp:213), "row<delim>col[<delim>value]" per line, row ids non-decreasing, rows =
+ * last row id + 1, cols = largest column id + 1, symmetrize mirrors an upper-triangular pattern-only input; `.mtx` -- always
+ * pattern-only, one line after the size line is skipped, symmetry ignored (csr.cpp:309-365).  Inputs on which the
+ * reference throws or runs into undefined behaviour return SPARTA_ERR_IO.  SPARTA_IO_STRICT reads the documented formats. */
+int sparta_csr_read(const char* path, const char* delimiter, int32_t pattern_only, int32_t mat_fmt, int32_t symmetrize, int32_t mode,
+                    sparta_csr_host* out);
+void sparta_csr_host_free(sparta_csr_host* m);
+
+/* replaces CSR::save_to_edgelist (src/general/csr.cpp:169-179): "i<delim>j" per entry (el) / "j<delim>i" (mtx flavour) */
+int sparta_csr_write_edgelist(const char* path, int64_t rows, const int64_t* rowptr, const int32_t* colidx, const char* delimiter,
+                              int32_t mat_fmt);
+
+/* the grouping file `<outfile>.g` that save_blocking_data writes (src/general/utilities.cpp:239-243): one group id per line */
+int sparta_grouping_write(const char* path, const int64_t* grouping, int64_t n);
+/* replaces read_grouping_file + the count-line rule of test/general/Matrix_Analysis.cpp:10-32,77-78: lines that do not start
+ * with a number are skipped; a file with expected_rows + 1 numbers has a leading count, which is dropped.  expected_rows < 0:
+ * no check.  *n_out = number of ids found (also on SPARTA_ERR_IO when it does not match expected_rows). */
+int sparta_grouping_read(const char* path, int64_t expected_rows, int64_t* out, int64_t capacity, int64_t* n_out);
+
+/* the reference's 32-column statistics row (src/general/utilities.cpp:175-236): one header line and one value line, every field
+ * followed by ','; floats print as std::to_string(float) ("%f").  Field names are the reference's CSV column names. */
+typedef struct sparta_csv_fields {
+    const char* matrix;           /* CLineReader::filename_ */
+    int64_t rows, cols, nonzeros;
+    int32_t symmetrize, blocking_algo;
+    float   tau;
+    int32_t row_block_size, col_block_size, use_pattern, sim_use_groups, sim_measure, reorder;
+    const char* exp_name;
+    int32_t b_cols, warmup, exp_repetitions, multiplication_algo, n_streams;
+    float   time_to_block, time_to_merge, time_to_compare;          /* microseconds (sparta_reorder_stats) */
+    int64_t vbr_nzcount, vbr_nzblocks_count;                        /* sparta_blocking_info */
+    float   vbr_average_height;
+    int64_t vbr_longest_row, merge_counter, comparison_counter;
+    float   average_merge_tau, average_row_distance;
+    float   avg_time_multiply, std_time_multiply;                   /* milliseconds */
+} sparta_csv_fields;
+int sparta_blocking_csv_row(const sparta_csv_fields* f, char* header_out, int64_t header_cap, char* values_out, int64_t values_cap);
+
+/* the row permutation of CSR::reorder_by_degree (src/general/csr.cpp:123-155; flag -r -1 / 1): perm_out[k] = old index of
+ * the row that moves to position k (apply with CSR::permute_rows semantics, utilities.h:95-107) */
+int sparta_degree_permutation(int64_t rows, const int64_t* rowptr, int32_t descending, int64_t* perm_out);
+
 /* ---- VBS build (host-side C++) ------------------------------------------------------------- */
 /* the five arrays + scalars of struct VBR (include/matrices.h:93-104), owned by the library */
 typedef struct sparta_vbs_host {

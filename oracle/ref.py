@@ -42,6 +42,11 @@ def lib():
         L.ref_csr_pattern_only.argtypes = [vp]
         L.ref_csr_export.argtypes = [vp, lp, lp, fp]
         L.ref_csr_multiply.argtypes = [vp, fp, C.c_long, fp]
+        L.ref_csr_reorder.argtypes = [vp, lp, C.c_long]
+        L.ref_csr_reorder_by_degree.argtypes = [vp, C.c_int]
+        L.ref_csr_save_to_edgelist.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        L.ref_save_blocking_data.argtypes = [vp, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_float, fp, fp, C.c_char_p, C.c_long,
+                                             C.c_char_p, C.c_long]
         L.ref_get_grouping.argtypes = [vp, C.c_int, C.c_float, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int,
                                        lp, lp, fp, lp, fp]
         L.ref_get_permutation.argtypes = [lp, C.c_long, lp]
@@ -127,6 +132,37 @@ class RefCSR:
             stats.update(VBR_nzcount=int(info[0]), VBR_nzblocks_count=int(info[1]), VBR_longest_row=int(info[2]),
                          VBR_average_height=float(finfo[0]))
         return g, stats
+
+    def reorder(self, grouping):
+        g = _i64(grouping)
+        lib().ref_csr_reorder(self.h, _lp(g), len(g))
+
+    def reorder_by_degree(self, descending=True):
+        lib().ref_csr_reorder_by_degree(self.h, int(bool(descending)))
+
+    def save_to_edgelist(self, path, delim=" ", pattern_only=False, mat_fmt=0):
+        if lib().ref_csr_save_to_edgelist(self.h, str(path).encode(), delim.encode(), int(pattern_only), int(mat_fmt)) != 0:
+            raise OSError("cannot write %s" % path)
+
+    CSV_INTS = ("symmetrize", "blocking_algo", "row_block_size", "col_block_size", "use_pattern", "sim_use_groups", "sim_measure",
+                "reorder", "b_cols", "warmup", "exp_repetitions", "multiplication_algo", "n_streams", "force_fixed_size")
+
+    def save_blocking_data(self, filename="m.el", exp_name="", tau=0.1, timers=None, mult=None, **ints):
+        """the reference's save_blocking_data (utilities.cpp:175-245) after a GetGrouping with these settings:
+        returns (csv text = header line + value line, grouping-file text)"""
+        defaults = dict(symmetrize=0, blocking_algo=3, row_block_size=3, col_block_size=3, use_pattern=1, sim_use_groups=0,
+                        sim_measure=1, reorder=0, b_cols=1024, warmup=1, exp_repetitions=5, multiplication_algo=0, n_streams=4,
+                        force_fixed_size=0)
+        defaults.update(ints)
+        arr = (C.c_int * len(self.CSV_INTS))(*[int(defaults[k]) for k in self.CSV_INTS])
+        t = None if timers is None else np.ascontiguousarray(timers, np.float32)
+        m = None if mult is None else np.ascontiguousarray(mult, np.float32)
+        csv = C.create_string_buffer(1 << 14)
+        g = C.create_string_buffer(32 * self.rows + 64)
+        rc = lib().ref_save_blocking_data(self.h, filename.encode(), exp_name.encode(), arr, float(tau), _fp(t), _fp(m), csv, len(csv), g, len(g))
+        if rc != 0:
+            raise RuntimeError("ref_save_blocking_data failed")
+        return csv.value.decode(), g.value.decode()
 
     def __del__(self):
         try:

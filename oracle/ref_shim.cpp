@@ -15,7 +15,9 @@
 #include <algorithm>
 #include "matrices.h"     // reference: include/matrices.h  (struct CSR, struct VBR)
 #include "blocking.h"     // reference: include/blocking.h  (BlockingEngine, distances)
-#include "utilities.h"    // reference: include/utilities.h (merge_rows, get_permutation, ...)
+#include "utilities.h"    // reference: include/utilities.h (merge_rows, get_permutation, save_blocking_data, ...)
+#include "input.h"        // reference: include/input.h     (CLineReader: the fields save_blocking_data prints)
+#include <sstream>
 
 namespace {
 // The reference's CSR has no array constructor (include/matrices.h:58-82); build an
@@ -197,5 +199,61 @@ void ref_vbr_export(void* h, long* row_part, long* nzcount, long* jab, float* ma
 }
 // reference: src/general/vbr.cpp:323-372
 void ref_vbr_multiply(void* h, float* B, int B_cols, float* C) { ((VBR*)h)->multiply(B, B_cols, C); }
+
+
+// reference: src/general/csr.cpp:101-109 / :123-155 / :169-179 (row permutations and the edge-list writer)
+void ref_csr_reorder(void* h, const long* grouping, long n)
+{
+    std::vector<intT> g(grouping, grouping + n);
+    ((CSR*)h)->reorder(g);
+}
+void ref_csr_reorder_by_degree(void* h, int descending) { ((CSR*)h)->reorder_by_degree(descending != 0); }
+int ref_csr_save_to_edgelist(void* h, const char* path, const char* delim, int pattern_only, int mat_fmt)
+{
+    std::ofstream out(path);
+    if (!out.good()) return -1;
+    ((CSR*)h)->save_to_edgelist(out, delim, pattern_only != 0, (MatrixFormat)mat_fmt);
+    return 0;
+}
+
+// reference: src/general/utilities.cpp:175-245 (save_blocking_data: the 32-column CSV row + the grouping file).
+// ints: [symmetrize, blocking_algo, row_block_size, col_block_size, use_pattern, sim_use_groups, sim_measure, reorder,
+//        b_cols, warmup, exp_repetitions, multiplication_algo, n_streams, force_fixed_size]
+// Runs GetGrouping with those settings first (save_blocking_data prints the engine's counters and grouping_result).
+// timers_in (3 floats, may be NULL): overwrite timer_total / timer_merges / timer_comparisons so that the row is reproducible;
+// mult_in (2 floats, may be NULL): multiplication_timer_avg / _std.
+int ref_save_blocking_data(void* h, const char* filename, const char* exp_name, const int* ints, float tau, const float* timers_in,
+                           const float* mult_in, char* csv_out, long csv_cap, char* grouping_out, long grouping_cap)
+{
+    CSR* c = (CSR*)h;
+    char prog[] = "shim";
+    char* argv[] = {prog, nullptr};
+    optind = 1;
+    CLineReader cl(1, argv);
+    cl.filename_ = filename; cl.exp_name_ = exp_name;
+    cl.symmetrize_ = ints[0] != 0; cl.blocking_algo_ = ints[1]; cl.row_block_size_ = ints[2]; cl.col_block_size_ = ints[3];
+    cl.sim_use_pattern_ = ints[4] != 0; cl.sim_use_groups_ = ints[5] != 0; cl.sim_measure_ = ints[6]; cl.reorder_ = ints[7];
+    cl.B_cols_ = ints[8]; cl.warmup_ = ints[9]; cl.exp_repetitions_ = ints[10]; cl.multiplication_algo_ = ints[11];
+    cl.n_streams_ = ints[12]; cl.tau_ = tau;
+    BlockingEngine e;
+    e.tau = tau; e.col_block_size = ints[3]; e.row_block_size = ints[2];
+    e.use_groups = ints[5] != 0; e.use_pattern = ints[4] != 0; e.force_fixed_size = ints[13] != 0;
+    e.blocking_algo = (BlockingType)ints[1];
+    e.SetComparator(ints[6]);
+    e.GetGrouping(*c);
+    if (timers_in) { e.timer_total = timers_in[0]; e.timer_merges = timers_in[1]; e.timer_comparisons = timers_in[2]; }
+    if (mult_in) { e.multiplication_timer_avg = mult_in[0]; e.multiplication_timer_std = mult_in[1]; }
+    std::ostringstream csv, g;
+    std::streambuf* keep = std::cout.rdbuf();
+    std::ostringstream sink;
+    std::cout.rdbuf(sink.rdbuf());                       // save_blocking_data chats on stdout
+    save_blocking_data(csv, cl, e, *c, true, g);
+    std::cout.rdbuf(keep);
+    const std::string a = csv.str(), b = g.str();
+    if ((long)a.size() + 1 > csv_cap || (long)b.size() + 1 > grouping_cap) return -1;
+    std::memcpy(csv_out, a.c_str(), a.size() + 1);
+    std::memcpy(grouping_out, b.c_str(), b.size() + 1);
+    return 0;
+}
 
 } // extern "C"

@@ -14,9 +14,11 @@ Host-side mirror of the reference's operator interface for the ONE hot path
 All arithmetic happens in libsparta_amd.so (host C++ + HIP kernels for gfx950) through the C-ABI in
 include/sparta_amd.h; this package is a thin ctypes layer and holds no algorithmic fallback.
 """
-from ._lib import (SpartaError, LIB_PATH, F32, F16, BF16, COL_MAJOR, ROW_MAJOR, SPMM_MFMA, SPMM_EXACT)  # noqa: F401
+from ._lib import (SpartaError, LIB_PATH, F32, F16, BF16, COL_MAJOR, ROW_MAJOR, SPMM_MFMA, SPMM_EXACT,  # noqa: F401
+                   FMT_EL, FMT_MTX, IO_COMPAT, IO_STRICT)
 from .host import (CSR, BlockingEngine, VBR, get_permutation, get_partition, get_fixed_size_grouping,  # noqa: F401
-                   row_distance, merge_rows, BLOCKING_ALGOS)
+                   row_distance, merge_rows, BLOCKING_ALGOS, save_grouping, read_grouping_file, blocking_csv_row,
+                   save_blocking_data, CSV_COLUMNS)
 from .device import DeviceVBS, vbs_multiply, device_count  # noqa: F401
 from . import gen, dist  # noqa: F401
 

@@ -23,6 +23,8 @@ F32, F16, BF16 = 0, 1, 2
 COL_MAJOR, ROW_MAJOR = 0, 1
 PTR_HOST, PTR_DEVICE = 0, 1
 SPMM_MFMA, SPMM_EXACT = 0, 1
+FMT_EL, FMT_MTX = 0, 1
+IO_COMPAT, IO_STRICT = 0, 1
 
 # every symbol include/sparta_amd.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -32,7 +34,28 @@ SYMBOLS = [
     "sparta_vbs_spmm", "sparta_vbs_spmm_gathered", "sparta_vbs_set_class_timing",
     "sparta_vbs_class_times", "sparta_vbs_clock_mhz", "sparta_vbs_destroy", "sparta_vbs_info", "sparta_device_count", "sparta_last_error",
     "sparta_version",
+    "sparta_csr_read", "sparta_csr_host_free", "sparta_csr_write_edgelist", "sparta_grouping_write", "sparta_grouping_read",
+    "sparta_blocking_csv_row", "sparta_degree_permutation",
 ]
+
+
+class CsrHost(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("cols", C.c_int64), ("nnz", C.c_int64), ("pattern_only", C.c_int32),
+                ("rowptr", C.POINTER(C.c_int64)), ("colidx", C.POINTER(C.c_int32)), ("vals", C.POINTER(C.c_float))]
+
+
+class CsvFields(C.Structure):
+    _fields_ = [("matrix", C.c_char_p), ("rows", C.c_int64), ("cols", C.c_int64), ("nonzeros", C.c_int64),
+                ("symmetrize", C.c_int32), ("blocking_algo", C.c_int32), ("tau", C.c_float),
+                ("row_block_size", C.c_int32), ("col_block_size", C.c_int32), ("use_pattern", C.c_int32),
+                ("sim_use_groups", C.c_int32), ("sim_measure", C.c_int32), ("reorder", C.c_int32),
+                ("exp_name", C.c_char_p), ("b_cols", C.c_int32), ("warmup", C.c_int32), ("exp_repetitions", C.c_int32),
+                ("multiplication_algo", C.c_int32), ("n_streams", C.c_int32),
+                ("time_to_block", C.c_float), ("time_to_merge", C.c_float), ("time_to_compare", C.c_float),
+                ("vbr_nzcount", C.c_int64), ("vbr_nzblocks_count", C.c_int64), ("vbr_average_height", C.c_float),
+                ("vbr_longest_row", C.c_int64), ("merge_counter", C.c_int64), ("comparison_counter", C.c_int64),
+                ("average_merge_tau", C.c_float), ("average_row_distance", C.c_float),
+                ("avg_time_multiply", C.c_float), ("std_time_multiply", C.c_float)]
 
 
 class ReorderCfg(C.Structure):
@@ -90,6 +113,14 @@ def _load():
     L.sparta_vbs_class_times.argtypes = [vp, f32p]
     L.sparta_vbs_clock_mhz.argtypes = [vp, C.POINTER(C.c_double)]
     L.sparta_vbs_destroy.argtypes = [vp]
+    L.sparta_csr_read.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CsrHost)]
+    L.sparta_csr_host_free.argtypes = [C.POINTER(CsrHost)]
+    L.sparta_csr_host_free.restype = None
+    L.sparta_csr_write_edgelist.argtypes = [C.c_char_p, C.c_int64, i64p, i32p, C.c_char_p, C.c_int32]
+    L.sparta_grouping_write.argtypes = [C.c_char_p, i64p, C.c_int64]
+    L.sparta_grouping_read.argtypes = [C.c_char_p, C.c_int64, i64p, C.c_int64, C.POINTER(C.c_int64)]
+    L.sparta_blocking_csv_row.argtypes = [C.POINTER(CsvFields), C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]
+    L.sparta_degree_permutation.argtypes = [C.c_int64, i64p, C.c_int32, i64p]
     L.sparta_vbs_info.argtypes = [vp, i64p]
     L.sparta_device_count.argtypes = []
     L.sparta_last_error.restype = C.c_char_p

@@ -70,6 +70,55 @@ class CSR:
         v = np.ones(len(self.colidx), np.float32) if self.vals is None else self.vals
         return sp.csr_matrix((v, self.colidx, self.rowptr), shape=(self.rows, self.cols))
 
+    # ---- files and row permutations (the callers either side of the path) ------------------------------------------
+    @classmethod
+    def read_from_edgelist(cls, path, delimiter=" ", pattern_only=False, mat_fmt=_lib.FMT_EL, symmetrize=False,
+                           mode=_lib.IO_COMPAT):
+        """void CSR::read_from_edgelist(infile, delimiter, pattern_only, mat_fmt, symmetrize) (src/general/csr.cpp:183-365).
+        mode IO_COMPAT reproduces the reference's readers (first data line of an .el dropped, .mtx pattern-only with one
+        line skipped after the size line); IO_STRICT reads the formats as documented."""
+        h = _lib.CsrHost()
+        check(lib.sparta_csr_read(str(path).encode(), delimiter.encode(), int(bool(pattern_only)), int(mat_fmt),
+                                  int(bool(symmetrize)), int(mode), C.byref(h)))
+        try:
+            rowptr = np.ctypeslib.as_array(h.rowptr, shape=(h.rows + 1,)).copy()
+            colidx = np.ctypeslib.as_array(h.colidx, shape=(max(h.nnz, 1),))[:h.nnz].copy()
+            vals = None if h.pattern_only else np.ctypeslib.as_array(h.vals, shape=(max(h.nnz, 1),))[:h.nnz].copy()
+            return cls(h.rows, h.cols, rowptr, colidx, vals)
+        finally:
+            lib.sparta_csr_host_free(C.byref(h))
+
+    def save_to_edgelist(self, path, delimiter=" ", mat_fmt=_lib.FMT_EL):
+        """void CSR::save_to_edgelist(outfile, delimiter, pattern_only, mat_fmt) (csr.cpp:169-179)."""
+        check(lib.sparta_csr_write_edgelist(str(path).encode(), self.rows, _p64(self.rowptr), _p32(self.colidx), delimiter.encode(),
+                                            int(mat_fmt)))
+
+    def permute_rows(self, permutation):
+        """void CSR::permute_rows(permutation) (csr.cpp:67-76, utilities.h:95-107): new row k = old row permutation[k]."""
+        p = np.ascontiguousarray(permutation, np.int64)
+        if p.shape != (self.rows,):
+            raise ValueError("CSR.permute_rows argument must have the same length as rows")
+        cnt = self.nzcount[p]
+        rowptr = np.zeros(self.rows + 1, np.int64)
+        np.cumsum(cnt, out=rowptr[1:])
+        src = np.repeat(self.rowptr[:-1][p] - rowptr[:-1], cnt) + np.arange(int(rowptr[-1]), dtype=np.int64)
+        self.colidx = np.ascontiguousarray(self.colidx[src])
+        if self.vals is not None:
+            self.vals = np.ascontiguousarray(self.vals[src])
+        self.rowptr = rowptr
+
+    def reorder(self, grouping):
+        """void CSR::reorder(grouping) (csr.cpp:101-109): rows of one group become adjacent (get_permutation order)."""
+        if len(grouping) != self.rows:
+            raise ValueError("CSR.reorder argument must have the same length as rows")
+        self.permute_rows(get_permutation(grouping))
+
+    def reorder_by_degree(self, descending=True):
+        """void CSR::reorder_by_degree(descending) (csr.cpp:123-155; flag -r 1 / -1)."""
+        perm = np.empty(self.rows, np.int64)
+        check(lib.sparta_degree_permutation(self.rows, _p64(self.rowptr), int(bool(descending)), _p64(perm)))
+        self.permute_rows(perm)
+
 
 class BlockingEngine:
     """Row-clustering reorder engine; field names and defaults of the reference's BlockingEngine
@@ -242,3 +291,80 @@ def merge_rows(row_a, row_b):
     n = C.c_int64(0)
     check(lib.sparta_merge_rows(_p64(a), len(a), _p64(b), len(b), _p64(out), C.byref(n)))
     return out[:n.value].copy()
+
+
+def save_grouping(path, grouping):
+    """The `<outfile>.g` file of save_blocking_data (src/general/utilities.cpp:239-243): one group id per line."""
+    g = np.ascontiguousarray(grouping, np.int64)
+    check(lib.sparta_grouping_write(str(path).encode(), _p64(g), len(g)))
+
+
+def read_grouping_file(path, rows=None):
+    """read_grouping_file + the leading-count rule of test/general/Matrix_Analysis.cpp:10-32,77-78."""
+    cap = 1 << 16
+    while True:
+        out = np.empty(cap, np.int64)
+        n = C.c_int64(0)
+        rc = lib.sparta_grouping_read(str(path).encode(), -1 if rows is None else int(rows), _p64(out), cap, C.byref(n))
+        if rc != 0 and n.value > cap:
+            cap = int(n.value) + 1
+            continue
+        check(rc)
+        return out[:n.value].copy()
+
+
+CSV_COLUMNS = ("matrix", "rows", "cols", "nonzeros", "symmetrize", "blocking_algo", "tau", "row_block_size", "col_block_size",
+               "use_pattern", "sim_use_groups", "sim_measure", "reorder", "exp_name", "b_cols", "warmup", "exp_repetitions",
+               "multiplication_algo", "n_streams", "time_to_block", "time_to_merge", "time_to_compare", "VBR_nzcount",
+               "VBR_nzblocks_count", "VBR_average_height", "VBR_longest_row", "merge_counter", "comparison_counter",
+               "average_merge_tau", "average_row_distance", "avg_time_multiply", "std_time_multiply")
+
+
+def blocking_csv_row(**fields):
+    """(header, values) of the reference's 32-column statistics row (src/general/utilities.cpp:175-236).  Keyword names are
+    the CSV column names (CSV_COLUMNS); missing ones default to 0 / ""."""
+    f = _lib.CsvFields()
+    names = {"VBR_nzcount": "vbr_nzcount", "VBR_nzblocks_count": "vbr_nzblocks_count", "VBR_average_height": "vbr_average_height",
+             "VBR_longest_row": "vbr_longest_row"}
+    unknown = set(fields) - set(CSV_COLUMNS)
+    if unknown:
+        raise TypeError("unknown CSV columns: %s" % sorted(unknown))
+    keep = []
+    for k in CSV_COLUMNS:
+        v = fields.get(k, "" if k in ("matrix", "exp_name") else 0)
+        if k in ("matrix", "exp_name"):
+            v = str(v).encode()
+            keep.append(v)
+        setattr(f, names.get(k, k), v)
+    hb, vb = C.create_string_buffer(2048), C.create_string_buffer(4096)
+    check(lib.sparta_blocking_csv_row(C.byref(f), hb, len(hb), vb, len(vb)))
+    return hb.value.decode(), vb.value.decode()
+
+
+def save_blocking_data(outfile, engine, cmat, grouping, save_blocking=True, **fields):
+    """save_blocking_data(outfile, cLine, bEngine, cmat, save_blocking, blocking_outfile) (utilities.cpp:175-245): appends the
+    header + value line to `outfile` and writes the grouping to `outfile + ".g"`.  Blocking statistics come from
+    `engine` (CollectBlockingInfo + the counters of the last GetGrouping); the command-line fields are keyword arguments."""
+    if engine.grouping_result is None:
+        engine.grouping_result = np.ascontiguousarray(grouping, np.int64)
+    engine.CollectBlockingInfo(cmat)
+    row = dict(rows=cmat.rows, cols=cmat.cols, nonzeros=cmat.nztot(), blocking_algo=int(engine.blocking_algo), tau=float(engine.tau),
+               row_block_size=int(engine.row_block_size), col_block_size=int(engine.col_block_size),
+               use_pattern=int(bool(engine.use_pattern)), sim_use_groups=int(bool(engine.use_groups)),
+               sim_measure=int(engine.sim_measure),
+               time_to_block=float(getattr(engine, "timer_total", 0.0)), time_to_merge=float(getattr(engine, "timer_merges", 0.0)),
+               time_to_compare=float(getattr(engine, "timer_comparisons", 0.0)),
+               VBR_nzcount=int(engine.VBR_nzcount), VBR_nzblocks_count=int(engine.VBR_nzblocks_count),
+               VBR_average_height=float(engine.VBR_average_height), VBR_longest_row=int(engine.VBR_longest_row),
+               merge_counter=int(getattr(engine, "merge_counter", 0)), comparison_counter=int(getattr(engine, "comparison_counter", 0)),
+               average_merge_tau=float(getattr(engine, "average_merge_tau", 0.0)),
+               average_row_distance=float(getattr(engine, "average_row_distance", 0.0)),
+               avg_time_multiply=float(getattr(engine, "multiplication_timer_avg", 0.0)),
+               std_time_multiply=float(getattr(engine, "multiplication_timer_std", 0.0)))
+    row.update(fields)
+    header, values = blocking_csv_row(**row)
+    with open(outfile, "a") as f:
+        f.write(header + "\n" + values + "\n")
+    if save_blocking:
+        save_grouping(str(outfile) + ".g", grouping)
+    return header, values
