@@ -144,6 +144,10 @@ typedef struct sparta_csr_host {
  * reference throws or runs into undefined behaviour return SPARTA_ERR_IO.  SPARTA_IO_STRICT reads the documented formats. */
 int sparta_csr_read(const char* path, const char* delimiter, int32_t pattern_only, int32_t mat_fmt, int32_t symmetrize, int32_t mode,
                     sparta_csr_host* out);
+/* the same readers on a text already in memory (what is left in the std::ifstream the reference's CSR constructor is handed,
+ * include/matrices.h:58-63) */
+int sparta_csr_read_buffer(const char* text, int64_t len, const char* delimiter, int32_t pattern_only, int32_t mat_fmt, int32_t symmetrize,
+                           int32_t mode, sparta_csr_host* out);
 void sparta_csr_host_free(sparta_csr_host* m);
 
 /* replaces CSR::save_to_edgelist (src/general/csr.cpp:169-179): "i<delim>j" per entry (el) / "j<delim>i" (mtx flavour) */

@@ -12,11 +12,16 @@
 //     vbmat.multiply(mat_B, B_cols, mat_C);                                  // include/matrices.h:121  (runs on the GPU here)
 //
 // Same type names, field names, argument order and semantics (C is accumulated into; B, C column-major host
-// buffers; `dt` in ms covers the device multiply only).  What is NOT here: the file readers / CLineReader (a driver
-// concern; build a CSR from arrays with CSR::from_flat or fill nzcount/ja/ma yourself) and the CPU CSR::multiply.
+// buffers; `dt` in ms covers the device multiply only).  The file readers, the row permutations, the grouping file and
+// save_blocking_data's CSV row are here too (same quirks as the reference's, see SPARTA_IO_COMPAT in sparta_amd.h).
+// What is NOT here: CLineReader's getopt parsing (a plain struct with the same public fields stands in) and the CPU
+// CSR::multiply (the product has no CPU SpMM).
 // Errors: the reference prints and continues; these shims throw std::runtime_error carrying sparta_last_error().
 #pragma once
 #include <cstring>
+#include <fstream>
+#include <iterator>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -27,7 +32,10 @@ typedef long int intT;   // include/definitions.h:4
 typedef float DataT;     // :5
 typedef float DataT_C;   // :6
 
+enum MatrixFormat { el, mtx };                                                                                                      // :15
 enum BlockingType { iterative, iterative_structured, fixed_size, iterative_clocked, iterative_queue, iterative_max_size, scramble };   // :17
+
+inline std::vector<intT> get_permutation(const std::vector<intT>& grouping);
 
 namespace sparta_compat_detail {
 inline void check(int rc, const char* what) {
@@ -44,6 +52,10 @@ struct CSR {
     bool pattern_only = false;
 
     CSR() = default;
+    // include/matrices.h:58-63: CSR(infile, delimiter, pattern_only, mat_fmt) -- reads what is left in the stream
+    CSR(std::ifstream& infile, std::string delimiter = " ", bool pattern_only = true, MatrixFormat mat_fmt = mtx) {
+        read_from_edgelist(infile, delimiter, pattern_only, mat_fmt);
+    }
     CSR(const CSR&) = delete;
     CSR& operator=(const CSR&) = delete;
     ~CSR() { clean(); }
@@ -55,6 +67,56 @@ struct CSR {
         ja = nullptr; ma = nullptr; nzcount = nullptr; rows = cols = 0;
     }
     intT nztot() const { intT n = 0; for (intT i = 0; i < rows; i++) n += nzcount[i]; return n; }
+
+    // src/general/csr.cpp:183-365, reference behaviour (SPARTA_IO_COMPAT): .el drops its first line, .mtx is pattern-only
+    void read_from_edgelist(std::ifstream& infile, std::string delimiter = " ", bool pattern_only = true, MatrixFormat mat_fmt = mtx,
+                            bool symmetrize = false) {
+        const std::string text((std::istreambuf_iterator<char>(infile)), std::istreambuf_iterator<char>());
+        sparta_csr_host h;
+        sparta_compat_detail::check(sparta_csr_read_buffer(text.data(), (int64_t)text.size(), delimiter.c_str(), pattern_only, (int32_t)mat_fmt,
+                                                           symmetrize, SPARTA_IO_COMPAT, &h), "CSR::read_from_edgelist");
+        std::vector<intT> rp(h.rowptr, h.rowptr + h.rows + 1), ci(h.colidx, h.colidx + h.nnz);
+        from_flat(*this, h.rows, h.cols, rp.data(), ci.data(), h.pattern_only ? nullptr : h.vals);
+        sparta_csr_host_free(&h);
+    }
+    // src/general/csr.cpp:169-179
+    void save_to_edgelist(std::ofstream& outfile, std::string delimiter = " ", bool pattern_only = true, MatrixFormat mat_fmt = el) const {
+        (void)pattern_only;
+        for (intT i = 0; i < rows; i++)
+            for (intT nz = 0; nz < nzcount[i]; nz++) {
+                if (mat_fmt == mtx) outfile << ja[i][nz] << delimiter << i << "\n";
+                else outfile << i << delimiter << ja[i][nz] << "\n";
+            }
+    }
+    // src/general/csr.cpp:67-76 (utilities.h:95-107): new row k = old row permutation[k]
+    void permute_rows(std::vector<intT> permutation) {
+        if ((intT)permutation.size() != rows) throw std::invalid_argument("CSR.permute_rows argument bust have same lenght as rows");
+        std::vector<intT*> nja((size_t)rows);
+        std::vector<DataT*> nma((size_t)rows);
+        std::vector<intT> nnz((size_t)rows);
+        for (intT k = 0; k < rows; k++) {
+            nja[(size_t)k] = ja[permutation[(size_t)k]];
+            if (!pattern_only) nma[(size_t)k] = ma[permutation[(size_t)k]];
+            nnz[(size_t)k] = nzcount[permutation[(size_t)k]];
+        }
+        for (intT k = 0; k < rows; k++) {
+            ja[k] = nja[(size_t)k];
+            if (!pattern_only) ma[k] = nma[(size_t)k];
+            nzcount[k] = nnz[(size_t)k];
+        }
+    }
+    // src/general/csr.cpp:101-109
+    void reorder(std::vector<intT> grouping) {
+        if ((intT)grouping.size() != rows) throw std::invalid_argument("CSR.reorder argument bust have same lenght as rows");
+        permute_rows(get_permutation(grouping));
+    }
+    // src/general/csr.cpp:123-155
+    void reorder_by_degree(bool descending = true) {
+        std::vector<int64_t> rp((size_t)rows + 1, 0), perm((size_t)rows);
+        for (intT i = 0; i < rows; i++) rp[(size_t)i + 1] = rp[(size_t)i] + nzcount[i];
+        sparta_compat_detail::check(sparta_degree_permutation(rows, rp.data(), descending, perm.data()), "CSR::reorder_by_degree");
+        permute_rows(std::vector<intT>(perm.begin(), perm.end()));
+    }
 
     // build from flat CSR arrays (vals == nullptr -> pattern_only)
     static void from_flat(CSR& out, intT rows, intT cols, const intT* rowptr, const intT* colidx, const DataT* vals) {
@@ -174,6 +236,54 @@ class BlockingEngine {
    private:
     int sim_measure_ = 1;
 };
+
+// include/input.h:12-45: the fields save_blocking_data prints (no getopt here: fill them from your own argument parser)
+struct CLineReader {
+    std::string filename_ = "data/TEST_matrix_weighted.el", outfile_ = "results/TEST_results.txt", exp_name_ = "", reader_delimiter_ = " ";
+    int mat_fmt_ = 0;
+    bool sim_use_groups_ = 0, sim_use_pattern_ = 1, pattern_only_ = 0, force_fixed_size = 0, symmetrize_ = false;
+    int blocking_algo_ = 3, seed_ = 0, sim_measure_ = 1, reorder_ = 0, col_block_size_ = 3, row_block_size_ = 3;
+    float tau_ = 0.1f;
+    int verbose_ = 1, multiplication_algo_ = 0, B_cols_ = 1024, warmup_ = 1, exp_repetitions_ = 5, n_streams_ = 4;
+};
+
+// src/general/utilities.cpp:175-245: one header line + one value line (32 columns) to `outfile`, the grouping to `blocking_outfile`
+inline void save_blocking_data(std::ostream& outfile, CLineReader& cLine, BlockingEngine& bEngine, CSR& cmat, bool save_blocking,
+                               std::ostream& blocking_outfile) {
+    bEngine.CollectBlockingInfo(cmat);
+    sparta_csv_fields f;
+    f.matrix = cLine.filename_.c_str(); f.rows = cmat.rows; f.cols = cmat.cols; f.nonzeros = cmat.nztot();
+    f.symmetrize = cLine.symmetrize_; f.blocking_algo = cLine.blocking_algo_; f.tau = cLine.tau_;
+    f.row_block_size = cLine.row_block_size_; f.col_block_size = cLine.col_block_size_; f.use_pattern = cLine.sim_use_pattern_;
+    f.sim_use_groups = cLine.sim_use_groups_; f.sim_measure = cLine.sim_measure_; f.reorder = cLine.reorder_;
+    f.exp_name = cLine.exp_name_.c_str(); f.b_cols = cLine.B_cols_; f.warmup = cLine.warmup_; f.exp_repetitions = cLine.exp_repetitions_;
+    f.multiplication_algo = cLine.multiplication_algo_; f.n_streams = cLine.n_streams_;
+    f.time_to_block = bEngine.timer_total; f.time_to_merge = bEngine.timer_merges; f.time_to_compare = bEngine.timer_comparisons;
+    f.vbr_nzcount = bEngine.VBR_nzcount; f.vbr_nzblocks_count = bEngine.VBR_nzblocks_count;
+    f.vbr_average_height = bEngine.VBR_average_height; f.vbr_longest_row = bEngine.VBR_longest_row;
+    f.merge_counter = bEngine.merge_counter; f.comparison_counter = bEngine.comparison_counter;
+    f.average_merge_tau = bEngine.average_merge_tau; f.average_row_distance = bEngine.average_row_distance;
+    f.avg_time_multiply = bEngine.multiplication_timer_avg; f.std_time_multiply = bEngine.multiplication_timer_std;
+    char header[2048], values[4096];
+    sparta_compat_detail::check(sparta_blocking_csv_row(&f, header, sizeof header, values, sizeof values), "save_blocking_data");
+    outfile << header << std::endl;
+    outfile << values << std::endl;
+    if (save_blocking)
+        for (intT i = 0; i < cmat.rows; i++) blocking_outfile << bEngine.grouping_result[(size_t)i] << "\n";
+}
+
+// test/general/Matrix_Analysis.cpp:10-32 (the caller drops a leading count: `if (size == rows + 1) erase(begin)`, :78)
+inline std::vector<intT> read_grouping_file(const std::string& filename) {
+    std::vector<int64_t> buf(1 << 16);
+    int64_t n = 0;
+    int rc = sparta_grouping_read(filename.c_str(), -1, buf.data(), (int64_t)buf.size(), &n);
+    if (rc != SPARTA_OK && n > (int64_t)buf.size()) {
+        buf.resize((size_t)n);
+        rc = sparta_grouping_read(filename.c_str(), -1, buf.data(), (int64_t)buf.size(), &n);
+    }
+    if (rc != SPARTA_OK) return std::vector<intT>();             // the reference prints a message and returns an empty vector
+    return std::vector<intT>(buf.begin(), buf.begin() + n);
+}
 
 // include/matrices.h:93-125
 struct VBR {

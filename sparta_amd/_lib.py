@@ -34,7 +34,7 @@ SYMBOLS = [
     "sparta_vbs_spmm", "sparta_vbs_spmm_gathered", "sparta_vbs_set_class_timing",
     "sparta_vbs_class_times", "sparta_vbs_clock_mhz", "sparta_vbs_destroy", "sparta_vbs_info", "sparta_device_count", "sparta_last_error",
     "sparta_version",
-    "sparta_csr_read", "sparta_csr_host_free", "sparta_csr_write_edgelist", "sparta_grouping_write", "sparta_grouping_read",
+    "sparta_csr_read", "sparta_csr_read_buffer", "sparta_csr_host_free", "sparta_csr_write_edgelist", "sparta_grouping_write", "sparta_grouping_read",
     "sparta_blocking_csv_row", "sparta_degree_permutation",
 ]
 
@@ -114,6 +114,7 @@ def _load():
     L.sparta_vbs_clock_mhz.argtypes = [vp, C.POINTER(C.c_double)]
     L.sparta_vbs_destroy.argtypes = [vp]
     L.sparta_csr_read.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CsrHost)]
+    L.sparta_csr_read_buffer.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(CsrHost)]
     L.sparta_csr_host_free.argtypes = [C.POINTER(CsrHost)]
     L.sparta_csr_host_free.restype = None
     L.sparta_csr_write_edgelist.argtypes = [C.c_char_p, C.c_int64, i64p, i32p, C.c_char_p, C.c_int32]

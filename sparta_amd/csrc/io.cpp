@@ -255,20 +255,33 @@ std::string f2s(float v) {                                  // std::to_string(fl
 
 extern "C" {
 
-int sparta_csr_read(const char* path, const char* delimiter, int32_t pattern_only, int32_t mat_fmt, int32_t symmetrize, int32_t mode,
-                    sparta_csr_host* out) {
-    if (!path || !out) return fail(SPARTA_ERR_INVALID, "sparta_csr_read: NULL argument");
-    std::memset(out, 0, sizeof *out);
+static int read_stream(std::istream& in, const char* delimiter, int32_t pattern_only, int32_t mat_fmt, int32_t symmetrize, int32_t mode,
+                       sparta_csr_host* out) {
     if (mat_fmt != SPARTA_FMT_EL && mat_fmt != SPARTA_FMT_MTX) return fail(SPARTA_ERR_INVALID, "sparta_csr_read: mat_fmt must be SPARTA_FMT_EL or SPARTA_FMT_MTX");
     if (mode != SPARTA_IO_COMPAT && mode != SPARTA_IO_STRICT) return fail(SPARTA_ERR_INVALID, "sparta_csr_read: mode must be SPARTA_IO_COMPAT or SPARTA_IO_STRICT");
-    std::ifstream in(path);
-    if (!in.good()) return fail(SPARTA_ERR_IO, std::string("sparta_csr_read: cannot open '") + path + "'");
     const std::string delim = delimiter ? delimiter : " ";
     if (mat_fmt == SPARTA_FMT_MTX) {
         if (mode == SPARTA_IO_COMPAT) return read_mtx_compat(in, out);
         return read_mtx_strict(in, pattern_only != 0, out);
     }
     return read_el(in, delim, pattern_only != 0, symmetrize != 0, mode == SPARTA_IO_COMPAT, out);
+}
+
+int sparta_csr_read(const char* path, const char* delimiter, int32_t pattern_only, int32_t mat_fmt, int32_t symmetrize, int32_t mode,
+                    sparta_csr_host* out) {
+    if (!path || !out) return fail(SPARTA_ERR_INVALID, "sparta_csr_read: NULL argument");
+    std::memset(out, 0, sizeof *out);
+    std::ifstream in(path);
+    if (!in.good()) return fail(SPARTA_ERR_IO, std::string("sparta_csr_read: cannot open '") + path + "'");
+    return read_stream(in, delimiter, pattern_only, mat_fmt, symmetrize, mode, out);
+}
+
+int sparta_csr_read_buffer(const char* text, int64_t len, const char* delimiter, int32_t pattern_only, int32_t mat_fmt, int32_t symmetrize,
+                           int32_t mode, sparta_csr_host* out) {
+    if ((!text && len > 0) || len < 0 || !out) return fail(SPARTA_ERR_INVALID, "sparta_csr_read_buffer: bad argument");
+    std::memset(out, 0, sizeof *out);
+    std::istringstream in(std::string(text ? text : "", (size_t)len));
+    return read_stream(in, delimiter, pattern_only, mat_fmt, symmetrize, mode, out);
 }
 
 void sparta_csr_host_free(sparta_csr_host* m) {

@@ -5,9 +5,39 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <sstream>
 #include "sparta_compat.hpp"
 
+// written like the reference's Matrix_Blocking driver (test/general/Matrix_Blocking.cpp): read, block, save statistics + grouping
+static int io_mode(const char* path) {
+    std::ifstream fin(path);
+    CSR cmat(fin, " ", false, el);
+    std::printf("read: %ld %ld %ld\n", cmat.rows, cmat.cols, cmat.nztot());
+    CLineReader cli;
+    cli.filename_ = "data/TEST_matrix_weighted.el"; cli.exp_name_ = "exp0"; cli.tau_ = 0.6f; cli.col_block_size_ = 3; cli.row_block_size_ = 3;
+    BlockingEngine bEngine;
+    bEngine.tau = cli.tau_; bEngine.col_block_size = cli.col_block_size_; bEngine.row_block_size = cli.row_block_size_;
+    bEngine.blocking_algo = (BlockingType)cli.blocking_algo_; bEngine.SetComparator(cli.sim_measure_);
+    bEngine.GetGrouping(cmat);
+    bEngine.timer_total = 1234.5f; bEngine.timer_merges = 77.25f; bEngine.timer_comparisons = 901.0f;    // pinned clocks (golden fixture)
+    bEngine.multiplication_timer_avg = 0.125f; bEngine.multiplication_timer_std = 0.001f;
+    std::ostringstream csv, g;
+    save_blocking_data(csv, cli, bEngine, cmat, true, g);
+    std::string c = csv.str(), gs = g.str();
+    for (char& ch : c) if (ch == '\n') ch = '|';
+    for (char& ch : gs) if (ch == '\n') ch = ' ';
+    std::printf("csv:%s\ngfile:%s\n", c.c_str(), gs.c_str());
+    cmat.reorder_by_degree(true);
+    std::printf("degrees:");
+    for (intT i = 0; i < cmat.rows; i++) std::printf(" %ld", cmat.nzcount[i]);
+    std::printf("\n");
+    cmat.reorder(bEngine.grouping_result);                 // any grouping of the right length permutes the rows
+    std::printf("nnz_after: %ld\n", cmat.nztot());
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 2 && std::strcmp(argv[1], "io") == 0) return io_mode(argv[2]);
     const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
     // data/TEST_matrix_weighted.el as the reference's reader parses it (first data line dropped)
     intT rowptr[] = {0, 0, 3, 6, 10, 10, 11, 11, 11, 12};

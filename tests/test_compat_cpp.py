@@ -18,8 +18,8 @@ def _build():
     return EXE
 
 
-def _run(mode):
-    out = subprocess.check_output([_build(), mode], text=True)
+def _run(mode, *args):
+    out = subprocess.check_output([_build(), mode] + list(args), text=True)
     return dict(line.split(":", 1) for line in out.strip().splitlines())
 
 
@@ -38,3 +38,15 @@ def test_compat_driver_multiplies_on_gpu():
     want = [0, 0, 0, 0, 126, 22, 102, 14, 10, 0, 0, 0, 0, 306, 49, 219, 32, 55]
     assert [float(x) for x in r["C"].split()] == want
     assert [float(x) for x in r["C2"].split()] == [2 * x for x in want]
+
+
+def test_compat_driver_reads_blocks_and_writes_the_csv_row_like_the_reference():
+    """CSR(ifstream, ...) + save_blocking_data + reorder_by_degree, against the compiled reference's output (tests/golden/io.npz)"""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "io.npz"))
+    r = _run("io", os.path.join(ROOT, "tests", "golden", "ref_data", "TEST_matrix_weighted.el"))
+    assert r["read"].split() == ["9", "9", "12"]
+    assert r["csv"] == str(z["csv/0/csv"]).replace("\n", "|")
+    assert r["gfile"].split() == str(z["csv/0/gfile"]).split()
+    assert [int(x) for x in r["degrees"].split()] == sorted([0, 3, 3, 4, 0, 1, 0, 0, 1], reverse=True)
+    assert r["nnz_after"].split() == ["12"]
