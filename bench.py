@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--row-block", type=int, default=32, help="max / fixed block-row height (-B)")
     ap.add_argument("--force-fixed", type=int, default=1, help="-F: re-chunk clusters into equal heights")
     ap.add_argument("--col-block", type=int, default=32)
+    ap.add_argument("--dtype", choices=["f32", "f16", "bf16"], default="f32",
+                    help="storage type of A and B on the device (accumulation and C are always fp32); 16-bit: single GPU only")
     ap.add_argument("--ncols", type=int, default=128)
     ap.add_argument("--fixed-height", type=int, default=0, help="reorder OFF: fixed block-row height instead of clustering")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,12 +106,21 @@ def main():
     t0 = time.time()
     vb = sa.VBR().fill_from_CSR_inplace(m, grouping, w, args.row_block, bool(args.force_fixed) and not args.fixed_height)
     t_build = time.time() - t0
-    d = vb.to_device(local_rank)
+    h16 = args.dtype != "f32"
+    if h16 and distributed:
+        raise SystemExit("--dtype f16/bf16 is a single-GPU option (the gathered-B entry point is fp32)")
+    d = vb.to_device(local_rank, dtype={"f32": sa.F32, "f16": sa.F16, "bf16": sa.BF16}[args.dtype])
     info = d.info()
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    ldb = vb.cols
     if not distributed:
         B = (torch.rand(vb.cols * N, generator=g, dtype=torch.float32) - 0.5).to(dev)      # column-major, ld = cols
+        if h16:                                                # 16-bit B, leading dimension padded to a multiple of 8 elements
+            ldb = (vb.cols + 7) // 8 * 8
+            B32 = B
+            B = torch.zeros(ldb * N, dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16, device=dev)
+            B.view(N, ldb)[:, :vb.cols] = B32.view(N, vb.cols).to(B.dtype)
         B_shard = B_gath = None
     else:
         B_shard = (torch.rand(shard_rows * N, generator=g, dtype=torch.float32) - 0.5).to(dev)   # column-major, ld = shard_rows
@@ -118,7 +129,7 @@ def main():
 
     def step():
         if not distributed:
-            d.spmm(B, C, N, accumulate=False)
+            d.spmm(B, C, N, accumulate=False, ldb=ldb)
         else:
             dist.all_gather_into_tensor(B_gath, B_shard)          # the one exchange step (RCCL over xGMI)
             d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False)
@@ -209,10 +220,20 @@ def main():
         "algorithmic_gbs": round(bytes_alg / (kernel_ms_total * 1e-3) / 1e9, 1) if kernel_ms_total > 0 else 0.0,
         "algorithmic_bytes": round(bytes_alg),
     }
+    if h16:
+        # 16-bit storage: the MFMAs take 1/8 (fp16 / bf16 dense peak ~2.5 PFLOP/s) of the fp32 time while the bytes only halve:
+        # the kernel is bound by memory traffic.  Algorithmic bytes: packed 16-bit A (read once) + 16-bit B (once) + fp32 C.
+        bytes16 = float(info["a_bytes"]) + 2.0 * ldb * N + 4.0 * vb.rows * N
+        gbs = bytes16 / (kernel_ms_total * 1e-3) / 1e9 if kernel_ms_total > 0 else 0.0
+        roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                         "kernel": "vbs_spmm_h16_stream_kernel", "algorithmic_bytes": round(bytes16), "algorithmic_gbs": round(gbs, 1),
+                         "executed_tflops": round(dom_tflops, 3)})
+        roofline.pop("mixed_roofline_frac", None)
     # `peak` is the 2.4 GHz figure of MI355X_MICROARCH.md; under this load the board does not hold 2.4 GHz (power), so the
     # measured shader clock and the fraction of the matrix peak AT THAT CLOCK are reported next to it (informational)
     if kernel_mhz.get(dom, 0) > 0:
         roofline["shader_clock_mhz"] = round(kernel_mhz[dom], 0)
+    if kernel_mhz.get(dom, 0) > 0 and not h16:
         roofline["frac_at_measured_clock"] = round(dom_tflops / (PEAK_MFMA_F32_TFLOPS * kernel_mhz[dom] / PEAK_CLOCK_MHZ), 4)
 
     # ---- CPU baseline: the reference's own VBR::multiply on this host, 1 thread -----------------------------------
@@ -221,7 +242,7 @@ def main():
         try:
             from oracle import ref, oracle as O
             if not distributed:
-                Bh = B.cpu().numpy()
+                Bh = (B.view(N, ldb)[:, :vb.cols].float().contiguous().view(-1) if h16 else B).cpu().numpy()
             else:
                 Bh = sa.dist.gathered_to_colmajor(B_gath.cpu().numpy(), world, shard_rows, N)
             # bounded sample: a prefix of block-rows worth <= ~2e10 executed flops (about 10-20 s of scalar CPU work)
@@ -260,7 +281,7 @@ def main():
     out = {
         "metric": "Block-sparse SpMM GFLOP/s", "value": round(useful_gflops, 2), "unit": "GFLOP/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {
             "workload": ("cant-like FEM 9x9x257 mesh x 3 dof (62451^2, %d nnz), B = %d cols, fp32" % (nnz_local, N)) if not distributed else
                         ("row-partitioned FEM 9x9x%d mesh x 3 dof (%d^2 padded, %d nnz), B = %d cols, fp32, 1 all-gather of B per step"

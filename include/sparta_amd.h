@@ -217,7 +217,8 @@ typedef struct sparta_vbs sparta_vbs_t;   /* opaque; owns the device image of A 
 
 /* Uploads a VBS matrix (the reference's arrays, host pointers) to `device` once and builds the tile
  * plan.  Replaces the per-call cudaMalloc + H2D of A that every reference back-end performs
- * (src/cuda/cuda_utilities.cpp:779-789).  dtype conversion (f32 -> f16/bf16) happens here. */
+ * (src/cuda/cuda_utilities.cpp:779-789).  dtype SPARTA_F16 / SPARTA_BF16: the values are rounded (nearest even) and
+ * re-laid-out for the 16-bit MFMA here, once (needs block_col_size % 32 == 0); products are accumulated in fp32. */
 int sparta_vbs_create(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t block_col_size,
                       const int64_t* row_part, const int64_t* nzcount, const int64_t* jab, const float* mab,
                       int32_t dtype, int32_t device);
@@ -232,8 +233,11 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
  *   cublas_fixed_blocks_multiply / cublas_blockmat_batched / cutlas_* (const VBR&, DataT* B, int B_cols,
  *   DataT_C* C, float& dt[, int n_streams])            (include/cuda_utilities.h:38-44,
  *                                                        include/cutlass_bellpack_lib.h:19-25).
- * B: `cols` x n_cols, C: `rows` x n_cols (rows of this handle), element type fp32 for dtype F32,
- * and the handle's 16-bit type for B with fp32 C otherwise.  accumulate = 1 is the reference's
+ * B: `cols` x n_cols, C: `rows` x n_cols (rows of this handle).  fp32 handles: fp32 B and C, any layout, any n_cols.
+ * 16-bit handles: C is fp32; with SPARTA_PTR_DEVICE B is in the handle's 16-bit type, column-major, ldb even, n_cols a
+ * multiple of 128 (SPARTA_ERR_UNSUPPORTED otherwise); with SPARTA_PTR_HOST B is fp32 like in the reference and is rounded
+ * on the device.  Tolerance of the 16-bit path: exact products of the ROUNDED inputs, fp32 accumulation -- the same bound
+ * as the fp32 MFMA path relative to the reference's multiply run on the rounded inputs.  accumulate = 1 is the reference's
  * semantics (C += A*B); 0 overwrites C (every row of C is written).  ptr_space HOST: buffers are
  * copied to/from the device around the kernel and *dt_ms (may be NULL) covers the kernel only;
  * DEVICE: launched on `stream` (a hipStream_t, NULL = default stream); if dt_ms != NULL the call

@@ -727,6 +727,223 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
     clock_probe(p.clk, 2);
 }
 
+// =====================================================================================================
+// 16-bit (fp16 / bf16) storage, fp32 accumulation: vbs_spmm_h16_stream_kernel<KP, MI2, BF16>
+// Same persistent design, step records, plans and epilogue as the fp32 stream kernel; what changes is the operand path.
+// * A is re-laid-out ONCE at sparta_vbs_create: every step's slice is a dense row-major TM x KP chunk (k contiguous, rows
+//   past the tile zero), the chunks of a tile back to back.  The 16-bit MFMA wants 8 consecutive k of one row per lane; the
+//   reference's column-major blocks have k strided, and transposing 16-bit data on the way into LDS costs 8 ds_write_b16 per
+//   16-byte load.  The host-side VBS (the boundary) keeps the reference's layout; only the device copy differs.
+// * B must be column-major (k contiguous per column) with an even leading dimension: Bs[j][k], As[i][k], rows padded by
+//   8 elements; a fragment is one ds_read_b128 (8 k) per operand and feeds v_mfma_f32_32x32x16_{f16,bf16}.
+// * D = Bpanel^T . Atile^T as in the fp32 kernels (accumulator layout and epilogue are the same); an MFMA sums its k slots,
+//   so any lane -> k assignment works as long as both operands use the same one (lane group g takes k = kb + 8g .. +7).
+// A step moves half the bytes of the fp32 kernel and its MFMAs take 1/8 of the time: this kernel is bound by the load path
+// (L2 / Infinity Cache -> LDS), not by MFMA.
+// =====================================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int KP, bool MI2, bool BF16>
+__global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const StreamParams p) {
+    constexpr int TN = kTN, TM = MI2 ? 64 : 32;
+    constexpr int LDK = KP + 8;                          // elements per LDS row
+    constexpr int BSZ = TN * LDK;                        // elements of the B panel image
+    constexpr int STAGE = BSZ + 64 * LDK;                // elements per LDS stage
+    constexpr int CPC = KP / 8;                          // 16-byte chunks per row / column
+    constexpr int CPP = kThreads / CPC;                  // B columns covered by one load pass
+    constexpr int NBL = TN / CPP;                        // B loads per thread and step (4 for KP 64, 2 for KP 32)
+    constexpr int NAL = (TM * CPC + kThreads - 1) / kThreads;   // A loads per thread and step (2, 1, 1, 1)
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 31, g = lane >> 5;
+    const int n0 = blockIdx.y * TN;
+    const int s_begin = p.worker_range[2 * blockIdx.x];
+    const int n = p.worker_range[2 * blockIdx.x + 1] - s_begin;
+    if (n <= 0) return;
+    clock_probe(p.clk, 0);
+    float* ws = p.ws + (int64_t)blockIdx.y * p.ws_slab_stride;
+    const uint16_t* A16 = reinterpret_cast<const uint16_t*>(p.A);
+    const uint16_t* B16 = reinterpret_cast<const uint16_t*>(p.B);
+    const uint16_t* Bt16 = reinterpret_cast<const uint16_t*>(p.B_tail);
+
+    const int32_t* srec = reinterpret_cast<const int32_t*>(p.steps + s_begin);
+    int vrec0 = srec[lane];
+    int vrec1 = srec[64 + lane];
+    int vnext = 0;
+    auto field = [&](int s, int f) __attribute__((always_inline)) -> int32_t {
+        const int ln = ((s & 7) << 3) + f;
+        const int32_t x0 = __builtin_amdgcn_readlane(vrec0, ln), x1 = __builtin_amdgcn_readlane(vrec1, ln);
+        return ((s >> 3) & 1) ? x1 : x0;
+    };
+    enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6 };
+
+    const int bj0 = tid / CPC, bc = tid % CPC;           // B: column bj0 + CPP q, chunk bc (k = 8 bc .. 8 bc + 7)
+    const int ac = tid % (TM * CPC);                     // A: chunk ac (+ 256 q) of the contiguous TM x KP slice (clamped: duplicates are harmless)
+    const int64_t ld_t = (int64_t)p.w;                   // leading dimension of B_tail
+    const uint32_t voffB = (uint32_t)((bc * 8 + bj0 * p.ldb) * 2), voffBt = (uint32_t)((bc * 8 + (n0 + bj0) * ld_t) * 2);
+    const uint32_t qstepB = (uint32_t)(CPP * p.ldb * 2), qstepBt = (uint32_t)(CPP * ld_t * 2);
+    const int64_t n0off = (int64_t)n0 * p.ldb;
+    const uint32_t lwB = (uint32_t)((bj0 * LDK + bc * 8) * 2);
+    const uint32_t lwA = (uint32_t)((BSZ + (ac / CPC) * LDK + (ac % CPC) * 8) * 2);
+    const uint32_t lrB = (uint32_t)(((32 * wave + lm) * LDK + 8 * g) * 2);
+    const uint32_t lrA = (uint32_t)((BSZ + lm * LDK + 8 * g) * 2);
+    const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 32 * wave + 4 * g) * 4) : (uint32_t)((lm + (32 * wave + 4 * g) * p.ldc) * 4);
+    char* const ldsb = reinterpret_cast<char*>(lds);
+
+    u32x4 b0[NBL], a0[NAL], b1[NBL], a1[NAL];
+
+    int64_t g_aoff = 0;
+    auto issue_loads = [&](int s, u32x4 (&rb)[NBL], u32x4 (&ra)[NAL]) __attribute__((always_inline)) {
+        const int32_t flags = field(s, F_FLAGS);
+        if (flags & STEP_FIRST) g_aoff = (int64_t)(uint32_t)field(s, F_AOFF_LO) | ((int64_t)field(s, F_AOFF_HI) << 32);
+        else g_aoff += (int64_t)TM * KP;                 // the slices of a tile are back to back
+        const bool tail = (flags & STEP_TAIL) != 0;
+        const int64_t gk0 = field(s, F_BROW);
+        const uint16_t* bptr = tail ? Bt16 + gk0 : B16 + gk0 + n0off;
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(bptr), 0, 0x7ffffff0, 0x00020000);
+        const uint32_t vo = tail ? voffBt : voffB, qs = tail ? qstepBt : qstepB;
+#pragma unroll
+        for (int q = 0; q < NBL; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo, qs * q, 0);
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A16 + g_aoff), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < NAL; q++) ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rA, (uint32_t)ac * 16u, (uint32_t)(q * kThreads * 16), 2);
+    };
+    auto write_stage = [&](auto stage_tag, const u32x4 (&rb)[NBL], const u32x4 (&ra)[NAL]) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_tag)::value;
+#pragma unroll
+        for (int q = 0; q < NBL; q++) *reinterpret_cast<u32x4*>(ldsb + lwB + (ST * STAGE + q * CPP * LDK) * 2) = rb[q];
+#pragma unroll
+        for (int q = 0; q < NAL; q++) *reinterpret_cast<u32x4*>(ldsb + lwA + (ST * STAGE + q * (kThreads / CPC) * LDK) * 2) = ra[q];
+    };
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    auto mfma = [&](const u32x4& bf, const u32x4& af, f32x16& acc) __attribute__((always_inline)) {
+        if constexpr (BF16) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf), __builtin_bit_cast(bf16x8, af), acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf), __builtin_bit_cast(f16x8, af), acc, 0, 0, 0);
+    };
+
+    auto iteration_t = [&](int i, int32_t flags, u32x4 (&wb)[NBL], u32x4 (&wa)[NAL], auto par_tag) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_tag)::value;
+        using nxt_t = std::integral_constant<int, 1 - PAR>;
+        write_stage(nxt_t{}, wb, wa);
+        issue_loads(i + 3, wb, wa);
+#pragma unroll
+        for (int kb = 0; kb < KP; kb += 16) {
+            const u32x4 bf = *reinterpret_cast<const u32x4*>(ldsb + lrB + (PAR * STAGE + kb) * 2);
+            const u32x4 af0 = *reinterpret_cast<const u32x4*>(ldsb + lrA + (PAR * STAGE + kb) * 2);
+            mfma(bf, af0, acc0);
+            if constexpr (MI2) {
+                const u32x4 af1 = *reinterpret_cast<const u32x4*>(ldsb + lrA + (PAR * STAGE + 32 * LDK + kb) * 2);
+                mfma(bf, af1, acc1);
+            }
+        }
+        if (flags & STEP_LAST) {
+            if (flags & STEP_SPLIT) {
+                const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_SLOT) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc0[q]), rW, (uint32_t)tid * 4u, (uint32_t)(q * kThreads * 4), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1[q]), rW, (uint32_t)tid * 4u, (uint32_t)((16 + q) * kThreads * 4), 0);
+                }
+            } else {
+                const int mt = flags & 0xffff;
+                const int64_t c_row = field(i, F_CROW);
+                float* cbase = p.c_row_major ? p.C + c_row * p.ldc + n0 : p.C + c_row + (int64_t)n0 * p.ldc;
+                const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
+                const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;
+                const uint32_t mistep = p.c_row_major ? (uint32_t)p.ldc * 128u : 128u;
+#pragma unroll
+                for (int mi = 0; mi < (MI2 ? 2 : 1); mi++) {
+                    if (mi * 32 + lm < mt) {
+                        float v[16];
+#pragma unroll
+                        for (int q = 0; q < 16; q++) v[q] = mi == 0 ? acc0[q] : acc1[q];
+                        if (p.accumulate) {
+                            uint32_t old[16];
+#pragma unroll
+                            for (int q = 0; q < 16; q++) old[q] = __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
+#pragma unroll
+                            for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 16; q++)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
+        }
+        __syncthreads();
+    };
+
+    using st0 = std::integral_constant<int, 0>;
+    using st1 = std::integral_constant<int, 1>;
+    issue_loads(0, b0, a0);
+    issue_loads(1, b1, a1);
+    write_stage(st0{}, b0, a0);
+    issue_loads(2, b0, a0);
+    __syncthreads();
+    // record batches: see the fp32 kernel.  At least 4 steps x (NBL + NAL >= 3) = 12 loads are issued between request and touch.
+    auto batch_upkeep = [&](int i) __attribute__((always_inline)) {
+        if ((i & 7) == 0 && i > 0) {
+            const int32_t* nb = srec + (int64_t)((i >> 3) + 1) * 64 + lane;
+            asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
+        }
+        if ((i & 7) == 4 && i > 4) {
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(vnext) : : "memory");
+            if (((i >> 3) + 1) & 1) vrec1 = vnext; else vrec0 = vnext;
+        }
+    };
+    const int n_even = n & ~1;
+    for (int i = 0; i < n_even; i += 2) {
+        batch_upkeep(i);
+        iteration_t(i, field(i, F_FLAGS), b1, a1, st0{});
+        iteration_t(i + 1, field(i + 1, F_FLAGS), b0, a0, st1{});
+    }
+    if (n & 1) {
+        batch_upkeep(n_even);
+        iteration_t(n_even, field(n_even, F_FLAGS), b1, a1, st0{});
+    }
+    clock_probe(p.clk, 2);
+}
+
+// zero-padded copy of the rows of a 16-bit column-major B that face the last (partial) block column: B_tail[k + w j], k < w
+__global__ __launch_bounds__(kThreads) void vbs_tail_copy_h16_kernel(const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N,
+                                                                     uint16_t* B_tail) {
+    const int64_t total = (int64_t)w * N;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int64_t k = e % w, j = e / w;
+        B_tail[e] = (row0 + k < cols) ? B[row0 + k + j * ldb] : (uint16_t)0;
+    }
+}
+
+// fp32 -> fp16 / bf16 (round to nearest even), column by column: src ld_in, dst ld_out (host-pointer convenience path)
+template <bool BF16>
+__global__ __launch_bounds__(kThreads) void vbs_convert_h16_kernel(const float* src, int64_t ld_in, int64_t rows, int64_t n_cols, uint16_t* dst,
+                                                                   int64_t ld_out) {
+    const int64_t total = rows * n_cols;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int64_t k = e % rows, j = e / rows;
+        const float v = src[k + j * ld_in];
+        uint16_t o;
+        if constexpr (BF16) {
+            uint32_t u = __float_as_uint(v);
+            if ((u & 0x7fffffffu) > 0x7f800000u) o = (uint16_t)((u >> 16) | 0x40);          // NaN stays NaN
+            else o = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        } else {
+            const _Float16 h = (_Float16)v;
+            o = __builtin_bit_cast(uint16_t, h);
+        }
+        dst[k + j * ld_out] = o;
+    }
+}
+
 // adds the partial images of every split tile (fixed order: worker order) and writes the tile
 __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_fixup_kernel(const FixRec* fix, const int32_t* fix_slots, const float* ws_all,
                                                                       int64_t ws_slab_stride, float* C, int64_t ldc, int c_row_major,
@@ -826,7 +1043,8 @@ struct DeviceGuard {
 struct sparta_vbs {
     int device = 0, dtype = SPARTA_F32;
     int64_t rows = 0, cols = 0, block_rows = 0, w = 0, nblocks = 0, nztot = 0;
-    float* d_A = nullptr;
+    float* d_A = nullptr;                    // fp32: the reference's mab; 16-bit handles: packed slices (see sparta_vbs_create)
+    int kp16 = 0;                            // 16-bit handles: k depth of a step (32 or 64)
     int32_t* d_jab = nullptr;
     TileDesc* d_tiles[4] = {nullptr, nullptr, nullptr, nullptr};   // classes 16, 32, 64, 128
     int64_t n_tiles[4] = {0, 0, 0, 0};       // launch entries (real tiles + padding)
@@ -856,6 +1074,8 @@ struct sparta_vbs {
     float tune_ms[2] = {0.0f, 0.0f};
     void* d_tune = nullptr;
     size_t d_tune_bytes = 0;
+    void* d_B16 = nullptr;                 // 16-bit handles, host-pointer calls: B converted on the device
+    size_t d_B16_bytes = 0;
     long long* d_clk = nullptr;           // clock probe: [4 launches][4] = {s_memtime, s_memrealtime} at entry, at exit
     hipEvent_t tev0 = nullptr, tev1 = nullptr;
     void* d_B = nullptr;
@@ -892,6 +1112,20 @@ int ensure_scratch(void** ptr, size_t* have, size_t need) {
     return SPARTA_OK;
 }
 
+// fp32 -> fp16 / bf16 bits, round to nearest even (what the device conversion kernel does too)
+inline uint16_t to_h16(float v, bool bf16) {
+    if (bf16) {
+        uint32_t u;
+        std::memcpy(&u, &v, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+        return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    const _Float16 h = (_Float16)v;
+    uint16_t o;
+    std::memcpy(&o, &h, 2);
+    return o;
+}
+
 void destroy_impl(sparta_vbs* v) {
     if (!v) return;
     DeviceGuard g(v->device);
@@ -909,6 +1143,7 @@ void destroy_impl(sparta_vbs* v) {
     if (v->d_ws) (void)hipFree(v->d_ws);
     if (v->d_btail) (void)hipFree(v->d_btail);
     if (v->d_tune) (void)hipFree(v->d_tune);
+    if (v->d_B16) (void)hipFree(v->d_B16);
     if (v->d_clk) (void)hipFree(v->d_clk);
     if (v->tev0) (void)hipEventDestroy(v->tev0);
     if (v->tev1) (void)hipEventDestroy(v->tev1);
@@ -941,7 +1176,10 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
     if (rows <= 0 || cols <= 0 || block_rows <= 0 || w <= 0 || !row_part || !nzcount)
         return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad dimensions or NULL index array");
     if (br0 < 0 || br1 > block_rows || br0 >= br1) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad block-row range");
-    if (dtype != SPARTA_F32) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: only SPARTA_F32 is implemented in this build");
+    if (dtype != SPARTA_F32 && dtype != SPARTA_F16 && dtype != SPARTA_BF16) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad dtype");
+    const bool h16 = dtype != SPARTA_F32;
+    if (h16 && w % 32 != 0)
+        return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: SPARTA_F16 / SPARTA_BF16 need block_col_size % 32 == 0 (only the stream kernels have a 16-bit form)");
     if (rows > INT32_MAX || w > (1 << 20)) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: rows >= 2^31 or w > 2^20");
     const int64_t block_cols = (cols - 1) / w + 1;
 
@@ -1052,6 +1290,9 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
     std::vector<int32_t> fix_slots;
     int n_workers = 0, n_split = 0;
     int plan_aligned[2] = {0, 0};
+    // k depth of a step: 32 for fp32; the 16-bit kernels take 64 when the block width allows (their steps are short: fewer, fatter)
+    const int64_t kp = !h16 ? SK_KP : (w % 64 == 0 ? 64 : 32);
+    std::vector<uint16_t> a16;               // 16-bit handles: A re-laid-out as dense row-major TM x kp slices, one per step
     if (w % SK_KP == 0) {
         hipDeviceProp_t prop;
         int cus = 256;
@@ -1061,6 +1302,7 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
         n_workers = ((cus * per_cu + 7) / 8) * 8;
         // modelled cost of a step and of a tile's epilogue, per type
         int c2 = 20, c1 = 13, ct = 6;
+        if (h16) { c2 = 12; c1 = 10; }                   // load-bound steps: cost ~ bytes moved, (64 + 128) vs (32 + 128) rows and columns
         if (const char* e = std::getenv("SPARTA_COST_MODEL")) sscanf(e, "%d,%d,%d", &c2, &c1, &ct);
         int64_t split_penalty = 120;                     // cost units (~0.11 us each) the fix-up launch adds to a split plan
         if (const char* e = std::getenv("SPARTA_SPLIT_PENALTY")) split_penalty = atoll(e);
@@ -1093,9 +1335,19 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
                         TileSpan sp{(int64_t)st.size(), 0, c_row, mt};
                         for (int64_t b = 0; b < nb; b++) {
                             const int64_t jb = jab[jab_lo + jo2 + b];
-                            for (int64_t ks = 0; ks < w; ks += SK_KP) {
+                            for (int64_t ks = 0; ks < w; ks += kp) {
                                 StepRec r;
                                 r.a_off = mo2 + r0 + (b * w + ks) * h;
+                                if (h16) {                                  // pack this step's slice: [row][k], rows past the tile zero
+                                    const int64_t tms = ty ? 64 : 32;
+                                    r.a_off = (int64_t)a16.size();
+                                    a16.resize(a16.size() + (size_t)(tms * kp), 0);
+                                    uint16_t* dst = a16.data() + r.a_off;
+                                    const float* blk = mab + mab_lo + mo2 + b * h * w;       // column-major h x w block
+                                    for (int64_t rr = 0; rr < mt; rr++)
+                                        for (int64_t kk = 0; kk < kp; kk++)
+                                            dst[rr * kp + kk] = to_h16(blk[(ks + kk) * h + r0 + rr], dtype == SPARTA_BF16);
+                                }
                                 r.b_row = (int32_t)(jb * w + ks);
                                 r.h = (int32_t)h;
                                 r.c_row = c_row;
@@ -1262,10 +1514,19 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
         }                                                                                                    \
     } while (0)
     // A is padded by 128 floats so that no (masked-off) lane ever forms an address past the allocation
-    v->a_bytes = (nztot + 128) * (int64_t)sizeof(float);
-    CREATE_TRY(hipMalloc((void**)&v->d_A, (size_t)v->a_bytes));
-    CREATE_TRY(hipMemset(v->d_A, 0, (size_t)v->a_bytes));
-    if (nztot > 0) CREATE_TRY(hipMemcpy(v->d_A, mab + mab_lo, (size_t)nztot * sizeof(float), hipMemcpyHostToDevice));
+    if (!h16) {
+        v->a_bytes = (nztot + 128) * (int64_t)sizeof(float);
+        CREATE_TRY(hipMalloc((void**)&v->d_A, (size_t)v->a_bytes));
+        CREATE_TRY(hipMemset(v->d_A, 0, (size_t)v->a_bytes));
+        if (nztot > 0) CREATE_TRY(hipMemcpy(v->d_A, mab + mab_lo, (size_t)nztot * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        // the look-ahead of the pipeline reads up to 3 slices past the last one (never multiplied): pad
+        v->a_bytes = ((int64_t)a16.size() + 4 * 64 * 64) * (int64_t)sizeof(uint16_t);
+        CREATE_TRY(hipMalloc((void**)&v->d_A, (size_t)v->a_bytes));
+        CREATE_TRY(hipMemset(v->d_A, 0, (size_t)v->a_bytes));
+        if (!a16.empty()) CREATE_TRY(hipMemcpy(v->d_A, a16.data(), a16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        v->kp16 = (int)kp;
+    }
     CREATE_TRY(hipMalloc((void**)&v->d_jab, jab32.size() * sizeof(int32_t)));
     CREATE_TRY(hipMemcpy(v->d_jab, jab32.data(), jab32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     for (int c = 0; c < 4; c++) {
@@ -1352,6 +1613,94 @@ int sparta_vbs_clock_mhz(sparta_vbs_t* A, double* mhz_out) {
 namespace {
 
 // shared implementation of sparta_vbs_spmm / sparta_vbs_spmm_gathered
+template <int KP, bool MI2>
+void launch_h16(bool bf16, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, true>), grid, dim3(kThreads), 0, st, sp);
+    else hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, false>), grid, dim3(kThreads), 0, st, sp);
+}
+
+// 16-bit handles (SPARTA_F16 / SPARTA_BF16): A and B in the 16-bit type, fp32 accumulation, fp32 C.  Device pointers: B is a
+// 16-bit column-major matrix (ldb in elements, even).  Host pointers keep the reference's contract (fp32 B in, fp32 C out):
+// B is converted on the device (round to nearest even).
+int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int64_t shard_rows, int32_t n_cols, void* C, int64_t ldc,
+                int32_t c_layout, int32_t accumulate, int32_t ptr_space, hipStream_t st, int32_t algo, float* dt_ms) {
+    using sparta::fail;
+    if (algo != SPARTA_SPMM_MFMA) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: SPARTA_SPMM_EXACT needs an fp32 handle");
+    if (shard_rows != 0) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm_gathered: fp32 handles only in this build");
+    if (b_layout != SPARTA_COL_MAJOR) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit handles need a column-major B (k contiguous)");
+    if (n_cols % kTN != 0) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit handles need n_cols % 128 == 0");
+    const bool bf16 = A->dtype == SPARTA_BF16;
+    const size_t c_elems = (size_t)ldc * (size_t)(c_layout == SPARTA_COL_MAJOR ? n_cols : A->rows);
+    const uint16_t* dB = (const uint16_t*)B;
+    float* dC = (float*)C;
+    int64_t ldb16 = ldb;
+    if (ptr_space == SPARTA_PTR_HOST) {
+        const size_t b_elems = (size_t)ldb * (size_t)n_cols;
+        ldb16 = (A->cols + 7) / 8 * 8;
+        if (int rc = ensure_scratch(&A->d_B, &A->d_B_bytes, b_elems * sizeof(float))) return rc;
+        if (int rc = ensure_scratch(&A->d_B16, &A->d_B16_bytes, (size_t)ldb16 * n_cols * sizeof(uint16_t))) return rc;
+        if (int rc = ensure_scratch(&A->d_C, &A->d_C_bytes, c_elems * sizeof(float))) return rc;
+        HIP_TRY(hipMemcpyAsync(A->d_B, B, b_elems * sizeof(float), hipMemcpyHostToDevice, st));
+        if (accumulate) HIP_TRY(hipMemcpyAsync(A->d_C, C, c_elems * sizeof(float), hipMemcpyHostToDevice, st));
+        else if (c_elems > 0) HIP_TRY(hipMemsetAsync(A->d_C, 0, c_elems * sizeof(float), st));
+        if (bf16) hipLaunchKernelGGL((vbs_convert_h16_kernel<true>), dim3(1024), dim3(kThreads), 0, st, (const float*)A->d_B, ldb, A->cols, (int64_t)n_cols, (uint16_t*)A->d_B16, ldb16);
+        else hipLaunchKernelGGL((vbs_convert_h16_kernel<false>), dim3(1024), dim3(kThreads), 0, st, (const float*)A->d_B, ldb, A->cols, (int64_t)n_cols, (uint16_t*)A->d_B16, ldb16);
+        dB = (const uint16_t*)A->d_B16;
+        dC = (float*)A->d_C;
+    } else if (ldb % 2 != 0) {
+        return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit B needs an even leading dimension (16-byte loads start on 4-byte boundaries)");
+    }
+    if (dt_ms) HIP_TRY(hipEventRecord(A->ev0, st));
+    const int n_nt = n_cols / kTN;
+    const bool prof = A->class_timing;
+    for (int c = 0; c < 4; c++) A->class_ran[c] = false;
+    const size_t slab = (size_t)A->n_slots * SK_SLOT_FLOATS;
+    if (A->n_split > 0)
+        if (int rc = ensure_scratch(&A->d_ws, &A->d_ws_bytes, slab * n_nt * sizeof(float))) return rc;
+    StreamParams sp;
+    sp.A = A->d_A; sp.B = (const float*)dB; sp.C = dC; sp.ws = (float*)A->d_ws;
+    sp.ldb = ldb16; sp.ldc = ldc; sp.cols = A->cols; sp.shard_rows = 0; sp.shard_stride = 0;
+    sp.ws_slab_stride = (int64_t)slab; sp.accumulate = accumulate != 0; sp.c_row_major = c_layout == SPARTA_ROW_MAJOR;
+    sp.N = n_cols; sp.w = (int32_t)A->w; sp.B_tail = nullptr; sp.clk = nullptr;
+    if (A->n_steps[0] + A->n_steps[1] > 0) {
+        if (prof) HIP_TRY(hipEventRecord(A->cev[0][0], st));
+        if (A->has_tail) {
+            if (int rc = ensure_scratch(&A->d_btail, &A->d_btail_bytes, (size_t)A->w * n_cols * sizeof(uint16_t))) return rc;
+            const int64_t row0 = ((A->cols - 1) / A->w) * A->w;
+            hipLaunchKernelGGL(vbs_tail_copy_h16_kernel, dim3(32), dim3(kThreads), 0, st, dB, ldb16, row0, A->cols, (int)A->w, (int)n_cols, (uint16_t*)A->d_btail);
+            sp.B_tail = (const float*)A->d_btail;
+        }
+        const dim3 grid((unsigned)A->n_workers, (unsigned)n_nt);
+        const int probe_ty = A->n_steps[1] >= A->n_steps[0] ? 1 : 0;
+        for (int ty = 1; ty >= 0; ty--) {
+            if (A->n_steps[ty] == 0) continue;
+            sp.steps = A->d_steps[ty]; sp.worker_range = A->d_wrange[ty];
+            sp.clk = (prof && ty == probe_ty) ? A->d_clk : nullptr;
+            if (A->kp16 == 64) { if (ty) launch_h16<64, true>(bf16, grid, st, sp); else launch_h16<64, false>(bf16, grid, st, sp); }
+            else { if (ty) launch_h16<32, true>(bf16, grid, st, sp); else launch_h16<32, false>(bf16, grid, st, sp); }
+        }
+        if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
+    }
+    if (A->n_fix > 0) {
+        if (prof) HIP_TRY(hipEventRecord(A->cev[1][0], st));
+        hipLaunchKernelGGL(vbs_spmm_f32_fixup_kernel, dim3((unsigned)A->n_fix, (unsigned)n_nt), dim3(kThreads), 0, st, A->d_fix, A->d_fix_slots,
+                           (const float*)A->d_ws, (int64_t)slab, dC, ldc, (int)(c_layout == SPARTA_ROW_MAJOR), (int)(accumulate != 0));
+        if (prof) { HIP_TRY(hipEventRecord(A->cev[1][1], st)); A->class_ran[1] = true; }
+    }
+    A->last_path = 1;
+    HIP_TRY(hipGetLastError());
+    if (dt_ms) {
+        HIP_TRY(hipEventRecord(A->ev1, st));
+        HIP_TRY(hipEventSynchronize(A->ev1));
+        HIP_TRY(hipEventElapsedTime(dt_ms, A->ev0, A->ev1));
+    }
+    if (ptr_space == SPARTA_PTR_HOST) {
+        HIP_TRY(hipMemcpyAsync(C, A->d_C, c_elems * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SPARTA_OK;
+}
+
 int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int64_t shard_rows, int64_t shard_stride, int32_t n_cols,
               void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, int32_t ptr_space, void* stream, int32_t algo,
               float* dt_ms) {
@@ -1369,6 +1718,8 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
     DeviceGuard guard(A->device);
     if (!guard.ok) return fail(SPARTA_ERR_HIP, "sparta_vbs_spmm: hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
+    if (A->dtype != SPARTA_F32)
+        return spmm16_impl(A, B, ldb, b_layout, shard_rows, n_cols, C, ldc, c_layout, accumulate, ptr_space, st, algo, dt_ms);
 
     const float* dB = (const float*)B;
     float* dC = (float*)C;

@@ -57,10 +57,12 @@ class DeviceVBS:
     def spmm(self, B, C_out, n_cols, accumulate=False, algo=_lib.SPMM_MFMA, b_layout=_lib.COL_MAJOR, c_layout=_lib.COL_MAJOR,
              ldb=None, ldc=None, timed=False, stream=None):
         """Device tensors (torch, on this device): stream-ordered on torch's current stream, no copies.
-        B: cols x n_cols, C: rows x n_cols in the given layouts. Returns kernel ms if timed else None."""
+        B: cols x n_cols, C: rows x n_cols in the given layouts. Returns kernel ms if timed else None.
+        Handles created with dtype F16 / BF16 take B in that type (column-major, even ldb); C is always float32."""
         import torch
-        if not (B.is_cuda and C_out.is_cuda and B.dtype == torch.float32 and C_out.dtype == torch.float32):
-            raise ValueError("B and C must be float32 tensors on the GPU")
+        want_b = {_lib.F32: torch.float32, _lib.F16: torch.float16, _lib.BF16: torch.bfloat16}[self.dtype]
+        if not (B.is_cuda and C_out.is_cuda and B.dtype == want_b and C_out.dtype == torch.float32):
+            raise ValueError("B must be a %s tensor and C a float32 tensor, both on the GPU" % want_b)
         if B.device.index != self.device or C_out.device.index != self.device:
             raise ValueError("B and C must live on device %d" % self.device)
         ldb = (self.cols if b_layout == _lib.COL_MAJOR else n_cols) if ldb is None else ldb

@@ -435,3 +435,91 @@ def test_clock_probe_reports_a_plausible_shader_clock():
     d.set_class_timing(False)
     assert sum(ms.values()) > 0
     assert any(500.0 < x < 3000.0 for x in mhz.values()), mhz
+
+
+# ---- 16-bit storage (fp16 / bf16), fp32 accumulation ------------------------------------------------------------------------
+def _round16(x, dtype):
+    """fp32 -> fp16 / bf16 -> fp32, round to nearest even (numpy for fp16, bit arithmetic for bf16)"""
+    x = np.ascontiguousarray(x, np.float32)
+    if dtype == sa.F16:
+        return x.astype(np.float16).astype(np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+H16_SHAPES = [
+    (1500, 1500, 60000, 64, ("tau", 0.5), 128),        # KP 64, both tile types, tail block column (cols % w != 0)
+    (900, 960, 30000, 32, ("tau", 0.6), 128),          # KP 32
+    (2000, 1024, 40000, 128, ("fixed", 100), 256),     # w = 128: two 64-deep steps per block, two column slabs
+    (3000, 640, 20000, 32, ("keeper", 32), 128),       # many 32-row tiles
+    (64, 6400, 30000, 64, ("fixed", 64), 128),         # one long tile
+]
+
+
+@pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("rows,cols,nnz,w,blk,n", H16_SHAPES)
+def test_16bit_storage_vs_oracle_on_rounded_inputs(dtype, rows, cols, nnz, w, blk, n):
+    """A and B are rounded to the 16-bit type, products of two 16-bit values are exact in fp32, accumulation is fp32: the
+    oracle (fp32 VBR::multiply restatement) on the ROUNDED inputs is the reference; tolerance as for the fp32 MFMA path."""
+    torch = _torch()
+    m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + cols + w)
+    if blk[0] == "tau":
+        g = sa.BlockingEngine(tau=blk[1], col_block_size=w).GetGrouping(m)
+    elif blk[0] == "keeper":
+        g = sa.BlockingEngine(tau=0.5, col_block_size=w, row_block_size=blk[1], blocking_algo=5).GetGrouping(m)
+    else:
+        g = np.arange(rows) // blk[1]
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=5)
+    mab_r, B_r = _round16(v.mab, dtype), _round16(B, dtype)
+    Co = O.vbr_multiply(v.rows, v.cols, v.block_col_size, v.row_part, v.nzcount, v.jab, mab_r, B_r, n, None)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n)
+    d = v.to_device(0, dtype=dtype)
+    tdt = torch.float16 if dtype == sa.F16 else torch.bfloat16
+    ldb = (v.cols + 7) // 8 * 8                                       # padded, even leading dimension
+    Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    Bt.view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
+    for cl in (sa.COL_MAJOR, sa.ROW_MAJOR):
+        Ct = torch.full((v.rows * n,), 7.0, dtype=torch.float32, device="cuda")
+        d.spmm(Bt, Ct, n, ldb=ldb, c_layout=cl)
+        torch.cuda.synchronize()
+        got = Ct.cpu().numpy()
+        if cl == sa.ROW_MAJOR:
+            got = np.ascontiguousarray(got.reshape(v.rows, n).T).reshape(-1)
+        _check(got, Co, bound, "16-bit c_layout %d" % cl)
+    # accumulate, and the host-pointer contract (fp32 B in, converted on the device)
+    C0 = sa.gen.dense_rhs(v.rows, n, seed=11)
+    Ct = torch.from_numpy(C0).cuda()
+    d.spmm(Bt, Ct, n, ldb=ldb, accumulate=True)
+    torch.cuda.synchronize()
+    _check(Ct.cpu().numpy(), C0 + Co, bound + np.abs(C0), "16-bit accumulate")
+    Ch = np.zeros(v.rows * n, np.float32)
+    d.spmm_host(B, n, Ch, accumulate=False)
+    _check(Ch, Co, bound, "16-bit host pointers")
+    C2 = torch.empty(v.rows * n, dtype=torch.float32, device="cuda")
+    C3 = torch.empty(v.rows * n, dtype=torch.float32, device="cuda")
+    d.spmm(Bt, C2, n, ldb=ldb); d.spmm(Bt, C3, n, ldb=ldb)
+    torch.cuda.synchronize()
+    assert torch.equal(C2, C3)
+
+
+def test_16bit_handles_reject_what_they_cannot_do():
+    torch = _torch()
+    m = sa.gen.uniform_random(256, 256, 3000, seed=2)
+    v48 = sa.VBR().fill_from_CSR_inplace_fixed(m, 32, 48)
+    with pytest.raises(sa.SpartaError):
+        v48.to_device(0, dtype=sa.F16)                                # w % 32 != 0
+    v = sa.VBR().fill_from_CSR_inplace_fixed(m, 32, 32)
+    d = v.to_device(0, dtype=sa.F16)
+    B = torch.zeros(v.cols * 128, dtype=torch.float16, device="cuda")
+    C = torch.zeros(v.rows * 128, dtype=torch.float32, device="cuda")
+    with pytest.raises(sa.SpartaError):
+        d.spmm(B, C, 128, b_layout=sa.ROW_MAJOR)
+    with pytest.raises(sa.SpartaError):
+        d.spmm(B, C, 128, algo=sa.SPMM_EXACT)
+    with pytest.raises(ValueError):
+        d.spmm(B.float(), C, 128)                                     # fp32 B on a 16-bit handle
+    B96 = torch.zeros(v.cols * 96, dtype=torch.float16, device="cuda")
+    with pytest.raises(sa.SpartaError):
+        d.spmm(B96, C, 96)                                            # n_cols % 128 != 0
