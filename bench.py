@@ -301,9 +301,17 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
-    print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()
+    # RCCL writes its version banner to C stdout (fully buffered when redirected: it would surface AFTER our line at exit).
+    # Flush C stdio first so that the JSON line is the last thing this process prints.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -10,6 +10,6 @@ for pmc in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "FETCH_SIZE GRBM_GUI_ACTIVE" \
            "WRITE_SIZE TCC_HIT TCC_MISS" ; do
   i=$((i+1))
-  rocprofv3 --pmc $pmc --output-format csv -d $out/p$i -- python3 "$@" > $out/p$i.log 2>&1
+  timeout 150 rocprofv3 --pmc $pmc --output-format csv -d $out/p$i -- python3 "$@" > $out/p$i.log 2>&1
 done
 python3 scripts/pmc_summary.py "$out"

@@ -423,7 +423,7 @@ struct StepRec {                          // 32 bytes, one per (block, 32-deep k
     int32_t c_row;                        // first row of C of the tile
     int32_t mt_flags;                     // rows of the tile (low 16 bits) | STEP_* flags
     int32_t slot;                         // workspace slot for STEP_LAST|STEP_SPLIT, else -1
-    int32_t pad;
+    int32_t pad;                          // gathered-B step lists: index of the slab that holds b_row (b_row is then slab-local); else 0
 };
 static_assert(sizeof(StepRec) == 32, "StepRec must stay 32 bytes");
 
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
         const int32_t x0 = __builtin_amdgcn_readlane(vrec0, ln), x1 = __builtin_amdgcn_readlane(vrec1, ln);
         return ((s >> 3) & 1) ? x1 : x0;
     };
-    enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6 };
+    enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6, F_SHARD = 7 };
 
     // per-thread constant byte offsets (the only vector part of any address in the loop)
     const int bj0 = tid >> 3, bk = (tid & 7) * 4;       // col-major B: column bj0 + 32q, k = bk..bk+3   (q = 0..3)
@@ -545,11 +545,9 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
         const bool tail = (flags & STEP_TAIL) != 0;
         int64_t gk0 = field(s, F_BROW);
         const float* Bbase = tail ? p.B_tail : p.B;
-        if constexpr (GATHERED) {                        // slab index is wave-uniform; a panel never straddles slabs (shard_rows % w == 0)
-            const int64_t sh = gk0 / p.shard_rows;
-            Bbase += sh * p.shard_stride;
-            gk0 -= sh * p.shard_rows;
-        }
+        if constexpr (GATHERED) {                        // a panel never straddles slabs (shard_rows % w == 0); the host split b_row into
+            Bbase += (int64_t)field(s, F_SHARD) * p.shard_stride;   // (slab, row inside the slab) when it built the gathered step list:
+        }                                                // a 64-bit division here costs ~40 instructions per step, 10 of them VALU
         const float* bptr = tail ? Bbase + (BRM ? gk0 * ld_t : gk0) : Bbase + (BRM ? gk0 * p.ldb : gk0) + n0off;
         const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bptr), 0, 0x7ffffff0, 0x00020000);
         const uint32_t vo = tail ? voffBt : voffB, qs = tail ? qstepBt : qstepB;
@@ -1059,6 +1057,9 @@ struct sparta_vbs {
     bool class_ran[4] = {false, false, false, false};
     // stream plan (w % 32 == 0): see vbs_spmm_f32_stream_kernel
     StepRec* d_steps[2] = {nullptr, nullptr};      // per tile type: [0] <= 32 rows, [1] 33..64 rows
+    std::vector<StepRec> h_steps[2];               // host copies (padded), source of the gathered-B variants
+    StepRec* d_steps_g[2] = {nullptr, nullptr};    // step lists for sparta_vbs_spmm_gathered with shard_rows == g_shard_rows
+    int64_t g_shard_rows = 0;
     int32_t* d_wrange[2] = {nullptr, nullptr};
     FixRec* d_fix = nullptr;
     int32_t* d_fix_slots = nullptr;
@@ -1136,6 +1137,7 @@ void destroy_impl(sparta_vbs* v) {
     if (v->d_brows) (void)hipFree(v->d_brows);
     for (int ty = 0; ty < 2; ty++) {
         if (v->d_steps[ty]) (void)hipFree(v->d_steps[ty]);
+        if (v->d_steps_g[ty]) (void)hipFree(v->d_steps_g[ty]);
         if (v->d_wrange[ty]) (void)hipFree(v->d_wrange[ty]);
     }
     if (v->d_fix) (void)hipFree(v->d_fix);
@@ -1552,6 +1554,7 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
             for (int k = 0; k < 24; k++) { StepRec d = st[(size_t)v->n_steps[ty] - 1]; d.mt_flags = (d.mt_flags & ~(STEP_LAST | STEP_SPLIT)) | STEP_FIRST; st.push_back(d); }
             CREATE_TRY(hipMalloc((void**)&v->d_steps[ty], st.size() * sizeof(StepRec)));
             CREATE_TRY(hipMemcpy(v->d_steps[ty], st.data(), st.size() * sizeof(StepRec), hipMemcpyHostToDevice));
+            v->h_steps[ty] = st;
             CREATE_TRY(hipMalloc((void**)&v->d_wrange[ty], wrange[ty].size() * sizeof(int32_t)));
             CREATE_TRY(hipMemcpy(v->d_wrange[ty], wrange[ty].data(), wrange[ty].size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
@@ -1757,6 +1760,17 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
             const size_t slab = (size_t)A->n_slots * SK_SLOT_FLOATS;
             if (A->n_split > 0)
                 if (int rc = ensure_scratch(&A->d_ws, &A->d_ws_bytes, slab * n_nt * sizeof(float))) return rc;
+            if (shard_rows > 0 && A->g_shard_rows != shard_rows) {          // (re)build the gathered step lists: b_row -> (slab, local row)
+                for (int ty = 0; ty < 2; ty++) {
+                    if (A->h_steps[ty].empty()) continue;
+                    std::vector<StepRec> g = A->h_steps[ty];
+                    for (StepRec& r : g) { r.pad = (int32_t)(r.b_row / shard_rows); r.b_row = (int32_t)(r.b_row % shard_rows); }
+                    if (!A->d_steps_g[ty]) HIP_TRY(hipMalloc((void**)&A->d_steps_g[ty], g.size() * sizeof(StepRec)));
+                    HIP_TRY(hipMemcpyAsync(A->d_steps_g[ty], g.data(), g.size() * sizeof(StepRec), hipMemcpyHostToDevice, st));
+                    HIP_TRY(hipStreamSynchronize(st));                       // g goes out of scope
+                }
+                A->g_shard_rows = shard_rows;
+            }
             StreamParams sp;
             sp.A = A->d_A; sp.B = dB; sp.C = Cout; sp.ws = (float*)A->d_ws;
             sp.ldb = ldb; sp.ldc = ldc; sp.cols = A->cols; sp.shard_rows = shard_rows; sp.shard_stride = shard_stride;
@@ -1777,7 +1791,7 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                 const int probe_ty = A->n_steps[1] >= A->n_steps[0] ? 1 : 0;
                 for (int ty = 1; ty >= 0; ty--) {
                     if (A->n_steps[ty] == 0) continue;
-                    sp.steps = A->d_steps[ty]; sp.worker_range = A->d_wrange[ty];
+                    sp.steps = shard_rows > 0 ? A->d_steps_g[ty] : A->d_steps[ty]; sp.worker_range = A->d_wrange[ty];
                     sp.clk = (prof && ty == probe_ty) ? A->d_clk : nullptr;
                     if (ty) {
                         if (shard_rows > 0) hipLaunchKernelGGL((vbs_spmm_f32_stream_kernel<false, true, true>), grid, dim3(kThreads), 0, st, sp);
