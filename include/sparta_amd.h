@@ -206,6 +206,12 @@ int sparta_vbs_build(int64_t rows, int64_t cols, const int64_t* rowptr, const in
                      sparta_vbs_host* out);
 void sparta_vbs_host_free(sparta_vbs_host* v);
 
+/* Binary VBS container ("SPARTAVB", little-endian, 96-byte header + the four arrays, FNV-1a checksum; layout in
+ * sparta_amd/csrc/io.cpp): the reorder + build cost is paid once.  sparta_vbs_load verifies magic, sizes, checksum and the
+ * structural invariants and fills *out (release with sparta_vbs_host_free).  No reference counterpart. */
+int sparta_vbs_save(const char* path, const sparta_vbs_host* v);
+int sparta_vbs_load(const char* path, sparta_vbs_host* out);
+
 /* replaces BlockingEngine::CollectBlockingInfo (src/general/blocking.cpp:576-631): statistics of
  * the VBS a grouping would give, without building it. info_out: [VBR_nzcount, VBR_nzblocks_count,
  * VBR_longest_row]; avg_height_out: VBR_average_height. */

@@ -414,3 +414,110 @@ int sparta_degree_permutation(int64_t rows, const int64_t* rowptr, int32_t desce
 }
 
 }  // extern "C"
+
+// ---- binary VBS container -----------------------------------------------------------------------------------------------------
+// The reorder + build cost is paid once: a VBS (the reference's five arrays, include/matrices.h:93-104) in one little-endian file.
+//   bytes  0.. 7  magic "SPARTAVB"          8..11  uint32 version = 1        12..15  uint32 header bytes = 96
+//         16..79  int64 rows, cols, block_rows, block_cols, block_col_size, nztot, nblocks, reserved (0)
+//         80..87  uint64 FNV-1a 64 of the payload                              88..95  uint64 payload bytes
+//   payload: int64 row_part[block_rows + 1] | int64 nzcount[block_rows] | int64 jab[nblocks] | float mab[nztot]
+// No reference counterpart ("a binary VBS container so reorder cost is paid once").
+namespace {
+constexpr char kVbsMagic[8] = {'S', 'P', 'A', 'R', 'T', 'A', 'V', 'B'};
+inline uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
+    const unsigned char* p = (const unsigned char*)data;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+}  // namespace
+
+extern "C" {
+
+int sparta_vbs_save(const char* path, const sparta_vbs_host* v) {
+    if (!path || !v) return fail(SPARTA_ERR_INVALID, "sparta_vbs_save: NULL argument");
+    if (v->block_rows < 0 || v->nblocks < 0 || v->nztot < 0 || !v->row_part || (v->block_rows > 0 && !v->nzcount) || (v->nblocks > 0 && !v->jab) ||
+        (v->nztot > 0 && !v->mab))
+        return fail(SPARTA_ERR_INVALID, "sparta_vbs_save: inconsistent VBS");
+    const size_t n_rp = (size_t)(v->block_rows + 1) * 8, n_nz = (size_t)v->block_rows * 8, n_jab = (size_t)v->nblocks * 8, n_mab = (size_t)v->nztot * 4;
+    uint64_t h = 14695981039346656037ull;
+    h = fnv1a(v->row_part, n_rp, h);
+    h = fnv1a(v->nzcount, n_nz, h);
+    h = fnv1a(v->jab, n_jab, h);
+    h = fnv1a(v->mab, n_mab, h);
+    unsigned char head[96];
+    std::memset(head, 0, sizeof head);
+    std::memcpy(head, kVbsMagic, 8);
+    const uint32_t ver = 1, hb = 96;
+    std::memcpy(head + 8, &ver, 4);
+    std::memcpy(head + 12, &hb, 4);
+    const int64_t dims[8] = {v->rows, v->cols, v->block_rows, v->block_cols, v->block_col_size, v->nztot, v->nblocks, 0};
+    std::memcpy(head + 16, dims, 64);
+    const uint64_t payload = n_rp + n_nz + n_jab + n_mab;
+    std::memcpy(head + 80, &h, 8);
+    std::memcpy(head + 88, &payload, 8);
+    std::ofstream o(path, std::ios::binary);
+    if (!o.good()) return fail(SPARTA_ERR_IO, std::string("sparta_vbs_save: cannot open '") + path + "'");
+    o.write((const char*)head, 96);
+    o.write((const char*)v->row_part, (std::streamsize)n_rp);
+    o.write((const char*)v->nzcount, (std::streamsize)n_nz);
+    o.write((const char*)v->jab, (std::streamsize)n_jab);
+    o.write((const char*)v->mab, (std::streamsize)n_mab);
+    o.flush();
+    return o.good() ? SPARTA_OK : fail(SPARTA_ERR_IO, "sparta_vbs_save: write failed");
+}
+
+int sparta_vbs_load(const char* path, sparta_vbs_host* out) {
+    if (!path || !out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_load: NULL argument");
+    std::memset(out, 0, sizeof *out);
+    std::ifstream in(path, std::ios::binary);
+    if (!in.good()) return fail(SPARTA_ERR_IO, std::string("sparta_vbs_load: cannot open '") + path + "'");
+    unsigned char head[96];
+    in.read((char*)head, 96);
+    if (in.gcount() != 96 || std::memcmp(head, kVbsMagic, 8) != 0) return fail(SPARTA_ERR_IO, "sparta_vbs_load: not a SPARTAVB file");
+    uint32_t ver, hb;
+    std::memcpy(&ver, head + 8, 4);
+    std::memcpy(&hb, head + 12, 4);
+    if (ver != 1 || hb != 96) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_load: unknown container version");
+    int64_t dims[8];
+    uint64_t want_hash, payload;
+    std::memcpy(dims, head + 16, 64);
+    std::memcpy(&want_hash, head + 80, 8);
+    std::memcpy(&payload, head + 88, 8);
+    const int64_t rows = dims[0], cols = dims[1], br = dims[2], bc = dims[3], w = dims[4], nztot = dims[5], nblocks = dims[6];
+    if (rows < 0 || cols < 0 || br < 0 || bc < 0 || w <= 0 || nztot < 0 || nblocks < 0 || br > (int64_t)1 << 40 || nblocks > (int64_t)1 << 40 ||
+        nztot > (int64_t)1 << 44)
+        return fail(SPARTA_ERR_IO, "sparta_vbs_load: implausible header");
+    const size_t n_rp = (size_t)(br + 1) * 8, n_nz = (size_t)br * 8, n_jab = (size_t)nblocks * 8, n_mab = (size_t)nztot * 4;
+    if (payload != n_rp + n_nz + n_jab + n_mab) return fail(SPARTA_ERR_IO, "sparta_vbs_load: header and payload size disagree");
+    out->rows = rows; out->cols = cols; out->block_rows = br; out->block_cols = bc; out->block_col_size = w; out->nztot = nztot; out->nblocks = nblocks;
+    out->row_part = (int64_t*)std::malloc(n_rp);
+    out->nzcount = (int64_t*)std::malloc(std::max<size_t>(n_nz, 8));
+    out->jab = (int64_t*)std::malloc(std::max<size_t>(n_jab, 8));
+    out->mab = (float*)std::malloc(std::max<size_t>(n_mab, 4));
+    auto bail = [&](int code, const char* msg) { sparta_vbs_host_free(out); return fail(code, msg); };
+    if (!out->row_part || !out->nzcount || !out->jab || !out->mab) return bail(SPARTA_ERR_ALLOC, "sparta_vbs_load: out of host memory");
+    in.read((char*)out->row_part, (std::streamsize)n_rp);
+    in.read((char*)out->nzcount, (std::streamsize)n_nz);
+    in.read((char*)out->jab, (std::streamsize)n_jab);
+    in.read((char*)out->mab, (std::streamsize)n_mab);
+    if (!in.good() && !(in.eof() && (size_t)in.gcount() == n_mab)) return bail(SPARTA_ERR_IO, "sparta_vbs_load: file is truncated");
+    uint64_t h = 14695981039346656037ull;
+    h = fnv1a(out->row_part, n_rp, h);
+    h = fnv1a(out->nzcount, n_nz, h);
+    h = fnv1a(out->jab, n_jab, h);
+    h = fnv1a(out->mab, n_mab, h);
+    if (h != want_hash) return bail(SPARTA_ERR_IO, "sparta_vbs_load: checksum mismatch (corrupted file)");
+    // structural checks: what sparta_vbs_create would reject later is rejected here with the file's name on it
+    if (out->row_part[0] != 0 || out->row_part[br] != rows) return bail(SPARTA_ERR_IO, "sparta_vbs_load: row_part does not span [0, rows]");
+    int64_t nb = 0, area = 0;
+    for (int64_t i = 0; i < br; i++) {
+        const int64_t hh = out->row_part[i + 1] - out->row_part[i];
+        if (hh < 0 || out->nzcount[i] < 0) return bail(SPARTA_ERR_IO, "sparta_vbs_load: negative height or count");
+        nb += out->nzcount[i];
+        area += out->nzcount[i] * hh * w;
+    }
+    if (nb != nblocks || area != nztot) return bail(SPARTA_ERR_IO, "sparta_vbs_load: counts do not add up");
+    return SPARTA_OK;
+}
+
+}  // extern "C"

@@ -241,6 +241,30 @@ class VBR:
         v.nztot = len(v.mab)
         return v
 
+    def save(self, path):
+        """Binary container (sparta_vbs_save): the five arrays + checksum in one file -- the reorder is paid once."""
+        h = _lib.VbsHost()
+        h.rows, h.cols, h.block_rows, h.block_cols = self.rows, self.cols, self.block_rows, self.block_cols
+        h.block_col_size, h.nztot, h.nblocks = self.block_col_size, len(self.mab), len(self.jab)
+        rp, nz = np.ascontiguousarray(self.row_part, np.int64), np.ascontiguousarray(self.nzcount, np.int64)
+        jab, mab = np.ascontiguousarray(self.jab, np.int64), np.ascontiguousarray(self.mab, np.float32)
+        h.row_part, h.nzcount, h.jab, h.mab = _p64(rp), _p64(nz), _p64(jab), _pf(mab)
+        check(lib.sparta_vbs_save(str(path).encode(), C.byref(h)))
+
+    @classmethod
+    def load(cls, path):
+        h = _lib.VbsHost()
+        check(lib.sparta_vbs_load(str(path).encode(), C.byref(h)))
+        try:
+            v = cls.from_arrays(h.rows, h.cols, h.block_col_size, np.ctypeslib.as_array(h.row_part, (h.block_rows + 1,)).copy(),
+                                np.ctypeslib.as_array(h.nzcount, (max(h.block_rows, 1),))[:h.block_rows].copy(),
+                                np.ctypeslib.as_array(h.jab, (max(h.nblocks, 1),))[:h.nblocks].copy(),
+                                np.ctypeslib.as_array(h.mab, (max(h.nztot, 1),))[:h.nztot].copy())
+            v.block_cols = h.block_cols
+            return v
+        finally:
+            lib.sparta_vbs_host_free(C.byref(h))
+
     def to_device(self, device=0, dtype=_lib.F32, block_row_range=None):
         from .device import DeviceVBS
         return DeviceVBS(self, device=device, dtype=dtype, block_row_range=block_row_range)

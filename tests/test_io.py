@@ -296,3 +296,59 @@ def test_random_edge_lists_against_the_live_reference(tmp_path):
         _same_csr(sa.CSR.read_from_edgelist(p, delim, po), live.rows, live.cols, rp, ci, None if po else v)
         o = IO.read_el(p.read_text(), delim, po, False)
         assert np.array_equal(o[2], rp) and np.array_equal(o[3], ci) and (po or np.array_equal(o[4], v))
+
+
+# ---- binary VBS container ------------------------------------------------------------------------------------------------------
+def _fnv1a(chunks):
+    h = 14695981039346656037
+    for c in chunks:
+        for b in c.tobytes():
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_vbs_container_round_trip_and_layout(tmp_path):
+    import struct
+    m = sa.gen.uniform_random(90, 130, 700, seed=4)
+    g = sa.BlockingEngine(tau=0.6, col_block_size=16).GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, 16)
+    p = tmp_path / "a.vbs"
+    v.save(p)
+    back = sa.VBR.load(p)
+    for name in ("rows", "cols", "block_rows", "block_cols", "block_col_size", "nztot"):
+        assert getattr(back, name) == getattr(v, name), name
+    for name in ("row_part", "nzcount", "jab", "mab"):
+        assert np.array_equal(getattr(back, name), getattr(v, name)), name
+    # the documented layout, parsed independently
+    raw = p.read_bytes()
+    assert raw[:8] == b"SPARTAVB" and struct.unpack_from("<II", raw, 8) == (1, 96)
+    dims = struct.unpack_from("<8q", raw, 16)
+    assert dims[:7] == (v.rows, v.cols, v.block_rows, v.block_cols, v.block_col_size, v.nztot, len(v.jab))
+    chk, payload = struct.unpack_from("<QQ", raw, 80)
+    assert payload == len(raw) - 96 == 8 * (v.block_rows + 1) + 8 * v.block_rows + 8 * len(v.jab) + 4 * v.nztot
+    assert chk == _fnv1a([v.row_part, v.nzcount, v.jab, v.mab])
+    off = 96
+    assert np.array_equal(np.frombuffer(raw, "<i8", v.block_rows + 1, off), v.row_part)
+    off += 8 * (v.block_rows + 1) + 8 * v.block_rows + 8 * len(v.jab)
+    assert np.array_equal(np.frombuffer(raw, "<f4", v.nztot, off), v.mab)
+
+
+def test_vbs_container_rejects_damage(tmp_path):
+    m = sa.gen.uniform_random(40, 40, 200, seed=6)
+    v = sa.VBR().fill_from_CSR_inplace_fixed(m, 8, 8)
+    p = tmp_path / "a.vbs"
+    v.save(p)
+    raw = bytearray(p.read_bytes())
+    cases = {"flip": bytes(raw[:200]) + bytes([raw[200] ^ 1]) + bytes(raw[201:]), "trunc": bytes(raw[:-5]), "magic": b"NOTAVBS!" + bytes(raw[8:]),
+             "short": bytes(raw[:40]), "version": bytes(raw[:8]) + (2).to_bytes(4, "little") + bytes(raw[12:])}
+    for name, data in cases.items():
+        q = tmp_path / (name + ".vbs")
+        q.write_bytes(data)
+        with pytest.raises(sa.SpartaError):
+            sa.VBR.load(q)
+    with pytest.raises(sa.SpartaError):
+        sa.VBR.load(tmp_path / "missing.vbs")
+    empty = sa.VBR.from_arrays(5, 7, 4, np.array([0, 5]), np.array([0]), np.zeros(0, np.int64), np.zeros(0, np.float32))
+    empty.save(tmp_path / "e.vbs")
+    e2 = sa.VBR.load(tmp_path / "e.vbs")
+    assert e2.rows == 5 and e2.nztot == 0 and len(e2.jab) == 0
