@@ -1653,6 +1653,9 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
     } else if (ldb % 2 != 0) {
         return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit B needs an even leading dimension (16-byte loads start on 4-byte boundaries)");
     }
+    // 32-bit byte offsets inside a 128-column slab (see the fp32 path): 127 x ld x element size < 2^31
+    if (ldb16 * 128 * 2 >= ((int64_t)1 << 31) - 65536 || (c_layout == SPARTA_ROW_MAJOR ? ldc * 64 : ldc * 128) * 4 >= ((int64_t)1 << 31) - 65536)
+        return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: leading dimension too large for the 16-bit stream kernels (ldb < 8.3 M, ldc < 4.1 M elements)");
     if (dt_ms) HIP_TRY(hipEventRecord(A->ev0, st));
     const int n_nt = n_cols / kTN;
     const bool prof = A->class_timing;
@@ -1752,7 +1755,15 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
         const int n_nt = (n_cols + kTN - 1) / kTN;
         const bool full_slabs = (n_cols % kTN) == 0;
         // two product paths (both branch-free, both need full panels) + the generic fallback for odd shapes
-        const bool can_stream = A->n_workers > 0 && full_slabs && !novec && !force_generic();
+        // The stream kernels address B and C through buffer descriptors with 32-bit byte offsets inside one 128-column slab
+        // (range-checked against 2 GB): 127 columns x leading dimension x 4 bytes must stay below 2^31, i.e. ld < 4.2 M
+        // elements for the column-major layouts.  Larger leading dimensions take the per-class / generic kernels (64-bit
+        // pointer arithmetic).
+        const int64_t ld_lim = ((int64_t)1 << 31) / (128 * 4) - 64;
+        const bool ld_ok = (b_layout == SPARTA_ROW_MAJOR ? ldb * 32 : ldb * 128) < ((int64_t)1 << 29) - 4096 &&
+                           (c_layout == SPARTA_ROW_MAJOR ? ldc * 64 : ldc * 128) < ((int64_t)1 << 29) - 4096;
+        (void)ld_lim;
+        const bool can_stream = A->n_workers > 0 && full_slabs && !novec && !force_generic() && ld_ok;
         const bool can_class = (A->w % kKP) == 0 && full_slabs && !novec && !force_generic();
 
         // persistent stream kernel + fix-up of the split tiles

@@ -523,3 +523,27 @@ def test_16bit_handles_reject_what_they_cannot_do():
     B96 = torch.zeros(v.cols * 96, dtype=torch.float16, device="cuda")
     with pytest.raises(sa.SpartaError):
         d.spmm(B96, C, 96)                                            # n_cols % 128 != 0
+
+
+def test_huge_leading_dimensions_take_the_64bit_kernels():
+    """The stream kernels address a 128-column slab with 32-bit byte offsets: leading dimensions beyond 4.2 M elements must
+    not reach them (a buffer load past 2 GB returns 0, a store is dropped -- silently)."""
+    torch = _torch()
+    m = sa.gen.uniform_random(700, 900, 9000, seed=31)
+    v = sa.VBR().fill_from_CSR_inplace_fixed(m, 64, 64)
+    n, ld = 128, 4_400_000
+    B = sa.gen.dense_rhs(v.cols, n, seed=2)
+    Co = _oracle_c(v, B, n)
+    bound = U.abs_bound(v.rows, v.cols, 64, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+    d = v.to_device(0)
+    Bt = torch.zeros(ld * n, dtype=torch.float32, device="cuda")
+    Bt.view(n, ld)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda()
+    Ct = torch.full((ld * n,), 3.0, dtype=torch.float32, device="cuda")
+    d.spmm(Bt, Ct, n, ldb=ld, ldc=ld)
+    torch.cuda.synchronize()
+    assert d.info()["last_path"] in (2, 3)
+    got = Ct.view(n, ld)[:, :v.rows].contiguous().view(-1).cpu().numpy()
+    _check(got, Co, bound, "huge ld")
+    assert float(Ct.view(n, ld)[:, v.rows:v.rows + 8].min()) == 3.0          # nothing written outside the rows of C
+    del Bt, Ct
+    torch.cuda.empty_cache()
