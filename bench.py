@@ -48,8 +48,8 @@ def mixed_roofline_seconds(row_part, nzcount, w, n_cols, cols, accumulate=False)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--tau", type=float, default=0.6)
     ap.add_argument("--algo", type=int, default=5, help="reference BlockingType: 3 iterative_clocked, 5 iterative_max_size (Keeper)")
     ap.add_argument("--row-block", type=int, default=32, help="max / fixed block-row height (-B)")
@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--ncols", type=int, default=128)
     ap.add_argument("--fixed-height", type=int, default=0, help="reorder OFF: fixed block-row height instead of clustering")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the steps from a captured HIP graph (measured: no gain -- the step is one 60 us kernel and eager launches already queue ahead)")
     ap.add_argument("--dist-path", action="store_true", help="run the multi-GPU code path (slab + all-gather + gathered SpMM) even with one rank")
     args = ap.parse_args()
 
@@ -142,8 +144,33 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # Optional: capture G consecutive steps in a HIP graph (sparta_vbs_spmm is stream-ordered and capture-safe once the
+    # plan-time autotune of the first call is over) and replay it K / G times: EXACTLY K steps in the timed region.
+    graph, G = None, 1
+    if not distributed and args.graph:
+        G = max(g_ for g_ in range(1, 11) if args.steps % g_ == 0)
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                step()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    for _ in range(G):
+                        step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize()
+            graph.replay()                                   # one untimed replay
+            torch.cuda.synchronize()
+        except Exception as e:                               # capture not available: eager launches
+            print("HIP graph capture failed (%s); launching eagerly" % e, file=sys.stderr)
+            graph, G = None, 1
+    fence()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
+    if graph is not None:
+        for _ in range(args.steps // G):
+            graph.replay()
+    for _ in range(0 if graph is not None else args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t_start
@@ -297,6 +324,7 @@ def main():
             "executed_gflops": round(flops_exec * world / (ms_per_step * 1e-3) / 1e9, 1),
             "host_seconds": {"generate": round(t_gen, 2), "reorder": round(t_reorder, 2), "vbs_build": round(t_build, 2)},
             "parallelism": "row-partition x%d, B all-gather" % world if distributed else "single GPU",
+            "launch": ("HIP graph of %d steps, replayed %d times" % (G, args.steps // G)) if graph is not None else "eager",
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
