@@ -1,0 +1,53 @@
+"""Developer tool: per-step s_memtime timeline of one workgroup of the fp32 stream kernel (build: make -C sparta_amd/csrc timeline;
+run with SPARTA_AMD_LIB=sparta_amd/libsparta_amd_tl.so).  usage: python scripts/timeline.py [long|flagship]"""
+import ctypes as C
+import os
+import sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import sparta_amd as sa
+from sparta_amd._lib import lib
+
+what = sys.argv[1] if len(sys.argv) > 1 else "long"
+N = 128
+if what == "long":
+    m = sa.gen.uniform_random(65536, 8192, int(65536 * 8192 * 0.01), seed=1)
+    vb = sa.VBR().fill_from_CSR_inplace_fixed(m, 64, 64)
+else:
+    m = sa.gen.cant_like(seed=2)
+    g = sa.BlockingEngine(blocking_algo=5, tau=0.6, col_block_size=32, row_block_size=32, force_fixed_size=True).GetGrouping(m)
+    vb = sa.VBR().fill_from_CSR_inplace(m, g, 32, 32, True)
+os.environ["SPARTA_PATH"] = "stream"
+d = vb.to_device(0)
+B = torch.from_numpy(sa.gen.dense_rhs(vb.cols, N, seed=3)).cuda()
+Cc = torch.zeros(vb.rows * N, dtype=torch.float32, device="cuda")
+for _ in range(20):
+    d.spmm(B, Cc, N)
+d.set_class_timing(True)
+for _ in range(3):
+    d.spmm(B, Cc, N)
+torch.cuda.synchronize()
+print("kernel ms", d.class_times(), "MHz", d.clock_mhz())
+out = np.zeros(4 * 64 * 8, np.int64)
+lib.sparta_debug_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+assert lib.sparta_debug_timeline(d.h, out.ctypes.data_as(C.POINTER(C.c_longlong))) == 0
+t = out.reshape(4, 64, 8)
+names = ["round0", "round1", "round2", "round3+loads", "epilogue", "barrier", "to next step"]
+for wv in range(4):
+    tw = t[wv]
+    ok = tw[:, 0] > 0
+    if ok.sum() < 4:
+        print("wave", wv, "no data"); continue
+    tw = tw[ok]
+    seg = np.diff(tw[:, :7], axis=1)                       # segments inside a step
+    nxt = tw[1:, 0] - tw[:-1, 6]                           # barrier exit -> next step's first stamp
+    step = tw[1:, 0] - tw[:-1, 0]
+    print("wave %d: %d steps; step period mean %.0f (min %d max %d) s_memtime ticks" % (wv, len(tw), step.mean(), step.min(), step.max()))
+    for k in range(6):
+        print("    %-14s mean %7.0f  min %6d  max %6d" % (names[k], seg[:, k].mean(), seg[:, k].min(), seg[:, k].max()))
+    print("    %-14s mean %7.0f  min %6d  max %6d" % (names[6], nxt.mean(), nxt.min(), nxt.max()))
+print("first 6 steps of wave 0 (relative ticks):")
+w0 = t[0][t[0][:, 0] > 0]
+for r in w0[:6]:
+    print("   ", (r[:7] - w0[0][0]).tolist(), "flags %x" % r[7])

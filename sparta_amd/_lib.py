@@ -15,7 +15,7 @@ except ImportError:  # pragma: no cover - torch is optional for the pure C-ABI u
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsparta_amd.so")
+LIB_PATH = os.environ.get("SPARTA_AMD_LIB") or os.path.join(_HERE, "libsparta_amd.so")   # SPARTA_AMD_LIB: developer builds (make timeline)
 
 # status codes (include/sparta_amd.h)
 OK, ERR_INVALID, ERR_ALLOC, ERR_HIP, ERR_UNSUPPORTED, ERR_IO, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6

@@ -77,6 +77,16 @@ struct SpmmParams {
 
 // Clock probe: s_memtime counts shader-clock cycles, s_memrealtime a constant 100 MHz; the ratio over a kernel's lifetime is
 // the clock the MFMA pipes actually ran at (the board drops it under a dense fp32 MFMA load: DESIGN.md, "clock").
+// Developer instrumentation (make TIMELINE=1 -> libsparta_amd_tl.so; never in the product build): s_memtime stamps inside the steps
+// of one workgroup of the fp32 stream kernel, written behind the 16 clock-probe words.  scripts/timeline.py reads them.
+#ifdef SPARTA_TIMELINE
+#define TL_STEPS 64
+#define TL_FIRST 16
+#define TL_STAMP(k) do { if (tl_on) asm volatile("s_memtime %0" : "=s"(tl[k])); } while (0)
+#else
+#define TL_STAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ void clock_probe(long long* clk, int slot) {
     if (clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         clk[slot] = (long long)__builtin_readcyclecounter();
@@ -534,15 +544,23 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
     // ---- G: global -> registers; steps are requested strictly in order s = 0, 1, 2, ... ----------------------
     int64_t g_aoff = 0;                                  // scalar cursor of the G stage
     int32_t g_h = 1;
-    auto issue_loads = [&](int s, u32x4 (&rb)[4], u32x4 (&ra)[2]) __attribute__((always_inline)) {
+    uint32_t voA_cur = 0, vo_cur = voffB;
+    int32_t tail_prev = 0;
+    auto issue_loads = [&](int s, u32x4 (&rb)[4], u32x4 (&ra)[2]) __attribute__((always_inline)) -> int32_t {
         const int32_t flags = field(s, F_FLAGS);
         if (flags & STEP_FIRST) {                        // tile (segment) start: re-seat the cursor, else it just advances
             g_aoff = (int64_t)(uint32_t)field(s, F_AOFF_LO) | ((int64_t)field(s, F_AOFF_HI) << 32);
             g_h = field(s, F_H);
+            voA_cur = (uint32_t)(ak0 * g_h + ai) * 4u;
         } else {
             g_aoff += (int64_t)KP * g_h;                 // consecutive steps of a block-row are contiguous in A (column-major blocks back to back)
         }
-        const bool tail = (flags & STEP_TAIL) != 0;
+        const int32_t tail = (flags & STEP_TAIL) != 0;
+        if (tail != tail_prev) {
+            vo_cur = tail ? voffBt : voffB;
+            asm volatile("" : "+v"(vo_cur));
+            tail_prev = tail;
+        }
         int64_t gk0 = field(s, F_BROW);
         const float* Bbase = tail ? p.B_tail : p.B;
         if constexpr (GATHERED) {                        // a panel never straddles slabs (shard_rows % w == 0); the host split b_row into
@@ -550,16 +568,17 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
         }                                                // a 64-bit division here costs ~40 instructions per step, 10 of them VALU
         const float* bptr = tail ? Bbase + (BRM ? gk0 * ld_t : gk0) : Bbase + (BRM ? gk0 * p.ldb : gk0) + n0off;
         const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bptr), 0, 0x7ffffff0, 0x00020000);
-        const uint32_t vo = tail ? voffBt : voffB, qs = tail ? qstepBt : qstepB;
+        const uint32_t qs = tail ? qstepBt : qstepB;
 #pragma unroll
-        for (int q = 0; q < 4; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo, qs * q, 0);
+        for (int q = 0; q < 4; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, qs * q, 0);
         // A slice: 16-byte loads along the rows of a column, streamed (nt: read exactly once).  Rows past the tile read
         // what follows in memory (next rows / next column / the pad behind A): never stored.
         const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + g_aoff), 0, 0x7ffffff0, 0x00020000);
-        const uint32_t voA = (uint32_t)(ak0 * g_h + ai) * 4u;
-        ra[0] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA, 0, 2);
-        if constexpr (MI2) ra[1] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA, (uint32_t)(16 * g_h) * 4u, 2);
+        ra[0] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA_cur, 0, 2);
+        if constexpr (MI2) ra[1] = __builtin_amdgcn_raw_buffer_load_b128(rA, voA_cur, (uint32_t)(16 * g_h) * 4u, 2);
+        return flags;
     };
+    int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq_new = 0;
 
     // ---- W: registers -> LDS stage (compile-time stage => immediate offsets) -----------------------------------
     auto write_b = [&](auto stage_tag, const u32x4 (&rb)[4], int q) __attribute__((always_inline)) {
@@ -573,10 +592,19 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
 
     // ---- C: fragments + MFMA ------------------------------------------------------------------------------
     struct Frag { float a[2][4]; f32x4 b; };
-    auto read_frag = [&](auto stage_tag, int kb, const bool mi2) __attribute__((always_inline)) {
+    uint32_t a_addr[2][4];
+#pragma unroll
+    for (int st = 0; st < 2; st++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            a_addr[st][r] = lrA + (uint32_t)((st * STAGE + 8 * r * TM) * 4);
+            asm volatile("" : "+v"(a_addr[st][r]));
+        }
+    auto read_frag = [&](auto stage_tag, auto kb_tag, const bool mi2) __attribute__((always_inline)) {
         constexpr int ST = decltype(stage_tag)::value;
+        constexpr int kb = decltype(kb_tag)::value;
         Frag f;
-        const float* as = reinterpret_cast<const float*>(ldsb + lrA + (ST * STAGE + kb * TM) * 4);
+        const float* as = reinterpret_cast<const float*>(ldsb + a_addr[ST][kb / 8]);
 #pragma unroll
         for (int m = 0; m < 4; m++) f.a[0][m] = as[m * TM];
         if (mi2) {
@@ -611,31 +639,40 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
         constexpr int PAR = decltype(par_tag)::value;
         using cur_t = std::integral_constant<int, PAR>;
         using nxt_t = std::integral_constant<int, 1 - PAR>;
+#ifdef SPARTA_TIMELINE
+        unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool tl_on = p.clk != nullptr && blockIdx.x == 8 && blockIdx.y == 0 && i >= TL_FIRST && i < TL_FIRST + TL_STEPS;
+#endif
+        TL_STAMP(0);
         // Straight-line rounds: fragments of round r, the LDS writes / global loads that ride along, MFMAs of round r; the
         // instruction scheduler interleaves across rounds.  Two hand-pinned orders were measured and lost: fragments one
         // round ahead inside the step (+3..8 % time) and one round ahead ACROSS the step boundary with the barrier moved
         // to the middle of the step (+3.5 %): the kernel runs against the board's power limit ("clock"), where
         // extra LDS traffic and issue slots cost more than the LDS latency they hide.
         {
-            const Frag f = read_frag(cur_t{}, 0, mi2);
+            const Frag f = read_frag(cur_t{}, std::integral_constant<int, 0>{}, mi2);
             write_b(nxt_t{}, wb, 0); write_b(nxt_t{}, wb, 1);
             mfma4(f, mi2);
         }
+        TL_STAMP(1);
         {
-            const Frag f = read_frag(cur_t{}, 8, mi2);
+            const Frag f = read_frag(cur_t{}, std::integral_constant<int, 8>{}, mi2);
             write_b(nxt_t{}, wb, 2); write_b(nxt_t{}, wb, 3);
             mfma4(f, mi2);
         }
+        TL_STAMP(2);
         {
-            const Frag f = read_frag(cur_t{}, 16, mi2);
+            const Frag f = read_frag(cur_t{}, std::integral_constant<int, 16>{}, mi2);
             write_a(nxt_t{}, wa, 0); write_a(nxt_t{}, wa, 1);
             mfma4(f, mi2);
         }
+        TL_STAMP(3);
         {
-            const Frag f = read_frag(cur_t{}, 24, mi2);
-            issue_loads(i + 3, wb, wa);
+            const Frag f = read_frag(cur_t{}, std::integral_constant<int, 24>{}, mi2);
+            fq_new = issue_loads(i + 3, wb, wa);
             mfma4(f, mi2);
         }
+        TL_STAMP(4);
         if (flags & STEP_LAST) {
             // epilogue: scalar descriptor + scalar per-register offsets, the per-thread part is a kernel-lifetime constant.
             // The accumulators are cleared HERE (every segment start follows a segment end), not at STEP_FIRST: a
@@ -676,18 +713,31 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
 #pragma unroll
             for (int q = 0; q < 16; q++) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
         }
+        TL_STAMP(5);
         __syncthreads();
+        TL_STAMP(6);
+#ifdef SPARTA_TIMELINE
+        if (tl_on) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                long long* o = p.clk + 16 + ((int64_t)wave * TL_STEPS + (i - TL_FIRST)) * 8;
+#pragma unroll
+                for (int k = 0; k < 7; k++) o[k] = (long long)tl[k];
+                o[7] = flags;
+            }
+        }
+#endif
     };
     // ---- prologue: G(0) G(1) | W(0) | G(2) ------------------------------------------------------------------
     using st0 = std::integral_constant<int, 0>;
     using st1 = std::integral_constant<int, 1>;
-    issue_loads(0, b0, a0);
-    issue_loads(1, b1, a1);
+    fq0 = issue_loads(0, b0, a0);
+    fq1 = issue_loads(1, b1, a1);
 #pragma unroll
     for (int q = 0; q < 4; q++) write_b(st0{}, b0, q);
 #pragma unroll
     for (int q = 0; q < 2; q++) write_a(st0{}, a0, q);
-    issue_loads(2, b0, a0);
+    fq2 = issue_loads(2, b0, a0);
     __syncthreads();
     // Batch k+1 of the step records is requested at step 8k and only TOUCHED at step 8k+4 (first needed at 8k+5 by the
     // look-ahead of 3); the register it replaces (batch k-1) is dead by then.  Both sides are inline asm on purpose: with a
@@ -715,12 +765,14 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
     const int n_even = n & ~1;
     for (int i = 0; i < n_even; i += 2) {
         batch_upkeep(i);
-        iteration_t(i, field(i, F_FLAGS), b1, a1, st0{}, mi2_t{});
-        iteration_t(i + 1, field(i + 1, F_FLAGS), b0, a0, st1{}, mi2_t{});
+        iteration_t(i, fq0, b1, a1, st0{}, mi2_t{});
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+        iteration_t(i + 1, fq0, b0, a0, st1{}, mi2_t{});
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
     }
     if (n & 1) {
         batch_upkeep(n_even);
-        iteration_t(n_even, field(n_even, F_FLAGS), b1, a1, st0{}, mi2_t{});
+        iteration_t(n_even, fq0, b1, a1, st0{}, mi2_t{});
     }
     clock_probe(p.clk, 2);
 }
@@ -1594,6 +1646,16 @@ int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info) {
     return SPARTA_OK;
 }
 
+#ifdef SPARTA_TIMELINE
+// developer build only: the raw timeline words (4 waves x 64 steps x 8)
+int sparta_debug_timeline(sparta_vbs_t* A, long long* out) {
+    if (!A || !out || !A->d_clk) return -1;
+    DeviceGuard guard(A->device);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpy(out, A->d_clk + 16, 4 * 64 * 8 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int sparta_vbs_clock_mhz(sparta_vbs_t* A, double* mhz_out) {
     using sparta::fail;
     if (!A || !mhz_out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_clock_mhz: NULL argument");
@@ -1929,8 +1991,8 @@ int sparta_vbs_set_class_timing(sparta_vbs_t* A, int32_t enable) {
             for (int e = 0; e < 2; e++) HIP_TRY(hipEventCreate(&A->cev[c][e]));
     }
     if (enable && !A->d_clk) {
-        HIP_TRY(hipMalloc((void**)&A->d_clk, 16 * sizeof(long long)));
-        HIP_TRY(hipMemset(A->d_clk, 0, 16 * sizeof(long long)));
+        HIP_TRY(hipMalloc((void**)&A->d_clk, (16 + 4 * 64 * 8) * sizeof(long long)));
+        HIP_TRY(hipMemset(A->d_clk, 0, (16 + 4 * 64 * 8) * sizeof(long long)));
     }
     A->class_timing = enable != 0;
     return SPARTA_OK;
