@@ -29,10 +29,23 @@ for _ in range(3):
     d.spmm(B, Cc, N)
 torch.cuda.synchronize()
 print("kernel ms", d.class_times(), "MHz", d.clock_mhz())
-out = np.zeros(4 * 64 * 8, np.int64)
+out = np.zeros(4 * 64 * 8 + 2048, np.int64)
 lib.sparta_debug_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 assert lib.sparta_debug_timeline(d.h, out.ctypes.data_as(C.POINTER(C.c_longlong))) == 0
-t = out.reshape(4, 64, 8)
+t = out[:4 * 64 * 8].reshape(4, 64, 8)
+wk = out[4 * 64 * 8:].reshape(1024, 2)
+wk = wk[wk[:, 1] > 0]
+if len(wk):
+    t0 = wk[:, 0].min()
+    st, en = (wk[:, 0] - t0) / 100.0, (wk[:, 1] - t0) / 100.0       # 100 MHz ticks -> us
+    dur = en - st
+    print('workers: %d; start spread %.1f us; duration mean %.1f min %.1f max %.1f us; last end %.1f us' % (len(wk), st.max(), dur.mean(), dur.min(), dur.max(), en.max()))
+    ids = np.nonzero(out[4 * 64 * 8:].reshape(1024, 2)[:, 1] > 0)[0]
+    for x in range(8):
+        sel = ids % 8 == x
+        print('   XCD %d: duration mean %.1f max %.1f, end mean %.1f max %.1f' % (x, dur[sel].mean(), dur[sel].max(), en[sel].mean(), en[sel].max()))
+    order = np.argsort(dur)
+    print('   slowest workers', ids[order[-6:]].tolist(), 'fastest', ids[order[:6]].tolist())
 names = ["round0", "round1", "round2", "round3+loads", "epilogue", "barrier", "to next step"]
 for wv in range(4):
     tw = t[wv]

@@ -503,6 +503,10 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
     const int n = p.worker_range[2 * blockIdx.x + 1] - s_begin;
     if (n <= 0) return;
     clock_probe(p.clk, 0);
+#ifdef SPARTA_TIMELINE
+    long long tl_t0 = 0;
+    if (p.clk != nullptr && blockIdx.y == 0 && tid == 0 && blockIdx.x < 1024) tl_t0 = wall_clock64();
+#endif
     float* ws = p.ws + (int64_t)blockIdx.y * p.ws_slab_stride;
 
     // ---- step records, read COALESCED and kept in registers -----------------------------------------------
@@ -775,6 +779,12 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
         iteration_t(n_even, fq0, b1, a1, st0{}, mi2_t{});
     }
     clock_probe(p.clk, 2);
+#ifdef SPARTA_TIMELINE
+    if (p.clk != nullptr && blockIdx.y == 0 && tid == 0 && blockIdx.x < 1024) {
+        p.clk[16 + 4 * 64 * 8 + 2 * blockIdx.x] = tl_t0;
+        p.clk[16 + 4 * 64 * 8 + 2 * blockIdx.x + 1] = wall_clock64();
+    }
+#endif
 }
 
 // =====================================================================================================
@@ -1362,6 +1372,8 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
         if (const char* e = std::getenv("SPARTA_SPLIT_PENALTY")) split_penalty = atoll(e);
         bool interleave = false;                         // SPARTA_STREAM_INTERLEAVE=1: deal whole tiles round-robin inside an XCD (measured: +-2 %, L2 locality is not the limit)
         if (const char* e = std::getenv("SPARTA_STREAM_INTERLEAVE")) interleave = atoi(e) != 0;
+        double slot_bias = 0.0;                          // SPARTA_SLOT_BIAS: extra share of the workgroup dispatched first onto a CU
+        if (const char* e = std::getenv("SPARTA_SLOT_BIAS")) slot_bias = std::max(-0.9, std::min(0.9, atof(e)));
         int align_mode = -1;                             // SPARTA_STREAM_ALIGN=0 always split, 1 never split, unset: cheaper one
         if (const char* e = std::getenv("SPARTA_STREAM_ALIGN")) align_mode = atoi(e) ? 1 : 0;
         if ((int64_t)cols > INT32_MAX)
@@ -1433,8 +1445,21 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
             const int per_x = n_workers / 8;
             std::vector<int64_t> bnd((size_t)n_workers + 1, S);
             bnd[0] = 0;
+            // Share of a worker.  The two (three) workgroups that share a CU do not progress at the same rate: the SIMD arbiter
+            // serves the OLDER wave first, so the workgroup dispatched first (j < #CU per XCD) runs ahead -- measured on equal
+            // ranges: the older one finished 512 steps in ~780 us, the younger one in 1030 us, the last 250 us alone on the CU at
+            // single-occupancy speed.  Give the older one `slot_bias` more work and the younger one as much less.
+            std::vector<double> wpos((size_t)n_workers, 1.0), wcum((size_t)n_workers + 1, 0.0);
+            {
+                const int cus_x = std::max(1, per_x / per_cu);
+                for (int pos = 0; pos < n_workers; pos++) {
+                    const int slot = std::min(per_cu - 1, (pos % per_x) / cus_x);
+                    wpos[(size_t)pos] = per_cu == 1 ? 1.0 : 1.0 + slot_bias * (1.0 - 2.0 * slot / (double)(per_cu - 1));
+                }
+                for (int pos = 0; pos < n_workers; pos++) wcum[(size_t)pos + 1] = wcum[(size_t)pos] + wpos[(size_t)pos];
+            }
             for (int k = 1; k < n_workers; k++) {
-                const int64_t target = total_cost * k / n_workers;
+                const int64_t target = (int64_t)((double)total_cost * wcum[(size_t)k] / wcum[(size_t)n_workers]);
                 int64_t pos = std::lower_bound(cum.begin(), cum.end(), target) - cum.begin();
                 bnd[(size_t)k] = std::min<int64_t>(std::max(pos, bnd[(size_t)k - 1]), S);
             }
@@ -1444,13 +1469,14 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
             {
                 const int64_t step_cost = ty ? c2 : c1;
                 auto tile_cost = [&](size_t t) { return (spans[t].last - spans[t].first + 1) * step_cost + ct; };
-                int64_t lo = 0, hi = total_cost;
+                int64_t lo = 0, hi = total_cost * 2;
                 for (size_t t = 0; t < spans.size(); t++) lo = std::max(lo, tile_cost(t));
-                auto bins_needed = [&](int64_t L) {
+                auto cap = [&](int64_t L, int64_t bin) { return bin < n_workers ? (int64_t)((double)L * wpos[(size_t)bin]) : L; };
+                auto bins_needed = [&](int64_t L) {                 // bin b holds at most L x (its worker's share)
                     int64_t bins = 1, cur = 0;
                     for (size_t t = 0; t < spans.size(); t++) {
                         const int64_t c = tile_cost(t);
-                        if (cur > 0 && cur + c > L) { bins++; cur = 0; }
+                        if (cur > 0 && cur + c > cap(L, bins - 1)) { bins++; cur = 0; }
                         cur += c;
                     }
                     return bins;
@@ -1467,7 +1493,7 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
                     int64_t bin = 0, cur = 0;
                     for (size_t t = 0; t < spans.size(); t++) {
                         const int64_t c = tile_cost(t);
-                        if (cur > 0 && cur + c > lo) { bin++; bnd[(size_t)bin] = spans[t].first; cur = 0; }
+                        if (cur > 0 && cur + c > cap(lo, bin) && bin + 1 < n_workers) { bin++; bnd[(size_t)bin] = spans[t].first; cur = 0; }
                         cur += c;
                     }
                     if (interleave) {
@@ -1652,7 +1678,7 @@ int sparta_debug_timeline(sparta_vbs_t* A, long long* out) {
     if (!A || !out || !A->d_clk) return -1;
     DeviceGuard guard(A->device);
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    return hipMemcpy(out, A->d_clk + 16, 4 * 64 * 8 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    return hipMemcpy(out, A->d_clk + 16, (4 * 64 * 8 + 2048) * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -1991,8 +2017,8 @@ int sparta_vbs_set_class_timing(sparta_vbs_t* A, int32_t enable) {
             for (int e = 0; e < 2; e++) HIP_TRY(hipEventCreate(&A->cev[c][e]));
     }
     if (enable && !A->d_clk) {
-        HIP_TRY(hipMalloc((void**)&A->d_clk, (16 + 4 * 64 * 8) * sizeof(long long)));
-        HIP_TRY(hipMemset(A->d_clk, 0, (16 + 4 * 64 * 8) * sizeof(long long)));
+        HIP_TRY(hipMalloc((void**)&A->d_clk, (16 + 4 * 64 * 8 + 2048) * sizeof(long long)));
+        HIP_TRY(hipMemset(A->d_clk, 0, (16 + 4 * 64 * 8 + 2048) * sizeof(long long)));
     }
     A->class_timing = enable != 0;
     return SPARTA_OK;
