@@ -856,21 +856,30 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
     u32x4 b0[NBL], a0[NAL], b1[NBL], a1[NAL];
 
     int64_t g_aoff = 0;
-    auto issue_loads = [&](int s, u32x4 (&rb)[NBL], u32x4 (&ra)[NAL]) __attribute__((always_inline)) {
+    uint32_t vo_cur = voffB;                             // see the fp32 kernel: every VALU instruction in the steady state costs an MFMA slot
+    int32_t tail_prev = 0;
+    auto issue_loads = [&](int s, u32x4 (&rb)[NBL], u32x4 (&ra)[NAL]) __attribute__((always_inline)) -> int32_t {
         const int32_t flags = field(s, F_FLAGS);
         if (flags & STEP_FIRST) g_aoff = (int64_t)(uint32_t)field(s, F_AOFF_LO) | ((int64_t)field(s, F_AOFF_HI) << 32);
         else g_aoff += (int64_t)TM * KP;                 // the slices of a tile are back to back
-        const bool tail = (flags & STEP_TAIL) != 0;
+        const int32_t tail = (flags & STEP_TAIL) != 0;
+        if (tail != tail_prev) {
+            vo_cur = tail ? voffBt : voffB;
+            asm volatile("" : "+v"(vo_cur));
+            tail_prev = tail;
+        }
         const int64_t gk0 = field(s, F_BROW);
         const uint16_t* bptr = tail ? Bt16 + gk0 : B16 + gk0 + n0off;
         const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(bptr), 0, 0x7ffffff0, 0x00020000);
-        const uint32_t vo = tail ? voffBt : voffB, qs = tail ? qstepBt : qstepB;
+        const uint32_t qs = tail ? qstepBt : qstepB;
 #pragma unroll
-        for (int q = 0; q < NBL; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo, qs * q, 0);
+        for (int q = 0; q < NBL; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, qs * q, 0);
         const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A16 + g_aoff), 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
         for (int q = 0; q < NAL; q++) ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rA, (uint32_t)ac * 16u, (uint32_t)(q * kThreads * 16), 2);
+        return flags;
     };
+    int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq_new = 0;
     auto write_stage = [&](auto stage_tag, const u32x4 (&rb)[NBL], const u32x4 (&ra)[NAL]) __attribute__((always_inline)) {
         constexpr int ST = decltype(stage_tag)::value;
 #pragma unroll
@@ -891,7 +900,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
         constexpr int PAR = decltype(par_tag)::value;
         using nxt_t = std::integral_constant<int, 1 - PAR>;
         write_stage(nxt_t{}, wb, wa);
-        issue_loads(i + 3, wb, wa);
+        fq_new = issue_loads(i + 3, wb, wa);
 #pragma unroll
         for (int kb = 0; kb < KP; kb += 16) {
             const u32x4 bf = *reinterpret_cast<const u32x4*>(ldsb + lrB + (PAR * STAGE + kb) * 2);
@@ -944,10 +953,10 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
 
     using st0 = std::integral_constant<int, 0>;
     using st1 = std::integral_constant<int, 1>;
-    issue_loads(0, b0, a0);
-    issue_loads(1, b1, a1);
+    fq0 = issue_loads(0, b0, a0);
+    fq1 = issue_loads(1, b1, a1);
     write_stage(st0{}, b0, a0);
-    issue_loads(2, b0, a0);
+    fq2 = issue_loads(2, b0, a0);
     __syncthreads();
     // record batches: see the fp32 kernel.  At least 4 steps x (NBL + NAL >= 3) = 12 loads are issued between request and touch.
     auto batch_upkeep = [&](int i) __attribute__((always_inline)) {
@@ -963,12 +972,14 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
     const int n_even = n & ~1;
     for (int i = 0; i < n_even; i += 2) {
         batch_upkeep(i);
-        iteration_t(i, field(i, F_FLAGS), b1, a1, st0{});
-        iteration_t(i + 1, field(i + 1, F_FLAGS), b0, a0, st1{});
+        iteration_t(i, fq0, b1, a1, st0{});
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+        iteration_t(i + 1, fq0, b0, a0, st1{});
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
     }
     if (n & 1) {
         batch_upkeep(n_even);
-        iteration_t(n_even, field(n_even, F_FLAGS), b1, a1, st0{});
+        iteration_t(n_even, fq0, b1, a1, st0{});
     }
     clock_probe(p.clk, 2);
 }
