@@ -50,7 +50,7 @@ extern "C" {
 
 /* BlockingType of the reference, same numeric values (include/definitions.h:17; flag -a) */
 #define SPARTA_BLOCKING_ITERATIVE            0
-#define SPARTA_BLOCKING_ITERATIVE_STRUCTURED 1   /* m:n structured variant -- not on the hot path: UNSUPPORTED */
+#define SPARTA_BLOCKING_ITERATIVE_STRUCTURED 1   /* m:n structured variant (IterativeBlockingPatternMN, blocking.cpp:19-87) */
 #define SPARTA_BLOCKING_FIXED_SIZE           2
 #define SPARTA_BLOCKING_ITERATIVE_CLOCKED    3   /* the reference's default (include/input.h:27) */
 #define SPARTA_BLOCKING_ITERATIVE_QUEUE      4
@@ -79,6 +79,8 @@ typedef struct sparta_reorder_cfg {
     int64_t row_block_size;    /* max / fixed block-row height (-B, default 3)    */
     int32_t use_pattern;       /* merge rows into the pattern  (-p, default 1)    */
     int32_t force_fixed_size;  /* re-chunk into equal heights  (-F, default 0)    */
+    int32_t structured_m;      /* blocking_algo 1 only: at most m hits per column ... (include/blocking.h:20, default 2) */
+    int32_t structured_n;      /* ... inside every run of n merged rows               (include/blocking.h:21, default 4) */
 } sparta_reorder_cfg;
 
 /* replaces the measuring fields of BlockingEngine (include/blocking.h:28-42) */

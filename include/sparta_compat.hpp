@@ -215,6 +215,7 @@ class BlockingEngine {
         cfg.blocking_algo = (int32_t)blocking_algo; cfg.sim_measure = sim_measure_; cfg.tau = tau;
         cfg.use_groups = use_groups; cfg.col_block_size = col_block_size; cfg.row_block_size = row_block_size;
         cfg.use_pattern = use_pattern; cfg.force_fixed_size = force_fixed_size;
+        cfg.structured_m = structured_m; cfg.structured_n = structured_n;
         sparta_reorder_stats st;
         grouping_result.assign((size_t)cmat.rows, 0);
         sparta_compat_detail::check(sparta_reorder(cmat.rows, cmat.cols, rp.data(), ci.data(), &cfg, (int64_t*)grouping_result.data(), &st), "GetGrouping");

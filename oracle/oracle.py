@@ -93,12 +93,15 @@ def get_fixed_size_grouping(grouping, row_block_size):
 
 
 def get_grouping(rows, rowptr, colidx, blocking_algo=3, sim_measure=1, tau=0.5, col_block_size=1, row_block_size=1,
-                 use_groups=False, use_pattern=True, force_fixed_size=False):
+                 use_groups=False, use_pattern=True, force_fixed_size=False, structured_m=2, structured_n=4):
     rp, ci = _l(rowptr), _l(colidx)
     g = np.zeros(rows, np.int64)
     cnt = np.zeros(2, np.int64)
-    rc = lib().oracle_get_grouping(rows, _lp(rp), _lp(ci), blocking_algo, sim_measure, tau, col_block_size, row_block_size,
-                                   int(use_groups), int(use_pattern), int(force_fixed_size), _lp(g), _lp(cnt))
+    L = lib()
+    L.oracle_get_grouping_mn.argtypes = [C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_long), C.c_int, C.c_int, C.c_float, C.c_long, C.c_long,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    rc = L.oracle_get_grouping_mn(rows, _lp(rp), _lp(ci), blocking_algo, sim_measure, tau, col_block_size, row_block_size,
+                                  int(use_groups), int(use_pattern), int(force_fixed_size), int(structured_m), int(structured_n), _lp(g), _lp(cnt))
     if rc != 0:
         raise NotImplementedError("oracle does not restate blocking_algo %d" % blocking_algo)
     return g, dict(comparison_counter=int(cnt[0]), merge_counter=int(cnt[1]))

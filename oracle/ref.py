@@ -42,6 +42,7 @@ def lib():
         L.ref_csr_pattern_only.argtypes = [vp]
         L.ref_csr_export.argtypes = [vp, lp, lp, fp]
         L.ref_csr_multiply.argtypes = [vp, fp, C.c_long, fp]
+        L.ref_set_structured.argtypes = [C.c_int, C.c_int]
         L.ref_csr_reorder.argtypes = [vp, lp, C.c_long]
         L.ref_csr_reorder_by_degree.argtypes = [vp, C.c_int]
         L.ref_csr_save_to_edgelist.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
@@ -117,7 +118,8 @@ class RefCSR:
         return Cm
 
     def grouping(self, algo=3, tau=0.5, col_block_size=1, row_block_size=1, use_groups=False,
-                 use_pattern=True, force_fixed_size=False, sim_measure=1, with_info=False):
+                 use_pattern=True, force_fixed_size=False, sim_measure=1, with_info=False, structured_m=2, structured_n=4):
+        lib().ref_set_structured(int(structured_m), int(structured_n))
         g = np.zeros(self.rows, np.int64)
         st = np.zeros(2, np.int64)
         fst = np.zeros(2, np.float32)

@@ -34,7 +34,12 @@ CSR* make_empty_csr(bool pattern_only)
 }
 }
 
+static int g_structured_m = 2, g_structured_n = 4;
+
 extern "C" {
+
+// m:n parameters of IterativeBlockingPatternMN for the following ref_get_grouping calls (blocking_algo 1)
+void ref_set_structured(int m, int n) { g_structured_m = m; g_structured_n = n; }
 
 void* ref_csr_create(long rows, long cols, const long* rowptr, const long* colidx, const float* vals)
 {
@@ -113,6 +118,7 @@ int ref_get_grouping(void* h, int algo, float tau, long col_block_size, long row
     e.use_pattern = use_pattern != 0;
     e.force_fixed_size = force_fixed_size != 0;
     e.blocking_algo = (BlockingType)algo;
+    e.structured_m = g_structured_m; e.structured_n = g_structured_n;     // include/blocking.h:20-21 (defaults 2, 4)
     e.SetComparator(sim_measure);
     std::vector<intT> g = e.GetGrouping(*c);
     std::copy(g.begin(), g.end(), grouping_out);

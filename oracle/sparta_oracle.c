@@ -456,6 +456,80 @@ static void blocking_plain(long rows, const long* rowptr, const long* colidx, fl
     free(pattern.data); free(merged.data);
 }
 
+/* IterativeBlockingPatternMN, src/general/blocking.cpp:19-87 with check_structured_sparsity / update_structured_sparsity,
+ * src/general/utilities.cpp:56-129: the plain algorithm plus an m:n guard -- inside every run of structured_n merged rows no
+ * column may be hit more than structured_m times.  Note `if (use_pattern)` guards the merge here (it does not in the plain one). */
+static int mn_check(const lvec* pat, const lvec* cnt, const long* row, long row_len, int m)
+{
+    long i = 0, j = 0;
+    while (i < pat->size && j < row_len) {
+        if (pat->data[i] < row[j]) i++;
+        else if (pat->data[i] > row[j]) j++;
+        else { if (cnt->data[i] >= m) return 0; i++; j++; }
+    }
+    return 1;
+}
+static void mn_update(lvec* pat, lvec* cnt, lvec* np_, lvec* nc_, const long* row, long row_len)
+{
+    lvec_reserve(np_, pat->size + row_len); lvec_reserve(nc_, pat->size + row_len);
+    long i = 0, j = 0, k = 0;
+    while (i < pat->size && j < row_len) {
+        if (pat->data[i] < row[j]) { np_->data[k] = pat->data[i]; nc_->data[k++] = cnt->data[i]; i++; }
+        else if (pat->data[i] > row[j]) { np_->data[k] = row[j]; nc_->data[k++] = 1; j++; }
+        else { np_->data[k] = pat->data[i]; nc_->data[k++] = cnt->data[i] + 1; i++; j++; }
+    }
+    while (i < pat->size) { np_->data[k] = pat->data[i]; nc_->data[k++] = cnt->data[i]; i++; }
+    while (j < row_len) { np_->data[k] = row[j]; nc_->data[k++] = 1; j++; }
+    np_->size = nc_->size = k;
+    lvec t = *pat; *pat = *np_; *np_ = t;
+    t = *cnt; *cnt = *nc_; *nc_ = t;
+}
+static void blocking_mn(long rows, const long* rowptr, const long* colidx, float tau, dist_fn distance, long block_size, int use_size,
+                        int use_pattern, int structured_m, int structured_n, long* grouping, long* comparison_counter, long* merge_counter)
+{
+    for (long i = 0; i < rows; i++) grouping[i] = -1;
+    lvec pattern = {0, 0, 0}, merged = {0, 0, 0}, sp = {0, 0, 0}, sc = {0, 0, 0}, t1 = {0, 0, 0}, t2 = {0, 0, 0};
+    for (long i = 0; i < rows; i++) {
+        if (grouping[i] != -1) continue;
+        long current_group_size = 1;
+        grouping[i] = i;
+        long ni = rowptr[i + 1] - rowptr[i];
+        lvec_reserve(&pattern, ni);
+        memcpy(pattern.data, colidx + rowptr[i], sizeof(long) * (size_t)ni);
+        pattern.size = ni;
+        int row_counter = 1;                                           /* :33 */
+        lvec_reserve(&sp, ni); lvec_reserve(&sc, ni);
+        memcpy(sp.data, pattern.data, sizeof(long) * (size_t)ni);
+        for (long k = 0; k < ni; k++) sc.data[k] = 1;
+        sp.size = sc.size = ni;
+        for (long j = i + 1; j < rows; j++) {
+            if (grouping[j] != -1) continue;
+            (*comparison_counter)++;
+            const long* row_j = colidx + rowptr[j];
+            long nj = rowptr[j + 1] - rowptr[j];
+            float dist = distance(pattern.data, pattern.size, current_group_size, row_j, nj, 1, block_size);
+            if (dist < tau) {
+                int ok = 1;
+                if (row_counter % structured_n == 0) { row_counter = 0; sp.size = sc.size = 0; }      /* :50-56 */
+                else ok = mn_check(&sp, &sc, row_j, nj, structured_m);
+                if (ok) {
+                    (*merge_counter)++;
+                    grouping[j] = i;
+                    if (use_pattern) {
+                        lvec_reserve(&merged, pattern.size + nj);
+                        merged.size = oracle_merge_rows(pattern.data, pattern.size, row_j, nj, merged.data);
+                        lvec t = pattern; pattern = merged; merged = t;
+                    }
+                    if (use_size) current_group_size++;
+                    mn_update(&sp, &sc, &t1, &t2, row_j, nj);
+                    row_counter++;
+                }
+            }
+        }
+    }
+    free(pattern.data); free(merged.data); free(sp.data); free(sc.data); free(t1.data); free(t2.data);
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* std::set<std::pair<float,long>> of libstdc++ 11 (bits/stl_tree.h, src/c++98/tree.cc), restated   */
 /* ------------------------------------------------------------------------------------------------ */
@@ -729,6 +803,14 @@ int oracle_get_grouping(long rows, const long* rowptr, const long* colidx, int b
                         long col_block_size, long row_block_size, int use_groups, int use_pattern, int force_fixed_size,
                         long* grouping, long* counters)
 {
+    return oracle_get_grouping_mn(rows, rowptr, colidx, blocking_algo, sim_measure, tau, col_block_size, row_block_size, use_groups,
+                                  use_pattern, force_fixed_size, 2, 4, grouping, counters);     /* include/blocking.h:20-21 defaults */
+}
+
+int oracle_get_grouping_mn(long rows, const long* rowptr, const long* colidx, int blocking_algo, int sim_measure, float tau,
+                           long col_block_size, long row_block_size, int use_groups, int use_pattern, int force_fixed_size,
+                           int structured_m, int structured_n, long* grouping, long* counters)
+{
     long cmp = 0, mrg = 0;
     /* SetComparator (blocking.cpp:699-717): 0/2 Hamming, 1/3 Jaccard (the "OPENMP" twins compute the same) */
     dist_fn distance = (sim_measure & 1) ? oracle_jaccard_distance_group : oracle_hamming_distance_group;
@@ -738,6 +820,7 @@ int oracle_get_grouping(long rows, const long* rowptr, const long* colidx, int b
         case 0: blocking_plain(rows, rowptr, colidx, tau, distance, col_block_size, use_groups, grouping, &cmp, &mrg); break;
         case 2: for (long i = 0; i < rows; i++) grouping[i] = i / row_block_size; break;   /* FixedBlocking :554-562 */
         case 5: blocking_keeper(rows, rowptr, colidx, tau, distance, col_block_size, row_block_size, use_pattern, grouping, &cmp, &mrg); break;
+        case 1: blocking_mn(rows, rowptr, colidx, tau, distance, col_block_size, use_groups, use_pattern, structured_m, structured_n, grouping, &cmp, &mrg); break;
         default: return -1;
     }
     if (force_fixed_size && blocking_algo != 2) {                                           /* :670-673 */

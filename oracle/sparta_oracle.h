@@ -41,10 +41,14 @@ void oracle_get_fixed_size_grouping(const long* grouping, long n, long row_block
  *   0 iterative (:89-154), 2 fixed_size (:554-562), 3 iterative_clocked (:156-243), 4 iterative_queue (:245-338),
  *   5 iterative_max_size == IterativeBlockingKeeper (:433-549; needs libstdc++'s red-black tree, restated in the .c).
  * sim_measure: 0 Hamming, 1 Jaccard.  counters (may be NULL): [comparison_counter, merge_counter].
- * Returns 0, or -1 for an algorithm the oracle does not restate (1 structured, 6 scramble). */
+ * Returns 0, or -1 for an algorithm the oracle does not restate (6 scramble).  Algorithm 1 (m:n structured) runs with the
+ * reference's default m = 2, n = 4 here; oracle_get_grouping_mn takes them explicitly. */
 int oracle_get_grouping(long rows, const long* rowptr, const long* colidx, int blocking_algo, int sim_measure, float tau,
                         long col_block_size, long row_block_size, int use_groups, int use_pattern, int force_fixed_size,
                         long* grouping, long* counters);
+int oracle_get_grouping_mn(long rows, const long* rowptr, const long* colidx, int blocking_algo, int sim_measure, float tau,
+                           long col_block_size, long row_block_size, int use_groups, int use_pattern, int force_fixed_size,
+                           int structured_m, int structured_n, long* grouping, long* counters);
 
 /* VBR::fill_from_CSR_inplace, src/general/vbr.cpp:135-237.
  * Two calls: with mab == NULL it only fills dims_out = {rows, cols, block_rows, block_cols, nztot, nblocks} (and

@@ -61,7 +61,7 @@ class CsvFields(C.Structure):
 class ReorderCfg(C.Structure):
     _fields_ = [("blocking_algo", C.c_int32), ("sim_measure", C.c_int32), ("tau", C.c_float), ("use_groups", C.c_int32),
                 ("col_block_size", C.c_int64), ("row_block_size", C.c_int64), ("use_pattern", C.c_int32),
-                ("force_fixed_size", C.c_int32)]
+                ("force_fixed_size", C.c_int32), ("structured_m", C.c_int32), ("structured_n", C.c_int32)]
 
 
 class ReorderStats(C.Structure):

@@ -62,6 +62,8 @@ void sparta_reorder_cfg_default(sparta_reorder_cfg* c) {
     c->row_block_size = 3;                                  // :32
     c->use_pattern = 1;                                     // :22
     c->force_fixed_size = 0;                                // :24
+    c->structured_m = 2;                                    // include/blocking.h:20
+    c->structured_n = 4;                                    // :21
 }
 
 int sparta_reorder(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const sparta_reorder_cfg* cfg,

@@ -328,6 +328,73 @@ void plain(C& c, int64_t* grouping) {
     }
 }
 
+// Algorithm 1 (IterativeBlockingPatternMN, blocking.cpp:19-87): the plain algorithm (strict `<`) with an m:n guard taken from
+// check_structured_sparsity / update_structured_sparsity (utilities.cpp:56-129): a candidate that passes the distance test is
+// merged only if, inside the current run of structured_n merged rows, none of its columns has already been hit structured_m
+// times.  Here `use_pattern` does guard the pattern merge (:70-71).  The guard works on column ids, literally as written.
+template <class C>
+void structured_mn(C& c, int64_t* grouping) {
+    const int64_t rows = c.a.rows;
+    const float tau = c.cfg.tau;
+    const int m = c.cfg.structured_m, n = c.cfg.structured_n;
+    std::fill(grouping, grouping + rows, (int64_t)-1);
+    std::vector<int64_t> alive((size_t)rows), next, sp, sc, np_, nc_;
+    std::iota(alive.begin(), alive.end(), (int64_t)0);
+    auto check = [&](const int32_t* row, int64_t len) {
+        size_t i = 0; int64_t j = 0;
+        while (i < sp.size() && j < len) {
+            if (sp[i] < row[j]) i++;
+            else if (sp[i] > row[j]) j++;
+            else { if (sc[i] >= m) return false; i++; j++; }
+        }
+        return true;
+    };
+    auto update = [&](const int32_t* row, int64_t len) {
+        np_.clear(); nc_.clear();
+        size_t i = 0; int64_t j = 0;
+        while (i < sp.size() && j < len) {
+            if (sp[i] < row[j]) { np_.push_back(sp[i]); nc_.push_back(sc[i]); i++; }
+            else if (sp[i] > row[j]) { np_.push_back(row[j]); nc_.push_back(1); j++; }
+            else { np_.push_back(sp[i]); nc_.push_back(sc[i] + 1); i++; j++; }
+        }
+        for (; i < sp.size(); i++) { np_.push_back(sp[i]); nc_.push_back(sc[i]); }
+        for (; j < len; j++) { np_.push_back(row[j]); nc_.push_back(1); }
+        sp.swap(np_); sc.swap(nc_);
+    };
+    while (!alive.empty()) {
+        const int64_t i = alive[0];
+        grouping[i] = i;
+        c.assign(i);
+        int64_t gsize = 1;
+        int row_counter = 1;
+        sp.assign(c.a.row(i), c.a.row(i) + c.a.nnz_of(i));
+        sc.assign(sp.size(), 1);
+        next.clear();
+        for (size_t q = 1; q < alive.size(); q++) {
+            const int64_t j = alive[q];
+            c.comparisons++;
+            const float d = c.dist(gsize, j);
+            bool merged = false;
+            if (d < tau) {
+                bool ok = true;
+                if (row_counter % n == 0) { row_counter = 0; sp.clear(); sc.clear(); }
+                else ok = check(c.a.row(j), c.a.nnz_of(j));
+                if (ok) {
+                    c.merges++;
+                    grouping[j] = i;
+                    if (c.cfg.use_pattern) c.merge(j);
+                    if (c.cfg.use_groups) gsize++;
+                    update(c.a.row(j), c.a.nnz_of(j));
+                    row_counter++;
+                    merged = true;
+                }
+            }
+            if (!merged) next.push_back(j);
+        }
+        alive.swap(next);
+    }
+}
+
 // Algorithm 5 (-a 5 dispatches to IterativeBlockingKeeper, blocking.cpp:655, :433-549): clusters are
 // capped at row_block_size rows; the best rejected candidates are kept in an ordered set and used to
 // pad short clusters; complete clusters are numbered `seed`, incomplete ones `seed + rows` (:450,527-533).
@@ -469,7 +536,10 @@ int reorder(const CsrView& a, const sparta_reorder_cfg& cfg, int64_t* grouping_o
                            cfg.force_fixed_size;
     if (needs_rbs && cfg.row_block_size <= 0) return fail(SPARTA_ERR_INVALID, "sparta_reorder: row_block_size must be > 0");
     const bool iterative = cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE || cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_CLOCKED ||
-                           cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_QUEUE || cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_MAX_SIZE;
+                           cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_QUEUE || cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_MAX_SIZE ||
+                           cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_STRUCTURED;
+    if (cfg.blocking_algo == SPARTA_BLOCKING_ITERATIVE_STRUCTURED && (cfg.structured_m <= 0 || cfg.structured_n <= 0))
+        return fail(SPARTA_ERR_INVALID, "sparta_reorder: structured_m and structured_n must be > 0 for blocking_algo 1");
     if (int rc = validate_csr(a, false)) return rc;
 
     auto t0 = clk::now();
@@ -479,10 +549,11 @@ int reorder(const CsrView& a, const sparta_reorder_cfg& cfg, int64_t* grouping_o
         switch (cfg.blocking_algo) {
             case SPARTA_BLOCKING_ITERATIVE_MAX_SIZE: keeper(c, grouping_out); break;
             case SPARTA_BLOCKING_ITERATIVE: plain(c, grouping_out); break;
+            case SPARTA_BLOCKING_ITERATIVE_STRUCTURED: structured_mn(c, grouping_out); break;
             default: clocked(c, grouping_out); break;
         }
         st.comparison_counter = c.comparisons; st.merge_counter = c.merges;
-        if (cfg.blocking_algo != SPARTA_BLOCKING_ITERATIVE) {
+        if (cfg.blocking_algo != SPARTA_BLOCKING_ITERATIVE && cfg.blocking_algo != SPARTA_BLOCKING_ITERATIVE_STRUCTURED) {
             st.average_merge_tau = c.total_merge_tau / (float)c.merges;          // :239-240 (NaN when no merge, as in the reference)
             st.average_row_distance = c.total_row_distance / (float)c.merges;
         }
@@ -492,6 +563,7 @@ int reorder(const CsrView& a, const sparta_reorder_cfg& cfg, int64_t* grouping_o
         case SPARTA_BLOCKING_ITERATIVE_CLOCKED:
         case SPARTA_BLOCKING_ITERATIVE_QUEUE:
         case SPARTA_BLOCKING_ITERATIVE_MAX_SIZE:
+        case SPARTA_BLOCKING_ITERATIVE_STRUCTURED:
         case SPARTA_BLOCKING_ITERATIVE: {
             if (fast) { Ctx c(a, cfg); run(c); }
             else { LiteralCtx c(a, cfg); run(c); }
@@ -508,8 +580,7 @@ int reorder(const CsrView& a, const sparta_reorder_cfg& cfg, int64_t* grouping_o
             break;
         }
         default:
-            return fail(SPARTA_ERR_UNSUPPORTED, "sparta_reorder: blocking_algo " + std::to_string(cfg.blocking_algo) +
-                                                    " (m:n structured) is outside the hot path");
+            return fail(SPARTA_ERR_INVALID, "sparta_reorder: unknown blocking_algo " + std::to_string(cfg.blocking_algo));
     }
     if (cfg.force_fixed_size && cfg.blocking_algo != SPARTA_BLOCKING_FIXED_SIZE) {   // :670-673
         std::vector<int64_t> g = get_fixed_size_grouping(grouping_out, a.rows, cfg.row_block_size);

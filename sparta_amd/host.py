@@ -125,7 +125,7 @@ class BlockingEngine:
     (include/blocking.h:9-56)."""
 
     def __init__(self, tau=0.5, col_block_size=1, row_block_size=1, use_groups=False, use_pattern=True,
-                 force_fixed_size=False, blocking_algo=3, sim_measure=1):
+                 force_fixed_size=False, blocking_algo=3, sim_measure=1, structured_m=2, structured_n=4):
         self.tau = tau
         self.col_block_size = col_block_size
         self.row_block_size = row_block_size
@@ -134,6 +134,7 @@ class BlockingEngine:
         self.force_fixed_size = force_fixed_size
         self.blocking_algo = BLOCKING_ALGOS.get(blocking_algo, blocking_algo)
         self.sim_measure = sim_measure          # SetComparator(choice): 0 Hamming, 1 Jaccard (blocking.cpp:699-717)
+        self.structured_m, self.structured_n = structured_m, structured_n      # blocking_algo 1 (include/blocking.h:20-21)
         self.comparison_counter = 0
         self.merge_counter = 0
         self.timer_total = 0.0
@@ -162,6 +163,7 @@ class BlockingEngine:
         c.row_block_size = int(self.row_block_size)
         c.use_pattern = int(bool(self.use_pattern))
         c.force_fixed_size = int(bool(self.force_fixed_size))
+        c.structured_m, c.structured_n = int(self.structured_m), int(self.structured_n)
         return c
 
     def GetGrouping(self, cmat):

@@ -162,5 +162,30 @@ def main():
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def main_mn():
+    """mn.npz: IterativeBlockingPatternMN (blocking_algo 1) on three of the seeded matrices, m:n and flag variants"""
+    mats = matrices()
+    out = {}
+    cfgs = [dict(tau=0.5, w=4, m=2, n=4), dict(tau=0.8, w=1, m=1, n=3), dict(tau=0.6, w=16, m=3, n=2, use_groups=True),
+            dict(tau=0.5, w=8, m=2, n=4, use_pattern=False), dict(tau=0.7, w=8, m=1, n=1, ff=True, rbs=6), dict(tau=9.0, w=4, m=2, n=5, sim=0)]
+    for name in ("u256", "rect", "unsorted"):
+        m = mats[name]
+        rc = ref.RefCSR(m.rows, m.cols, m.rowptr, m.colidx.astype(np.int64), m.vals)
+        for k, cfg in enumerate(cfgs):
+            g, st = rc.grouping(algo=1, tau=cfg["tau"], col_block_size=cfg["w"], row_block_size=cfg.get("rbs", 1),
+                                use_groups=cfg.get("use_groups", False), use_pattern=cfg.get("use_pattern", True),
+                                force_fixed_size=cfg.get("ff", False), sim_measure=cfg.get("sim", 1),
+                                structured_m=cfg["m"], structured_n=cfg["n"])
+            out["%s/%d/cfg" % (name, k)] = np.array(repr(cfg))
+            out["%s/%d/grouping" % (name, k)] = g.astype(np.int32)
+            out["%s/%d/counters" % (name, k)] = np.array([st["comparison_counter"], st["merge_counter"]], np.int64)
+    np.savez_compressed(os.path.join(HERE, "mn.npz"), **out)
+    print("wrote mn.npz with", len(out), "arrays")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "mn":
+    main_mn()

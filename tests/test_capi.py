@@ -47,8 +47,11 @@ def test_error_reporting():
     assert ei.value.code == _lib.ERR_INVALID and "rowptr" in str(ei.value)
     ok = sa.CSR(3, 3, [0, 2, 2, 3], [1, 2, 0])
     with pytest.raises(sa.SpartaError) as ei:
-        sa.BlockingEngine(tau=0.5, col_block_size=2, blocking_algo=1).GetGrouping(ok)   # m:n structured: out of scope
-    assert ei.value.code == _lib.ERR_UNSUPPORTED
+        sa.BlockingEngine(tau=0.5, col_block_size=2, blocking_algo=1, structured_n=0).GetGrouping(ok)   # m:n structured needs m, n > 0
+    assert ei.value.code == _lib.ERR_INVALID
+    with pytest.raises(sa.SpartaError) as ei:
+        sa.BlockingEngine(tau=0.5, col_block_size=2, blocking_algo=9).GetGrouping(ok)
+    assert ei.value.code == _lib.ERR_INVALID
     with pytest.raises(sa.SpartaError):
         sa.BlockingEngine(tau=0.5, col_block_size=0).GetGrouping(ok)
     with pytest.raises(sa.SpartaError):

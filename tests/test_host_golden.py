@@ -72,3 +72,28 @@ def test_case_golden(key, name, cfg):
     e.CollectBlockingInfo(m)
     assert [e.VBR_nzcount, e.VBR_nzblocks_count, e.VBR_longest_row] == f["info"].tolist()
     assert np.float32(e.VBR_average_height) == f["avg_height"]
+
+
+def _mn_cases():
+    z = U.load("mn.npz")
+    return sorted({tuple(k.split("/")[:2]) for k in z.files})
+
+
+@pytest.mark.parametrize("name,k", _mn_cases())
+def test_structured_mn_blocking_matches_the_reference(name, k):
+    """blocking_algo 1 (IterativeBlockingPatternMN, blocking.cpp:19-87): product == oracle == compiled reference (mn.npz)"""
+    import ast
+    from oracle import oracle as O
+    z = U.load("mn.npz")
+    cfg = ast.literal_eval(str(z["%s/%s/cfg" % (name, k)]))
+    m = U.matrices()[name]
+    e = sa.BlockingEngine(tau=cfg["tau"], col_block_size=cfg["w"], row_block_size=cfg.get("rbs", 1), use_groups=cfg.get("use_groups", False),
+                          use_pattern=cfg.get("use_pattern", True), force_fixed_size=cfg.get("ff", False), blocking_algo=1,
+                          sim_measure=cfg.get("sim", 1), structured_m=cfg["m"], structured_n=cfg["n"])
+    g = e.GetGrouping(m)
+    want, cnt = z["%s/%s/grouping" % (name, k)], z["%s/%s/counters" % (name, k)]
+    assert np.array_equal(g, want)
+    assert [e.comparison_counter, e.merge_counter] == list(cnt)
+    go, co = O.get_grouping(m.rows, m.rowptr, m.colidx, 1, cfg.get("sim", 1), cfg["tau"], cfg["w"], cfg.get("rbs", 1),
+                            cfg.get("use_groups", False), cfg.get("use_pattern", True), cfg.get("ff", False), cfg["m"], cfg["n"])
+    assert np.array_equal(go, want) and [co["comparison_counter"], co["merge_counter"]] == list(cnt)

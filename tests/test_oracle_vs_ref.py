@@ -65,3 +65,24 @@ def test_real_world_edgelists(name):
     pv = sa.VBR().fill_from_CSR_inplace(m, gr, 64)
     for x, y in zip(rv.export(), (pv.row_part, pv.nzcount, pv.jab, pv.mab)):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.skipif(not ref.available(), reason="compiled reference not present")
+def test_structured_mn_random_cases_against_the_live_reference():
+    """blocking_algo 1: product, oracle restatement and the compiled reference on random small matrices and m:n settings"""
+    rng = np.random.Generator(np.random.PCG64(91))
+    for case in range(150):
+        rows, cols = int(rng.integers(2, 100)), int(rng.integers(2, 80))
+        m = sa.gen.uniform_random(rows, cols, int(rng.integers(0, rows * cols // 3 + 1)), seed=int(rng.integers(1 << 30)))
+        w, sm = int(rng.choice([1, 2, 3, 8])), int(rng.integers(0, 2))
+        tau = float(rng.integers(1, 12)) if sm == 0 else float(rng.choice([0.2, 0.5, 0.8, 1.0]))
+        mm, nn, ug, up = int(rng.integers(1, 4)), int(rng.integers(1, 6)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        e = sa.BlockingEngine(tau=tau, col_block_size=w, use_groups=ug, use_pattern=up, blocking_algo=1, sim_measure=sm,
+                              structured_m=mm, structured_n=nn)
+        g = e.GetGrouping(m)
+        gr, st = ref.RefCSR(m.rows, m.cols, m.rowptr, m.colidx, m.vals).grouping(
+            algo=1, tau=tau, col_block_size=w, use_groups=ug, use_pattern=up, sim_measure=sm, structured_m=mm, structured_n=nn)
+        go, co = O.get_grouping(m.rows, m.rowptr, m.colidx, 1, sm, tau, w, 1, ug, up, False, mm, nn)
+        assert np.array_equal(g, gr) and np.array_equal(go, gr), case
+        assert e.comparison_counter == st["comparison_counter"] == co["comparison_counter"]
+        assert e.merge_counter == st["merge_counter"] == co["merge_counter"]
