@@ -1234,140 +1234,47 @@ void destroy_impl(sparta_vbs* v) {
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int sparta_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
+// ---- host side of the stream kernels: the plan ---------------------------------------------------------------------------
+struct StreamPlanIn {
+    int64_t cols, w, br0, br1, jab_lo, mab_lo;
+    const int64_t* row_part; const int64_t* nzcount; const int64_t* jab; const float* mab;
+    int32_t dtype, device;
+};
+struct StreamPlanHost {
+    std::vector<StepRec> steps[2];            // per tile type: [0] <= 32 rows, [1] 33..64 rows
+    std::vector<int32_t> wrange[2];           // [2 * n_workers] begin / end step of every worker
+    std::vector<FixRec> fix;                  // split tiles + tiles of block-rows without blocks (zero fill)
+    std::vector<int32_t> fix_slots;
+    std::vector<uint16_t> a16;                // 16-bit handles: A re-laid-out as dense row-major TM x kp slices, one per step
+    int n_workers = 0, n_split = 0;
+    int plan_aligned[2] = {0, 0};
+    int64_t kp = SK_KP;
+};
 
-int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
-                            const int64_t* nzcount, const int64_t* jab, const float* mab, int64_t br0, int64_t br1, int32_t dtype,
-                            int32_t device) {
+int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
     using sparta::fail;
-    if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: out is NULL");
-    *out = nullptr;
-    if (rows <= 0 || cols <= 0 || block_rows <= 0 || w <= 0 || !row_part || !nzcount)
-        return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad dimensions or NULL index array");
-    if (br0 < 0 || br1 > block_rows || br0 >= br1) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad block-row range");
-    if (dtype != SPARTA_F32 && dtype != SPARTA_F16 && dtype != SPARTA_BF16) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad dtype");
+    const int64_t cols = in.cols, w = in.w, br0 = in.br0, br1 = in.br1, jab_lo = in.jab_lo, mab_lo = in.mab_lo;
+    const int64_t* row_part = in.row_part; const int64_t* nzcount = in.nzcount; const int64_t* jab = in.jab; const float* mab = in.mab;
+    const int32_t dtype = in.dtype, device = in.device;
     const bool h16 = dtype != SPARTA_F32;
-    if (h16 && w % 32 != 0)
-        return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: SPARTA_F16 / SPARTA_BF16 need block_col_size % 32 == 0 (only the stream kernels have a 16-bit form)");
-    if (rows > INT32_MAX || w > (1 << 20)) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: rows >= 2^31 or w > 2^20");
-    const int64_t block_cols = (cols - 1) / w + 1;
-
-    // validate the partition and locate the range inside jab / mab
-    if (row_part[0] != 0 || row_part[block_rows] != rows) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: row_part must span [0, rows]");
-    int64_t jab_lo = 0, mab_lo = 0, jab_hi = 0, mab_hi = 0, jo = 0, mo = 0;
-    for (int64_t ib = 0; ib < block_rows; ib++) {
-        const int64_t h = row_part[ib + 1] - row_part[ib];
-        if (h < 0 || nzcount[ib] < 0 || nzcount[ib] > block_cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: invalid row_part / nzcount");
-        if (h > INT32_MAX / 2 || nzcount[ib] > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: block-row too large");
-        if (ib == br0) { jab_lo = jo; mab_lo = mo; }
-        jo += nzcount[ib];
-        mo += nzcount[ib] * h * w;
-        if (ib == br1 - 1) { jab_hi = jo; mab_hi = mo; }
-    }
-    const int64_t nblocks = jab_hi - jab_lo, nztot = mab_hi - mab_lo;
-    if (nblocks > 0 && (!jab || !mab)) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: jab / mab is NULL");
-
-    int ndev = sparta_device_count();
-    if (ndev <= 0) return fail(SPARTA_ERR_NO_DEVICE, "sparta_vbs_create: no HIP device visible (this path has no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: device index out of range");
-
-    // ---- plan: row tiles per class -----------------------------------------------------------------
-    std::vector<TileDesc> tiles[4];
-    std::vector<BlockRowDesc> brows;
-    std::vector<int32_t> jab32((size_t)std::max<int64_t>(nblocks, 1));
-    for (int64_t q = 0; q < nblocks; q++) {
-        const int64_t jb = jab[jab_lo + q];
-        if (jb < 0 || jb >= block_cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: jab entry out of range");
-        jab32[(size_t)q] = (int32_t)jb;
-    }
-    int64_t exec_area = 0;
-    {
-        int64_t jo2 = 0, mo2 = 0;
-        const int64_t row0 = row_part[br0];
-        for (int64_t ib = br0; ib < br1; ib++) {
-            const int64_t h = row_part[ib + 1] - row_part[ib];
-            const int64_t nb = nzcount[ib];
-            if (h > 0) {
-                BlockRowDesc br{mo2, jo2, (int32_t)nb, (int32_t)h, (int32_t)(row_part[ib] - row0), 0};
-                brows.push_back(br);
-                int64_t r0 = 0;
-                while (r0 < h) {
-                    const int64_t rem = h - r0;
-                    int cls;
-                    int64_t mt;
-                    if (rem > 32) { cls = 2; mt = std::min<int64_t>(rem, 64); }
-                    else if (rem > 16) { cls = 1; mt = rem; }
-                    else { cls = 0; mt = rem; }
-                    const bool tail = (cols % w != 0) && nb > 0 && jab[jab_lo + jo2 + nb - 1] == block_cols - 1;
-                    TileDesc t{mo2 + r0, jo2, (int32_t)nb, (int32_t)h, (int32_t)(row_part[ib] - row0 + r0),
-                               (int32_t)mt | (tail ? TILE_TAIL : 0)};
-                    tiles[cls].push_back(t);
-                    const int64_t padded = cls == 0 ? 16 : ((mt + 31) / 32) * 32;
-                    exec_area += padded * w * nb;
-                    r0 += mt;
-                }
-            }
-            jo2 += nb;
-            mo2 += nb * h * w;
-        }
-    }
-
-    // ---- schedule: per class, 8 contiguous chunks of ~equal cost (one per XCD: neighbouring block-rows gather the
-    // same B panels, so they should share an L2), each chunk sorted by descending cost (the hardware hands workgroups
-    // to free slots in blockIdx order => longest-processing-time-first per XCD), interleaved so that entry t is XCD
-    // t % 8's (t / 8)-th item; short chunks are padded with empty tiles (nb = 0, mt = 0: nothing loaded or stored).
-    int64_t n_real[4];
-    for (int c = 0; c < 4; c++) n_real[c] = (int64_t)tiles[c].size();
-    {
-        const char* ord = std::getenv("SPARTA_TILE_ORDER");
-        const bool natural = ord && std::strcmp(ord, "natural") == 0;
-        for (int c = 0; c < 4; c++) {
-            std::vector<TileDesc>& L = tiles[c];
-            if (L.empty()) continue;
-            const int64_t rows_pad = c == 0 ? 16 : (c == 1 ? 32 : 64);
-            auto cost = [&](const TileDesc& t) { return (int64_t)t.nb * rows_pad + rows_pad / 4; };
-            int64_t total = 0;
-            for (const TileDesc& t : L) total += cost(t);
-            std::vector<std::vector<TileDesc>> chunk(8);
-            int64_t acc_cost = 0;
-            for (const TileDesc& t : L) {
-                int x = (int)std::min<int64_t>(7, (acc_cost * 8) / std::max<int64_t>(total, 1));
-                chunk[(size_t)x].push_back(t);
-                acc_cost += cost(t);
-            }
-            size_t maxlen = 0;
-            for (auto& ch : chunk) {
-                if (!natural) std::stable_sort(ch.begin(), ch.end(), [&](const TileDesc& a, const TileDesc& b) { return cost(a) > cost(b); });
-                maxlen = std::max(maxlen, ch.size());
-            }
-            std::vector<TileDesc> arranged(maxlen * 8, TileDesc{0, 0, 0, 1, 0, 0});
-            for (size_t x = 0; x < 8; x++)
-                for (size_t j = 0; j < chunk[x].size(); j++) arranged[j * 8 + x] = chunk[x][j];
-            L.swap(arranged);
-        }
-    }
-
+    std::vector<StepRec>(&steps)[2] = P.steps;
+    std::vector<int32_t>(&wrange)[2] = P.wrange;
+    std::vector<FixRec>& fix = P.fix;
+    std::vector<int32_t>& fix_slots = P.fix_slots;
+    std::vector<uint16_t>& a16 = P.a16;
+    int& n_workers = P.n_workers; int& n_split = P.n_split;
+    int(&plan_aligned)[2] = P.plan_aligned;
     // ---- stream plans (persistent kernels): flatten tiles into 32-deep steps, cut into equal-cost worker ranges ----
     // One plan per tile TYPE: ty = 1 tiles of 33..64 rows (two 32-row MFMA tiles per wave and step), ty = 0 tiles of
     // <= 32 rows (one).  Each type runs in its own launch of a kernel instantiated for that type only.  A single kernel
     // that picks the variant per step looks equivalent but compiles badly: at every join of the two variants the register
     // allocator reconciles the in-flight A/B registers and the accumulators with v_mov behind s_waitcnt vmcnt(0) / the
     // MFMA drain, which collapses the 3-step prefetch (measured: 72 non-MFMA VALU per step, 69 % of the matrix peak).
-    std::vector<StepRec> steps[2];
-    std::vector<int32_t> wrange[2];
-    std::vector<FixRec> fix;
-    std::vector<int32_t> fix_slots;
-    int n_workers = 0, n_split = 0;
-    int plan_aligned[2] = {0, 0};
     // k depth of a step: 32 for fp32; the 16-bit kernels take 64 when the block width allows (their steps are short: fewer, fatter)
     const int64_t kp = !h16 ? SK_KP : (w % 64 == 0 ? 64 : 32);
-    std::vector<uint16_t> a16;               // 16-bit handles: A re-laid-out as dense row-major TM x kp slices, one per step
+    P.kp = kp;
     if (w % SK_KP == 0) {
         hipDeviceProp_t prop;
         int cus = 256;
@@ -1586,6 +1493,144 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
             }
         }
     }
+
+    return SPARTA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sparta_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
+                            const int64_t* nzcount, const int64_t* jab, const float* mab, int64_t br0, int64_t br1, int32_t dtype,
+                            int32_t device) {
+    using sparta::fail;
+    if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: out is NULL");
+    *out = nullptr;
+    if (rows <= 0 || cols <= 0 || block_rows <= 0 || w <= 0 || !row_part || !nzcount)
+        return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad dimensions or NULL index array");
+    if (br0 < 0 || br1 > block_rows || br0 >= br1) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad block-row range");
+    if (dtype != SPARTA_F32 && dtype != SPARTA_F16 && dtype != SPARTA_BF16) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad dtype");
+    const bool h16 = dtype != SPARTA_F32;
+    if (h16 && w % 32 != 0)
+        return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: SPARTA_F16 / SPARTA_BF16 need block_col_size % 32 == 0 (only the stream kernels have a 16-bit form)");
+    if (rows > INT32_MAX || w > (1 << 20)) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: rows >= 2^31 or w > 2^20");
+    const int64_t block_cols = (cols - 1) / w + 1;
+
+    // validate the partition and locate the range inside jab / mab
+    if (row_part[0] != 0 || row_part[block_rows] != rows) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: row_part must span [0, rows]");
+    int64_t jab_lo = 0, mab_lo = 0, jab_hi = 0, mab_hi = 0, jo = 0, mo = 0;
+    for (int64_t ib = 0; ib < block_rows; ib++) {
+        const int64_t h = row_part[ib + 1] - row_part[ib];
+        if (h < 0 || nzcount[ib] < 0 || nzcount[ib] > block_cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: invalid row_part / nzcount");
+        if (h > INT32_MAX / 2 || nzcount[ib] > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: block-row too large");
+        if (ib == br0) { jab_lo = jo; mab_lo = mo; }
+        jo += nzcount[ib];
+        mo += nzcount[ib] * h * w;
+        if (ib == br1 - 1) { jab_hi = jo; mab_hi = mo; }
+    }
+    const int64_t nblocks = jab_hi - jab_lo, nztot = mab_hi - mab_lo;
+    if (nblocks > 0 && (!jab || !mab)) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: jab / mab is NULL");
+
+    int ndev = sparta_device_count();
+    if (ndev <= 0) return fail(SPARTA_ERR_NO_DEVICE, "sparta_vbs_create: no HIP device visible (this path has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: device index out of range");
+
+    // ---- plan: row tiles per class -----------------------------------------------------------------
+    std::vector<TileDesc> tiles[4];
+    std::vector<BlockRowDesc> brows;
+    std::vector<int32_t> jab32((size_t)std::max<int64_t>(nblocks, 1));
+    for (int64_t q = 0; q < nblocks; q++) {
+        const int64_t jb = jab[jab_lo + q];
+        if (jb < 0 || jb >= block_cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: jab entry out of range");
+        jab32[(size_t)q] = (int32_t)jb;
+    }
+    int64_t exec_area = 0;
+    {
+        int64_t jo2 = 0, mo2 = 0;
+        const int64_t row0 = row_part[br0];
+        for (int64_t ib = br0; ib < br1; ib++) {
+            const int64_t h = row_part[ib + 1] - row_part[ib];
+            const int64_t nb = nzcount[ib];
+            if (h > 0) {
+                BlockRowDesc br{mo2, jo2, (int32_t)nb, (int32_t)h, (int32_t)(row_part[ib] - row0), 0};
+                brows.push_back(br);
+                int64_t r0 = 0;
+                while (r0 < h) {
+                    const int64_t rem = h - r0;
+                    int cls;
+                    int64_t mt;
+                    if (rem > 32) { cls = 2; mt = std::min<int64_t>(rem, 64); }
+                    else if (rem > 16) { cls = 1; mt = rem; }
+                    else { cls = 0; mt = rem; }
+                    const bool tail = (cols % w != 0) && nb > 0 && jab[jab_lo + jo2 + nb - 1] == block_cols - 1;
+                    TileDesc t{mo2 + r0, jo2, (int32_t)nb, (int32_t)h, (int32_t)(row_part[ib] - row0 + r0),
+                               (int32_t)mt | (tail ? TILE_TAIL : 0)};
+                    tiles[cls].push_back(t);
+                    const int64_t padded = cls == 0 ? 16 : ((mt + 31) / 32) * 32;
+                    exec_area += padded * w * nb;
+                    r0 += mt;
+                }
+            }
+            jo2 += nb;
+            mo2 += nb * h * w;
+        }
+    }
+
+    // ---- schedule: per class, 8 contiguous chunks of ~equal cost (one per XCD: neighbouring block-rows gather the
+    // same B panels, so they should share an L2), each chunk sorted by descending cost (the hardware hands workgroups
+    // to free slots in blockIdx order => longest-processing-time-first per XCD), interleaved so that entry t is XCD
+    // t % 8's (t / 8)-th item; short chunks are padded with empty tiles (nb = 0, mt = 0: nothing loaded or stored).
+    int64_t n_real[4];
+    for (int c = 0; c < 4; c++) n_real[c] = (int64_t)tiles[c].size();
+    {
+        const char* ord = std::getenv("SPARTA_TILE_ORDER");
+        const bool natural = ord && std::strcmp(ord, "natural") == 0;
+        for (int c = 0; c < 4; c++) {
+            std::vector<TileDesc>& L = tiles[c];
+            if (L.empty()) continue;
+            const int64_t rows_pad = c == 0 ? 16 : (c == 1 ? 32 : 64);
+            auto cost = [&](const TileDesc& t) { return (int64_t)t.nb * rows_pad + rows_pad / 4; };
+            int64_t total = 0;
+            for (const TileDesc& t : L) total += cost(t);
+            std::vector<std::vector<TileDesc>> chunk(8);
+            int64_t acc_cost = 0;
+            for (const TileDesc& t : L) {
+                int x = (int)std::min<int64_t>(7, (acc_cost * 8) / std::max<int64_t>(total, 1));
+                chunk[(size_t)x].push_back(t);
+                acc_cost += cost(t);
+            }
+            size_t maxlen = 0;
+            for (auto& ch : chunk) {
+                if (!natural) std::stable_sort(ch.begin(), ch.end(), [&](const TileDesc& a, const TileDesc& b) { return cost(a) > cost(b); });
+                maxlen = std::max(maxlen, ch.size());
+            }
+            std::vector<TileDesc> arranged(maxlen * 8, TileDesc{0, 0, 0, 1, 0, 0});
+            for (size_t x = 0; x < 8; x++)
+                for (size_t j = 0; j < chunk[x].size(); j++) arranged[j * 8 + x] = chunk[x][j];
+            L.swap(arranged);
+        }
+    }
+
+    // ---- stream plans (persistent kernels): see build_stream_plans ----
+    StreamPlanHost plan;
+    {
+        StreamPlanIn pin{cols, w, br0, br1, jab_lo, mab_lo, row_part, nzcount, jab, mab, dtype, device};
+        if (int rc = build_stream_plans(pin, plan)) return rc;
+    }
+    std::vector<StepRec>(&steps)[2] = plan.steps;
+    std::vector<int32_t>(&wrange)[2] = plan.wrange;
+    std::vector<FixRec>& fix = plan.fix;
+    std::vector<int32_t>& fix_slots = plan.fix_slots;
+    std::vector<uint16_t>& a16 = plan.a16;
+    const int n_workers = plan.n_workers, n_split = plan.n_split;
+    const int64_t kp = plan.kp;
 
     sparta_vbs* v = new (std::nothrow) sparta_vbs;
     if (!v) return fail(SPARTA_ERR_ALLOC, "sparta_vbs_create: out of host memory");
