@@ -15,6 +15,7 @@
 // Behaviours that define parity are called out inline with the reference line they mirror.
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <numeric>
 #include <random>
@@ -156,14 +157,67 @@ struct CtxBase {
 
 // FAST policy -- valid when every row's columns are strictly ascending (the normal case): rows and the
 // cluster pattern are compared as lists of distinct column-block ids, the merge uses the closed form above.
+//
+// Candidate filter (exact).  Most (pattern, row) pairs of a large sparse matrix share no column block at all; their distance
+// is a closed form of the sizes (inter = 0) and needs no walk over the two lists.  An inverted index block -> rows tells
+// which rows CAN intersect the pattern: when a seed opens a cluster, and whenever a merge brings new blocks into the
+// pattern, the rows of those blocks' lists are stamped; an unstamped row has inter = 0 by construction.  A stamped row may
+// still have inter = 0 (the lossy merge can drop blocks again): it simply takes the full computation.  Same distances, same
+// decisions, same counters as before -- only the walk is skipped.  Stamping a block costs its list length, so a seed whose
+// blocks' lists add up to more than half of the matrix switches the filter off for its cluster (dense columns).
 struct Ctx : CtxBase {
     RowBlocks rb;
     Pattern pat;
-    Ctx(const CsrView& a_, const sparta_reorder_cfg& c) : CtxBase(a_, c) { rb = build_row_blocks(a, w); }
-    inline void assign(int64_t i) { pat.assign(a.row(i), a.nnz_of(i), w); }
-    inline void merge(int64_t j) { pat.merge(a.row(j), a.nnz_of(j), w); }
+    std::vector<int64_t> inv_ptr;            // block -> rows that contain it (ascending)
+    std::vector<int32_t> inv_row;
+    std::vector<int64_t> row_stamp, blk_stamp;
+    int64_t stamp = 0;
+    bool filter_on = false, have_index = false, force_filter = false;
+    Ctx(const CsrView& a_, const sparta_reorder_cfg& c) : CtxBase(a_, c) {
+        rb = build_row_blocks(a, w);
+        const char* e = std::getenv("SPARTA_REORDER_FILTER");             // 0: off, 1: on for every input, unset: on from 2048 rows
+        if (e && e[0] == '0') return;
+        if (a.rows > INT32_MAX || a.cols <= 0) return;
+        force_filter = e && e[0] == '1';
+        if (!(e && e[0] == '1') && a.rows < 2048) return;                      // small inputs: the index costs more than it saves
+        const int64_t nblk = (a.cols - 1) / w + 1;
+        inv_ptr.assign((size_t)nblk + 1, 0);
+        for (int32_t b : rb.idx) inv_ptr[(size_t)b + 1]++;
+        for (int64_t b = 0; b < nblk; b++) inv_ptr[(size_t)b + 1] += inv_ptr[(size_t)b];
+        inv_row.resize(rb.idx.size());
+        std::vector<int64_t> fill(inv_ptr.begin(), inv_ptr.end() - 1);
+        for (int64_t i = 0; i < a.rows; i++)
+            for (int64_t k = rb.ptr[(size_t)i]; k < rb.ptr[(size_t)i + 1]; k++) inv_row[(size_t)fill[(size_t)rb.idx[(size_t)k]]++] = (int32_t)i;
+        row_stamp.assign((size_t)a.rows, 0);
+        blk_stamp.assign((size_t)nblk, 0);
+        have_index = true;
+    }
+    inline void stamp_new_blocks() {
+        for (int32_t b : pat.blks) {
+            if (blk_stamp[(size_t)b] == stamp) continue;
+            blk_stamp[(size_t)b] = stamp;
+            for (int64_t k = inv_ptr[(size_t)b]; k < inv_ptr[(size_t)b + 1]; k++) row_stamp[(size_t)inv_row[(size_t)k]] = stamp;
+        }
+    }
+    inline void assign(int64_t i) {
+        pat.assign(a.row(i), a.nnz_of(i), w);
+        filter_on = false;
+        if (!have_index) return;
+        int64_t work = 0;
+        for (int32_t b : pat.blks) work += inv_ptr[(size_t)b + 1] - inv_ptr[(size_t)b];
+        if (work > a.rows / 2 && !force_filter) return;
+        stamp++;
+        filter_on = true;
+        stamp_new_blocks();
+    }
+    inline void merge(int64_t j) {
+        pat.merge(a.row(j), a.nnz_of(j), w);
+        if (filter_on) stamp_new_blocks();
+    }
     inline float dist(int64_t gsize, int64_t j) const {
-        int64_t inter = intersect_count(pat.blks.data(), (int64_t)pat.blks.size(), rb.row(j), rb.n(j));
+        const int64_t inter = (filter_on && row_stamp[(size_t)j] != stamp)
+                                  ? 0
+                                  : intersect_count(pat.blks.data(), (int64_t)pat.blks.size(), rb.row(j), rb.n(j));
         return distance_from_counts(sim, (int64_t)pat.cols.size(), (int64_t)pat.blks.size(), gsize, a.nnz_of(j), rb.n(j), 1, inter);
     }
 };

@@ -97,3 +97,28 @@ def test_structured_mn_blocking_matches_the_reference(name, k):
     go, co = O.get_grouping(m.rows, m.rowptr, m.colidx, 1, cfg.get("sim", 1), cfg["tau"], cfg["w"], cfg.get("rbs", 1),
                             cfg.get("use_groups", False), cfg.get("use_pattern", True), cfg.get("ff", False), cfg["m"], cfg["n"])
     assert np.array_equal(go, want) and [co["comparison_counter"], co["merge_counter"]] == list(cnt)
+
+
+@pytest.mark.parametrize("algo", [0, 1, 3, 4, 5])
+def test_candidate_filter_is_exact(monkeypatch, algo):
+    """The inverted-index candidate filter of the reorder engine only skips list walks whose outcome is known (no common
+    block): groupings and counters are identical with the filter forced on, forced off, and left to its size threshold."""
+    outs = []
+    for mode in ("0", "1", None):
+        if mode is None:
+            monkeypatch.delenv("SPARTA_REORDER_FILTER", raising=False)
+        else:
+            monkeypatch.setenv("SPARTA_REORDER_FILTER", mode)
+        res = []
+        for m, w, tau in ((sa.gen.uniform_random(5000, 7000, 30000, seed=41), 16, 0.7), (sa.gen.rmat(12, 40000, seed=42, pattern_only=True), 8, 0.5),
+                          (sa.gen.banded(3000, 9, 0.5, seed=43), 4, 0.4)):
+            for sim in (1, 0):
+                e = sa.BlockingEngine(tau=tau if sim else 6.0, col_block_size=w, row_block_size=24, blocking_algo=algo, sim_measure=sim,
+                                      use_groups=bool(algo == 3))
+                g = e.GetGrouping(m)
+                res.append((g.copy(), e.comparison_counter, e.merge_counter, np.float32(e.average_merge_tau).tobytes(),
+                            np.float32(e.average_row_distance).tobytes()))
+        outs.append(res)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
