@@ -20,6 +20,8 @@
 #include <numeric>
 #include <random>
 #include <set>
+#include <type_traits>
+#include <functional>
 #include <utility>
 
 #include "host_core.hpp"
@@ -350,6 +352,148 @@ void clocked(C& c, int64_t* grouping) {
     }
 }
 
+// Algorithms 3 / 4 in near-linear time, exactly -- for the reference's DEFAULT setting (Jaccard, use_groups = 0) and tau < 1.
+//
+// With cluster weight 1 the Jaccard distance of a pattern and a row that share no block is exactly 1.0f (2c / 2c), so such
+// a row is never merged (tau < 1) and the only thing the scan does to it is maintain `distances[j]`:
+//        pruned  (d_i != -1 and d_j != -1 and |d_i - d_j| > tau)  ->  d_j = -1, no comparison counted
+//        else                                                     ->  d_j = 1.0, one comparison counted
+// After its first such visit a row's entry is -1 or 1.0, and one seed applies ONE of two maps to all of them at once:
+//        g ("nothing with 1.0 is pruned"):  -1 -> 1.0,  1.0 -> 1.0            h ("1.0 is pruned"):  -1 -> 1.0,  1.0 -> -1
+// (an entry of -1 is never pruned).  So rows are kept in two classes with counters, a row remembers the seed ordinal at which
+// it was last touched individually and its class then, and its current class is that class pushed through the g / h sequence
+// since -- O(1) with a prefix count of h and the position of the last g.  Per seed, only these rows are handled one by one, in
+// ascending order as the reference's scan would meet them (a heap):
+//   * CANDIDATES: rows that share a block with the pattern (inverted index; rows of blocks that a merge brings in join the
+//     heap on the fly; an empty seed's candidates are the empty rows): exact prune test, exact distance, exact merge;
+//   * rows whose entry is still an individual value (the seed's previous candidates that were compared but not merged;
+//     initially every row, with the VLA's 0): the prune rule applied to that value, after which they join a class.
+// Everything else is two counter updates.  Same grouping, same counters, same float accumulators (only merges add to them,
+// and those happen in the same order) as clocked() -- checked against it and against the reference in the tests.
+void clocked_sparse(Ctx& c, int64_t* grouping) {
+    const CsrView& a = c.a;
+    const int64_t rows = a.rows;
+    const float tau = c.cfg.tau;
+    enum : uint8_t { NEG = 0, ONE = 1, IND = 2 };
+    std::fill(grouping, grouping + rows, (int64_t)-1);
+    std::vector<uint8_t> cls((size_t)rows, IND);
+    std::vector<float> val((size_t)rows, 0.0f);
+    std::vector<int32_t> touched((size_t)rows, -1);            // seed ordinal of the last individual handling
+    if (rows > 0) val[0] = -1.0f;                                // `float distances[rows] = {-1}`: element 0 is -1, the rest 0
+    std::vector<int64_t> fresh, next_fresh;                      // alive rows whose entry is an individual value
+    fresh.reserve((size_t)rows);
+    for (int64_t j = 0; j < rows; j++) fresh.push_back(j);
+    std::vector<int32_t> hpre;                                   // hpre[s] = number of h maps among seeds 0..s
+    std::vector<int32_t> lastg;                                  // lastg[s] = last seed <= s whose map is g, or -1
+    int64_t cnt[2] = {0, 0};
+    std::vector<int64_t> empties;                                // rows without nonzeros, ascending
+    for (int64_t j = 0; j < rows; j++) if (a.nnz_of(j) == 0) empties.push_back(j);
+    auto current_class = [&](int64_t j, int32_t upto) -> uint8_t {   // class of a stable row after seeds 0..upto
+        const int32_t t = touched[(size_t)j];
+        const uint8_t k = cls[(size_t)j];
+        if (upto <= t) return k;
+        const int32_t L = lastg[(size_t)upto];
+        if (L > t) return ((hpre[(size_t)upto] - hpre[(size_t)L]) & 1) ? NEG : ONE;
+        return ((hpre[(size_t)upto] - hpre[(size_t)t]) & 1) ? (uint8_t)(1 - k) : k;
+    };
+    // heap of rows to handle individually in this seed: (row, is_candidate)
+    std::vector<int64_t> heap;
+    auto heap_push = [&](int64_t j) { heap.push_back(j); std::push_heap(heap.begin(), heap.end(), std::greater<int64_t>()); };
+    auto heap_pop = [&]() { std::pop_heap(heap.begin(), heap.end(), std::greater<int64_t>()); const int64_t j = heap.back(); heap.pop_back(); return j; };
+    std::vector<int64_t> queued((size_t)rows, -1);               // seed ordinal at which the row was last put on the heap
+    int64_t seed_row = 0;
+    int32_t s = 0;
+    while (true) {
+        while (seed_row < rows && grouping[seed_row] != -1) seed_row++;
+        if (seed_row >= rows) break;
+        const int64_t i = seed_row;
+        // the seed's own entry
+        float di;
+        if (cls[(size_t)i] == IND) di = val[(size_t)i];
+        else { const uint8_t k = current_class(i, s - 1); di = k == NEG ? -1.0f : 1.0f; cnt[k]--; }
+        grouping[i] = i;
+        auto t0 = clk::now();
+        // candidates: rows of the pattern's blocks (ascending lists), or the empty rows for an empty seed
+        c.pat.assign(a.row(i), a.nnz_of(i), c.w);
+        c.stamp++;
+        heap.clear();
+        auto enqueue_block_rows = [&](int64_t after) {
+            for (int32_t b : c.pat.blks) {
+                if (c.blk_stamp[(size_t)b] == c.stamp) continue;
+                c.blk_stamp[(size_t)b] = c.stamp;
+                const int32_t* lo = c.inv_row.data() + c.inv_ptr[(size_t)b];
+                const int32_t* hi = c.inv_row.data() + c.inv_ptr[(size_t)b + 1];
+                for (const int32_t* q = std::upper_bound(lo, hi, (int32_t)after); q < hi; q++) {
+                    const int64_t j = *q;
+                    c.row_stamp[(size_t)j] = c.stamp;
+                    if (grouping[j] == -1 && queued[(size_t)j] != s) { queued[(size_t)j] = s; heap_push(j); }
+                }
+            }
+        };
+        enqueue_block_rows(i);
+        if (a.nnz_of(i) == 0) {
+            for (auto q = std::upper_bound(empties.begin(), empties.end(), i); q != empties.end(); ++q) {
+                const int64_t j = *q;
+                c.row_stamp[(size_t)j] = c.stamp;
+                if (grouping[j] == -1 && queued[(size_t)j] != s) { queued[(size_t)j] = s; heap_push(j); }
+            }
+        }
+        for (int64_t j : fresh)
+            if (j != i && grouping[j] == -1 && queued[(size_t)j] != s) { queued[(size_t)j] = s; heap_push(j); }
+        next_fresh.clear();
+        // the bulk map of this seed
+        const bool h_map = di != -1.0f && std::fabs(di - 1.0f) > tau;
+        int64_t joined[2] = {0, 0};                              // rows that become stable in this seed, by class
+        while (!heap.empty()) {
+            const int64_t j = heap_pop();
+            if (grouping[j] != -1) continue;
+            // entry of row j as the scan finds it
+            float dj;
+            if (cls[(size_t)j] == IND) dj = val[(size_t)j];
+            else { const uint8_t k = current_class(j, s - 1); dj = k == NEG ? -1.0f : 1.0f; cnt[k]--; }
+            const bool pruned = di != -1.0f && dj != -1.0f && std::fabs(di - dj) > tau;      // blocking.cpp:192-196
+            if (pruned) {
+                cls[(size_t)j] = NEG; touched[(size_t)j] = s; joined[NEG]++;
+                continue;
+            }
+            c.comparisons++;
+            float d;
+            if (c.row_stamp[(size_t)j] == c.stamp) {
+                const int64_t inter = intersect_count(c.pat.blks.data(), (int64_t)c.pat.blks.size(), c.rb.row(j), c.rb.n(j));
+                d = distance_from_counts(c.sim, (int64_t)c.pat.cols.size(), (int64_t)c.pat.blks.size(), 1, a.nnz_of(j), c.rb.n(j), 1, inter);
+            } else {
+                d = 1.0f;                                        // no common block: 2c / 2c (an empty row against a non-empty pattern: :927)
+            }
+            if (d <= tau) {                                      // :207
+                c.total_merge_tau += d;
+                c.total_row_distance += (float)(j - i);
+                c.merges++;
+                grouping[j] = i;
+                if (c.cfg.use_pattern) {
+                    auto tm = clk::now();
+                    c.pat.merge(a.row(j), a.nnz_of(j), c.w);
+                    enqueue_block_rows(j);
+                    c.t_merge += us_since(tm);
+                }
+            } else if (d == 1.0f) {
+                cls[(size_t)j] = ONE; touched[(size_t)j] = s; joined[ONE]++;
+            } else {
+                cls[(size_t)j] = IND; val[(size_t)j] = d; next_fresh.push_back(j);
+            }
+        }
+        // every other alive row: one of the two maps
+        if (h_map) { c.comparisons += cnt[NEG]; std::swap(cnt[NEG], cnt[ONE]); }
+        else { c.comparisons += cnt[NEG] + cnt[ONE]; cnt[ONE] += cnt[NEG]; cnt[NEG] = 0; }
+        cnt[NEG] += joined[NEG];
+        cnt[ONE] += joined[ONE];
+        hpre.push_back((hpre.empty() ? 0 : hpre.back()) + (h_map ? 1 : 0));
+        lastg.push_back(h_map ? (lastg.empty() ? -1 : lastg.back()) : s);
+        fresh.swap(next_fresh);
+        c.t_cmp += us_since(t0);
+        s++;
+    }
+}
+
 // Algorithm 0 (IterativeBlockingPattern, blocking.cpp:89-154): no prune, strict `<`, and -- because the
 // `if (use_pattern)` there guards only a timer macro -- the pattern merge ALWAYS runs (:128-132).
 template <class C>
@@ -599,12 +743,21 @@ int reorder(const CsrView& a, const sparta_reorder_cfg& cfg, int64_t* grouping_o
     auto t0 = clk::now();
     sparta_reorder_stats st{};
     const bool fast = iterative && all_rows_strictly_ascending(a);
+    // algorithms 3 / 4: the near-linear exact form where it applies (Jaccard, weight 1, tau < 1, ascending rows, index built)
+    auto run_clocked = [&](auto& c, int64_t* g) {
+        if constexpr (std::is_same<std::decay_t<decltype(c)>, Ctx>::value) {
+            const char* e = std::getenv("SPARTA_REORDER_SCALABLE");          // 0: never, 1: whenever it applies, unset: from 2048 rows
+            const bool applies = c.have_index && c.sim == SPARTA_SIM_JACCARD && !cfg.use_groups && cfg.tau < 1.0f && a.rows <= INT32_MAX;
+            if (applies && !(e && e[0] == '0')) { clocked_sparse(c, g); return; }
+        }
+        clocked(c, g);
+    };
     auto run = [&](auto& c) {
         switch (cfg.blocking_algo) {
             case SPARTA_BLOCKING_ITERATIVE_MAX_SIZE: keeper(c, grouping_out); break;
             case SPARTA_BLOCKING_ITERATIVE: plain(c, grouping_out); break;
             case SPARTA_BLOCKING_ITERATIVE_STRUCTURED: structured_mn(c, grouping_out); break;
-            default: clocked(c, grouping_out); break;
+            default: run_clocked(c, grouping_out); break;
         }
         st.comparison_counter = c.comparisons; st.merge_counter = c.merges;
         if (cfg.blocking_algo != SPARTA_BLOCKING_ITERATIVE && cfg.blocking_algo != SPARTA_BLOCKING_ITERATIVE_STRUCTURED) {

@@ -122,3 +122,34 @@ def test_candidate_filter_is_exact(monkeypatch, algo):
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+
+
+@pytest.mark.parametrize("algo", [3, 4])
+def test_near_linear_clocked_form_is_exact(monkeypatch, algo):
+    """clocked_sparse (two-class bookkeeping of distances[] + a heap of candidate rows) against the plain scan: same grouping,
+    counters and float statistics, with and without pattern merging, with empty and duplicate rows, for tau from 0 to just below 1."""
+    monkeypatch.setenv("SPARTA_REORDER_FILTER", "1")          # build the index for small inputs too
+    rng = np.random.Generator(np.random.PCG64(17 + algo))
+    for case in range(60):
+        rows, cols = int(rng.integers(1, 500)), int(rng.integers(1, 400))
+        m = sa.gen.uniform_random(rows, cols, int(rows * cols * float(rng.choice([0.003, 0.02, 0.1]))), seed=int(rng.integers(1 << 30)))
+        if case % 3 == 0 and rows > 8:                          # knock out a quarter of the rows, repeat some others
+            cnt = np.diff(m.rowptr)
+            cnt[rng.integers(0, rows, rows // 4)] = 0
+            src = rng.integers(0, rows, rows // 6)
+            rp, ci = [0], []
+            for r in range(rows):
+                rr = int(src[r % len(src)]) if (r % 7 == 3 and len(src)) else r
+                ci.extend(m.colidx[m.rowptr[rr]:m.rowptr[rr] + cnt[rr]].tolist())
+                rp.append(len(ci))
+            m = sa.CSR(rows, cols, rp, np.array(ci, np.int32), None)
+        w, tau = int(rng.choice([1, 3, 8, 32])), float(rng.choice([0.0, 0.2, 0.5, 0.8, 0.99]))
+        up = bool(rng.integers(0, 2))
+        res = []
+        for mode in ("0", "1"):
+            monkeypatch.setenv("SPARTA_REORDER_SCALABLE", mode)
+            e = sa.BlockingEngine(tau=tau, col_block_size=w, use_pattern=up, blocking_algo=algo)
+            g = e.GetGrouping(m)
+            res.append((g.tobytes(), e.comparison_counter, e.merge_counter, np.float32(e.average_merge_tau).tobytes(),
+                        np.float32(e.average_row_distance).tobytes()))
+        assert res[0] == res[1], (case, rows, cols, w, tau, up)
