@@ -12,7 +12,11 @@ A "step" is one pass of the hot path over one batch of synthetic input: C = A_vb
   N = 1  : BASELINE.json configs[1] -- SuiteSparse `cant` shape (62 451^2, 3-dof FEM, ~4.3 M nnz; generated, there is no
            network), B = 128 dense columns, fp32, reference layouts (B, C column-major).
   N > 1  : weak scaling of the same workload: the mesh grows N x along z, rank r owns row slab r of A and the matching
-           row shard of B; each step = ONE all-gather of B over RCCL/xGMI + the local SpMM; no collective on C.
+           row shard of B; each step = ONE collective on B over RCCL/xGMI + the local SpMM; no collective on C.
+           --exchange allgather : B replicated by one all-gather (what a slab that touches all of B needs);
+           --exchange blocks    : one all-to-all of only the row-blocks of B each slab touches (plan-time lists), overlapped
+                                  with the product against the rank's own shard (sparta_amd/dist.py: RowBlockExchange);
+           --exchange auto      : blocks when the slabs need < 50 % of the other shards, else allgather (default).
 
 value = useful GFLOP/s of the whole job = 2 * nnz * n_cols * n_gpus_units / time (dense-block padding is NOT counted).
 The JSON line also carries the roofline of the dominant kernel and a CPU baseline (the reference's own
@@ -62,6 +66,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the steps from a captured HIP graph (measured: no gain -- the step is one 60 us kernel and eager launches already queue ahead)")
+    ap.add_argument("--exchange", choices=["auto", "allgather", "blocks"], default="auto",
+                    help="N > 1: how the ranks' shards of B reach the slabs (see the module docstring)")
     ap.add_argument("--dist-path", action="store_true", help="run the multi-GPU code path (slab + all-gather + gathered SpMM) even with one rank")
     args = ap.parse_args()
 
@@ -129,9 +135,41 @@ def main():
         B_gath = torch.empty(world * shard_rows * N, dtype=torch.float32, device=dev)
     C = torch.zeros(vb.rows * N, dtype=torch.float32, device=dev)
 
+    # ---- N > 1: which exchange ------------------------------------------------------------------------------------
+    ex, exchange, exchange_note, B_tiles = None, None, "", None
+    if distributed:
+        dist.all_gather_into_tensor(B_gath, B_shard)              # setup: reference result for the self-check, B for the CPU baseline
+        exchange = args.exchange
+        if exchange != "allgather":
+            # the same shard in the row-block-tiled layout (block jb = one contiguous w x N column-major tile)
+            B_tiles = B_shard.view(N, shard_rows // w, w).permute(1, 0, 2).contiguous().view(-1)
+            ex = sa.dist.RowBlockExchange(vb, rank, world, shard_rows, N, device=local_rank)      # collective: need lists
+            if exchange == "auto":
+                exchange = "blocks" if ex.needed_fraction < 0.5 else "allgather"
+        if exchange == "blocks":
+            # self-check on the real collective: both exchanges must give the same C (two partial sums vs one: fp32 re-association)
+            d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False)
+            C_chk = torch.empty_like(C)
+            ex.step(B_tiles, C_chk)
+            torch.cuda.synchronize()
+            err = float((C_chk - C).abs().max() / C.abs().max().clamp_min(1e-30))
+            ok = torch.tensor([1.0 if err < 1e-4 else 0.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                print("rank %d: row-block exchange self-check FAILED (max rel err %.3e): using the all-gather" % (rank, err), file=sys.stderr)
+                exchange, exchange_note = "allgather", " (row-block exchange failed its self-check)"
+            del C_chk
+        if exchange == "allgather" and ex is not None:
+            ex.close()
+            ex = None
+    dmain, vbm = (ex.d_own, ex.own) if ex is not None else (d, vb)      # the handle / matrix whose kernel dominates a step
+    info = dmain.info()
+
     def step():
         if not distributed:
             d.spmm(B, C, N, accumulate=False, ldb=ldb)
+        elif ex is not None:
+            ex.step(B_tiles, C)                                    # pack + ONE all-to-all of the needed row-blocks || own product; + remote product
         else:
             dist.all_gather_into_tensor(B_gath, B_shard)          # the one exchange step (RCCL over xGMI)
             d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False)
@@ -181,16 +219,16 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- per-kernel device time (HIP events on the launch stream, one pair per kernel launch) ----------------------
-    d.set_class_timing(True)
+    dmain.set_class_timing(True)
     kt, kc = {}, {}
     for _ in range(min(args.steps, 50)):
         step()
-        for k, v in d.class_times().items():
+        for k, v in dmain.class_times().items():
             kt.setdefault(k, []).append(v)
-        for k, v in d.clock_mhz().items():        # s_memtime / s_memrealtime over the kernel: the clock the pipes really ran at
+        for k, v in dmain.clock_mhz().items():    # s_memtime / s_memrealtime over the kernel: the clock the pipes really ran at
             if v > 0:
                 kc.setdefault(k, []).append(v)
-    d.set_class_timing(False)
+    dmain.set_class_timing(False)
     kernel_ms = {k: float(np.mean(v)) for k, v in kt.items()}
     kernel_mhz = {k: float(np.mean(v)) for k, v in kc.items()}
     # A step that is ONE kernel launch (aligned stream plan, one tile type): time a run of launches with one event pair on the
@@ -208,7 +246,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         kernel_ms[live[0]] = e0.elapsed_time(e1) / reps
-    path = {1: "stream", 2: "class", 3: "generic"}.get(d.info()["last_path"], "?")
+    path = {1: "stream", 2: "class", 3: "generic"}.get(dmain.info()["last_path"], "?")
 
     nnz_local = m.nztot()
     nnz_total = nnz_local
@@ -225,17 +263,18 @@ def main():
 
     # ---- roofline of the dominant kernel (rank 0's launch) ------------------------------------------------------
     h = np.diff(vb.row_part)
+    flops_exec_full = 2.0 * float(vb.nztot) * N
     # stored area handled by each kernel: the stream kernel takes everything; the per-class kernels take the tiles of
     # their height class (block-rows are cut into <=64-row tiles; a remainder <=32 / <=16 rows goes to the thinner class)
-    area = {"stream": float(vb.nztot), "fixup": 0.0, "class16": 0.0, "class32": 0.0, "class64": 0.0}
-    for hh, nb in zip(h, vb.nzcount):
+    area = {"stream": float(vbm.nztot), "fixup": 0.0, "class16": 0.0, "class32": 0.0, "class64": 0.0}
+    for hh, nb in zip(h, vbm.nzcount):
         r = int(hh)
         while r > 0:
             mt = min(r, 64) if r > 32 else r
             c = "class64" if r > 32 else ("class32" if r > 16 else "class16")
             area[c] += float(mt) * w * float(nb)
             r -= mt
-    t_lb, flops_exec, bytes_alg = mixed_roofline_seconds(vb.row_part, vb.nzcount, w, N, vb.cols)
+    t_lb, flops_exec, bytes_alg = mixed_roofline_seconds(vbm.row_part, vbm.nzcount, w, N, vbm.cols)
     kernel_ms_total = sum(kernel_ms.values())
     dom = max(kernel_ms, key=lambda k: kernel_ms[k]) if kernel_ms else "stream"
     dom_tflops = 2.0 * area.get(dom, 0.0) * N / (kernel_ms[dom] * 1e-3) / 1e12 if kernel_ms.get(dom, 0) > 0 else 0.0
@@ -326,8 +365,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {
             "workload": ("cant-like FEM 9x9x257 mesh x 3 dof (62451^2, %d nnz), B = %d cols, fp32" % (nnz_local, N)) if not distributed else
-                        ("row-partitioned FEM 9x9x%d mesh x 3 dof (%d^2 padded, %d nnz), B = %d cols, fp32, 1 all-gather of B per step"
-                         % (257 * world, world * shard_rows, int(nnz_total), N)),
+                        ("row-partitioned FEM 9x9x%d mesh x 3 dof (%d^2 padded, %d nnz), B = %d cols, fp32, %s per step"
+                         % (257 * world, world * shard_rows, int(nnz_total), N,
+                            "1 all-gather of B" if ex is None else "1 all-to-all of the needed row-blocks of B")),
             "reorder": ("fixed height %d (reorder off)" % args.fixed_height) if args.fixed_height else
                        ("Jaccard %s tau=%.2f row_block=%d force_fixed=%d (reference flags -a %d -t %.2f -B %d -F %d -b %d)"
                         % ({3: "iterative_clocked", 5: "iterative_max_size/Keeper"}.get(args.algo, str(args.algo)), args.tau, args.row_block,
@@ -336,9 +376,12 @@ def main():
             "vbs_area": int(vb.nztot), "fill": round(nnz_local / max(vb.nztot, 1), 4),
             "mean_block_row_height": round(float(h.mean()), 2),
             "tiles": {"16": info["tiles16"], "32": info["tiles32"], "64": info["tiles64"]}, "kernel_path": path,
-            "executed_gflops": round(flops_exec * world / (ms_per_step * 1e-3) / 1e9, 1),
+            "executed_gflops": round(flops_exec_full * world / (ms_per_step * 1e-3) / 1e9, 1),
             "host_seconds": {"generate": round(t_gen, 2), "reorder": round(t_reorder, 2), "vbs_build": round(t_build, 2)},
-            "parallelism": "row-partition x%d, B all-gather" % world if distributed else "single GPU",
+            "parallelism": ("single GPU" if not distributed else
+                            ("row-partition x%d, B all-gather%s" % (world, exchange_note)) if ex is None else
+                            ("row-partition x%d, B row-block all-to-all (%d blocks sent / %d received by rank 0 per step = %.2f %% of the "
+                             "all-gather's traffic), own-shard product overlapped" % (world, ex.n_send, ex.n_recv, 100.0 * ex.needed_fraction))),
             "launch": ("HIP graph of %d steps, replayed %d times" % (G, args.steps // G)) if graph is not None else "eager",
         },
         "roofline": roofline,

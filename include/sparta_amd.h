@@ -262,6 +262,15 @@ int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layou
 int sparta_vbs_spmm_gathered(sparta_vbs_t* A, const void* B_gathered, int64_t shard_rows, int64_t shard_stride, int32_t n_cols,
                              void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, void* stream, int32_t algo, float* dt_ms);
 
+/* Multi-GPU, sparsity-aware exchange: gathers chunks of `block_bytes` bytes (a multiple of 16; one chunk = one
+ * block_col_size x n_cols tile of B in the row-block-tiled layout) from `src` into consecutive chunks of `dst`:
+ * dst chunk i = src chunk ids_dev[i].  All pointers are device pointers (16-byte aligned); stream-ordered.  A rank uses it
+ * to assemble the send buffer of the ONE all-to-all that ships to every other rank exactly the row-blocks of B that rank's
+ * slab of A touches (sparta_amd/dist.py: RowBlockExchange); the receive buffer is then read in place by
+ * sparta_vbs_spmm_gathered(shard_rows = block_col_size, shard_stride = block_col_size * n_cols).
+ * No reference counterpart (single-GPU). */
+int sparta_pack_blocks(const void* src, int64_t block_bytes, const int32_t* ids_dev, int64_t n_blocks, void* dst, void* stream);
+
 /* Per-tile-class device timing for roofline reports: when enabled, sparta_vbs_spmm brackets each class
  * launch with HIP events on the launch stream; sparta_vbs_class_times waits for them and writes the last
  * call's milliseconds into ms_out[4]: stream path -> {stream kernel, fix-up kernel, 0, 0};

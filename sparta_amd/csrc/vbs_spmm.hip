@@ -1020,6 +1020,7 @@ __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_fixup_kernel(const FixR
                                                                       int64_t ws_slab_stride, float* C, int64_t ldc, int c_row_major,
                                                                       int accumulate) {
     const FixRec fr = fix[blockIdx.x];
+    if (accumulate && fr.n_slots == 0) return;   // a block-row without blocks adds nothing to C (vbr.cpp:340-368 never touches its rows)
     const float* ws = ws_all + (int64_t)blockIdx.y * ws_slab_stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 31, g = lane >> 5;
     f32x16 acc0, acc1;
@@ -1046,6 +1047,16 @@ __global__ __launch_bounds__(kThreads) void vbs_tail_copy_kernel(const float* B,
             B_tail[idx] = row0 + k < cols ? B[row0 + k + j * ldb] : 0.0f;
         }
     }
+}
+
+// ---- row-block pack (multi-GPU exchange of only the needed rows of B) ---------------------------------
+// dst chunk i <- src chunk ids[i]; a chunk is one w x N tile of B (block_bytes, a multiple of 16).  One workgroup per
+// chunk and grid.y slice; 16-byte loads / stores, fully coalesced: HBM-bound, bytes = 2 x n_blocks x block_bytes.
+__global__ __launch_bounds__(kThreads) void pack_blocks_kernel(const u32x4* __restrict__ src, const int32_t* __restrict__ ids,
+                                                               u32x4* __restrict__ dst, int64_t block_vec) {
+    const int64_t from = (int64_t)ids[blockIdx.x] * block_vec, to = (int64_t)blockIdx.x * block_vec;
+    for (int64_t i = (int64_t)blockIdx.y * kThreads + threadIdx.x; i < block_vec; i += (int64_t)gridDim.y * kThreads)
+        dst[to + i] = __builtin_nontemporal_load(src + from + i);
 }
 
 // ---- exact-order kernel (parity aid) -----------------------------------------------------------------
@@ -1831,7 +1842,7 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
         }
         if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
     }
-    if (A->n_fix > 0) {
+    if (A->n_fix > 0 && !(accumulate && A->n_split == 0)) {   // C += 0 for the block-rows without blocks: nothing to launch
         if (prof) HIP_TRY(hipEventRecord(A->cev[1][0], st));
         hipLaunchKernelGGL(vbs_spmm_f32_fixup_kernel, dim3((unsigned)A->n_fix, (unsigned)n_nt), dim3(kThreads), 0, st, A->d_fix, A->d_fix_slots,
                            (const float*)A->d_ws, (int64_t)slab, dC, ldc, (int)(c_layout == SPARTA_ROW_MAJOR), (int)(accumulate != 0));
@@ -1960,7 +1971,7 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                 }
                 if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
             }
-            if (A->n_fix > 0) {
+            if (A->n_fix > 0 && !(accumulate && A->n_split == 0)) {   // C += 0 for the block-rows without blocks: nothing to launch
                 if (prof) HIP_TRY(hipEventRecord(A->cev[1][0], st));
                 hipLaunchKernelGGL(vbs_spmm_f32_fixup_kernel, dim3((unsigned)A->n_fix, (unsigned)n_nt), dim3(kThreads), 0, st, A->d_fix,
                                    A->d_fix_slots, (const float*)A->d_ws, (int64_t)slab, Cout, ldc, (int)(c_layout == SPARTA_ROW_MAJOR),
@@ -2090,6 +2101,22 @@ int sparta_vbs_class_times(sparta_vbs_t* A, float* ms_out) {
         HIP_TRY(hipEventSynchronize(A->cev[c][1]));
         HIP_TRY(hipEventElapsedTime(&ms_out[c], A->cev[c][0], A->cev[c][1]));
     }
+    return SPARTA_OK;
+}
+
+int sparta_pack_blocks(const void* src, int64_t block_bytes, const int32_t* ids_dev, int64_t n_blocks, void* dst, void* stream) {
+    using sparta::fail;
+    if (n_blocks < 0 || block_bytes <= 0 || block_bytes % 16 != 0)
+        return fail(SPARTA_ERR_INVALID, "sparta_pack_blocks: block_bytes must be a positive multiple of 16, n_blocks >= 0");
+    if (n_blocks == 0) return SPARTA_OK;
+    if (!src || !ids_dev || !dst) return fail(SPARTA_ERR_INVALID, "sparta_pack_blocks: NULL argument");
+    if (((uintptr_t)src | (uintptr_t)dst) % 16 != 0) return fail(SPARTA_ERR_INVALID, "sparta_pack_blocks: src and dst must be 16-byte aligned");
+    if (n_blocks > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_pack_blocks: too many blocks for one launch");
+    const int64_t vec = block_bytes / 16;
+    const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8, vec / (4 * kThreads)));
+    hipLaunchKernelGGL(pack_blocks_kernel, dim3((unsigned)n_blocks, gy), dim3(kThreads), 0, (hipStream_t)stream, (const u32x4*)src, ids_dev,
+                       (u32x4*)dst, vec);
+    HIP_TRY(hipGetLastError());
     return SPARTA_OK;
 }
 

@@ -7,7 +7,15 @@ for.  Block-rows are independent (each writes a disjoint row range of C, vbr.cpp
   * every rank owns the rows of B that correspond to its column shard and one `all_gather_into_tensor` assembles the
     n_shards column-major slabs on every GPU -- exactly the layout sparta_vbs_spmm_gathered consumes, no repacking;
   * C stays row-partitioned: there is no collective on C.
-One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm ("gloo" on CPU for the tests)."""
+One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm ("gloo" on CPU for the tests).
+
+Second exchange mode (RowBlockExchange): a slab of A usually touches only a few row-blocks of the other ranks' shards of B
+(a FEM slab: one plane of halo on each side; a clustered graph: its neighbours).  Replicating all of B then moves
+(world-1) x |shard| bytes per rank and step for nothing.  Here every rank tells the others once, at plan time, which
+column-blocks its slab touches; per step ONE all-to-all (RCCL send/recv pairs on the point-to-point xGMI links) ships
+exactly those row-blocks, while the product with the rank's OWN shard -- which needs no communication -- runs
+concurrently; the product with the received blocks is added afterwards.  A slab that touches everything degenerates to
+the all-gather's traffic; `needed_fraction` tells which mode pays."""
 import numpy as np
 
 
@@ -50,3 +58,152 @@ def gathered_to_colmajor(B_gathered, world_size, shard_rows, n_cols):
     """(host/numpy helper for tests) gathered slabs -> one column-major (world*shard_rows) x n_cols matrix, flat"""
     g = np.asarray(B_gathered).reshape(world_size, n_cols, shard_rows)      # slab s, column j, local row
     return np.ascontiguousarray(g.transpose(1, 0, 2)).reshape(-1)           # column j, slab s, local row
+
+
+# ---- sparsity-aware exchange: only the row-blocks of B a slab touches ---------------------------------------------
+
+def to_block_tiles(B_colmajor, rows, n_cols, w):
+    """(numpy helper) column-major rows x n_cols (ld = rows, rows % w == 0) -> row-block-tiled layout: block jb (rows
+    [jb*w, (jb+1)*w) of B) is one contiguous w x n_cols column-major tile (ld = w) at element offset jb * w * n_cols.
+    This is the layout RowBlockExchange keeps B in: a needed row-block is ONE contiguous chunk to send, and the SpMM kernel
+    reads it in place through sparta_vbs_spmm_gathered(shard_rows = w, shard_stride = w * n_cols)."""
+    B = np.asarray(B_colmajor).reshape(n_cols, rows // w, w)
+    return np.ascontiguousarray(B.transpose(1, 0, 2)).reshape(-1)
+
+
+def from_block_tiles(B_tiles, rows, n_cols, w):
+    B = np.asarray(B_tiles).reshape(rows // w, n_cols, w)
+    return np.ascontiguousarray(B.transpose(1, 0, 2)).reshape(-1)
+
+
+def needed_blocks(jab, block_col_size, shard_rows, world_size):
+    """Per source rank q: the sorted local ids (inside shard q) of the column-blocks that occur in `jab` (global ids in the
+    padded numbering  owner * shard_rows / w + local)."""
+    bps = int(shard_rows) // int(block_col_size)
+    u = np.unique(np.asarray(jab, np.int64))
+    if len(u) and (u[0] < 0 or u[-1] >= bps * world_size):
+        raise ValueError("column-block id outside world_size * shard_rows / block_col_size")
+    owner = u // bps
+    return [(u[owner == q] - q * bps).astype(np.int32) for q in range(world_size)]
+
+
+def split_own_remote(vb, rank, shard_rows, world_size):
+    """Column split of a slab's VBS (same block-rows, same values, blocks in the same order):
+      own    -- the blocks whose column-block lies in shard `rank`, ids local to the shard   (cols = shard_rows)
+      remote -- the others, ids compacted in (source rank, block) order = the order the all-to-all delivers the tiles
+                (cols = number of needed remote blocks * w; None when the slab touches no other shard)
+    plus need[q] (needed_blocks).  own * B_own + remote * B_received == vb * B up to the order of the fp32 sums."""
+    from .host import VBR
+    w = int(vb.block_col_size)
+    bps = int(shard_rows) // w
+    if int(shard_rows) % w or vb.cols != world_size * shard_rows:
+        raise ValueError("cols must be world_size * shard_rows and shard_rows a multiple of block_col_size")
+    need = needed_blocks(vb.jab, w, shard_rows, world_size)
+    jab = np.asarray(vb.jab, np.int64)
+    nzc = np.asarray(vb.nzcount, np.int64)
+    h = np.diff(np.asarray(vb.row_part, np.int64))
+    ib = np.repeat(np.arange(len(nzc)), nzc)                   # block-row of every block
+    size = h[ib] * w                                           # stored elements of every block
+    off = np.concatenate([[0], np.cumsum(size)])
+    is_own = (jab // bps) == rank
+    remote_ids = np.concatenate([need[q].astype(np.int64) + q * bps for q in range(world_size) if q != rank]
+                                + [np.zeros(0, np.int64)])
+
+    def take(mask, new_ids, new_cols):
+        sel = np.flatnonzero(mask)
+        sz = size[sel]
+        total = int(sz.sum())
+        start = np.concatenate([[0], np.cumsum(sz)])[:-1]
+        idx = np.repeat(off[sel] - start, sz) + np.arange(total)
+        mab = np.asarray(vb.mab, np.float32)[idx] if total else np.zeros(0, np.float32)
+        return VBR.from_arrays(vb.rows, new_cols, w, vb.row_part, np.bincount(ib[sel], minlength=len(nzc)), new_ids, mab)
+
+    own = take(is_own, jab[is_own] - rank * bps, int(shard_rows))
+    remote = None
+    if len(remote_ids):
+        remote = take(~is_own, np.searchsorted(remote_ids, jab[~is_own]), len(remote_ids) * w)
+    return own, remote, need
+
+
+class RowBlockExchange:
+    """Per-step exchange of only the needed row-blocks of B + the two-part product (see the module docstring).
+
+        ex = RowBlockExchange(vb_slab, rank, world, shard_rows, n_cols, device=local_rank)       # collective (plan exchange)
+        ex.step(B_own_tiles, C)          # B_own_tiles: this rank's shard in the row-block-tiled layout (to_block_tiles)
+
+    `pack` / `product` can be replaced (the CPU tests over gloo pass numpy-backed ones; the product path is the HIP
+    library and has no CPU form).  `all_need[p][q]` (every rank's needed_blocks) skips the plan-time collective."""
+
+    def __init__(self, vb, rank, world_size, shard_rows, n_cols, device=0, group=None, pack=None, product=None, all_need=None):
+        import torch
+        import torch.distributed as dist
+        self.rank, self.world, self.w, self.N = int(rank), int(world_size), int(vb.block_col_size), int(n_cols)
+        self.shard_rows, self.group, self.device = int(shard_rows), group, device
+        self.own, self.remote, self.need = split_own_remote(vb, rank, shard_rows, world_size)
+        tile = self.w * self.N
+        if all_need is not None:                  # single-process drivers / tests: every rank's need lists, already known
+            all_need = [[np.asarray(a).tolist() for a in per_rank] for per_rank in all_need]
+        elif self.world > 1:
+            all_need = [None] * self.world
+            dist.all_gather_object(all_need, [a.tolist() for a in self.need], group=group)
+        else:
+            all_need = [[a.tolist() for a in self.need]]
+        send = [np.asarray(all_need[p][self.rank], np.int32) if p != self.rank else np.zeros(0, np.int32) for p in range(self.world)]
+        bps = self.shard_rows // self.w
+        for a in send:
+            if len(a) and (a.min() < 0 or a.max() >= bps):
+                raise ValueError("a peer asked for a row-block outside this rank's shard")
+        self.send_ids_host = np.concatenate(send + [np.zeros(0, np.int32)]).astype(np.int32)
+        self.in_splits = [len(a) * tile for a in send]
+        self.out_splits = [len(self.need[q]) * tile if q != self.rank else 0 for q in range(self.world)]
+        self.n_send, self.n_recv = len(self.send_ids_host), sum(self.out_splits) // tile
+        # every rank must agree on whether the collective is called at all
+        self.any_exchange = any(len(all_need[p][q]) for p in range(self.world) for q in range(self.world) if p != q)
+        # fraction of the all-gather's per-rank traffic this exchange still moves (max over ranks): 1.0 = nothing saved
+        self.needed_fraction = (max(sum(len(all_need[p][q]) for q in range(self.world) if q != p) for p in range(self.world))
+                                / float(max(1, (self.world - 1) * bps)))
+        dev = torch.device("cpu") if device is None else torch.device("cuda", device)
+        self.send_ids = torch.from_numpy(self.send_ids_host).to(dev)
+        self.send_buf = torch.empty(max(1, self.n_send * tile), dtype=torch.float32, device=dev)
+        self.recv_buf = torch.empty(max(1, self.n_recv * tile), dtype=torch.float32, device=dev)
+        self._pack = pack if pack is not None else self._pack_hip
+        self._product = product if product is not None else self._product_hip
+        self.d_own = self.d_rem = None
+        if product is None:
+            self.d_own = self.own.to_device(device)
+            self.d_rem = self.remote.to_device(device) if self.remote is not None else None
+
+    # -- HIP implementations (the product) --
+    def _pack_hip(self, B_tiles):
+        import ctypes as C
+        import torch
+        from ._lib import lib, check
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        check(lib.sparta_pack_blocks(C.c_void_p(B_tiles.data_ptr()), self.w * self.N * 4, C.c_void_p(self.send_ids.data_ptr()), self.n_send,
+                                     C.c_void_p(self.send_buf.data_ptr()), C.c_void_p(st)))
+
+    def _product_hip(self, which, B_tiles, C_out, accumulate):
+        d = self.d_own if which == "own" else self.d_rem
+        d.spmm_gathered(B_tiles, self.w, C_out, self.N, accumulate=accumulate)
+
+    def step(self, B_own_tiles, C_out, accumulate=False):
+        """C (+)= A_slab * B with B distributed: pack -> all-to-all (asynchronous) || own-shard product -> remote product."""
+        import torch.distributed as dist
+        work = None
+        if self.any_exchange:
+            if self.n_send:
+                self._pack(B_own_tiles)
+            tile = self.w * self.N
+            work = dist.all_to_all_single(self.recv_buf[:self.n_recv * tile], self.send_buf[:self.n_send * tile], self.out_splits,
+                                          self.in_splits, group=self.group, async_op=True)
+        self._product("own", B_own_tiles, C_out, accumulate)
+        if work is not None:
+            work.wait()
+            if self.remote is not None:
+                self._product("remote", self.recv_buf, C_out, True)
+
+    def close(self):
+        for d in (self.d_own, self.d_rem):
+            if d is not None:
+                d.close()
+        self.d_own = self.d_rem = None

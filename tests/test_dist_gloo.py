@@ -75,3 +75,118 @@ def test_partition_block_rows_balances_work():
         assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
         work = np.array([(h[a:b] * 64 * nz[a:b]).sum() for a, b in parts], float)
         assert work.max() <= 1.25 * work.sum() / world + (h * 64 * nz).max()
+
+
+# ---- sparsity-aware exchange (RowBlockExchange): plan + ONE all-to-all of the needed row-blocks ---------------------
+
+def _cpu_hooks(ex_box, N, W_):
+    """numpy-backed stand-ins for the two HIP calls of RowBlockExchange (pack kernel, SpMM), for CPU tensors over gloo"""
+    import torch
+    from oracle import oracle as O
+    import sparta_amd as sa
+
+    def pack(B_tiles):
+        ex = ex_box[0]
+        t = B_tiles.view(-1, W_ * N)
+        ex.send_buf[:ex.n_send * W_ * N].view(-1, W_ * N).copy_(t[torch.from_numpy(ex.send_ids_host.astype(np.int64))])
+
+    def product(which, B_tiles, C_out, accumulate):
+        ex = ex_box[0]
+        v = ex.own if which == "own" else ex.remote
+        Bc = sa.dist.from_block_tiles(B_tiles.numpy()[:v.cols * N], v.cols, N, W_)
+        C0 = C_out.numpy().copy() if accumulate else None
+        Cn = O.vbr_multiply(v.rows, v.cols, W_, v.row_part, v.nzcount, v.jab, v.mab, Bc, N, C_in=C0)
+        C_out.copy_(torch.from_numpy(np.asarray(Cn, np.float32).reshape(-1)))
+    return pack, product
+
+
+def _worker_blocks(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import sparta_amd as sa
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, n_local, n_pad = sa.gen.fem3d_slab(3, 3, 6, rank, world, dof=3, pad_to=W, seed=9)
+        g = sa.BlockingEngine(tau=0.4, col_block_size=W).GetGrouping(m)
+        v = sa.VBR().fill_from_CSR_inplace(m, g, W)
+        shard = sa.gen.dense_rhs(n_pad, N, seed=70 + rank)                       # column-major n_pad x N
+        tiles = torch.from_numpy(sa.dist.to_block_tiles(shard, n_pad, N, W))
+        box = [None]
+        pack, product = _cpu_hooks(box, N, W)
+        ex = sa.dist.RowBlockExchange(v, rank, world, n_pad, N, device=None, pack=pack, product=product)
+        box[0] = ex
+        C = torch.full((v.rows * N,), 7.0)                                        # overwritten (accumulate = False)
+        ex.step(tiles, C)
+        C2 = C.clone()
+        ex.step(tiles, C2, accumulate=True)                                       # C2 = 2 * C
+        np.savez(os.path.join(out_dir, "blk%d.npz" % rank), C=C.numpy(), C2=C2.numpy(), perm=sa.get_permutation(g), rows=v.rows, n_pad=n_pad,
+                 n_send=ex.n_send, n_recv=ex.n_recv, frac=ex.needed_fraction, recv=ex.recv_buf.numpy()[:ex.n_recv * W * N],
+                 need=np.concatenate([a + q * (n_pad // W) for q, a in enumerate(ex.need) if q != rank] + [np.zeros(0, np.int64)]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_block_exchange_all_to_all(tmp_path, world):
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker_blocks, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    import sparta_amd as sa
+    from oracle import oracle as O
+    res = [np.load(os.path.join(str(tmp_path), "blk%d.npz" % r)) for r in range(world)]
+    n_pad = int(res[0]["n_pad"])
+    shards = [sa.gen.dense_rhs(n_pad, N, seed=70 + r) for r in range(world)]
+    Bfull = sa.dist.gathered_to_colmajor(np.concatenate(shards), world, n_pad, N).reshape(N, world * n_pad)
+    for r in range(world):
+        m, _, _ = sa.gen.fem3d_slab(3, 3, 6, r, world, dof=3, pad_to=W, seed=9)
+        Cc = O.csr_multiply(m.rows, m.rowptr, m.colidx, m.vals, Bfull.reshape(-1), m.cols, N).reshape(N, m.rows)
+        C = res[r]["C"].reshape(N, int(res[r]["rows"]))
+        want = Cc[:, res[r]["perm"]]
+        # two partial sums (own + received blocks) instead of one ascending sum: equal up to fp32 rounding of the re-association
+        assert np.allclose(C, want, rtol=0, atol=1e-5 * np.abs(want).max()), "rank %d" % r
+        assert np.allclose(res[r]["C2"].reshape(N, -1), 2 * C, rtol=0, atol=2e-5 * np.abs(want).max())
+        # what arrived is exactly the needed row-blocks of the peers, in (source rank, block) order
+        need = res[r]["need"]
+        got = res[r]["recv"].reshape(len(need), N, W)
+        for k, jb in enumerate(need):
+            assert np.array_equal(got[k], Bfull[:, jb * W:(jb + 1) * W]), (r, jb)
+        # a slab only needs the halo planes of its neighbours, far less than the all-gather moves
+        assert 0 < res[r]["n_recv"] < (world - 1) * (n_pad // W)
+        assert 0 < float(res[r]["frac"]) < 1
+    # a middle rank of three talks to both neighbours; the end ranks to one
+    if world == 3:
+        assert int(res[1]["n_recv"]) > int(res[0]["n_recv"])
+
+
+def test_split_own_remote_is_a_column_partition():
+    import sparta_amd as sa
+    from oracle import oracle as O
+    world, rank = 3, 1
+    m, n_local, n_pad = sa.gen.fem3d_slab(3, 3, 5, rank, world, dof=3, pad_to=W, seed=4)
+    g = sa.BlockingEngine(tau=0.5, col_block_size=W).GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, W)
+    own, rem, need = sa.dist.split_own_remote(v, rank, n_pad, world)
+    assert own.cols == n_pad and rem.cols == sum(len(need[q]) for q in range(world) if q != rank) * W
+    assert np.array_equal(own.nzcount + rem.nzcount, v.nzcount) and len(own.mab) + len(rem.mab) == len(v.mab)
+    assert sorted(np.concatenate([own.mab, rem.mab]).tolist()) == sorted(v.mab.tolist())
+    B = sa.gen.dense_rhs(v.cols, N, seed=5).reshape(N, v.cols)
+    bps = n_pad // W
+    ids = np.concatenate([need[q] + q * bps for q in range(world) if q != rank])
+    B_own = np.ascontiguousarray(B[:, rank * n_pad:(rank + 1) * n_pad]).reshape(-1)
+    B_rem = np.ascontiguousarray(np.concatenate([B[:, j * W:(j + 1) * W] for j in ids], axis=1)).reshape(-1)
+    C = O.vbr_multiply(own.rows, own.cols, W, own.row_part, own.nzcount, own.jab, own.mab, B_own, N)
+    C = O.vbr_multiply(rem.rows, rem.cols, W, rem.row_part, rem.nzcount, rem.jab, rem.mab, B_rem, N, C_in=C)
+    want = O.vbr_multiply(v.rows, v.cols, W, v.row_part, v.nzcount, v.jab, v.mab, B.reshape(-1), N)
+    assert np.allclose(C, want, rtol=0, atol=1e-5 * np.abs(want).max())
+    # tile layout round trip
+    t = sa.dist.to_block_tiles(B_own, n_pad, N, W)
+    assert np.array_equal(sa.dist.from_block_tiles(t, n_pad, N, W), B_own)
+    assert np.array_equal(t[:W], B_own[:W]) and np.array_equal(t[W:2 * W], B_own[n_pad:n_pad + W])
+    with pytest.raises(ValueError):
+        sa.dist.split_own_remote(v, rank, n_pad + W, world)

@@ -204,6 +204,76 @@ def test_non_finite_b_outside_the_matrix_does_not_leak():
         _check(got, Co, U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n))
 
 
+@pytest.mark.parametrize("world,w,n,mesh", [(3, 16, 40, (3, 3, 5)), (2, 32, 128, (5, 5, 12)), (4, 32, 256, (4, 4, 9))])
+def test_row_block_exchange_on_one_gpu(world, w, n, mesh):
+    """the sparsity-aware exchange with every rank played by this process: sparta_pack_blocks fills each rank's send buffer,
+    the all-to-all is emulated by device copies in its (source rank, block) delivery order, and the two products
+    (own shard || received row-blocks, both through sparta_vbs_spmm_gathered on the row-block-tiled layout) must add up to
+    the oracle's product of the slab with the whole B"""
+    torch = _torch()
+    slabs = [sa.gen.fem3d_slab(mesh[0], mesh[1], mesh[2], r, world, dof=3, pad_to=w, seed=4) for r in range(world)]
+    n_pad = slabs[0][2]
+    shards = [sa.gen.dense_rhs(n_pad, n, seed=50 + r) for r in range(world)]
+    Bfull = sa.dist.gathered_to_colmajor(np.concatenate(shards), world, n_pad, n)
+    tiles = [torch.from_numpy(sa.dist.to_block_tiles(s, n_pad, n, w)).cuda() for s in shards]
+    vbs, all_need = [], []
+    for m, _, _ in slabs:
+        g = sa.BlockingEngine(tau=0.4, col_block_size=w).GetGrouping(m)
+        vbs.append(sa.VBR().fill_from_CSR_inplace(m, g, w))
+        all_need.append(sa.dist.needed_blocks(vbs[-1].jab, w, n_pad, world))
+    exs = [sa.dist.RowBlockExchange(vbs[r], r, world, n_pad, n, device=0, all_need=all_need) for r in range(world)]
+    tile = w * n
+    for r in range(world):                                   # pack (HIP)
+        exs[r]._pack(tiles[r])
+    for p in range(world):                                   # the all-to-all: chunk q of p's receive buffer <- chunk p of q's send buffer
+        o = 0
+        for q in range(world):
+            k = exs[p].out_splits[q]
+            i0 = sum(exs[q].in_splits[:p])
+            assert exs[q].in_splits[p] == k
+            exs[p].recv_buf[o:o + k].copy_(exs[q].send_buf[i0:i0 + k])
+            o += k
+        assert o == exs[p].n_recv * tile
+    for r in range(world):
+        v = vbs[r]
+        Co = _oracle_c(v, Bfull, n)
+        bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, Bfull, n)
+        Ct = torch.full((v.rows * n,), 3.0, dtype=torch.float32, device="cuda")
+        exs[r]._product("own", tiles[r], Ct, False)
+        assert exs[r].remote is not None and 0 < exs[r].needed_fraction < 1
+        exs[r]._product("remote", exs[r].recv_buf, Ct, True)
+        torch.cuda.synchronize()
+        _check(Ct.cpu().numpy(), Co, bound, "row-block exchange rank %d" % r)
+        # accumulate = True on the own part: C += A * B
+        exs[r]._product("own", tiles[r], Ct, True)
+        exs[r]._product("remote", exs[r].recv_buf, Ct, True)
+        torch.cuda.synchronize()
+        _check(Ct.cpu().numpy(), 2 * Co, 2 * bound, "row-block exchange rank %d, accumulate" % r)
+        exs[r].close()
+
+
+def test_pack_blocks_contract():
+    torch = _torch()
+    import ctypes as C
+    from sparta_amd._lib import lib
+    src = torch.arange(64 * 40, dtype=torch.float32, device="cuda")
+    ids = torch.tensor([5, 0, 5, 39, 17], dtype=torch.int32, device="cuda")
+    dst = torch.zeros(5 * 64, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.sparta_pack_blocks(C.c_void_p(src.data_ptr()), 256, C.c_void_p(ids.data_ptr()), 5, C.c_void_p(dst.data_ptr()), C.c_void_p(st)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dst.view(5, 64), src.view(40, 64)[ids.long()])
+    big = torch.rand(37 * 8192, device="cuda")                      # 32 KB chunks: several grid.y slices
+    idb = torch.tensor([36, 1, 0, 20], dtype=torch.int32, device="cuda")
+    out = torch.zeros(4 * 8192, device="cuda")
+    assert lib.sparta_pack_blocks(C.c_void_p(big.data_ptr()), 32768, C.c_void_p(idb.data_ptr()), 4, C.c_void_p(out.data_ptr()), C.c_void_p(st)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(4, 8192), big.view(37, 8192)[idb.long()])
+    assert lib.sparta_pack_blocks(C.c_void_p(src.data_ptr()), 256, C.c_void_p(ids.data_ptr()), 0, C.c_void_p(dst.data_ptr()), C.c_void_p(st)) == 0
+    assert lib.sparta_pack_blocks(C.c_void_p(src.data_ptr()), 100, C.c_void_p(ids.data_ptr()), 5, C.c_void_p(dst.data_ptr()), C.c_void_p(st)) == sa._lib.ERR_INVALID
+    assert lib.sparta_pack_blocks(None, 256, C.c_void_p(ids.data_ptr()), 5, C.c_void_p(dst.data_ptr()), C.c_void_p(st)) == sa._lib.ERR_INVALID
+
+
 def test_block_row_range_handles_and_gathered_b():
     """the multi-GPU pieces on one GPU: row-range handles (sparta_vbs_create_range) reproduce the rows of the full
     product, and the gathered-B entry point reads an all-gather-shaped B"""
