@@ -56,6 +56,8 @@ extern "C" {
 #define SPARTA_BLOCKING_ITERATIVE_QUEUE      4
 #define SPARTA_BLOCKING_ITERATIVE_MAX_SIZE   5   /* dispatches to IterativeBlockingKeeper (blocking.cpp:655) */
 #define SPARTA_BLOCKING_SCRAMBLE             6
+#define SPARTA_BLOCKING_MINHASH              7   /* EXTENSION (not in the reference): LSH-bucketed clustering with the same merge rule, for inputs
+                                                   the quadratic scans cannot handle (approximate: see sparta_amd/csrc/reorder.cpp) */
 
 /* similarity measure, flag -m (include/input.h:29, src/general/blocking.cpp:699-717) */
 #define SPARTA_SIM_HAMMING 0
@@ -81,6 +83,10 @@ typedef struct sparta_reorder_cfg {
     int32_t force_fixed_size;  /* re-chunk into equal heights  (-F, default 0)    */
     int32_t structured_m;      /* blocking_algo 1 only: at most m hits per column ... (include/blocking.h:20, default 2) */
     int32_t structured_n;      /* ... inside every run of n merged rows               (include/blocking.h:21, default 4) */
+    int32_t minhash_bands;     /* blocking_algo 7 only: LSH bands (0 = 16) ...                                              */
+    int32_t minhash_rows;      /* ... minhash values per band (0 = from tau), ...                                            */
+    int32_t minhash_max_eval;  /* ... exact comparisons per seed at most (0 = 512), ...                                       */
+    int32_t minhash_max_rows;  /* ... a cluster stops growing once it has this many rows (0 = unlimited; identical rows join together) */
 } sparta_reorder_cfg;
 
 /* replaces the measuring fields of BlockingEngine (include/blocking.h:28-42) */

@@ -33,7 +33,8 @@ typedef float DataT;     // :5
 typedef float DataT_C;   // :6
 
 enum MatrixFormat { el, mtx };                                                                                                      // :15
-enum BlockingType { iterative, iterative_structured, fixed_size, iterative_clocked, iterative_queue, iterative_max_size, scramble };   // :17
+enum BlockingType { iterative, iterative_structured, fixed_size, iterative_clocked, iterative_queue, iterative_max_size, scramble,   // :17
+                    minhash /* = 7, extension: SPARTA_BLOCKING_MINHASH, not in the reference */ };
 
 inline std::vector<intT> get_permutation(const std::vector<intT>& grouping);
 
@@ -194,6 +195,7 @@ class BlockingEngine {
     bool use_pattern = true;
     bool force_fixed_size = false;
     int structured_m = 2, structured_n = 4;
+    int minhash_bands = 0, minhash_rows = 0, minhash_max_eval = 0, minhash_max_rows = 0;   // blocking_algo == minhash only; 0 = library default
     BlockingType blocking_algo = iterative_clocked;
 
     intT comparison_counter = 0, merge_counter = 0;
@@ -216,6 +218,7 @@ class BlockingEngine {
         cfg.use_groups = use_groups; cfg.col_block_size = col_block_size; cfg.row_block_size = row_block_size;
         cfg.use_pattern = use_pattern; cfg.force_fixed_size = force_fixed_size;
         cfg.structured_m = structured_m; cfg.structured_n = structured_n;
+        cfg.minhash_bands = minhash_bands; cfg.minhash_rows = minhash_rows; cfg.minhash_max_eval = minhash_max_eval; cfg.minhash_max_rows = minhash_max_rows;
         sparta_reorder_stats st;
         grouping_result.assign((size_t)cmat.rows, 0);
         sparta_compat_detail::check(sparta_reorder(cmat.rows, cmat.cols, rp.data(), ci.data(), &cfg, (int64_t*)grouping_result.data(), &st), "GetGrouping");

@@ -61,7 +61,8 @@ class CsvFields(C.Structure):
 class ReorderCfg(C.Structure):
     _fields_ = [("blocking_algo", C.c_int32), ("sim_measure", C.c_int32), ("tau", C.c_float), ("use_groups", C.c_int32),
                 ("col_block_size", C.c_int64), ("row_block_size", C.c_int64), ("use_pattern", C.c_int32),
-                ("force_fixed_size", C.c_int32), ("structured_m", C.c_int32), ("structured_n", C.c_int32)]
+                ("force_fixed_size", C.c_int32), ("structured_m", C.c_int32), ("structured_n", C.c_int32),
+                ("minhash_bands", C.c_int32), ("minhash_rows", C.c_int32), ("minhash_max_eval", C.c_int32), ("minhash_max_rows", C.c_int32)]
 
 
 class ReorderStats(C.Structure):

@@ -17,9 +17,11 @@
 #include <chrono>
 #include <cstdlib>
 #include <cmath>
+#include <cstdio>
 #include <numeric>
 #include <random>
 #include <set>
+#include <thread>
 #include <type_traits>
 #include <functional>
 #include <utility>
@@ -175,8 +177,9 @@ struct Ctx : CtxBase {
     std::vector<int64_t> row_stamp, blk_stamp;
     int64_t stamp = 0;
     bool filter_on = false, have_index = false, force_filter = false;
-    Ctx(const CsrView& a_, const sparta_reorder_cfg& c) : CtxBase(a_, c) {
+    Ctx(const CsrView& a_, const sparta_reorder_cfg& c, bool want_index = true) : CtxBase(a_, c) {
         rb = build_row_blocks(a, w);
+        if (!want_index) return;
         const char* e = std::getenv("SPARTA_REORDER_FILTER");             // 0: off, 1: on for every input, unset: on from 2048 rows
         if (e && e[0] == '0') return;
         if (a.rows > INT32_MAX || a.cols <= 0) return;
@@ -673,6 +676,264 @@ void keeper(C& c, int64_t* grouping) {
 
 // ---- public helpers ---------------------------------------------------------------------------
 
+// ---- Algorithm 7: LSH-bucketed clustering -- an EXTENSION, not in the reference -----------------
+// The reference's scans compare every seed with every later row: fine for 10^4..10^5 rows, hopeless for 10^6..10^7 (and its
+// stack VLA crashes above ~2 M rows).  This keeps the cluster semantics of algorithm 3 -- seeds in ascending row order, exact
+// distance of the evolving pattern and the candidate row (same Jaccard / Hamming functions, same cluster weights, same lossy
+// merge), merge when dist <= tau -- but only LOOKS at rows that an LSH index proposes:
+//   0. rows with identical block sets are folded first (distance 0: any tau merges them, and the merge leaves the pattern
+//      unchanged); power-law graphs have huge families of them (every row that only touches the hub block);
+//   1. every distinct row gets K = bands x r minhash values of its block set (multiply-shift hashes of a pre-mixed block id),
+//      band b's key = hash of its r values; per band the (key, row) pairs are sorted: rows with sim s collide in a given band
+//      with probability s^r, in at least one with 1 - (1 - s^r)^bands;
+//   2. a seed's candidates are the ungrouped later rows in the buckets of the PATTERN's signature (signature of a union =
+//      element-wise minimum, so after a merge only the bands whose key changed are looked up again), ordered by the number of
+//      colliding bands (the estimate of the similarity), at most `minhash_max_eval` exact comparisons per seed and
+//      kScanLimit entries per bucket look-up, so that uninformative giant buckets (rows that share only a hub block collide
+//      in many bands and are still too far apart to merge) cost a bounded amount.
+// Deterministic (fixed hash constants).  Quality is checked against the exact algorithm on inputs both can handle
+// (tests/test_host_golden.py::test_minhash_*): it cannot be bit-identical to the reference and does not claim to be.
+int64_t kScanLimit = 256;
+
+inline uint64_t mix64(uint64_t x) {              // splitmix64 finaliser
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+
+template <class F>
+void parallel_chunks(int64_t n, int n_threads, F&& f) {
+    n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, n));
+    if (n_threads == 1) { f(0, n); return; }
+    std::vector<std::thread> th;
+    const int64_t per = (n + n_threads - 1) / n_threads;
+    for (int t = 0; t < n_threads; t++) {
+        const int64_t lo = t * per, hi = std::min(n, lo + per);
+        if (lo >= hi) break;
+        th.emplace_back([&f, lo, hi] { f(lo, hi); });
+    }
+    for (auto& t : th) t.join();
+}
+
+void minhash_lsh(Ctx& c, int64_t* grouping) {
+    const CsrView& a = c.a;
+    const sparta_reorder_cfg& cfg = c.cfg;
+    const int64_t rows = a.rows;
+    const float tau = cfg.tau;
+    std::fill(grouping, grouping + rows, (int64_t)-1);
+    if (rows == 0) return;
+    int n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = std::getenv("SPARTA_REORDER_THREADS")) n_threads = std::max(1, atoi(e));
+    if (const char* e = std::getenv("SPARTA_MINHASH_SCAN")) kScanLimit = std::max(1, atoi(e));
+    int64_t patience = 32;                                       // consecutive failed candidates (best estimates first) before a seed gives up
+    if (const char* e = std::getenv("SPARTA_MINHASH_PATIENCE")) patience = std::max(1, atoi(e));
+
+    // ---- 0. fold identical rows: rep[i] = first row with the same block set (and, for Hamming's empty-row rule, the same nnz = 0 state)
+    std::vector<int32_t> rep((size_t)rows);
+    std::vector<int32_t> uniq;                                   // ascending representatives
+    std::vector<int64_t> dup_ptr;                                // duplicates of uniq[u] (excluding itself): dup_row[dup_ptr[u] .. dup_ptr[u+1])
+    std::vector<int32_t> dup_row;
+    {
+        std::vector<uint64_t> fh((size_t)rows);
+        parallel_chunks(rows, n_threads, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; i++) {
+                uint64_t h = 0x1234567 + (uint64_t)c.rb.n(i);
+                const int32_t* r = c.rb.row(i);
+                for (int64_t k = 0; k < c.rb.n(i); k++) h = mix64(h ^ (uint64_t)(uint32_t)r[k]);
+                fh[(size_t)i] = h;
+            }
+        });
+        std::vector<int32_t> order((size_t)rows);
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return fh[(size_t)x] != fh[(size_t)y] ? fh[(size_t)x] < fh[(size_t)y] : x < y; });
+        auto same = [&](int32_t x, int32_t y) {
+            return c.rb.n(x) == c.rb.n(y) && std::equal(c.rb.row(x), c.rb.row(x) + c.rb.n(x), c.rb.row(y));
+        };
+        for (size_t p = 0; p < order.size();) {                  // a run of equal hashes: group by true equality (first occurrence = representative)
+            size_t q = p;
+            while (q < order.size() && fh[(size_t)order[q]] == fh[(size_t)order[p]]) q++;
+            for (size_t x = p; x < q; x++) {
+                const int32_t i = order[x];
+                rep[(size_t)i] = i;
+                for (size_t y = p; y < x; y++)
+                    if (rep[(size_t)order[y]] == order[y] && same(order[y], i)) { rep[(size_t)i] = order[y]; break; }
+            }
+            p = q;
+        }
+        std::vector<int64_t> cnt((size_t)rows, 0);
+        for (int64_t i = 0; i < rows; i++) {
+            if (rep[(size_t)i] == i) uniq.push_back((int32_t)i); else cnt[(size_t)rep[(size_t)i]]++;
+        }
+        std::vector<int64_t> where((size_t)rows, -1);
+        dup_ptr.assign(uniq.size() + 1, 0);
+        for (size_t u = 0; u < uniq.size(); u++) { where[(size_t)uniq[u]] = (int64_t)u; dup_ptr[u + 1] = dup_ptr[u] + cnt[(size_t)uniq[u]]; }
+        dup_row.resize((size_t)dup_ptr.back());
+        std::vector<int64_t> fill(dup_ptr.begin(), dup_ptr.end() - 1);
+        for (int64_t i = 0; i < rows; i++)
+            if (rep[(size_t)i] != i) dup_row[(size_t)fill[(size_t)where[(size_t)rep[(size_t)i]]]++] = (int32_t)i;
+        // `where` doubles as row -> index in uniq below
+        for (int64_t i = 0; i < rows; i++) rep[(size_t)i] = (int32_t)where[(size_t)i];             // -1 for non-representatives
+    }
+    const int64_t U = (int64_t)uniq.size();
+    const bool verbose = std::getenv("SPARTA_MINHASH_VERBOSE") != nullptr;
+    auto t_ph = clk::now();
+    if (verbose) fprintf(stderr, "minhash: %lld rows, %lld distinct block sets\n", (long long)rows, (long long)U);
+
+    // ---- 1. signatures and band tables over the representatives
+    int bands = cfg.minhash_bands > 0 ? cfg.minhash_bands : 16;
+    int r = cfg.minhash_rows;
+    if (r <= 0) {                                                // largest r whose threshold (1/bands)^(1/r) stays below 0.75 x (1 - tau)
+        const double s0 = c.sim == SPARTA_SIM_JACCARD ? std::max(0.05, 1.0 - (double)tau) : 0.5;
+        r = 1;
+        for (int t = 2; t <= 6; t++)
+            if (std::pow(1.0 / bands, 1.0 / t) <= 0.75 * s0) r = t;
+    }
+    bands = std::min(bands, 64);
+    r = std::min(r, 8);
+    const int K = bands * r;
+    int64_t max_eval = cfg.minhash_max_eval > 0 ? cfg.minhash_max_eval : 512;
+    const int64_t cap = cfg.minhash_max_rows > 0 ? cfg.minhash_max_rows : INT64_MAX;
+    std::vector<uint64_t> ha((size_t)K), hb((size_t)K);
+    for (int k = 0; k < K; k++) { ha[(size_t)k] = mix64(2 * (uint64_t)k + 1) | 1ull; hb[(size_t)k] = mix64(0xabcdef01ull + (uint64_t)k); }
+    std::vector<uint32_t> sig((size_t)U * (size_t)K);
+    parallel_chunks(U, n_threads, [&](int64_t lo, int64_t hi) {
+        for (int64_t u = lo; u < hi; u++) {
+            uint32_t* sg = sig.data() + (size_t)u * K;
+            for (int k = 0; k < K; k++) sg[k] = UINT32_MAX;
+            const int32_t i = uniq[(size_t)u];
+            const int32_t* rw = c.rb.row(i);
+            for (int64_t q = 0; q < c.rb.n(i); q++) {
+                const uint64_t x = mix64((uint64_t)(uint32_t)rw[q]);
+                for (int k = 0; k < K; k++) sg[k] = std::min(sg[k], (uint32_t)((ha[(size_t)k] * x + hb[(size_t)k]) >> 32));
+            }
+        }
+    });
+    auto band_key = [&](const uint32_t* sg, int b) {
+        uint64_t h = 0x51ed270b + (uint64_t)b;
+        for (int t = 0; t < r; t++) h = mix64(h ^ sg[b * r + t]);
+        return h;
+    };
+    struct Entry { uint64_t key; int32_t u; };
+    std::vector<std::vector<Entry>> table((size_t)bands);
+    std::vector<int32_t> slot((size_t)bands * (size_t)U);
+    parallel_chunks(bands, n_threads, [&](int64_t lo, int64_t hi) {
+        for (int64_t b = lo; b < hi; b++) {
+            std::vector<Entry>& t = table[(size_t)b];
+            t.resize((size_t)U);
+            for (int64_t u = 0; u < U; u++) t[(size_t)u] = Entry{band_key(sig.data() + (size_t)u * K, (int)b), (int32_t)u};
+            std::sort(t.begin(), t.end(), [](const Entry& x, const Entry& y) { return x.key != y.key ? x.key < y.key : x.u < y.u; });
+            int32_t* ps = slot.data() + (size_t)b * (size_t)U;   // where each row sits in this band's table: a seed's first look-up needs no search
+            for (int64_t q = 0; q < U; q++) ps[t[(size_t)q].u] = (int32_t)q;
+        }
+    });
+
+    if (verbose) fprintf(stderr, "minhash: bands %d x %d values, signatures + tables %.2f s\n", bands, r, us_since(t_ph) * 1e-6);
+    float t_look = 0;
+    // ---- 2. seeds in ascending row order
+    std::vector<int32_t> seen((size_t)U, -1);                    // candidate of which seed (index in uniq)
+    std::vector<uint16_t> hits((size_t)U, 0);
+    std::vector<int32_t> cand, fresh, sorted;
+    std::vector<uint32_t> sigP((size_t)K);
+    std::vector<uint64_t> keyP((size_t)bands);
+    auto t_all = clk::now();
+    for (int64_t su = 0; su < U; su++) {
+        const int64_t i = uniq[(size_t)su];
+        if (grouping[i] != -1) continue;
+        int64_t members = 0, gsize = 1, evals = 0, failed = 0;
+        auto take = [&](int64_t u, float d) {                    // representative u and its duplicates join the cluster of seed i
+            const int64_t j = uniq[(size_t)u];
+            grouping[j] = i;
+            for (int64_t k = dup_ptr[(size_t)u]; k < dup_ptr[(size_t)u + 1]; k++) {
+                grouping[dup_row[(size_t)k]] = i;
+                c.merges++;                                       // a duplicate of a row already in the cluster: distance to the pattern as measured for it
+                c.total_merge_tau += (j == i ? 0.0f : d);
+                c.total_row_distance += (float)(dup_row[(size_t)k] - i);
+            }
+            members += 1 + (dup_ptr[(size_t)u + 1] - dup_ptr[(size_t)u]);
+            if (cfg.use_groups) gsize += (j == i ? 0 : 1) + (dup_ptr[(size_t)u + 1] - dup_ptr[(size_t)u]);
+        };
+        c.assign(i);
+        take(su, 0.0f);
+        std::copy(sig.begin() + (size_t)su * K, sig.begin() + (size_t)(su + 1) * K, sigP.begin());
+        for (int b = 0; b < bands; b++) keyP[(size_t)b] = band_key(sigP.data(), b);
+        uint64_t look = bands >= 64 ? ~0ull : ((1ull << bands) - 1);         // bands to look up in this round
+        bool first_round = true;                                 // the pattern's signature is still the seed's own
+        while (look && members < cap && evals < max_eval && failed < patience) {
+            fresh.clear();
+            auto tl = clk::now();
+            for (int b = 0; b < bands; b++) {
+                if (!((look >> b) & 1)) continue;
+                const std::vector<Entry>& t = table[(size_t)b];
+                const uint64_t key = keyP[(size_t)b];
+                auto it = first_round ? t.begin() + slot[(size_t)b * (size_t)U + (size_t)su] + 1
+                                      : std::lower_bound(t.begin(), t.end(), Entry{key, (int32_t)su + 1},
+                                                         [](const Entry& x, const Entry& y) { return x.key != y.key ? x.key < y.key : x.u < y.u; });
+                for (int64_t n = 0; it != t.end() && it->key == key && n < kScanLimit; ++it, ++n) {
+                    const int32_t u = it->u;
+                    if (grouping[uniq[(size_t)u]] != -1) continue;
+                    if (seen[(size_t)u] != (int32_t)su) { seen[(size_t)u] = (int32_t)su; hits[(size_t)u] = 0; fresh.push_back(u); }
+                    else if (hits[(size_t)u] == UINT16_MAX) continue;            // already evaluated for this seed
+                    hits[(size_t)u]++;
+                }
+            }
+            look = 0;
+            first_round = false;
+            if (verbose) t_look += us_since(tl);
+            // rows proposed before and not yet evaluated stay in `cand`; order all pending ones by collisions (desc), row (asc)
+            cand.insert(cand.end(), fresh.begin(), fresh.end());
+            cand.erase(std::remove_if(cand.begin(), cand.end(), [&](int32_t u) { return hits[(size_t)u] == UINT16_MAX || grouping[uniq[(size_t)u]] != -1; }),
+                       cand.end());
+            {                                                    // counting sort by collisions, most first (stable: discovery order inside a class)
+                int64_t cnt[66] = {0};
+                auto klass = [&](int32_t u) { return std::min<int>(hits[(size_t)u], 64); };
+                for (int32_t u : cand) cnt[klass(u)]++;
+                int64_t start[66], acc = 0;
+                for (int hh = 64; hh >= 0; hh--) { start[hh] = acc; acc += cnt[hh]; }
+                sorted.resize(cand.size());
+                for (int32_t u : cand) sorted[(size_t)start[klass(u)]++] = u;
+                cand.swap(sorted);
+            }
+            size_t pos = 0;
+            for (; pos < cand.size() && members < cap && evals < max_eval && failed < patience; pos++) {
+                const int32_t u = cand[pos];
+                const int64_t j = uniq[(size_t)u];
+                hits[(size_t)u] = UINT16_MAX;
+                evals++;
+                c.comparisons++;
+                const float d = c.dist(gsize, j);
+                if (!(d <= tau)) { failed++; continue; }
+                failed = 0;
+                c.total_merge_tau += d;
+                c.total_row_distance += (float)(j - i);
+                c.merges++;
+                take(u, d);
+                if (cfg.use_pattern) {
+                    auto tm = clk::now();
+                    c.merge(j);
+                    c.t_merge += us_since(tm);
+                    const uint32_t* sj = sig.data() + (size_t)u * K;
+                    for (int b = 0; b < bands; b++) {
+                        bool changed = false;
+                        for (int t = 0; t < r; t++)
+                            if (sj[b * r + t] < sigP[(size_t)(b * r + t)]) { sigP[(size_t)(b * r + t)] = sj[b * r + t]; changed = true; }
+                        if (changed) { keyP[(size_t)b] = band_key(sigP.data(), b); look |= 1ull << b; }
+                    }
+                    if (look) { pos++; break; }                  // the pattern moved: propose again before going on
+                }
+            }
+            cand.erase(cand.begin(), cand.begin() + (std::ptrdiff_t)pos);
+            if (!look && cand.empty()) break;
+            if (!look && pos == 0) break;
+        }
+        cand.clear();
+    }
+    c.t_cmp += us_since(t_all);
+    if (verbose) fprintf(stderr, "minhash: seed loop %.2f s (bucket look-ups %.2f s), %lld comparisons, %lld merges\n", us_since(t_all) * 1e-6, t_look * 1e-6,
+                         (long long)c.comparisons, (long long)c.merges);
+}
+
+
 // src/general/utilities.cpp:8-20.  The reference sorts row indices with std::sort (introsort, NOT
 // stable) under `grouping[i] < grouping[j]`; the order of rows inside one group is therefore whatever
 // libstdc++'s introsort leaves.  Calling the same standard algorithm with the same strict-weak order
@@ -774,6 +1035,17 @@ int reorder(const CsrView& a, const sparta_reorder_cfg& cfg, int64_t* grouping_o
         case SPARTA_BLOCKING_ITERATIVE: {
             if (fast) { Ctx c(a, cfg); run(c); }
             else { LiteralCtx c(a, cfg); run(c); }
+            break;
+        }
+        case SPARTA_BLOCKING_MINHASH: {                                          // extension: LSH-bucketed clustering for large inputs
+            if (a.rows > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_reorder: blocking_algo 7 handles up to 2^31 - 1 rows");
+            if (!all_rows_strictly_ascending(a)) return fail(SPARTA_ERR_INVALID, "sparta_reorder: blocking_algo 7 needs strictly ascending columns in every row");
+            Ctx c(a, cfg, false);
+            minhash_lsh(c, grouping_out);
+            st.comparison_counter = c.comparisons; st.merge_counter = c.merges;
+            st.average_merge_tau = c.total_merge_tau / (float)c.merges;
+            st.average_row_distance = c.total_row_distance / (float)c.merges;
+            st.timer_comparisons = c.t_cmp; st.timer_merges = c.t_merge;
             break;
         }
         case SPARTA_BLOCKING_FIXED_SIZE:                                         // :554-562

@@ -166,6 +166,7 @@ class RowBlockExchange:
         self.send_ids = torch.from_numpy(self.send_ids_host).to(dev)
         self.send_buf = torch.empty(max(1, self.n_send * tile), dtype=torch.float32, device=dev)
         self.recv_buf = torch.empty(max(1, self.n_recv * tile), dtype=torch.float32, device=dev)
+        self._send_view, self._recv_view = self.send_buf[:self.n_send * tile], self.recv_buf[:self.n_recv * tile]
         self._pack = pack if pack is not None else self._pack_hip
         self._product = product if product is not None else self._product_hip
         self.d_own = self.d_rem = None
@@ -193,9 +194,7 @@ class RowBlockExchange:
         if self.any_exchange:
             if self.n_send:
                 self._pack(B_own_tiles)
-            tile = self.w * self.N
-            work = dist.all_to_all_single(self.recv_buf[:self.n_recv * tile], self.send_buf[:self.n_send * tile], self.out_splits,
-                                          self.in_splits, group=self.group, async_op=True)
+            work = dist.all_to_all_single(self._recv_view, self._send_view, self.out_splits, self.in_splits, group=self.group, async_op=True)
         self._product("own", B_own_tiles, C_out, accumulate)
         if work is not None:
             work.wait()

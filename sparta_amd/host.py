@@ -8,7 +8,7 @@ from ._lib import lib, check
 
 # BlockingType (include/definitions.h:17) -- values of the `-a` flag
 BLOCKING_ALGOS = dict(iterative=0, iterative_structured=1, fixed_size=2, iterative_clocked=3, iterative_queue=4,
-                      iterative_max_size=5, scramble=6)
+                      iterative_max_size=5, scramble=6, minhash=7)   # 7: extension, not in the reference
 
 _i64p = C.POINTER(C.c_int64)
 _i32p = C.POINTER(C.c_int32)
@@ -125,7 +125,8 @@ class BlockingEngine:
     (include/blocking.h:9-56)."""
 
     def __init__(self, tau=0.5, col_block_size=1, row_block_size=1, use_groups=False, use_pattern=True,
-                 force_fixed_size=False, blocking_algo=3, sim_measure=1, structured_m=2, structured_n=4):
+                 force_fixed_size=False, blocking_algo=3, sim_measure=1, structured_m=2, structured_n=4,
+                 minhash_bands=0, minhash_rows=0, minhash_max_eval=0, minhash_max_rows=0):
         self.tau = tau
         self.col_block_size = col_block_size
         self.row_block_size = row_block_size
@@ -135,6 +136,8 @@ class BlockingEngine:
         self.blocking_algo = BLOCKING_ALGOS.get(blocking_algo, blocking_algo)
         self.sim_measure = sim_measure          # SetComparator(choice): 0 Hamming, 1 Jaccard (blocking.cpp:699-717)
         self.structured_m, self.structured_n = structured_m, structured_n      # blocking_algo 1 (include/blocking.h:20-21)
+        # blocking_algo 7 (extension: LSH-bucketed clustering); 0 = library defaults
+        self.minhash_bands, self.minhash_rows, self.minhash_max_eval, self.minhash_max_rows = minhash_bands, minhash_rows, minhash_max_eval, minhash_max_rows
         self.comparison_counter = 0
         self.merge_counter = 0
         self.timer_total = 0.0
@@ -164,6 +167,8 @@ class BlockingEngine:
         c.use_pattern = int(bool(self.use_pattern))
         c.force_fixed_size = int(bool(self.force_fixed_size))
         c.structured_m, c.structured_n = int(self.structured_m), int(self.structured_n)
+        c.minhash_bands, c.minhash_rows = int(self.minhash_bands), int(self.minhash_rows)
+        c.minhash_max_eval, c.minhash_max_rows = int(self.minhash_max_eval), int(self.minhash_max_rows)
         return c
 
     def GetGrouping(self, cmat):

@@ -153,3 +153,62 @@ def test_near_linear_clocked_form_is_exact(monkeypatch, algo):
             res.append((g.tobytes(), e.comparison_counter, e.merge_counter, np.float32(e.average_merge_tau).tobytes(),
                         np.float32(e.average_row_distance).tobytes()))
         assert res[0] == res[1], (case, rows, cols, w, tau, up)
+
+
+# ---- blocking_algo 7: LSH-bucketed clustering (an extension, approximate by design -- validated by QUALITY) --------------
+
+def _blocks_area(m, g, w):
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    return len(v.jab), int(v.nztot)
+
+
+@pytest.mark.parametrize("name,w,tau", [("fem", 32, 0.6), ("fem", 64, 0.4), ("rmat", 64, 0.6), ("rmat", 32, 0.4), ("uniform", 64, 0.7), ("banded", 16, 0.5)])
+def test_minhash_reorder_quality_against_the_exact_algorithm(name, w, tau):
+    """the scalable reorder is judged by the number of nonzero blocks and the stored area (fill) it
+    reaches relative to the exact algorithm 3 on inputs both can handle."""
+    m = {"fem": lambda: sa.gen.fem3d(7, 7, 60, 3, 2, pattern_only=True), "rmat": lambda: sa.gen.rmat(13, 100000, seed=3, symmetrize=True),
+         "uniform": lambda: sa.gen.uniform_random(6000, 6000, 60000, seed=1, pattern_only=True),
+         "banded": lambda: sa.gen.banded(12000, 12, density=0.5, seed=4, pattern_only=True)}[name]()
+    exact = sa.BlockingEngine(blocking_algo=3, tau=tau, col_block_size=w)
+    lsh = sa.BlockingEngine(blocking_algo="minhash", tau=tau, col_block_size=w)
+    ge, gl = exact.GetGrouping(m), lsh.GetGrouping(m)
+    be, ae = _blocks_area(m, ge, w)
+    bl, al = _blocks_area(m, gl, w)
+    assert bl <= 1.15 * be and al <= 1.15 * ae, (be, bl, ae, al)            # measured: -17 % .. +13 % area, -0.2 % .. +8 % blocks
+    assert lsh.comparison_counter < exact.comparison_counter / 10          # it looks at a small fraction of the pairs
+    # a valid grouping in the reference's convention: the id of a group is its first (seed) row
+    for gid in np.unique(gl):
+        assert gl[gid] == gid and np.flatnonzero(gl == gid)[0] == gid
+    # merges counted = rows that joined a seed
+    assert lsh.merge_counter == m.rows - len(np.unique(gl))
+    # deterministic
+    assert np.array_equal(gl, sa.BlockingEngine(blocking_algo=7, tau=tau, col_block_size=w).GetGrouping(m))
+
+
+def test_minhash_reorder_rules():
+    # identical rows always end up together, whatever tau; empty rows form one group (distance 0 between empty rows)
+    rows = [[0, 5, 9], [], [1, 2], [0, 5, 9], [], [40, 41], [1, 2], [0, 5, 9]]
+    rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])])
+    m = sa.CSR(len(rows), 64, rp, np.array([c for r in rows for c in r], np.int32), None)
+    g = sa.BlockingEngine(blocking_algo=7, tau=0.0, col_block_size=1).GetGrouping(m)
+    assert g.tolist() == [0, 1, 2, 0, 1, 5, 2, 0]
+    # tau = 1 with Jaccard merges everything that shares a bucket with the pattern; a cluster cap stops the growth
+    m2 = sa.gen.banded(400, 3, seed=2, pattern_only=True)
+    e = sa.BlockingEngine(blocking_algo=7, tau=0.9, col_block_size=4, minhash_max_rows=8)
+    g2 = e.GetGrouping(m2)
+    sizes = np.bincount(g2)[np.unique(g2)]
+    assert np.median(sizes) == 8 and sizes.max() < 16      # soft limit: a row's identical copies join together with it
+    assert np.bincount(sa.BlockingEngine(blocking_algo=7, tau=0.9, col_block_size=4).GetGrouping(m2)).max() > 8
+    # force_fixed_size re-chunks the order like for every other algorithm (blocking.cpp:670-673)
+    g3 = sa.BlockingEngine(blocking_algo=7, tau=0.5, col_block_size=4, row_block_size=16, force_fixed_size=True).GetGrouping(m2)
+    assert np.bincount(g3).tolist() == [16] * 25
+    # unsorted rows are refused (the exact algorithms reproduce the reference's behaviour on them; this one does not pretend to)
+    bad = sa.CSR(2, 8, [0, 2, 3], np.array([5, 1, 2], np.int32), None)
+    with pytest.raises(sa.SpartaError):
+        sa.BlockingEngine(blocking_algo=7, tau=0.5, col_block_size=2).GetGrouping(bad)
+    # 0 rows
+    assert sa.BlockingEngine(blocking_algo=7).GetGrouping(sa.CSR(0, 4, [0], np.zeros(0, np.int32), None)).tolist() == []
+    # the other measures / options run too (Hamming, cluster weights, no pattern merging)
+    for kw in (dict(sim_measure=0, tau=3.0), dict(use_groups=True, tau=0.5), dict(use_pattern=False, tau=0.5)):
+        gk = sa.BlockingEngine(blocking_algo=7, col_block_size=4, **kw).GetGrouping(m2)
+        assert len(gk) == 400 and (gk <= np.arange(400)).all()
