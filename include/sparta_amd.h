@@ -280,7 +280,9 @@ int sparta_pack_blocks(const void* src, int64_t block_bytes, const int32_t* ids_
 /* Per-tile-class device timing for roofline reports: when enabled, sparta_vbs_spmm brackets each class
  * launch with HIP events on the launch stream; sparta_vbs_class_times waits for them and writes the last
  * call's milliseconds into ms_out[4]: stream path -> {stream kernel, fix-up kernel, 0, 0};
- * per-class / generic path -> {<=16-row class, <=32-row class, <=64-row class, 0}. */
+ * per-class / generic path -> {<=16-row class, <=32-row class, <=64-row class, sparse-row kernels}.
+ * (Block-rows whose blocks are nearly empty are multiplied as sparse rows, HBM-bound, instead of as MFMA tiles: see
+ * sparta_amd/csrc/vbs_spmm.hip "sparse-row path"; env SPARTA_SPARSE_K=0 keeps everything on the MFMA kernels.) */
 int sparta_vbs_set_class_timing(sparta_vbs_t* A, int32_t enable);
 int sparta_vbs_class_times(sparta_vbs_t* A, float* ms_out);
 

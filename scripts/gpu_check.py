@@ -68,7 +68,7 @@ for tau, fixed in ((0.2, 0), (0.4, 0), (None, 32), (None, 64), (None, 128)):
     info = d.info()
     print('cant-like tau=%s fixed=%s: %.1f us  exec %.1f TF (padded %.1f TF)  useful %.2f TF  tiles %s' % (
         tau, fixed, t * 1e3, 2 * vb.nztot * N / t / 1e9, 2 * info['exec_area'] * N / t / 1e9, 2 * m.nztot() * N / t / 1e9,
-        [info[k] for k in ('tiles16', 'tiles32', 'tiles64', 'tiles128')]))
+        [info[k] for k in ('tiles16', 'tiles32', 'tiles64', 'sparse_rows')]))
     res['cant_%s_%s' % (tau, fixed)] = dict(ms=t, area=vb.nztot)
 os.makedirs('gpurun_out', exist_ok=True)
 json.dump(res, open('gpurun_out/gpu_check.json', 'w'), indent=1)

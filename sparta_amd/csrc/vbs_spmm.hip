@@ -1049,6 +1049,159 @@ __global__ __launch_bounds__(kThreads) void vbs_tail_copy_kernel(const float* B,
     }
 }
 
+// ---- sparse-row path: block-rows whose blocks are almost empty -----------------------------------------------------
+// A block-row of a clustered power-law matrix is typically 1-4 rows tall with 1-2 nonzeros per w-wide block: as a dense
+// tile it executes 32 x w x N multiply-adds and streams a w x N panel of B for a handful of useful products (measured on
+// R-MAT 2^20, fill 2 %: 4 TFLOP/s "executed", 0.09 TFLOP/s useful).  Such block-rows are taken out of the MFMA plans at
+// create time and kept as rows of (column, value) pairs -- the nonzeros of their blocks in the reference's order (blocks
+// ascending, k ascending) -- and multiplied the way the bytes want it: one wave per row, lanes across the columns of C, per
+// nonzero ONE contiguous N-float row of B (row-major; a column-major or gathered B is transposed once per call: 2 x |B|
+// bytes) and one FMA per element.  HBM/L2-bound: N * 4 bytes per nonzero.  This is the "wavefront-level partial sums for
+// thin / ragged blocks" leg of the path; exact zeros of A are skipped (0 * inf of the reference's dense loop is not
+// reproduced: finite B is the contract, as for its padded columns).
+template <int VEC> struct SpVec;
+template <> struct SpVec<1> { typedef float T; };
+template <> struct SpVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct SpVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
+
+struct SparseParams {
+    const int64_t* rowptr;     // [n_rows + 1] into col / val
+    const int32_t* col;
+    const float* val;
+    const int32_t* crow;       // C row of every sparse row
+    const int32_t* list;       // the rows this launch handles (ordinals)
+    int32_t n_list;
+    const float* B;            // row-major, ld = ldb
+    int64_t ldb;
+    float* out;                // row-major out: C itself (ld = ldc, row = crow) or the scratch (ld = N, row = ordinal)
+    int64_t ldo;
+    int32_t out_is_c, accumulate, N;
+};
+
+template <int VEC>
+__device__ __forceinline__ typename SpVec<VEC>::T sparse_row_partial(const SparseParams& p, int64_t p0, int64_t p1, int n0, int lane) {
+    typedef typename SpVec<VEC>::T V;
+    V acc = (V)(0.0f);
+    const bool in = VEC > 1 || n0 < p.N;
+    const float* Bl = p.B + (in ? n0 : 0);
+    for (int64_t q = p0; q < p1; q += 8) {
+        const int n = (int)(p1 - q < 8 ? p1 - q : 8);            // wave-uniform
+        int cl = 0;
+        float vl = 0.0f;
+        if (lane < n) { cl = p.col[q + lane]; vl = p.val[q + lane]; }
+        V b[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const int c = __builtin_amdgcn_readlane(cl, t);      // lanes >= n hold column 0: a valid row, never used
+            b[t] = *reinterpret_cast<const V*>(Bl + (int64_t)c * p.ldb);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vl), t));
+            if (t < n) acc += v * b[t];
+        }
+    }
+    return acc;
+}
+
+template <int VEC>
+__device__ __forceinline__ void sparse_row_store(const SparseParams& p, int ord, typename SpVec<VEC>::T acc, int n0) {
+    typedef typename SpVec<VEC>::T V;
+    if (VEC == 1 && n0 >= p.N) return;
+    float* o = p.out + (int64_t)(p.out_is_c ? p.crow[ord] : ord) * p.ldo + n0;
+    if (p.out_is_c && p.accumulate) acc += *reinterpret_cast<const V*>(o);
+    *reinterpret_cast<V*>(o) = acc;
+}
+
+// rows of ordinary length: one wave per row, 4 rows per workgroup; blockIdx.y walks N in chunks of 64 * VEC columns
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void sparse_rows_kernel(SparseParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= p.n_list) return;
+    const int ord = p.list[slot];
+    const int n0 = (blockIdx.y * 64 + lane) * VEC;
+    const int64_t p0 = p.rowptr[ord], p1 = p.rowptr[ord + 1];
+    sparse_row_store<VEC>(p, ord, sparse_row_partial<VEC>(p, p0, p1, n0, lane), n0);
+}
+
+// long rows (hubs): cut into segments of <= kSpSeg nonzeros, one wave per segment writes a partial row; a second launch adds
+// the partial rows of every long row in segment order (deterministic) and stores the row
+struct SpSegRec { int64_t p0; int32_t cnt, pad; };
+struct SpLongRec { int32_t ord, seg_begin, n_seg, pad; };
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void sparse_segments_kernel(SparseParams p, const SpSegRec* segs, int32_t n_segs, float* part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= n_segs) return;
+    const SpSegRec sg = segs[slot];
+    const int n0 = (blockIdx.y * 64 + lane) * VEC;
+    typename SpVec<VEC>::T acc = sparse_row_partial<VEC>(p, sg.p0, sg.p0 + sg.cnt, n0, lane);
+    if (VEC == 1 && n0 >= p.N) return;
+    *reinterpret_cast<typename SpVec<VEC>::T*>(part + (int64_t)slot * p.N + n0) = acc;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void sparse_reduce_kernel(SparseParams p, const SpLongRec* rows, int32_t n_rows, const float* part) {
+    typedef typename SpVec<VEC>::T V;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= n_rows) return;
+    const SpLongRec r = rows[slot];
+    const int n0 = (blockIdx.y * 64 + lane) * VEC;
+    if (VEC == 1 && n0 >= p.N) return;
+    V acc = (V)(0.0f);
+    for (int sgi = 0; sgi < r.n_seg; sgi++) acc += *reinterpret_cast<const V*>(part + (int64_t)(r.seg_begin + sgi) * p.N + n0);
+    sparse_row_store<VEC>(p, r.ord, acc, n0);
+}
+
+// B (column-major, ld = ldb, or the gathered slabs) -> row-major rows x N (ld = N); 32 x 32 tiles through LDS
+__global__ __launch_bounds__(kThreads) void b_to_row_major_kernel(const float* __restrict__ B, int64_t ldb, int64_t shard_rows, int64_t shard_stride,
+                                                                  int64_t rows, int N, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    const int n0 = blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8) {                           // read: lanes along the rows (contiguous in a column)
+        const int64_t r = r0 + tx;
+        const int n = n0 + j;
+        float v = 0.0f;
+        if (r < rows && n < N) v = shard_rows > 0 ? B[(r / shard_rows) * shard_stride + (r % shard_rows) + (int64_t)n * ldb] : B[r + (int64_t)n * ldb];
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {                           // write: lanes along the columns (contiguous in a row)
+        const int64_t r = r0 + j;
+        const int n = n0 + tx;
+        if (r < rows && n < N) out[r * N + n] = tile[tx][j];
+    }
+}
+
+// scratch (row-major, one row per sparse row) -> the column-major C rows they belong to
+__global__ __launch_bounds__(kThreads) void sparse_c_scatter_kernel(const float* __restrict__ src, const int32_t* __restrict__ crow, int64_t n_rows, int N,
+                                                                    float* __restrict__ C, int64_t ldc, int accumulate) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t t0 = (int64_t)blockIdx.x * 32;
+    const int n0 = blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t t = t0 + j;
+        const int n = n0 + tx;
+        tile[j][tx] = (t < n_rows && n < N) ? src[t * N + n] : 0.0f;
+    }
+    __syncthreads();
+    const int64_t t = t0 + tx;
+    const int32_t r = t < n_rows ? crow[t] : 0;
+    for (int j = ty; j < 32; j += 8) {
+        const int n = n0 + j;
+        if (t < n_rows && n < N) {
+            float* o = C + r + (int64_t)n * ldc;
+            *o = accumulate ? *o + tile[tx][j] : tile[tx][j];
+        }
+    }
+}
+
 // ---- row-block pack (multi-GPU exchange of only the needed rows of B) ---------------------------------
 // dst chunk i <- src chunk ids[i]; a chunk is one w x N tile of B (block_bytes, a multiple of 16).  One workgroup per
 // chunk and grid.y slice; 16-byte loads / stores, fully coalesced: HBM-bound, bytes = 2 x n_blocks x block_bytes.
@@ -1163,6 +1316,22 @@ struct sparta_vbs {
     size_t d_B16_bytes = 0;
     long long* d_clk = nullptr;           // clock probe: [4 launches][4] = {s_memtime, s_memrealtime} at entry, at exit
     hipEvent_t tev0 = nullptr, tev1 = nullptr;
+    // sparse-row path (fp32 handles): the block-rows taken out of the MFMA plans, as rows of (column, value)
+    int64_t n_sp_rows = 0, n_sp_short = 0, n_sp_long = 0, sp_nnz = 0;
+    int64_t* d_sp_rowptr = nullptr;
+    int32_t* d_sp_col = nullptr;
+    float* d_sp_val = nullptr;
+    int32_t* d_sp_crow = nullptr;
+    int32_t* d_sp_list = nullptr;          // the short rows (one wave each)
+    void* d_sp_segs = nullptr;             // SpSegRec[n_sp_segs]: segments of the long rows
+    void* d_sp_long = nullptr;             // SpLongRec[n_sp_long]
+    int64_t n_sp_segs = 0;
+    void* d_sp_part = nullptr;             // partial rows of the segments
+    size_t d_sp_part_bytes = 0;
+    void* d_Brm = nullptr;                 // row-major copy of a column-major / gathered B
+    size_t d_Brm_bytes = 0;
+    void* d_spC = nullptr;                 // row-major results awaiting the scatter into a column-major C
+    size_t d_spC_bytes = 0;
     void* d_B = nullptr;
     size_t d_B_bytes = 0;
     void* d_C = nullptr;
@@ -1233,6 +1402,16 @@ void destroy_impl(sparta_vbs* v) {
     if (v->d_clk) (void)hipFree(v->d_clk);
     if (v->tev0) (void)hipEventDestroy(v->tev0);
     if (v->tev1) (void)hipEventDestroy(v->tev1);
+    if (v->d_sp_rowptr) (void)hipFree(v->d_sp_rowptr);
+    if (v->d_sp_col) (void)hipFree(v->d_sp_col);
+    if (v->d_sp_val) (void)hipFree(v->d_sp_val);
+    if (v->d_sp_crow) (void)hipFree(v->d_sp_crow);
+    if (v->d_sp_list) (void)hipFree(v->d_sp_list);
+    if (v->d_sp_segs) (void)hipFree(v->d_sp_segs);
+    if (v->d_sp_long) (void)hipFree(v->d_sp_long);
+    if (v->d_sp_part) (void)hipFree(v->d_sp_part);
+    if (v->d_Brm) (void)hipFree(v->d_Brm);
+    if (v->d_spC) (void)hipFree(v->d_spC);
     if (v->d_B) (void)hipFree(v->d_B);
     if (v->d_C) (void)hipFree(v->d_C);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -1252,6 +1431,7 @@ struct StreamPlanIn {
     int64_t cols, w, br0, br1, jab_lo, mab_lo;
     const int64_t* row_part; const int64_t* nzcount; const int64_t* jab; const float* mab;
     int32_t dtype, device;
+    const uint8_t* skip;                      // [br1 - br0] block-rows handled by the sparse-row path (no tiles), or nullptr
 };
 struct StreamPlanHost {
     std::vector<StepRec> steps[2];            // per tile type: [0] <= 32 rows, [1] 33..64 rows
@@ -1319,7 +1499,8 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                 for (int64_t ib = br0; ib < br1; ib++) {
                     const int64_t h = row_part[ib + 1] - row_part[ib];
                     const int64_t nb = nzcount[ib];
-                    for (int64_t r0 = 0; r0 < h; r0 += SK_TM) {
+                    const bool skipped = in.skip && in.skip[ib - br0];
+                    for (int64_t r0 = 0; r0 < h && !skipped; r0 += SK_TM) {
                         const int32_t mt = (int32_t)std::min<int64_t>(SK_TM, h - r0);
                         if ((mt > 32 ? 1 : 0) != ty) continue;
                         const int32_t c_row = (int32_t)(row_part[ib] - row0 + r0);
@@ -1553,6 +1734,76 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
     if (ndev <= 0) return fail(SPARTA_ERR_NO_DEVICE, "sparta_vbs_create: no HIP device visible (this path has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: device index out of range");
 
+    // ---- sparse-row path: which block-rows are better served as rows of (column, value) --------------------------------
+    // An MFMA step (one <=32-row tile x 32 k x 128 columns) takes the time of ~12 nonzeros on the sparse-row path (2.1 ns per
+    // step across the 512 workers vs 512 B of B per nonzero and 128-column slab at ~3 TB/s): a block-row whose blocks hold
+    // fewer than SPARTA_SPARSE_K (default 10) nonzeros per step goes there.  SPARTA_SPARSE_K=0 switches the path off.
+    std::vector<uint8_t> sparse_flag;
+    std::vector<int64_t> sp_rowptr;
+    std::vector<int32_t> sp_col, sp_crow, sp_list;
+    std::vector<float> sp_val;
+    std::vector<SpSegRec> sp_segs;
+    std::vector<SpLongRec> sp_long;
+    constexpr int64_t kSpLong = 2048, kSpSeg = 1024;
+    int64_t n_sp_short = 0, n_sp_long = 0;
+    if (!h16) {
+        double K = 10.0;
+        if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
+        if (K > 0.0) {
+            sparse_flag.assign((size_t)(br1 - br0), 0);
+            int64_t jo2 = 0, mo2 = 0, n_flagged = 0;
+            const int64_t row0 = row_part[br0];
+            std::vector<int64_t> cnt;
+            sp_rowptr.push_back(0);
+            for (int64_t ib = br0; ib < br1; ib++) {
+                const int64_t h = row_part[ib + 1] - row_part[ib], nb = nzcount[ib];
+                const float* blk = mab + mab_lo + mo2;
+                const int64_t n_el = nb * h * w;
+                int64_t nnz = 0;
+                for (int64_t q = 0; q < n_el; q++) nnz += blk[q] != 0.0f;
+                const double steps_br = (double)nb * (double)((w + 31) / 32) * (double)((h + 31) / 32);
+                if (h > 0 && nb > 0 && (double)nnz < K * steps_br && (int64_t)sp_col.size() + nnz < ((int64_t)1 << 40)) {
+                    sparse_flag[(size_t)(ib - br0)] = 1;
+                    n_flagged++;
+                    // rows of this block-row: (column, value) in the reference's order (blocks ascending, k ascending: vbr.cpp:358-363)
+                    cnt.assign((size_t)h, 0);
+                    for (int64_t b = 0; b < nb; b++)
+                        for (int64_t k = 0; k < w; k++)
+                            for (int64_t i = 0; i < h; i++) cnt[(size_t)i] += (blk[(b * w + k) * h + i] != 0.0f) && jab[jab_lo + jo2 + b] * w + k < cols;
+                    const size_t base_row = sp_crow.size();
+                    for (int64_t i = 0; i < h; i++) {
+                        sp_crow.push_back((int32_t)(row_part[ib] - row0 + i));
+                        sp_rowptr.push_back(sp_rowptr.back() + cnt[(size_t)i]);
+                    }
+                    sp_col.resize((size_t)sp_rowptr.back());
+                    sp_val.resize((size_t)sp_rowptr.back());
+                    for (int64_t i = 0; i < h; i++) cnt[(size_t)i] = sp_rowptr[base_row + (size_t)i];
+                    for (int64_t b = 0; b < nb; b++) {
+                        const int64_t c0 = jab[jab_lo + jo2 + b] * w;
+                        for (int64_t k = 0; k < w && c0 + k < cols; k++)
+                            for (int64_t i = 0; i < h; i++) {
+                                const float a = blk[(b * w + k) * h + i];
+                                if (a != 0.0f) { sp_col[(size_t)cnt[(size_t)i]] = (int32_t)(c0 + k); sp_val[(size_t)cnt[(size_t)i]++] = a; }
+                            }
+                    }
+                }
+                jo2 += nb;
+                mo2 += n_el;
+            }
+            if (n_flagged == 0) sparse_flag.clear();
+            // short rows: one wave each; rows with more than kSpLong nonzeros (hubs): segments of kSpSeg, one wave each + a reduction
+            for (size_t t = 0; t < sp_crow.size(); t++) {
+                const int64_t p0 = sp_rowptr[t], n = sp_rowptr[t + 1] - p0;
+                if (n <= kSpLong) { sp_list.push_back((int32_t)t); continue; }
+                SpLongRec lr{(int32_t)t, (int32_t)sp_segs.size(), 0, 0};
+                for (int64_t o = 0; o < n; o += kSpSeg) { sp_segs.push_back(SpSegRec{p0 + o, (int32_t)std::min<int64_t>(kSpSeg, n - o), 0}); lr.n_seg++; }
+                sp_long.push_back(lr);
+            }
+            n_sp_short = (int64_t)sp_list.size(); n_sp_long = (int64_t)sp_long.size();
+        }
+    }
+    const uint8_t* skip = sparse_flag.empty() ? nullptr : sparse_flag.data();
+
     // ---- plan: row tiles per class -----------------------------------------------------------------
     std::vector<TileDesc> tiles[4];
     std::vector<BlockRowDesc> brows;
@@ -1572,7 +1823,7 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
             if (h > 0) {
                 BlockRowDesc br{mo2, jo2, (int32_t)nb, (int32_t)h, (int32_t)(row_part[ib] - row0), 0};
                 brows.push_back(br);
-                int64_t r0 = 0;
+                int64_t r0 = skip && skip[ib - br0] ? h : 0;     // sparse-row block-rows get no tiles
                 while (r0 < h) {
                     const int64_t rem = h - r0;
                     int cls;
@@ -1632,7 +1883,7 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
     // ---- stream plans (persistent kernels): see build_stream_plans ----
     StreamPlanHost plan;
     {
-        StreamPlanIn pin{cols, w, br0, br1, jab_lo, mab_lo, row_part, nzcount, jab, mab, dtype, device};
+        StreamPlanIn pin{cols, w, br0, br1, jab_lo, mab_lo, row_part, nzcount, jab, mab, dtype, device, skip};
         if (int rc = build_stream_plans(pin, plan)) return rc;
     }
     std::vector<StepRec>(&steps)[2] = plan.steps;
@@ -1710,6 +1961,32 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
         CREATE_TRY(hipMalloc((void**)&v->d_fix_slots, std::max<size_t>(fix_slots.size(), 1) * sizeof(int32_t)));
         if (!fix_slots.empty()) CREATE_TRY(hipMemcpy(v->d_fix_slots, fix_slots.data(), fix_slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    if (!sp_crow.empty()) {
+        v->n_sp_rows = (int64_t)sp_crow.size(); v->n_sp_short = n_sp_short; v->n_sp_long = n_sp_long; v->sp_nnz = sp_rowptr.back();
+        CREATE_TRY(hipMalloc((void**)&v->d_sp_rowptr, sp_rowptr.size() * sizeof(int64_t)));
+        CREATE_TRY(hipMemcpy(v->d_sp_rowptr, sp_rowptr.data(), sp_rowptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc((void**)&v->d_sp_col, (sp_col.size() + 64) * sizeof(int32_t)));      // +64: a batch reads up to 8 entries at once
+        CREATE_TRY(hipMemset(v->d_sp_col, 0, (sp_col.size() + 64) * sizeof(int32_t)));
+        CREATE_TRY(hipMalloc((void**)&v->d_sp_val, (sp_val.size() + 64) * sizeof(float)));
+        CREATE_TRY(hipMemset(v->d_sp_val, 0, (sp_val.size() + 64) * sizeof(float)));
+        if (!sp_col.empty()) {
+            CREATE_TRY(hipMemcpy(v->d_sp_col, sp_col.data(), sp_col.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMemcpy(v->d_sp_val, sp_val.data(), sp_val.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        CREATE_TRY(hipMalloc((void**)&v->d_sp_crow, sp_crow.size() * sizeof(int32_t)));
+        CREATE_TRY(hipMemcpy(v->d_sp_crow, sp_crow.data(), sp_crow.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (!sp_list.empty()) {
+            CREATE_TRY(hipMalloc((void**)&v->d_sp_list, sp_list.size() * sizeof(int32_t)));
+            CREATE_TRY(hipMemcpy(v->d_sp_list, sp_list.data(), sp_list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        if (!sp_long.empty()) {
+            v->n_sp_segs = (int64_t)sp_segs.size();
+            CREATE_TRY(hipMalloc(&v->d_sp_segs, sp_segs.size() * sizeof(SpSegRec)));
+            CREATE_TRY(hipMemcpy(v->d_sp_segs, sp_segs.data(), sp_segs.size() * sizeof(SpSegRec), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc(&v->d_sp_long, sp_long.size() * sizeof(SpLongRec)));
+            CREATE_TRY(hipMemcpy(v->d_sp_long, sp_long.data(), sp_long.size() * sizeof(SpLongRec), hipMemcpyHostToDevice));
+        }
+    }
     CREATE_TRY(hipEventCreate(&v->ev0));
     CREATE_TRY(hipEventCreate(&v->ev1));
     CREATE_TRY(hipEventCreate(&v->tev0));
@@ -1733,7 +2010,8 @@ int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info) {
     if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_info: NULL argument");
     std::memset(info, 0, 16 * sizeof(int64_t));
     info[0] = A->rows; info[1] = A->cols; info[2] = A->block_rows; info[3] = A->w; info[4] = A->nblocks; info[5] = A->nztot;
-    for (int c = 0; c < 4; c++) info[6 + c] = A->n_real_tiles[c];
+    for (int c = 0; c < 3; c++) info[6 + c] = A->n_real_tiles[c];
+    info[9] = A->n_sp_rows;                // rows handled by the sparse-row path
     info[10] = A->a_bytes; info[11] = A->exec_area;
     info[12] = A->n_steps[0] + A->n_steps[1]; info[13] = A->n_workers; info[14] = A->n_split; info[15] = A->last_path;
     return SPARTA_OK;
@@ -2040,6 +2318,61 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
         if (path == 1) { if (int rc = run_stream(dC, prof)) return rc; }
         else if (int rc = run_class(dC, path == 3, prof)) return rc;
         A->last_path = path;
+
+        // ---- the block-rows kept as sparse rows (disjoint rows of C: order against the MFMA launches does not matter) ----
+        if (A->n_sp_rows > 0) {
+            if (prof) HIP_TRY(hipEventRecord(A->cev[3][0], st));
+            SparseParams q;
+            q.rowptr = A->d_sp_rowptr; q.col = A->d_sp_col; q.val = A->d_sp_val; q.crow = A->d_sp_crow;
+            q.N = n_cols; q.accumulate = accumulate != 0;
+            if (b_layout == SPARTA_ROW_MAJOR && shard_rows == 0) { q.B = dB; q.ldb = ldb; }
+            else {
+                if (int rc = ensure_scratch(&A->d_Brm, &A->d_Brm_bytes, (size_t)A->cols * (size_t)n_cols * sizeof(float))) return rc;
+                hipLaunchKernelGGL(b_to_row_major_kernel, dim3((unsigned)((A->cols + 31) / 32), (unsigned)((n_cols + 31) / 32)), dim3(kThreads), 0, st,
+                                   dB, ldb, shard_rows, shard_stride, A->cols, (int)n_cols, (float*)A->d_Brm);
+                q.B = (const float*)A->d_Brm; q.ldb = n_cols;
+            }
+            if (c_layout == SPARTA_ROW_MAJOR) { q.out = dC; q.ldo = ldc; q.out_is_c = 1; }
+            else {
+                if (int rc = ensure_scratch(&A->d_spC, &A->d_spC_bytes, (size_t)A->n_sp_rows * (size_t)n_cols * sizeof(float))) return rc;
+                q.out = (float*)A->d_spC; q.ldo = n_cols; q.out_is_c = 0;
+            }
+            // widest vector the shapes allow: every row start 4 * VEC-byte aligned, N a multiple of 64 * VEC (no ragged chunk)
+            int vec = 1;
+            auto aligned = [&](int v) {
+                return n_cols % (64 * v) == 0 && q.ldb % v == 0 && q.ldo % v == 0 && ((uintptr_t)q.B % (4 * v)) == 0 && ((uintptr_t)q.out % (4 * v)) == 0;
+            };
+            if (aligned(4)) vec = 4; else if (aligned(2)) vec = 2;
+            const unsigned gy = (unsigned)((n_cols + 64 * vec - 1) / (64 * vec));
+            if (A->n_sp_short > 0) {
+                q.list = A->d_sp_list; q.n_list = (int32_t)A->n_sp_short;
+                const dim3 grid((unsigned)((A->n_sp_short + 3) / 4), gy);
+                if (vec == 4) hipLaunchKernelGGL(sparse_rows_kernel<4>, grid, dim3(kThreads), 0, st, q);
+                else if (vec == 2) hipLaunchKernelGGL(sparse_rows_kernel<2>, grid, dim3(kThreads), 0, st, q);
+                else hipLaunchKernelGGL(sparse_rows_kernel<1>, grid, dim3(kThreads), 0, st, q);
+            }
+            if (A->n_sp_long > 0) {
+                if (int rc = ensure_scratch(&A->d_sp_part, &A->d_sp_part_bytes, (size_t)A->n_sp_segs * (size_t)n_cols * sizeof(float))) return rc;
+                const SpSegRec* segs = (const SpSegRec*)A->d_sp_segs;
+                const SpLongRec* lrows = (const SpLongRec*)A->d_sp_long;
+                float* part = (float*)A->d_sp_part;
+                const dim3 g1((unsigned)((A->n_sp_segs + 3) / 4), gy), g2((unsigned)((A->n_sp_long + 3) / 4), gy);
+                if (vec == 4) {
+                    hipLaunchKernelGGL(sparse_segments_kernel<4>, g1, dim3(kThreads), 0, st, q, segs, (int32_t)A->n_sp_segs, part);
+                    hipLaunchKernelGGL(sparse_reduce_kernel<4>, g2, dim3(kThreads), 0, st, q, lrows, (int32_t)A->n_sp_long, (const float*)part);
+                } else if (vec == 2) {
+                    hipLaunchKernelGGL(sparse_segments_kernel<2>, g1, dim3(kThreads), 0, st, q, segs, (int32_t)A->n_sp_segs, part);
+                    hipLaunchKernelGGL(sparse_reduce_kernel<2>, g2, dim3(kThreads), 0, st, q, lrows, (int32_t)A->n_sp_long, (const float*)part);
+                } else {
+                    hipLaunchKernelGGL(sparse_segments_kernel<1>, g1, dim3(kThreads), 0, st, q, segs, (int32_t)A->n_sp_segs, part);
+                    hipLaunchKernelGGL(sparse_reduce_kernel<1>, g2, dim3(kThreads), 0, st, q, lrows, (int32_t)A->n_sp_long, (const float*)part);
+                }
+            }
+            if (!q.out_is_c)
+                hipLaunchKernelGGL(sparse_c_scatter_kernel, dim3((unsigned)((A->n_sp_rows + 31) / 32), (unsigned)((n_cols + 31) / 32)), dim3(kThreads), 0, st,
+                                   (const float*)A->d_spC, A->d_sp_crow, A->n_sp_rows, (int)n_cols, dC, ldc, (int)(accumulate != 0));
+            if (prof) { HIP_TRY(hipEventRecord(A->cev[3][1], st)); A->class_ran[3] = true; }
+        }
     }
     HIP_TRY(hipGetLastError());
     if (dt_ms) {

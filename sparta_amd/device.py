@@ -35,7 +35,7 @@ class DeviceVBS:
         a = np.zeros(16, np.int64)
         check(lib.sparta_vbs_info(self.h, a.ctypes.data_as(_i64p)))
         keys = ["rows", "cols", "block_rows", "block_col_size", "nblocks", "nztot", "tiles16", "tiles32", "tiles64",
-                "tiles128", "a_bytes", "exec_area", "stream_steps", "stream_workers", "split_tiles", "last_path"]
+                "sparse_rows", "a_bytes", "exec_area", "stream_steps", "stream_workers", "split_tiles", "last_path"]
         return {k: int(a[i]) for i, k in enumerate(keys)}
 
     def spmm_host(self, B, n_cols, C_out, accumulate=True, algo=_lib.SPMM_MFMA, b_layout=_lib.COL_MAJOR,
@@ -100,12 +100,13 @@ class DeviceVBS:
 
     def class_times(self):
         """ms of the last spmm per kernel (needs set_class_timing(True)).  Stream path (info()['last_path'] == 1):
-        {'stream': main persistent kernel, 'fixup': split-tile fix-up}; generic path: per tile class {16, 32, 64}."""
+        {'stream': main persistent kernel, 'fixup': split-tile fix-up}; generic path: per tile class {16, 32, 64}; 'sparse':
+        the sparse-row kernels (+ the transposes of B / C they need), 0 when the handle has no such rows."""
         a = np.zeros(4, np.float32)
         check(lib.sparta_vbs_class_times(self.h, a.ctypes.data_as(_f32p)))
         if self.info()["last_path"] == 1:
-            return {"stream": float(a[0]), "fixup": float(a[1])}
-        return {"class16": float(a[0]), "class32": float(a[1]), "class64": float(a[2])}
+            return {"stream": float(a[0]), "fixup": float(a[1]), "sparse": float(a[3])}
+        return {"class16": float(a[0]), "class32": float(a[1]), "class64": float(a[2]), "sparse": float(a[3])}
 
     def clock_mhz(self):
         """Shader clock (MHz) the product kernels of the last timed spmm ran at, keyed like class_times()

@@ -11,6 +11,17 @@ from oracle import oracle as O
 import _util as U
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["mfma-only", "with-sparse-rows"])
+def _sparse_row_mode(request, monkeypatch):
+    """every test runs twice: with the sparse-row path switched off (all block-rows on the MFMA kernels) and with the
+    library's own choice (nearly empty block-rows -- most of the small test matrices -- go to the sparse-row kernels)"""
+    if request.param == "mfma-only":
+        monkeypatch.setenv("SPARTA_SPARSE_K", "0")
+    else:
+        monkeypatch.delenv("SPARTA_SPARSE_K", raising=False)
+    return request.param
 TOL = 1e-5
 
 
@@ -391,7 +402,7 @@ def test_product_paths_vs_oracle(monkeypatch, path, rows, cols, nnz, w, blk, n):
             Ct = torch.full((v.rows * n,), 5.0, dtype=torch.float32, device="cuda")
             d.spmm(Bt, Ct, n, accumulate=False, b_layout=bl, c_layout=cl)
             torch.cuda.synchronize()
-            assert d.info()["last_path"] == want_path
+            assert d.info()["last_path"] == want_path or d.info()["sparse_rows"] == v.rows     # (every block-row on the sparse-row path: no MFMA launch at all)
             got = Ct.cpu().numpy()
             if cl == sa.ROW_MAJOR:
                 got = np.ascontiguousarray(got.reshape(v.rows, n).T).reshape(-1)
@@ -617,3 +628,79 @@ def test_huge_leading_dimensions_take_the_64bit_kernels():
     assert float(Ct.view(n, ld)[:, v.rows:v.rows + 8].min()) == 3.0          # nothing written outside the rows of C
     del Bt, Ct
     torch.cuda.empty_cache()
+
+
+# ---- sparse-row path: nearly empty block-rows are multiplied as rows of (column, value) --------------------------------
+
+@pytest.mark.parametrize("n", [1, 37, 64, 128, 256, 320])
+def test_sparse_row_path_mixed_matrix(_sparse_row_mode, n):
+    """a matrix with BOTH kinds of block-rows: dense clusters (MFMA tiles) and scattered singletons, a hub row (> 4096 nonzeros:
+    the workgroup-per-row kernel), empty rows, a ragged last block column; every layout, accumulate, host pointers, gathered B"""
+    torch = _torch()
+    rng = np.random.Generator(np.random.PCG64(5))
+    rows, cols, w = 700, 9000 + 13, 32
+    rr, cc = [], []
+    for i in range(0, 256):                                   # dense part: 256 rows sharing 40 columns blocks -> tall, full blocks
+        c = rng.choice(1280, 400, replace=False)
+        rr.append(np.full(400, i)); cc.append(c)
+    for i in range(256, 690):                                 # scattered part: 1-6 nonzeros anywhere
+        k = int(rng.integers(1, 7))
+        rr.append(np.full(k, i)); cc.append(rng.choice(cols, k, replace=False))
+    rr.append(np.full(6000, 690)); cc.append(rng.choice(cols, 6000, replace=False))     # hub row
+    r, c = np.concatenate(rr), np.concatenate(cc)                                        # rows 691..699 stay empty
+    order = np.lexsort((c, r))
+    r, c = r[order], c[order]
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=rows))])
+    m = sa.CSR(rows, cols, rowptr, c.astype(np.int32), rng.uniform(-1, 1, len(c)).astype(np.float32))
+    g = sa.BlockingEngine(tau=0.5, col_block_size=w).GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=11)
+    Co = _oracle_c(v, B, n)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+    d = v.to_device(0)
+    info = d.info()
+    if _sparse_row_mode == "with-sparse-rows":
+        assert 0 < info["sparse_rows"] < v.rows and info["tiles16"] + info["tiles32"] + info["tiles64"] > 0
+    else:
+        assert info["sparse_rows"] == 0
+    Bcm = torch.from_numpy(B).cuda()
+    Brm = torch.from_numpy(np.ascontiguousarray(B.reshape(n, v.cols).T).reshape(-1)).cuda()
+    for bl, Bt in ((sa.COL_MAJOR, Bcm), (sa.ROW_MAJOR, Brm)):
+        for cl in (sa.COL_MAJOR, sa.ROW_MAJOR):
+            for acc in (False, True):
+                C0 = sa.gen.dense_rhs(v.rows, n, seed=12)
+                Ct = torch.from_numpy(C0 if cl == sa.COL_MAJOR else np.ascontiguousarray(C0.reshape(n, v.rows).T).reshape(-1)).cuda()
+                d.spmm(Bt, Ct, n, accumulate=acc, b_layout=bl, c_layout=cl)
+                torch.cuda.synchronize()
+                got = Ct.cpu().numpy()
+                if cl == sa.ROW_MAJOR:
+                    got = np.ascontiguousarray(got.reshape(v.rows, n).T).reshape(-1)
+                want = _oracle_c(v, B, n, C0) if acc else Co
+                _check(got, want, bound + (np.abs(C0) if acc else 0), "sparse rows n=%d layouts %d %d acc %d" % (n, bl, cl, acc))
+    # host pointers (the reference's contract: C += A * B)
+    Ch = sa.gen.dense_rhs(v.rows, n, seed=13)
+    want = _oracle_c(v, B, n, Ch)
+    d.spmm_host(B, n, Ch, accumulate=True)
+    _check(Ch, want, bound + np.abs(want), "sparse rows, host pointers")
+    # the exact-order kernel still covers every row
+    Ce = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
+    d.spmm(Bcm, Ce, n, algo=sa.SPMM_EXACT)
+    torch.cuda.synchronize()
+    assert np.array_equal(Ce.cpu().numpy(), Co)
+
+
+def test_sparse_row_path_gathered_b(_sparse_row_mode):
+    torch = _torch()
+    world, w, n = 2, 16, 96
+    m = sa.gen.uniform_random(500, 2 * 640, 4000, seed=8)          # scattered: everything goes to the sparse-row path
+    n_pad = 640
+    v = sa.VBR().fill_from_CSR_inplace(m, sa.BlockingEngine(tau=0.3, col_block_size=w).GetGrouping(m), w)
+    gathered = np.concatenate([sa.gen.dense_rhs(n_pad, n, seed=60 + r) for r in range(world)])
+    Bfull = sa.dist.gathered_to_colmajor(gathered, world, n_pad, n)
+    d = v.to_device(0)
+    Ct = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
+    d.spmm_gathered(torch.from_numpy(gathered).cuda(), n_pad, Ct, n)
+    torch.cuda.synchronize()
+    _check(Ct.cpu().numpy(), _oracle_c(v, Bfull, n), U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, Bfull, n), "sparse rows, gathered B")
+    if _sparse_row_mode == "with-sparse-rows":
+        assert d.info()["sparse_rows"] > 0
