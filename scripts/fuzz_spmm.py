@@ -38,7 +38,12 @@ for case in range(n_cases):
     Cs = torch.zeros_like(Ce)
     da.spmm(B.abs(), Cs, n, algo=sa.SPMM_EXACT)
     tol = 1e-5 * Cs + 1e-30
-    for path in ("auto", "stream", "class", "generic"):
+    # sparse-row path: off / the library's choice / forced for every block-row that has a block
+    for path, spk in [(p_, k_) for p_ in ("auto", "stream", "class", "generic") for k_ in ("0", None)] + [("auto", "1e9")]:
+        if spk is None:
+            os.environ.pop("SPARTA_SPARSE_K", None)
+        else:
+            os.environ["SPARTA_SPARSE_K"] = spk
         for align in (("0", "1") if path == "stream" else ("",)):
             os.environ["SPARTA_PATH"] = path
             if align:
@@ -54,7 +59,7 @@ for case in range(n_cases):
                 err = (C - want).abs()
                 if bool((err > tol + (1e-6 if acc else 0.0)).any()):
                     bad += 1
-                    print("MISMATCH case", case, dict(rows=rows, cols=cols, nnz=nnz, w=w, n=n, kind=kind, path=path, align=align, acc=acc),
+                    print("MISMATCH case", case, dict(rows=rows, cols=cols, nnz=nnz, w=w, n=n, kind=kind, path=path, align=align, acc=acc, sparse_k=spk),
                           "max err", float(err.max()), "last_path", d2.info()["last_path"])
     if w % 32 == 0 and n % 128 == 0:
         for dt, tdt in ((sa.F16, torch.float16), (sa.BF16, torch.bfloat16)):
