@@ -1064,6 +1064,15 @@ template <> struct SpVec<1> { typedef float T; };
 template <> struct SpVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
 template <> struct SpVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
 
+template <int VEC> struct SpRaw16;        // VEC 16-bit values as loaded
+template <> struct SpRaw16<1> { typedef unsigned short T; };
+template <> struct SpRaw16<2> { typedef unsigned short T __attribute__((ext_vector_type(2))); };
+template <> struct SpRaw16<4> { typedef unsigned short T __attribute__((ext_vector_type(4))); };
+
+__device__ __forceinline__ float sp_widen(unsigned short u, bool bf16) {
+    return bf16 ? __builtin_bit_cast(float, (uint32_t)u << 16) : (float)__builtin_bit_cast(_Float16, u);
+}
+
 struct SparseParams {
     const int64_t* rowptr;     // [n_rows + 1] into col / val
     const int32_t* col;
@@ -1071,34 +1080,43 @@ struct SparseParams {
     const int32_t* crow;       // C row of every sparse row
     const int32_t* list;       // the rows this launch handles (ordinals)
     int32_t n_list;
-    const float* B;            // row-major, ld = ldb
+    const void* B;             // row-major, ld = ldb elements; fp32 (BK = 0), fp16 (1) or bf16 (2)
     int64_t ldb;
     float* out;                // row-major out: C itself (ld = ldc, row = crow) or the scratch (ld = N, row = ordinal)
     int64_t ldo;
     int32_t out_is_c, accumulate, N;
 };
 
-template <int VEC>
+template <int VEC, int BK>
 __device__ __forceinline__ typename SpVec<VEC>::T sparse_row_partial(const SparseParams& p, int64_t p0, int64_t p1, int n0, int lane) {
     typedef typename SpVec<VEC>::T V;
+    typedef typename std::conditional<BK == 0, float, unsigned short>::type E;
+    typedef typename std::conditional<BK == 0, V, typename SpRaw16<VEC>::T>::type L;
     V acc = (V)(0.0f);
     const bool in = VEC > 1 || n0 < p.N;
-    const float* Bl = p.B + (in ? n0 : 0);
+    const E* Bl = (const E*)p.B + (in ? n0 : 0);
     for (int64_t q = p0; q < p1; q += 8) {
         const int n = (int)(p1 - q < 8 ? p1 - q : 8);            // wave-uniform
         int cl = 0;
         float vl = 0.0f;
         if (lane < n) { cl = p.col[q + lane]; vl = p.val[q + lane]; }
-        V b[8];
+        L b[8];
 #pragma unroll
         for (int t = 0; t < 8; t++) {
             const int c = __builtin_amdgcn_readlane(cl, t);      // lanes >= n hold column 0: a valid row, never used
-            b[t] = *reinterpret_cast<const V*>(Bl + (int64_t)c * p.ldb);
+            b[t] = *reinterpret_cast<const L*>(Bl + (int64_t)c * p.ldb);
         }
 #pragma unroll
         for (int t = 0; t < 8; t++) {
             const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vl), t));
-            if (t < n) acc += v * b[t];
+            if (t < n) {
+                if constexpr (BK == 0) acc += v * b[t];
+                else if constexpr (VEC == 1) acc += v * sp_widen(b[t], BK == 2);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VEC; e++) acc[e] += v * sp_widen(b[t][e], BK == 2);
+                }
+            }
         }
     }
     return acc;
@@ -1114,7 +1132,7 @@ __device__ __forceinline__ void sparse_row_store(const SparseParams& p, int ord,
 }
 
 // rows of ordinary length: one wave per row, 4 rows per workgroup; blockIdx.y walks N in chunks of 64 * VEC columns
-template <int VEC>
+template <int VEC, int BK>
 __global__ __launch_bounds__(kThreads) void sparse_rows_kernel(SparseParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = blockIdx.x * 4 + wave;
@@ -1122,7 +1140,7 @@ __global__ __launch_bounds__(kThreads) void sparse_rows_kernel(SparseParams p) {
     const int ord = p.list[slot];
     const int n0 = (blockIdx.y * 64 + lane) * VEC;
     const int64_t p0 = p.rowptr[ord], p1 = p.rowptr[ord + 1];
-    sparse_row_store<VEC>(p, ord, sparse_row_partial<VEC>(p, p0, p1, n0, lane), n0);
+    sparse_row_store<VEC>(p, ord, sparse_row_partial<VEC, BK>(p, p0, p1, n0, lane), n0);
 }
 
 // long rows (hubs): cut into segments of <= kSpSeg nonzeros, one wave per segment writes a partial row; a second launch adds
@@ -1130,14 +1148,14 @@ __global__ __launch_bounds__(kThreads) void sparse_rows_kernel(SparseParams p) {
 struct SpSegRec { int64_t p0; int32_t cnt, pad; };
 struct SpLongRec { int32_t ord, seg_begin, n_seg, pad; };
 
-template <int VEC>
+template <int VEC, int BK>
 __global__ __launch_bounds__(kThreads) void sparse_segments_kernel(SparseParams p, const SpSegRec* segs, int32_t n_segs, float* part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = blockIdx.x * 4 + wave;
     if (slot >= n_segs) return;
     const SpSegRec sg = segs[slot];
     const int n0 = (blockIdx.y * 64 + lane) * VEC;
-    typename SpVec<VEC>::T acc = sparse_row_partial<VEC>(p, sg.p0, sg.p0 + sg.cnt, n0, lane);
+    typename SpVec<VEC>::T acc = sparse_row_partial<VEC, BK>(p, sg.p0, sg.p0 + sg.cnt, n0, lane);
     if (VEC == 1 && n0 >= p.N) return;
     *reinterpret_cast<typename SpVec<VEC>::T*>(part + (int64_t)slot * p.N + n0) = acc;
 }
@@ -1157,16 +1175,17 @@ __global__ __launch_bounds__(kThreads) void sparse_reduce_kernel(SparseParams p,
 }
 
 // B (column-major, ld = ldb, or the gathered slabs) -> row-major rows x N (ld = N); 32 x 32 tiles through LDS
-__global__ __launch_bounds__(kThreads) void b_to_row_major_kernel(const float* __restrict__ B, int64_t ldb, int64_t shard_rows, int64_t shard_stride,
-                                                                  int64_t rows, int N, float* __restrict__ out) {
-    __shared__ float tile[32][33];
+template <class E>
+__global__ __launch_bounds__(kThreads) void b_to_row_major_kernel(const E* __restrict__ B, int64_t ldb, int64_t shard_rows, int64_t shard_stride,
+                                                                  int64_t rows, int N, E* __restrict__ out) {
+    __shared__ E tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
     const int64_t r0 = (int64_t)blockIdx.x * 32;
     const int n0 = blockIdx.y * 32;
     for (int j = ty; j < 32; j += 8) {                           // read: lanes along the rows (contiguous in a column)
         const int64_t r = r0 + tx;
         const int n = n0 + j;
-        float v = 0.0f;
+        E v = (E)0;
         if (r < rows && n < N) v = shard_rows > 0 ? B[(r / shard_rows) * shard_stride + (r % shard_rows) + (int64_t)n * ldb] : B[r + (int64_t)n * ldb];
         tile[j][tx] = v;
     }
@@ -1746,7 +1765,15 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
     std::vector<SpLongRec> sp_long;
     constexpr int64_t kSpLong = 2048, kSpSeg = 1024;
     int64_t n_sp_short = 0, n_sp_long = 0;
-    if (!h16) {
+    // 16-bit handles: the values the kernels multiply are the ROUNDED ones (a value that rounds to zero is a zero)
+    const bool bf16h = dtype == SPARTA_BF16;
+    auto stored = [&](float x) -> float {
+        if (!h16) return x;
+        const uint16_t u = to_h16(x, bf16h);
+        if (bf16h) { const uint32_t v32 = (uint32_t)u << 16; float f; std::memcpy(&f, &v32, 4); return f; }
+        _Float16 hh; std::memcpy(&hh, &u, 2); return (float)hh;
+    };
+    {
         double K = 10.0;
         if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
         if (K > 0.0) {
@@ -1760,8 +1787,9 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
                 const float* blk = mab + mab_lo + mo2;
                 const int64_t n_el = nb * h * w;
                 int64_t nnz = 0;
-                for (int64_t q = 0; q < n_el; q++) nnz += blk[q] != 0.0f;
-                const double steps_br = (double)nb * (double)((w + 31) / 32) * (double)((h + 31) / 32);
+                for (int64_t q = 0; q < n_el; q++) nnz += stored(blk[q]) != 0.0f;
+                const int64_t kdep = h16 && w % 64 == 0 ? 64 : 32;                     // k depth of a step of the kernels this handle would use
+                const double steps_br = (double)nb * (double)((w + kdep - 1) / kdep) * (double)((h + 31) / 32);
                 if (h > 0 && nb > 0 && (double)nnz < K * steps_br && (int64_t)sp_col.size() + nnz < ((int64_t)1 << 40)) {
                     sparse_flag[(size_t)(ib - br0)] = 1;
                     n_flagged++;
@@ -1769,7 +1797,7 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
                     cnt.assign((size_t)h, 0);
                     for (int64_t b = 0; b < nb; b++)
                         for (int64_t k = 0; k < w; k++)
-                            for (int64_t i = 0; i < h; i++) cnt[(size_t)i] += (blk[(b * w + k) * h + i] != 0.0f) && jab[jab_lo + jo2 + b] * w + k < cols;
+                            for (int64_t i = 0; i < h; i++) cnt[(size_t)i] += (stored(blk[(b * w + k) * h + i]) != 0.0f) && jab[jab_lo + jo2 + b] * w + k < cols;
                     const size_t base_row = sp_crow.size();
                     for (int64_t i = 0; i < h; i++) {
                         sp_crow.push_back((int32_t)(row_part[ib] - row0 + i));
@@ -1782,7 +1810,7 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
                         const int64_t c0 = jab[jab_lo + jo2 + b] * w;
                         for (int64_t k = 0; k < w && c0 + k < cols; k++)
                             for (int64_t i = 0; i < h; i++) {
-                                const float a = blk[(b * w + k) * h + i];
+                                const float a = stored(blk[(b * w + k) * h + i]);
                                 if (a != 0.0f) { sp_col[(size_t)cnt[(size_t)i]] = (int32_t)(c0 + k); sp_val[(size_t)cnt[(size_t)i]++] = a; }
                             }
                     }
@@ -2055,6 +2083,65 @@ void launch_h16(bool bf16, dim3 grid, hipStream_t st, const StreamParams& sp) {
     else hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, false>), grid, dim3(kThreads), 0, st, sp);
 }
 
+// sparse-row path, shared by the fp32 and the 16-bit handles.  bk: element type of B (0 fp32, 1 fp16, 2 bf16); C is fp32.
+template <int VEC, int BK>
+void launch_sparse_kernels(sparta_vbs_t* A, SparseParams q, unsigned gy, int32_t n_cols, hipStream_t st) {
+    if (A->n_sp_short > 0) {
+        q.list = A->d_sp_list; q.n_list = (int32_t)A->n_sp_short;
+        hipLaunchKernelGGL((sparse_rows_kernel<VEC, BK>), dim3((unsigned)((A->n_sp_short + 3) / 4), gy), dim3(kThreads), 0, st, q);
+    }
+    if (A->n_sp_long > 0) {
+        float* part = (float*)A->d_sp_part;
+        hipLaunchKernelGGL((sparse_segments_kernel<VEC, BK>), dim3((unsigned)((A->n_sp_segs + 3) / 4), gy), dim3(kThreads), 0, st, q,
+                           (const SpSegRec*)A->d_sp_segs, (int32_t)A->n_sp_segs, part);
+        hipLaunchKernelGGL(sparse_reduce_kernel<VEC>, dim3((unsigned)((A->n_sp_long + 3) / 4), gy), dim3(kThreads), 0, st, q,
+                           (const SpLongRec*)A->d_sp_long, (int32_t)A->n_sp_long, (const float*)part);
+    }
+}
+
+int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_major, int64_t shard_rows, int64_t shard_stride, int bk,
+                       int32_t n_cols, float* dC, int64_t ldc, bool c_row_major, bool accumulate, hipStream_t st) {
+    const size_t esz = bk == 0 ? 4 : 2;
+    SparseParams q;
+    q.rowptr = A->d_sp_rowptr; q.col = A->d_sp_col; q.val = A->d_sp_val; q.crow = A->d_sp_crow;
+    q.list = nullptr; q.n_list = 0;
+    q.N = n_cols; q.accumulate = accumulate;
+    if (b_row_major && shard_rows == 0) { q.B = dB; q.ldb = ldb; }
+    else {
+        if (int rc = ensure_scratch(&A->d_Brm, &A->d_Brm_bytes, (size_t)A->cols * (size_t)n_cols * esz)) return rc;
+        const dim3 grid((unsigned)((A->cols + 31) / 32), (unsigned)((n_cols + 31) / 32));
+        if (bk == 0) hipLaunchKernelGGL(b_to_row_major_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)dB, ldb, shard_rows, shard_stride, A->cols, (int)n_cols, (float*)A->d_Brm);
+        else hipLaunchKernelGGL(b_to_row_major_kernel<unsigned short>, grid, dim3(kThreads), 0, st, (const unsigned short*)dB, ldb, shard_rows, shard_stride, A->cols, (int)n_cols, (unsigned short*)A->d_Brm);
+        q.B = A->d_Brm; q.ldb = n_cols;
+    }
+    if (c_row_major) { q.out = dC; q.ldo = ldc; q.out_is_c = 1; }
+    else {
+        if (int rc = ensure_scratch(&A->d_spC, &A->d_spC_bytes, (size_t)A->n_sp_rows * (size_t)n_cols * sizeof(float))) return rc;
+        q.out = (float*)A->d_spC; q.ldo = n_cols; q.out_is_c = 0;
+    }
+    if (A->n_sp_long > 0)
+        if (int rc = ensure_scratch(&A->d_sp_part, &A->d_sp_part_bytes, (size_t)A->n_sp_segs * (size_t)n_cols * sizeof(float))) return rc;
+    // widest vector the shapes allow: every row start VEC-element aligned, N a multiple of 64 * VEC (no ragged chunk)
+    auto aligned = [&](int v) {
+        return n_cols % (64 * v) == 0 && q.ldb % v == 0 && q.ldo % v == 0 && ((uintptr_t)q.B % (esz * v)) == 0 && ((uintptr_t)q.out % (4 * v)) == 0;
+    };
+    const int vec = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
+    const unsigned gy = (unsigned)((n_cols + 64 * vec - 1) / (64 * vec));
+#define SPARTA_SP_DISPATCH(V_)                                                             \
+    do {                                                                                   \
+        if (bk == 0) launch_sparse_kernels<V_, 0>(A, q, gy, n_cols, st);                   \
+        else if (bk == 1) launch_sparse_kernels<V_, 1>(A, q, gy, n_cols, st);              \
+        else launch_sparse_kernels<V_, 2>(A, q, gy, n_cols, st);                           \
+    } while (0)
+    if (vec == 4) SPARTA_SP_DISPATCH(4); else if (vec == 2) SPARTA_SP_DISPATCH(2); else SPARTA_SP_DISPATCH(1);
+#undef SPARTA_SP_DISPATCH
+    if (!q.out_is_c)
+        hipLaunchKernelGGL(sparse_c_scatter_kernel, dim3((unsigned)((A->n_sp_rows + 31) / 32), (unsigned)((n_cols + 31) / 32)), dim3(kThreads), 0, st,
+                           (const float*)A->d_spC, A->d_sp_crow, A->n_sp_rows, (int)n_cols, dC, ldc, (int)accumulate);
+    HIP_TRY(hipGetLastError());
+    return SPARTA_OK;
+}
+
 // 16-bit handles (SPARTA_F16 / SPARTA_BF16): A and B in the 16-bit type, fp32 accumulation, fp32 C.  Device pointers: B is a
 // 16-bit column-major matrix (ldb in elements, even).  Host pointers keep the reference's contract (fp32 B in, fp32 C out):
 // B is converted on the device (round to nearest even).
@@ -2125,6 +2212,11 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
         hipLaunchKernelGGL(vbs_spmm_f32_fixup_kernel, dim3((unsigned)A->n_fix, (unsigned)n_nt), dim3(kThreads), 0, st, A->d_fix, A->d_fix_slots,
                            (const float*)A->d_ws, (int64_t)slab, dC, ldc, (int)(c_layout == SPARTA_ROW_MAJOR), (int)(accumulate != 0));
         if (prof) { HIP_TRY(hipEventRecord(A->cev[1][1], st)); A->class_ran[1] = true; }
+    }
+    if (A->n_sp_rows > 0) {                  // nearly empty block-rows: sparse rows over a row-major 16-bit copy of B
+        if (prof) HIP_TRY(hipEventRecord(A->cev[3][0], st));
+        if (int rc = launch_sparse_rows(A, dB, ldb16, false, 0, 0, bf16 ? 2 : 1, n_cols, dC, ldc, c_layout == SPARTA_ROW_MAJOR, accumulate != 0, st)) return rc;
+        if (prof) { HIP_TRY(hipEventRecord(A->cev[3][1], st)); A->class_ran[3] = true; }
     }
     A->last_path = 1;
     HIP_TRY(hipGetLastError());
@@ -2322,55 +2414,8 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
         // ---- the block-rows kept as sparse rows (disjoint rows of C: order against the MFMA launches does not matter) ----
         if (A->n_sp_rows > 0) {
             if (prof) HIP_TRY(hipEventRecord(A->cev[3][0], st));
-            SparseParams q;
-            q.rowptr = A->d_sp_rowptr; q.col = A->d_sp_col; q.val = A->d_sp_val; q.crow = A->d_sp_crow;
-            q.N = n_cols; q.accumulate = accumulate != 0;
-            if (b_layout == SPARTA_ROW_MAJOR && shard_rows == 0) { q.B = dB; q.ldb = ldb; }
-            else {
-                if (int rc = ensure_scratch(&A->d_Brm, &A->d_Brm_bytes, (size_t)A->cols * (size_t)n_cols * sizeof(float))) return rc;
-                hipLaunchKernelGGL(b_to_row_major_kernel, dim3((unsigned)((A->cols + 31) / 32), (unsigned)((n_cols + 31) / 32)), dim3(kThreads), 0, st,
-                                   dB, ldb, shard_rows, shard_stride, A->cols, (int)n_cols, (float*)A->d_Brm);
-                q.B = (const float*)A->d_Brm; q.ldb = n_cols;
-            }
-            if (c_layout == SPARTA_ROW_MAJOR) { q.out = dC; q.ldo = ldc; q.out_is_c = 1; }
-            else {
-                if (int rc = ensure_scratch(&A->d_spC, &A->d_spC_bytes, (size_t)A->n_sp_rows * (size_t)n_cols * sizeof(float))) return rc;
-                q.out = (float*)A->d_spC; q.ldo = n_cols; q.out_is_c = 0;
-            }
-            // widest vector the shapes allow: every row start 4 * VEC-byte aligned, N a multiple of 64 * VEC (no ragged chunk)
-            int vec = 1;
-            auto aligned = [&](int v) {
-                return n_cols % (64 * v) == 0 && q.ldb % v == 0 && q.ldo % v == 0 && ((uintptr_t)q.B % (4 * v)) == 0 && ((uintptr_t)q.out % (4 * v)) == 0;
-            };
-            if (aligned(4)) vec = 4; else if (aligned(2)) vec = 2;
-            const unsigned gy = (unsigned)((n_cols + 64 * vec - 1) / (64 * vec));
-            if (A->n_sp_short > 0) {
-                q.list = A->d_sp_list; q.n_list = (int32_t)A->n_sp_short;
-                const dim3 grid((unsigned)((A->n_sp_short + 3) / 4), gy);
-                if (vec == 4) hipLaunchKernelGGL(sparse_rows_kernel<4>, grid, dim3(kThreads), 0, st, q);
-                else if (vec == 2) hipLaunchKernelGGL(sparse_rows_kernel<2>, grid, dim3(kThreads), 0, st, q);
-                else hipLaunchKernelGGL(sparse_rows_kernel<1>, grid, dim3(kThreads), 0, st, q);
-            }
-            if (A->n_sp_long > 0) {
-                if (int rc = ensure_scratch(&A->d_sp_part, &A->d_sp_part_bytes, (size_t)A->n_sp_segs * (size_t)n_cols * sizeof(float))) return rc;
-                const SpSegRec* segs = (const SpSegRec*)A->d_sp_segs;
-                const SpLongRec* lrows = (const SpLongRec*)A->d_sp_long;
-                float* part = (float*)A->d_sp_part;
-                const dim3 g1((unsigned)((A->n_sp_segs + 3) / 4), gy), g2((unsigned)((A->n_sp_long + 3) / 4), gy);
-                if (vec == 4) {
-                    hipLaunchKernelGGL(sparse_segments_kernel<4>, g1, dim3(kThreads), 0, st, q, segs, (int32_t)A->n_sp_segs, part);
-                    hipLaunchKernelGGL(sparse_reduce_kernel<4>, g2, dim3(kThreads), 0, st, q, lrows, (int32_t)A->n_sp_long, (const float*)part);
-                } else if (vec == 2) {
-                    hipLaunchKernelGGL(sparse_segments_kernel<2>, g1, dim3(kThreads), 0, st, q, segs, (int32_t)A->n_sp_segs, part);
-                    hipLaunchKernelGGL(sparse_reduce_kernel<2>, g2, dim3(kThreads), 0, st, q, lrows, (int32_t)A->n_sp_long, (const float*)part);
-                } else {
-                    hipLaunchKernelGGL(sparse_segments_kernel<1>, g1, dim3(kThreads), 0, st, q, segs, (int32_t)A->n_sp_segs, part);
-                    hipLaunchKernelGGL(sparse_reduce_kernel<1>, g2, dim3(kThreads), 0, st, q, lrows, (int32_t)A->n_sp_long, (const float*)part);
-                }
-            }
-            if (!q.out_is_c)
-                hipLaunchKernelGGL(sparse_c_scatter_kernel, dim3((unsigned)((A->n_sp_rows + 31) / 32), (unsigned)((n_cols + 31) / 32)), dim3(kThreads), 0, st,
-                                   (const float*)A->d_spC, A->d_sp_crow, A->n_sp_rows, (int)n_cols, dC, ldc, (int)(accumulate != 0));
+            if (int rc = launch_sparse_rows(A, dB, ldb, b_layout == SPARTA_ROW_MAJOR, shard_rows, shard_stride, 0, n_cols, dC, ldc,
+                                            c_layout == SPARTA_ROW_MAJOR, accumulate != 0, st)) return rc;
             if (prof) { HIP_TRY(hipEventRecord(A->cev[3][1], st)); A->class_ran[3] = true; }
         }
     }

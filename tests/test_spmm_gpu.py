@@ -637,6 +637,14 @@ def test_sparse_row_path_mixed_matrix(_sparse_row_mode, n):
     """a matrix with BOTH kinds of block-rows: dense clusters (MFMA tiles) and scattered singletons, a hub row (> 4096 nonzeros:
     the workgroup-per-row kernel), empty rows, a ragged last block column; every layout, accumulate, host pointers, gathered B"""
     torch = _torch()
+    m, w = _mixed_matrix()
+    g = sa.BlockingEngine(tau=0.5, col_block_size=w).GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=11)
+    _mixed_checks(torch, _sparse_row_mode, v, w, B, n)
+
+
+def _mixed_matrix():
     rng = np.random.Generator(np.random.PCG64(5))
     rows, cols, w = 700, 9000 + 13, 32
     rr, cc = [], []
@@ -651,10 +659,10 @@ def test_sparse_row_path_mixed_matrix(_sparse_row_mode, n):
     order = np.lexsort((c, r))
     r, c = r[order], c[order]
     rowptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=rows))])
-    m = sa.CSR(rows, cols, rowptr, c.astype(np.int32), rng.uniform(-1, 1, len(c)).astype(np.float32))
-    g = sa.BlockingEngine(tau=0.5, col_block_size=w).GetGrouping(m)
-    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
-    B = sa.gen.dense_rhs(v.cols, n, seed=11)
+    return sa.CSR(rows, cols, rowptr, c.astype(np.int32), rng.uniform(-1, 1, len(c)).astype(np.float32)), w
+
+
+def _mixed_checks(torch, _sparse_row_mode, v, w, B, n):
     Co = _oracle_c(v, B, n)
     bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
     d = v.to_device(0)
@@ -704,3 +712,36 @@ def test_sparse_row_path_gathered_b(_sparse_row_mode):
     _check(Ct.cpu().numpy(), _oracle_c(v, Bfull, n), U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, Bfull, n), "sparse rows, gathered B")
     if _sparse_row_mode == "with-sparse-rows":
         assert d.info()["sparse_rows"] > 0
+
+
+@pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("n", [128, 256])
+def test_sparse_row_path_16bit(_sparse_row_mode, dtype, n):
+    """16-bit handles: the sparse rows hold the ROUNDED values of A and read a row-major 16-bit copy of B; reference = the oracle
+    on the rounded inputs (products of two 16-bit values are exact in fp32), tolerance as everywhere"""
+    torch = _torch()
+    m, w = _mixed_matrix()
+    v = sa.VBR().fill_from_CSR_inplace(m, sa.BlockingEngine(tau=0.5, col_block_size=w).GetGrouping(m), w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=21)
+    mab_r, B_r = _round16(v.mab, dtype), _round16(B, dtype)
+    Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n, None)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n)
+    d = v.to_device(0, dtype=dtype)
+    assert (d.info()["sparse_rows"] > 0) == (_sparse_row_mode == "with-sparse-rows")
+    tdt = torch.float16 if dtype == sa.F16 else torch.bfloat16
+    ldb = (v.cols + 7) // 8 * 8
+    Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    Bt.view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
+    for cl in (sa.COL_MAJOR, sa.ROW_MAJOR):
+        for acc in (False, True):
+            C0 = sa.gen.dense_rhs(v.rows, n, seed=22)
+            Ct = torch.from_numpy(C0 if cl == sa.COL_MAJOR else np.ascontiguousarray(C0.reshape(n, v.rows).T).reshape(-1)).cuda()
+            d.spmm(Bt, Ct, n, ldb=ldb, c_layout=cl, accumulate=acc)
+            torch.cuda.synchronize()
+            got = Ct.cpu().numpy()
+            if cl == sa.ROW_MAJOR:
+                got = np.ascontiguousarray(got.reshape(v.rows, n).T).reshape(-1)
+            _check(got, Co + (C0 if acc else 0), bound + (np.abs(C0) if acc else 0), "16-bit sparse rows c_layout %d acc %d" % (cl, acc))
+    Ch = np.zeros(v.rows * n, np.float32)
+    d.spmm_host(B, n, Ch, accumulate=False)
+    _check(Ch, Co, bound, "16-bit sparse rows, host pointers")
