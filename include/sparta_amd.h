@@ -303,6 +303,10 @@ int sparta_vbs_destroy(sparta_vbs_t* A);
  *  [15] kernel path of the last sparta_vbs_spmm: 1 stream, 2 per-class, 3 generic */
 int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info_out);
 
+/* the sparse-row part of the plan. info_out (int64[4]): [0] rows [1] nonzeros kept as (column, value) pairs
+ * [2] rows handled one wave each [3] hub rows (cut into segments) */
+int sparta_vbs_sparse_info(const sparta_vbs_t* A, int64_t* info_out);
+
 /* number of visible HIP devices (0 when none); never initialises a device context */
 int sparta_device_count(void);
 

@@ -2045,6 +2045,12 @@ int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info) {
     return SPARTA_OK;
 }
 
+int sparta_vbs_sparse_info(const sparta_vbs_t* A, int64_t* info) {
+    if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_sparse_info: NULL argument");
+    info[0] = A->n_sp_rows; info[1] = A->sp_nnz; info[2] = A->n_sp_short; info[3] = A->n_sp_long;
+    return SPARTA_OK;
+}
+
 #ifdef SPARTA_TIMELINE
 // developer build only: the raw timeline words (4 waves x 64 steps x 8)
 int sparta_debug_timeline(sparta_vbs_t* A, long long* out) {

@@ -38,6 +38,12 @@ class DeviceVBS:
                 "sparse_rows", "a_bytes", "exec_area", "stream_steps", "stream_workers", "split_tiles", "last_path"]
         return {k: int(a[i]) for i, k in enumerate(keys)}
 
+    def sparse_info(self):
+        """the part of the matrix on the sparse-row path: rows, nonzeros, rows handled by one wave, hub rows"""
+        a = np.zeros(4, np.int64)
+        check(lib.sparta_vbs_sparse_info(self.h, a.ctypes.data_as(_i64p)))
+        return {"rows": int(a[0]), "nnz": int(a[1]), "short_rows": int(a[2]), "hub_rows": int(a[3])}
+
     def spmm_host(self, B, n_cols, C_out, accumulate=True, algo=_lib.SPMM_MFMA, b_layout=_lib.COL_MAJOR,
                   c_layout=_lib.COL_MAJOR):
         """Host buffers in, host buffers out (the reference back-ends' contract). Returns kernel ms."""
