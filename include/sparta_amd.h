@@ -243,6 +243,16 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
                             const int64_t* row_part, const int64_t* nzcount, const int64_t* jab, const float* mab,
                             int64_t block_row_begin, int64_t block_row_end, int32_t dtype, int32_t device);
 
+/* Device handle straight from the CSR and a grouping, for matrices whose VBS image is mostly zeros (clustered power-law graphs:
+ * 98 % of the stored area): does what sparta_vbs_build + sparta_vbs_create do, except that the block-rows the sparse-row
+ * kernels will take anyway are never expanded into dense blocks -- neither on the host nor on the device.  Same product as a
+ * handle made the two-step way (same decisions, same kernels, same data).  Columns must be strictly ascending within a row.
+ * SPARTA_SPMM_EXACT is not available on such a handle.  No reference counterpart (the reference always expands:
+ * src/general/vbr.cpp:205-228). */
+int sparta_vbs_create_from_csr(sparta_vbs_t** out, int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals,
+                               const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, int32_t force_fixed_size,
+                               int32_t dtype, int32_t device);
+
 /* C (+)= A * B.  Replaces VBR::multiply(B, B_cols, C) (include/matrices.h:121) and the GPU back-ends
  *   cublas_fixed_blocks_multiply / cublas_blockmat_batched / cutlas_* (const VBR&, DataT* B, int B_cols,
  *   DataT_C* C, float& dt[, int n_streams])            (include/cuda_utilities.h:38-44,

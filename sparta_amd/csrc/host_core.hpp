@@ -39,6 +39,15 @@ std::vector<int64_t> merge_rows(const int64_t* a, int64_t na, const int64_t* b, 
 // ---- VBS builder (vbs_build.cpp) -------------------------------------------------------------
 int vbs_build(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t row_block_size,
               bool force_fixed_size, sparta_vbs_host* out);
+// hybrid build (sparta_vbs_create_from_csr): the block-rows left to the device's sparse-row path, as rows of (column, value)
+struct HybridSparse {
+    std::vector<uint8_t> flag;        // per block-row: 1 = not in the dense image
+    std::vector<int64_t> rowptr;      // rows of the flagged block-rows, in reordered order
+    std::vector<int32_t> col, crow;   // crow: reordered row index (= row of C)
+    std::vector<float> val;
+};
+int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, bool force_fixed_size,
+                     double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp);
 int blocking_info(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t* info_out, float* avg_height_out);
 
 }  // namespace sparta

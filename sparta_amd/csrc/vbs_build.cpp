@@ -63,13 +63,24 @@ struct BlockCollector {
 
 int vbs_build(const CsrView& a, const int64_t* grouping, int64_t w, int64_t row_block_size, bool force_fixed,
               sparta_vbs_host* out) {
+    return vbs_build_hybrid(a, grouping, w, row_block_size, force_fixed, 0.0, 32, out, nullptr);
+}
+
+// The same builder, optionally "hybrid" (sp != nullptr, K > 0): block-rows whose blocks would hold fewer than K nonzeros per
+// MFMA step (one <=32-row tile x kdep columns of a block) are NOT materialised as dense blocks -- `out` gets nzcount = 0 for
+// them -- and come back in `sp` as rows of (column, value) in reordered row order, for the device's sparse-row path
+// (sparta_vbs_create_from_csr).  A clustered power-law matrix is 98 % zeros inside its blocks: the dense image of a
+// 20 M-nonzero R-MAT matrix is 4 GB, of a 124 M-nonzero one 25 GB, all of it skipped by the kernels that then run.
+int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64_t row_block_size, bool force_fixed,
+                     double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp) {
     if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_build: out is NULL");
     std::memset(out, 0, sizeof(*out));
     if (w <= 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_build: col_block_size must be > 0");
     if (force_fixed && row_block_size <= 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_build: force_fixed_size needs row_block_size > 0");
     if (a.rows <= 0 || a.cols <= 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_build: empty matrix");
     if (!grouping) return fail(SPARTA_ERR_INVALID, "sparta_vbs_build: grouping is NULL");
-    if (int rc = validate_csr(a, false)) return rc;
+    const bool hybrid = sp != nullptr && K > 0.0;
+    if (int rc = validate_csr(a, hybrid)) return rc;                      // the sparse rows are taken as they are: ascending, no duplicates
 
     std::vector<int64_t> part = get_partition(grouping, a.rows);          // vbr.cpp:139
     std::vector<int64_t> perm = get_permutation(grouping, a.rows);        // vbr.cpp:140
@@ -100,6 +111,44 @@ int vbs_build(const CsrView& a, const int64_t* grouping, int64_t w, int64_t row_
         }
     });
 
+    // hybrid: decide per block-row, empty the dense image of the sparse ones, collect their rows
+    if (hybrid) {
+        sp->flag.assign((size_t)block_rows, 0);
+        sp->rowptr.assign(1, 0);
+        sp->col.clear(); sp->val.clear(); sp->crow.clear();
+        for (int64_t ib = 0; ib < block_rows; ib++) {
+            const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0, nb = out->nzcount[ib];
+            if (h <= 0 || nb <= 0) continue;
+            int64_t nnz = 0;
+            for (int64_t r = r0; r < r1; r++) {
+                const int64_t i = perm[(size_t)r];
+                if (i >= a.rows) continue;
+                const float* v = a.vals ? a.vals + a.rowptr[i] : nullptr;
+                const int64_t n = a.nnz_of(i);
+                if (!v) { nnz += n; continue; }
+                for (int64_t k = 0; k < n; k++) nnz += v[k] != 0.0f;
+            }
+            const double steps_br = (double)nb * (double)((w + kdep - 1) / kdep) * (double)((h + 31) / 32);
+            if (!((double)nnz < K * steps_br)) continue;
+            sp->flag[(size_t)ib] = 1;
+            out->nzcount[ib] = 0;
+            for (int64_t r = r0; r < r1; r++) {
+                const int64_t i = perm[(size_t)r];
+                if (i < a.rows) {
+                    const int32_t* cj = a.row(i);
+                    const float* v = a.vals ? a.vals + a.rowptr[i] : nullptr;
+                    const int64_t n = a.nnz_of(i);
+                    for (int64_t k = 0; k < n; k++) {
+                        const float x = v ? v[k] : 1.0f;                  // pattern-only matrices store 1 (vbr.cpp:217)
+                        if (x != 0.0f) { sp->col.push_back(cj[k]); sp->val.push_back(x); }
+                    }
+                }
+                sp->crow.push_back((int32_t)r);                           // padded rows too: they are rows of C
+                sp->rowptr.push_back((int64_t)sp->col.size());
+            }
+        }
+    }
+
     // offsets
     std::vector<int64_t> jab_off((size_t)block_rows + 1, 0), mab_off((size_t)block_rows + 1, 0);
     for (int64_t ib = 0; ib < block_rows; ib++) {
@@ -118,6 +167,7 @@ int vbs_build(const CsrView& a, const int64_t* grouping, int64_t w, int64_t row_
         BlockCollector bc(block_cols);
         for (int64_t ib = lo; ib < hi; ib++) {
             const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
+            if (hybrid && sp->flag[(size_t)ib]) continue;                 // not materialised
             bc.collect(a, perm.data(), r0, r1, w, (int32_t)(ib - lo + 1));
             int64_t* jab = out->jab + jab_off[(size_t)ib];
             for (size_t s = 0; s < bc.touched.size(); s++) jab[s] = bc.touched[s];

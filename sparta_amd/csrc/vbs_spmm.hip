@@ -1337,6 +1337,7 @@ struct sparta_vbs {
     hipEvent_t tev0 = nullptr, tev1 = nullptr;
     // sparse-row path (fp32 handles): the block-rows taken out of the MFMA plans, as rows of (column, value)
     int64_t n_sp_rows = 0, n_sp_short = 0, n_sp_long = 0, sp_nnz = 0;
+    bool ext_sparse = false;               // created from CSR: the sparse rows have no dense image (no exact-order kernel for them)
     int64_t* d_sp_rowptr = nullptr;
     int32_t* d_sp_col = nullptr;
     float* d_sp_val = nullptr;
@@ -1718,9 +1719,11 @@ int sparta_device_count(void) {
     return n;
 }
 
-int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
-                            const int64_t* nzcount, const int64_t* jab, const float* mab, int64_t br0, int64_t br1, int32_t dtype,
-                            int32_t device) {
+// `ext` (sparta_vbs_create_from_csr): the sparse-row part of the matrix decided and collected by the hybrid host builder --
+// those block-rows have nzcount = 0 in the arrays given here and must get neither tiles nor zero-fill records.
+static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
+                       const int64_t* nzcount, const int64_t* jab, const float* mab, int64_t br0, int64_t br1, int32_t dtype,
+                       int32_t device, const sparta::HybridSparse* ext) {
     using sparta::fail;
     if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: out is NULL");
     *out = nullptr;
@@ -1773,7 +1776,21 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
         if (bf16h) { const uint32_t v32 = (uint32_t)u << 16; float f; std::memcpy(&f, &v32, 4); return f; }
         _Float16 hh; std::memcpy(&hh, &u, 2); return (float)hh;
     };
-    {
+    if (ext) {
+        sparse_flag = ext->flag;
+        bool any = false;
+        for (uint8_t f : sparse_flag) any = any || f;
+        if (!any) sparse_flag.clear();
+        sp_rowptr.assign(1, 0);
+        for (size_t t = 0; t < ext->crow.size(); t++) {
+            for (int64_t k = ext->rowptr[t]; k < ext->rowptr[t + 1]; k++) {
+                const float a = stored(ext->val[(size_t)k]);
+                if (a != 0.0f && ext->col[(size_t)k] < cols) { sp_col.push_back(ext->col[(size_t)k]); sp_val.push_back(a); }
+            }
+            sp_crow.push_back(ext->crow[t]);
+            sp_rowptr.push_back((int64_t)sp_col.size());
+        }
+    } else {
         double K = 10.0;
         if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
         if (K > 0.0) {
@@ -1819,6 +1836,10 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
                 mo2 += n_el;
             }
             if (n_flagged == 0) sparse_flag.clear();
+        }
+    }
+    {
+        {
             // short rows: one wave each; rows with more than kSpLong nonzeros (hubs): segments of kSpSeg, one wave each + a reduction
             for (size_t t = 0; t < sp_crow.size(); t++) {
                 const int64_t p0 = sp_rowptr[t], n = sp_rowptr[t + 1] - p0;
@@ -2022,6 +2043,43 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
 #undef CREATE_TRY
     *out = v;
     return SPARTA_OK;
+}
+
+int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
+                            const int64_t* nzcount, const int64_t* jab, const float* mab, int64_t br0, int64_t br1, int32_t dtype,
+                            int32_t device) {
+    return create_core(out, rows, cols, block_rows, w, row_part, nzcount, jab, mab, br0, br1, dtype, device, nullptr);
+}
+
+int sparta_vbs_create_from_csr(sparta_vbs_t** out, int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals,
+                               const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, int32_t force_fixed_size,
+                               int32_t dtype, int32_t device) {
+    using sparta::fail;
+    if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create_from_csr: out is NULL");
+    *out = nullptr;
+    if (dtype != SPARTA_F32 && dtype != SPARTA_F16 && dtype != SPARTA_BF16) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create_from_csr: bad dtype");
+    sparta_vbs_host h;
+    std::memset(&h, 0, sizeof(h));
+    int rc = SPARTA_OK;
+    try {
+        sparta::CsrView a;
+        a.rows = rows; a.cols = cols; a.rowptr = rowptr; a.colidx = colidx; a.vals = vals;
+        double K = 10.0;
+        if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
+        const int64_t kdep = (dtype != SPARTA_F32 && col_block_size % 64 == 0) ? 64 : 32;
+        sparta::HybridSparse sp;
+        rc = sparta::vbs_build_hybrid(a, grouping, col_block_size, row_block_size, force_fixed_size != 0, K, kdep, &h, K > 0.0 ? &sp : nullptr);
+        if (rc == SPARTA_OK)
+            rc = create_core(out, h.rows, h.cols, h.block_rows, col_block_size, h.row_part, h.nzcount, h.jab, h.mab, 0, h.block_rows, dtype, device,
+                             K > 0.0 ? &sp : nullptr);
+        if (rc == SPARTA_OK && K > 0.0) (*out)->ext_sparse = true;
+    } catch (const std::bad_alloc&) {
+        rc = fail(SPARTA_ERR_ALLOC, "sparta_vbs_create_from_csr: out of host memory");
+    } catch (const std::exception& e) {
+        rc = fail(SPARTA_ERR_INVALID, std::string("sparta_vbs_create_from_csr: ") + e.what());
+    }
+    sparta_vbs_host_free(&h);
+    return rc;
 }
 
 int sparta_vbs_create(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
@@ -2273,6 +2331,8 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
         dC = (float*)A->d_C;
     }
 
+    if (algo == SPARTA_SPMM_EXACT && A->ext_sparse && A->n_sp_rows > 0)
+        return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: SPARTA_SPMM_EXACT needs the dense image of every block-row (handle made by sparta_vbs_create_from_csr)");
     if (dt_ms) HIP_TRY(hipEventRecord(A->ev0, st));
     if (algo == SPARTA_SPMM_EXACT) {
         if (A->n_brows > 0) {

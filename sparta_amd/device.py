@@ -20,6 +20,8 @@ class DeviceVBS:
         self.device = int(device)
         self.dtype = dtype
         self.h = C.c_void_p(None)
+        if vbmat is None:                      # from_csr fills the handle
+            return
         rp = np.ascontiguousarray(vbmat.row_part, np.int64)
         nz = np.ascontiguousarray(vbmat.nzcount, np.int64)
         jab = np.ascontiguousarray(vbmat.jab, np.int64)
@@ -30,6 +32,24 @@ class DeviceVBS:
                                           mab.ctypes.data_as(_f32p), int(b0), int(b1), int(dtype), self.device))
         info = self.info()
         self.rows, self.cols = info["rows"], info["cols"]
+
+    @classmethod
+    def from_csr(cls, cmat, grouping, col_block_size, row_block_size=0, force_fixed_size=False, device=0, dtype=_lib.F32):
+        """sparta_vbs_create_from_csr: build + upload in one step without expanding the nearly empty block-rows into dense blocks
+        (what makes 10^8-nonzero power-law matrices fit); same product as VBR().fill_from_CSR_inplace(...).to_device()."""
+        self = cls(None, device=device, dtype=dtype)
+        g = np.ascontiguousarray(grouping, np.int64)
+        if g.shape != (cmat.rows,):
+            raise ValueError("grouping must have one entry per row")
+        rp = np.ascontiguousarray(cmat.rowptr, np.int64)
+        ci = np.ascontiguousarray(cmat.colidx, np.int32)
+        vals = None if cmat.vals is None else np.ascontiguousarray(cmat.vals, np.float32)
+        check(lib.sparta_vbs_create_from_csr(C.byref(self.h), cmat.rows, cmat.cols, rp.ctypes.data_as(_i64p), ci.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             None if vals is None else vals.ctypes.data_as(_f32p), g.ctypes.data_as(_i64p), int(col_block_size),
+                                             int(row_block_size), int(bool(force_fixed_size)), int(dtype), self.device))
+        info = self.info()
+        self.rows, self.cols = info["rows"], info["cols"]
+        return self
 
     def info(self):
         a = np.zeros(16, np.int64)

@@ -745,3 +745,57 @@ def test_sparse_row_path_16bit(_sparse_row_mode, dtype, n):
     Ch = np.zeros(v.rows * n, np.float32)
     d.spmm_host(B, n, Ch, accumulate=False)
     _check(Ch, Co, bound, "16-bit sparse rows, host pointers")
+
+
+@pytest.mark.parametrize("dtype", [sa.F32, sa.F16], ids=["f32", "f16"])
+@pytest.mark.parametrize("case", ["mixed", "rmat", "rmat-fixed"])
+def test_create_from_csr_gives_the_same_product(_sparse_row_mode, case, dtype):
+    """sparta_vbs_create_from_csr never expands the nearly empty block-rows; the product must be BIT-identical to the one of a
+    handle made by sparta_vbs_build + sparta_vbs_create (same decisions, same kernels, same data), and equal to the oracle's"""
+    torch = _torch()
+    n = 128
+    if case == "mixed":
+        m, w = _mixed_matrix()
+        eng, rbs, ff = sa.BlockingEngine(tau=0.5, col_block_size=w), 0, False
+    else:
+        m, w = sa.gen.rmat(13, 60000, seed=5, symmetrize=True, pattern_only=(case == "rmat")), 32
+        ff = case == "rmat-fixed"
+        rbs = 24 if ff else 0
+        eng = sa.BlockingEngine(blocking_algo=7, tau=0.5, col_block_size=w, row_block_size=max(rbs, 1), force_fixed_size=ff)
+    g = eng.GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w, rbs, ff)
+    d1 = v.to_device(0, dtype=dtype)
+    d2 = sa.DeviceVBS.from_csr(m, g, w, rbs, ff, device=0, dtype=dtype)
+    i1, i2 = d1.info(), d2.info()
+    assert (i1["rows"], i1["cols"], i1["sparse_rows"], i1["tiles16"], i1["tiles32"], i1["tiles64"]) == \
+           (i2["rows"], i2["cols"], i2["sparse_rows"], i2["tiles16"], i2["tiles32"], i2["tiles64"])
+    assert d1.sparse_info() == d2.sparse_info()
+    if _sparse_row_mode == "with-sparse-rows":
+        assert i2["sparse_rows"] > 0 and i2["nztot"] < i1["nztot"]               # the dense image shrank
+    tdt = {sa.F32: torch.float32, sa.F16: torch.float16}[dtype]
+    ldb = (v.cols + 7) // 8 * 8
+    B = sa.gen.dense_rhs(v.cols, n, seed=31)
+    Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    Bt.view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
+    for cl in (sa.COL_MAJOR, sa.ROW_MAJOR):
+        for acc in (False, True):
+            C1 = torch.full((v.rows * n,), 0.25, dtype=torch.float32, device="cuda")
+            C2 = C1.clone()
+            d1.spmm(Bt, C1, n, ldb=ldb, c_layout=cl, accumulate=acc)
+            d2.spmm(Bt, C2, n, ldb=ldb, c_layout=cl, accumulate=acc)
+            torch.cuda.synchronize()
+            assert torch.equal(C1, C2), (case, cl, acc)
+    if dtype == sa.F32:
+        Co = _oracle_c(v, B, n)
+        C2 = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
+        d2.spmm(Bt, C2, n, ldb=ldb)
+        torch.cuda.synchronize()
+        _check(C2.cpu().numpy(), Co, U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n), "from_csr " + case)
+        if i2["sparse_rows"] > 0:
+            with pytest.raises(sa.SpartaError):
+                d2.spmm(Bt, C2, n, ldb=ldb, algo=sa.SPMM_EXACT)
+    # unsorted columns are refused (the sparse rows are taken as they are)
+    if _sparse_row_mode == "with-sparse-rows":
+        bad = sa.CSR(2, 8, [0, 2, 3], np.array([5, 1, 2], np.int32), None)
+        with pytest.raises(sa.SpartaError):
+            sa.DeviceVBS.from_csr(bad, np.array([0, 1]), 4)
