@@ -163,9 +163,13 @@ def main():
             # self-check on the real collective: both exchanges must give the same C (two partial sums vs one: fp32 re-association)
             d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False)
             C_chk = torch.empty_like(C)
-            ex.step(B_tiles, C_chk)
-            torch.cuda.synchronize()
-            err = float((C_chk - C).abs().max() / C.abs().max().clamp_min(1e-30))
+            err = float("inf")
+            try:
+                ex.step(B_tiles, C_chk)
+                torch.cuda.synchronize()
+                err = float((C_chk - C).abs().max() / C.abs().max().clamp_min(1e-30))
+            except Exception as e:                                 # reported, never silent: the line below names the fallback
+                print("rank %d: row-block exchange raised %r" % (rank, e), file=sys.stderr)
             ok = torch.tensor([1.0 if err < 1e-4 else 0.0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if float(ok.item()) < 1.0:
