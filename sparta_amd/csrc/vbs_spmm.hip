@@ -1015,7 +1015,40 @@ __global__ __launch_bounds__(kThreads) void vbs_convert_h16_kernel(const float* 
     }
 }
 
-// adds the partial images of every split tile (fixed order: worker order) and writes the tile
+// A tile that dominates the plan (a hub block-row) is split over hundreds of workers; adding its partial images one after the
+// other in ONE workgroup is a latency-bound chain (measured: 512 images, 350 us).  First stage for such plans: blockIdx.z = group
+// of kFixGroup consecutive images, summed in order into the group's first image; the fix-up kernel then adds the group leaders
+// (stride kFixGroup).  Fixed grouping -> the result is reproducible run to run.
+constexpr int kFixGroup = 16;
+__global__ __launch_bounds__(kThreads) void vbs_spmm_f32_fixup_group_kernel(const FixRec* fix, const int32_t* big, const int32_t* fix_slots,
+                                                                            float* ws_all, int64_t ws_slab_stride) {
+    const FixRec fr = fix[big[blockIdx.x]];          // only the tiles with more than 2 * kFixGroup images come here
+    const int s0 = blockIdx.z * kFixGroup;
+    if (s0 + 1 >= fr.n_slots) return;                 // no such group, or a group of one image
+    float* ws = ws_all + (int64_t)blockIdx.y * ws_slab_stride;
+    const int tid = threadIdx.x;
+    const int s1 = s0 + kFixGroup < fr.n_slots ? s0 + kFixGroup : fr.n_slots;
+    float* lead = ws + (int64_t)fix_slots[fr.slot_begin + s0] * SK_SLOT_FLOATS + tid;
+    float acc[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) acc[q] = lead[q * kThreads];
+    int s = s0 + 1;
+    for (; s + 2 <= s1; s += 2) {
+        const float* i0 = ws + (int64_t)fix_slots[fr.slot_begin + s] * SK_SLOT_FLOATS + tid;
+        const float* i1 = ws + (int64_t)fix_slots[fr.slot_begin + s + 1] * SK_SLOT_FLOATS + tid;
+#pragma unroll
+        for (int q = 0; q < 32; q++) { const float a0 = i0[q * kThreads], a1 = i1[q * kThreads]; acc[q] += a0; acc[q] += a1; }
+    }
+    for (; s < s1; s++) {
+        const float* i0 = ws + (int64_t)fix_slots[fr.slot_begin + s] * SK_SLOT_FLOATS + tid;
+#pragma unroll
+        for (int q = 0; q < 32; q++) acc[q] += i0[q * kThreads];
+    }
+#pragma unroll
+    for (int q = 0; q < 32; q++) lead[q * kThreads] = acc[q];
+}
+
+// adds the partial images of every split tile (fixed order: worker order; `stride` > 1 after the group stage) and writes the tile
 __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_fixup_kernel(const FixRec* fix, const int32_t* fix_slots, const float* ws_all,
                                                                       int64_t ws_slab_stride, float* C, int64_t ldc, int c_row_major,
                                                                       int accumulate) {
@@ -1026,7 +1059,24 @@ __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_fixup_kernel(const FixR
     f32x16 acc0, acc1;
 #pragma unroll
     for (int q = 0; q < 16; q++) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
-    for (int s = 0; s < fr.n_slots; s++) {
+    // the partial images are added in slot order, four at a time (four independent loads in flight per element: a tile that
+    // dominates the plan is split over hundreds of workers, and one dependent chain of loads per element is latency-bound)
+    const int stride = fr.n_slots > 2 * kFixGroup ? kFixGroup : 1;   // such tiles went through the group stage: add the group leaders
+    int s = 0;
+    for (; s + 3 * stride < fr.n_slots; s += 4 * stride) {
+        const float* i0 = ws + (int64_t)fix_slots[fr.slot_begin + s] * SK_SLOT_FLOATS + tid;
+        const float* i1 = ws + (int64_t)fix_slots[fr.slot_begin + s + stride] * SK_SLOT_FLOATS + tid;
+        const float* i2 = ws + (int64_t)fix_slots[fr.slot_begin + s + 2 * stride] * SK_SLOT_FLOATS + tid;
+        const float* i3 = ws + (int64_t)fix_slots[fr.slot_begin + s + 3 * stride] * SK_SLOT_FLOATS + tid;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const float a0 = i0[q * kThreads], a1 = i1[q * kThreads], a2 = i2[q * kThreads], a3 = i3[q * kThreads];
+            const float b0 = i0[(16 + q) * kThreads], b1 = i1[(16 + q) * kThreads], b2 = i2[(16 + q) * kThreads], b3 = i3[(16 + q) * kThreads];
+            acc0[q] += a0; acc0[q] += a1; acc0[q] += a2; acc0[q] += a3;
+            acc1[q] += b0; acc1[q] += b1; acc1[q] += b2; acc1[q] += b3;
+        }
+    }
+    for (; s < fr.n_slots; s += stride) {
         const float* img = ws + (int64_t)fix_slots[fr.slot_begin + s] * SK_SLOT_FLOATS + tid;
 #pragma unroll
         for (int q = 0; q < 16; q++) { acc0[q] += img[q * kThreads]; acc1[q] += img[(16 + q) * kThreads]; }
@@ -1321,6 +1371,9 @@ struct sparta_vbs {
     int32_t* d_fix_slots = nullptr;
     int64_t n_steps[2] = {0, 0};
     int32_t n_workers = 0, n_fix = 0, n_split = 0, n_slots = 0;
+    int32_t max_tile_slots = 0;            // most partial images of one split tile
+    int32_t* d_big_fix = nullptr;          // fix records with more than 2 * kFixGroup images (group stage)
+    int32_t n_big_fix = 0;
     void* d_ws = nullptr;
     size_t d_ws_bytes = 0;
     bool has_tail = false;                 // cols % w != 0: the stream path needs B_tail
@@ -1415,6 +1468,7 @@ void destroy_impl(sparta_vbs* v) {
     }
     if (v->d_fix) (void)hipFree(v->d_fix);
     if (v->d_fix_slots) (void)hipFree(v->d_fix_slots);
+    if (v->d_big_fix) (void)hipFree(v->d_big_fix);
     if (v->d_ws) (void)hipFree(v->d_ws);
     if (v->d_btail) (void)hipFree(v->d_btail);
     if (v->d_tune) (void)hipFree(v->d_tune);
@@ -1759,14 +1813,19 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     // ---- sparse-row path: which block-rows are better served as rows of (column, value) --------------------------------
     // An MFMA step (one <=32-row tile x 32 k x 128 columns) takes the time of ~12 nonzeros on the sparse-row path (2.1 ns per
     // step across the 512 workers vs 512 B of B per nonzero and 128-column slab at ~3 TB/s): a block-row whose blocks hold
-    // fewer than SPARTA_SPARSE_K (default 10) nonzeros per step goes there.  SPARTA_SPARSE_K=0 switches the path off.
+    // fewer than SPARTA_SPARSE_K (default 24) nonzeros per step goes there (measured break-even, scripts/sparse_k_sweep.py:
+    // ~60 nonzeros per step while B fits the L2s, ~15 when its rows come from HBM).  SPARTA_SPARSE_K=0 switches the path off.
     std::vector<uint8_t> sparse_flag;
     std::vector<int64_t> sp_rowptr;
     std::vector<int32_t> sp_col, sp_crow, sp_list;
     std::vector<float> sp_val;
     std::vector<SpSegRec> sp_segs;
     std::vector<SpLongRec> sp_long;
-    constexpr int64_t kSpLong = 2048, kSpSeg = 1024;
+    // a wave keeps 8 rows of B in flight: a row of n nonzeros takes ~n / 8 memory latencies whatever else the GPU is doing, so rows
+    // longer than kSpLong are cut into kSpSeg-nonzero segments that run on different waves (SPARTA_SPARSE_SEG overrides kSpSeg)
+    int64_t kSpSeg = 256;
+    if (const char* e = std::getenv("SPARTA_SPARSE_SEG")) kSpSeg = std::max(8, atoi(e));
+    const int64_t kSpLong = 2 * kSpSeg;
     int64_t n_sp_short = 0, n_sp_long = 0;
     // 16-bit handles: the values the kernels multiply are the ROUNDED ones (a value that rounds to zero is a zero)
     const bool bf16h = dtype == SPARTA_BF16;
@@ -1791,7 +1850,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             sp_rowptr.push_back((int64_t)sp_col.size());
         }
     } else {
-        double K = 10.0;
+        double K = 24.0;
         if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
         if (K > 0.0) {
             sparse_flag.assign((size_t)(br1 - br0), 0);
@@ -1991,6 +2050,16 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     if (!steps[0].empty() || !steps[1].empty() || !fix.empty()) {
         v->has_tail = (cols % w) != 0;
         v->n_workers = n_workers; v->n_fix = (int32_t)fix.size(); v->n_split = n_split; v->n_slots = (int32_t)fix_slots.size();
+        std::vector<int32_t> big_fix;
+        for (size_t q = 0; q < fix.size(); q++) {
+            v->max_tile_slots = std::max(v->max_tile_slots, fix[q].n_slots);
+            if (fix[q].n_slots > 2 * kFixGroup) big_fix.push_back((int32_t)q);
+        }
+        v->n_big_fix = (int32_t)big_fix.size();
+        if (!big_fix.empty()) {
+            CREATE_TRY(hipMalloc((void**)&v->d_big_fix, big_fix.size() * sizeof(int32_t)));
+            CREATE_TRY(hipMemcpy(v->d_big_fix, big_fix.data(), big_fix.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
         for (int ty = 0; ty < 2; ty++) {
             std::vector<StepRec>& st = steps[ty];
             v->n_steps[ty] = (int64_t)st.size();
@@ -2064,7 +2133,7 @@ int sparta_vbs_create_from_csr(sparta_vbs_t** out, int64_t rows, int64_t cols, c
     try {
         sparta::CsrView a;
         a.rows = rows; a.cols = cols; a.rowptr = rowptr; a.colidx = colidx; a.vals = vals;
-        double K = 10.0;
+        double K = 24.0;
         if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
         const int64_t kdep = (dtype != SPARTA_F32 && col_block_size % 64 == 0) ? 64 : 32;
         sparta::HybridSparse sp;
@@ -2273,6 +2342,9 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
     }
     if (A->n_fix > 0 && !(accumulate && A->n_split == 0)) {   // C += 0 for the block-rows without blocks: nothing to launch
         if (prof) HIP_TRY(hipEventRecord(A->cev[1][0], st));
+        if (A->n_big_fix > 0)
+            hipLaunchKernelGGL(vbs_spmm_f32_fixup_group_kernel, dim3((unsigned)A->n_big_fix, (unsigned)n_nt, (unsigned)((A->max_tile_slots + kFixGroup - 1) / kFixGroup)),
+                               dim3(kThreads), 0, st, A->d_fix, A->d_big_fix, A->d_fix_slots, (float*)A->d_ws, (int64_t)slab);
         hipLaunchKernelGGL(vbs_spmm_f32_fixup_kernel, dim3((unsigned)A->n_fix, (unsigned)n_nt), dim3(kThreads), 0, st, A->d_fix, A->d_fix_slots,
                            (const float*)A->d_ws, (int64_t)slab, dC, ldc, (int)(c_layout == SPARTA_ROW_MAJOR), (int)(accumulate != 0));
         if (prof) { HIP_TRY(hipEventRecord(A->cev[1][1], st)); A->class_ran[1] = true; }
@@ -2409,6 +2481,10 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
             }
             if (A->n_fix > 0 && !(accumulate && A->n_split == 0)) {   // C += 0 for the block-rows without blocks: nothing to launch
                 if (prof) HIP_TRY(hipEventRecord(A->cev[1][0], st));
+                if (A->n_big_fix > 0)
+                    hipLaunchKernelGGL(vbs_spmm_f32_fixup_group_kernel,
+                                       dim3((unsigned)A->n_big_fix, (unsigned)n_nt, (unsigned)((A->max_tile_slots + kFixGroup - 1) / kFixGroup)), dim3(kThreads), 0, st,
+                                       A->d_fix, A->d_big_fix, A->d_fix_slots, (float*)A->d_ws, (int64_t)slab);
                 hipLaunchKernelGGL(vbs_spmm_f32_fixup_kernel, dim3((unsigned)A->n_fix, (unsigned)n_nt), dim3(kThreads), 0, st, A->d_fix,
                                    A->d_fix_slots, (const float*)A->d_ws, (int64_t)slab, Cout, ldc, (int)(c_layout == SPARTA_ROW_MAJOR),
                                    (int)(accumulate != 0));
