@@ -473,6 +473,7 @@ def test_stream_plan_modes(monkeypatch, align, rows, cols, nnz, w, blk, n):
     torch = _torch()
     monkeypatch.setenv("SPARTA_PATH", "stream")
     monkeypatch.setenv("SPARTA_STREAM_ALIGN", align)
+    monkeypatch.setenv("SPARTA_SPARSE_K", "0")              # the subject is the stream plan: keep every block-row on it
     m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + w)
     if blk[0] == "tau":
         g = sa.BlockingEngine(tau=blk[1], col_block_size=w).GetGrouping(m)
