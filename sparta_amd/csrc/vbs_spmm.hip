@@ -1897,19 +1897,15 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             if (n_flagged == 0) sparse_flag.clear();
         }
     }
-    {
-        {
-            // short rows: one wave each; rows with more than kSpLong nonzeros (hubs): segments of kSpSeg, one wave each + a reduction
-            for (size_t t = 0; t < sp_crow.size(); t++) {
-                const int64_t p0 = sp_rowptr[t], n = sp_rowptr[t + 1] - p0;
-                if (n <= kSpLong) { sp_list.push_back((int32_t)t); continue; }
-                SpLongRec lr{(int32_t)t, (int32_t)sp_segs.size(), 0, 0};
-                for (int64_t o = 0; o < n; o += kSpSeg) { sp_segs.push_back(SpSegRec{p0 + o, (int32_t)std::min<int64_t>(kSpSeg, n - o), 0}); lr.n_seg++; }
-                sp_long.push_back(lr);
-            }
-            n_sp_short = (int64_t)sp_list.size(); n_sp_long = (int64_t)sp_long.size();
-        }
+    // short rows: one wave each; rows with more than kSpLong nonzeros (hubs): segments of kSpSeg, one wave each + a reduction
+    for (size_t t = 0; t < sp_crow.size(); t++) {
+        const int64_t p0 = sp_rowptr[t], n = sp_rowptr[t + 1] - p0;
+        if (n <= kSpLong) { sp_list.push_back((int32_t)t); continue; }
+        SpLongRec lr{(int32_t)t, (int32_t)sp_segs.size(), 0, 0};
+        for (int64_t o = 0; o < n; o += kSpSeg) { sp_segs.push_back(SpSegRec{p0 + o, (int32_t)std::min<int64_t>(kSpSeg, n - o), 0}); lr.n_seg++; }
+        sp_long.push_back(lr);
     }
+    n_sp_short = (int64_t)sp_list.size(); n_sp_long = (int64_t)sp_long.size();
     const uint8_t* skip = sparse_flag.empty() ? nullptr : sparse_flag.data();
 
     // ---- plan: row tiles per class -----------------------------------------------------------------
@@ -2218,7 +2214,7 @@ void launch_h16(bool bf16, dim3 grid, hipStream_t st, const StreamParams& sp) {
 
 // sparse-row path, shared by the fp32 and the 16-bit handles.  bk: element type of B (0 fp32, 1 fp16, 2 bf16); C is fp32.
 template <int VEC, int BK>
-void launch_sparse_kernels(sparta_vbs_t* A, SparseParams q, unsigned gy, int32_t n_cols, hipStream_t st) {
+void launch_sparse_kernels(sparta_vbs_t* A, SparseParams q, unsigned gy, hipStream_t st) {
     if (A->n_sp_short > 0) {
         q.list = A->d_sp_list; q.n_list = (int32_t)A->n_sp_short;
         hipLaunchKernelGGL((sparse_rows_kernel<VEC, BK>), dim3((unsigned)((A->n_sp_short + 3) / 4), gy), dim3(kThreads), 0, st, q);
@@ -2262,9 +2258,9 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     const unsigned gy = (unsigned)((n_cols + 64 * vec - 1) / (64 * vec));
 #define SPARTA_SP_DISPATCH(V_)                                                             \
     do {                                                                                   \
-        if (bk == 0) launch_sparse_kernels<V_, 0>(A, q, gy, n_cols, st);                   \
-        else if (bk == 1) launch_sparse_kernels<V_, 1>(A, q, gy, n_cols, st);              \
-        else launch_sparse_kernels<V_, 2>(A, q, gy, n_cols, st);                           \
+        if (bk == 0) launch_sparse_kernels<V_, 0>(A, q, gy, st);                   \
+        else if (bk == 1) launch_sparse_kernels<V_, 1>(A, q, gy, st);              \
+        else launch_sparse_kernels<V_, 2>(A, q, gy, st);                           \
     } while (0)
     if (vec == 4) SPARTA_SP_DISPATCH(4); else if (vec == 2) SPARTA_SP_DISPATCH(2); else SPARTA_SP_DISPATCH(1);
 #undef SPARTA_SP_DISPATCH
