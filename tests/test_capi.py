@@ -62,6 +62,20 @@ def test_error_reporting():
     assert _lib.lib.sparta_vbs_info(None, None) == _lib.ERR_INVALID
     assert _lib.lib.sparta_vbs_spmm(None, None, 0, 0, 1, None, 0, 0, 0, 0, None, 0, None) == _lib.ERR_INVALID
     assert b"NULL" in _lib.lib.sparta_last_error()
+    assert _lib.lib.sparta_vbs_sparse_info(None, None) == _lib.ERR_INVALID
+    # the exchange pack kernel validates before it touches the GPU: nothing to copy is fine anywhere, bad sizes are refused
+    assert _lib.lib.sparta_pack_blocks(None, 256, None, 0, None, None) == _lib.OK
+    assert _lib.lib.sparta_pack_blocks(None, 100, None, 3, None, None) == _lib.ERR_INVALID
+    assert _lib.lib.sparta_pack_blocks(None, 256, None, 3, None, None) == _lib.ERR_INVALID
+    # a device handle straight from the CSR: argument errors first, then "no device" here (a GPU box builds it: tests/test_spmm_gpu.py)
+    import ctypes as C
+    h = C.c_void_p(None)
+    assert _lib.lib.sparta_vbs_create_from_csr(None, 3, 3, None, None, None, None, 2, 0, 0, _lib.F32, 0) == _lib.ERR_INVALID
+    assert _lib.lib.sparta_vbs_create_from_csr(C.byref(h), 3, 3, None, None, None, None, 2, 0, 0, 77, 0) == _lib.ERR_INVALID
+    if sa.device_count() == 0:
+        with pytest.raises(sa.SpartaError) as ei:
+            sa.DeviceVBS.from_csr(ok, np.array([0, 0, 2]), 2)
+        assert ei.value.code == _lib.ERR_NO_DEVICE
 
 
 def test_empty_rows_and_padding_rules():

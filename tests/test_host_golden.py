@@ -212,3 +212,18 @@ def test_minhash_reorder_rules():
     for kw in (dict(sim_measure=0, tau=3.0), dict(use_groups=True, tau=0.5), dict(use_pattern=False, tau=0.5)):
         gk = sa.BlockingEngine(blocking_algo=7, col_block_size=4, **kw).GetGrouping(m2)
         assert len(gk) == 400 and (gk <= np.arange(400)).all()
+
+
+def test_minhash_reorder_equals_the_exact_algorithm_at_tau_zero():
+    """tau = 0 merges exactly the rows with the same block set as the seed: no approximation is left, algorithm 7 must return
+    algorithm 3's grouping (and the same merge count) -- with empty rows, repeated rows and every block width"""
+    rng = np.random.Generator(np.random.PCG64(77))
+    for case in range(40):
+        rows, cols = int(rng.integers(1, 400)), int(rng.integers(1, 60))
+        m = sa.gen.uniform_random(rows, cols, int(rows * cols * float(rng.choice([0.02, 0.1, 0.4]))), seed=int(rng.integers(1 << 30)), pattern_only=True)
+        w = int(rng.choice([1, 2, 5, 16]))
+        e3 = sa.BlockingEngine(blocking_algo=3, tau=0.0, col_block_size=w)
+        e7 = sa.BlockingEngine(blocking_algo=7, tau=0.0, col_block_size=w)
+        g3, g7 = e3.GetGrouping(m), e7.GetGrouping(m)
+        assert np.array_equal(g3, g7), (case, rows, cols, w)
+        assert e3.merge_counter == e7.merge_counter
