@@ -128,8 +128,7 @@ def main():
     vb = sa.VBR().fill_from_CSR_inplace(m, grouping, w, args.row_block, bool(args.force_fixed) and not args.fixed_height)
     t_build = time.time() - t0
     h16 = args.dtype != "f32"
-    if h16 and distributed:
-        raise SystemExit("--dtype f16/bf16 is a single-GPU option (the gathered-B entry point is fp32)")
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
     d = vb.to_device(local_rank, dtype={"f32": sa.F32, "f16": sa.F16, "bf16": sa.BF16}[args.dtype])
     info = d.info()
 
@@ -144,8 +143,8 @@ def main():
             B.view(N, ldb)[:, :vb.cols] = B32.view(N, vb.cols).to(B.dtype)
         B_shard = B_gath = None
     else:
-        B_shard = (torch.rand(shard_rows * N, generator=g, dtype=torch.float32) - 0.5).to(dev)   # column-major, ld = shard_rows
-        B_gath = torch.empty(world * shard_rows * N, dtype=torch.float32, device=dev)
+        B_shard = (torch.rand(shard_rows * N, generator=g, dtype=torch.float32) - 0.5).to(dev).to(tdt)   # column-major, ld = shard_rows
+        B_gath = torch.empty(world * shard_rows * N, dtype=tdt, device=dev)
     C = torch.zeros(vb.rows * N, dtype=torch.float32, device=dev)
 
     # ---- N > 1: which exchange ------------------------------------------------------------------------------------
@@ -156,7 +155,8 @@ def main():
         if exchange != "allgather":
             # the same shard in the row-block-tiled layout (block jb = one contiguous w x N column-major tile)
             B_tiles = B_shard.view(N, shard_rows // w, w).permute(1, 0, 2).contiguous().view(-1)
-            ex = sa.dist.RowBlockExchange(vb, rank, world, shard_rows, N, device=local_rank)      # collective: need lists
+            ex = sa.dist.RowBlockExchange(vb, rank, world, shard_rows, N, device=local_rank,
+                                          dtype={"f32": sa.F32, "f16": sa.F16, "bf16": sa.BF16}[args.dtype])      # collective: need lists
             if exchange == "auto":
                 exchange = "blocks" if ex.needed_fraction < 0.5 else "allgather"
         if exchange == "blocks":
@@ -360,7 +360,7 @@ def main():
             if not distributed:
                 Bh = (B.view(N, ldb)[:, :vb.cols].float().contiguous().view(-1) if h16 else B).cpu().numpy()
             else:
-                Bh = sa.dist.gathered_to_colmajor(B_gath.cpu().numpy(), world, shard_rows, N)
+                Bh = sa.dist.gathered_to_colmajor(B_gath.float().cpu().numpy(), world, shard_rows, N)
             # bounded sample: a prefix of block-rows worth <= ~2e10 executed flops (about 10-20 s of scalar CPU work)
             per_row = 2.0 * np.diff(vb.row_part) * w * vb.nzcount * N
             cum = np.cumsum(per_row)

@@ -274,7 +274,8 @@ int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layou
  * every GPU: n_shards consecutive column-major slabs of shard_rows x n_cols (ld = shard_rows), slab s holding
  * rows [s*shard_rows, (s+1)*shard_rows) of B, consecutive slabs shard_stride elements apart.  shard_rows must
  * be a multiple of block_col_size (so that no B panel straddles two slabs) and cols == n_shards * shard_rows.
- * Device pointers only.  No reference counterpart (the reference is single-GPU: SURVEY.md section 2.1). */
+ * Device pointers only; 16-bit handles take the slabs in their 16-bit type (shard_rows and shard_stride even).
+ * No reference counterpart (the reference is single-GPU: SURVEY.md section 2.1). */
 int sparta_vbs_spmm_gathered(sparta_vbs_t* A, const void* B_gathered, int64_t shard_rows, int64_t shard_stride, int32_t n_cols,
                              void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, void* stream, int32_t algo, float* dt_ms);
 

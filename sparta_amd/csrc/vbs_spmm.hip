@@ -804,7 +804,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int KP, bool MI2, bool BF16>
+template <int KP, bool MI2, bool BF16, bool GATHERED>
 __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const StreamParams p) {
     constexpr int TN = kTN, TM = MI2 ? 64 : 32;
     constexpr int LDK = KP + 8;                          // elements per LDS row
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
         const int32_t x0 = __builtin_amdgcn_readlane(vrec0, ln), x1 = __builtin_amdgcn_readlane(vrec1, ln);
         return ((s >> 3) & 1) ? x1 : x0;
     };
-    enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6 };
+    enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6, F_SHARD = 7 };
 
     const int bj0 = tid / CPC, bc = tid % CPC;           // B: column bj0 + CPP q, chunk bc (k = 8 bc .. 8 bc + 7)
     const int ac = tid % (TM * CPC);                     // A: chunk ac (+ 256 q) of the contiguous TM x KP slice (clamped: duplicates are harmless)
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
             tail_prev = tail;
         }
         const int64_t gk0 = field(s, F_BROW);
-        const uint16_t* bptr = tail ? Bt16 + gk0 : B16 + gk0 + n0off;
+        const uint16_t* bptr = tail ? Bt16 + gk0 : B16 + (GATHERED ? (int64_t)field(s, F_SHARD) * p.shard_stride : (int64_t)0) + gk0 + n0off;   // gathered: (slab, row inside the slab), see the fp32 kernel
         const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(bptr), 0, 0x7ffffff0, 0x00020000);
         const uint32_t qs = tail ? qstepBt : qstepB;
 #pragma unroll
@@ -2207,9 +2207,29 @@ namespace {
 
 // shared implementation of sparta_vbs_spmm / sparta_vbs_spmm_gathered
 template <int KP, bool MI2>
-void launch_h16(bool bf16, dim3 grid, hipStream_t st, const StreamParams& sp) {
-    if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, true>), grid, dim3(kThreads), 0, st, sp);
-    else hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, false>), grid, dim3(kThreads), 0, st, sp);
+void launch_h16(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (gathered) {
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, true, true>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, false, true>), grid, dim3(kThreads), 0, st, sp);
+    } else {
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, true, false>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, false, false>), grid, dim3(kThreads), 0, st, sp);
+    }
+}
+
+// step lists for a gathered B (slab index + row inside the slab), rebuilt when the slab height changes
+int ensure_gathered_steps(sparta_vbs_t* A, int64_t shard_rows, hipStream_t st) {
+    if (A->g_shard_rows == shard_rows) return SPARTA_OK;
+    for (int ty = 0; ty < 2; ty++) {
+        if (A->h_steps[ty].empty()) continue;
+        std::vector<StepRec> g = A->h_steps[ty];
+        for (StepRec& r : g) { r.pad = (int32_t)(r.b_row / shard_rows); r.b_row = (int32_t)(r.b_row % shard_rows); }
+        if (!A->d_steps_g[ty]) HIP_TRY(hipMalloc((void**)&A->d_steps_g[ty], g.size() * sizeof(StepRec)));
+        HIP_TRY(hipMemcpyAsync(A->d_steps_g[ty], g.data(), g.size() * sizeof(StepRec), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));                       // g goes out of scope
+    }
+    A->g_shard_rows = shard_rows;
+    return SPARTA_OK;
 }
 
 // sparse-row path, shared by the fp32 and the 16-bit handles.  bk: element type of B (0 fp32, 1 fp16, 2 bf16); C is fp32.
@@ -2274,11 +2294,11 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
 // 16-bit handles (SPARTA_F16 / SPARTA_BF16): A and B in the 16-bit type, fp32 accumulation, fp32 C.  Device pointers: B is a
 // 16-bit column-major matrix (ldb in elements, even).  Host pointers keep the reference's contract (fp32 B in, fp32 C out):
 // B is converted on the device (round to nearest even).
-int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int64_t shard_rows, int32_t n_cols, void* C, int64_t ldc,
-                int32_t c_layout, int32_t accumulate, int32_t ptr_space, hipStream_t st, int32_t algo, float* dt_ms) {
+int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int64_t shard_rows, int64_t shard_stride, int32_t n_cols, void* C,
+                int64_t ldc, int32_t c_layout, int32_t accumulate, int32_t ptr_space, hipStream_t st, int32_t algo, float* dt_ms) {
     using sparta::fail;
     if (algo != SPARTA_SPMM_MFMA) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: SPARTA_SPMM_EXACT needs an fp32 handle");
-    if (shard_rows != 0) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm_gathered: fp32 handles only in this build");
+    if (shard_rows != 0 && ptr_space != SPARTA_PTR_DEVICE) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: device pointers only");
     if (b_layout != SPARTA_COL_MAJOR) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit handles need a column-major B (k contiguous)");
     if (n_cols % kTN != 0) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit handles need n_cols % 128 == 0");
     const bool bf16 = A->dtype == SPARTA_BF16;
@@ -2314,12 +2334,14 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
         if (int rc = ensure_scratch(&A->d_ws, &A->d_ws_bytes, slab * n_nt * sizeof(float))) return rc;
     StreamParams sp;
     sp.A = A->d_A; sp.B = (const float*)dB; sp.C = dC; sp.ws = (float*)A->d_ws;
-    sp.ldb = ldb16; sp.ldc = ldc; sp.cols = A->cols; sp.shard_rows = 0; sp.shard_stride = 0;
+    sp.ldb = ldb16; sp.ldc = ldc; sp.cols = A->cols; sp.shard_rows = shard_rows; sp.shard_stride = shard_stride;
+    if (shard_rows > 0)
+        if (int rc = ensure_gathered_steps(A, shard_rows, st)) return rc;
     sp.ws_slab_stride = (int64_t)slab; sp.accumulate = accumulate != 0; sp.c_row_major = c_layout == SPARTA_ROW_MAJOR;
     sp.N = n_cols; sp.w = (int32_t)A->w; sp.B_tail = nullptr; sp.clk = nullptr;
     if (A->n_steps[0] + A->n_steps[1] > 0) {
         if (prof) HIP_TRY(hipEventRecord(A->cev[0][0], st));
-        if (A->has_tail) {
+        if (A->has_tail && shard_rows == 0) {
             if (int rc = ensure_scratch(&A->d_btail, &A->d_btail_bytes, (size_t)A->w * n_cols * sizeof(uint16_t))) return rc;
             const int64_t row0 = ((A->cols - 1) / A->w) * A->w;
             hipLaunchKernelGGL(vbs_tail_copy_h16_kernel, dim3(32), dim3(kThreads), 0, st, dB, ldb16, row0, A->cols, (int)A->w, (int)n_cols, (uint16_t*)A->d_btail);
@@ -2329,10 +2351,11 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
         const int probe_ty = A->n_steps[1] >= A->n_steps[0] ? 1 : 0;
         for (int ty = 1; ty >= 0; ty--) {
             if (A->n_steps[ty] == 0) continue;
-            sp.steps = A->d_steps[ty]; sp.worker_range = A->d_wrange[ty];
+            sp.steps = shard_rows > 0 ? A->d_steps_g[ty] : A->d_steps[ty]; sp.worker_range = A->d_wrange[ty];
             sp.clk = (prof && ty == probe_ty) ? A->d_clk : nullptr;
-            if (A->kp16 == 64) { if (ty) launch_h16<64, true>(bf16, grid, st, sp); else launch_h16<64, false>(bf16, grid, st, sp); }
-            else { if (ty) launch_h16<32, true>(bf16, grid, st, sp); else launch_h16<32, false>(bf16, grid, st, sp); }
+            const bool gth = shard_rows > 0;
+            if (A->kp16 == 64) { if (ty) launch_h16<64, true>(bf16, gth, grid, st, sp); else launch_h16<64, false>(bf16, gth, grid, st, sp); }
+            else { if (ty) launch_h16<32, true>(bf16, gth, grid, st, sp); else launch_h16<32, false>(bf16, gth, grid, st, sp); }
         }
         if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
     }
@@ -2347,7 +2370,7 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
     }
     if (A->n_sp_rows > 0) {                  // nearly empty block-rows: sparse rows over a row-major 16-bit copy of B
         if (prof) HIP_TRY(hipEventRecord(A->cev[3][0], st));
-        if (int rc = launch_sparse_rows(A, dB, ldb16, false, 0, 0, bf16 ? 2 : 1, n_cols, dC, ldc, c_layout == SPARTA_ROW_MAJOR, accumulate != 0, st)) return rc;
+        if (int rc = launch_sparse_rows(A, dB, ldb16, false, shard_rows, shard_stride, bf16 ? 2 : 1, n_cols, dC, ldc, c_layout == SPARTA_ROW_MAJOR, accumulate != 0, st)) return rc;
         if (prof) { HIP_TRY(hipEventRecord(A->cev[3][1], st)); A->class_ran[3] = true; }
     }
     A->last_path = 1;
@@ -2382,7 +2405,7 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
     if (!guard.ok) return fail(SPARTA_ERR_HIP, "sparta_vbs_spmm: hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
     if (A->dtype != SPARTA_F32)
-        return spmm16_impl(A, B, ldb, b_layout, shard_rows, n_cols, C, ldc, c_layout, accumulate, ptr_space, st, algo, dt_ms);
+        return spmm16_impl(A, B, ldb, b_layout, shard_rows, shard_stride, n_cols, C, ldc, c_layout, accumulate, ptr_space, st, algo, dt_ms);
 
     const float* dB = (const float*)B;
     float* dC = (float*)C;
@@ -2430,17 +2453,8 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
             const size_t slab = (size_t)A->n_slots * SK_SLOT_FLOATS;
             if (A->n_split > 0)
                 if (int rc = ensure_scratch(&A->d_ws, &A->d_ws_bytes, slab * n_nt * sizeof(float))) return rc;
-            if (shard_rows > 0 && A->g_shard_rows != shard_rows) {          // (re)build the gathered step lists: b_row -> (slab, local row)
-                for (int ty = 0; ty < 2; ty++) {
-                    if (A->h_steps[ty].empty()) continue;
-                    std::vector<StepRec> g = A->h_steps[ty];
-                    for (StepRec& r : g) { r.pad = (int32_t)(r.b_row / shard_rows); r.b_row = (int32_t)(r.b_row % shard_rows); }
-                    if (!A->d_steps_g[ty]) HIP_TRY(hipMalloc((void**)&A->d_steps_g[ty], g.size() * sizeof(StepRec)));
-                    HIP_TRY(hipMemcpyAsync(A->d_steps_g[ty], g.data(), g.size() * sizeof(StepRec), hipMemcpyHostToDevice, st));
-                    HIP_TRY(hipStreamSynchronize(st));                       // g goes out of scope
-                }
-                A->g_shard_rows = shard_rows;
-            }
+            if (shard_rows > 0)
+                if (int rc = ensure_gathered_steps(A, shard_rows, st)) return rc;
             StreamParams sp;
             sp.A = A->d_A; sp.B = dB; sp.C = Cout; sp.ws = (float*)A->d_ws;
             sp.ldb = ldb; sp.ldc = ldc; sp.cols = A->cols; sp.shard_rows = shard_rows; sp.shard_stride = shard_stride;

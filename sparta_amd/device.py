@@ -108,8 +108,9 @@ class DeviceVBS:
                       c_layout=_lib.COL_MAJOR, shard_stride=None, timed=False, stream=None):
         """Multi-GPU entry: B_gathered is the all-gather result (n_shards column-major slabs of shard_rows x n_cols)."""
         import torch
-        if not (B_gathered.is_cuda and C_out.is_cuda and B_gathered.dtype == torch.float32 and C_out.dtype == torch.float32):
-            raise ValueError("B_gathered and C must be float32 tensors on the GPU")
+        want_b = {_lib.F32: torch.float32, _lib.F16: torch.float16, _lib.BF16: torch.bfloat16}[self.dtype]
+        if not (B_gathered.is_cuda and C_out.is_cuda and B_gathered.dtype == want_b and C_out.dtype == torch.float32):
+            raise ValueError("B_gathered must be a %s tensor and C a float32 tensor, both on the GPU" % want_b)
         shard_stride = shard_rows * n_cols if shard_stride is None else shard_stride
         if B_gathered.numel() < (self.cols // shard_rows) * shard_stride:
             raise ValueError("B_gathered too small")

@@ -134,7 +134,7 @@ class RowBlockExchange:
     `pack` / `product` can be replaced (the CPU tests over gloo pass numpy-backed ones; the product path is the HIP
     library and has no CPU form).  `all_need[p][q]` (every rank's needed_blocks) skips the plan-time collective."""
 
-    def __init__(self, vb, rank, world_size, shard_rows, n_cols, device=0, group=None, pack=None, product=None, all_need=None):
+    def __init__(self, vb, rank, world_size, shard_rows, n_cols, device=0, group=None, pack=None, product=None, all_need=None, dtype=0):
         import torch
         import torch.distributed as dist
         self.rank, self.world, self.w, self.N = int(rank), int(world_size), int(vb.block_col_size), int(n_cols)
@@ -163,16 +163,19 @@ class RowBlockExchange:
         self.needed_fraction = (max(sum(len(all_need[p][q]) for q in range(self.world) if q != p) for p in range(self.world))
                                 / float(max(1, (self.world - 1) * bps)))
         dev = torch.device("cpu") if device is None else torch.device("cuda", device)
+        self.dtype = dtype                     # storage type of A and B on the device (sparta_amd.F32 / F16 / BF16); C is fp32
+        tdt = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}[int(dtype)]
+        self.elem_bytes = 4 if int(dtype) == 0 else 2
         self.send_ids = torch.from_numpy(self.send_ids_host).to(dev)
-        self.send_buf = torch.empty(max(1, self.n_send * tile), dtype=torch.float32, device=dev)
-        self.recv_buf = torch.empty(max(1, self.n_recv * tile), dtype=torch.float32, device=dev)
+        self.send_buf = torch.empty(max(1, self.n_send * tile), dtype=tdt, device=dev)
+        self.recv_buf = torch.empty(max(1, self.n_recv * tile), dtype=tdt, device=dev)
         self._send_view, self._recv_view = self.send_buf[:self.n_send * tile], self.recv_buf[:self.n_recv * tile]
         self._pack = pack if pack is not None else self._pack_hip
         self._product = product if product is not None else self._product_hip
         self.d_own = self.d_rem = None
         if product is None:
-            self.d_own = self.own.to_device(device)
-            self.d_rem = self.remote.to_device(device) if self.remote is not None else None
+            self.d_own = self.own.to_device(device, dtype=dtype)
+            self.d_rem = self.remote.to_device(device, dtype=dtype) if self.remote is not None else None
 
     # -- HIP implementations (the product) --
     def _pack_hip(self, B_tiles):
@@ -180,7 +183,7 @@ class RowBlockExchange:
         import torch
         from ._lib import lib, check
         st = torch.cuda.current_stream(self.device).cuda_stream
-        check(lib.sparta_pack_blocks(C.c_void_p(B_tiles.data_ptr()), self.w * self.N * 4, C.c_void_p(self.send_ids.data_ptr()), self.n_send,
+        check(lib.sparta_pack_blocks(C.c_void_p(B_tiles.data_ptr()), self.w * self.N * self.elem_bytes, C.c_void_p(self.send_ids.data_ptr()), self.n_send,
                                      C.c_void_p(self.send_buf.data_ptr()), C.c_void_p(st)))
 
     def _product_hip(self, which, B_tiles, C_out, accumulate):

@@ -800,3 +800,51 @@ def test_create_from_csr_gives_the_same_product(_sparse_row_mode, case, dtype):
         bad = sa.CSR(2, 8, [0, 2, 3], np.array([5, 1, 2], np.int32), None)
         with pytest.raises(sa.SpartaError):
             sa.DeviceVBS.from_csr(bad, np.array([0, 1]), 4)
+
+
+@pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
+def test_16bit_gathered_b_and_row_block_exchange(_sparse_row_mode, dtype):
+    """the multi-GPU entry points with 16-bit storage: sparta_vbs_spmm_gathered on an all-gather-shaped 16-bit B, and the
+    row-block exchange (pack kernel + the two products on the row-block-tiled layout) with every rank played on one GPU"""
+    torch = _torch()
+    tdt = torch.float16 if dtype == sa.F16 else torch.bfloat16
+    world, w, n = 3, 32, 128
+    slabs = [sa.gen.fem3d_slab(4, 4, 9, r, world, dof=3, pad_to=w, seed=4) for r in range(world)]
+    n_pad = slabs[0][2]
+    shards = [sa.gen.dense_rhs(n_pad, n, seed=50 + r) for r in range(world)]
+    gathered = np.concatenate(shards)
+    Bfull = sa.dist.gathered_to_colmajor(gathered, world, n_pad, n)
+    B_r = _round16(Bfull, dtype)
+    tiles = [torch.from_numpy(sa.dist.to_block_tiles(s, n_pad, n, w)).cuda().to(tdt) for s in shards]
+    vbs, all_need = [], []
+    for m, _, _ in slabs:
+        vbs.append(sa.VBR().fill_from_CSR_inplace(m, sa.BlockingEngine(tau=0.4, col_block_size=w).GetGrouping(m), w))
+        all_need.append(sa.dist.needed_blocks(vbs[-1].jab, w, n_pad, world))
+    exs = [sa.dist.RowBlockExchange(vbs[r], r, world, n_pad, n, device=0, all_need=all_need, dtype=dtype) for r in range(world)]
+    tile = w * n
+    for r in range(world):
+        exs[r]._pack(tiles[r])
+    for p in range(world):
+        o = 0
+        for q in range(world):
+            k = exs[p].out_splits[q]
+            i0 = sum(exs[q].in_splits[:p])
+            exs[p].recv_buf[o:o + k].copy_(exs[q].send_buf[i0:i0 + k])
+            o += k
+    Bg = torch.from_numpy(gathered).cuda().to(tdt)
+    for r in range(world):
+        v = vbs[r]
+        mab_r = _round16(v.mab, dtype)
+        Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n, None)
+        bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n)
+        d = v.to_device(0, dtype=dtype)
+        Ct = torch.full((v.rows * n,), 2.0, dtype=torch.float32, device="cuda")
+        d.spmm_gathered(Bg, n_pad, Ct, n)
+        torch.cuda.synchronize()
+        _check(Ct.cpu().numpy(), Co, bound, "16-bit gathered B rank %d" % r)
+        Ct.fill_(5.0)
+        exs[r]._product("own", tiles[r], Ct, False)
+        exs[r]._product("remote", exs[r].recv_buf, Ct, True)
+        torch.cuda.synchronize()
+        _check(Ct.cpu().numpy(), Co, bound, "16-bit row-block exchange rank %d" % r)
+        exs[r].close()
