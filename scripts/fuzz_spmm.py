@@ -61,6 +61,25 @@ for case in range(n_cases):
                     bad += 1
                     print("MISMATCH case", case, dict(rows=rows, cols=cols, nnz=nnz, w=w, n=n, kind=kind, path=path, align=align, acc=acc, sparse_k=spk),
                           "max err", float(err.max()), "last_path", d2.info()["last_path"])
+    # handles made straight from the CSR (nearly empty block-rows never expanded) must reproduce the two-step handle bit for bit
+    for spk in (None, "1e9"):
+        if spk is None:
+            os.environ.pop("SPARTA_SPARSE_K", None)
+        else:
+            os.environ["SPARTA_SPARSE_K"] = spk
+        os.environ["SPARTA_PATH"] = "auto"
+        os.environ.pop("SPARTA_STREAM_ALIGN", None)
+        d1, d2 = v.to_device(0), sa.DeviceVBS.from_csr(m, g, w, device=0)
+        for lay in (sa.COL_MAJOR, sa.ROW_MAJOR):
+            Bl = B if lay == sa.COL_MAJOR else B.view(n, v.cols).t().contiguous().view(-1)
+            C1, C2 = torch.full_like(Ce, 1.5), torch.full_like(Ce, 1.5)
+            d1.spmm(Bl, C1, n, accumulate=True, b_layout=lay, c_layout=lay)
+            d2.spmm(Bl, C2, n, accumulate=True, b_layout=lay, c_layout=lay)
+            torch.cuda.synchronize()
+            if not torch.equal(C1, C2) or d1.sparse_info() != d2.sparse_info():
+                bad += 1
+                print("MISMATCH from_csr case", case, dict(rows=rows, cols=cols, nnz=nnz, w=w, n=n, kind=kind, sparse_k=spk, lay=lay), d1.sparse_info(), d2.sparse_info())
+    os.environ.pop("SPARTA_SPARSE_K", None)
     if w % 32 == 0 and n % 128 == 0:
         for dt, tdt in ((sa.F16, torch.float16), (sa.BF16, torch.bfloat16)):
             os.environ.pop("SPARTA_PATH", None)
