@@ -220,6 +220,15 @@ void sparta_vbs_host_free(sparta_vbs_host* v);
 int sparta_vbs_save(const char* path, const sparta_vbs_host* v);
 int sparta_vbs_load(const char* path, sparta_vbs_host* out);
 
+/* Blocked-ELL view of a fixed-square-block VBS: replaces prepare_cusparse_BLOCKEDELLPACK(VBR*, int* ell_blocksize, int* ellValue_cols,
+ * int* ellColInd_rows, int* ellColInd_cols, int* num_blocks, intT** ellColInd, DataT_C** ellValues)
+ * (src/cuda/cuda_utilities.cpp:1656-1710) -- the arrays the reference hands to cusparseCreateBlockedEll.  ell_blocksize =
+ * block_col_size; *ell_cols_out = most blocks in a block-row; ell_col_ind: (rows / bs) x ell_cols, -1 = padding block;
+ * ell_values: rows x (ell_cols * bs), row-major.  Call with ell_col_ind = ell_values = NULL to get ell_cols first.
+ * SPARTA_ERR_INVALID where the reference exits (rows or cols not a multiple of the block size) and where its silent
+ * assumption fails (a block-row that is not bs rows tall). */
+int sparta_vbs_to_blocked_ell(const sparta_vbs_host* v, int64_t* ell_cols_out, int64_t* ell_col_ind, float* ell_values);
+
 /* replaces BlockingEngine::CollectBlockingInfo (src/general/blocking.cpp:576-631): statistics of
  * the VBS a grouping would give, without building it. info_out: [VBR_nzcount, VBR_nzblocks_count,
  * VBR_longest_row]; avg_height_out: VBR_average_height. */

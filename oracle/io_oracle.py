@@ -243,3 +243,36 @@ def degree_permutation(rowptr, descending, get_permutation):
                 k -= 1
             v[k] = x
     return np.array(v, np.int64)
+
+
+def blocked_ell(rows, cols, bs, nzcount, jab, mab):
+    """prepare_cusparse_BLOCKEDELLPACK (src/cuda/cuda_utilities.cpp:1656-1710), loop for loop.  The reference file is CUDA (cuSPARSE
+    headers) and cannot be compiled here: PARITY UNPINNED for this function beyond this restatement and the property that the
+    Blocked-ELL arrays expand to the same dense matrix as the VBS (tests/test_io.py)."""
+    if rows % bs != 0 or cols % bs != 0:
+        raise RefUndefined("exit(__LINE__): rows / cols not a multiple of ell_blocksize (:1666-1672)")
+    ind_rows = rows // bs                                               # :1674
+    ind_cols = 0
+    for i in range(ind_rows):                                           # :1675-1679
+        if nzcount[i] > ind_cols:
+            ind_cols = int(nzcount[i])
+    val_cols = ind_cols * bs                                            # :1680
+    ind = np.zeros((ind_rows, ind_cols), np.int64)
+    val = np.zeros((rows, val_cols), np.float32)
+    k_col = 0
+    for i in range(ind_rows):                                           # :1688-1695
+        for j in range(ind_cols):
+            if j < nzcount[i]:
+                ind[i, j] = jab[k_col]
+                k_col += 1
+            else:
+                ind[i, j] = -1
+    vbr_shift = bel_shift = 0
+    flat = val.reshape(-1)
+    for k in range(ind_rows):                                           # :1698-1705
+        for i in range(bs):
+            for j in range(val_cols):
+                flat[bel_shift + i * val_cols + j] = mab[vbr_shift + j * bs + i] if ind[k, j // bs] != -1 else 0.0
+        vbr_shift += int(nzcount[k]) * bs * bs
+        bel_shift += ind_cols * bs * bs
+    return bs, ind, val

@@ -35,7 +35,7 @@ SYMBOLS = [
     "sparta_vbs_class_times", "sparta_vbs_clock_mhz", "sparta_vbs_destroy", "sparta_vbs_info", "sparta_vbs_sparse_info", "sparta_device_count", "sparta_last_error",
     "sparta_version",
     "sparta_csr_read", "sparta_csr_read_buffer", "sparta_csr_host_free", "sparta_csr_write_edgelist", "sparta_grouping_write", "sparta_grouping_read",
-    "sparta_blocking_csv_row", "sparta_degree_permutation", "sparta_vbs_save", "sparta_vbs_load",
+    "sparta_blocking_csv_row", "sparta_degree_permutation", "sparta_vbs_save", "sparta_vbs_load", "sparta_vbs_to_blocked_ell",
 ]
 
 
@@ -103,6 +103,7 @@ def _load():
     L.sparta_vbs_host_free.argtypes = [C.POINTER(VbsHost)]
     L.sparta_vbs_save.argtypes = [C.c_char_p, C.POINTER(VbsHost)]
     L.sparta_vbs_load.argtypes = [C.c_char_p, C.POINTER(VbsHost)]
+    L.sparta_vbs_to_blocked_ell.argtypes = [C.POINTER(VbsHost), i64p, i64p, f32p]
     L.sparta_vbs_host_free.restype = None
     L.sparta_blocking_info.argtypes = [C.c_int64, C.c_int64, i64p, i32p, i64p, C.c_int64, i64p, f32p]
     L.sparta_vbs_create.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, C.c_int64, C.c_int64, i64p, i64p, i64p, f32p,

@@ -433,6 +433,43 @@ inline uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
 
 extern "C" {
 
+// Blocked-ELL view of a VBS with square blocks -- restates prepare_cusparse_BLOCKEDELLPACK (src/cuda/cuda_utilities.cpp:1656-1710),
+// the mapping the reference feeds to cusparseCreateBlockedEll: ell_blocksize = block_col_size; ellColInd[rows/bs][ell_cols] holds
+// the block-column ids of a block-row in VBS order, padded with -1 ("the algorithm automatically pads it with a complete zero
+// block", :1691); ellValues is row-major rows x (ell_cols * bs), element (k*bs + i, j) = mab[shift_k + j*bs + i] when block j / bs
+// of block-row k exists, else 0 (:1700-1701).  The reference requires rows % bs == 0 and cols % bs == 0 (exit otherwise,
+// :1666-1672) and silently ASSUMES that every block-row is bs rows tall (it indexes nzcount by i < rows / bs and strides mab by
+// bs*bs per block, :1675-1705): here that assumption is checked.
+int sparta_vbs_to_blocked_ell(const sparta_vbs_host* v, int64_t* ell_cols_out, int64_t* ell_col_ind, float* ell_values) {
+    if (!v || !ell_cols_out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_to_blocked_ell: NULL argument");
+    const int64_t bs = v->block_col_size;
+    if (bs <= 0 || v->rows % bs != 0 || v->cols % bs != 0)
+        return fail(SPARTA_ERR_INVALID, v->rows % std::max<int64_t>(bs, 1) != 0 ? "The number of rows is not multiple of ell_blocksize"
+                                                                                : "The number of cols is not multiple of ell_blocksize");
+    if (v->block_rows != v->rows / bs) return fail(SPARTA_ERR_INVALID, "sparta_vbs_to_blocked_ell: every block-row must be block_col_size rows tall (fixed square blocking)");
+    int64_t ell_cols = 0;
+    for (int64_t k = 0; k < v->block_rows; k++) {
+        if (v->row_part[k + 1] - v->row_part[k] != bs)
+            return fail(SPARTA_ERR_INVALID, "sparta_vbs_to_blocked_ell: every block-row must be block_col_size rows tall (fixed square blocking)");
+        ell_cols = std::max(ell_cols, v->nzcount[k]);
+    }
+    *ell_cols_out = ell_cols;
+    if (!ell_col_ind || !ell_values) return SPARTA_OK;                     // size query
+    const int64_t vcols = ell_cols * bs;
+    int64_t jo = 0, mo = 0;
+    for (int64_t k = 0; k < v->block_rows; k++) {
+        const int64_t nb = v->nzcount[k];
+        for (int64_t j = 0; j < ell_cols; j++) ell_col_ind[k * ell_cols + j] = j < nb ? v->jab[jo + j] : -1;
+        for (int64_t i = 0; i < bs; i++) {
+            float* row = ell_values + (k * bs + i) * vcols;
+            for (int64_t j = 0; j < vcols; j++) row[j] = j / bs < nb ? v->mab[mo + j * bs + i] : 0.0f;
+        }
+        jo += nb;
+        mo += nb * bs * bs;
+    }
+    return SPARTA_OK;
+}
+
 int sparta_vbs_save(const char* path, const sparta_vbs_host* v) {
     if (!path || !v) return fail(SPARTA_ERR_INVALID, "sparta_vbs_save: NULL argument");
     if (v->block_rows < 0 || v->nblocks < 0 || v->nztot < 0 || !v->row_part || (v->block_rows > 0 && !v->nzcount) || (v->nblocks > 0 && !v->jab) ||

@@ -248,6 +248,27 @@ class VBR:
         v.nztot = len(v.mab)
         return v
 
+    def _host_struct(self):
+        h = _lib.VbsHost()
+        h.rows, h.cols, h.block_rows, h.block_cols = self.rows, self.cols, self.block_rows, self.block_cols
+        h.block_col_size, h.nztot, h.nblocks = self.block_col_size, len(self.mab), len(self.jab)
+        keep = (np.ascontiguousarray(self.row_part, np.int64), np.ascontiguousarray(self.nzcount, np.int64),
+                np.ascontiguousarray(self.jab, np.int64), np.ascontiguousarray(self.mab, np.float32))
+        h.row_part, h.nzcount, h.jab, h.mab = _p64(keep[0]), _p64(keep[1]), _p64(keep[2]), _pf(keep[3])
+        return h, keep
+
+    def to_blocked_ell(self):
+        """prepare_cusparse_BLOCKEDELLPACK (src/cuda/cuda_utilities.cpp:1656-1710): -> (ell_blocksize, ellColInd[rows/bs][ell_cols] with
+        -1 padding, ellValues[rows][ell_cols * bs]); needs fixed square blocks (row_block_size == col_block_size, padded sizes)."""
+        h, keep = self._host_struct()
+        n = C.c_int64(0)
+        check(lib.sparta_vbs_to_blocked_ell(C.byref(h), C.byref(n), None, None))
+        bs = int(self.block_col_size)
+        ind = np.zeros((self.rows // bs, n.value), np.int64)
+        val = np.zeros((self.rows, n.value * bs), np.float32)
+        check(lib.sparta_vbs_to_blocked_ell(C.byref(h), C.byref(n), _p64(ind), _pf(val)))
+        return bs, ind, val
+
     def save(self, path):
         """Binary container (sparta_vbs_save): the five arrays + checksum in one file -- the reorder is paid once."""
         h = _lib.VbsHost()

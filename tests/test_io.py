@@ -352,3 +352,48 @@ def test_vbs_container_rejects_damage(tmp_path):
     empty.save(tmp_path / "e.vbs")
     e2 = sa.VBR.load(tmp_path / "e.vbs")
     assert e2.rows == 5 and e2.nztot == 0 and len(e2.jab) == 0
+
+
+# ---- Blocked-ELL view (prepare_cusparse_BLOCKEDELLPACK, cuda_utilities.cpp:1656-1710) ---------------------------------------------
+
+@pytest.mark.parametrize("rows,cols,nnz,bs", [(24, 36, 60, 4), (64, 64, 300, 8), (30, 18, 0, 6), (16, 48, 200, 16)])
+def test_blocked_ell_view(rows, cols, nnz, bs):
+    m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + cols + bs)
+    v = sa.VBR().fill_from_CSR_inplace_fixed(m, bs, bs)
+    b, ind, val = v.to_blocked_ell()
+    bo, indo, valo = IO.blocked_ell(v.rows, v.cols, bs, v.nzcount, v.jab, v.mab)
+    assert b == bo == bs and np.array_equal(ind, indo) and np.array_equal(val, valo)
+    # the Blocked-ELL arrays expand to the matrix itself; padding blocks are -1 / zeros
+    dense = np.zeros((rows, cols), np.float32)
+    for i in range(rows):
+        dense[i, m.colidx[m.rowptr[i]:m.rowptr[i + 1]]] = m.vals[m.rowptr[i]:m.rowptr[i + 1]]
+    back = np.zeros((v.rows, v.cols), np.float32)
+    for k in range(ind.shape[0]):
+        for j in range(ind.shape[1]):
+            if ind[k, j] >= 0:
+                back[k * bs:(k + 1) * bs, ind[k, j] * bs:(ind[k, j] + 1) * bs] = val[k * bs:(k + 1) * bs, j * bs:(j + 1) * bs]
+            else:
+                assert not val[k * bs:(k + 1) * bs, j * bs:(j + 1) * bs].any()
+    perm = sa.get_permutation(np.arange(rows) // bs)                  # rows of a VBS are in get_permutation order (unstable sort: even a fixed grid permutes inside its groups)
+    assert np.array_equal(back, dense[perm])
+    assert ind.shape == (rows // bs, int(v.nzcount.max()) if len(v.nzcount) else 0)
+    for k in range(ind.shape[0]):
+        assert (ind[k] >= 0).sum() == v.nzcount[k] and list(ind[k][:v.nzcount[k]]) == sorted(ind[k][:v.nzcount[k]])
+
+
+def test_blocked_ell_view_rejects_what_the_reference_cannot_handle():
+    m = sa.gen.uniform_random(30, 20, 80, seed=3)
+    # sizes that are not multiples of the block size: the reference prints and exits (:1666-1672)
+    with pytest.raises(sa.SpartaError) as ei:
+        sa.VBR().fill_from_CSR_inplace_fixed(m, 4, 4).to_blocked_ell()
+    assert "multiple of ell_blocksize" in str(ei.value)
+    with pytest.raises(IO.RefUndefined):
+        IO.blocked_ell(30, 20, 4, [], [], [])
+    # block-rows that are not bs tall: the reference indexes as if they were (garbage); refused here
+    g = sa.BlockingEngine(tau=0.5, col_block_size=4).GetGrouping(sa.gen.uniform_random(32, 20, 80, seed=3))
+    with pytest.raises(sa.SpartaError):
+        sa.VBR().fill_from_CSR_inplace(sa.gen.uniform_random(32, 20, 80, seed=3), g, 4).to_blocked_ell()
+    # force_fixed_size pads rows / cols up to multiples: then it works for any size
+    v = sa.VBR().fill_from_CSR_inplace(m, np.arange(30) // 4, 4, 4, True)
+    bs, ind, val = v.to_blocked_ell()
+    assert (v.rows, v.cols) == (32, 20) and ind.shape[0] == 8 and val.shape == (32, ind.shape[1] * 4)
