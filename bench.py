@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--force-fixed", type=int, default=1, help="-F: re-chunk clusters into equal heights")
     ap.add_argument("--col-block", type=int, default=32)
     ap.add_argument("--dtype", choices=["f32", "f16", "bf16"], default="f32",
-                    help="storage type of A and B on the device (accumulation and C are always fp32); 16-bit: single GPU only")
+                    help="storage type of A and B on the device (accumulation and C are always fp32)")
     ap.add_argument("--ncols", type=int, default=128)
     ap.add_argument("--fixed-height", type=int, default=0, help="reorder OFF: fixed block-row height instead of clustering")
     ap.add_argument("--no-cpu-baseline", action="store_true")
