@@ -1,5 +1,7 @@
 """CPU: the product's host-side C++ (reorder engine + VBS builder, through the C-ABI / sparta_amd mirror classes)
 against the golden vectors from the compiled reference -- including algorithm 5 (IterativeBlockingKeeper) and 6."""
+import os
+
 import numpy as np
 import pytest
 
@@ -227,3 +229,17 @@ def test_minhash_reorder_equals_the_exact_algorithm_at_tau_zero():
         g3, g7 = e3.GetGrouping(m), e7.GetGrouping(m)
         assert np.array_equal(g3, g7), (case, rows, cols, w)
         assert e3.merge_counter == e7.merge_counter
+
+
+def test_minhash_regression_fixture():
+    """blocking_algo 7 has no reference; tests/golden/minhash_regression.npz pins what it returns for seeded inputs (regression only)"""
+    import hashlib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_minhash", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden_minhash.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "minhash_regression.npz"))
+    for i, c in enumerate(mod.CASES):
+        g, cmp_, mrg = mod.run(c)
+        assert bytes(fx["sha%d" % i]) == hashlib.sha256(g.tobytes()).digest(), c
+        assert fx["stat%d" % i].tolist() == [cmp_, mrg, len(np.unique(g))]
