@@ -64,3 +64,20 @@ print("first 6 steps of wave 0 (relative ticks):")
 w0 = t[0][t[0][:, 0] > 0]
 for r in w0[:6]:
     print("   ", (r[:7] - w0[0][0]).tolist(), "flags %x" % r[7])
+# steps that end a tile (epilogue: 16-32 stores per wave) and the steps right after them, against the rest
+STEP_LAST = 1 << 17
+for wv in range(1):
+    tw = t[wv][t[wv][:, 0] > 0]
+    if len(tw) < 8:
+        break
+    last = (tw[:, 7] & STEP_LAST) != 0
+    period = tw[1:, 0] - tw[:-1, 0]                        # period[k]: start of step k -> start of step k+1
+    seg = np.diff(tw[:, :7], axis=1)
+    after1 = np.roll(last, 1); after1[0] = False
+    after2 = np.roll(last, 2); after2[:2] = False
+    for name, sel in (("tile-end steps", last), ("1st step after a tile end", after1 & ~last), ("2nd step after", after2 & ~last & ~after1), ("other steps", ~last & ~after1 & ~after2)):
+        s = sel[:-1]
+        if s.sum() == 0:
+            continue
+        print("%-28s n=%3d period mean %6.0f | rounds %s | epilogue %5.0f barrier %5.0f" % (name, s.sum(), period[s].mean(), np.round(seg[:-1][s][:, :4].mean(axis=0)).astype(int).tolist(),
+              seg[:-1][s][:, 4].mean(), seg[:-1][s][:, 5].mean()))
