@@ -67,7 +67,7 @@ for case in range(n_cases):
             os.environ.pop("SPARTA_SPARSE_K", None)
         else:
             os.environ["SPARTA_SPARSE_K"] = spk
-        os.environ["SPARTA_PATH"] = "auto"
+        os.environ["SPARTA_PATH"] = "stream" if (w % 32 == 0 and n % 128 == 0) else "generic"    # bit-for-bit: the same MFMA path on both handles
         os.environ.pop("SPARTA_STREAM_ALIGN", None)
         d1, d2 = v.to_device(0), sa.DeviceVBS.from_csr(m, g, w, device=0)
         for lay in (sa.COL_MAJOR, sa.ROW_MAJOR):

@@ -1131,6 +1131,8 @@ struct SparseParams {
     const int32_t* list;       // the rows this launch handles (ordinals)
     int32_t n_list;
     const void* B;             // row-major, ld = ldb elements; fp32 (BK = 0), fp16 (1) or bf16 (2)
+    int64_t b_col_stride;      // 0: row-major B as above.  > 0: B is COLUMN-major (element (k, n) at slab(k) + k % shard_rows + n * b_col_stride),
+    int64_t shard_rows, shard_stride;   //      read in place, one 4-byte gather per element: only worth it for a handful of sparse rows
     int64_t ldb;
     float* out;                // row-major out: C itself (ld = ldc, row = crow) or the scratch (ld = N, row = ordinal)
     int64_t ldo;
@@ -1151,10 +1153,20 @@ __device__ __forceinline__ typename SpVec<VEC>::T sparse_row_partial(const Spars
         float vl = 0.0f;
         if (lane < n) { cl = p.col[q + lane]; vl = p.val[q + lane]; }
         L b[8];
+        if (VEC == 1 && p.b_col_stride > 0) {                    // column-major B in place (few sparse rows: cheaper than transposing all of B)
+            const E* Bc = (const E*)p.B + (in ? (int64_t)n0 * p.b_col_stride : 0);
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const int c = __builtin_amdgcn_readlane(cl, t);      // lanes >= n hold column 0: a valid row, never used
-            b[t] = *reinterpret_cast<const L*>(Bl + (int64_t)c * p.ldb);
+            for (int t = 0; t < 8; t++) {
+                const int64_t c = __builtin_amdgcn_readlane(cl, t);
+                const int64_t off = p.shard_rows > 0 ? (c / p.shard_rows) * p.shard_stride + c % p.shard_rows : c;
+                b[t] = *reinterpret_cast<const L*>(Bc + off);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int c = __builtin_amdgcn_readlane(cl, t);  // lanes >= n hold column 0: a valid row, never used
+                b[t] = *reinterpret_cast<const L*>(Bl + (int64_t)c * p.ldb);
+            }
         }
 #pragma unroll
         for (int t = 0; t < 8; t++) {
@@ -2255,7 +2267,12 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     q.rowptr = A->d_sp_rowptr; q.col = A->d_sp_col; q.val = A->d_sp_val; q.crow = A->d_sp_crow;
     q.list = nullptr; q.n_list = 0;
     q.N = n_cols; q.accumulate = accumulate;
+    q.b_col_stride = 0; q.shard_rows = 0; q.shard_stride = 0;
+    // A column-major B read in place costs one 64-byte line per ELEMENT (16 x the bytes of a row-major row); transposing costs
+    // 2 x |B| once.  In place wins while  nnz * 16 < 2 * cols.
+    const bool in_place = !(b_row_major && shard_rows == 0) && A->sp_nnz * 8 < A->cols;
     if (b_row_major && shard_rows == 0) { q.B = dB; q.ldb = ldb; }
+    else if (in_place) { q.B = dB; q.ldb = 0; q.b_col_stride = ldb; q.shard_rows = shard_rows; q.shard_stride = shard_stride; }
     else {
         if (int rc = ensure_scratch(&A->d_Brm, &A->d_Brm_bytes, (size_t)A->cols * (size_t)n_cols * esz)) return rc;
         const dim3 grid((unsigned)((A->cols + 31) / 32), (unsigned)((n_cols + 31) / 32));
@@ -2274,7 +2291,7 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     auto aligned = [&](int v) {
         return n_cols % (64 * v) == 0 && q.ldb % v == 0 && q.ldo % v == 0 && ((uintptr_t)q.B % (esz * v)) == 0 && ((uintptr_t)q.out % (4 * v)) == 0;
     };
-    const int vec = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
+    const int vec = in_place ? 1 : (aligned(4) ? 4 : (aligned(2) ? 2 : 1));
     const unsigned gy = (unsigned)((n_cols + 64 * vec - 1) / (64 * vec));
 #define SPARTA_SP_DISPATCH(V_)                                                             \
     do {                                                                                   \

@@ -750,10 +750,11 @@ def test_sparse_row_path_16bit(_sparse_row_mode, dtype, n):
 
 @pytest.mark.parametrize("dtype", [sa.F32, sa.F16], ids=["f32", "f16"])
 @pytest.mark.parametrize("case", ["mixed", "rmat", "rmat-fixed"])
-def test_create_from_csr_gives_the_same_product(_sparse_row_mode, case, dtype):
+def test_create_from_csr_gives_the_same_product(monkeypatch, _sparse_row_mode, case, dtype):
     """sparta_vbs_create_from_csr never expands the nearly empty block-rows; the product must be BIT-identical to the one of a
     handle made by sparta_vbs_build + sparta_vbs_create (same decisions, same kernels, same data), and equal to the oracle's"""
     torch = _torch()
+    monkeypatch.setenv("SPARTA_PATH", "stream")              # two handles compared bit for bit: same MFMA path on both (no autotune)
     n = 128
     if case == "mixed":
         m, w = _mixed_matrix()
@@ -848,3 +849,48 @@ def test_16bit_gathered_b_and_row_block_exchange(_sparse_row_mode, dtype):
         torch.cuda.synchronize()
         _check(Ct.cpu().numpy(), Co, bound, "16-bit row-block exchange rank %d" % r)
         exs[r].close()
+
+
+@pytest.mark.parametrize("dtype", [sa.F32, sa.BF16], ids=["f32", "bf16"])
+def test_few_sparse_rows_read_a_column_major_b_in_place(_sparse_row_mode, dtype):
+    """a handful of sparse rows next to a large dense part: transposing all of B for them would cost more than the rows
+    themselves, so a column-major (or gathered) B is gathered in place"""
+    torch = _torch()
+    rng = np.random.Generator(np.random.PCG64(9))
+    rows, cols, w, n = 200, 6400, 32, 128
+    rr, cc = [], []
+    for i in range(192):                                      # dense part
+        c = rng.choice(640, 300, replace=False)
+        rr.append(np.full(300, i)); cc.append(c)
+    for i in range(192, 197):                                 # five scattered rows (rows 197..199 empty)
+        c = rng.choice(cols, 4, replace=False)
+        rr.append(np.full(4, i)); cc.append(c)
+    r, c = np.concatenate(rr), np.concatenate(cc)
+    o = np.lexsort((c, r)); r, c = r[o], c[o]
+    m = sa.CSR(rows, cols, np.concatenate([[0], np.cumsum(np.bincount(r, minlength=rows))]), c.astype(np.int32), rng.uniform(-1, 1, len(c)).astype(np.float32))
+    g = np.concatenate([np.arange(192) // 32, np.arange(192, 200)])
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=3)
+    tdt = {sa.F32: torch.float32, sa.BF16: torch.bfloat16}[dtype]
+    mab_r, B_r = (v.mab, B) if dtype == sa.F32 else (_round16(v.mab, dtype), _round16(B, dtype))
+    Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n, None)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n)
+    d = v.to_device(0, dtype=dtype)
+    if _sparse_row_mode == "with-sparse-rows":
+        sp = d.sparse_info()
+        assert 0 < sp["rows"] <= 8 and sp["nnz"] * 8 < v.cols
+    Bt = torch.from_numpy(B).cuda().to(tdt)
+    for cl in (sa.COL_MAJOR, sa.ROW_MAJOR):
+        Ct = torch.full((v.rows * n,), 9.0, dtype=torch.float32, device="cuda")
+        d.spmm(Bt, Ct, n, c_layout=cl)
+        torch.cuda.synchronize()
+        got = Ct.cpu().numpy()
+        if cl == sa.ROW_MAJOR:
+            got = np.ascontiguousarray(got.reshape(v.rows, n).T).reshape(-1)
+        _check(got, Co, bound, "few sparse rows, c_layout %d" % cl)
+    # gathered B (two slabs of 3200 rows)
+    Bg = torch.from_numpy(np.ascontiguousarray(B.reshape(n, 2, 3200).transpose(1, 0, 2)).reshape(-1)).cuda().to(tdt)
+    Ct = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
+    d.spmm_gathered(Bg, 3200, Ct, n)
+    torch.cuda.synchronize()
+    _check(Ct.cpu().numpy(), Co, bound, "few sparse rows, gathered B")
