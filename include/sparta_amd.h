@@ -86,7 +86,7 @@ typedef struct sparta_reorder_cfg {
     int32_t minhash_bands;     /* blocking_algo 7 only: LSH bands (0 = 16) ...                                              */
     int32_t minhash_rows;      /* ... minhash values per band (0 = from tau), ...                                            */
     int32_t minhash_max_eval;  /* ... exact comparisons per seed at most (0 = 512), ...                                       */
-    int32_t minhash_max_rows;  /* ... a cluster stops growing once it has this many rows (0 = unlimited; identical rows join together) */
+    int32_t minhash_max_rows;  /* ... a cluster never grows beyond this many rows (0 = unlimited); only a seed's own identical copies can exceed it */
 } sparta_reorder_cfg;
 
 /* replaces the measuring fields of BlockingEngine (include/blocking.h:28-42) */

@@ -899,6 +899,7 @@ void minhash_lsh(Ctx& c, int64_t* grouping) {
                 const int32_t u = cand[pos];
                 const int64_t j = uniq[(size_t)u];
                 hits[(size_t)u] = UINT16_MAX;
+                if (members + 1 + (dup_ptr[(size_t)u + 1] - dup_ptr[(size_t)u]) > cap) continue;   // the row and its identical copies would not fit: left to another seed
                 evals++;
                 c.comparisons++;
                 const float d = c.dist(gsize, j);
