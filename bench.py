@@ -49,6 +49,38 @@ def mixed_roofline_seconds(row_part, nzcount, w, n_cols, cols, accumulate=False)
     return float(t), float(flops.sum()), float(byts.sum() + cols * n_cols * 4.0)
 
 
+def _stage_collectives_through_host(dist, sa):
+    """--backend gloo (debug): gloo has no device collectives for these calls, so the few this file uses go through host copies."""
+    import torch
+
+    class _Done:
+        def wait(self):
+            return True
+
+    real_ag, real_ar, real_bar = dist.all_gather_into_tensor, dist.all_reduce, dist.barrier
+
+    def all_gather_into_tensor(out, inp, group=None):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        real_ag(o, inp.cpu(), group=group)
+        out.copy_(o)
+
+    def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
+        c = t.cpu()
+        real_ar(c, op=op, group=group)
+        t.copy_(c)
+
+    def a2a(self):
+        torch.cuda.synchronize()
+        o = torch.empty(self._recv_view.shape, dtype=self._recv_view.dtype)
+        dist.all_to_all_single(o, self._send_view.cpu(), self.out_splits, self.in_splits, group=self.group)
+        self._recv_view.copy_(o)
+        return _Done()
+
+    dist.all_gather_into_tensor, dist.all_reduce = all_gather_into_tensor, all_reduce
+    dist.barrier = lambda *a, **k: real_bar()
+    sa.dist.RowBlockExchange._all_to_all = a2a
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +104,9 @@ def main():
     ap.add_argument("--rmat-scale", type=int, default=20)
     ap.add_argument("--exchange", choices=["auto", "allgather", "blocks"], default="auto",
                     help="N > 1: how the ranks' shards of B reach the slabs (see the module docstring)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: DEBUG ONLY -- several ranks on ONE GPU (a one-GPU box), collectives staged through host memory; checks the "
+                         "multi-rank logic end to end, its timings mean nothing")
     ap.add_argument("--dist-path", action="store_true", help="run the multi-GPU code path (slab + all-gather + gathered SpMM) even with one rank")
     args = ap.parse_args()
 
@@ -88,6 +123,8 @@ def main():
         raise SystemExit("for --gpus > 1 launch with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the SpMM path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -96,7 +133,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            _stage_collectives_through_host(dist, sa)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     w, N = args.col_block, args.ncols
     t0 = time.time()

@@ -190,14 +190,18 @@ class RowBlockExchange:
         d = self.d_own if which == "own" else self.d_rem
         d.spmm_gathered(B_tiles, self.w, C_out, self.N, accumulate=accumulate)
 
+    def _all_to_all(self):
+        """the ONE collective of a step (asynchronous: returns the work handle)"""
+        import torch.distributed as dist
+        return dist.all_to_all_single(self._recv_view, self._send_view, self.out_splits, self.in_splits, group=self.group, async_op=True)
+
     def step(self, B_own_tiles, C_out, accumulate=False):
         """C (+)= A_slab * B with B distributed: pack -> all-to-all (asynchronous) || own-shard product -> remote product."""
-        import torch.distributed as dist
         work = None
         if self.any_exchange:
             if self.n_send:
                 self._pack(B_own_tiles)
-            work = dist.all_to_all_single(self._recv_view, self._send_view, self.out_splits, self.in_splits, group=self.group, async_op=True)
+            work = self._all_to_all()
         self._product("own", B_own_tiles, C_out, accumulate)
         if work is not None:
             work.wait()
