@@ -1236,49 +1236,52 @@ __global__ __launch_bounds__(kThreads) void sparse_reduce_kernel(SparseParams p,
     sparse_row_store<VEC>(p, r.ord, acc, n0);
 }
 
-// B (column-major, ld = ldb, or the gathered slabs) -> row-major rows x N (ld = N); 32 x 32 tiles through LDS
+// B (column-major, ld = ldb, or the gathered slabs) -> row-major rows x N (ld = N); 64 x 64 tiles through LDS: a wave reads 64
+// consecutive rows of one column (256 contiguous bytes) and writes 64 consecutive columns of one row (256 contiguous bytes)
 template <class E>
 __global__ __launch_bounds__(kThreads) void b_to_row_major_kernel(const E* __restrict__ B, int64_t ldb, int64_t shard_rows, int64_t shard_stride,
                                                                   int64_t rows, int N, E* __restrict__ out) {
-    __shared__ E tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
-    const int64_t r0 = (int64_t)blockIdx.x * 32;
-    const int n0 = blockIdx.y * 32;
-    for (int j = ty; j < 32; j += 8) {                           // read: lanes along the rows (contiguous in a column)
-        const int64_t r = r0 + tx;
+    __shared__ E tile[64][65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 64;
+    const int64_t r = r0 + lane;
+    int64_t roff = r;
+    if (shard_rows > 0 && r < rows) roff = (r / shard_rows) * shard_stride + (r % shard_rows);   // shard_rows % 64 need not hold: per lane
+    for (int j = wave; j < 64; j += 4) {                         // read: lanes along the rows (contiguous in a column)
         const int n = n0 + j;
         E v = (E)0;
-        if (r < rows && n < N) v = shard_rows > 0 ? B[(r / shard_rows) * shard_stride + (r % shard_rows) + (int64_t)n * ldb] : B[r + (int64_t)n * ldb];
-        tile[j][tx] = v;
+        if (r < rows && n < N) v = B[roff + (int64_t)n * ldb];
+        tile[j][lane] = v;
     }
     __syncthreads();
-    for (int j = ty; j < 32; j += 8) {                           // write: lanes along the columns (contiguous in a row)
-        const int64_t r = r0 + j;
-        const int n = n0 + tx;
-        if (r < rows && n < N) out[r * N + n] = tile[tx][j];
+    for (int j = wave; j < 64; j += 4) {                         // write: lanes along the columns (contiguous in a row)
+        const int64_t rr = r0 + j;
+        const int n = n0 + lane;
+        if (rr < rows && n < N) out[rr * N + n] = tile[lane][j];
     }
 }
 
 // scratch (row-major, one row per sparse row) -> the column-major C rows they belong to
 __global__ __launch_bounds__(kThreads) void sparse_c_scatter_kernel(const float* __restrict__ src, const int32_t* __restrict__ crow, int64_t n_rows, int N,
                                                                     float* __restrict__ C, int64_t ldc, int accumulate) {
-    __shared__ float tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int64_t t0 = (int64_t)blockIdx.x * 32;
-    const int n0 = blockIdx.y * 32;
-    for (int j = ty; j < 32; j += 8) {
+    __shared__ float tile[64][65];                               // 64 sparse rows x 64 columns
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 64;
+    for (int j = wave; j < 64; j += 4) {                         // read: lanes along the columns of one scratch row
         const int64_t t = t0 + j;
-        const int n = n0 + tx;
-        tile[j][tx] = (t < n_rows && n < N) ? src[t * N + n] : 0.0f;
+        const int n = n0 + lane;
+        tile[j][lane] = (t < n_rows && n < N) ? src[t * N + n] : 0.0f;
     }
     __syncthreads();
-    const int64_t t = t0 + tx;
-    const int32_t r = t < n_rows ? crow[t] : 0;
-    for (int j = ty; j < 32; j += 8) {
+    const int64_t t = t0 + lane;
+    const int32_t r = t < n_rows ? crow[t] : 0;                  // consecutive sparse rows are mostly consecutive rows of C
+    for (int j = wave; j < 64; j += 4) {                         // write: lanes along the rows of one column of C
         const int n = n0 + j;
         if (t < n_rows && n < N) {
             float* o = C + r + (int64_t)n * ldc;
-            *o = accumulate ? *o + tile[tx][j] : tile[tx][j];
+            *o = accumulate ? *o + tile[lane][j] : tile[lane][j];
         }
     }
 }
@@ -2275,7 +2278,7 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     else if (in_place) { q.B = dB; q.ldb = 0; q.b_col_stride = ldb; q.shard_rows = shard_rows; q.shard_stride = shard_stride; }
     else {
         if (int rc = ensure_scratch(&A->d_Brm, &A->d_Brm_bytes, (size_t)A->cols * (size_t)n_cols * esz)) return rc;
-        const dim3 grid((unsigned)((A->cols + 31) / 32), (unsigned)((n_cols + 31) / 32));
+        const dim3 grid((unsigned)((A->cols + 63) / 64), (unsigned)((n_cols + 63) / 64));
         if (bk == 0) hipLaunchKernelGGL(b_to_row_major_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)dB, ldb, shard_rows, shard_stride, A->cols, (int)n_cols, (float*)A->d_Brm);
         else hipLaunchKernelGGL(b_to_row_major_kernel<unsigned short>, grid, dim3(kThreads), 0, st, (const unsigned short*)dB, ldb, shard_rows, shard_stride, A->cols, (int)n_cols, (unsigned short*)A->d_Brm);
         q.B = A->d_Brm; q.ldb = n_cols;
@@ -2302,7 +2305,7 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     if (vec == 4) SPARTA_SP_DISPATCH(4); else if (vec == 2) SPARTA_SP_DISPATCH(2); else SPARTA_SP_DISPATCH(1);
 #undef SPARTA_SP_DISPATCH
     if (!q.out_is_c)
-        hipLaunchKernelGGL(sparse_c_scatter_kernel, dim3((unsigned)((A->n_sp_rows + 31) / 32), (unsigned)((n_cols + 31) / 32)), dim3(kThreads), 0, st,
+        hipLaunchKernelGGL(sparse_c_scatter_kernel, dim3((unsigned)((A->n_sp_rows + 63) / 64), (unsigned)((n_cols + 63) / 64)), dim3(kThreads), 0, st,
                            (const float*)A->d_spC, A->d_sp_crow, A->n_sp_rows, (int)n_cols, dC, ldc, (int)accumulate);
     HIP_TRY(hipGetLastError());
     return SPARTA_OK;
