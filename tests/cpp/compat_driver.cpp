@@ -63,6 +63,14 @@ int main(int argc, char** argv) {
     bEngine.CollectBlockingInfo(cmat);
     std::printf("info: %ld %ld %ld\n", bEngine.VBR_nzcount, bEngine.VBR_nzblocks_count, bEngine.VBR_longest_row);
 
+    // the extension algorithm through the same class (BlockingType minhash = 7): tau = 0 groups exactly the rows with the same block set
+    BlockingEngine lsh;
+    lsh.tau = 0.0f; lsh.col_block_size = 3; lsh.blocking_algo = minhash; lsh.minhash_bands = 8;
+    lsh.GetGrouping(cmat);
+    std::printf("minhash:");
+    for (intT g : lsh.grouping_result) std::printf(" %ld", g);
+    std::printf("\n");
+
     if (gpu) {
         std::vector<DataT> B(18);
         for (int i = 0; i < 18; i++) B[(size_t)i] = (DataT)(i + 1);

@@ -30,6 +30,8 @@ def test_compat_driver_host_side():
     assert r["dims"].split() == "9 9 4 3 33".split()
     assert r["jab"].split() == "0 1 2 2 0".split()
     assert r["info"].split() == ["33", "5", "3"]
+    # rows 0, 4, 6, 7 are empty; rows 1 and 3 touch the same blocks {0, 1, 2} of 3 columns
+    assert r["minhash"].split() == "0 1 2 1 0 5 0 0 8".split()
 
 
 @pytest.mark.gpu
