@@ -102,6 +102,9 @@ def main():
                     help="cant: BASELINE configs[1] (the default, what `value` is quoted on); rmat: configs[3] in miniature -- R-MAT 2^scale rows, "
                          "10 edges per row symmetrised, reordered by blocking_algo 7 (single GPU; carried by the sparse-row kernels: roofline.bound = hbm)")
     ap.add_argument("--rmat-scale", type=int, default=20)
+    ap.add_argument("--matrix", default=None,
+                    help="run the single-GPU pipeline on a matrix file instead of the synthetic workload (.mtx MatrixMarket or .el edge list, read as "
+                         "documented = SPARTA_IO_STRICT): e.g. the real SuiteSparse cant.mtx where a copy is at hand (none can be fetched here)")
     ap.add_argument("--exchange", choices=["auto", "allgather", "blocks"], default="auto",
                     help="N > 1: how the ranks' shards of B reach the slabs (see the module docstring)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -145,7 +148,14 @@ def main():
     rmat = args.workload == "rmat"
     if rmat and distributed:
         raise SystemExit("--workload rmat is a single-GPU option")
-    if rmat:
+    if args.matrix:
+        if distributed:
+            raise SystemExit("--matrix is a single-GPU option")
+        fmt = sa._lib.FMT_MTX if args.matrix.lower().endswith(".mtx") else sa._lib.FMT_EL
+        m = sa.CSR.read_from_edgelist(args.matrix, mat_fmt=fmt, mode=sa._lib.IO_STRICT)
+        n_local, shard_rows = m.rows, None
+        rmat = False
+    elif rmat:
         m = sa.gen.rmat(args.rmat_scale, 10 << args.rmat_scale, seed=3, symmetrize=True, pattern_only=False)
         n_local, shard_rows = m.rows, None
         if args.algo == 5 and args.tau == 0.6 and w == 32:       # untouched defaults: the settings this workload is meant for
@@ -449,9 +459,10 @@ def main():
     out = {
         "metric": "Block-sparse SpMM GFLOP/s", "value": round(useful_gflops, 2), "unit": "GFLOP/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "file" if args.matrix else "synthetic",
         "config": {
-            "workload": ("R-MAT 2^%d (a,b,c = 0.57,0.19,0.19; 10 edges per row, symmetrised: %d^2, %d nnz), B = %d cols, %s"
+            "workload": ("%s (%d x %d, %d nnz), B = %d cols, %s" % (os.path.basename(args.matrix), m.rows, m.cols, nnz_local, N, args.dtype)) if args.matrix else
+                        ("R-MAT 2^%d (a,b,c = 0.57,0.19,0.19; 10 edges per row, symmetrised: %d^2, %d nnz), B = %d cols, %s"
                          % (args.rmat_scale, m.rows, nnz_local, N, args.dtype)) if rmat else
                         ("cant-like FEM 9x9x257 mesh x 3 dof (62451^2, %d nnz), B = %d cols, fp32" % (nnz_local, N)) if not distributed else
                         ("row-partitioned FEM 9x9x%d mesh x 3 dof (%d^2 padded, %d nnz), B = %d cols, fp32, %s per step"
