@@ -173,6 +173,7 @@ class RowBlockExchange:
         self._pack = pack if pack is not None else self._pack_hip
         self._product = product if product is not None else self._product_hip
         self.d_own = self.d_rem = None
+        self._side = None
         if product is None:
             self.d_own = self.own.to_device(device, dtype=dtype)
             self.d_rem = self.remote.to_device(device, dtype=dtype) if self.remote is not None else None
@@ -197,16 +198,32 @@ class RowBlockExchange:
 
     def step(self, B_own_tiles, C_out, accumulate=False):
         """C (+)= A_slab * B with B distributed: pack -> all-to-all (asynchronous) || own-shard product -> remote product."""
-        work = None
-        if self.any_exchange:
+        work = pack_done = None
+        if self.any_exchange and self.device is not None:
+            # pack + collective go to a side stream so that the own-shard product (which needs neither) starts at once
+            import torch
+            main = torch.cuda.current_stream(self.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+                self._pack_ev = torch.cuda.Event()
+            self._side.wait_stream(main)                       # B_own_tiles is ready when `main` gets here
+            with torch.cuda.stream(self._side):
+                if self.n_send:
+                    self._pack(B_own_tiles)
+                    pack_done = self._pack_ev
+                    pack_done.record(self._side)
+                work = self._all_to_all()
+        elif self.any_exchange:
             if self.n_send:
                 self._pack(B_own_tiles)
             work = self._all_to_all()
         self._product("own", B_own_tiles, C_out, accumulate)
         if work is not None:
-            work.wait()
+            work.wait()                                        # the current stream waits for the collective
             if self.remote is not None:
                 self._product("remote", self.recv_buf, C_out, True)
+        if pack_done is not None:
+            torch.cuda.current_stream(self.device).wait_event(pack_done)    # the caller may overwrite B_own_tiles after step()
 
     def close(self):
         for d in (self.d_own, self.d_rem):
