@@ -1109,6 +1109,9 @@ __global__ __launch_bounds__(kThreads) void vbs_tail_copy_kernel(const float* B,
 // bytes) and one FMA per element.  HBM/L2-bound: N * 4 bytes per nonzero.  This is the "wavefront-level partial sums for
 // thin / ragged blocks" leg of the path; exact zeros of A are skipped (0 * inf of the reference's dense loop is not
 // reproduced: finite B is the contract, as for its padded columns).
+#ifndef SP_BATCH
+#define SP_BATCH 16     /* rows of B a wave keeps in flight (measured 8 -> 16: +1..10 %) */
+#endif
 template <int VEC> struct SpVec;
 template <> struct SpVec<1> { typedef float T; };
 template <> struct SpVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
@@ -1147,29 +1150,29 @@ __device__ __forceinline__ typename SpVec<VEC>::T sparse_row_partial(const Spars
     V acc = (V)(0.0f);
     const bool in = VEC > 1 || n0 < p.N;
     const E* Bl = (const E*)p.B + (in ? n0 : 0);
-    for (int64_t q = p0; q < p1; q += 8) {
-        const int n = (int)(p1 - q < 8 ? p1 - q : 8);            // wave-uniform
+    for (int64_t q = p0; q < p1; q += SP_BATCH) {
+        const int n = (int)(p1 - q < SP_BATCH ? p1 - q : SP_BATCH);            // wave-uniform
         int cl = 0;
         float vl = 0.0f;
         if (lane < n) { cl = p.col[q + lane]; vl = p.val[q + lane]; }
-        L b[8];
+        L b[SP_BATCH];
         if (VEC == 1 && p.b_col_stride > 0) {                    // column-major B in place (few sparse rows: cheaper than transposing all of B)
             const E* Bc = (const E*)p.B + (in ? (int64_t)n0 * p.b_col_stride : 0);
 #pragma unroll
-            for (int t = 0; t < 8; t++) {
+            for (int t = 0; t < SP_BATCH; t++) {
                 const int64_t c = __builtin_amdgcn_readlane(cl, t);
                 const int64_t off = p.shard_rows > 0 ? (c / p.shard_rows) * p.shard_stride + c % p.shard_rows : c;
                 b[t] = *reinterpret_cast<const L*>(Bc + off);
             }
         } else {
 #pragma unroll
-            for (int t = 0; t < 8; t++) {
+            for (int t = 0; t < SP_BATCH; t++) {
                 const int c = __builtin_amdgcn_readlane(cl, t);  // lanes >= n hold column 0: a valid row, never used
                 b[t] = *reinterpret_cast<const L*>(Bl + (int64_t)c * p.ldb);
             }
         }
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
+        for (int t = 0; t < SP_BATCH; t++) {
             const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vl), t));
             if (t < n) {
                 if constexpr (BK == 0) acc += v * b[t];
@@ -1836,7 +1839,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     std::vector<float> sp_val;
     std::vector<SpSegRec> sp_segs;
     std::vector<SpLongRec> sp_long;
-    // a wave keeps 8 rows of B in flight: a row of n nonzeros takes ~n / 8 memory latencies whatever else the GPU is doing, so rows
+    // a wave keeps SP_BATCH (16) rows of B in flight: a row of n nonzeros takes ~n / 16 memory latencies whatever else the GPU is doing, so rows
     // longer than kSpLong are cut into kSpSeg-nonzero segments that run on different waves (SPARTA_SPARSE_SEG overrides kSpSeg)
     int64_t kSpSeg = 256;
     if (const char* e = std::getenv("SPARTA_SPARSE_SEG")) kSpSeg = std::max(8, atoi(e));
@@ -2094,7 +2097,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         v->n_sp_rows = (int64_t)sp_crow.size(); v->n_sp_short = n_sp_short; v->n_sp_long = n_sp_long; v->sp_nnz = sp_rowptr.back();
         CREATE_TRY(hipMalloc((void**)&v->d_sp_rowptr, sp_rowptr.size() * sizeof(int64_t)));
         CREATE_TRY(hipMemcpy(v->d_sp_rowptr, sp_rowptr.data(), sp_rowptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-        CREATE_TRY(hipMalloc((void**)&v->d_sp_col, (sp_col.size() + 64) * sizeof(int32_t)));      // +64: a batch reads up to 8 entries at once
+        CREATE_TRY(hipMalloc((void**)&v->d_sp_col, (sp_col.size() + 64) * sizeof(int32_t)));      // +64: a batch reads up to SP_BATCH entries at once
         CREATE_TRY(hipMemset(v->d_sp_col, 0, (sp_col.size() + 64) * sizeof(int32_t)));
         CREATE_TRY(hipMalloc((void**)&v->d_sp_val, (sp_val.size() + 64) * sizeof(float)));
         CREATE_TRY(hipMemset(v->d_sp_val, 0, (sp_val.size() + 64) * sizeof(float)));
