@@ -693,7 +693,6 @@ void keeper(C& c, int64_t* grouping) {
 //      in many bands and are still too far apart to merge) cost a bounded amount.
 // Deterministic (fixed hash constants).  Quality is checked against the exact algorithm on inputs both can handle
 // (tests/test_host_golden.py::test_minhash_*): it cannot be bit-identical to the reference and does not claim to be.
-int64_t kScanLimit = 256;
 
 inline uint64_t mix64(uint64_t x) {              // splitmix64 finaliser
     x += 0x9e3779b97f4a7c15ull;
@@ -725,6 +724,7 @@ void minhash_lsh(Ctx& c, int64_t* grouping) {
     if (rows == 0) return;
     int n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* e = std::getenv("SPARTA_REORDER_THREADS")) n_threads = std::max(1, atoi(e));
+    int64_t kScanLimit = 256;                                    // entries looked at per bucket look-up
     if (const char* e = std::getenv("SPARTA_MINHASH_SCAN")) kScanLimit = std::max(1, atoi(e));
     int64_t patience = 32;                                       // consecutive failed candidates (best estimates first) before a seed gives up
     if (const char* e = std::getenv("SPARTA_MINHASH_PATIENCE")) patience = std::max(1, atoi(e));
