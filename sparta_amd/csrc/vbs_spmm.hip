@@ -1841,9 +1841,10 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     std::vector<SpLongRec> sp_long;
     // a wave keeps SP_BATCH (16) rows of B in flight: a row of n nonzeros takes ~n / 16 memory latencies whatever else the GPU is doing, so rows
     // longer than kSpLong are cut into kSpSeg-nonzero segments that run on different waves (SPARTA_SPARSE_SEG overrides kSpSeg)
-    int64_t kSpSeg = 256;
+    // The segment length follows the size of the sparse part (decided below, once it is known): short segments keep a small
+    // problem parallel (R-MAT 2^16: 128 -> 148 us, 512 -> 187 us), long ones save partial rows on a large one (2^20: 3.99 vs 3.75 ms).
+    int64_t kSpSeg = 0;
     if (const char* e = std::getenv("SPARTA_SPARSE_SEG")) kSpSeg = std::max(8, atoi(e));
-    const int64_t kSpLong = 2 * kSpSeg;
     int64_t n_sp_short = 0, n_sp_long = 0;
     // 16-bit handles: the values the kernels multiply are the ROUNDED ones (a value that rounds to zero is a zero)
     const bool bf16h = dtype == SPARTA_BF16;
@@ -1916,6 +1917,11 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         }
     }
     // short rows: one wave each; rows with more than kSpLong nonzeros (hubs): segments of kSpSeg, one wave each + a reduction
+    if (kSpSeg == 0) {
+        const int64_t total = sp_rowptr.empty() ? 0 : sp_rowptr.back();
+        kSpSeg = total < ((int64_t)4 << 20) ? 128 : (total < ((int64_t)16 << 20) ? 256 : 512);
+    }
+    const int64_t kSpLong = 2 * kSpSeg;
     for (size_t t = 0; t < sp_crow.size(); t++) {
         const int64_t p0 = sp_rowptr[t], n = sp_rowptr[t + 1] - p0;
         if (n <= kSpLong) { sp_list.push_back((int32_t)t); continue; }
