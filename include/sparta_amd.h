@@ -297,6 +297,18 @@ int sparta_vbs_spmm_gathered(sparta_vbs_t* A, const void* B_gathered, int64_t sh
  * No reference counterpart (single-GPU). */
 int sparta_pack_blocks(const void* src, int64_t block_bytes, const int32_t* ids_dev, int64_t n_blocks, void* dst, void* stream);
 
+/* B * A (dense x VBS).  The reference's cublas_blockmat_multiplyBA(const VBR&, DataT* B, int B_rows, DataT_C* C, float& dt, int n_streams)
+ * (include/cuda_utilities.h:40, src/cuda/cuda_utilities.cpp:553-721) is NOT a B * A (it offsets B by block_col_size * ib elements, uses
+ * the first block-row's height for every block and sizes C as B_rows x A_rows: DESIGN.md section 8), so there is nothing to be identical
+ * to; these two entries compute the product itself.  sparta_vbs_create_transposed uploads A^T (same VBS arrays as sparta_vbs_create);
+ * sparta_vbs_spmm_ba: C (M x cols, column-major, ldc) (+)= B (M x rows, column-major, ldb) * A, rows of A in the VBS's (reordered) order.
+ * fp32 tolerance as for sparta_vbs_spmm. */
+int sparta_vbs_create_transposed(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t block_col_size,
+                                 const int64_t* row_part, const int64_t* nzcount, const int64_t* jab, const float* mab,
+                                 int32_t dtype, int32_t device);
+int sparta_vbs_spmm_ba(sparta_vbs_t* At, const void* B, int64_t ldb, int32_t M, void* C, int64_t ldc, int32_t accumulate,
+                       int32_t ptr_space, void* stream, float* dt_ms);
+
 /* Per-tile-class device timing for roofline reports: when enabled, sparta_vbs_spmm brackets each class
  * launch with HIP events on the launch stream; sparta_vbs_class_times waits for them and writes the last
  * call's milliseconds into ms_out[4]: stream path -> {stream kernel, fix-up kernel, 0, 0};

@@ -306,6 +306,7 @@ struct VBR {
 
     void clean() {
         if (dev_) { sparta_vbs_destroy(dev_); dev_ = nullptr; }
+        if (dev_t_) { sparta_vbs_destroy(dev_t_); dev_t_ = nullptr; }
         delete[] nzcount; delete[] jab; delete[] row_part; delete[] mab;
         nzcount = jab = row_part = nullptr; mab = nullptr;
         rows = cols = block_rows = block_cols = nztot = block_col_size = 0;
@@ -344,13 +345,25 @@ struct VBR {
                                                     SPARTA_SPMM_MFMA, dt), "VBR::multiply");
     }
 
+    // C += B * A (dense x VBS): B is B_rows x rows, C is B_rows x cols, column-major (ld = B_rows).  Call shape of the reference's
+    // cublas_blockmat_multiplyBA (include/cuda_utilities.h:40) -- whose own arithmetic is not a B * A (src/cuda/cuda_utilities.cpp:649-663).
+    void multiply_BA(DataT* B, int B_rows, DataT_C* C, float* dt = nullptr, int device = 0) const {
+        if (!dev_t_)
+            sparta_compat_detail::check(sparta_vbs_create_transposed(&dev_t_, rows, cols, block_rows, block_col_size, (const int64_t*)row_part,
+                                                                     (const int64_t*)nzcount, (const int64_t*)jab, mab, SPARTA_F32, device), "VBR::multiply_BA (upload)");
+        sparta_compat_detail::check(sparta_vbs_spmm_ba(dev_t_, B, B_rows, B_rows, C, B_rows, 1, SPARTA_PTR_HOST, nullptr, dt), "VBR::multiply_BA");
+    }
+
    private:
     mutable sparta_vbs_t* dev_ = nullptr;   // device image, created on first multiply, released by clean()
+    mutable sparta_vbs_t* dev_t_ = nullptr; // device image of the transpose (multiply_BA)
 };
 
 // include/cuda_utilities.h:38,42 and include/cutlass_bellpack_lib.h:21,25 -- one fused kernel family behind all of them.
 // n_streams is accepted for source compatibility and ignored (there is no per-block launch to spread over streams).
 inline void cublas_fixed_blocks_multiply(const VBR& vbmatA, DataT* B, int B_cols, DataT_C* C, float& dt, int n_streams = 4) { (void)n_streams; vbmatA.multiply(B, B_cols, C, &dt); }
 inline void cublas_blockmat_batched(const VBR& vbmatA, DataT* B, int B_cols, DataT_C* C, float& dt) { vbmatA.multiply(B, B_cols, C, &dt); }
+// include/cuda_utilities.h:40 -- same call shape; computes C (B_rows x A.cols) += B (B_rows x A.rows) * A, which the reference's body does not (see VBR::multiply_BA)
+inline void cublas_blockmat_multiplyBA(const VBR& vbmatA, DataT* B, int B_rows, DataT_C* C, float& dt, int n_streams = 4) { (void)n_streams; vbmatA.multiply_BA(B, B_rows, C, &dt); }
 inline void cutlas_fixed_blocks_multiply(const VBR& vbmatA, DataT* B, int B_cols, DataT_C* C, float& dt) { vbmatA.multiply(B, B_cols, C, &dt); }
 inline void cutlas_blockmat_batched(const VBR& vbmatA, DataT* B, int B_cols, DataT_C* C, float& dt) { vbmatA.multiply(B, B_cols, C, &dt); }

@@ -47,7 +47,7 @@ struct HybridSparse {
     std::vector<float> val;
 };
 int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, bool force_fixed_size,
-                     double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp);
+                     double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp, bool keep_order = false);
 int blocking_info(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t* info_out, float* avg_height_out);
 
 }  // namespace sparta

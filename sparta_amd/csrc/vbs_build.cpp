@@ -63,7 +63,7 @@ struct BlockCollector {
 
 int vbs_build(const CsrView& a, const int64_t* grouping, int64_t w, int64_t row_block_size, bool force_fixed,
               sparta_vbs_host* out) {
-    return vbs_build_hybrid(a, grouping, w, row_block_size, force_fixed, 0.0, 32, out, nullptr);
+    return vbs_build_hybrid(a, grouping, w, row_block_size, force_fixed, 0.0, 32, out, nullptr, false);
 }
 
 // The same builder, optionally "hybrid" (sp != nullptr, K > 0): block-rows whose blocks would hold fewer than K nonzeros per
@@ -72,7 +72,7 @@ int vbs_build(const CsrView& a, const int64_t* grouping, int64_t w, int64_t row_
 // (sparta_vbs_create_from_csr).  A clustered power-law matrix is 98 % zeros inside its blocks: the dense image of a
 // 20 M-nonzero R-MAT matrix is 4 GB, of a 124 M-nonzero one 25 GB, all of it skipped by the kernels that then run.
 int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64_t row_block_size, bool force_fixed,
-                     double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp) {
+                     double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp, bool keep_order) {
     if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_build: out is NULL");
     std::memset(out, 0, sizeof(*out));
     if (w <= 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_build: col_block_size must be > 0");
@@ -84,6 +84,13 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
 
     std::vector<int64_t> part = get_partition(grouping, a.rows);          // vbr.cpp:139
     std::vector<int64_t> perm = get_permutation(grouping, a.rows);        // vbr.cpp:140
+    if (keep_order) {
+        // the rows stay where they are (the reference's permutation is an UNSTABLE sort by group id: it shuffles rows inside a group
+        // even when the groups are already contiguous); needs a non-decreasing grouping.  Used for A^T, whose rows are columns of C.
+        for (int64_t i = 1; i < a.rows; i++)
+            if (grouping[i] < grouping[i - 1]) return fail(SPARTA_ERR_INVALID, "vbs_build: keep_order needs a non-decreasing grouping");
+        for (int64_t i = 0; i < a.rows; i++) perm[(size_t)i] = i;
+    }
 
     int64_t rows = a.rows, cols = a.cols;
     if (force_fixed) {                                                    // vbr.cpp:143-148

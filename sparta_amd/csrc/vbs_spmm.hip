@@ -2140,9 +2140,9 @@ int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int6
     return create_core(out, rows, cols, block_rows, w, row_part, nzcount, jab, mab, br0, br1, dtype, device, nullptr);
 }
 
-int sparta_vbs_create_from_csr(sparta_vbs_t** out, int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals,
-                               const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, int32_t force_fixed_size,
-                               int32_t dtype, int32_t device) {
+static int create_from_csr_impl(sparta_vbs_t** out, int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals,
+                                const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, int32_t force_fixed_size,
+                                int32_t dtype, int32_t device, bool keep_order) {
     using sparta::fail;
     if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create_from_csr: out is NULL");
     *out = nullptr;
@@ -2157,7 +2157,7 @@ int sparta_vbs_create_from_csr(sparta_vbs_t** out, int64_t rows, int64_t cols, c
         if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
         const int64_t kdep = (dtype != SPARTA_F32 && col_block_size % 64 == 0) ? 64 : 32;
         sparta::HybridSparse sp;
-        rc = sparta::vbs_build_hybrid(a, grouping, col_block_size, row_block_size, force_fixed_size != 0, K, kdep, &h, K > 0.0 ? &sp : nullptr);
+        rc = sparta::vbs_build_hybrid(a, grouping, col_block_size, row_block_size, force_fixed_size != 0, K, kdep, &h, K > 0.0 ? &sp : nullptr, keep_order);
         if (rc == SPARTA_OK)
             rc = create_core(out, h.rows, h.cols, h.block_rows, col_block_size, h.row_part, h.nzcount, h.jab, h.mab, 0, h.block_rows, dtype, device,
                              K > 0.0 ? &sp : nullptr);
@@ -2169,6 +2169,74 @@ int sparta_vbs_create_from_csr(sparta_vbs_t** out, int64_t rows, int64_t cols, c
     }
     sparta_vbs_host_free(&h);
     return rc;
+}
+
+int sparta_vbs_create_from_csr(sparta_vbs_t** out, int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals,
+                               const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, int32_t force_fixed_size,
+                               int32_t dtype, int32_t device) {
+    return create_from_csr_impl(out, rows, cols, rowptr, colidx, vals, grouping, col_block_size, row_block_size, force_fixed_size, dtype, device, false);
+}
+
+// A^T of a VBS as a device handle: with it, B * A (dense x VBS) is an ordinary product -- C^T = A^T * B^T, and a column-major
+// M x rows B IS a row-major rows x M B^T (same bytes), a column-major M x cols C IS a row-major cols x M C^T.  The reference's own
+// "inverted" product (cublas_blockmat_multiplyBA, src/cuda/cuda_utilities.cpp:553-721) is not a B * A; this one is.
+int sparta_vbs_create_transposed(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
+                                 const int64_t* nzcount, const int64_t* jab, const float* mab, int32_t dtype, int32_t device) {
+    using sparta::fail;
+    if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create_transposed: out is NULL");
+    *out = nullptr;
+    if (rows <= 0 || cols <= 0 || block_rows <= 0 || w <= 0 || !row_part || !nzcount)
+        return fail(SPARTA_ERR_INVALID, "sparta_vbs_create_transposed: bad dimensions or NULL index array");
+    if (rows > INT32_MAX || cols > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create_transposed: more than 2^31 - 1 rows or columns");
+    try {
+        // CSR of A^T: row j = column j of A, entries (reordered row i, value) ascending in i; exact zeros of the blocks are dropped
+        std::vector<int64_t> rp((size_t)cols + 1, 0);
+        int64_t jo = 0, mo = 0;
+        for (int64_t ib = 0; ib < block_rows; ib++) {
+            const int64_t h = row_part[ib + 1] - row_part[ib], nb = nzcount[ib];
+            if (h < 0 || nb < 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create_transposed: invalid row_part / nzcount");
+            for (int64_t b = 0; b < nb; b++) {
+                const int64_t c0 = jab[jo + b] * w;
+                if (c0 < 0 || c0 >= cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create_transposed: jab entry out of range");
+                for (int64_t k = 0; k < w && c0 + k < cols; k++)
+                    for (int64_t i = 0; i < h; i++) rp[(size_t)(c0 + k) + 1] += mab[mo + (b * w + k) * h + i] != 0.0f;
+            }
+            jo += nb; mo += nb * h * w;
+        }
+        for (int64_t j = 0; j < cols; j++) rp[(size_t)j + 1] += rp[(size_t)j];
+        std::vector<int32_t> ci((size_t)rp[(size_t)cols]);
+        std::vector<float> va((size_t)rp[(size_t)cols]);
+        std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
+        jo = 0; mo = 0;
+        for (int64_t ib = 0; ib < block_rows; ib++) {
+            const int64_t h = row_part[ib + 1] - row_part[ib], nb = nzcount[ib];
+            for (int64_t b = 0; b < nb; b++) {
+                const int64_t c0 = jab[jo + b] * w;
+                for (int64_t k = 0; k < w && c0 + k < cols; k++)
+                    for (int64_t i = 0; i < h; i++) {
+                        const float a = mab[mo + (b * w + k) * h + i];
+                        if (a != 0.0f) { const int64_t q = fill[(size_t)(c0 + k)]++; ci[(size_t)q] = (int32_t)(row_part[ib] + i); va[(size_t)q] = a; }
+                    }
+            }
+            jo += nb; mo += nb * h * w;
+        }
+        // block-rows of A^T = the column blocks of A (w rows each); its column blocks are 32 reordered rows of A wide
+        std::vector<int64_t> grouping((size_t)cols);
+        for (int64_t j = 0; j < cols; j++) grouping[(size_t)j] = j / w;
+        return create_from_csr_impl(out, cols, rows, rp.data(), ci.data(), va.data(), grouping.data(), 32, 0, 0, dtype, device, true);   // rows stay in place: they are the columns of C
+    } catch (const std::bad_alloc&) {
+        return fail(SPARTA_ERR_ALLOC, "sparta_vbs_create_transposed: out of host memory");
+    }
+}
+
+/* C (+)= B * A with the handle of A^T (sparta_vbs_create_transposed): B is M x rows(A), C is M x cols(A), both column-major. */
+int sparta_vbs_spmm_ba(sparta_vbs_t* At, const void* B, int64_t ldb, int32_t M, void* C, int64_t ldc, int32_t accumulate, int32_t ptr_space,
+                       void* stream, float* dt_ms) {
+    using sparta::fail;
+    if (!At) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_ba: NULL handle");
+    if (M <= 0 || ldb < M || ldc < M) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_ba: need M > 0, ldb >= M, ldc >= M");
+    // a column-major M x rows matrix with leading dimension ld is the row-major rows x M matrix with the same ld
+    return sparta_vbs_spmm(At, B, ldb, SPARTA_ROW_MAJOR, M, C, ldc, SPARTA_ROW_MAJOR, accumulate, ptr_space, stream, SPARTA_SPMM_MFMA, dt_ms);
 }
 
 int sparta_vbs_create(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,

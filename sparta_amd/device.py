@@ -51,6 +51,33 @@ class DeviceVBS:
         self.rows, self.cols = info["rows"], info["cols"]
         return self
 
+    @classmethod
+    def transposed_of(cls, vbmat, device=0, dtype=_lib.F32):
+        """sparta_vbs_create_transposed: the handle of A^T, for the B * A product (spmm_BA)"""
+        self = cls(None, device=device, dtype=dtype)
+        rp = np.ascontiguousarray(vbmat.row_part, np.int64)
+        nz = np.ascontiguousarray(vbmat.nzcount, np.int64)
+        jab = np.ascontiguousarray(vbmat.jab, np.int64)
+        mab = np.ascontiguousarray(vbmat.mab, np.float32)
+        check(lib.sparta_vbs_create_transposed(C.byref(self.h), vbmat.rows, vbmat.cols, vbmat.block_rows, vbmat.block_col_size,
+                                               rp.ctypes.data_as(_i64p), nz.ctypes.data_as(_i64p), jab.ctypes.data_as(_i64p),
+                                               mab.ctypes.data_as(_f32p), int(dtype), self.device))
+        info = self.info()
+        self.rows, self.cols = info["rows"], info["cols"]          # rows = cols(A), cols = rows(A)
+        return self
+
+    def spmm_BA_host(self, B, M, C_out, accumulate=True):
+        """C (+)= B * A on the handle of A^T, host buffers: B is M x rows(A), C is M x cols(A), both column-major (ld = M).  Returns kernel ms."""
+        B = np.ascontiguousarray(B, np.float32).reshape(-1)
+        if not (isinstance(C_out, np.ndarray) and C_out.dtype == np.float32 and C_out.flags.c_contiguous):
+            raise ValueError("C must be a contiguous float32 numpy array (it is written in place)")
+        if B.size < M * self.cols or C_out.size < M * self.rows:
+            raise ValueError("B or C too small")
+        dt = C.c_float(0)
+        check(lib.sparta_vbs_spmm_ba(self.h, B.ctypes.data_as(C.c_void_p), int(M), int(M), C_out.ctypes.data_as(C.c_void_p), int(M),
+                                     int(bool(accumulate)), _lib.PTR_HOST, None, C.byref(dt)))
+        return dt.value
+
     def info(self):
         a = np.zeros(16, np.int64)
         check(lib.sparta_vbs_info(self.h, a.ctypes.data_as(_i64p)))

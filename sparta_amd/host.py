@@ -297,6 +297,15 @@ class VBR:
         from .device import DeviceVBS
         return DeviceVBS(self, device=device, dtype=dtype, block_row_range=block_row_range)
 
+    def multiply_BA(self, B, B_rows, C_out, device=0):
+        """C += B * A (dense x VBS), host buffers, column-major: B is B_rows x rows, C is B_rows x cols.  The reference's
+        cublas_blockmat_multiplyBA (include/cuda_utilities.h:40) has this call shape but does not compute this product (DESIGN.md
+        section 8); this does.  Returns the kernel time in ms."""
+        from .device import DeviceVBS
+        if getattr(self, "_dev_t", None) is None or self._dev_t.device != device:
+            self._dev_t = DeviceVBS.transposed_of(self, device=device)
+        return self._dev_t.spmm_BA_host(B, B_rows, C_out, accumulate=True)
+
     def multiply(self, B, B_cols, C_out, device=0, algo=_lib.SPMM_MFMA):
         """void VBR::multiply(DataT* B, int B_cols, DataT_C* C)  (include/matrices.h:121): C += A*B with host
         buffers, column-major, ld(B) = cols, ld(C) = rows -- executed on the GPU.  Returns the kernel time in ms."""

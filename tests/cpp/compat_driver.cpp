@@ -84,6 +84,14 @@ int main(int argc, char** argv) {
         std::printf("C2:");
         for (float c : C) std::printf(" %g", c);
         std::printf("\n");
+        // dense x VBS with the reference's call shape (include/cuda_utilities.h:40): D (2 x 9) += E (2 x 9) * A
+        std::vector<DataT> E(18);
+        for (int i = 0; i < 18; i++) E[(size_t)i] = (DataT)(i % 5) - 2.0f;
+        std::vector<DataT_C> D(18, 0.0f);
+        cublas_blockmat_multiplyBA(vbmat, E.data(), 2, D.data(), dt);
+        std::printf("BA:");
+        for (float c : D) std::printf(" %g", c);
+        std::printf("\n");
     }
     return 0;
 }

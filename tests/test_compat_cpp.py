@@ -40,6 +40,22 @@ def test_compat_driver_multiplies_on_gpu():
     want = [0, 0, 0, 0, 126, 22, 102, 14, 10, 0, 0, 0, 0, 306, 49, 219, 32, 55]
     assert [float(x) for x in r["C"].split()] == want
     assert [float(x) for x in r["C2"].split()] == [2 * x for x in want]
+    # B * A: rows of A in the VBS's order (get_permutation of the printed grouping), small integers -> exact
+    import numpy as np
+    import sys
+    sys.path.insert(0, ROOT)
+    import sparta_amd as sa
+    rowptr = [0, 0, 3, 6, 10, 10, 11, 11, 11, 12]
+    colidx = [2, 5, 8, 5, 6, 8, 1, 3, 7, 8, 6, 1]
+    vals = [5, 8, 7, 1, 1, 1, 1, 1, 3, 8, 2, 5]
+    A = np.zeros((9, 9))
+    for i in range(9):
+        for k in range(rowptr[i], rowptr[i + 1]):
+            A[i, colidx[k]] = vals[k]
+    perm = sa.get_permutation(np.array([int(x) for x in r["grouping"].split()]))
+    E = (np.arange(18) % 5 - 2.0).reshape(9, 2).T                    # column-major 2 x 9
+    want_ba = (E @ A[perm]).T.reshape(-1)                            # column-major 2 x 9
+    assert [float(x) for x in r["BA"].split()] == want_ba.tolist()
 
 
 def test_compat_driver_reads_blocks_and_writes_the_csv_row_like_the_reference():

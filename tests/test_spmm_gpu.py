@@ -894,3 +894,30 @@ def test_few_sparse_rows_read_a_column_major_b_in_place(_sparse_row_mode, dtype)
     d.spmm_gathered(Bg, 3200, Ct, n)
     torch.cuda.synchronize()
     _check(Ct.cpu().numpy(), Co, bound, "few sparse rows, gathered B")
+
+
+@pytest.mark.parametrize("M", [1, 37, 128, 256])
+def test_dense_times_vbs_product(_sparse_row_mode, M):
+    """C += B * A (dense x VBS) through the handle of A^T: against a float64 product of B with the dense form of the VBS"""
+    rng = np.random.Generator(np.random.PCG64(M))
+    m = sa.gen.uniform_random(700, 520, 9000, seed=12)
+    w = 16
+    g = sa.BlockingEngine(tau=0.5, col_block_size=w).GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    perm = sa.get_permutation(g)
+    A = np.zeros((m.rows, m.cols), np.float64)
+    for i in range(m.rows):
+        A[i, m.colidx[m.rowptr[i]:m.rowptr[i + 1]]] = m.vals[m.rowptr[i]:m.rowptr[i + 1]]
+    A = A[perm]                                              # rows in the VBS's order
+    B = rng.uniform(-1, 1, (M, v.rows)).astype(np.float32)
+    C0 = rng.uniform(-1, 1, (M, v.cols)).astype(np.float32)
+    want = C0.astype(np.float64) + B.astype(np.float64) @ A
+    scale = np.abs(C0).astype(np.float64) + np.abs(B).astype(np.float64) @ np.abs(A)
+    Cc = np.ascontiguousarray(C0.T).reshape(-1)              # column-major M x cols
+    dt = v.multiply_BA(np.ascontiguousarray(B.T).reshape(-1), M, Cc)
+    got = Cc.reshape(v.cols, M).T
+    assert dt >= 0 and np.all(np.abs(got - want) <= 1e-5 * scale + 1e-30)
+    # a second call accumulates again
+    v.multiply_BA(np.ascontiguousarray(B.T).reshape(-1), M, Cc)
+    got2 = Cc.reshape(v.cols, M).T
+    assert np.all(np.abs(got2 - (want + B.astype(np.float64) @ A)) <= 2e-5 * scale + 1e-30)
