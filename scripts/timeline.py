@@ -19,14 +19,19 @@ else:
     g = sa.BlockingEngine(blocking_algo=5, tau=0.6, col_block_size=32, row_block_size=32, force_fixed_size=True).GetGrouping(m)
     vb = sa.VBR().fill_from_CSR_inplace(m, g, 32, 32, True)
 os.environ["SPARTA_PATH"] = "stream"
-d = vb.to_device(0)
-B = torch.from_numpy(sa.gen.dense_rhs(vb.cols, N, seed=3)).cuda()
+h16 = len(sys.argv) > 2 and sys.argv[2] == "h16"          # python scripts/timeline.py flagship h16: the 16-bit stream kernel
+d = vb.to_device(0, dtype=sa.F16 if h16 else sa.F32)
+ldb = (vb.cols + 7) // 8 * 8 if h16 else vb.cols
+if h16:
+    B = ((torch.rand(ldb * N) - 0.5).to(torch.float16)).cuda()
+else:
+    B = torch.from_numpy(sa.gen.dense_rhs(vb.cols, N, seed=3)).cuda()
 Cc = torch.zeros(vb.rows * N, dtype=torch.float32, device="cuda")
 for _ in range(20):
-    d.spmm(B, Cc, N)
+    d.spmm(B, Cc, N, ldb=ldb)
 d.set_class_timing(True)
 for _ in range(3):
-    d.spmm(B, Cc, N)
+    d.spmm(B, Cc, N, ldb=ldb)
 torch.cuda.synchronize()
 print("kernel ms", d.class_times(), "MHz", d.clock_mhz())
 out = np.zeros(4 * 64 * 8 + 2048, np.int64)
@@ -47,6 +52,8 @@ if len(wk):
     order = np.argsort(dur)
     print('   slowest workers', ids[order[-6:]].tolist(), 'fastest', ids[order[:6]].tolist())
 names = ["round0", "round1", "round2", "round3+loads", "epilogue", "barrier", "to next step"]
+if h16:
+    names = ["LDS write", "issue loads", "frag + MFMA", "-", "epilogue", "barrier", "to next step"]
 for wv in range(4):
     tw = t[wv]
     ok = tw[:, 0] > 0

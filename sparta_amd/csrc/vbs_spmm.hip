@@ -442,6 +442,12 @@ struct FixRec {                           // one per split tile
     int32_t slot_begin, n_slots;          // its partial images: fix_slots[slot_begin .. slot_begin + n_slots)
 };
 
+__device__ __forceinline__ int32_t sk_field(int vrec0, int vrec1, int s, int f) {   // field f of step s's record (see the kernels)
+    const int ln = ((s & 7) << 3) + f;
+    const int32_t x0 = __builtin_amdgcn_readlane(vrec0, ln), x1 = __builtin_amdgcn_readlane(vrec1, ln);
+    return ((s >> 3) & 1) ? x1 : x0;
+}
+
 struct StreamParams {
     const StepRec* steps;
     const int32_t* worker_range;          // [2 * P]: begin, end step of every worker
@@ -519,11 +525,10 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
     int vrec0 = srec[lane];
     int vrec1 = srec[64 + lane];
     int vnext = 0;
-    auto field = [&](int s, int f) __attribute__((always_inline)) -> int32_t {
-        const int ln = ((s & 7) << 3) + f;
-        const int32_t x0 = __builtin_amdgcn_readlane(vrec0, ln), x1 = __builtin_amdgcn_readlane(vrec1, ln);
-        return ((s >> 3) & 1) ? x1 : x0;
-    };
+    // a macro over a free function, not a lambda: every closure between the loop body and vrec0 / vrec1 is one more level of
+    // pointer indirection the optimiser has to peel before it can keep them in registers (three levels deep it gave up and
+    // left one of them in memory: an LDS / scratch read behind a full wait in every step)
+#define field(s, f) sk_field(vrec0, vrec1, (s), (f))
     enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6, F_SHARD = 7 };
 
     // per-thread constant byte offsets (the only vector part of any address in the loop)
@@ -756,7 +761,11 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
         }
         if ((i & 7) == 4 && i > 4) {
             asm volatile("s_waitcnt vmcnt(6)" : "+v"(vnext) : : "memory");
-            if (((i >> 3) + 1) & 1) vrec1 = vnext; else vrec0 = vnext;
+            // two selects, not "if (odd) vrec1 = vnext; else vrec0 = vnext;": the compiler merges the two stores of that form into one store
+                // through a selected POINTER, which pins vrec0 / vrec1 in scratch memory -- every step then reloads them behind vmcnt(0)
+                const bool odd = (((i >> 3) + 1) & 1) != 0;
+                vrec1 = odd ? vnext : vrec1;
+                vrec0 = odd ? vrec0 : vnext;
         }
     };
 
@@ -804,7 +813,10 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int KP, bool MI2, bool BF16, bool GATHERED>
+// DEEP: four register sets instead of two -- loads run 5 steps ahead of the MFMAs (4 steps of panels in flight per workgroup
+// instead of 2).  A 16-bit step has 64-128 cycles of MFMA per wave: what a step costs is how long its panel takes to arrive
+// divided by the number of panels in flight, and the registers are there (2 waves per SIMD: 256 VGPRs each).
+template <int KP, bool MI2, bool BF16, bool GATHERED, bool DEEP>
 __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const StreamParams p) {
     constexpr int TN = kTN, TM = MI2 ? 64 : 32;
     constexpr int LDK = KP + 8;                          // elements per LDS row
@@ -824,6 +836,10 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
     const int n = p.worker_range[2 * blockIdx.x + 1] - s_begin;
     if (n <= 0) return;
     clock_probe(p.clk, 0);
+#ifdef SPARTA_TIMELINE
+    long long tl_t0 = 0;
+    if (p.clk != nullptr && blockIdx.y == 0 && tid == 0 && blockIdx.x < 1024) tl_t0 = wall_clock64();
+#endif
     float* ws = p.ws + (int64_t)blockIdx.y * p.ws_slab_stride;
     const uint16_t* A16 = reinterpret_cast<const uint16_t*>(p.A);
     const uint16_t* B16 = reinterpret_cast<const uint16_t*>(p.B);
@@ -833,11 +849,10 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
     int vrec0 = srec[lane];
     int vrec1 = srec[64 + lane];
     int vnext = 0;
-    auto field = [&](int s, int f) __attribute__((always_inline)) -> int32_t {
-        const int ln = ((s & 7) << 3) + f;
-        const int32_t x0 = __builtin_amdgcn_readlane(vrec0, ln), x1 = __builtin_amdgcn_readlane(vrec1, ln);
-        return ((s >> 3) & 1) ? x1 : x0;
-    };
+    // a macro over a free function, not a lambda: every closure between the loop body and vrec0 / vrec1 is one more level of
+    // pointer indirection the optimiser has to peel before it can keep them in registers (three levels deep it gave up and
+    // left one of them in memory: an LDS / scratch read behind a full wait in every step)
+#define field(s, f) sk_field(vrec0, vrec1, (s), (f))
     enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6, F_SHARD = 7 };
 
     const int bj0 = tid / CPC, bc = tid % CPC;           // B: column bj0 + CPP q, chunk bc (k = 8 bc .. 8 bc + 7)
@@ -854,6 +869,8 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
     char* const ldsb = reinterpret_cast<char*>(lds);
 
     u32x4 b0[NBL], a0[NAL], b1[NBL], a1[NAL];
+    u32x4 b2[DEEP ? NBL : 1], a2[DEEP ? NAL : 1], b3[DEEP ? NBL : 1], a3[DEEP ? NAL : 1];     // DEEP: register sets 2 / 3
+    constexpr int AHEAD = DEEP ? 5 : 3;                  // a register set written to LDS at step i is refilled with step i + AHEAD
 
     int64_t g_aoff = 0;
     uint32_t vo_cur = voffB;                             // see the fp32 kernel: every VALU instruction in the steady state costs an MFMA slot
@@ -899,8 +916,15 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
     auto iteration_t = [&](int i, int32_t flags, u32x4 (&wb)[NBL], u32x4 (&wa)[NAL], auto par_tag) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
         using nxt_t = std::integral_constant<int, 1 - PAR>;
+#ifdef SPARTA_TIMELINE
+        unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool tl_on = p.clk != nullptr && blockIdx.x == 8 && blockIdx.y == 0 && i >= TL_FIRST && i < TL_FIRST + TL_STEPS;
+#endif
+        TL_STAMP(0);
         write_stage(nxt_t{}, wb, wa);
-        fq_new = issue_loads(i + 3, wb, wa);
+        TL_STAMP(1);
+        fq_new = issue_loads(i + AHEAD, wb, wa);
+        TL_STAMP(2);
 #pragma unroll
         for (int kb = 0; kb < KP; kb += 16) {
             const u32x4 bf = *reinterpret_cast<const u32x4*>(ldsb + lrB + (PAR * STAGE + kb) * 2);
@@ -911,6 +935,8 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
                 mfma(bf, af1, acc1);
             }
         }
+        TL_STAMP(3);
+        TL_STAMP(4);
         if (flags & STEP_LAST) {
             if (flags & STEP_SPLIT) {
                 const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_SLOT) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
@@ -948,41 +974,126 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
 #pragma unroll
             for (int q = 0; q < 16; q++) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
         }
+        TL_STAMP(5);
         __syncthreads();
+        TL_STAMP(6);
+#ifdef SPARTA_TIMELINE
+        if (tl_on) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                long long* o = p.clk + 16 + ((int64_t)wave * TL_STEPS + (i - TL_FIRST)) * 8;
+#pragma unroll
+                for (int k = 0; k < 7; k++) o[k] = (long long)tl[k];
+                o[7] = flags;
+            }
+        }
+#endif
     };
 
     using st0 = std::integral_constant<int, 0>;
     using st1 = std::integral_constant<int, 1>;
-    fq0 = issue_loads(0, b0, a0);
-    fq1 = issue_loads(1, b1, a1);
-    write_stage(st0{}, b0, a0);
-    fq2 = issue_loads(2, b0, a0);
-    __syncthreads();
-    // record batches: see the fp32 kernel.  At least 4 steps x (NBL + NAL >= 3) = 12 loads are issued between request and touch.
-    auto batch_upkeep = [&](int i) __attribute__((always_inline)) {
-        if ((i & 7) == 0 && i > 0) {
-            const int32_t* nb = srec + (int64_t)((i >> 3) + 1) * 64 + lane;
-            asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
+    if constexpr (!DEEP) {
+        fq0 = issue_loads(0, b0, a0);
+        fq1 = issue_loads(1, b1, a1);
+        write_stage(st0{}, b0, a0);
+        fq2 = issue_loads(2, b0, a0);
+        __syncthreads();
+        // record batches: see the fp32 kernel.  At least 4 steps x (NBL + NAL >= 3) = 12 loads are issued between request and touch.
+        auto batch_upkeep = [&](int i) __attribute__((always_inline)) {
+            if ((i & 7) == 0 && i > 0) {
+                const int32_t* nb = srec + (int64_t)((i >> 3) + 1) * 64 + lane;
+                asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
+            }
+            if ((i & 7) == 4 && i > 4) {
+                asm volatile("s_waitcnt vmcnt(3)" : "+v"(vnext) : : "memory");
+                // two selects, not "if (odd) vrec1 = vnext; else vrec0 = vnext;": the compiler merges the two stores of that form into one store
+                // through a selected POINTER, which pins vrec0 / vrec1 in scratch memory -- every step then reloads them behind vmcnt(0)
+                const bool odd = (((i >> 3) + 1) & 1) != 0;
+                vrec1 = odd ? vnext : vrec1;
+                vrec0 = odd ? vrec0 : vnext;
+            }
+        };
+        const int n_even = n & ~1;
+        for (int i = 0; i < n_even; i += 2) {
+            batch_upkeep(i);
+            iteration_t(i, fq0, b1, a1, st0{});
+            fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+            iteration_t(i + 1, fq0, b0, a0, st1{});
+            fq0 = fq1; fq1 = fq2; fq2 = fq_new;
         }
-        if ((i & 7) == 4 && i > 4) {
-            asm volatile("s_waitcnt vmcnt(3)" : "+v"(vnext) : : "memory");
-            if (((i >> 3) + 1) & 1) vrec1 = vnext; else vrec0 = vnext;
+        if (n & 1) {
+            batch_upkeep(n_even);
+            iteration_t(n_even, fq0, b1, a1, st0{});
         }
-    };
-    const int n_even = n & ~1;
-    for (int i = 0; i < n_even; i += 2) {
-        batch_upkeep(i);
-        iteration_t(i, fq0, b1, a1, st0{});
-        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-        iteration_t(i + 1, fq0, b0, a0, st1{});
-        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-    }
-    if (n & 1) {
-        batch_upkeep(n_even);
-        iteration_t(n_even, fq0, b1, a1, st0{});
+    } else {
+        // Step s lives in register set s & 3 and LDS stage s & 1.  Iteration i computes step i, writes step i + 1 (set (i + 1) & 3)
+        // into the other stage and refills that set with step i + 5: steps i + 2 .. i + 5 are in flight under step i.
+        int32_t fq3 = 0, fq4 = 0;
+        fq0 = issue_loads(0, b0, a0);
+        fq1 = issue_loads(1, b1, a1);
+        write_stage(st0{}, b0, a0);
+        fq2 = issue_loads(2, b2, a2);
+        fq3 = issue_loads(3, b3, a3);
+        fq4 = issue_loads(4, b0, a0);
+        __syncthreads();
+        // Record batches (8 steps each; vrec0 / vrec1 hold batches k, k + 1): step 8k + 3 is the first to look into batch k + 1
+        // (its refill is step 8k + 8), so batch k + 1 is requested at step 8k - 2 and touched at step 8k + 2; the register it
+        // replaces (batch k - 1) is dead from step 8k on.  The four steps in between issue 4 x (NBL + NAL >= 3) >= 12 loads and
+        // memory returns in order: vmcnt(12) at the touch is a wait the pipeline has already paid.
+        auto upkeep_request = [&](int i) __attribute__((always_inline)) {
+            if ((i & 7) == 6) {
+                const int32_t* nb = srec + (int64_t)((i >> 3) + 2) * 64 + lane;
+                asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
+            }
+        };
+        auto upkeep_touch = [&](int i) __attribute__((always_inline)) {
+            if ((i & 7) == 2 && i > 2) {
+                asm volatile("s_waitcnt vmcnt(12)" : "+v"(vnext) : : "memory");
+                // two selects, not "if (odd) vrec1 = vnext; else vrec0 = vnext;": the compiler merges the two stores of that form into one store
+                // through a selected POINTER, which pins vrec0 / vrec1 in scratch memory -- every step then reloads them behind vmcnt(0)
+                const bool odd = (((i >> 3) + 1) & 1) != 0;
+                vrec1 = odd ? vnext : vrec1;
+                vrec0 = odd ? vrec0 : vnext;
+            }
+        };
+        auto rotate = [&]() __attribute__((always_inline)) { fq0 = fq1; fq1 = fq2; fq2 = fq3; fq3 = fq4; fq4 = fq_new; };
+        const int n4 = n & ~3;
+        for (int i = 0; i < n4; i += 4) {
+            iteration_t(i, fq0, b1, a1, st0{});
+            rotate();
+            iteration_t(i + 1, fq0, b2, a2, st1{});
+            rotate();
+            upkeep_request(i + 2);
+            upkeep_touch(i + 2);
+            iteration_t(i + 2, fq0, b3, a3, st0{});
+            rotate();
+            iteration_t(i + 3, fq0, b0, a0, st1{});
+            rotate();
+        }
+        // the last n & 3 steps, peeled (see the fp32 kernel on why not a break inside the loop)
+        if (n & 3) {
+            iteration_t(n4, fq0, b1, a1, st0{});
+            rotate();
+            if ((n & 3) > 1) {
+                iteration_t(n4 + 1, fq0, b2, a2, st1{});
+                rotate();
+                if ((n & 3) > 2) {
+                    upkeep_touch(n4 + 2);
+                    iteration_t(n4 + 2, fq0, b3, a3, st0{});
+                }
+            }
+        }
     }
     clock_probe(p.clk, 2);
+#ifdef SPARTA_TIMELINE
+    if (p.clk != nullptr && blockIdx.y == 0 && tid == 0 && blockIdx.x < 1024) {
+        p.clk[16 + 4 * 64 * 8 + 2 * blockIdx.x] = tl_t0;
+        p.clk[16 + 4 * 64 * 8 + 2 * blockIdx.x + 1] = wall_clock64();
+    }
+#endif
 }
+
+#undef field
 
 // zero-padded copy of the rows of a 16-bit column-major B that face the last (partial) block column: B_tail[k + w j], k < w
 __global__ __launch_bounds__(kThreads) void vbs_tail_copy_h16_kernel(const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N,
@@ -1592,6 +1703,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                     const int64_t h = row_part[ib + 1] - row_part[ib];
                     const int64_t nb = nzcount[ib];
                     const bool skipped = in.skip && in.skip[ib - br0];
+                    const int dbg_probe = [] { const char* e = std::getenv("SPARTA_DBG_PROBE"); return e ? atoi(e) : 0; }();
                     for (int64_t r0 = 0; r0 < h && !skipped; r0 += SK_TM) {
                         const int32_t mt = (int32_t)std::min<int64_t>(SK_TM, h - r0);
                         if ((mt > 32 ? 1 : 0) != ty) continue;
@@ -1623,6 +1735,12 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                                 if ((jb + 1) * w > cols) { r.mt_flags |= STEP_TAIL; r.b_row = (int32_t)ks; }   // read from the zero-padded B_tail
                                 r.slot = -1;
                                 r.pad = 0;
+                                if (dbg_probe) {                            // developer probe (timing only, results are wrong): which stream bounds a step
+                                    if (dbg_probe & 1) r.b_row = (int32_t)ks;                                   // every panel of B is the same (cache-hot) one
+                                    if ((dbg_probe & 2) && h16) r.a_off = (b * w + ks) / kp * (ty ? 64 : 32) * kp;   // every tile reads the first slices of A
+                                    if ((dbg_probe & 2) && !h16) r.a_off = r0 + (b * w + ks) * h;
+                                    if (dbg_probe & 4) r.c_row = 0;                                             // every tile writes the first rows of C
+                                }
                                 cum.push_back(total_cost);
                                 total_cost += ty ? c2 : c1;
                                 st.push_back(r);
@@ -2046,8 +2164,8 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         CREATE_TRY(hipMemset(v->d_A, 0, (size_t)v->a_bytes));
         if (nztot > 0) CREATE_TRY(hipMemcpy(v->d_A, mab + mab_lo, (size_t)nztot * sizeof(float), hipMemcpyHostToDevice));
     } else {
-        // the look-ahead of the pipeline reads up to 3 slices past the last one (never multiplied): pad
-        v->a_bytes = ((int64_t)a16.size() + 4 * 64 * 64) * (int64_t)sizeof(uint16_t);
+        // the look-ahead of the pipeline reads up to 5 slices past the last one (never multiplied): pad
+        v->a_bytes = ((int64_t)a16.size() + 8 * 64 * 64) * (int64_t)sizeof(uint16_t);
         CREATE_TRY(hipMalloc((void**)&v->d_A, (size_t)v->a_bytes));
         CREATE_TRY(hipMemset(v->d_A, 0, (size_t)v->a_bytes));
         if (!a16.empty()) CREATE_TRY(hipMemcpy(v->d_A, a16.data(), a16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -2084,8 +2202,8 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             std::vector<StepRec>& st = steps[ty];
             v->n_steps[ty] = (int64_t)st.size();
             if (st.empty()) continue;
-            // the pipeline prefetches up to 3 steps (and one 8-record batch) past a range end: pad with harmless copies
-            for (int k = 0; k < 24; k++) { StepRec d = st[(size_t)v->n_steps[ty] - 1]; d.mt_flags = (d.mt_flags & ~(STEP_LAST | STEP_SPLIT)) | STEP_FIRST; st.push_back(d); }
+            // the pipeline prefetches up to 5 steps (and up to two 8-record batches) past a range end: pad with harmless copies
+            for (int k = 0; k < 32; k++) { StepRec d = st[(size_t)v->n_steps[ty] - 1]; d.mt_flags = (d.mt_flags & ~(STEP_LAST | STEP_SPLIT)) | STEP_FIRST; st.push_back(d); }
             CREATE_TRY(hipMalloc((void**)&v->d_steps[ty], st.size() * sizeof(StepRec)));
             CREATE_TRY(hipMemcpy(v->d_steps[ty], st.data(), st.size() * sizeof(StepRec), hipMemcpyHostToDevice));
             v->h_steps[ty] = st;
@@ -2298,15 +2416,23 @@ int sparta_vbs_clock_mhz(sparta_vbs_t* A, double* mhz_out) {
 namespace {
 
 // shared implementation of sparta_vbs_spmm / sparta_vbs_spmm_gathered
+template <int KP, bool MI2, bool DEEP>
+void launch_h16_d(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (gathered) {
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, true, true, DEEP>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, false, true, DEEP>), grid, dim3(kThreads), 0, st, sp);
+    } else {
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, true, false, DEEP>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, false, false, DEEP>), grid, dim3(kThreads), 0, st, sp);
+    }
+}
+// SPARTA_H16_DEPTH=4 selects the four-register-set pipeline (loads 5 steps ahead); default: two sets, 3 steps ahead -- measured equal
+// within 1 % on every shape (scripts/h16_depth_ab.py): the 16-bit steps are not bound by the bytes in flight
+bool h16_deep() { const char* e = std::getenv("SPARTA_H16_DEPTH"); return e && atoi(e) == 4; }   // read per launch: scripts flip it between timings
 template <int KP, bool MI2>
 void launch_h16(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
-    if (gathered) {
-        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, true, true>), grid, dim3(kThreads), 0, st, sp);
-        else hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, false, true>), grid, dim3(kThreads), 0, st, sp);
-    } else {
-        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, true, false>), grid, dim3(kThreads), 0, st, sp);
-        else hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, false, false>), grid, dim3(kThreads), 0, st, sp);
-    }
+    if (h16_deep()) launch_h16_d<KP, MI2, true>(bf16, gathered, grid, st, sp);
+    else launch_h16_d<KP, MI2, false>(bf16, gathered, grid, st, sp);
 }
 
 // step lists for a gathered B (slab index + row inside the slab), rebuilt when the slab height changes
