@@ -360,7 +360,8 @@ def main():
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         wk = tj.get("workload", {})
-        if wk.get("vbs_area") == int(vb.nztot) and wk.get("n_cols") == N and wk.get("kernel_path") == path and not distributed:
+        if (wk.get("vbs_area") == int(vb.nztot) and wk.get("n_cols") == N and wk.get("kernel_path") == path and not distributed
+                and wk.get("dtype", "f32") == args.dtype):
             traffic = round(float(tj["hbm_bytes_per_launch"]))
     except Exception:
         traffic = None
@@ -398,7 +399,9 @@ def main():
         bytes16 = float(info["a_bytes"]) + 2.0 * ldb * N + 4.0 * vb.rows * N
         gbs = bytes16 / (kernel_ms_total * 1e-3) / 1e9 if kernel_ms_total > 0 else 0.0
         roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                         "kernel": "vbs_spmm_h16_stream_kernel", "algorithmic_bytes": round(bytes16), "algorithmic_gbs": round(gbs, 1),
+                         "kernel": ("vbs_spmm_h16_direct_kernel" if (w % 64 != 0 and info["tiles64"] == 0 and os.environ.get("SPARTA_H16_PATH", "a")[0] != "l")
+                                    or os.environ.get("SPARTA_H16_PATH", "a")[0] == "d" else "vbs_spmm_h16_stream_kernel"),
+                         "algorithmic_bytes": round(bytes16), "algorithmic_gbs": round(gbs, 1),
                          "executed_tflops": round(dom_tflops, 3)})
         roofline.pop("mixed_roofline_frac", None)
     # `peak` is the 2.4 GHz figure of MI355X_MICROARCH.md; under this load the board does not hold 2.4 GHz (power), so the

@@ -539,12 +539,19 @@ H16_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("kernel", ["auto", "lds", "lds-depth4", "direct"])
 @pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("rows,cols,nnz,w,blk,n", H16_SHAPES)
-def test_16bit_storage_vs_oracle_on_rounded_inputs(dtype, rows, cols, nnz, w, blk, n):
+def test_16bit_storage_vs_oracle_on_rounded_inputs(monkeypatch, kernel, dtype, rows, cols, nnz, w, blk, n):
     """A and B are rounded to the 16-bit type, products of two 16-bit values are exact in fp32, accumulation is fp32: the
-    oracle (fp32 VBR::multiply restatement) on the ROUNDED inputs is the reference; tolerance as for the fp32 MFMA path."""
+    oracle (fp32 VBR::multiply restatement) on the ROUNDED inputs is the reference; tolerance as for the fp32 MFMA path.
+    Every 16-bit kernel is held to it: the LDS-staged one (two and four register sets) and the direct-to-register one, each
+    forced on every shape, next to the library's own choice."""
     torch = _torch()
+    if kernel != "auto":
+        monkeypatch.setenv("SPARTA_H16_PATH", kernel.split("-")[0])
+    if kernel == "lds-depth4":
+        monkeypatch.setenv("SPARTA_H16_DEPTH", "4")
     m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + cols + w)
     if blk[0] == "tau":
         g = sa.BlockingEngine(tau=blk[1], col_block_size=w).GetGrouping(m)
@@ -803,11 +810,15 @@ def test_create_from_csr_gives_the_same_product(monkeypatch, _sparse_row_mode, c
             sa.DeviceVBS.from_csr(bad, np.array([0, 1]), 4)
 
 
+@pytest.mark.parametrize("kernel", ["auto", "lds", "direct"])
 @pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
-def test_16bit_gathered_b_and_row_block_exchange(_sparse_row_mode, dtype):
+def test_16bit_gathered_b_and_row_block_exchange(monkeypatch, _sparse_row_mode, dtype, kernel):
     """the multi-GPU entry points with 16-bit storage: sparta_vbs_spmm_gathered on an all-gather-shaped 16-bit B, and the
-    row-block exchange (pack kernel + the two products on the row-block-tiled layout) with every rank played on one GPU"""
+    row-block exchange (pack kernel + the two products on the row-block-tiled layout) with every rank played on one GPU;
+    with the library's choice of 16-bit kernel and with each of the two forced"""
     torch = _torch()
+    if kernel != "auto":
+        monkeypatch.setenv("SPARTA_H16_PATH", kernel)
     tdt = torch.float16 if dtype == sa.F16 else torch.bfloat16
     world, w, n = 3, 32, 128
     slabs = [sa.gen.fem3d_slab(4, 4, 9, r, world, dof=3, pad_to=w, seed=4) for r in range(world)]
