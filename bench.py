@@ -358,7 +358,7 @@ def main():
     # profiled workload is the one running now
     traffic = None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json" if args.dtype == "f32" else "traffic_%s.json" % args.dtype)))
         wk = tj.get("workload", {})
         if (wk.get("vbs_area") == int(vb.nztot) and wk.get("n_cols") == N and wk.get("kernel_path") == path and not distributed
                 and wk.get("dtype", "f32") == args.dtype):

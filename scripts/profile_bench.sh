@@ -1,15 +1,17 @@
 #!/bin/bash
-# usage (on the GPU box, via gpurun): scripts/profile_bench.sh <tag>
+# usage (on the GPU box, via gpurun): scripts/profile_bench.sh <tag> [extra bench.py arguments, e.g. --dtype f16]
 # 1) rocprofv3 --kernel-trace --stats of the default bench command, 2) separate --pmc passes (counters only) for HBM traffic.
 set -u
 tag=$1
+shift
+extra="$*"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag
 mkdir -p $out
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline > $out/bench_trace.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT TCC_MISS --output-format csv -d $out/pmc_write -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_pmc_write.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $out/pmc_sq -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_pmc_sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $extra --no-cpu-baseline > $out/bench_trace.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_fetch -- python3 bench.py $extra --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT TCC_MISS --output-format csv -d $out/pmc_write -- python3 bench.py $extra --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_pmc_write.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $out/pmc_sq -- python3 bench.py $extra --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_pmc_sq.log 2>&1
 python3 - "$out" <<'PY'
 import sys, glob, csv, collections, json, re
 out = sys.argv[1]
@@ -40,7 +42,7 @@ try:
     json.dump({
         "note": "HBM bytes per launch of the dominant kernel of the default bench.py workload, from rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, counters only). Correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE (KB) reports 1/2 of a wide coalesced read on gfx950 -> doubled; WRITE_SIZE (KB) exact.",
         "command": "scripts/profile_bench.sh <tag>  (rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -- python3 bench.py ...; rocprofv3 --pmc WRITE_SIZE TCC_HIT TCC_MISS -- python3 bench.py ...)",
-        "workload": {"vbs_area": bj["config"]["vbs_area"], "n_cols": bj["config"]["n_cols"], "kernel_path": bj["config"]["kernel_path"]},
+        "workload": {"vbs_area": bj["config"]["vbs_area"], "n_cols": bj["config"]["n_cols"], "kernel_path": bj["config"]["kernel_path"], "dtype": bj["dtype"]},
         "kernel": key, "kernel_avg_ns_in_trace": dom["avg_ns"],
         "FETCH_SIZE_KB": p["FETCH_SIZE"], "WRITE_SIZE_KB": p["WRITE_SIZE"], "hbm_bytes_per_launch": p["hbm_bytes_per_launch_corrected"],
     }, open(out + "/traffic.json", "w"), indent=1)
