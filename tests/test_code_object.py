@@ -1,0 +1,49 @@
+"""The compiled gfx950 code object of the stream kernels, checked without a GPU.
+
+Why: the persistent kernels keep their whole pipeline state in registers on purpose.  Twice the compiler quietly moved a piece of
+it to memory (a stack slot reloaded behind `s_waitcnt vmcnt(0)` every step; then an LDS slot behind `lgkmcnt(0)`): results stay
+right, the 16-bit kernels ran 25-30 % slower.  The kernel descriptors say so in two numbers, so they are pinned
+here: no private (scratch) segment, no VGPR spills, and exactly the LDS the `__shared__` arrays of the source ask for."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernel_metadata(tmp_path):
+    lib = os.path.join(ROOT, "sparta_amd", "libsparta_amd.so")
+    tools = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not os.path.exists(lib) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("library or LLVM binutils not available")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.run([tools[0], "--dump-section", ".hip_fatbin=" + fat, lib], check=True)
+    subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co], check=True)
+    notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
+    kernels = {}
+    for block in re.split(r"\n  - \.agpr_count:", notes)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        kernels[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
+                         for k in ("private_segment_fixed_size", "group_segment_fixed_size", "vgpr_spill_count", "vgpr_count")}
+    return kernels
+
+
+def test_stream_kernels_keep_their_state_in_registers(tmp_path):
+    kernels = _kernel_metadata(tmp_path)
+    stream = {n: m for n, m in kernels.items() if "stream_kernel" in n or "direct_kernel" in n}
+    assert len(stream) >= 6 + 32 + 16, sorted(stream)                     # fp32: 6 instantiations, 16-bit LDS-staged: 32, direct: 16
+    for name, m in stream.items():
+        assert m["private_segment_fixed_size"] == 0, (name, m)
+        assert m["vgpr_spill_count"] == 0, (name, m)
+        assert m["vgpr_count"] <= 256, (name, m)                          # two 256-thread workgroups per CU
+        if "direct_kernel" in name:
+            want = {0}
+        elif "h16_stream_kernel" in name:                                 # 2 stages x (128 + 64) rows x (KP + 8) 16-bit elements
+            want = {2 * (128 + 64) * (32 + 8) * 2} if "ILi32E" in name else {2 * (128 + 64) * (64 + 8) * 2}
+        else:                                                             # fp32: 2 stages x (B panel [+4 pad when column-major] + 32 x 64 A slice) floats
+            want = {2 * (128 * 36 + 32 * 64) * 4, 2 * (32 * 128 + 32 * 64) * 4}
+        assert m["group_segment_fixed_size"] in want, (name, m, want)
