@@ -1635,6 +1635,28 @@ __global__ __launch_bounds__(kThreads) void vbs_spmm_f32_exact_kernel(const Bloc
             return sparta::fail(SPARTA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
     } while (0)
 
+// Zero fill of a long run of rows of C (block-rows without blocks under accumulate = 0).  An R-MAT matrix has hundreds of thousands
+// of empty rows; clustering puts them into ONE block-row, i.e. one contiguous row range of the permuted C.  As 64-row fix-up tiles
+// that range is written in 128 / 256-byte pieces (2.4 TB/s measured); here every line (a column of a column-major C: `nrows`
+// contiguous floats; a row of a row-major C) is streamed with 16-byte stores.
+__global__ __launch_bounds__(kThreads) void vbs_zero_rows_kernel(float* C, int64_t ldc, int c_row_major, int64_t row0, int64_t nrows, int N) {
+    const int64_t n_lines = c_row_major ? nrows : (int64_t)N;
+    const int64_t line_len = c_row_major ? (int64_t)N : nrows;
+    float* base = c_row_major ? C + row0 * ldc : C + row0;
+    for (int64_t line = blockIdx.y; line < n_lines; line += gridDim.y) {
+        float* p = base + line * ldc;
+        const int64_t head = std::min<int64_t>(line_len, (int64_t)(((16u - (uint32_t)((uintptr_t)p & 15u)) & 15u) >> 2));
+        const int64_t body4 = (line_len - head) >> 2, tail = (line_len - head) & 3;
+        f32x4* q = reinterpret_cast<f32x4*>(p + head);
+        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < body4; e += (int64_t)gridDim.x * kThreads) q[e] = z;
+        if (blockIdx.x == 0) {
+            if ((int64_t)threadIdx.x < head) p[threadIdx.x] = 0.0f;
+            if ((int64_t)threadIdx.x < tail) p[head + 4 * body4 + threadIdx.x] = 0.0f;
+        }
+    }
+}
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;
@@ -1674,6 +1696,7 @@ struct sparta_vbs {
     int64_t g_shard_rows = 0;
     int32_t* d_wrange[2] = {nullptr, nullptr};
     FixRec* d_fix = nullptr;
+    std::vector<std::pair<int64_t, int64_t>> zero_ranges;   // long runs of rows without blocks (local C rows), see vbs_zero_rows_kernel
     int32_t* d_fix_slots = nullptr;
     int64_t n_steps[2] = {0, 0};
     int32_t n_workers = 0, n_fix = 0, n_split = 0, n_slots = 0;
@@ -1817,12 +1840,15 @@ struct StreamPlanHost {
     std::vector<StepRec> steps[2];            // per tile type: [0] <= 32 rows, [1] 33..64 rows
     std::vector<int32_t> wrange[2];           // [2 * n_workers] begin / end step of every worker
     std::vector<FixRec> fix;                  // split tiles + tiles of block-rows without blocks (zero fill)
+    std::vector<std::pair<int64_t, int64_t>> zero_ranges;   // (first row, rows) of long block-rows without blocks: vbs_zero_rows_kernel instead of fix-up tiles
     std::vector<int32_t> fix_slots;
     std::vector<uint16_t> a16;                // 16-bit handles: A re-laid-out as dense row-major TM x kp slices, one per step
     int n_workers = 0, n_split = 0;
     int plan_aligned[2] = {0, 0};
     int64_t kp = SK_KP;
 };
+
+constexpr int64_t kZeroRangeRows = 2048;    // block-rows without blocks at least this tall are zero-filled by vbs_zero_rows_kernel
 
 int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
     using sparta::fail;
@@ -1881,7 +1907,9 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                     const int64_t nb = nzcount[ib];
                     const bool skipped = in.skip && in.skip[ib - br0];
                     const int dbg_probe = [] { const char* e = std::getenv("SPARTA_DBG_PROBE"); return e ? atoi(e) : 0; }();
-                    for (int64_t r0 = 0; r0 < h && !skipped; r0 += SK_TM) {
+                    const bool zero_range = nb == 0 && !skipped && h >= kZeroRangeRows;     // one streamed fill instead of h / 64 fix-up tiles
+                    if (zero_range && ty == 0) P.zero_ranges.emplace_back(row_part[ib] - row0, h);
+                    for (int64_t r0 = 0; r0 < h && !skipped && !zero_range; r0 += SK_TM) {
                         const int32_t mt = (int32_t)std::min<int64_t>(SK_TM, h - r0);
                         if ((mt > 32 ? 1 : 0) != ty) continue;
                         const int32_t c_row = (int32_t)(row_part[ib] - row0 + r0);
@@ -2320,6 +2348,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     sparta_vbs* v = new (std::nothrow) sparta_vbs;
     if (!v) return fail(SPARTA_ERR_ALLOC, "sparta_vbs_create: out of host memory");
     v->device = device; v->dtype = dtype;
+    v->zero_ranges = plan.zero_ranges;
     v->rows = row_part[br1] - row_part[br0]; v->cols = cols; v->block_rows = br1 - br0; v->w = w;
     v->nblocks = nblocks; v->nztot = nztot; v->exec_area = exec_area;
 
@@ -2362,7 +2391,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         CREATE_TRY(hipMalloc((void**)&v->d_brows, brows.size() * sizeof(BlockRowDesc)));
         CREATE_TRY(hipMemcpy(v->d_brows, brows.data(), brows.size() * sizeof(BlockRowDesc), hipMemcpyHostToDevice));
     }
-    if (!steps[0].empty() || !steps[1].empty() || !fix.empty()) {
+    if (!steps[0].empty() || !steps[1].empty() || !fix.empty() || !plan.zero_ranges.empty()) {
         v->has_tail = (cols % w) != 0;
         v->n_workers = n_workers; v->n_fix = (int32_t)fix.size(); v->n_split = n_split; v->n_slots = (int32_t)fix_slots.size();
         std::vector<int32_t> big_fix;
@@ -2633,6 +2662,16 @@ void launch_h16(bool bf16, bool gathered, dim3 grid, hipStream_t st, const Strea
     else launch_h16_d<KP, MI2, false>(bf16, gathered, grid, st, sp);
 }
 
+// long runs of rows without blocks, accumulate = 0: streamed zero fill (vbs_zero_rows_kernel), one launch per run
+void launch_zero_ranges(sparta_vbs_t* A, float* C, int64_t ldc, bool c_row_major, int n_cols, hipStream_t st) {
+    for (const auto& zr : A->zero_ranges) {
+        const int64_t n_lines = c_row_major ? zr.second : (int64_t)n_cols, line_len = c_row_major ? (int64_t)n_cols : zr.second;
+        const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (line_len / 4 + kThreads - 1) / kThreads));
+        const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_lines, 16384));
+        hipLaunchKernelGGL(vbs_zero_rows_kernel, dim3(gx, gy), dim3(kThreads), 0, st, C, ldc, (int)c_row_major, zr.first, zr.second, n_cols);
+    }
+}
+
 // step lists for a gathered B (slab index + row inside the slab), rebuilt when the slab height changes
 int ensure_gathered_steps(sparta_vbs_t* A, int64_t shard_rows, hipStream_t st) {
     if (A->g_shard_rows == shard_rows) return SPARTA_OK;
@@ -2780,13 +2819,17 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
         }
         if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
     }
-    if (A->n_fix > 0 && !(accumulate && A->n_split == 0)) {   // C += 0 for the block-rows without blocks: nothing to launch
+    const bool fix_launch = A->n_fix > 0 && !(accumulate && A->n_split == 0);   // C += 0 for the block-rows without blocks: nothing to launch
+    const bool zero_launch = !A->zero_ranges.empty() && !accumulate;
+    if (fix_launch || zero_launch) {
         if (prof) HIP_TRY(hipEventRecord(A->cev[1][0], st));
-        if (A->n_big_fix > 0)
+        if (fix_launch && A->n_big_fix > 0)
             hipLaunchKernelGGL(vbs_spmm_f32_fixup_group_kernel, dim3((unsigned)A->n_big_fix, (unsigned)n_nt, (unsigned)((A->max_tile_slots + kFixGroup - 1) / kFixGroup)),
                                dim3(kThreads), 0, st, A->d_fix, A->d_big_fix, A->d_fix_slots, (float*)A->d_ws, (int64_t)slab);
-        hipLaunchKernelGGL(vbs_spmm_f32_fixup_kernel, dim3((unsigned)A->n_fix, (unsigned)n_nt), dim3(kThreads), 0, st, A->d_fix, A->d_fix_slots,
-                           (const float*)A->d_ws, (int64_t)slab, dC, ldc, (int)(c_layout == SPARTA_ROW_MAJOR), (int)(accumulate != 0));
+        if (fix_launch)
+            hipLaunchKernelGGL(vbs_spmm_f32_fixup_kernel, dim3((unsigned)A->n_fix, (unsigned)n_nt), dim3(kThreads), 0, st, A->d_fix, A->d_fix_slots,
+                               (const float*)A->d_ws, (int64_t)slab, dC, ldc, (int)(c_layout == SPARTA_ROW_MAJOR), (int)(accumulate != 0));
+        if (zero_launch) launch_zero_ranges(A, dC, ldc, c_layout == SPARTA_ROW_MAJOR, n_cols, st);
         if (prof) { HIP_TRY(hipEventRecord(A->cev[1][1], st)); A->class_ran[1] = true; }
     }
     if (A->n_sp_rows > 0) {                  // nearly empty block-rows: sparse rows over a row-major 16-bit copy of B
@@ -2910,15 +2953,19 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                 }
                 if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
             }
-            if (A->n_fix > 0 && !(accumulate && A->n_split == 0)) {   // C += 0 for the block-rows without blocks: nothing to launch
+            const bool fix_launch = A->n_fix > 0 && !(accumulate && A->n_split == 0);   // C += 0 for the block-rows without blocks: nothing to launch
+            const bool zero_launch = !A->zero_ranges.empty() && !accumulate;
+            if (fix_launch || zero_launch) {
                 if (prof) HIP_TRY(hipEventRecord(A->cev[1][0], st));
-                if (A->n_big_fix > 0)
+                if (fix_launch && A->n_big_fix > 0)
                     hipLaunchKernelGGL(vbs_spmm_f32_fixup_group_kernel,
                                        dim3((unsigned)A->n_big_fix, (unsigned)n_nt, (unsigned)((A->max_tile_slots + kFixGroup - 1) / kFixGroup)), dim3(kThreads), 0, st,
                                        A->d_fix, A->d_big_fix, A->d_fix_slots, (float*)A->d_ws, (int64_t)slab);
-                hipLaunchKernelGGL(vbs_spmm_f32_fixup_kernel, dim3((unsigned)A->n_fix, (unsigned)n_nt), dim3(kThreads), 0, st, A->d_fix,
-                                   A->d_fix_slots, (const float*)A->d_ws, (int64_t)slab, Cout, ldc, (int)(c_layout == SPARTA_ROW_MAJOR),
-                                   (int)(accumulate != 0));
+                if (fix_launch)
+                    hipLaunchKernelGGL(vbs_spmm_f32_fixup_kernel, dim3((unsigned)A->n_fix, (unsigned)n_nt), dim3(kThreads), 0, st, A->d_fix,
+                                       A->d_fix_slots, (const float*)A->d_ws, (int64_t)slab, Cout, ldc, (int)(c_layout == SPARTA_ROW_MAJOR),
+                                       (int)(accumulate != 0));
+                if (zero_launch) launch_zero_ranges(A, Cout, ldc, c_layout == SPARTA_ROW_MAJOR, n_cols, st);
                 if (prof) { HIP_TRY(hipEventRecord(A->cev[1][1], st)); A->class_ran[1] = true; }
             }
             return SPARTA_OK;

@@ -932,3 +932,57 @@ def test_dense_times_vbs_product(_sparse_row_mode, M):
     v.multiply_BA(np.ascontiguousarray(B.T).reshape(-1), M, Cc)
     got2 = Cc.reshape(v.cols, M).T
     assert np.all(np.abs(got2 - (want + B.astype(np.float64) @ A)) <= 2e-5 * scale + 1e-30)
+
+
+@pytest.mark.parametrize("dtype", [sa.F32, sa.F16], ids=["f32", "f16"])
+@pytest.mark.parametrize("first_empty,n_empty", [(640, 4100), (0, 2048), (1001, 2500)])
+def test_long_run_of_empty_rows_is_zero_filled_by_the_streamed_fill(monkeypatch, dtype, first_empty, n_empty):
+    """A block-row without blocks that is thousands of rows tall (what the empty rows of a power-law matrix become after clustering)
+    is zero-filled by `vbs_zero_rows_kernel` instead of 64-row fix-up tiles: C = 0 there under accumulate = 0 (also at a row offset
+    that is not 16-byte aligned, and in both layouts of C), untouched under accumulate = 1; the rows around it are the oracle's."""
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_PATH", "stream")
+    rows, cols, w, n = first_empty + n_empty + 700, 1024, 32, 128
+    m0 = sa.gen.uniform_random(rows, cols, 40000, seed=77)
+    keep = np.ones(rows, bool); keep[first_empty:first_empty + n_empty] = False
+    cnt = np.diff(m0.rowptr) * keep
+    sel = np.repeat(keep, np.diff(m0.rowptr))
+    m = sa.CSR(rows, cols, np.concatenate([[0], np.cumsum(cnt)]), m0.colidx[sel], m0.vals[sel])
+    g = np.empty(rows, np.int64)
+    g[:first_empty] = np.arange(first_empty) // 32
+    g[first_empty:first_empty + n_empty] = 10 ** 6                   # the empty rows: ONE group, starting at row `first_empty` of the permuted C
+    g[first_empty + n_empty:] = 10 ** 6 + 1 + np.arange(rows - first_empty - n_empty) // 32
+    g = np.unique(g, return_inverse=True)[1]
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    h = np.diff(v.row_part)
+    assert h.max() == n_empty and v.row_part[int(np.argmax(h))] == first_empty
+    B = sa.gen.dense_rhs(v.cols, n, seed=5)
+    if dtype == sa.F16:
+        mab_r, B_r = _round16(v.mab, dtype), _round16(B, dtype)
+    else:
+        mab_r, B_r = v.mab, B
+    Co = O.vbr_multiply(v.rows, v.cols, v.block_col_size, v.row_part, v.nzcount, v.jab, mab_r, B_r, n, None)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n)
+    d = v.to_device(0, dtype=dtype)
+    if dtype == sa.F16:
+        ldb = (v.cols + 7) // 8 * 8
+        Bt = torch.zeros(ldb * n, dtype=torch.float16, device="cuda")
+        Bt.view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(torch.float16)
+    else:
+        ldb, Bt = v.cols, torch.from_numpy(B).cuda()
+    for cl in (sa.COL_MAJOR, sa.ROW_MAJOR):
+        Ct = torch.full((v.rows * n,), 7.0, dtype=torch.float32, device="cuda")
+        d.spmm(Bt, Ct, n, ldb=ldb, c_layout=cl)
+        torch.cuda.synchronize()
+        got = Ct.cpu().numpy()
+        if cl == sa.ROW_MAJOR:
+            got = np.ascontiguousarray(got.reshape(v.rows, n).T).reshape(-1)
+        _check(got, Co, bound, "long empty block-row, c_layout %d" % cl)
+        ib = int(np.argmax(h))
+        assert v.nzcount[ib] == 0
+        assert not got.reshape(n, v.rows)[:, v.row_part[ib]:v.row_part[ib + 1]].any()
+    C0 = sa.gen.dense_rhs(v.rows, n, seed=11)
+    Ct = torch.from_numpy(C0).cuda()
+    d.spmm(Bt, Ct, n, ldb=ldb, accumulate=True)
+    torch.cuda.synchronize()
+    _check(Ct.cpu().numpy(), C0 + Co, bound + np.abs(C0), "long empty block-row, accumulate")
