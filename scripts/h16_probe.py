@@ -1,5 +1,6 @@
 """Developer script: which stream bounds a step of the stream kernels?  SPARTA_DBG_PROBE bits: 1 = one hot B panel, 2 = hot A, 4 = one C tile.
-Timing only (the products are wrong under a probe)."""
+Timing only (the products are wrong under a probe): the probes exist in the developer build only -
+make -C sparta_amd/csrc timeline; SPARTA_AMD_LIB=sparta_amd/libsparta_amd_tl.so python scripts/h16_probe.py"""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1906,7 +1906,11 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                     const int64_t h = row_part[ib + 1] - row_part[ib];
                     const int64_t nb = nzcount[ib];
                     const bool skipped = in.skip && in.skip[ib - br0];
+#ifdef SPARTA_TIMELINE                              // developer build only (make timeline): a probe makes the products WRONG on purpose
                     const int dbg_probe = [] { const char* e = std::getenv("SPARTA_DBG_PROBE"); return e ? atoi(e) : 0; }();
+#else
+                    constexpr int dbg_probe = 0;
+#endif
                     const bool zero_range = nb == 0 && !skipped && h >= kZeroRangeRows;     // one streamed fill instead of h / 64 fix-up tiles
                     if (zero_range && ty == 0) P.zero_ranges.emplace_back(row_part[ib] - row0, h);
                     for (int64_t r0 = 0; r0 < h && !skipped && !zero_range; r0 += SK_TM) {
