@@ -986,3 +986,60 @@ def test_long_run_of_empty_rows_is_zero_filled_by_the_streamed_fill(monkeypatch,
     d.spmm(Bt, Ct, n, ldb=ldb, accumulate=True)
     torch.cuda.synchronize()
     _check(Ct.cpu().numpy(), C0 + Co, bound + np.abs(C0), "long empty block-row, accumulate")
+
+
+@pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
+def test_full_size_16bit_flagship_kernels_agree_and_match_the_oracle(monkeypatch, dtype):
+    """The configuration `bench.py --dtype f16|bf16` times (cant-like 62 451^2, Keeper tau 0.6, 32 x 32 blocks, N = 128) at full size:
+    (i) the two 16-bit kernels (LDS-staged, direct-to-register) and the library's own choice give the same bits, (ii) two runs are
+    bit-identical, (iii) sampled block-rows match the oracle on the ROUNDED inputs within the fp32 bound, (iv) the column checksum
+    1^T C == (1^T A_rounded) B_rounded."""
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_PATH", "stream")
+    m = sa.gen.cant_like(seed=2)
+    w, n = 32, 128
+    g = sa.BlockingEngine(blocking_algo=5, tau=0.6, col_block_size=w, row_block_size=32, force_fixed_size=True, sim_measure=1).GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w, 32, True)
+    d = v.to_device(0, dtype=dtype)
+    tdt = torch.float16 if dtype == sa.F16 else torch.bfloat16
+    B = sa.gen.dense_rhs(v.cols, n, seed=1)
+    ldb = (v.cols + 7) // 8 * 8
+    Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    Bt.view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
+
+    def run(kernel):
+        if kernel is None:
+            monkeypatch.delenv("SPARTA_H16_PATH", raising=False)
+        else:
+            monkeypatch.setenv("SPARTA_H16_PATH", kernel)
+        Ct = torch.full((v.rows * n,), 3.0, dtype=torch.float32, device="cuda")
+        d.spmm(Bt, Ct, n, ldb=ldb, accumulate=False)
+        torch.cuda.synchronize()
+        return Ct
+    C_auto, C_lds, C_dir = run(None), run("lds"), run("direct")
+    assert torch.equal(C_auto, C_lds) and torch.equal(C_auto, C_dir)           # (i)
+    assert torch.equal(C_auto, run(None))                                      # (ii)
+    mab_r, B_r = _round16(v.mab, dtype), _round16(B, dtype)
+    Ch = C_auto.cpu().numpy().reshape(n, v.rows)
+    absA, absB = np.abs(mab_r), np.abs(B_r)
+    rng = np.random.Generator(np.random.PCG64(1))
+    for ib in rng.choice(v.block_rows, size=12, replace=False):               # (iii)
+        r0, r1 = int(v.row_part[ib]), int(v.row_part[ib + 1])
+        Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n, block_row_range=(int(ib), int(ib) + 1)).reshape(n, v.rows)
+        bd = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, absA, absB, n, block_row_range=(int(ib), int(ib) + 1)).reshape(n, v.rows)
+        _check(Ch[:, r0:r1], Co[:, r0:r1], bd[:, r0:r1], "16-bit flagship block-row %d" % ib)
+    # (iv): 1^T A over the stored (rounded) blocks, column-block by column-block
+    colsum = np.zeros((v.cols + w - 1) // w * w, np.float64)
+    starts = np.concatenate([[0], np.cumsum(v.nzcount)]).astype(np.int64)
+    hs = np.diff(v.row_part).astype(np.int64)
+    pos = 0
+    for ib in range(v.block_rows):
+        hgt = int(hs[ib])
+        for b in range(int(v.nzcount[ib])):
+            jb = int(v.jab[starts[ib] + b])
+            blk = mab_r[pos:pos + hgt * w].astype(np.float64).reshape(w, hgt)   # column-major h x w block: [k][row]
+            colsum[jb * w:(jb + 1) * w] += blk.sum(axis=1)
+            pos += hgt * w
+    want = colsum[:v.cols] @ B_r.astype(np.float64).reshape(n, v.cols).T
+    got = Ch.astype(np.float64).sum(axis=1)
+    assert np.allclose(got, want, rtol=0, atol=1e-3 * max(1.0, float(np.abs(want).max())))
