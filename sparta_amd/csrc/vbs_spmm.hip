@@ -1534,8 +1534,11 @@ __global__ __launch_bounds__(kThreads) void b_to_row_major_kernel(const E* __res
                                                                   int64_t rows, int N, E* __restrict__ out) {
     __shared__ E tile[64][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t r0 = (int64_t)blockIdx.x * 64;
-    const int n0 = blockIdx.y * 64;
+    // 1-D grid, column tile fastest: the workgroups that run together complete whole rows of the row-major copy (and read the same
+    // 64 rows of every column tile) instead of each touching one 128 / 256-byte piece of 64 rows that the next piece follows much later
+    const int n_ct = (N + 63) / 64;
+    const int64_t r0 = (int64_t)(blockIdx.x / n_ct) * 64;
+    const int n0 = (int)(blockIdx.x % n_ct) * 64;
     const int64_t r = r0 + lane;
     int64_t roff = r;
     if (shard_rows > 0 && r < rows) roff = (r / shard_rows) * shard_stride + (r % shard_rows);   // shard_rows % 64 need not hold: per lane
@@ -1558,8 +1561,9 @@ __global__ __launch_bounds__(kThreads) void sparse_c_scatter_kernel(const float*
                                                                     float* __restrict__ C, int64_t ldc, int accumulate) {
     __shared__ float tile[64][65];                               // 64 sparse rows x 64 columns
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t t0 = (int64_t)blockIdx.x * 64;
-    const int n0 = blockIdx.y * 64;
+    const int n_ct = (N + 63) / 64;                              // 1-D grid, column tile fastest (see b_to_row_major_kernel)
+    const int64_t t0 = (int64_t)(blockIdx.x / n_ct) * 64;
+    const int n0 = (int)(blockIdx.x % n_ct) * 64;
     for (int j = wave; j < 64; j += 4) {                         // read: lanes along the columns of one scratch row
         const int64_t t = t0 + j;
         const int n = n0 + lane;
@@ -2722,7 +2726,9 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     else if (in_place) { q.B = dB; q.ldb = 0; q.b_col_stride = ldb; q.shard_rows = shard_rows; q.shard_stride = shard_stride; }
     else {
         if (int rc = ensure_scratch(&A->d_Brm, &A->d_Brm_bytes, (size_t)A->cols * (size_t)n_cols * esz)) return rc;
-        const dim3 grid((unsigned)((A->cols + 63) / 64), (unsigned)((n_cols + 63) / 64));
+        const int64_t n_wg = ((A->cols + 63) / 64) * (int64_t)((n_cols + 63) / 64);
+        if (n_wg > INT32_MAX) return sparta::fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: B too large for the transpose grid");
+        const dim3 grid((unsigned)n_wg);
         if (bk == 0) hipLaunchKernelGGL(b_to_row_major_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)dB, ldb, shard_rows, shard_stride, A->cols, (int)n_cols, (float*)A->d_Brm);
         else hipLaunchKernelGGL(b_to_row_major_kernel<unsigned short>, grid, dim3(kThreads), 0, st, (const unsigned short*)dB, ldb, shard_rows, shard_stride, A->cols, (int)n_cols, (unsigned short*)A->d_Brm);
         q.B = A->d_Brm; q.ldb = n_cols;
@@ -2749,7 +2755,7 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     if (vec == 4) SPARTA_SP_DISPATCH(4); else if (vec == 2) SPARTA_SP_DISPATCH(2); else SPARTA_SP_DISPATCH(1);
 #undef SPARTA_SP_DISPATCH
     if (!q.out_is_c)
-        hipLaunchKernelGGL(sparse_c_scatter_kernel, dim3((unsigned)((A->n_sp_rows + 63) / 64), (unsigned)((n_cols + 63) / 64)), dim3(kThreads), 0, st,
+        hipLaunchKernelGGL(sparse_c_scatter_kernel, dim3((unsigned)(((A->n_sp_rows + 63) / 64) * (int64_t)((n_cols + 63) / 64))), dim3(kThreads), 0, st,
                            (const float*)A->d_spC, A->d_sp_crow, A->n_sp_rows, (int)n_cols, dC, ldc, (int)accumulate);
     HIP_TRY(hipGetLastError());
     return SPARTA_OK;
