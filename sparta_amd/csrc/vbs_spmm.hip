@@ -1540,18 +1540,25 @@ __global__ __launch_bounds__(kThreads) void b_to_row_major_kernel(const E* __res
     const int64_t r0 = (int64_t)(blockIdx.x / n_ct) * 64;
     const int n0 = (int)(blockIdx.x % n_ct) * 64;
     const int64_t r = r0 + lane;
-    int64_t roff = r;
-    if (shard_rows > 0 && r < rows) roff = (r / shard_rows) * shard_stride + (r % shard_rows);   // shard_rows % 64 need not hold: per lane
-    for (int j = wave; j < 64; j += 4) {                         // read: lanes along the rows (contiguous in a column)
-        const int n = n0 + j;
-        E v = (E)0;
-        if (r < rows && n < N) v = B[roff + (int64_t)n * ldb];
-        tile[j][lane] = v;
+    // All 16 loads of a lane are issued before the first one is used: addresses are clamped into the matrix instead of guarded (a
+    // guarded load in a rolled loop was one load in flight per wave - 2.5 TB/s whatever the access pattern), the guard is applied
+    // to the value.
+    const int64_t rc = r < rows ? r : rows - 1;
+    const int64_t roff = shard_rows > 0 ? (rc / shard_rows) * shard_stride + (rc % shard_rows) : rc;   // shard_rows % 64 need not hold: per lane
+    E v[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {                               // read: lanes along the rows (contiguous in a column)
+        const int n = n0 + wave + 4 * q;
+        v[q] = B[roff + (int64_t)(n < N ? n : N - 1) * ldb];
     }
+#pragma unroll
+    for (int q = 0; q < 16; q++) tile[wave + 4 * q][lane] = (r < rows && n0 + wave + 4 * q < N) ? v[q] : (E)0;
     __syncthreads();
-    for (int j = wave; j < 64; j += 4) {                         // write: lanes along the columns (contiguous in a row)
+    const int n = n0 + lane;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {                               // write: lanes along the columns (contiguous in a row)
+        const int j = wave + 4 * q;
         const int64_t rr = r0 + j;
-        const int n = n0 + lane;
         if (rr < rows && n < N) out[rr * N + n] = tile[lane][j];
     }
 }
@@ -1564,19 +1571,39 @@ __global__ __launch_bounds__(kThreads) void sparse_c_scatter_kernel(const float*
     const int n_ct = (N + 63) / 64;                              // 1-D grid, column tile fastest (see b_to_row_major_kernel)
     const int64_t t0 = (int64_t)(blockIdx.x / n_ct) * 64;
     const int n0 = (int)(blockIdx.x % n_ct) * 64;
-    for (int j = wave; j < 64; j += 4) {                         // read: lanes along the columns of one scratch row
-        const int64_t t = t0 + j;
+    const int64_t t = t0 + lane;
+    const int32_t r = crow[t < n_rows ? t : n_rows - 1];         // consecutive sparse rows are mostly consecutive rows of C (requested with the tile's loads)
+    {
         const int n = n0 + lane;
-        tile[j][lane] = (t < n_rows && n < N) ? src[t * N + n] : 0.0f;
+        const int nc = n < N ? n : N - 1;
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {                           // read: lanes along the columns of one scratch row; 16 loads in flight (clamped, not guarded)
+            const int64_t t = t0 + wave + 4 * q;
+            v[q] = src[(t < n_rows ? t : n_rows - 1) * N + nc];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) tile[wave + 4 * q][lane] = (t0 + wave + 4 * q < n_rows && n < N) ? v[q] : 0.0f;
     }
     __syncthreads();
-    const int64_t t = t0 + lane;
-    const int32_t r = t < n_rows ? crow[t] : 0;                  // consecutive sparse rows are mostly consecutive rows of C
-    for (int j = wave; j < 64; j += 4) {                         // write: lanes along the rows of one column of C
-        const int n = n0 + j;
-        if (t < n_rows && n < N) {
-            float* o = C + r + (int64_t)n * ldc;
-            *o = accumulate ? *o + tile[lane][j] : tile[lane][j];
+    if (t >= n_rows) return;
+    if (accumulate) {
+        float old[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int n = n0 + wave + 4 * q;
+            old[q] = C[r + (int64_t)(n < N ? n : N - 1) * ldc];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int n = n0 + wave + 4 * q;
+            if (n < N) C[r + (int64_t)n * ldc] = old[q] + tile[lane][wave + 4 * q];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {                           // write: lanes along the rows of one column of C
+            const int n = n0 + wave + 4 * q;
+            if (n < N) C[r + (int64_t)n * ldc] = tile[lane][wave + 4 * q];
         }
     }
 }
