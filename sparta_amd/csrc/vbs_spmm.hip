@@ -1614,8 +1614,17 @@ __global__ __launch_bounds__(kThreads) void sparse_c_scatter_kernel(const float*
 __global__ __launch_bounds__(kThreads) void pack_blocks_kernel(const u32x4* __restrict__ src, const int32_t* __restrict__ ids,
                                                                u32x4* __restrict__ dst, int64_t block_vec) {
     const int64_t from = (int64_t)ids[blockIdx.x] * block_vec, to = (int64_t)blockIdx.x * block_vec;
-    for (int64_t i = (int64_t)blockIdx.y * kThreads + threadIdx.x; i < block_vec; i += (int64_t)gridDim.y * kThreads)
-        dst[to + i] = __builtin_nontemporal_load(src + from + i);
+    const int64_t stride = (int64_t)gridDim.y * kThreads;
+    // four loads of a thread in flight (clamped addresses, guarded stores): the pack is the head of the exchange's critical path and a
+    // 16 KB tile is four rounds of the workgroup - one round at a time is four memory latencies in a row
+    for (int64_t i = (int64_t)blockIdx.y * kThreads + threadIdx.x; i < block_vec; i += 4 * stride) {
+        u32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = __builtin_nontemporal_load(src + from + std::min<int64_t>(i + q * stride, block_vec - 1));
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (i + q * stride < block_vec) dst[to + i + q * stride] = v[q];
+    }
 }
 
 // ---- exact-order kernel (parity aid) -----------------------------------------------------------------
