@@ -723,7 +723,7 @@ def test_sparse_row_path_gathered_b(_sparse_row_mode):
 
 
 @pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
-@pytest.mark.parametrize("n", [128, 256])
+@pytest.mark.parametrize("n", [128, 256, 512])                  # 512: two column chunks per row (blockIdx.y) with 4-element vectors
 def test_sparse_row_path_16bit(_sparse_row_mode, dtype, n):
     """16-bit handles: the sparse rows hold the ROUNDED values of A and read a row-major 16-bit copy of B; reference = the oracle
     on the rounded inputs (products of two 16-bit values are exact in fp32), tolerance as everywhere"""
