@@ -214,6 +214,16 @@ int sparta_vbs_build(int64_t rows, int64_t cols, const int64_t* rowptr, const in
                      sparta_vbs_host* out);
 void sparta_vbs_host_free(sparta_vbs_host* v);
 
+/* replaces VBR::fill_from_CSR(cmat, row_partition, block_size) (include/matrices.h:117, src/general/vbr.cpp:239-321): the rows
+ * keep their order, block-row ib = rows [row_partition[ib], row_partition[ib+1]); repeated entries give block-rows of height 0
+ * with nzcount 0, as in the reference.  Where the reference prints "PARTITION CHECK ERROR" and continues (vbr.cpp:253-257) this
+ * returns SPARTA_ERR_INVALID. */
+int sparta_vbs_build_partition(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals,
+                               const int64_t* row_partition, int64_t n_part, int64_t block_size, sparta_vbs_host* out);
+/* replaces VBR::partition_check(candidate_part) (src/general/vbr.cpp:108-118): 0 = valid, 1 = empty, 2 = last entry != rows,
+ * 3 = decreasing.  (A status of the partition, not a SPARTA_* code.) */
+int sparta_vbs_partition_check(const int64_t* part, int64_t n_part, int64_t rows);
+
 /* Binary VBS container ("SPARTAVB", little-endian, 96-byte header + the four arrays, FNV-1a checksum; layout in
  * sparta_amd/csrc/io.cpp): the reorder + build cost is paid once.  sparta_vbs_load verifies magic, sizes, checksum and the
  * structural invariants and fills *out (release with sparta_vbs_host_free).  No reference counterpart. */

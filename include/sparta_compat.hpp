@@ -24,6 +24,7 @@
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <iostream>
 #include <vector>
 
 #include "sparta_amd.h"
@@ -322,11 +323,7 @@ struct VBR {
         sparta_compat_detail::check(sparta_vbs_build(cmat.rows, cmat.cols, rp.data(), ci.data(), cmat.pattern_only ? nullptr : v.data(),
                                                      (const int64_t*)grouping.data(), col_block_size, row_block_size, force_fixed_size, &h),
                                     "VBR::fill_from_CSR_inplace");
-        rows = h.rows; cols = h.cols; block_rows = h.block_rows; block_cols = h.block_cols; block_col_size = h.block_col_size; nztot = h.nztot;
-        row_part = new intT[h.block_rows + 1]; std::memcpy(row_part, h.row_part, sizeof(intT) * (size_t)(h.block_rows + 1));
-        nzcount = new intT[h.block_rows > 0 ? h.block_rows : 1]; std::memcpy(nzcount, h.nzcount, sizeof(intT) * (size_t)h.block_rows);
-        jab = new intT[h.nblocks > 0 ? h.nblocks : 1]; std::memcpy(jab, h.jab, sizeof(intT) * (size_t)h.nblocks);
-        mab = new DataT[h.nztot > 0 ? h.nztot : 1]; std::memcpy(mab, h.mab, sizeof(DataT) * (size_t)h.nztot);
+        take(h);
         sparta_vbs_host_free(&h);
     }
     // src/general/vbr.cpp:121-132
@@ -334,6 +331,30 @@ struct VBR {
         std::vector<intT> grouping((size_t)cmat.rows);
         for (intT i = 0; i < cmat.rows; i++) grouping[(size_t)i] = i / row_block_size;
         fill_from_CSR_inplace(cmat, grouping, col_block_size, row_block_size, force_fixed_size);
+    }
+
+    // src/general/vbr.cpp:239-321 -- rows keep their order, block-rows from a row partition
+    void fill_from_CSR(const CSR& cmat, const std::vector<intT>& row_partition, intT block_size) {
+        clean();
+        std::vector<int64_t> rp; std::vector<int32_t> ci; std::vector<float> v;
+        cmat.to_flat(rp, ci, v);
+        sparta_vbs_host h;
+        sparta_compat_detail::check(sparta_vbs_build_partition(cmat.rows, cmat.cols, rp.data(), ci.data(), cmat.pattern_only ? nullptr : v.data(),
+                                                               (const int64_t*)row_partition.data(), (int64_t)row_partition.size(), block_size, &h),
+                                    "VBR::fill_from_CSR");
+        take(h);
+        sparta_vbs_host_free(&h);
+    }
+    // src/general/vbr.cpp:33-49 -- where the values of block-row `row_block_idx` start in mab
+    DataT* get_block_start(intT row_block_idx) {
+        if (row_block_idx >= block_rows) { std::cerr << " [RANGE ERROR] VBR::get_block_start" << std::endl; return mab; }
+        DataT* ptr = mab;
+        for (intT ib = 0; ib < row_block_idx; ib++) ptr += (row_part[ib + 1] - row_part[ib]) * nzcount[ib] * block_col_size;
+        return ptr;
+    }
+    // src/general/vbr.cpp:108-118 -- 0 = valid partition of [0, rows]
+    int partition_check(const std::vector<intT>& candidate_part) {
+        return sparta_vbs_partition_check((const int64_t*)candidate_part.data(), (int64_t)candidate_part.size(), rows);
     }
 
     // include/matrices.h:121 -- C += A*B, host buffers, column-major; runs the MFMA kernels on `device`
@@ -355,6 +376,13 @@ struct VBR {
     }
 
    private:
+    void take(const sparta_vbs_host& h) {      // the library's arrays -> this object's own (new[] / delete[] as in the reference)
+        rows = h.rows; cols = h.cols; block_rows = h.block_rows; block_cols = h.block_cols; block_col_size = h.block_col_size; nztot = h.nztot;
+        row_part = new intT[h.block_rows + 1]; std::memcpy(row_part, h.row_part, sizeof(intT) * (size_t)(h.block_rows + 1));
+        nzcount = new intT[h.block_rows > 0 ? h.block_rows : 1]; std::memcpy(nzcount, h.nzcount, sizeof(intT) * (size_t)h.block_rows);
+        jab = new intT[h.nblocks > 0 ? h.nblocks : 1]; std::memcpy(jab, h.jab, sizeof(intT) * (size_t)h.nblocks);
+        mab = new DataT[h.nztot > 0 ? h.nztot : 1]; std::memcpy(mab, h.mab, sizeof(DataT) * (size_t)h.nztot);
+    }
     mutable sparta_vbs_t* dev_ = nullptr;   // device image, created on first multiply, released by clean()
     mutable sparta_vbs_t* dev_t_ = nullptr; // device image of the transpose (multiply_BA)
 };

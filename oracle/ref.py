@@ -61,6 +61,11 @@ def lib():
         L.ref_vbr_create.restype = vp
         L.ref_vbr_create.argtypes = [vp, lp, C.c_long, C.c_long, C.c_long, C.c_int]
         L.ref_vbr_destroy.argtypes = [vp]
+        L.ref_vbr_create_partition.restype = vp
+        L.ref_vbr_create_partition.argtypes = [vp, lp, C.c_long, C.c_long]
+        L.ref_vbr_block_start.restype = C.c_long
+        L.ref_vbr_block_start.argtypes = [vp, C.c_long]
+        L.ref_vbr_partition_check.argtypes = [vp, lp, C.c_long]
         L.ref_vbr_dims.argtypes = [vp, lp]
         L.ref_vbr_export.argtypes = [vp, lp, lp, lp, fp]
         L.ref_vbr_multiply.argtypes = [vp, fp, C.c_int, fp]
@@ -178,9 +183,13 @@ class RefCSR:
 class RefVBR:
     """Owns a reference `VBR` (include/matrices.h:93-122) built by fill_from_CSR_inplace."""
 
-    def __init__(self, csr, grouping, col_block_size, row_block_size=0, force_fixed_size=False):
-        g = _i64(grouping)
-        self.h = lib().ref_vbr_create(csr.h, _lp(g), len(g), col_block_size, row_block_size, int(force_fixed_size))
+    def __init__(self, csr, grouping, col_block_size, row_block_size=0, force_fixed_size=False, row_partition=None):
+        if row_partition is not None:          # VBR::fill_from_CSR (vbr.cpp:239-321): no permutation, block-rows from a partition
+            rp = _i64(row_partition)
+            self.h = lib().ref_vbr_create_partition(csr.h, _lp(rp), len(rp), col_block_size)
+        else:
+            g = _i64(grouping)
+            self.h = lib().ref_vbr_create(csr.h, _lp(g), len(g), col_block_size, row_block_size, int(force_fixed_size))
         d = np.zeros(7, np.int64)
         lib().ref_vbr_dims(self.h, _lp(d))
         (self.rows, self.cols, self.block_rows, self.block_cols, self.block_col_size, self.nztot, self.nblocks) = map(int, d)
@@ -192,6 +201,15 @@ class RefVBR:
         mab = np.zeros(self.nztot, np.float32) if with_mab else None
         lib().ref_vbr_export(self.h, _lp(rp), _lp(nz), _lp(jab), _fp(mab))
         return rp, nz, jab, mab
+
+    def block_start(self, row_block_idx):
+        """VBR::get_block_start (vbr.cpp:33-49) as an element offset into mab"""
+        return int(lib().ref_vbr_block_start(self.h, int(row_block_idx)))
+
+    def partition_check(self, part):
+        """VBR::partition_check (vbr.cpp:108-118)"""
+        p = _i64(part)
+        return int(lib().ref_vbr_partition_check(self.h, _lp(p), len(p)))
 
     def multiply(self, B, n_cols, Cin=None):
         """reference VBR::multiply: C += A*B, B col-major ld=cols, C col-major ld=rows (vbr.cpp:323-372)."""

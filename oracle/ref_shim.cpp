@@ -184,6 +184,23 @@ void* ref_vbr_create(void* hcsr, const long* grouping, long n, long col_block_si
     v->fill_from_CSR_inplace(*c, g, col_block_size, row_block_size, force_fixed_size != 0);
     return v;
 }
+// reference: src/general/vbr.cpp:239-321 (rows keep their order, block-rows given by a row partition)
+void* ref_vbr_create_partition(void* hcsr, const long* row_partition, long n_part, long block_size)
+{
+    CSR* c = (CSR*)hcsr;
+    std::vector<intT> part(row_partition, row_partition + n_part);
+    VBR* v = new VBR;
+    v->rows = 0; v->cols = 0; v->mab = nullptr; v->jab = nullptr; v->nzcount = nullptr; v->row_part = nullptr;
+    v->fill_from_CSR(*c, part, block_size);
+    return v;
+}
+// reference: src/general/vbr.cpp:33-49 (as an element offset into mab) and :108-118
+long ref_vbr_block_start(void* h, long row_block_idx) { VBR* v = (VBR*)h; return (long)(v->get_block_start(row_block_idx) - v->mab); }
+int ref_vbr_partition_check(void* h, const long* part, long n_part)
+{
+    std::vector<intT> p(part, part + n_part);
+    return ((VBR*)h)->partition_check(p);
+}
 void ref_vbr_destroy(void* h) { delete (VBR*)h; }
 // out: rows, cols, block_rows, block_cols, block_col_size, nztot, total nonzero blocks
 void ref_vbr_dims(void* h, long* out)

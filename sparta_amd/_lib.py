@@ -36,6 +36,7 @@ SYMBOLS = [
     "sparta_version",
     "sparta_csr_read", "sparta_csr_read_buffer", "sparta_csr_host_free", "sparta_csr_write_edgelist", "sparta_grouping_write", "sparta_grouping_read",
     "sparta_blocking_csv_row", "sparta_degree_permutation", "sparta_vbs_save", "sparta_vbs_load", "sparta_vbs_to_blocked_ell",
+    "sparta_vbs_build_partition", "sparta_vbs_partition_check",
 ]
 
 
@@ -101,6 +102,8 @@ def _load():
     L.sparta_vbs_build.argtypes = [C.c_int64, C.c_int64, i64p, i32p, f32p, i64p, C.c_int64, C.c_int64, C.c_int32,
                                    C.POINTER(VbsHost)]
     L.sparta_vbs_host_free.argtypes = [C.POINTER(VbsHost)]
+    L.sparta_vbs_build_partition.argtypes = [C.c_int64, C.c_int64, i64p, i32p, f32p, i64p, C.c_int64, C.c_int64, C.POINTER(VbsHost)]
+    L.sparta_vbs_partition_check.argtypes = [i64p, C.c_int64, C.c_int64]
     L.sparta_vbs_save.argtypes = [C.c_char_p, C.POINTER(VbsHost)]
     L.sparta_vbs_load.argtypes = [C.c_char_p, C.POINTER(VbsHost)]
     L.sparta_vbs_to_blocked_ell.argtypes = [C.POINTER(VbsHost), i64p, i64p, f32p]

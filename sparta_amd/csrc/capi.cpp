@@ -1,6 +1,8 @@
 // capi.cpp -- extern "C" glue for the host-side part of include/sparta_amd.h
-// (the device part lives in vbs_spmm.hip).  No exception leaves this file.
+// (the device part lives in vbs_capi.cpp + the k_*.hip kernel translation units).  No exception leaves this file.
 #include <cstring>
+#include <algorithm>
+#include <cstdlib>
 #include <exception>
 #include <new>
 
@@ -132,6 +134,51 @@ int sparta_vbs_build(int64_t rows, int64_t cols, const int64_t* rowptr, const in
     CsrView a; a.rows = rows; a.cols = cols; a.rowptr = rowptr; a.colidx = colidx; a.vals = vals;
     int rc = vbs_build(a, grouping, col_block_size, row_block_size, force_fixed_size != 0, out);
     return rc;
+    SPARTA_CATCH
+}
+
+int sparta_vbs_partition_check(const int64_t* part, int64_t n_part, int64_t rows) {
+    // VBR::partition_check (src/general/vbr.cpp:108-118): 0 = valid, 1 = empty, 2 = last entry != rows, 3 = decreasing
+    if (!part || n_part <= 0) return 1;
+    if (part[n_part - 1] != rows) return 2;
+    for (int64_t i = 1; i < n_part; i++)
+        if (part[i] < part[i - 1]) return 3;
+    return 0;
+}
+
+int sparta_vbs_build_partition(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals,
+                               const int64_t* row_partition, int64_t n_part, int64_t block_size, sparta_vbs_host* out) {
+    SPARTA_TRY
+    if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_build_partition: out is NULL");
+    std::memset(out, 0, sizeof(*out));
+    const int chk = sparta_vbs_partition_check(row_partition, n_part, rows);
+    if (chk != 0 || row_partition[0] != 0)          // the reference prints "PARTITION CHECK ERROR" and carries on into undefined behaviour
+        return fail(SPARTA_ERR_INVALID, "sparta_vbs_build_partition: partition check failed with error " + std::to_string(chk != 0 ? chk : 4));
+    CsrView a; a.rows = rows; a.cols = cols; a.rowptr = rowptr; a.colidx = colidx; a.vals = vals;
+    // rows keep their order: grouping[i] = the block-row that holds row i (non-decreasing), built without the reference's sort
+    std::vector<int64_t> grouping((size_t)rows);
+    for (int64_t ib = 0; ib + 1 < n_part; ib++)
+        for (int64_t i = row_partition[ib]; i < row_partition[ib + 1]; i++) grouping[(size_t)i] = ib;
+    sparta_vbs_host h;
+    int rc = vbs_build_hybrid(a, grouping.data(), block_size, 0, false, 0.0, 32, &h, nullptr, true);
+    if (rc != SPARTA_OK) return rc;
+    // block-rows of height 0 (repeated partition entries) exist in the reference's arrays with nzcount 0: put them back
+    const int64_t block_rows = n_part - 1;
+    if (h.block_rows != block_rows) {
+        int64_t* rp = (int64_t*)std::malloc(sizeof(int64_t) * (size_t)(block_rows + 1));
+        int64_t* nz = (int64_t*)std::malloc(sizeof(int64_t) * (size_t)std::max<int64_t>(block_rows, 1));
+        if (!rp || !nz) { std::free(rp); std::free(nz); sparta_vbs_host_free(&h); return fail(SPARTA_ERR_ALLOC, "sparta_vbs_build_partition: out of host memory"); }
+        int64_t src = 0;
+        for (int64_t ib = 0; ib < block_rows; ib++) {
+            rp[ib] = row_partition[ib];
+            nz[ib] = row_partition[ib + 1] > row_partition[ib] ? h.nzcount[src++] : 0;
+        }
+        rp[block_rows] = rows;
+        std::free(h.row_part); std::free(h.nzcount);
+        h.row_part = rp; h.nzcount = nz; h.block_rows = block_rows;
+    }
+    *out = h;
+    return SPARTA_OK;
     SPARTA_CATCH
 }
 

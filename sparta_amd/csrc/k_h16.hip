@@ -1,0 +1,577 @@
+// k_h16.hip -- fp16 / bf16 storage with fp32 accumulation: the LDS-staged and the direct (operands straight into the MFMA
+// registers) persistent stream kernels, the 16-bit B-tail copy and the fp32 -> 16-bit conversion of the host-pointer path.
+// Part of the device side of libsparta_amd.so; see vbs_device.hpp for the translation-unit map and DESIGN.md section 8.
+#include "vbs_kernel_common.hpp"
+
+using namespace sparta_dev;
+
+namespace {
+
+// =====================================================================================================
+// 16-bit (fp16 / bf16) storage, fp32 accumulation: vbs_spmm_h16_stream_kernel<KP, MI2, BF16>
+// Same persistent design, step records, plans and epilogue as the fp32 stream kernel; what changes is the operand path.
+// * A is re-laid-out ONCE at sparta_vbs_create: every step's slice is a dense row-major TM x KP chunk (k contiguous, rows
+//   past the tile zero), the chunks of a tile back to back.  The 16-bit MFMA wants 8 consecutive k of one row per lane; the
+//   reference's column-major blocks have k strided, and transposing 16-bit data on the way into LDS costs 8 ds_write_b16 per
+//   16-byte load.  The host-side VBS (the boundary) keeps the reference's layout; only the device copy differs.
+// * B must be column-major (k contiguous per column) with an even leading dimension: Bs[j][k], As[i][k], rows padded by
+//   8 elements; a fragment is one ds_read_b128 (8 k) per operand and feeds v_mfma_f32_32x32x16_{f16,bf16}.
+// * D = Bpanel^T . Atile^T as in the fp32 kernels (accumulator layout and epilogue are the same); an MFMA sums its k slots,
+//   so any lane -> k assignment works as long as both operands use the same one (lane group g takes k = kb + 8g .. +7).
+// A step moves half the bytes of the fp32 kernel and its MFMAs take 1/8 of the time: this kernel is bound by the load path
+// (L2 / Infinity Cache -> LDS), not by MFMA.
+// =====================================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// DEEP: four register sets instead of two -- loads run 5 steps ahead of the MFMAs (4 steps of panels in flight per workgroup
+// instead of 2).  A 16-bit step has 64-128 cycles of MFMA per wave: what a step costs is how long its panel takes to arrive
+// divided by the number of panels in flight, and the registers are there (2 waves per SIMD: 256 VGPRs each).
+template <int KP, bool MI2, bool BF16, bool GATHERED, bool DEEP>
+__global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const StreamParams p) {
+    constexpr int TN = kTN, TM = MI2 ? 64 : 32;
+    constexpr int LDK = KP + 8;                          // elements per LDS row
+    constexpr int BSZ = TN * LDK;                        // elements of the B panel image
+    constexpr int STAGE = BSZ + 64 * LDK;                // elements per LDS stage
+    constexpr int CPC = KP / 8;                          // 16-byte chunks per row / column
+    constexpr int CPP = kThreads / CPC;                  // B columns covered by one load pass
+    constexpr int NBL = TN / CPP;                        // B loads per thread and step (4 for KP 64, 2 for KP 32)
+    constexpr int NAL = (TM * CPC + kThreads - 1) / kThreads;   // A loads per thread and step (2, 1, 1, 1)
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 31, g = lane >> 5;
+    const int n0 = blockIdx.y * TN;
+    const int s_begin = p.worker_range[2 * blockIdx.x];
+    const int n = p.worker_range[2 * blockIdx.x + 1] - s_begin;
+    if (n <= 0) return;
+    clock_probe(p.clk, 0);
+#ifdef SPARTA_TIMELINE
+    long long tl_t0 = 0;
+    if (p.clk != nullptr && blockIdx.y == 0 && tid == 0 && blockIdx.x < 1024) tl_t0 = wall_clock64();
+#endif
+    float* ws = p.ws + (int64_t)blockIdx.y * p.ws_slab_stride;
+    const uint16_t* A16 = reinterpret_cast<const uint16_t*>(p.A);
+    const uint16_t* B16 = reinterpret_cast<const uint16_t*>(p.B);
+    const uint16_t* Bt16 = reinterpret_cast<const uint16_t*>(p.B_tail);
+
+    const int32_t* srec = reinterpret_cast<const int32_t*>(p.steps + s_begin);
+    int vrec0 = srec[lane];
+    int vrec1 = srec[64 + lane];
+    int vnext = 0;
+    // a macro over a free function, not a lambda: every closure between the loop body and vrec0 / vrec1 is one more level of
+    // pointer indirection the optimiser has to peel before it can keep them in registers (three levels deep it gave up and
+    // left one of them in memory: an LDS / scratch read behind a full wait in every step)
+#define field(s, f) sk_field(vrec0, vrec1, (s), (f))
+    enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6, F_SHARD = 7 };
+
+    const int bj0 = tid / CPC, bc = tid % CPC;           // B: column bj0 + CPP q, chunk bc (k = 8 bc .. 8 bc + 7)
+    const int ac = tid % (TM * CPC);                     // A: chunk ac (+ 256 q) of the contiguous TM x KP slice (clamped: duplicates are harmless)
+    const int64_t ld_t = (int64_t)p.w;                   // leading dimension of B_tail
+    const uint32_t voffB = (uint32_t)((bc * 8 + bj0 * p.ldb) * 2), voffBt = (uint32_t)((bc * 8 + (n0 + bj0) * ld_t) * 2);
+    const uint32_t qstepB = (uint32_t)(CPP * p.ldb * 2), qstepBt = (uint32_t)(CPP * ld_t * 2);
+    const int64_t n0off = (int64_t)n0 * p.ldb;
+    const uint32_t lwB = (uint32_t)((bj0 * LDK + bc * 8) * 2);
+    const uint32_t lwA = (uint32_t)((BSZ + (ac / CPC) * LDK + (ac % CPC) * 8) * 2);
+    const uint32_t lrB = (uint32_t)(((32 * wave + lm) * LDK + 8 * g) * 2);
+    const uint32_t lrA = (uint32_t)((BSZ + lm * LDK + 8 * g) * 2);
+    const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 32 * wave + 4 * g) * 4) : (uint32_t)((lm + (32 * wave + 4 * g) * p.ldc) * 4);
+    char* const ldsb = reinterpret_cast<char*>(lds);
+
+    u32x4 b0[NBL], a0[NAL], b1[NBL], a1[NAL];
+    u32x4 b2[DEEP ? NBL : 1], a2[DEEP ? NAL : 1], b3[DEEP ? NBL : 1], a3[DEEP ? NAL : 1];     // DEEP: register sets 2 / 3
+    constexpr int AHEAD = DEEP ? 5 : 3;                  // a register set written to LDS at step i is refilled with step i + AHEAD
+
+    int64_t g_aoff = 0;
+    uint32_t vo_cur = voffB;                             // see the fp32 kernel: every VALU instruction in the steady state costs an MFMA slot
+    int32_t tail_prev = 0;
+    auto issue_loads = [&](int s, u32x4 (&rb)[NBL], u32x4 (&ra)[NAL]) __attribute__((always_inline)) -> int32_t {
+        const int32_t flags = field(s, F_FLAGS);
+        if (flags & STEP_FIRST) g_aoff = (int64_t)(uint32_t)field(s, F_AOFF_LO) | ((int64_t)field(s, F_AOFF_HI) << 32);
+        else g_aoff += (int64_t)TM * KP;                 // the slices of a tile are back to back
+        const int32_t tail = (flags & STEP_TAIL) != 0;
+        if (tail != tail_prev) {
+            vo_cur = tail ? voffBt : voffB;
+            asm volatile("" : "+v"(vo_cur));
+            tail_prev = tail;
+        }
+        const int64_t gk0 = field(s, F_BROW);
+        const uint16_t* bptr = tail ? Bt16 + gk0 : B16 + (GATHERED ? (int64_t)field(s, F_SHARD) * p.shard_stride : (int64_t)0) + gk0 + n0off;   // gathered: (slab, row inside the slab), see the fp32 kernel
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(bptr), 0, 0x7ffffff0, 0x00020000);
+        const uint32_t qs = tail ? qstepBt : qstepB;
+#pragma unroll
+        for (int q = 0; q < NBL; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, qs * q, 0);
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A16 + g_aoff), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < NAL; q++) ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rA, (uint32_t)ac * 16u, (uint32_t)(q * kThreads * 16), 2);
+        return flags;
+    };
+    int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq_new = 0;
+    auto write_stage = [&](auto stage_tag, const u32x4 (&rb)[NBL], const u32x4 (&ra)[NAL]) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_tag)::value;
+#pragma unroll
+        for (int q = 0; q < NBL; q++) *reinterpret_cast<u32x4*>(ldsb + lwB + (ST * STAGE + q * CPP * LDK) * 2) = rb[q];
+#pragma unroll
+        for (int q = 0; q < NAL; q++) *reinterpret_cast<u32x4*>(ldsb + lwA + (ST * STAGE + q * (kThreads / CPC) * LDK) * 2) = ra[q];
+    };
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    auto mfma = [&](const u32x4& bf, const u32x4& af, f32x16& acc) __attribute__((always_inline)) {
+        if constexpr (BF16) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf), __builtin_bit_cast(bf16x8, af), acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf), __builtin_bit_cast(f16x8, af), acc, 0, 0, 0);
+    };
+
+    auto iteration_t = [&](int i, int32_t flags, u32x4 (&wb)[NBL], u32x4 (&wa)[NAL], auto par_tag) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_tag)::value;
+        using nxt_t = std::integral_constant<int, 1 - PAR>;
+#ifdef SPARTA_TIMELINE
+        unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool tl_on = p.clk != nullptr && blockIdx.x == 8 && blockIdx.y == 0 && i >= TL_FIRST && i < TL_FIRST + TL_STEPS;
+#endif
+        TL_STAMP(0);
+        write_stage(nxt_t{}, wb, wa);
+        TL_STAMP(1);
+        fq_new = issue_loads(i + AHEAD, wb, wa);
+        TL_STAMP(2);
+#pragma unroll
+        for (int kb = 0; kb < KP; kb += 16) {
+            const u32x4 bf = *reinterpret_cast<const u32x4*>(ldsb + lrB + (PAR * STAGE + kb) * 2);
+            const u32x4 af0 = *reinterpret_cast<const u32x4*>(ldsb + lrA + (PAR * STAGE + kb) * 2);
+            mfma(bf, af0, acc0);
+            if constexpr (MI2) {
+                const u32x4 af1 = *reinterpret_cast<const u32x4*>(ldsb + lrA + (PAR * STAGE + 32 * LDK + kb) * 2);
+                mfma(bf, af1, acc1);
+            }
+        }
+        TL_STAMP(3);
+        TL_STAMP(4);
+        if (flags & STEP_LAST) {
+            if (flags & STEP_SPLIT) {
+                const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_SLOT) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc0[q]), rW, (uint32_t)tid * 4u, (uint32_t)(q * kThreads * 4), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1[q]), rW, (uint32_t)tid * 4u, (uint32_t)((16 + q) * kThreads * 4), 0);
+                }
+            } else {
+                const int mt = flags & 0xffff;
+                const int64_t c_row = field(i, F_CROW);
+                float* cbase = p.c_row_major ? p.C + c_row * p.ldc + n0 : p.C + c_row + (int64_t)n0 * p.ldc;
+                const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
+                const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;
+                const uint32_t mistep = p.c_row_major ? (uint32_t)p.ldc * 128u : 128u;
+#pragma unroll
+                for (int mi = 0; mi < (MI2 ? 2 : 1); mi++) {
+                    if (mi * 32 + lm < mt) {
+                        float v[16];
+#pragma unroll
+                        for (int q = 0; q < 16; q++) v[q] = mi == 0 ? acc0[q] : acc1[q];
+                        if (p.accumulate) {
+                            uint32_t old[16];
+#pragma unroll
+                            for (int q = 0; q < 16; q++) old[q] = __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
+#pragma unroll
+                            for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 16; q++)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
+        }
+        TL_STAMP(5);
+        __syncthreads();
+        TL_STAMP(6);
+#ifdef SPARTA_TIMELINE
+        if (tl_on) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                long long* o = p.clk + 16 + ((int64_t)wave * TL_STEPS + (i - TL_FIRST)) * 8;
+#pragma unroll
+                for (int k = 0; k < 7; k++) o[k] = (long long)tl[k];
+                o[7] = flags;
+            }
+        }
+#endif
+    };
+
+    using st0 = std::integral_constant<int, 0>;
+    using st1 = std::integral_constant<int, 1>;
+    if constexpr (!DEEP) {
+        fq0 = issue_loads(0, b0, a0);
+        fq1 = issue_loads(1, b1, a1);
+        write_stage(st0{}, b0, a0);
+        fq2 = issue_loads(2, b0, a0);
+        __syncthreads();
+        // record batches: see the fp32 kernel.  At least 4 steps x (NBL + NAL >= 3) = 12 loads are issued between request and touch.
+        auto batch_upkeep = [&](int i) __attribute__((always_inline)) {
+            if ((i & 7) == 0 && i > 0) {
+                const int32_t* nb = srec + (int64_t)((i >> 3) + 1) * 64 + lane;
+                asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
+            }
+            if ((i & 7) == 4 && i > 4) {
+                asm volatile("s_waitcnt vmcnt(3)" : "+v"(vnext) : : "memory");
+                // two selects, not "if (odd) vrec1 = vnext; else vrec0 = vnext;": the compiler merges the two stores of that form into one store
+                // through a selected POINTER, which pins vrec0 / vrec1 in scratch memory -- every step then reloads them behind vmcnt(0)
+                const bool odd = (((i >> 3) + 1) & 1) != 0;
+                vrec1 = odd ? vnext : vrec1;
+                vrec0 = odd ? vrec0 : vnext;
+            }
+        };
+        const int n_even = n & ~1;
+        for (int i = 0; i < n_even; i += 2) {
+            batch_upkeep(i);
+            iteration_t(i, fq0, b1, a1, st0{});
+            fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+            iteration_t(i + 1, fq0, b0, a0, st1{});
+            fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+        }
+        if (n & 1) {
+            batch_upkeep(n_even);
+            iteration_t(n_even, fq0, b1, a1, st0{});
+        }
+    } else {
+        // Step s lives in register set s & 3 and LDS stage s & 1.  Iteration i computes step i, writes step i + 1 (set (i + 1) & 3)
+        // into the other stage and refills that set with step i + 5: steps i + 2 .. i + 5 are in flight under step i.
+        int32_t fq3 = 0, fq4 = 0;
+        fq0 = issue_loads(0, b0, a0);
+        fq1 = issue_loads(1, b1, a1);
+        write_stage(st0{}, b0, a0);
+        fq2 = issue_loads(2, b2, a2);
+        fq3 = issue_loads(3, b3, a3);
+        fq4 = issue_loads(4, b0, a0);
+        __syncthreads();
+        // Record batches (8 steps each; vrec0 / vrec1 hold batches k, k + 1): step 8k + 3 is the first to look into batch k + 1
+        // (its refill is step 8k + 8), so batch k + 1 is requested at step 8k - 2 and touched at step 8k + 2; the register it
+        // replaces (batch k - 1) is dead from step 8k on.  The four steps in between issue 4 x (NBL + NAL >= 3) >= 12 loads and
+        // memory returns in order: vmcnt(12) at the touch is a wait the pipeline has already paid.
+        auto upkeep_request = [&](int i) __attribute__((always_inline)) {
+            if ((i & 7) == 6) {
+                const int32_t* nb = srec + (int64_t)((i >> 3) + 2) * 64 + lane;
+                asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
+            }
+        };
+        auto upkeep_touch = [&](int i) __attribute__((always_inline)) {
+            if ((i & 7) == 2 && i > 2) {
+                asm volatile("s_waitcnt vmcnt(12)" : "+v"(vnext) : : "memory");
+                // two selects, not "if (odd) vrec1 = vnext; else vrec0 = vnext;": the compiler merges the two stores of that form into one store
+                // through a selected POINTER, which pins vrec0 / vrec1 in scratch memory -- every step then reloads them behind vmcnt(0)
+                const bool odd = (((i >> 3) + 1) & 1) != 0;
+                vrec1 = odd ? vnext : vrec1;
+                vrec0 = odd ? vrec0 : vnext;
+            }
+        };
+        auto rotate = [&]() __attribute__((always_inline)) { fq0 = fq1; fq1 = fq2; fq2 = fq3; fq3 = fq4; fq4 = fq_new; };
+        const int n4 = n & ~3;
+        for (int i = 0; i < n4; i += 4) {
+            iteration_t(i, fq0, b1, a1, st0{});
+            rotate();
+            iteration_t(i + 1, fq0, b2, a2, st1{});
+            rotate();
+            upkeep_request(i + 2);
+            upkeep_touch(i + 2);
+            iteration_t(i + 2, fq0, b3, a3, st0{});
+            rotate();
+            iteration_t(i + 3, fq0, b0, a0, st1{});
+            rotate();
+        }
+        // the last n & 3 steps, peeled (see the fp32 kernel on why not a break inside the loop)
+        if (n & 3) {
+            iteration_t(n4, fq0, b1, a1, st0{});
+            rotate();
+            if ((n & 3) > 1) {
+                iteration_t(n4 + 1, fq0, b2, a2, st1{});
+                rotate();
+                if ((n & 3) > 2) {
+                    upkeep_touch(n4 + 2);
+                    iteration_t(n4 + 2, fq0, b3, a3, st0{});
+                }
+            }
+        }
+    }
+    clock_probe(p.clk, 2);
+#ifdef SPARTA_TIMELINE
+    if (p.clk != nullptr && blockIdx.y == 0 && tid == 0 && blockIdx.x < 1024) {
+        p.clk[16 + 4 * 64 * 8 + 2 * blockIdx.x] = tl_t0;
+        p.clk[16 + 4 * 64 * 8 + 2 * blockIdx.x + 1] = wall_clock64();
+    }
+#endif
+}
+
+#undef field
+
+// =====================================================================================================
+// 16-bit storage, operands straight from global memory into the MFMA registers: vbs_spmm_h16_direct_kernel<KP, MI2, BF16, GATHERED>
+// A 16-bit step has 64-256 cycles of MFMA per wave; in the LDS-staged kernel above what a step costs is its bookkeeping: the
+// register -> LDS -> register round trip, one workgroup barrier and the four waves waiting for each other (measured with the
+// in-kernel timeline: ~1300 cycles per step with every byte cache-hot).  The packed A slices (row-major, k contiguous) and a
+// column-major B (k contiguous) already ARE the per-lane operand layout of v_mfma_f32_32x32x16: lane (lm, g) needs 8 consecutive
+// k of row / column lm, one 16-byte load.  So here nothing is staged: every wave loads its own fragments (its 32 columns of B,
+// and the A slice, which the four waves of a workgroup share through the L1), keeps LOOK steps of them in flight in registers and
+// never synchronises with the other waves -- no LDS, no barrier.  Same plans, step records, accumulator layout, epilogue and
+// fix-up as the other stream kernels (a wave's accumulator image is identical, so the split-tile workspace is too).
+// =====================================================================================================
+template <int KP, bool MI2, bool BF16, bool GATHERED>
+__global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const StreamParams p) {
+    constexpr int TN = kTN, TM = MI2 ? 64 : 32;
+    constexpr int NK = KP / 16;                          // MFMAs (k groups of 16) per step and 32-row tile
+    constexpr int NA = MI2 ? 2 : 1;
+    constexpr int LOOK = 4;                              // register sets = steps in flight
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 31, g = lane >> 5;
+    const int n0 = blockIdx.y * TN;
+    const int s_begin = p.worker_range[2 * blockIdx.x];
+    const int n = p.worker_range[2 * blockIdx.x + 1] - s_begin;
+    if (n <= 0) return;
+    clock_probe(p.clk, 0);
+    float* ws = p.ws + (int64_t)blockIdx.y * p.ws_slab_stride;
+    const uint16_t* A16 = reinterpret_cast<const uint16_t*>(p.A);
+    const uint16_t* B16 = reinterpret_cast<const uint16_t*>(p.B);
+    const uint16_t* Bt16 = reinterpret_cast<const uint16_t*>(p.B_tail);
+
+    const int32_t* srec = reinterpret_cast<const int32_t*>(p.steps + s_begin);
+    int vrec0 = srec[lane];
+    int vrec1 = srec[64 + lane];
+    int vnext = 0;
+#define field(s, f) sk_field(vrec0, vrec1, (s), (f))
+    enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6, F_SHARD = 7 };
+
+    const int64_t ld_t = (int64_t)p.w;                   // leading dimension of B_tail
+    const uint32_t voffB = (uint32_t)(((32 * wave + lm) * p.ldb + 8 * g) * 2);
+    const uint32_t voffBt = (uint32_t)(((n0 + 32 * wave + lm) * ld_t + 8 * g) * 2);
+    const uint32_t voffA = (uint32_t)((lm * KP + 8 * g) * 2);
+    const int64_t n0off = (int64_t)n0 * p.ldb;
+    const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 32 * wave + 4 * g) * 4) : (uint32_t)((lm + (32 * wave + 4 * g) * p.ldc) * 4);
+
+    struct Set { u32x4 b[NK]; u32x4 a[NA][NK]; };
+    Set r0, r1, r2, r3;
+
+    int64_t g_aoff = 0;
+    uint32_t vo_cur = voffB;
+    int32_t tail_prev = 0;
+    auto issue_loads = [&](int s, Set& r) __attribute__((always_inline)) -> int32_t {
+        const int32_t flags = field(s, F_FLAGS);
+        if (flags & STEP_FIRST) g_aoff = (int64_t)(uint32_t)field(s, F_AOFF_LO) | ((int64_t)field(s, F_AOFF_HI) << 32);
+        else g_aoff += (int64_t)TM * KP;                 // the slices of a tile are back to back
+        const int32_t tail = (flags & STEP_TAIL) != 0;
+        if (tail != tail_prev) {
+            vo_cur = tail ? voffBt : voffB;
+            asm volatile("" : "+v"(vo_cur));
+            tail_prev = tail;
+        }
+        const int64_t gk0 = field(s, F_BROW);
+        const uint16_t* bptr = tail ? Bt16 + gk0 : B16 + (GATHERED ? (int64_t)field(s, F_SHARD) * p.shard_stride : (int64_t)0) + gk0 + n0off;
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(bptr), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < NK; q++) r.b[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, (uint32_t)(q * 32), 0);
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A16 + g_aoff), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int mi = 0; mi < NA; mi++)
+#pragma unroll
+            for (int q = 0; q < NK; q++) r.a[mi][q] = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA, (uint32_t)(mi * 32 * KP * 2 + q * 32), 0);
+        return flags;
+    };
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    auto mfma = [&](const u32x4& bf, const u32x4& af, f32x16& acc) __attribute__((always_inline)) {
+        if constexpr (BF16) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf), __builtin_bit_cast(bf16x8, af), acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf), __builtin_bit_cast(f16x8, af), acc, 0, 0, 0);
+    };
+
+    int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq3 = 0, fq_new = 0;
+    // one step: multiply from register set r (step i), run the tile epilogue if it ends here, refill r with step i + LOOK
+    auto iteration_t = [&](int i, int32_t flags, Set& r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NK; q++) {
+            mfma(r.b[q], r.a[0][q], acc0);
+            if constexpr (MI2) mfma(r.b[q], r.a[1][q], acc1);
+        }
+        if (flags & STEP_LAST) {
+            if (flags & STEP_SPLIT) {
+                const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_SLOT) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc0[q]), rW, (uint32_t)tid * 4u, (uint32_t)(q * kThreads * 4), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1[q]), rW, (uint32_t)tid * 4u, (uint32_t)((16 + q) * kThreads * 4), 0);
+                }
+            } else {
+                const int mt = flags & 0xffff;
+                const int64_t c_row = field(i, F_CROW);
+                float* cbase = p.c_row_major ? p.C + c_row * p.ldc + n0 : p.C + c_row + (int64_t)n0 * p.ldc;
+                const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
+                const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;
+                const uint32_t mistep = p.c_row_major ? (uint32_t)p.ldc * 128u : 128u;
+#pragma unroll
+                for (int mi = 0; mi < (MI2 ? 2 : 1); mi++) {
+                    if (mi * 32 + lm < mt) {
+                        float v[16];
+#pragma unroll
+                        for (int q = 0; q < 16; q++) v[q] = mi == 0 ? acc0[q] : acc1[q];
+                        if (p.accumulate) {
+                            uint32_t old[16];
+#pragma unroll
+                            for (int q = 0; q < 16; q++) old[q] = __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
+#pragma unroll
+                            for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 16; q++)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
+        }
+        fq_new = issue_loads(i + LOOK, r);
+    };
+
+    fq0 = issue_loads(0, r0);
+    fq1 = issue_loads(1, r1);
+    fq2 = issue_loads(2, r2);
+    fq3 = issue_loads(3, r3);
+    // Record batches (8 steps each; vrec0 / vrec1 hold batches k, k + 1): step 8k + 4 is the first to look into batch k + 1 (its
+    // refill is step 8k + 8).  Batch k + 1 is requested at step 8k and touched at step 8k + 4; the register it replaces (batch
+    // k - 1) is dead from step 8k on.  The four steps in between issue 4 x (>= 4) loads and memory returns in order: vmcnt(12)
+    // at the touch is a wait the pipeline pays anyway.
+    auto batch_upkeep = [&](int i) __attribute__((always_inline)) {
+        if ((i & 7) == 0 && i > 0) {
+            const int32_t* nb = srec + (int64_t)((i >> 3) + 1) * 64 + lane;
+            asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
+        }
+        if ((i & 7) == 4 && i > 4) {
+            asm volatile("s_waitcnt vmcnt(12)" : "+v"(vnext) : : "memory");
+            const bool odd = (((i >> 3) + 1) & 1) != 0;
+            vrec1 = odd ? vnext : vrec1;
+            vrec0 = odd ? vrec0 : vnext;
+        }
+    };
+    auto rotate = [&]() __attribute__((always_inline)) { fq0 = fq1; fq1 = fq2; fq2 = fq3; fq3 = fq_new; };
+    const int n4 = n & ~3;
+    for (int i = 0; i < n4; i += 4) {
+        batch_upkeep(i);
+        iteration_t(i, fq0, r0);
+        rotate();
+        iteration_t(i + 1, fq0, r1);
+        rotate();
+        iteration_t(i + 2, fq0, r2);
+        rotate();
+        iteration_t(i + 3, fq0, r3);
+        rotate();
+    }
+    if (n & 3) {                                         // the last n & 3 steps, peeled
+        batch_upkeep(n4);
+        iteration_t(n4, fq0, r0);
+        rotate();
+        if ((n & 3) > 1) {
+            iteration_t(n4 + 1, fq0, r1);
+            rotate();
+            if ((n & 3) > 2) iteration_t(n4 + 2, fq0, r2);
+        }
+    }
+    clock_probe(p.clk, 2);
+#undef field
+}
+
+// zero-padded copy of the rows of a 16-bit column-major B that face the last (partial) block column: B_tail[k + w j], k < w
+__global__ __launch_bounds__(kThreads) void vbs_tail_copy_h16_kernel(const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N,
+                                                                     uint16_t* B_tail) {
+    const int64_t total = (int64_t)w * N;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int64_t k = e % w, j = e / w;
+        B_tail[e] = (row0 + k < cols) ? B[row0 + k + j * ldb] : (uint16_t)0;
+    }
+}
+
+// fp32 -> fp16 / bf16 (round to nearest even), column by column: src ld_in, dst ld_out (host-pointer convenience path)
+template <bool BF16>
+__global__ __launch_bounds__(kThreads) void vbs_convert_h16_kernel(const float* src, int64_t ld_in, int64_t rows, int64_t n_cols, uint16_t* dst,
+                                                                   int64_t ld_out) {
+    const int64_t total = rows * n_cols;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        const int64_t k = e % rows, j = e / rows;
+        const float v = src[k + j * ld_in];
+        uint16_t o;
+        if constexpr (BF16) {
+            uint32_t u = __float_as_uint(v);
+            if ((u & 0x7fffffffu) > 0x7f800000u) o = (uint16_t)((u >> 16) | 0x40);          // NaN stays NaN
+            else o = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        } else {
+            const _Float16 h = (_Float16)v;
+            o = __builtin_bit_cast(uint16_t, h);
+        }
+        dst[k + j * ld_out] = o;
+    }
+}
+
+template <int KP, bool MI2, bool DEEP>
+void launch_h16_d(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (gathered) {
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, true, true, DEEP>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, false, true, DEEP>), grid, dim3(kThreads), 0, st, sp);
+    } else {
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, true, false, DEEP>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_stream_kernel<KP, MI2, false, false, DEEP>), grid, dim3(kThreads), 0, st, sp);
+    }
+}
+// SPARTA_H16_DEPTH=4 selects the four-register-set pipeline (loads 5 steps ahead); default: two sets, 3 steps ahead -- measured equal
+// within 1 % on every shape (scripts/h16_depth_ab.py): the 16-bit steps are not bound by the bytes in flight
+bool h16_deep() { const char* e = std::getenv("SPARTA_H16_DEPTH"); return e && atoi(e) == 4; }   // read per launch: scripts flip it between timings
+// Which 16-bit kernel: SPARTA_H16_PATH=lds | direct forces one; default (auto): operands straight into registers
+// (vbs_spmm_h16_direct_kernel) for 32-deep steps of one 32-row MFMA tile -- 36.4 vs 38.0 us on the flagship, bit-identical --
+// and the LDS-staged kernel for everything else (64-row tiles / 64-deep steps: the four waves would each fetch the whole A
+// slice and a wave-load would touch 64 cache lines: 57 vs 29 us).  Read per launch: scripts flip it between timings.
+bool h16_direct(int kp, bool mi2) {
+    const char* e = std::getenv("SPARTA_H16_PATH");
+    if (e && e[0] == 'l') return false;
+    if (e && e[0] == 'd') return true;
+    return kp == 32 && !mi2;
+}
+template <int KP, bool MI2>
+void launch_h16_direct(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (gathered) {
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, true, true>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, false, true>), grid, dim3(kThreads), 0, st, sp);
+    } else {
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, true, false>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, false, false>), grid, dim3(kThreads), 0, st, sp);
+    }
+}
+template <int KP, bool MI2>
+void launch_h16(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (h16_direct(KP, MI2)) { launch_h16_direct<KP, MI2>(bf16, gathered, grid, st, sp); return; }
+    if (h16_deep()) launch_h16_d<KP, MI2, true>(bf16, gathered, grid, st, sp);
+    else launch_h16_d<KP, MI2, false>(bf16, gathered, grid, st, sp);
+}
+
+}  // namespace
+
+namespace sparta_dev {
+
+bool h16_uses_direct_kernel(int kp, bool mi2) { return h16_direct(kp, mi2); }
+
+void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (kp == 64) { if (mi2) launch_h16<64, true>(bf16, gathered, grid, st, sp); else launch_h16<64, false>(bf16, gathered, grid, st, sp); }
+    else { if (mi2) launch_h16<32, true>(bf16, gathered, grid, st, sp); else launch_h16<32, false>(bf16, gathered, grid, st, sp); }
+}
+
+void launch_tail_copy_h16(hipStream_t st, const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N, uint16_t* B_tail) {
+    hipLaunchKernelGGL(vbs_tail_copy_h16_kernel, dim3(32), dim3(kThreads), 0, st, B, ldb, row0, cols, w, N, B_tail);
+}
+
+void launch_convert_h16(bool bf16, hipStream_t st, const float* src, int64_t ld_in, int64_t rows, int64_t n_cols, uint16_t* dst, int64_t ld_out) {
+    if (bf16) hipLaunchKernelGGL((vbs_convert_h16_kernel<true>), dim3(1024), dim3(kThreads), 0, st, src, ld_in, rows, n_cols, dst, ld_out);
+    else hipLaunchKernelGGL((vbs_convert_h16_kernel<false>), dim3(1024), dim3(kThreads), 0, st, src, ld_in, rows, n_cols, dst, ld_out);
+}
+
+}  // namespace sparta_dev

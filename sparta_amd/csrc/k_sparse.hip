@@ -1,0 +1,277 @@
+// k_sparse.hip -- the HBM-bound leg of the path: sparse-row kernels for nearly empty block-rows ("wavefront-level partial sums
+// for thin / ragged blocks"), the layout transposes they need for the reference's column-major B / C, and the row-block pack of
+// the multi-GPU exchange.  Part of the device side of libsparta_amd.so; see vbs_device.hpp and DESIGN.md section 3.2 (4).
+#include "vbs_kernel_common.hpp"
+
+using namespace sparta_dev;
+
+namespace {
+
+// ---- sparse-row path: block-rows whose blocks are almost empty -----------------------------------------------------
+// A block-row of a clustered power-law matrix is typically 1-4 rows tall with 1-2 nonzeros per w-wide block: as a dense
+// tile it executes 32 x w x N multiply-adds and streams a w x N panel of B for a handful of useful products (measured on
+// R-MAT 2^20, fill 2 %: 4 TFLOP/s "executed", 0.09 TFLOP/s useful).  Such block-rows are taken out of the MFMA plans at
+// create time and kept as rows of (column, value) pairs -- the nonzeros of their blocks in the reference's order (blocks
+// ascending, k ascending) -- and multiplied the way the bytes want it: one wave per row, lanes across the columns of C, per
+// nonzero ONE contiguous N-float row of B (row-major; a column-major or gathered B is transposed once per call: 2 x |B|
+// bytes) and one FMA per element.  HBM/L2-bound: N * 4 bytes per nonzero.  This is the "wavefront-level partial sums for
+// thin / ragged blocks" leg of the path; exact zeros of A are skipped (0 * inf of the reference's dense loop is not
+// reproduced: finite B is the contract, as for its padded columns).
+#ifndef SP_BATCH
+#define SP_BATCH 16     /* rows of B a wave keeps in flight (measured 8 -> 16: +1..10 %) */
+#endif
+template <int VEC> struct SpVec;
+template <> struct SpVec<1> { typedef float T; };
+template <> struct SpVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct SpVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
+
+template <int VEC> struct SpRaw16;        // VEC 16-bit values as loaded
+template <> struct SpRaw16<1> { typedef unsigned short T; };
+template <> struct SpRaw16<2> { typedef unsigned short T __attribute__((ext_vector_type(2))); };
+template <> struct SpRaw16<4> { typedef unsigned short T __attribute__((ext_vector_type(4))); };
+
+__device__ __forceinline__ float sp_widen(unsigned short u, bool bf16) {
+    return bf16 ? __builtin_bit_cast(float, (uint32_t)u << 16) : (float)__builtin_bit_cast(_Float16, u);
+}
+
+template <int VEC, int BK>
+__device__ __forceinline__ typename SpVec<VEC>::T sparse_row_partial(const SparseParams& p, int64_t p0, int64_t p1, int n0, int lane) {
+    typedef typename SpVec<VEC>::T V;
+    typedef typename std::conditional<BK == 0, float, unsigned short>::type E;
+    typedef typename std::conditional<BK == 0, V, typename SpRaw16<VEC>::T>::type L;
+    V acc = (V)(0.0f);
+    const bool in = VEC > 1 || n0 < p.N;
+    const E* Bl = (const E*)p.B + (in ? n0 : 0);
+    for (int64_t q = p0; q < p1; q += SP_BATCH) {
+        const int n = (int)(p1 - q < SP_BATCH ? p1 - q : SP_BATCH);            // wave-uniform
+        int cl = 0;
+        float vl = 0.0f;
+        if (lane < n) { cl = p.col[q + lane]; vl = p.val[q + lane]; }
+        L b[SP_BATCH];
+        if (VEC == 1 && p.b_col_stride > 0) {                    // column-major B in place (few sparse rows: cheaper than transposing all of B)
+            const E* Bc = (const E*)p.B + (in ? (int64_t)n0 * p.b_col_stride : 0);
+#pragma unroll
+            for (int t = 0; t < SP_BATCH; t++) {
+                const int64_t c = __builtin_amdgcn_readlane(cl, t);
+                const int64_t off = p.shard_rows > 0 ? (c / p.shard_rows) * p.shard_stride + c % p.shard_rows : c;
+                b[t] = *reinterpret_cast<const L*>(Bc + off);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < SP_BATCH; t++) {
+                const int c = __builtin_amdgcn_readlane(cl, t);  // lanes >= n hold column 0: a valid row, never used
+                b[t] = *reinterpret_cast<const L*>(Bl + (int64_t)c * p.ldb);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < SP_BATCH; t++) {
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vl), t));
+            if (t < n) {
+                if constexpr (BK == 0) acc += v * b[t];
+                else if constexpr (VEC == 1) acc += v * sp_widen(b[t], BK == 2);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VEC; e++) acc[e] += v * sp_widen(b[t][e], BK == 2);
+                }
+            }
+        }
+    }
+    return acc;
+}
+
+template <int VEC>
+__device__ __forceinline__ void sparse_row_store(const SparseParams& p, int ord, typename SpVec<VEC>::T acc, int n0) {
+    typedef typename SpVec<VEC>::T V;
+    if (VEC == 1 && n0 >= p.N) return;
+    float* o = p.out + (int64_t)(p.out_is_c ? p.crow[ord] : ord) * p.ldo + n0;
+    if (p.out_is_c && p.accumulate) acc += *reinterpret_cast<const V*>(o);
+    *reinterpret_cast<V*>(o) = acc;
+}
+
+// rows of ordinary length: one wave per row, 4 rows per workgroup; blockIdx.y walks N in chunks of 64 * VEC columns
+template <int VEC, int BK>
+__global__ __launch_bounds__(kThreads) void sparse_rows_kernel(SparseParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= p.n_list) return;
+    const int ord = p.list[slot];
+    const int n0 = (blockIdx.y * 64 + lane) * VEC;
+    const int64_t p0 = p.rowptr[ord], p1 = p.rowptr[ord + 1];
+    sparse_row_store<VEC>(p, ord, sparse_row_partial<VEC, BK>(p, p0, p1, n0, lane), n0);
+}
+
+// long rows (hubs): cut into segments of <= kSpSeg nonzeros, one wave per segment writes a partial row; a second launch adds
+// the partial rows of every long row in segment order (deterministic) and stores the row
+
+template <int VEC, int BK>
+__global__ __launch_bounds__(kThreads) void sparse_segments_kernel(SparseParams p, const SpSegRec* segs, int32_t n_segs, float* part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= n_segs) return;
+    const SpSegRec sg = segs[slot];
+    const int n0 = (blockIdx.y * 64 + lane) * VEC;
+    typename SpVec<VEC>::T acc = sparse_row_partial<VEC, BK>(p, sg.p0, sg.p0 + sg.cnt, n0, lane);
+    if (VEC == 1 && n0 >= p.N) return;
+    *reinterpret_cast<typename SpVec<VEC>::T*>(part + (int64_t)slot * p.N + n0) = acc;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void sparse_reduce_kernel(SparseParams p, const SpLongRec* rows, int32_t n_rows, const float* part) {
+    typedef typename SpVec<VEC>::T V;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= n_rows) return;
+    const SpLongRec r = rows[slot];
+    const int n0 = (blockIdx.y * 64 + lane) * VEC;
+    if (VEC == 1 && n0 >= p.N) return;
+    V acc = (V)(0.0f);
+    for (int sgi = 0; sgi < r.n_seg; sgi++) acc += *reinterpret_cast<const V*>(part + (int64_t)(r.seg_begin + sgi) * p.N + n0);
+    sparse_row_store<VEC>(p, r.ord, acc, n0);
+}
+
+// B (column-major, ld = ldb, or the gathered slabs) -> row-major rows x N (ld = N); 64 x 64 tiles through LDS: a wave reads 64
+// consecutive rows of one column (256 contiguous bytes) and writes 64 consecutive columns of one row (256 contiguous bytes)
+template <class E>
+__global__ __launch_bounds__(kThreads) void b_to_row_major_kernel(const E* __restrict__ B, int64_t ldb, int64_t shard_rows, int64_t shard_stride,
+                                                                  int64_t rows, int N, E* __restrict__ out) {
+    __shared__ E tile[64][65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // 1-D grid, column tile fastest: the workgroups that run together complete whole rows of the row-major copy (and read the same
+    // 64 rows of every column tile) instead of each touching one 128 / 256-byte piece of 64 rows that the next piece follows much later
+    const int n_ct = (N + 63) / 64;
+    const int64_t r0 = (int64_t)(blockIdx.x / n_ct) * 64;
+    const int n0 = (int)(blockIdx.x % n_ct) * 64;
+    const int64_t r = r0 + lane;
+    // All 16 loads of a lane are issued before the first one is used: addresses are clamped into the matrix instead of guarded (a
+    // guarded load in a rolled loop was one load in flight per wave - 2.5 TB/s whatever the access pattern), the guard is applied
+    // to the value.
+    const int64_t rc = r < rows ? r : rows - 1;
+    const int64_t roff = shard_rows > 0 ? (rc / shard_rows) * shard_stride + (rc % shard_rows) : rc;   // shard_rows % 64 need not hold: per lane
+    E v[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {                               // read: lanes along the rows (contiguous in a column)
+        const int n = n0 + wave + 4 * q;
+        v[q] = B[roff + (int64_t)(n < N ? n : N - 1) * ldb];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) tile[wave + 4 * q][lane] = (r < rows && n0 + wave + 4 * q < N) ? v[q] : (E)0;
+    __syncthreads();
+    const int n = n0 + lane;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {                               // write: lanes along the columns (contiguous in a row)
+        const int j = wave + 4 * q;
+        const int64_t rr = r0 + j;
+        if (rr < rows && n < N) out[rr * N + n] = tile[lane][j];
+    }
+}
+
+// scratch (row-major, one row per sparse row) -> the column-major C rows they belong to
+__global__ __launch_bounds__(kThreads) void sparse_c_scatter_kernel(const float* __restrict__ src, const int32_t* __restrict__ crow, int64_t n_rows, int N,
+                                                                    float* __restrict__ C, int64_t ldc, int accumulate) {
+    __shared__ float tile[64][65];                               // 64 sparse rows x 64 columns
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_ct = (N + 63) / 64;                              // 1-D grid, column tile fastest (see b_to_row_major_kernel)
+    const int64_t t0 = (int64_t)(blockIdx.x / n_ct) * 64;
+    const int n0 = (int)(blockIdx.x % n_ct) * 64;
+    const int64_t t = t0 + lane;
+    const int32_t r = crow[t < n_rows ? t : n_rows - 1];         // consecutive sparse rows are mostly consecutive rows of C (requested with the tile's loads)
+    {
+        const int n = n0 + lane;
+        const int nc = n < N ? n : N - 1;
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {                           // read: lanes along the columns of one scratch row; 16 loads in flight (clamped, not guarded)
+            const int64_t t = t0 + wave + 4 * q;
+            v[q] = src[(t < n_rows ? t : n_rows - 1) * N + nc];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) tile[wave + 4 * q][lane] = (t0 + wave + 4 * q < n_rows && n < N) ? v[q] : 0.0f;
+    }
+    __syncthreads();
+    if (t >= n_rows) return;
+    if (accumulate) {
+        float old[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int n = n0 + wave + 4 * q;
+            old[q] = C[r + (int64_t)(n < N ? n : N - 1) * ldc];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int n = n0 + wave + 4 * q;
+            if (n < N) C[r + (int64_t)n * ldc] = old[q] + tile[lane][wave + 4 * q];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {                           // write: lanes along the rows of one column of C
+            const int n = n0 + wave + 4 * q;
+            if (n < N) C[r + (int64_t)n * ldc] = tile[lane][wave + 4 * q];
+        }
+    }
+}
+
+// ---- row-block pack (multi-GPU exchange of only the needed rows of B) ---------------------------------
+// dst chunk i <- src chunk ids[i]; a chunk is one w x N tile of B (block_bytes, a multiple of 16).  One workgroup per
+// chunk and grid.y slice; 16-byte loads / stores, fully coalesced: HBM-bound, bytes = 2 x n_blocks x block_bytes.
+__global__ __launch_bounds__(kThreads) void pack_blocks_kernel(const u32x4* __restrict__ src, const int32_t* __restrict__ ids,
+                                                               u32x4* __restrict__ dst, int64_t block_vec) {
+    const int64_t from = (int64_t)ids[blockIdx.x] * block_vec, to = (int64_t)blockIdx.x * block_vec;
+    const int64_t stride = (int64_t)gridDim.y * kThreads;
+    // four loads of a thread in flight (clamped addresses, guarded stores): the pack is the head of the exchange's critical path and a
+    // 16 KB tile is four rounds of the workgroup - one round at a time is four memory latencies in a row
+    for (int64_t i = (int64_t)blockIdx.y * kThreads + threadIdx.x; i < block_vec; i += 4 * stride) {
+        u32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = __builtin_nontemporal_load(src + from + std::min<int64_t>(i + q * stride, block_vec - 1));
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (i + q * stride < block_vec) dst[to + i + q * stride] = v[q];
+    }
+}
+
+}  // namespace
+
+namespace sparta_dev {
+
+namespace {
+template <int VEC, int BK>
+void launch_sparse_t(SparseParams q, unsigned gy, hipStream_t st, const int32_t* list, int64_t n_short, const SpSegRec* segs, int64_t n_segs,
+                     const SpLongRec* longs, int64_t n_long, float* part) {
+    if (n_short > 0) {
+        q.list = list; q.n_list = (int32_t)n_short;
+        hipLaunchKernelGGL((sparse_rows_kernel<VEC, BK>), dim3((unsigned)((n_short + 3) / 4), gy), dim3(kThreads), 0, st, q);
+    }
+    if (n_long > 0) {
+        hipLaunchKernelGGL((sparse_segments_kernel<VEC, BK>), dim3((unsigned)((n_segs + 3) / 4), gy), dim3(kThreads), 0, st, q, segs, (int32_t)n_segs, part);
+        hipLaunchKernelGGL(sparse_reduce_kernel<VEC>, dim3((unsigned)((n_long + 3) / 4), gy), dim3(kThreads), 0, st, q, longs, (int32_t)n_long, (const float*)part);
+    }
+}
+}  // namespace
+
+void launch_sparse_kernels(int vec, int bk, const SparseParams& q, unsigned gy, hipStream_t st, const int32_t* list, int64_t n_short, const SpSegRec* segs,
+                           int64_t n_segs, const SpLongRec* longs, int64_t n_long, float* part) {
+#define SPARTA_SP_DISPATCH(V_)                                                                                         \
+    do {                                                                                                               \
+        if (bk == 0) launch_sparse_t<V_, 0>(q, gy, st, list, n_short, segs, n_segs, longs, n_long, part);              \
+        else if (bk == 1) launch_sparse_t<V_, 1>(q, gy, st, list, n_short, segs, n_segs, longs, n_long, part);         \
+        else launch_sparse_t<V_, 2>(q, gy, st, list, n_short, segs, n_segs, longs, n_long, part);                      \
+    } while (0)
+    if (vec == 4) SPARTA_SP_DISPATCH(4); else if (vec == 2) SPARTA_SP_DISPATCH(2); else SPARTA_SP_DISPATCH(1);
+#undef SPARTA_SP_DISPATCH
+}
+
+void launch_b_to_row_major(bool is16, unsigned grid, hipStream_t st, const void* B, int64_t ldb, int64_t shard_rows, int64_t shard_stride, int64_t rows, int N,
+                           void* out) {
+    if (!is16) hipLaunchKernelGGL(b_to_row_major_kernel<float>, dim3(grid), dim3(kThreads), 0, st, (const float*)B, ldb, shard_rows, shard_stride, rows, N, (float*)out);
+    else hipLaunchKernelGGL(b_to_row_major_kernel<unsigned short>, dim3(grid), dim3(kThreads), 0, st, (const unsigned short*)B, ldb, shard_rows, shard_stride, rows, N, (unsigned short*)out);
+}
+
+void launch_c_scatter(unsigned grid, hipStream_t st, const float* src, const int32_t* crow, int64_t n_rows, int N, float* C, int64_t ldc, int accumulate) {
+    hipLaunchKernelGGL(sparse_c_scatter_kernel, dim3(grid), dim3(kThreads), 0, st, src, crow, n_rows, N, C, ldc, accumulate);
+}
+
+void launch_pack_blocks(dim3 grid, hipStream_t st, const void* src, const int32_t* ids, void* dst, int64_t block_vec) {
+    hipLaunchKernelGGL(pack_blocks_kernel, grid, dim3(kThreads), 0, st, (const u32x4*)src, ids, (u32x4*)dst, block_vec);
+}
+
+}  // namespace sparta_dev

@@ -1,0 +1,1027 @@
+// vbs_capi.cpp -- the device image of a VBS matrix (sparta_vbs) and the C-ABI entry points that create, multiply and destroy
+// it: sparta_vbs_create* / sparta_vbs_spmm* / sparta_pack_blocks (include/sparta_amd.h).  Host code only: kernels live in the
+// k_*.hip translation units and are reached through the launch functions of vbs_device.hpp.
+//
+// What it replaces in the reference: the CPU triple loop VBR::multiply (src/general/vbr.cpp:323-372)
+// and the "one library GEMM per nonzero block" GPU back-ends (src/cuda/cuda_utilities.cpp:39-887,
+// src/cuda/cutlass_bellpack_lib.cu:380-1019).  Not a translation of either: there is ONE fused kernel
+// family, no vendor BLAS/SPARSE call, no per-block launch.
+//
+#include <memory>
+
+#include "vbs_device.hpp"
+
+using namespace sparta_dev;
+
+// No exception leaves this file: the plan builder and the image builders grow large std::vectors (step lists, packed 16-bit A,
+// sparse rows), so std::bad_alloc is a real outcome on 10^8..10^9-nonzero inputs and must come back as a status code.
+#define SPARTA_GUARD_BEGIN try {
+#define SPARTA_GUARD_END(name_)                                                                                       \
+    }                                                                                                                  \
+    catch (const std::bad_alloc&) { return sparta::fail(SPARTA_ERR_ALLOC, std::string(name_) + ": out of host memory"); } \
+    catch (const std::exception& e) { return sparta::fail(SPARTA_ERR_INVALID, std::string(name_) + ": " + e.what()); }  \
+    catch (...) { return sparta::fail(SPARTA_ERR_INVALID, std::string(name_) + ": unknown C++ exception"); }
+
+namespace {
+
+bool force_generic() { const char* e = std::getenv("SPARTA_FORCE_GENERIC"); return e && e[0] == '1'; }
+
+int ensure_scratch(void** ptr, size_t* have, size_t need) {
+    if (*have >= need) return SPARTA_OK;
+    if (*ptr) { (void)hipFree(*ptr); *ptr = nullptr; *have = 0; }
+    HIP_TRY(hipMalloc(ptr, need));
+    *have = need;
+    return SPARTA_OK;
+}
+
+void destroy_impl(sparta_vbs* v) {
+    if (!v) return;
+    DeviceGuard g(v->device);
+    if (v->d_A) (void)hipFree(v->d_A);
+    if (v->d_jab) (void)hipFree(v->d_jab);
+    for (int c = 0; c < 4; c++)
+        if (v->d_tiles[c]) (void)hipFree(v->d_tiles[c]);
+    if (v->d_brows) (void)hipFree(v->d_brows);
+    for (int ty = 0; ty < 2; ty++) {
+        if (v->d_steps[ty]) (void)hipFree(v->d_steps[ty]);
+        if (v->d_steps_g[ty]) (void)hipFree(v->d_steps_g[ty]);
+        if (v->d_wrange[ty]) (void)hipFree(v->d_wrange[ty]);
+    }
+    if (v->d_fix) (void)hipFree(v->d_fix);
+    if (v->d_fix_slots) (void)hipFree(v->d_fix_slots);
+    if (v->d_big_fix) (void)hipFree(v->d_big_fix);
+    if (v->d_ws) (void)hipFree(v->d_ws);
+    if (v->d_btail) (void)hipFree(v->d_btail);
+    if (v->d_tune) (void)hipFree(v->d_tune);
+    if (v->d_B16) (void)hipFree(v->d_B16);
+    if (v->d_clk) (void)hipFree(v->d_clk);
+    if (v->tev0) (void)hipEventDestroy(v->tev0);
+    if (v->tev1) (void)hipEventDestroy(v->tev1);
+    if (v->d_sp_rowptr) (void)hipFree(v->d_sp_rowptr);
+    if (v->d_sp_col) (void)hipFree(v->d_sp_col);
+    if (v->d_sp_val) (void)hipFree(v->d_sp_val);
+    if (v->d_sp_crow) (void)hipFree(v->d_sp_crow);
+    if (v->d_sp_list) (void)hipFree(v->d_sp_list);
+    if (v->d_sp_segs) (void)hipFree(v->d_sp_segs);
+    if (v->d_sp_long) (void)hipFree(v->d_sp_long);
+    if (v->d_sp_part) (void)hipFree(v->d_sp_part);
+    if (v->d_Brm) (void)hipFree(v->d_Brm);
+    if (v->d_spC) (void)hipFree(v->d_spC);
+    if (v->d_B) (void)hipFree(v->d_B);
+    if (v->d_C) (void)hipFree(v->d_C);
+    if (v->ev0) (void)hipEventDestroy(v->ev0);
+    if (v->ev1) (void)hipEventDestroy(v->ev1);
+    for (int c = 0; c < 4; c++)
+        for (int e = 0; e < 2; e++)
+            if (v->cev[c][e]) (void)hipEventDestroy(v->cev[c][e]);
+    delete v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sparta_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// `ext` (sparta_vbs_create_from_csr): the sparse-row part of the matrix decided and collected by the hybrid host builder --
+// those block-rows have nzcount = 0 in the arrays given here and must get neither tiles nor zero-fill records.
+static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
+                       const int64_t* nzcount, const int64_t* jab, const float* mab, int64_t br0, int64_t br1, int32_t dtype,
+                       int32_t device, const sparta::HybridSparse* ext) {
+    using sparta::fail;
+    if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: out is NULL");
+    *out = nullptr;
+    if (rows <= 0 || cols <= 0 || block_rows <= 0 || w <= 0 || !row_part || !nzcount)
+        return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad dimensions or NULL index array");
+    if (br0 < 0 || br1 > block_rows || br0 >= br1) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad block-row range");
+    if (dtype != SPARTA_F32 && dtype != SPARTA_F16 && dtype != SPARTA_BF16) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad dtype");
+    const bool h16 = dtype != SPARTA_F32;
+    if (h16 && w % 32 != 0)
+        return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: SPARTA_F16 / SPARTA_BF16 need block_col_size % 32 == 0 (only the stream kernels have a 16-bit form)");
+    if (rows > INT32_MAX || w > (1 << 20)) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: rows >= 2^31 or w > 2^20");
+    const int64_t block_cols = (cols - 1) / w + 1;
+
+    // validate the partition and locate the range inside jab / mab
+    if (row_part[0] != 0 || row_part[block_rows] != rows) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: row_part must span [0, rows]");
+    int64_t jab_lo = 0, mab_lo = 0, jab_hi = 0, mab_hi = 0, jo = 0, mo = 0;
+    for (int64_t ib = 0; ib < block_rows; ib++) {
+        const int64_t h = row_part[ib + 1] - row_part[ib];
+        if (h < 0 || nzcount[ib] < 0 || nzcount[ib] > block_cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: invalid row_part / nzcount");
+        if (h > INT32_MAX / 2 || nzcount[ib] > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: block-row too large");
+        if (ib == br0) { jab_lo = jo; mab_lo = mo; }
+        jo += nzcount[ib];
+        mo += nzcount[ib] * h * w;
+        if (ib == br1 - 1) { jab_hi = jo; mab_hi = mo; }
+    }
+    const int64_t nblocks = jab_hi - jab_lo, nztot = mab_hi - mab_lo;
+    if (nblocks > 0 && (!jab || !mab)) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: jab / mab is NULL");
+
+    int ndev = sparta_device_count();
+    if (ndev <= 0) return fail(SPARTA_ERR_NO_DEVICE, "sparta_vbs_create: no HIP device visible (this path has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: device index out of range");
+
+    // ---- sparse-row path: which block-rows are better served as rows of (column, value) --------------------------------
+    // An MFMA step (one <=32-row tile x 32 k x 128 columns) takes the time of ~12 nonzeros on the sparse-row path (2.1 ns per
+    // step across the 512 workers vs 512 B of B per nonzero and 128-column slab at ~3 TB/s): a block-row whose blocks hold
+    // fewer than SPARTA_SPARSE_K (default 24) nonzeros per step goes there (measured break-even, scripts/sparse_k_sweep.py:
+    // ~60 nonzeros per step while B fits the L2s, ~15 when its rows come from HBM).  SPARTA_SPARSE_K=0 switches the path off.
+    std::vector<uint8_t> sparse_flag;
+    std::vector<int64_t> sp_rowptr;
+    std::vector<int32_t> sp_col, sp_crow, sp_list;
+    std::vector<float> sp_val;
+    std::vector<SpSegRec> sp_segs;
+    std::vector<SpLongRec> sp_long;
+    // a wave keeps SP_BATCH (16) rows of B in flight: a row of n nonzeros takes ~n / 16 memory latencies whatever else the GPU is doing, so rows
+    // longer than kSpLong are cut into kSpSeg-nonzero segments that run on different waves (SPARTA_SPARSE_SEG overrides kSpSeg)
+    // The segment length follows the size of the sparse part (decided below, once it is known): short segments keep a small
+    // problem parallel (R-MAT 2^16: 128 -> 148 us, 512 -> 187 us), long ones save partial rows on a large one (2^20: 3.99 vs 3.75 ms).
+    int64_t kSpSeg = 0;
+    if (const char* e = std::getenv("SPARTA_SPARSE_SEG")) kSpSeg = std::max(8, atoi(e));
+    int64_t n_sp_short = 0, n_sp_long = 0;
+    // 16-bit handles: the values the kernels multiply are the ROUNDED ones (a value that rounds to zero is a zero)
+    const bool bf16h = dtype == SPARTA_BF16;
+    auto stored = [&](float x) -> float {
+        if (!h16) return x;
+        const uint16_t u = to_h16(x, bf16h);
+        if (bf16h) { const uint32_t v32 = (uint32_t)u << 16; float f; std::memcpy(&f, &v32, 4); return f; }
+        _Float16 hh; std::memcpy(&hh, &u, 2); return (float)hh;
+    };
+    if (ext) {
+        sparse_flag = ext->flag;
+        bool any = false;
+        for (uint8_t f : sparse_flag) any = any || f;
+        if (!any) sparse_flag.clear();
+        sp_rowptr.assign(1, 0);
+        for (size_t t = 0; t < ext->crow.size(); t++) {
+            for (int64_t k = ext->rowptr[t]; k < ext->rowptr[t + 1]; k++) {
+                const float a = stored(ext->val[(size_t)k]);
+                if (a != 0.0f && ext->col[(size_t)k] < cols) { sp_col.push_back(ext->col[(size_t)k]); sp_val.push_back(a); }
+            }
+            sp_crow.push_back(ext->crow[t]);
+            sp_rowptr.push_back((int64_t)sp_col.size());
+        }
+    } else {
+        double K = 24.0;
+        if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
+        if (K > 0.0) {
+            sparse_flag.assign((size_t)(br1 - br0), 0);
+            int64_t jo2 = 0, mo2 = 0, n_flagged = 0;
+            const int64_t row0 = row_part[br0];
+            std::vector<int64_t> cnt;
+            sp_rowptr.push_back(0);
+            for (int64_t ib = br0; ib < br1; ib++) {
+                const int64_t h = row_part[ib + 1] - row_part[ib], nb = nzcount[ib];
+                const float* blk = mab + mab_lo + mo2;
+                const int64_t n_el = nb * h * w;
+                int64_t nnz = 0;
+                for (int64_t q = 0; q < n_el; q++) nnz += stored(blk[q]) != 0.0f;
+                const int64_t kdep = h16 && w % 64 == 0 ? 64 : 32;                     // k depth of a step of the kernels this handle would use
+                const double steps_br = (double)nb * (double)((w + kdep - 1) / kdep) * (double)((h + 31) / 32);
+                if (h > 0 && nb > 0 && (double)nnz < K * steps_br && (int64_t)sp_col.size() + nnz < ((int64_t)1 << 40)) {
+                    sparse_flag[(size_t)(ib - br0)] = 1;
+                    n_flagged++;
+                    // rows of this block-row: (column, value) in the reference's order (blocks ascending, k ascending: vbr.cpp:358-363)
+                    cnt.assign((size_t)h, 0);
+                    for (int64_t b = 0; b < nb; b++)
+                        for (int64_t k = 0; k < w; k++)
+                            for (int64_t i = 0; i < h; i++) cnt[(size_t)i] += (stored(blk[(b * w + k) * h + i]) != 0.0f) && jab[jab_lo + jo2 + b] * w + k < cols;
+                    const size_t base_row = sp_crow.size();
+                    for (int64_t i = 0; i < h; i++) {
+                        sp_crow.push_back((int32_t)(row_part[ib] - row0 + i));
+                        sp_rowptr.push_back(sp_rowptr.back() + cnt[(size_t)i]);
+                    }
+                    sp_col.resize((size_t)sp_rowptr.back());
+                    sp_val.resize((size_t)sp_rowptr.back());
+                    for (int64_t i = 0; i < h; i++) cnt[(size_t)i] = sp_rowptr[base_row + (size_t)i];
+                    for (int64_t b = 0; b < nb; b++) {
+                        const int64_t c0 = jab[jab_lo + jo2 + b] * w;
+                        for (int64_t k = 0; k < w && c0 + k < cols; k++)
+                            for (int64_t i = 0; i < h; i++) {
+                                const float a = stored(blk[(b * w + k) * h + i]);
+                                if (a != 0.0f) { sp_col[(size_t)cnt[(size_t)i]] = (int32_t)(c0 + k); sp_val[(size_t)cnt[(size_t)i]++] = a; }
+                            }
+                    }
+                }
+                jo2 += nb;
+                mo2 += n_el;
+            }
+            if (n_flagged == 0) sparse_flag.clear();
+        }
+    }
+    // short rows: one wave each; rows with more than kSpLong nonzeros (hubs): segments of kSpSeg, one wave each + a reduction
+    if (kSpSeg == 0) {
+        const int64_t total = sp_rowptr.empty() ? 0 : sp_rowptr.back();
+        kSpSeg = total < ((int64_t)4 << 20) ? 128 : (total < ((int64_t)16 << 20) ? 256 : 512);
+    }
+    const int64_t kSpLong = 2 * kSpSeg;
+    for (size_t t = 0; t < sp_crow.size(); t++) {
+        const int64_t p0 = sp_rowptr[t], n = sp_rowptr[t + 1] - p0;
+        if (n <= kSpLong) { sp_list.push_back((int32_t)t); continue; }
+        SpLongRec lr{(int32_t)t, (int32_t)sp_segs.size(), 0, 0};
+        for (int64_t o = 0; o < n; o += kSpSeg) { sp_segs.push_back(SpSegRec{p0 + o, (int32_t)std::min<int64_t>(kSpSeg, n - o), 0}); lr.n_seg++; }
+        sp_long.push_back(lr);
+    }
+    n_sp_short = (int64_t)sp_list.size(); n_sp_long = (int64_t)sp_long.size();
+    const uint8_t* skip = sparse_flag.empty() ? nullptr : sparse_flag.data();
+
+    // ---- plan: row tiles per class -----------------------------------------------------------------
+    std::vector<TileDesc> tiles[4];
+    std::vector<BlockRowDesc> brows;
+    std::vector<int32_t> jab32((size_t)std::max<int64_t>(nblocks, 1));
+    for (int64_t q = 0; q < nblocks; q++) {
+        const int64_t jb = jab[jab_lo + q];
+        if (jb < 0 || jb >= block_cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: jab entry out of range");
+        jab32[(size_t)q] = (int32_t)jb;
+    }
+    int64_t exec_area = 0;
+    {
+        int64_t jo2 = 0, mo2 = 0;
+        const int64_t row0 = row_part[br0];
+        for (int64_t ib = br0; ib < br1; ib++) {
+            const int64_t h = row_part[ib + 1] - row_part[ib];
+            const int64_t nb = nzcount[ib];
+            if (h > 0) {
+                BlockRowDesc br{mo2, jo2, (int32_t)nb, (int32_t)h, (int32_t)(row_part[ib] - row0), 0};
+                brows.push_back(br);
+                int64_t r0 = skip && skip[ib - br0] ? h : 0;     // sparse-row block-rows get no tiles
+                while (r0 < h) {
+                    const int64_t rem = h - r0;
+                    int cls;
+                    int64_t mt;
+                    if (rem > 32) { cls = 2; mt = std::min<int64_t>(rem, 64); }
+                    else if (rem > 16) { cls = 1; mt = rem; }
+                    else { cls = 0; mt = rem; }
+                    const bool tail = (cols % w != 0) && nb > 0 && jab[jab_lo + jo2 + nb - 1] == block_cols - 1;
+                    TileDesc t{mo2 + r0, jo2, (int32_t)nb, (int32_t)h, (int32_t)(row_part[ib] - row0 + r0),
+                               (int32_t)mt | (tail ? TILE_TAIL : 0)};
+                    tiles[cls].push_back(t);
+                    const int64_t padded = cls == 0 ? 16 : ((mt + 31) / 32) * 32;
+                    exec_area += padded * w * nb;
+                    r0 += mt;
+                }
+            }
+            jo2 += nb;
+            mo2 += nb * h * w;
+        }
+    }
+
+    // ---- schedule: per class, 8 contiguous chunks of ~equal cost (one per XCD: neighbouring block-rows gather the
+    // same B panels, so they should share an L2), each chunk sorted by descending cost (the hardware hands workgroups
+    // to free slots in blockIdx order => longest-processing-time-first per XCD), interleaved so that entry t is XCD
+    // t % 8's (t / 8)-th item; short chunks are padded with empty tiles (nb = 0, mt = 0: nothing loaded or stored).
+    int64_t n_real[4];
+    for (int c = 0; c < 4; c++) n_real[c] = (int64_t)tiles[c].size();
+    {
+        const char* ord = std::getenv("SPARTA_TILE_ORDER");
+        const bool natural = ord && std::strcmp(ord, "natural") == 0;
+        for (int c = 0; c < 4; c++) {
+            std::vector<TileDesc>& L = tiles[c];
+            if (L.empty()) continue;
+            const int64_t rows_pad = c == 0 ? 16 : (c == 1 ? 32 : 64);
+            auto cost = [&](const TileDesc& t) { return (int64_t)t.nb * rows_pad + rows_pad / 4; };
+            int64_t total = 0;
+            for (const TileDesc& t : L) total += cost(t);
+            std::vector<std::vector<TileDesc>> chunk(8);
+            int64_t acc_cost = 0;
+            for (const TileDesc& t : L) {
+                int x = (int)std::min<int64_t>(7, (acc_cost * 8) / std::max<int64_t>(total, 1));
+                chunk[(size_t)x].push_back(t);
+                acc_cost += cost(t);
+            }
+            size_t maxlen = 0;
+            for (auto& ch : chunk) {
+                if (!natural) std::stable_sort(ch.begin(), ch.end(), [&](const TileDesc& a, const TileDesc& b) { return cost(a) > cost(b); });
+                maxlen = std::max(maxlen, ch.size());
+            }
+            std::vector<TileDesc> arranged(maxlen * 8, TileDesc{0, 0, 0, 1, 0, 0});
+            for (size_t x = 0; x < 8; x++)
+                for (size_t j = 0; j < chunk[x].size(); j++) arranged[j * 8 + x] = chunk[x][j];
+            L.swap(arranged);
+        }
+    }
+
+    // ---- stream plans (persistent kernels): see build_stream_plans ----
+    StreamPlanHost plan;
+    {
+        StreamPlanIn pin{cols, w, br0, br1, jab_lo, mab_lo, row_part, nzcount, jab, mab, dtype, device, skip};
+        if (int rc = build_stream_plans(pin, plan)) return rc;
+    }
+    std::vector<StepRec>(&steps)[2] = plan.steps;
+    std::vector<int32_t>(&wrange)[2] = plan.wrange;
+    std::vector<FixRec>& fix = plan.fix;
+    std::vector<int32_t>& fix_slots = plan.fix_slots;
+    std::vector<uint16_t>& a16 = plan.a16;
+    const int n_workers = plan.n_workers, n_split = plan.n_split;
+    const int64_t kp = plan.kp;
+
+    // the handle is owned by `hold` until it is handed to the caller: any early return or exception below frees it and every
+    // device allocation made so far
+    struct VbsDeleter { void operator()(sparta_vbs* q) const { destroy_impl(q); } };
+    std::unique_ptr<sparta_vbs, VbsDeleter> hold(new (std::nothrow) sparta_vbs);
+    sparta_vbs* v = hold.get();
+    if (!v) return fail(SPARTA_ERR_ALLOC, "sparta_vbs_create: out of host memory");
+    v->device = device; v->dtype = dtype;
+    v->zero_ranges = plan.zero_ranges;
+    v->rows = row_part[br1] - row_part[br0]; v->cols = cols; v->block_rows = br1 - br0; v->w = w;
+    v->nblocks = nblocks; v->nztot = nztot; v->exec_area = exec_area;
+
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(SPARTA_ERR_HIP, "sparta_vbs_create: hipSetDevice failed");
+#define CREATE_TRY(expr)                                                                                     \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) {                                                                              \
+            std::string m_ = std::string(#expr) + ": " + hipGetErrorString(e_);                              \
+            return fail(e_ == hipErrorOutOfMemory ? SPARTA_ERR_ALLOC : SPARTA_ERR_HIP, m_);                  \
+        }                                                                                                    \
+    } while (0)
+    // A is padded by 128 floats so that no (masked-off) lane ever forms an address past the allocation
+    if (!h16) {
+        v->a_bytes = (nztot + 128) * (int64_t)sizeof(float);
+        CREATE_TRY(hipMalloc((void**)&v->d_A, (size_t)v->a_bytes));
+        CREATE_TRY(hipMemset(v->d_A, 0, (size_t)v->a_bytes));
+        if (nztot > 0) CREATE_TRY(hipMemcpy(v->d_A, mab + mab_lo, (size_t)nztot * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        // the look-ahead of the pipeline reads up to 5 slices past the last one (never multiplied): pad
+        v->a_bytes = ((int64_t)a16.size() + 8 * 64 * 64) * (int64_t)sizeof(uint16_t);
+        CREATE_TRY(hipMalloc((void**)&v->d_A, (size_t)v->a_bytes));
+        CREATE_TRY(hipMemset(v->d_A, 0, (size_t)v->a_bytes));
+        if (!a16.empty()) CREATE_TRY(hipMemcpy(v->d_A, a16.data(), a16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        v->kp16 = (int)kp;
+    }
+    CREATE_TRY(hipMalloc((void**)&v->d_jab, jab32.size() * sizeof(int32_t)));
+    CREATE_TRY(hipMemcpy(v->d_jab, jab32.data(), jab32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    for (int c = 0; c < 4; c++) {
+        v->n_tiles[c] = (int64_t)tiles[c].size();
+        v->n_real_tiles[c] = n_real[c];
+        if (tiles[c].empty()) continue;
+        CREATE_TRY(hipMalloc((void**)&v->d_tiles[c], tiles[c].size() * sizeof(TileDesc)));
+        CREATE_TRY(hipMemcpy(v->d_tiles[c], tiles[c].data(), tiles[c].size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    }
+    v->n_brows = (int64_t)brows.size();
+    if (!brows.empty()) {
+        CREATE_TRY(hipMalloc((void**)&v->d_brows, brows.size() * sizeof(BlockRowDesc)));
+        CREATE_TRY(hipMemcpy(v->d_brows, brows.data(), brows.size() * sizeof(BlockRowDesc), hipMemcpyHostToDevice));
+    }
+    if (!steps[0].empty() || !steps[1].empty() || !fix.empty() || !plan.zero_ranges.empty()) {
+        v->has_tail = (cols % w) != 0;
+        v->n_workers = n_workers; v->n_fix = (int32_t)fix.size(); v->n_split = n_split; v->n_slots = (int32_t)fix_slots.size();
+        std::vector<int32_t> big_fix;
+        for (size_t q = 0; q < fix.size(); q++) {
+            v->max_tile_slots = std::max(v->max_tile_slots, fix[q].n_slots);
+            if (fix[q].n_slots > 2 * kFixGroup) big_fix.push_back((int32_t)q);
+        }
+        v->n_big_fix = (int32_t)big_fix.size();
+        if (!big_fix.empty()) {
+            CREATE_TRY(hipMalloc((void**)&v->d_big_fix, big_fix.size() * sizeof(int32_t)));
+            CREATE_TRY(hipMemcpy(v->d_big_fix, big_fix.data(), big_fix.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        for (int ty = 0; ty < 2; ty++) {
+            std::vector<StepRec>& st = steps[ty];
+            v->n_steps[ty] = (int64_t)st.size();
+            if (st.empty()) continue;
+            // the pipeline prefetches up to 5 steps (and up to two 8-record batches) past a range end: pad with harmless copies
+            for (int k = 0; k < 32; k++) { StepRec d = st[(size_t)v->n_steps[ty] - 1]; d.mt_flags = (d.mt_flags & ~(STEP_LAST | STEP_SPLIT)) | STEP_FIRST; st.push_back(d); }
+            CREATE_TRY(hipMalloc((void**)&v->d_steps[ty], st.size() * sizeof(StepRec)));
+            CREATE_TRY(hipMemcpy(v->d_steps[ty], st.data(), st.size() * sizeof(StepRec), hipMemcpyHostToDevice));
+            v->h_steps[ty] = st;
+            CREATE_TRY(hipMalloc((void**)&v->d_wrange[ty], wrange[ty].size() * sizeof(int32_t)));
+            CREATE_TRY(hipMemcpy(v->d_wrange[ty], wrange[ty].data(), wrange[ty].size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        if (!fix.empty()) {
+            CREATE_TRY(hipMalloc((void**)&v->d_fix, fix.size() * sizeof(FixRec)));
+            CREATE_TRY(hipMemcpy(v->d_fix, fix.data(), fix.size() * sizeof(FixRec), hipMemcpyHostToDevice));
+        }
+        CREATE_TRY(hipMalloc((void**)&v->d_fix_slots, std::max<size_t>(fix_slots.size(), 1) * sizeof(int32_t)));
+        if (!fix_slots.empty()) CREATE_TRY(hipMemcpy(v->d_fix_slots, fix_slots.data(), fix_slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    if (!sp_crow.empty()) {
+        v->n_sp_rows = (int64_t)sp_crow.size(); v->n_sp_short = n_sp_short; v->n_sp_long = n_sp_long; v->sp_nnz = sp_rowptr.back();
+        CREATE_TRY(hipMalloc((void**)&v->d_sp_rowptr, sp_rowptr.size() * sizeof(int64_t)));
+        CREATE_TRY(hipMemcpy(v->d_sp_rowptr, sp_rowptr.data(), sp_rowptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc((void**)&v->d_sp_col, (sp_col.size() + 64) * sizeof(int32_t)));      // +64: a batch reads up to SP_BATCH entries at once
+        CREATE_TRY(hipMemset(v->d_sp_col, 0, (sp_col.size() + 64) * sizeof(int32_t)));
+        CREATE_TRY(hipMalloc((void**)&v->d_sp_val, (sp_val.size() + 64) * sizeof(float)));
+        CREATE_TRY(hipMemset(v->d_sp_val, 0, (sp_val.size() + 64) * sizeof(float)));
+        if (!sp_col.empty()) {
+            CREATE_TRY(hipMemcpy(v->d_sp_col, sp_col.data(), sp_col.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMemcpy(v->d_sp_val, sp_val.data(), sp_val.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        CREATE_TRY(hipMalloc((void**)&v->d_sp_crow, sp_crow.size() * sizeof(int32_t)));
+        CREATE_TRY(hipMemcpy(v->d_sp_crow, sp_crow.data(), sp_crow.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (!sp_list.empty()) {
+            CREATE_TRY(hipMalloc((void**)&v->d_sp_list, sp_list.size() * sizeof(int32_t)));
+            CREATE_TRY(hipMemcpy(v->d_sp_list, sp_list.data(), sp_list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        if (!sp_long.empty()) {
+            v->n_sp_segs = (int64_t)sp_segs.size();
+            CREATE_TRY(hipMalloc(&v->d_sp_segs, sp_segs.size() * sizeof(SpSegRec)));
+            CREATE_TRY(hipMemcpy(v->d_sp_segs, sp_segs.data(), sp_segs.size() * sizeof(SpSegRec), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc(&v->d_sp_long, sp_long.size() * sizeof(SpLongRec)));
+            CREATE_TRY(hipMemcpy(v->d_sp_long, sp_long.data(), sp_long.size() * sizeof(SpLongRec), hipMemcpyHostToDevice));
+        }
+    }
+    CREATE_TRY(hipEventCreate(&v->ev0));
+    CREATE_TRY(hipEventCreate(&v->ev1));
+    CREATE_TRY(hipEventCreate(&v->tev0));
+    CREATE_TRY(hipEventCreate(&v->tev1));
+#undef CREATE_TRY
+    *out = hold.release();
+    return SPARTA_OK;
+}
+
+int sparta_vbs_create_range(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
+                            const int64_t* nzcount, const int64_t* jab, const float* mab, int64_t br0, int64_t br1, int32_t dtype,
+                            int32_t device) {
+    SPARTA_GUARD_BEGIN
+    return create_core(out, rows, cols, block_rows, w, row_part, nzcount, jab, mab, br0, br1, dtype, device, nullptr);
+    SPARTA_GUARD_END("sparta_vbs_create")
+}
+
+static int create_from_csr_impl(sparta_vbs_t** out, int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals,
+                                const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, int32_t force_fixed_size,
+                                int32_t dtype, int32_t device, bool keep_order) {
+    using sparta::fail;
+    if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create_from_csr: out is NULL");
+    *out = nullptr;
+    if (dtype != SPARTA_F32 && dtype != SPARTA_F16 && dtype != SPARTA_BF16) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create_from_csr: bad dtype");
+    sparta_vbs_host h;
+    std::memset(&h, 0, sizeof(h));
+    int rc = SPARTA_OK;
+    try {
+        sparta::CsrView a;
+        a.rows = rows; a.cols = cols; a.rowptr = rowptr; a.colidx = colidx; a.vals = vals;
+        double K = 24.0;
+        if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
+        const int64_t kdep = (dtype != SPARTA_F32 && col_block_size % 64 == 0) ? 64 : 32;
+        sparta::HybridSparse sp;
+        rc = sparta::vbs_build_hybrid(a, grouping, col_block_size, row_block_size, force_fixed_size != 0, K, kdep, &h, K > 0.0 ? &sp : nullptr, keep_order);
+        if (rc == SPARTA_OK)
+            rc = create_core(out, h.rows, h.cols, h.block_rows, col_block_size, h.row_part, h.nzcount, h.jab, h.mab, 0, h.block_rows, dtype, device,
+                             K > 0.0 ? &sp : nullptr);
+        if (rc == SPARTA_OK && K > 0.0) (*out)->ext_sparse = true;
+    } catch (const std::bad_alloc&) {
+        rc = fail(SPARTA_ERR_ALLOC, "sparta_vbs_create_from_csr: out of host memory");
+    } catch (const std::exception& e) {
+        rc = fail(SPARTA_ERR_INVALID, std::string("sparta_vbs_create_from_csr: ") + e.what());
+    }
+    sparta_vbs_host_free(&h);
+    return rc;
+}
+
+int sparta_vbs_create_from_csr(sparta_vbs_t** out, int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals,
+                               const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, int32_t force_fixed_size,
+                               int32_t dtype, int32_t device) {
+    return create_from_csr_impl(out, rows, cols, rowptr, colidx, vals, grouping, col_block_size, row_block_size, force_fixed_size, dtype, device, false);
+}
+
+// A^T of a VBS as a device handle: with it, B * A (dense x VBS) is an ordinary product -- C^T = A^T * B^T, and a column-major
+// M x rows B IS a row-major rows x M B^T (same bytes), a column-major M x cols C IS a row-major cols x M C^T.  The reference's own
+// "inverted" product (cublas_blockmat_multiplyBA, src/cuda/cuda_utilities.cpp:553-721) is not a B * A; this one is.
+int sparta_vbs_create_transposed(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
+                                 const int64_t* nzcount, const int64_t* jab, const float* mab, int32_t dtype, int32_t device) {
+    using sparta::fail;
+    if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create_transposed: out is NULL");
+    *out = nullptr;
+    if (rows <= 0 || cols <= 0 || block_rows <= 0 || w <= 0 || !row_part || !nzcount)
+        return fail(SPARTA_ERR_INVALID, "sparta_vbs_create_transposed: bad dimensions or NULL index array");
+    if (rows > INT32_MAX || cols > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create_transposed: more than 2^31 - 1 rows or columns");
+    try {
+        // CSR of A^T: row j = column j of A, entries (reordered row i, value) ascending in i; exact zeros of the blocks are dropped
+        std::vector<int64_t> rp((size_t)cols + 1, 0);
+        int64_t jo = 0, mo = 0;
+        for (int64_t ib = 0; ib < block_rows; ib++) {
+            const int64_t h = row_part[ib + 1] - row_part[ib], nb = nzcount[ib];
+            if (h < 0 || nb < 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create_transposed: invalid row_part / nzcount");
+            for (int64_t b = 0; b < nb; b++) {
+                const int64_t c0 = jab[jo + b] * w;
+                if (c0 < 0 || c0 >= cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create_transposed: jab entry out of range");
+                for (int64_t k = 0; k < w && c0 + k < cols; k++)
+                    for (int64_t i = 0; i < h; i++) rp[(size_t)(c0 + k) + 1] += mab[mo + (b * w + k) * h + i] != 0.0f;
+            }
+            jo += nb; mo += nb * h * w;
+        }
+        for (int64_t j = 0; j < cols; j++) rp[(size_t)j + 1] += rp[(size_t)j];
+        std::vector<int32_t> ci((size_t)rp[(size_t)cols]);
+        std::vector<float> va((size_t)rp[(size_t)cols]);
+        std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
+        jo = 0; mo = 0;
+        for (int64_t ib = 0; ib < block_rows; ib++) {
+            const int64_t h = row_part[ib + 1] - row_part[ib], nb = nzcount[ib];
+            for (int64_t b = 0; b < nb; b++) {
+                const int64_t c0 = jab[jo + b] * w;
+                for (int64_t k = 0; k < w && c0 + k < cols; k++)
+                    for (int64_t i = 0; i < h; i++) {
+                        const float a = mab[mo + (b * w + k) * h + i];
+                        if (a != 0.0f) { const int64_t q = fill[(size_t)(c0 + k)]++; ci[(size_t)q] = (int32_t)(row_part[ib] + i); va[(size_t)q] = a; }
+                    }
+            }
+            jo += nb; mo += nb * h * w;
+        }
+        // block-rows of A^T = the column blocks of A (w rows each); its column blocks are 32 reordered rows of A wide
+        std::vector<int64_t> grouping((size_t)cols);
+        for (int64_t j = 0; j < cols; j++) grouping[(size_t)j] = j / w;
+        return create_from_csr_impl(out, cols, rows, rp.data(), ci.data(), va.data(), grouping.data(), 32, 0, 0, dtype, device, true);   // rows stay in place: they are the columns of C
+    } catch (const std::bad_alloc&) {
+        return fail(SPARTA_ERR_ALLOC, "sparta_vbs_create_transposed: out of host memory");
+    } catch (const std::exception& e) {
+        return fail(SPARTA_ERR_INVALID, std::string("sparta_vbs_create_transposed: ") + e.what());
+    }
+}
+
+/* C (+)= B * A with the handle of A^T (sparta_vbs_create_transposed): B is M x rows(A), C is M x cols(A), both column-major. */
+int sparta_vbs_spmm_ba(sparta_vbs_t* At, const void* B, int64_t ldb, int32_t M, void* C, int64_t ldc, int32_t accumulate, int32_t ptr_space,
+                       void* stream, float* dt_ms) {
+    using sparta::fail;
+    if (!At) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_ba: NULL handle");
+    if (M <= 0 || ldb < M || ldc < M) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_ba: need M > 0, ldb >= M, ldc >= M");
+    // a column-major M x rows matrix with leading dimension ld is the row-major rows x M matrix with the same ld
+    return sparta_vbs_spmm(At, B, ldb, SPARTA_ROW_MAJOR, M, C, ldc, SPARTA_ROW_MAJOR, accumulate, ptr_space, stream, SPARTA_SPMM_MFMA, dt_ms);
+}
+
+int sparta_vbs_create(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
+                      const int64_t* nzcount, const int64_t* jab, const float* mab, int32_t dtype, int32_t device) {
+    return sparta_vbs_create_range(out, rows, cols, block_rows, w, row_part, nzcount, jab, mab, 0, block_rows, dtype, device);
+}
+
+int sparta_vbs_destroy(sparta_vbs_t* A) {
+    destroy_impl(A);
+    return SPARTA_OK;
+}
+
+int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info) {
+    if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_info: NULL argument");
+    std::memset(info, 0, 16 * sizeof(int64_t));
+    info[0] = A->rows; info[1] = A->cols; info[2] = A->block_rows; info[3] = A->w; info[4] = A->nblocks; info[5] = A->nztot;
+    for (int c = 0; c < 3; c++) info[6 + c] = A->n_real_tiles[c];
+    info[9] = A->n_sp_rows;                // rows handled by the sparse-row path
+    info[10] = A->a_bytes; info[11] = A->exec_area;
+    info[12] = A->n_steps[0] + A->n_steps[1]; info[13] = A->n_workers; info[14] = A->n_split; info[15] = A->last_path;
+    return SPARTA_OK;
+}
+
+int sparta_vbs_sparse_info(const sparta_vbs_t* A, int64_t* info) {
+    if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_sparse_info: NULL argument");
+    info[0] = A->n_sp_rows; info[1] = A->sp_nnz; info[2] = A->n_sp_short; info[3] = A->n_sp_long;
+    return SPARTA_OK;
+}
+
+#ifdef SPARTA_TIMELINE
+// developer build only: the raw timeline words (4 waves x 64 steps x 8)
+int sparta_debug_timeline(sparta_vbs_t* A, long long* out) {
+    if (!A || !out || !A->d_clk) return -1;
+    DeviceGuard guard(A->device);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpy(out, A->d_clk + 16, (4 * 64 * 8 + 2048) * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
+int sparta_vbs_clock_mhz(sparta_vbs_t* A, double* mhz_out) {
+    using sparta::fail;
+    if (!A || !mhz_out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_clock_mhz: NULL argument");
+    DeviceGuard guard(A->device);
+    for (int c = 0; c < 4; c++) mhz_out[c] = 0.0;
+    if (!A->class_timing || !A->d_clk) return SPARTA_OK;
+    long long h[16];
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h, A->d_clk, sizeof(h), hipMemcpyDeviceToHost));
+    for (int c = 0; c < 4; c++) {
+        if (!A->class_ran[c]) continue;
+        const long long dc = h[4 * c + 2] - h[4 * c], dr = h[4 * c + 3] - h[4 * c + 1];
+        if (dr > 0 && dc > 0) mhz_out[c] = (double)dc / (double)dr * 100.0;      // s_memrealtime ticks at 100 MHz
+    }
+    return SPARTA_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// long runs of rows without blocks, accumulate = 0: streamed zero fill (vbs_zero_rows_kernel), one launch per run
+void launch_zero_ranges(sparta_vbs_t* A, float* C, int64_t ldc, bool c_row_major, int n_cols, hipStream_t st) {
+    for (const auto& zr : A->zero_ranges) {
+        const int64_t n_lines = c_row_major ? zr.second : (int64_t)n_cols, line_len = c_row_major ? (int64_t)n_cols : zr.second;
+        const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (line_len / 4 + kThreads - 1) / kThreads));
+        const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_lines, 16384));
+        launch_zero_rows(dim3(gx, gy), st, C, ldc, (int)c_row_major, zr.first, zr.second, n_cols);
+    }
+}
+
+// step lists for a gathered B (slab index + row inside the slab), rebuilt when the slab height changes
+int ensure_gathered_steps(sparta_vbs_t* A, int64_t shard_rows, hipStream_t st) {
+    if (A->g_shard_rows == shard_rows) return SPARTA_OK;
+    for (int ty = 0; ty < 2; ty++) {
+        if (A->h_steps[ty].empty()) continue;
+        std::vector<StepRec> g = A->h_steps[ty];
+        for (StepRec& r : g) { r.pad = (int32_t)(r.b_row / shard_rows); r.b_row = (int32_t)(r.b_row % shard_rows); }
+        if (!A->d_steps_g[ty]) HIP_TRY(hipMalloc((void**)&A->d_steps_g[ty], g.size() * sizeof(StepRec)));
+        HIP_TRY(hipMemcpyAsync(A->d_steps_g[ty], g.data(), g.size() * sizeof(StepRec), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));                       // g goes out of scope
+    }
+    A->g_shard_rows = shard_rows;
+    return SPARTA_OK;
+}
+
+
+int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_major, int64_t shard_rows, int64_t shard_stride, int bk,
+                       int32_t n_cols, float* dC, int64_t ldc, bool c_row_major, bool accumulate, hipStream_t st) {
+    const size_t esz = bk == 0 ? 4 : 2;
+    SparseParams q;
+    q.rowptr = A->d_sp_rowptr; q.col = A->d_sp_col; q.val = A->d_sp_val; q.crow = A->d_sp_crow;
+    q.list = nullptr; q.n_list = 0;
+    q.N = n_cols; q.accumulate = accumulate;
+    q.b_col_stride = 0; q.shard_rows = 0; q.shard_stride = 0;
+    // A column-major B read in place costs one 64-byte line per ELEMENT (16 x the bytes of a row-major row); transposing costs
+    // 2 x |B| once.  In place wins while  nnz * 16 < 2 * cols.
+    const bool in_place = !(b_row_major && shard_rows == 0) && A->sp_nnz * 8 < A->cols;
+    if (b_row_major && shard_rows == 0) { q.B = dB; q.ldb = ldb; }
+    else if (in_place) { q.B = dB; q.ldb = 0; q.b_col_stride = ldb; q.shard_rows = shard_rows; q.shard_stride = shard_stride; }
+    else {
+        if (int rc = ensure_scratch(&A->d_Brm, &A->d_Brm_bytes, (size_t)A->cols * (size_t)n_cols * esz)) return rc;
+        const int64_t n_wg = ((A->cols + 63) / 64) * (int64_t)((n_cols + 63) / 64);
+        if (n_wg > INT32_MAX) return sparta::fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: B too large for the transpose grid");
+        launch_b_to_row_major(bk != 0, (unsigned)n_wg, st, dB, ldb, shard_rows, shard_stride, A->cols, (int)n_cols, A->d_Brm);
+        q.B = A->d_Brm; q.ldb = n_cols;
+    }
+    if (c_row_major) { q.out = dC; q.ldo = ldc; q.out_is_c = 1; }
+    else {
+        if (int rc = ensure_scratch(&A->d_spC, &A->d_spC_bytes, (size_t)A->n_sp_rows * (size_t)n_cols * sizeof(float))) return rc;
+        q.out = (float*)A->d_spC; q.ldo = n_cols; q.out_is_c = 0;
+    }
+    if (A->n_sp_long > 0)
+        if (int rc = ensure_scratch(&A->d_sp_part, &A->d_sp_part_bytes, (size_t)A->n_sp_segs * (size_t)n_cols * sizeof(float))) return rc;
+    // widest vector the shapes allow: every row start VEC-element aligned, N a multiple of 64 * VEC (no ragged chunk)
+    auto aligned = [&](int v) {
+        return n_cols % (64 * v) == 0 && q.ldb % v == 0 && q.ldo % v == 0 && ((uintptr_t)q.B % (esz * v)) == 0 && ((uintptr_t)q.out % (4 * v)) == 0;
+    };
+    const int vec = in_place ? 1 : (aligned(4) ? 4 : (aligned(2) ? 2 : 1));
+    const unsigned gy = (unsigned)((n_cols + 64 * vec - 1) / (64 * vec));
+    launch_sparse_kernels(vec, bk, q, gy, st, A->d_sp_list, A->n_sp_short, (const SpSegRec*)A->d_sp_segs, A->n_sp_segs, (const SpLongRec*)A->d_sp_long,
+                          A->n_sp_long, (float*)A->d_sp_part);
+    if (!q.out_is_c)
+        launch_c_scatter((unsigned)(((A->n_sp_rows + 63) / 64) * (int64_t)((n_cols + 63) / 64)), st, (const float*)A->d_spC, A->d_sp_crow, A->n_sp_rows,
+                         (int)n_cols, dC, ldc, (int)accumulate);
+    HIP_TRY(hipGetLastError());
+    return SPARTA_OK;
+}
+
+// 16-bit handles (SPARTA_F16 / SPARTA_BF16): A and B in the 16-bit type, fp32 accumulation, fp32 C.  Device pointers: B is a
+// 16-bit column-major matrix (ldb in elements, even).  Host pointers keep the reference's contract (fp32 B in, fp32 C out):
+// B is converted on the device (round to nearest even).
+int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int64_t shard_rows, int64_t shard_stride, int32_t n_cols, void* C,
+                int64_t ldc, int32_t c_layout, int32_t accumulate, int32_t ptr_space, hipStream_t st, int32_t algo, float* dt_ms) {
+    using sparta::fail;
+    if (algo != SPARTA_SPMM_MFMA) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: SPARTA_SPMM_EXACT needs an fp32 handle");
+    if (shard_rows != 0 && ptr_space != SPARTA_PTR_DEVICE) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: device pointers only");
+    if (b_layout != SPARTA_COL_MAJOR) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit handles need a column-major B (k contiguous)");
+    if (n_cols % kTN != 0) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit handles need n_cols % 128 == 0");
+    const bool bf16 = A->dtype == SPARTA_BF16;
+    const size_t c_elems = (size_t)ldc * (size_t)(c_layout == SPARTA_COL_MAJOR ? n_cols : A->rows);
+    const uint16_t* dB = (const uint16_t*)B;
+    float* dC = (float*)C;
+    int64_t ldb16 = ldb;
+    if (ptr_space == SPARTA_PTR_HOST) {
+        const size_t b_elems = (size_t)ldb * (size_t)n_cols;
+        ldb16 = (A->cols + 7) / 8 * 8;
+        if (int rc = ensure_scratch(&A->d_B, &A->d_B_bytes, b_elems * sizeof(float))) return rc;
+        if (int rc = ensure_scratch(&A->d_B16, &A->d_B16_bytes, (size_t)ldb16 * n_cols * sizeof(uint16_t))) return rc;
+        if (int rc = ensure_scratch(&A->d_C, &A->d_C_bytes, c_elems * sizeof(float))) return rc;
+        HIP_TRY(hipMemcpyAsync(A->d_B, B, b_elems * sizeof(float), hipMemcpyHostToDevice, st));
+        if (accumulate) HIP_TRY(hipMemcpyAsync(A->d_C, C, c_elems * sizeof(float), hipMemcpyHostToDevice, st));
+        else if (c_elems > 0) HIP_TRY(hipMemsetAsync(A->d_C, 0, c_elems * sizeof(float), st));
+        launch_convert_h16(bf16, st, (const float*)A->d_B, ldb, A->cols, (int64_t)n_cols, (uint16_t*)A->d_B16, ldb16);
+        dB = (const uint16_t*)A->d_B16;
+        dC = (float*)A->d_C;
+    } else if (ldb % 2 != 0) {
+        return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit B needs an even leading dimension (16-byte loads start on 4-byte boundaries)");
+    }
+    // 32-bit byte offsets inside a 128-column slab (see the fp32 path): 127 x ld x element size < 2^31
+    if (ldb16 * 128 * 2 >= ((int64_t)1 << 31) - 65536 || (c_layout == SPARTA_ROW_MAJOR ? ldc * 64 : ldc * 128) * 4 >= ((int64_t)1 << 31) - 65536)
+        return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: leading dimension too large for the 16-bit stream kernels (ldb < 8.3 M, ldc < 4.1 M elements)");
+    if (dt_ms) HIP_TRY(hipEventRecord(A->ev0, st));
+    const int n_nt = n_cols / kTN;
+    const bool prof = A->class_timing;
+    for (int c = 0; c < 4; c++) A->class_ran[c] = false;
+    const size_t slab = (size_t)A->n_slots * SK_SLOT_FLOATS;
+    if (A->n_split > 0)
+        if (int rc = ensure_scratch(&A->d_ws, &A->d_ws_bytes, slab * n_nt * sizeof(float))) return rc;
+    StreamParams sp;
+    sp.A = A->d_A; sp.B = (const float*)dB; sp.C = dC; sp.ws = (float*)A->d_ws;
+    sp.ldb = ldb16; sp.ldc = ldc; sp.cols = A->cols; sp.shard_rows = shard_rows; sp.shard_stride = shard_stride;
+    if (shard_rows > 0)
+        if (int rc = ensure_gathered_steps(A, shard_rows, st)) return rc;
+    sp.ws_slab_stride = (int64_t)slab; sp.accumulate = accumulate != 0; sp.c_row_major = c_layout == SPARTA_ROW_MAJOR;
+    sp.N = n_cols; sp.w = (int32_t)A->w; sp.B_tail = nullptr; sp.clk = nullptr;
+    if (A->n_steps[0] + A->n_steps[1] > 0) {
+        if (prof) HIP_TRY(hipEventRecord(A->cev[0][0], st));
+        if (A->has_tail && shard_rows == 0) {
+            if (int rc = ensure_scratch(&A->d_btail, &A->d_btail_bytes, (size_t)A->w * n_cols * sizeof(uint16_t))) return rc;
+            const int64_t row0 = ((A->cols - 1) / A->w) * A->w;
+            launch_tail_copy_h16(st, dB, ldb16, row0, A->cols, (int)A->w, (int)n_cols, (uint16_t*)A->d_btail);
+            sp.B_tail = (const float*)A->d_btail;
+        }
+        const dim3 grid((unsigned)A->n_workers, (unsigned)n_nt);
+        const int probe_ty = A->n_steps[1] >= A->n_steps[0] ? 1 : 0;
+        for (int ty = 1; ty >= 0; ty--) {
+            if (A->n_steps[ty] == 0) continue;
+            sp.steps = shard_rows > 0 ? A->d_steps_g[ty] : A->d_steps[ty]; sp.worker_range = A->d_wrange[ty];
+            sp.clk = (prof && ty == probe_ty) ? A->d_clk : nullptr;
+            const bool gth = shard_rows > 0;
+            launch_h16_stream(A->kp16, ty != 0, bf16, gth, grid, st, sp);
+        }
+        if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
+    }
+    const bool fix_launch = A->n_fix > 0 && !(accumulate && A->n_split == 0);   // C += 0 for the block-rows without blocks: nothing to launch
+    const bool zero_launch = !A->zero_ranges.empty() && !accumulate;
+    if (fix_launch || zero_launch) {
+        if (prof) HIP_TRY(hipEventRecord(A->cev[1][0], st));
+        if (fix_launch && A->n_big_fix > 0)
+            launch_fixup_group(dim3((unsigned)A->n_big_fix, (unsigned)n_nt, (unsigned)((A->max_tile_slots + kFixGroup - 1) / kFixGroup)), st, A->d_fix,
+                               A->d_big_fix, A->d_fix_slots, (float*)A->d_ws, (int64_t)slab);
+        if (fix_launch)
+            launch_fixup(dim3((unsigned)A->n_fix, (unsigned)n_nt), st, A->d_fix, A->d_fix_slots, (const float*)A->d_ws, (int64_t)slab, dC, ldc,
+                         (int)(c_layout == SPARTA_ROW_MAJOR), (int)(accumulate != 0));
+        if (zero_launch) launch_zero_ranges(A, dC, ldc, c_layout == SPARTA_ROW_MAJOR, n_cols, st);
+        if (prof) { HIP_TRY(hipEventRecord(A->cev[1][1], st)); A->class_ran[1] = true; }
+    }
+    if (A->n_sp_rows > 0) {                  // nearly empty block-rows: sparse rows over a row-major 16-bit copy of B
+        if (prof) HIP_TRY(hipEventRecord(A->cev[3][0], st));
+        if (int rc = launch_sparse_rows(A, dB, ldb16, false, shard_rows, shard_stride, bf16 ? 2 : 1, n_cols, dC, ldc, c_layout == SPARTA_ROW_MAJOR, accumulate != 0, st)) return rc;
+        if (prof) { HIP_TRY(hipEventRecord(A->cev[3][1], st)); A->class_ran[3] = true; }
+    }
+    A->last_path = 1;
+    HIP_TRY(hipGetLastError());
+    if (dt_ms) {
+        HIP_TRY(hipEventRecord(A->ev1, st));
+        HIP_TRY(hipEventSynchronize(A->ev1));
+        HIP_TRY(hipEventElapsedTime(dt_ms, A->ev0, A->ev1));
+    }
+    if (ptr_space == SPARTA_PTR_HOST) {
+        HIP_TRY(hipMemcpyAsync(C, A->d_C, c_elems * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SPARTA_OK;
+}
+
+int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int64_t shard_rows, int64_t shard_stride, int32_t n_cols,
+              void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, int32_t ptr_space, void* stream, int32_t algo,
+              float* dt_ms) {
+    using sparta::fail;
+    if (!A || !B || !C) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: NULL argument");
+    if (n_cols <= 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: n_cols must be > 0");
+    if (b_layout != SPARTA_COL_MAJOR && b_layout != SPARTA_ROW_MAJOR) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: bad b_layout");
+    if (c_layout != SPARTA_COL_MAJOR && c_layout != SPARTA_ROW_MAJOR) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: bad c_layout");
+    if (shard_rows == 0 && ldb < (b_layout == SPARTA_COL_MAJOR ? A->cols : (int64_t)n_cols))
+        return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: ldb too small");
+    if (ldc < (c_layout == SPARTA_COL_MAJOR ? A->rows : (int64_t)n_cols)) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: ldc too small");
+    if (algo != SPARTA_SPMM_MFMA && algo != SPARTA_SPMM_EXACT) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: bad algo");
+    if (ptr_space != SPARTA_PTR_HOST && ptr_space != SPARTA_PTR_DEVICE) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: bad ptr_space");
+
+    DeviceGuard guard(A->device);
+    if (!guard.ok) return fail(SPARTA_ERR_HIP, "sparta_vbs_spmm: hipSetDevice failed");
+    hipStream_t st = (hipStream_t)stream;
+    if (A->dtype != SPARTA_F32)
+        return spmm16_impl(A, B, ldb, b_layout, shard_rows, shard_stride, n_cols, C, ldc, c_layout, accumulate, ptr_space, st, algo, dt_ms);
+
+    const float* dB = (const float*)B;
+    float* dC = (float*)C;
+    const size_t b_elems = (size_t)ldb * (size_t)(b_layout == SPARTA_COL_MAJOR ? n_cols : A->cols);
+    const size_t c_elems = (size_t)ldc * (size_t)(c_layout == SPARTA_COL_MAJOR ? n_cols : A->rows);
+    if (ptr_space == SPARTA_PTR_HOST) {
+        // the reference's back-end contract: host in, host out, dt excludes the copies
+        if (int rc = ensure_scratch(&A->d_B, &A->d_B_bytes, b_elems * sizeof(float))) return rc;
+        if (int rc = ensure_scratch(&A->d_C, &A->d_C_bytes, c_elems * sizeof(float))) return rc;
+        HIP_TRY(hipMemcpyAsync(A->d_B, B, b_elems * sizeof(float), hipMemcpyHostToDevice, st));
+        if (accumulate) HIP_TRY(hipMemcpyAsync(A->d_C, C, c_elems * sizeof(float), hipMemcpyHostToDevice, st));
+        else if (c_elems > 0) HIP_TRY(hipMemsetAsync(A->d_C, 0, c_elems * sizeof(float), st));   // ld padding stays defined
+        dB = (const float*)A->d_B;
+        dC = (float*)A->d_C;
+    }
+
+    if (algo == SPARTA_SPMM_EXACT && A->ext_sparse && A->n_sp_rows > 0)
+        return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: SPARTA_SPMM_EXACT needs the dense image of every block-row (handle made by sparta_vbs_create_from_csr)");
+    if (dt_ms) HIP_TRY(hipEventRecord(A->ev0, st));
+    if (algo == SPARTA_SPMM_EXACT) {
+        if (A->n_brows > 0) {
+            launch_f32_exact((unsigned)A->n_brows, st, A->d_brows, A->d_jab, A->d_A, dB, dC, ldb, ldc, A->cols, (int)n_cols, (int)A->w,
+                             (int)(b_layout == SPARTA_ROW_MAJOR), (int)(c_layout == SPARTA_ROW_MAJOR), (int)accumulate, shard_rows, shard_stride);
+        }
+    } else {
+        const char* nv = std::getenv("SPARTA_NO_VEC");
+        const bool novec = nv && nv[0] == '1';
+        const int n_nt = (n_cols + kTN - 1) / kTN;
+        const bool full_slabs = (n_cols % kTN) == 0;
+        // two product paths (both branch-free, both need full panels) + the generic fallback for odd shapes
+        // The stream kernels address B and C through buffer descriptors with 32-bit byte offsets inside one 128-column slab
+        // (range-checked against 2 GB): 127 columns x leading dimension x 4 bytes must stay below 2^31, i.e. ld < 4.2 M
+        // elements for the column-major layouts.  Larger leading dimensions take the per-class / generic kernels (64-bit
+        // pointer arithmetic).
+        const int64_t ld_lim = ((int64_t)1 << 31) / (128 * 4) - 64;
+        const bool ld_ok = (b_layout == SPARTA_ROW_MAJOR ? ldb * 32 : ldb * 128) < ((int64_t)1 << 29) - 4096 &&
+                           (c_layout == SPARTA_ROW_MAJOR ? ldc * 64 : ldc * 128) < ((int64_t)1 << 29) - 4096;
+        (void)ld_lim;
+        const bool can_stream = A->n_workers > 0 && full_slabs && !novec && !force_generic() && ld_ok;
+        const bool can_class = (A->w % kKP) == 0 && full_slabs && !novec && !force_generic();
+
+        // persistent stream kernel + fix-up of the split tiles
+        auto run_stream = [&](float* Cout, bool prof) -> int {
+            const size_t slab = (size_t)A->n_slots * SK_SLOT_FLOATS;
+            if (A->n_split > 0)
+                if (int rc = ensure_scratch(&A->d_ws, &A->d_ws_bytes, slab * n_nt * sizeof(float))) return rc;
+            if (shard_rows > 0)
+                if (int rc = ensure_gathered_steps(A, shard_rows, st)) return rc;
+            StreamParams sp;
+            sp.A = A->d_A; sp.B = dB; sp.C = Cout; sp.ws = (float*)A->d_ws;
+            sp.ldb = ldb; sp.ldc = ldc; sp.cols = A->cols; sp.shard_rows = shard_rows; sp.shard_stride = shard_stride;
+            sp.ws_slab_stride = (int64_t)slab; sp.accumulate = accumulate != 0; sp.c_row_major = c_layout == SPARTA_ROW_MAJOR;
+            sp.N = n_cols; sp.w = (int32_t)A->w; sp.B_tail = nullptr;
+            sp.clk = nullptr;
+            if (A->n_steps[0] + A->n_steps[1] > 0) {
+                if (prof) HIP_TRY(hipEventRecord(A->cev[0][0], st));
+                if (A->has_tail && shard_rows == 0) {
+                    if (int rc = ensure_scratch(&A->d_btail, &A->d_btail_bytes, (size_t)A->w * n_cols * sizeof(float))) return rc;
+                    const int64_t row0 = ((A->cols - 1) / A->w) * A->w;
+                    launch_tail_copy(st, dB, ldb, (int)(b_layout == SPARTA_ROW_MAJOR), row0, A->cols, (int)A->w, (int)n_cols, (float*)A->d_btail);
+                    sp.B_tail = (const float*)A->d_btail;
+                }
+                const dim3 grid((unsigned)A->n_workers, (unsigned)n_nt);
+                // heavier type first; the clock probe rides on the launch with more steps
+                const int probe_ty = A->n_steps[1] >= A->n_steps[0] ? 1 : 0;
+                for (int ty = 1; ty >= 0; ty--) {
+                    if (A->n_steps[ty] == 0) continue;
+                    sp.steps = shard_rows > 0 ? A->d_steps_g[ty] : A->d_steps[ty]; sp.worker_range = A->d_wrange[ty];
+                    sp.clk = (prof && ty == probe_ty) ? A->d_clk : nullptr;
+                    launch_f32_stream(ty != 0, b_layout == SPARTA_ROW_MAJOR, shard_rows > 0, grid, st, sp);
+                }
+                if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
+            }
+            const bool fix_launch = A->n_fix > 0 && !(accumulate && A->n_split == 0);   // C += 0 for the block-rows without blocks: nothing to launch
+            const bool zero_launch = !A->zero_ranges.empty() && !accumulate;
+            if (fix_launch || zero_launch) {
+                if (prof) HIP_TRY(hipEventRecord(A->cev[1][0], st));
+                if (fix_launch && A->n_big_fix > 0)
+                    launch_fixup_group(dim3((unsigned)A->n_big_fix, (unsigned)n_nt, (unsigned)((A->max_tile_slots + kFixGroup - 1) / kFixGroup)), st, A->d_fix,
+                                       A->d_big_fix, A->d_fix_slots, (float*)A->d_ws, (int64_t)slab);
+                if (fix_launch)
+                    launch_fixup(dim3((unsigned)A->n_fix, (unsigned)n_nt), st, A->d_fix, A->d_fix_slots, (const float*)A->d_ws, (int64_t)slab, Cout, ldc,
+                                 (int)(c_layout == SPARTA_ROW_MAJOR), (int)(accumulate != 0));
+                if (zero_launch) launch_zero_ranges(A, Cout, ldc, c_layout == SPARTA_ROW_MAJOR, n_cols, st);
+                if (prof) { HIP_TRY(hipEventRecord(A->cev[1][1], st)); A->class_ran[1] = true; }
+            }
+            return SPARTA_OK;
+        };
+        // one launch per tile class (<=16 / <=32 / <=64 rows), one workgroup per tile
+        auto run_class = [&](float* Cout, bool generic, bool prof) -> int {
+            SpmmParams p;
+            p.jab = A->d_jab; p.A = A->d_A; p.B = dB; p.C = Cout; p.ldb = ldb; p.ldc = ldc; p.cols = A->cols;
+            p.n_ntiles = n_nt; p.N = n_cols; p.w = (int32_t)A->w;
+            p.b_row_major = b_layout == SPARTA_ROW_MAJOR; p.c_row_major = c_layout == SPARTA_ROW_MAJOR;
+            p.accumulate = accumulate != 0;
+            p.shard_rows = shard_rows; p.shard_stride = shard_stride;
+            p.vec_ok = novec ? 0 : 1;
+            for (int c = 3; c >= 0; c--) {              // heavy classes first
+                if (A->n_tiles[c] == 0) continue;
+                if (A->n_tiles[c] * (int64_t)p.n_ntiles > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: grid too large");
+                p.tiles = A->d_tiles[c]; p.n_tiles = (int32_t)A->n_tiles[c];
+                p.clk = prof ? A->d_clk + 4 * c : nullptr;
+                if (prof) HIP_TRY(hipEventRecord(A->cev[c][0], st));
+                launch_f32_class(c, p.b_row_major != 0, generic, p, st);
+                if (prof) { HIP_TRY(hipEventRecord(A->cev[c][1], st)); A->class_ran[c] = true; }
+            }
+            return SPARTA_OK;
+        };
+
+        // ---- choose the path: forced by SPARTA_PATH, else measured once per (n_cols, layouts, gathered) on this handle -------
+        int path = 3;                                   // 1 stream, 2 per-class fast, 3 generic
+        const char* pe = std::getenv("SPARTA_PATH");
+        const std::string forced = pe ? pe : "auto";
+        if (forced == "stream") path = can_stream ? 1 : 3;
+        else if (forced == "class") path = can_class ? 2 : 3;
+        else if (forced == "generic") path = 3;
+        else if (can_stream && can_class) {
+            const int64_t key = ((int64_t)n_cols << 8) | (b_layout << 2) | (c_layout << 1) | (shard_rows > 0 ? 1 : 0);
+            path = 0;
+            for (const auto& kv : A->tuned) if (kv.first == key) path = kv.second;
+            if (path == 0) {
+                // plan-time autotune: both paths write a scratch C (the caller's C must not be accumulated into twice)
+                if (int rc = ensure_scratch(&A->d_tune, &A->d_tune_bytes, c_elems * sizeof(float))) return rc;
+                float best[3] = {0.0f, 1e30f, 1e30f};
+                for (int cand = 1; cand <= 2; cand++) {
+                    for (int rep = 0; rep < 4; rep++) {
+                        HIP_TRY(hipEventRecord(A->tev0, st));
+                        if (int rc = cand == 1 ? run_stream((float*)A->d_tune, false) : run_class((float*)A->d_tune, false, false)) return rc;
+                        HIP_TRY(hipEventRecord(A->tev1, st));
+                        HIP_TRY(hipEventSynchronize(A->tev1));
+                        float ms = 0.0f;
+                        HIP_TRY(hipEventElapsedTime(&ms, A->tev0, A->tev1));
+                        if (rep > 0) best[cand] = std::min(best[cand], ms);
+                    }
+                }
+                path = best[1] <= best[2] ? 1 : 2;
+                A->tuned.emplace_back(key, path);
+                A->tune_ms[0] = best[1]; A->tune_ms[1] = best[2];
+            }
+        } else if (can_stream) path = 1;
+        else if (can_class) path = 2;
+
+        const bool prof = A->class_timing;
+        for (int c = 0; c < 4; c++) A->class_ran[c] = false;
+        if (path == 1) { if (int rc = run_stream(dC, prof)) return rc; }
+        else if (int rc = run_class(dC, path == 3, prof)) return rc;
+        A->last_path = path;
+
+        // ---- the block-rows kept as sparse rows (disjoint rows of C: order against the MFMA launches does not matter) ----
+        if (A->n_sp_rows > 0) {
+            if (prof) HIP_TRY(hipEventRecord(A->cev[3][0], st));
+            if (int rc = launch_sparse_rows(A, dB, ldb, b_layout == SPARTA_ROW_MAJOR, shard_rows, shard_stride, 0, n_cols, dC, ldc,
+                                            c_layout == SPARTA_ROW_MAJOR, accumulate != 0, st)) return rc;
+            if (prof) { HIP_TRY(hipEventRecord(A->cev[3][1], st)); A->class_ran[3] = true; }
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    if (dt_ms) {
+        HIP_TRY(hipEventRecord(A->ev1, st));
+        HIP_TRY(hipEventSynchronize(A->ev1));
+        HIP_TRY(hipEventElapsedTime(dt_ms, A->ev0, A->ev1));
+    }
+    if (ptr_space == SPARTA_PTR_HOST) {
+        HIP_TRY(hipMemcpyAsync(C, A->d_C, c_elems * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SPARTA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int32_t n_cols, void* C, int64_t ldc,
+                    int32_t c_layout, int32_t accumulate, int32_t ptr_space, void* stream, int32_t algo, float* dt_ms) {
+    SPARTA_GUARD_BEGIN
+    return spmm_impl(A, B, ldb, b_layout, 0, 0, n_cols, C, ldc, c_layout, accumulate, ptr_space, stream, algo, dt_ms);
+    SPARTA_GUARD_END("sparta_vbs_spmm")
+}
+
+int sparta_vbs_spmm_gathered(sparta_vbs_t* A, const void* B_gathered, int64_t shard_rows, int64_t shard_stride, int32_t n_cols,
+                             void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, void* stream, int32_t algo, float* dt_ms) {
+    using sparta::fail;
+    if (!A) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: NULL handle");
+    if (shard_rows <= 0 || shard_rows % A->w != 0)
+        return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: shard_rows must be a positive multiple of block_col_size");
+    if (shard_stride < shard_rows * (int64_t)n_cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: shard_stride too small");
+    if (A->cols % shard_rows != 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: cols must be n_shards * shard_rows");
+    SPARTA_GUARD_BEGIN
+    return spmm_impl(A, B_gathered, shard_rows, SPARTA_COL_MAJOR, shard_rows, shard_stride, n_cols, C, ldc, c_layout, accumulate,
+                     SPARTA_PTR_DEVICE, stream, algo, dt_ms);
+    SPARTA_GUARD_END("sparta_vbs_spmm_gathered")
+}
+
+int sparta_vbs_set_class_timing(sparta_vbs_t* A, int32_t enable) {
+    using sparta::fail;
+    if (!A) return fail(SPARTA_ERR_INVALID, "sparta_vbs_set_class_timing: NULL handle");
+    DeviceGuard guard(A->device);
+    if (enable && !A->cev[0][0]) {
+        for (int c = 0; c < 4; c++)
+            for (int e = 0; e < 2; e++) HIP_TRY(hipEventCreate(&A->cev[c][e]));
+    }
+    if (enable && !A->d_clk) {
+        HIP_TRY(hipMalloc((void**)&A->d_clk, (16 + 4 * 64 * 8 + 2048) * sizeof(long long)));
+        HIP_TRY(hipMemset(A->d_clk, 0, (16 + 4 * 64 * 8 + 2048) * sizeof(long long)));
+    }
+    A->class_timing = enable != 0;
+    return SPARTA_OK;
+}
+
+int sparta_vbs_class_times(sparta_vbs_t* A, float* ms_out) {
+    using sparta::fail;
+    if (!A || !ms_out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_class_times: NULL argument");
+    DeviceGuard guard(A->device);
+    for (int c = 0; c < 4; c++) {
+        ms_out[c] = 0.0f;
+        if (!A->class_timing || !A->class_ran[c]) continue;
+        HIP_TRY(hipEventSynchronize(A->cev[c][1]));
+        HIP_TRY(hipEventElapsedTime(&ms_out[c], A->cev[c][0], A->cev[c][1]));
+    }
+    return SPARTA_OK;
+}
+
+int sparta_pack_blocks(const void* src, int64_t block_bytes, const int32_t* ids_dev, int64_t n_blocks, void* dst, void* stream) {
+    using sparta::fail;
+    if (n_blocks < 0 || block_bytes <= 0 || block_bytes % 16 != 0)
+        return fail(SPARTA_ERR_INVALID, "sparta_pack_blocks: block_bytes must be a positive multiple of 16, n_blocks >= 0");
+    if (n_blocks == 0) return SPARTA_OK;
+    if (!src || !ids_dev || !dst) return fail(SPARTA_ERR_INVALID, "sparta_pack_blocks: NULL argument");
+    if (((uintptr_t)src | (uintptr_t)dst) % 16 != 0) return fail(SPARTA_ERR_INVALID, "sparta_pack_blocks: src and dst must be 16-byte aligned");
+    if (n_blocks > INT32_MAX) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_pack_blocks: too many blocks for one launch");
+    const int64_t vec = block_bytes / 16;
+    const unsigned gy = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8, vec / (4 * kThreads)));
+    launch_pack_blocks(dim3((unsigned)n_blocks, gy), (hipStream_t)stream, src, ids_dev, dst, vec);
+    HIP_TRY(hipGetLastError());
+    return SPARTA_OK;
+}
+
+}  // extern "C"

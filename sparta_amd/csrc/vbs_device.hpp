@@ -1,0 +1,270 @@
+// vbs_device.hpp -- declarations shared by the translation units of the device side of libsparta_amd.so:
+//   k_f32_class.hip   per-class fp32 MFMA kernels + the exact-order parity kernel
+//   k_f32_stream.hip  persistent fp32 stream kernels, fix-up, B-tail copy, zero fill
+//   k_h16.hip         fp16 / bf16 storage: LDS-staged and direct stream kernels, conversions
+//   k_sparse.hip      sparse-row kernels, layout transposes, row-block pack
+//   vbs_plan.cpp      host: stream plans (step lists, worker ranges, split tiles)
+//   vbs_capi.cpp      host: device image (sparta_vbs), sparta_vbs_create* / sparta_vbs_spmm* (include/sparta_amd.h)
+// Every kernel TU exports plain launch functions (namespace sparta_dev); the host TUs never see a __global__ symbol.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "host_core.hpp"
+
+namespace sparta_dev {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned: global_load_dwordx4 on any float address
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kTN = 128;   // columns of C per workgroup
+constexpr int kKP = 64;    // k-depth of one panel step
+
+// one row tile of one block-row
+struct TileDesc {
+    int64_t a_off;     // element offset into A of (first block of the block-row) + r0
+    int64_t jab_off;   // offset into jab of the block-row's first block-column id
+    int32_t nb;        // nonzero blocks in the block-row
+    int32_t h;         // block-row height = leading dimension of each of its blocks
+    int32_t c_row;     // first row of C written by this tile
+    int32_t mt_flags;  // low 16 bits: rows in this tile (<= class height); TILE_* flags above
+};
+constexpr int32_t TILE_TAIL = 1 << 16;   // the block-row's last block lies in the zero-padded last block column (cols % w != 0)
+static_assert(sizeof(TileDesc) == 32, "TileDesc must stay 32 bytes");
+
+struct SpmmParams {
+    const TileDesc* tiles;
+    const int32_t* jab;
+    const float* A;
+    const float* B;
+    float* C;
+    int64_t ldb, ldc;
+    int64_t cols;      // valid rows of B
+    int32_t n_tiles, n_ntiles;
+    int32_t N, w;
+    int32_t b_row_major, c_row_major;
+    int32_t accumulate, vec_ok;
+    int64_t shard_stride; // elements between consecutive slabs of a gathered B
+    int64_t shard_rows;   // 0: B is one matrix; >0: B is an all-gather result of column-major shard_rows x N slabs
+    long long* clk;       // clock probe (NULL = off): workgroup 0 writes {s_memtime, s_memrealtime} at entry and exit
+};
+
+constexpr int SK_KP = 32;                 // k depth of a step
+constexpr int SK_TM = 64;                 // max rows of a tile
+constexpr int32_t STEP_FIRST = 1 << 16;   // first step of a (segment of a) tile: accumulators start at zero
+constexpr int32_t STEP_LAST = 1 << 17;    // last step of a (segment of a) tile: run the epilogue
+constexpr int32_t STEP_SPLIT = 1 << 18;   // the tile is shared with another worker: epilogue goes to the workspace
+constexpr int32_t STEP_TAIL = 1 << 19;    // panel of the zero-padded last block column: read from StreamParams::B_tail, b_row = k offset in it
+constexpr int SK_SLOT_FLOATS = 32 * kThreads;   // one partial accumulator image: 32 registers x 256 threads
+
+struct StepRec {                          // 32 bytes, one per (block, 32-deep k slice), in execution order
+    int64_t a_off;                        // element offset into A of (tile row 0, first k of this step)
+    int32_t b_row;                        // first row of B of this step's panel (jb * w + ks)
+    int32_t h;                            // leading dimension of the A block (block-row height)
+    int32_t c_row;                        // first row of C of the tile
+    int32_t mt_flags;                     // rows of the tile (low 16 bits) | STEP_* flags
+    int32_t slot;                         // workspace slot for STEP_LAST|STEP_SPLIT, else -1
+    int32_t pad;                          // gathered-B step lists: index of the slab that holds b_row (b_row is then slab-local); else 0
+};
+static_assert(sizeof(StepRec) == 32, "StepRec must stay 32 bytes");
+
+struct FixRec {                           // one per split tile
+    int32_t c_row, mt;
+    int32_t slot_begin, n_slots;          // its partial images: fix_slots[slot_begin .. slot_begin + n_slots)
+};
+
+struct StreamParams {
+    const StepRec* steps;
+    const int32_t* worker_range;          // [2 * P]: begin, end step of every worker
+    const float* A;
+    const float* B;
+    const float* B_tail;                  // zero-padded copy of B's last (partial) block row: w x N, ld = w (col-major) / N (row-major)
+    float* C;
+    float* ws;                            // partial images: [n_ntiles][n_slots][SK_SLOT_FLOATS], one per segment of a split tile
+    int64_t ldb, ldc, cols;
+    int64_t shard_rows, shard_stride;
+    int64_t ws_slab_stride;               // floats between the workspaces of consecutive 128-column slabs
+    int32_t accumulate, c_row_major;
+    int32_t N, w;
+    long long* clk;                       // clock probe, see clock_probe()
+};
+
+constexpr int kFixGroup = 16;   // partial images per group of the fix-up group stage (k_f32_stream.hip)
+
+struct SparseParams {
+    const int64_t* rowptr;     // [n_rows + 1] into col / val
+    const int32_t* col;
+    const float* val;
+    const int32_t* crow;       // C row of every sparse row
+    const int32_t* list;       // the rows this launch handles (ordinals)
+    int32_t n_list;
+    const void* B;             // row-major, ld = ldb elements; fp32 (BK = 0), fp16 (1) or bf16 (2)
+    int64_t b_col_stride;      // 0: row-major B as above.  > 0: B is COLUMN-major (element (k, n) at slab(k) + k % shard_rows + n * b_col_stride),
+    int64_t shard_rows, shard_stride;   //      read in place, one 4-byte gather per element: only worth it for a handful of sparse rows
+    int64_t ldb;
+    float* out;                // row-major out: C itself (ld = ldc, row = crow) or the scratch (ld = N, row = ordinal)
+    int64_t ldo;
+    int32_t out_is_c, accumulate, N;
+};
+
+struct SpSegRec { int64_t p0; int32_t cnt, pad; };
+struct SpLongRec { int32_t ord, seg_begin, n_seg, pad; };
+
+struct BlockRowDesc {
+    int64_t a_off, jab_off;
+    int32_t nb, h, c_row, pad;
+};
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return sparta::fail(SPARTA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace sparta_dev
+
+struct sparta_vbs {
+    int device = 0, dtype = SPARTA_F32;
+    int64_t rows = 0, cols = 0, block_rows = 0, w = 0, nblocks = 0, nztot = 0;
+    float* d_A = nullptr;                    // fp32: the reference's mab; 16-bit handles: packed slices (see sparta_vbs_create)
+    int kp16 = 0;                            // 16-bit handles: k depth of a step (32 or 64)
+    int32_t* d_jab = nullptr;
+    sparta_dev::TileDesc* d_tiles[4] = {nullptr, nullptr, nullptr, nullptr};   // classes 16, 32, 64, 128
+    int64_t n_tiles[4] = {0, 0, 0, 0};       // launch entries (real tiles + padding)
+    int64_t n_real_tiles[4] = {0, 0, 0, 0};
+    sparta_dev::BlockRowDesc* d_brows = nullptr;
+    int64_t n_brows = 0;
+    int64_t exec_area = 0;
+    int64_t a_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t cev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    bool class_timing = false;
+    bool class_ran[4] = {false, false, false, false};
+    // stream plan (w % 32 == 0): see vbs_spmm_f32_stream_kernel
+    sparta_dev::StepRec* d_steps[2] = {nullptr, nullptr};      // per tile type: [0] <= 32 rows, [1] 33..64 rows
+    std::vector<sparta_dev::StepRec> h_steps[2];               // host copies (padded), source of the gathered-B variants
+    sparta_dev::StepRec* d_steps_g[2] = {nullptr, nullptr};    // step lists for sparta_vbs_spmm_gathered with shard_rows == g_shard_rows
+    int64_t g_shard_rows = 0;
+    int32_t* d_wrange[2] = {nullptr, nullptr};
+    sparta_dev::FixRec* d_fix = nullptr;
+    std::vector<std::pair<int64_t, int64_t>> zero_ranges;   // long runs of rows without blocks (local C rows), see vbs_zero_rows_kernel
+    int32_t* d_fix_slots = nullptr;
+    int64_t n_steps[2] = {0, 0};
+    int32_t n_workers = 0, n_fix = 0, n_split = 0, n_slots = 0;
+    int32_t max_tile_slots = 0;            // most partial images of one split tile
+    int32_t* d_big_fix = nullptr;          // fix records with more than 2 * kFixGroup images (group stage)
+    int32_t n_big_fix = 0;
+    void* d_ws = nullptr;
+    size_t d_ws_bytes = 0;
+    bool has_tail = false;                 // cols % w != 0: the stream path needs B_tail
+    void* d_btail = nullptr;
+    size_t d_btail_bytes = 0;
+    int last_path = 0;                     // 1: stream kernel, 2: per-class branch-free kernels, 3: per-class generic kernels
+    std::vector<std::pair<int64_t, int>> tuned;   // (n_cols/layout key) -> measured best path
+    float tune_ms[2] = {0.0f, 0.0f};
+    void* d_tune = nullptr;
+    size_t d_tune_bytes = 0;
+    void* d_B16 = nullptr;                 // 16-bit handles, host-pointer calls: B converted on the device
+    size_t d_B16_bytes = 0;
+    long long* d_clk = nullptr;           // clock probe: [4 launches][4] = {s_memtime, s_memrealtime} at entry, at exit
+    hipEvent_t tev0 = nullptr, tev1 = nullptr;
+    // sparse-row path (fp32 handles): the block-rows taken out of the MFMA plans, as rows of (column, value)
+    int64_t n_sp_rows = 0, n_sp_short = 0, n_sp_long = 0, sp_nnz = 0;
+    bool ext_sparse = false;               // created from CSR: the sparse rows have no dense image (no exact-order kernel for them)
+    int64_t* d_sp_rowptr = nullptr;
+    int32_t* d_sp_col = nullptr;
+    float* d_sp_val = nullptr;
+    int32_t* d_sp_crow = nullptr;
+    int32_t* d_sp_list = nullptr;          // the short rows (one wave each)
+    void* d_sp_segs = nullptr;             // SpSegRec[n_sp_segs]: segments of the long rows
+    void* d_sp_long = nullptr;             // SpLongRec[n_sp_long]
+    int64_t n_sp_segs = 0;
+    void* d_sp_part = nullptr;             // partial rows of the segments
+    size_t d_sp_part_bytes = 0;
+    void* d_Brm = nullptr;                 // row-major copy of a column-major / gathered B
+    size_t d_Brm_bytes = 0;
+    void* d_spC = nullptr;                 // row-major results awaiting the scatter into a column-major C
+    size_t d_spC_bytes = 0;
+    void* d_B = nullptr;
+    size_t d_B_bytes = 0;
+    void* d_C = nullptr;
+    size_t d_C_bytes = 0;
+};
+
+namespace sparta_dev {
+
+// ---- launch functions exported by the kernel translation units ------------------------------------------------------
+// k_f32_class.hip
+void launch_f32_class(int cls, bool b_row_major, bool generic, const SpmmParams& p, hipStream_t st);
+void launch_f32_exact(unsigned n_brows, hipStream_t st, const BlockRowDesc* rows, const int32_t* jab, const float* A, const float* B, float* C,
+                      int64_t ldb, int64_t ldc, int64_t cols, int N, int w, int b_row_major, int c_row_major, int accumulate, int64_t shard_rows,
+                      int64_t shard_stride);
+// k_f32_stream.hip
+void launch_f32_stream(bool mi2, bool b_row_major, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
+void launch_fixup_group(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* big, const int32_t* fix_slots, float* ws_all, int64_t ws_slab_stride);
+void launch_fixup(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* fix_slots, const float* ws_all, int64_t ws_slab_stride, float* C, int64_t ldc,
+                  int c_row_major, int accumulate);
+void launch_tail_copy(hipStream_t st, const float* B, int64_t ldb, int b_row_major, int64_t row0, int64_t cols, int w, int N, float* B_tail);
+void launch_zero_rows(dim3 grid, hipStream_t st, float* C, int64_t ldc, int c_row_major, int64_t row0, int64_t nrows, int N);
+// k_h16.hip
+void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
+bool h16_uses_direct_kernel(int kp, bool mi2);
+void launch_tail_copy_h16(hipStream_t st, const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N, uint16_t* B_tail);
+void launch_convert_h16(bool bf16, hipStream_t st, const float* src, int64_t ld_in, int64_t rows, int64_t n_cols, uint16_t* dst, int64_t ld_out);
+// k_sparse.hip
+void launch_sparse_kernels(int vec, int bk, const SparseParams& q, unsigned gy, hipStream_t st, const int32_t* list, int64_t n_short, const SpSegRec* segs,
+                           int64_t n_segs, const SpLongRec* longs, int64_t n_long, float* part);
+void launch_b_to_row_major(bool is16, unsigned grid, hipStream_t st, const void* B, int64_t ldb, int64_t shard_rows, int64_t shard_stride, int64_t rows, int N,
+                           void* out);
+void launch_c_scatter(unsigned grid, hipStream_t st, const float* src, const int32_t* crow, int64_t n_rows, int N, float* C, int64_t ldc, int accumulate);
+void launch_pack_blocks(dim3 grid, hipStream_t st, const void* src, const int32_t* ids, void* dst, int64_t block_vec);
+
+// vbs_plan.cpp
+struct StreamPlanIn {
+    int64_t cols, w, br0, br1, jab_lo, mab_lo;
+    const int64_t* row_part; const int64_t* nzcount; const int64_t* jab; const float* mab;
+    int32_t dtype, device;
+    const uint8_t* skip;                      // [br1 - br0] block-rows handled by the sparse-row path (no tiles), or nullptr
+};
+struct StreamPlanHost {
+    std::vector<StepRec> steps[2];            // per tile type: [0] <= 32 rows, [1] 33..64 rows
+    std::vector<int32_t> wrange[2];           // [2 * n_workers] begin / end step of every worker
+    std::vector<FixRec> fix;                  // split tiles + tiles of block-rows without blocks (zero fill)
+    std::vector<std::pair<int64_t, int64_t>> zero_ranges;   // (first row, rows) of long block-rows without blocks: vbs_zero_rows_kernel instead of fix-up tiles
+    std::vector<int32_t> fix_slots;
+    std::vector<uint16_t> a16;                // 16-bit handles: A re-laid-out as dense row-major TM x kp slices, one per step
+    int n_workers = 0, n_split = 0;
+    int plan_aligned[2] = {0, 0};
+    int64_t kp = SK_KP;
+};
+constexpr int64_t kZeroRangeRows = 2048;    // block-rows without blocks at least this tall are zero-filled by vbs_zero_rows_kernel
+int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P);
+uint16_t to_h16(float v, bool bf16);   // fp32 -> fp16 / bf16 bits, round to nearest even (what the device conversion kernel does too)
+
+}  // namespace sparta_dev

@@ -1,0 +1,280 @@
+// vbs_plan.cpp -- host side of the stream kernels: the plan.  Flattens the row tiles of a VBS (or of a block-row range of it)
+// into step lists, cuts them into worker ranges (aligned / split), records the split tiles for the fix-up and, for 16-bit
+// handles, packs A into per-step slices.  Plain host C++ (no kernel, no HIP call).  See DESIGN.md section 3.2 (2).
+#include "vbs_device.hpp"
+
+namespace sparta_dev {
+
+// fp32 -> fp16 / bf16 bits, round to nearest even (what the device conversion kernel does too)
+uint16_t to_h16(float v, bool bf16) {
+    if (bf16) {
+        uint32_t u;
+        std::memcpy(&u, &v, 4);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+        return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    const _Float16 h = (_Float16)v;
+    uint16_t o;
+    std::memcpy(&o, &h, 2);
+    return o;
+}
+
+int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
+    using sparta::fail;
+    const int64_t cols = in.cols, w = in.w, br0 = in.br0, br1 = in.br1, jab_lo = in.jab_lo, mab_lo = in.mab_lo;
+    const int64_t* row_part = in.row_part; const int64_t* nzcount = in.nzcount; const int64_t* jab = in.jab; const float* mab = in.mab;
+    const int32_t dtype = in.dtype, device = in.device;
+    const bool h16 = dtype != SPARTA_F32;
+    std::vector<StepRec>(&steps)[2] = P.steps;
+    std::vector<int32_t>(&wrange)[2] = P.wrange;
+    std::vector<FixRec>& fix = P.fix;
+    std::vector<int32_t>& fix_slots = P.fix_slots;
+    std::vector<uint16_t>& a16 = P.a16;
+    int& n_workers = P.n_workers; int& n_split = P.n_split;
+    int(&plan_aligned)[2] = P.plan_aligned;
+    // ---- stream plans (persistent kernels): flatten tiles into 32-deep steps, cut into equal-cost worker ranges ----
+    // One plan per tile TYPE: ty = 1 tiles of 33..64 rows (two 32-row MFMA tiles per wave and step), ty = 0 tiles of
+    // <= 32 rows (one).  Each type runs in its own launch of a kernel instantiated for that type only.  A single kernel
+    // that picks the variant per step looks equivalent but compiles badly: at every join of the two variants the register
+    // allocator reconciles the in-flight A/B registers and the accumulators with v_mov behind s_waitcnt vmcnt(0) / the
+    // MFMA drain, which collapses the 3-step prefetch (measured: 72 non-MFMA VALU per step, 69 % of the matrix peak).
+    // k depth of a step: 32 for fp32; the 16-bit kernels take 64 when the block width allows (their steps are short: fewer, fatter)
+    const int64_t kp = !h16 ? SK_KP : (w % 64 == 0 ? 64 : 32);
+    P.kp = kp;
+    if (w % SK_KP == 0) {
+        hipDeviceProp_t prop;
+        int cus = 256;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        int per_cu = 2;
+        if (const char* e = std::getenv("SPARTA_WORKERS_PER_CU")) per_cu = std::max(1, std::min(3, atoi(e)));
+        n_workers = ((cus * per_cu + 7) / 8) * 8;
+        // modelled cost of a step and of a tile's epilogue, per type
+        int c2 = 20, c1 = 13, ct = 6;
+        if (h16) { c2 = 12; c1 = 10; }                   // load-bound steps: cost ~ bytes moved, (64 + 128) vs (32 + 128) rows and columns
+        if (const char* e = std::getenv("SPARTA_COST_MODEL")) sscanf(e, "%d,%d,%d", &c2, &c1, &ct);
+        int64_t split_penalty = 120;                     // cost units (~0.11 us each) the fix-up launch adds to a split plan
+        if (const char* e = std::getenv("SPARTA_SPLIT_PENALTY")) split_penalty = atoll(e);
+        bool interleave = false;                         // SPARTA_STREAM_INTERLEAVE=1: deal whole tiles round-robin inside an XCD (measured: +-2 %, L2 locality is not the limit)
+        if (const char* e = std::getenv("SPARTA_STREAM_INTERLEAVE")) interleave = atoi(e) != 0;
+        double slot_bias = 0.0;                          // SPARTA_SLOT_BIAS: extra share of the workgroup dispatched first onto a CU
+        if (const char* e = std::getenv("SPARTA_SLOT_BIAS")) slot_bias = std::max(-0.9, std::min(0.9, atof(e)));
+        int align_mode = -1;                             // SPARTA_STREAM_ALIGN=0 always split, 1 never split, unset: cheaper one
+        if (const char* e = std::getenv("SPARTA_STREAM_ALIGN")) align_mode = atoi(e) ? 1 : 0;
+        if ((int64_t)cols > INT32_MAX)
+            return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: matrix too large for 32-bit step indexing");
+        for (int ty = 0; ty < 2; ty++) {
+            std::vector<StepRec>& st = steps[ty];
+            struct TileSpan { int64_t first, last; int32_t c_row, mt; };     // step range of a tile
+            std::vector<TileSpan> spans;
+            std::vector<int64_t> cum;                                        // cumulative cost BEFORE step s
+            int64_t total_cost = 0;
+            {
+                int64_t jo2 = 0, mo2 = 0;
+                const int64_t row0 = row_part[br0];
+                for (int64_t ib = br0; ib < br1; ib++) {
+                    const int64_t h = row_part[ib + 1] - row_part[ib];
+                    const int64_t nb = nzcount[ib];
+                    const bool skipped = in.skip && in.skip[ib - br0];
+#ifdef SPARTA_TIMELINE                              // developer build only (make timeline): a probe makes the products WRONG on purpose
+                    const int dbg_probe = [] { const char* e = std::getenv("SPARTA_DBG_PROBE"); return e ? atoi(e) : 0; }();
+#else
+                    constexpr int dbg_probe = 0;
+#endif
+                    const bool zero_range = nb == 0 && !skipped && h >= kZeroRangeRows;     // one streamed fill instead of h / 64 fix-up tiles
+                    if (zero_range && ty == 0) P.zero_ranges.emplace_back(row_part[ib] - row0, h);
+                    for (int64_t r0 = 0; r0 < h && !skipped && !zero_range; r0 += SK_TM) {
+                        const int32_t mt = (int32_t)std::min<int64_t>(SK_TM, h - r0);
+                        if ((mt > 32 ? 1 : 0) != ty) continue;
+                        const int32_t c_row = (int32_t)(row_part[ib] - row0 + r0);
+                        if (nb == 0) {                                      // nothing to multiply: the fix-up kernel writes the zeros
+                            fix.push_back(FixRec{c_row, mt, 0, 0});
+                            continue;
+                        }
+                        TileSpan sp{(int64_t)st.size(), 0, c_row, mt};
+                        for (int64_t b = 0; b < nb; b++) {
+                            const int64_t jb = jab[jab_lo + jo2 + b];
+                            for (int64_t ks = 0; ks < w; ks += kp) {
+                                StepRec r;
+                                r.a_off = mo2 + r0 + (b * w + ks) * h;
+                                if (h16) {                                  // pack this step's slice: [row][k], rows past the tile zero
+                                    const int64_t tms = ty ? 64 : 32;
+                                    r.a_off = (int64_t)a16.size();
+                                    a16.resize(a16.size() + (size_t)(tms * kp), 0);
+                                    uint16_t* dst = a16.data() + r.a_off;
+                                    const float* blk = mab + mab_lo + mo2 + b * h * w;       // column-major h x w block
+                                    for (int64_t rr = 0; rr < mt; rr++)
+                                        for (int64_t kk = 0; kk < kp; kk++)
+                                            dst[rr * kp + kk] = to_h16(blk[(ks + kk) * h + r0 + rr], dtype == SPARTA_BF16);
+                                }
+                                r.b_row = (int32_t)(jb * w + ks);
+                                r.h = (int32_t)h;
+                                r.c_row = c_row;
+                                r.mt_flags = mt;
+                                if ((jb + 1) * w > cols) { r.mt_flags |= STEP_TAIL; r.b_row = (int32_t)ks; }   // read from the zero-padded B_tail
+                                r.slot = -1;
+                                r.pad = 0;
+                                if (dbg_probe) {                            // developer probe (timing only, results are wrong): which stream bounds a step
+                                    if (dbg_probe & 1) r.b_row = (int32_t)ks;                                   // every panel of B is the same (cache-hot) one
+                                    if ((dbg_probe & 2) && h16) r.a_off = (b * w + ks) / kp * (ty ? 64 : 32) * kp;   // every tile reads the first slices of A
+                                    if ((dbg_probe & 2) && !h16) r.a_off = r0 + (b * w + ks) * h;
+                                    if (dbg_probe & 4) r.c_row = 0;                                             // every tile writes the first rows of C
+                                }
+                                cum.push_back(total_cost);
+                                total_cost += ty ? c2 : c1;
+                                st.push_back(r);
+                            }
+                        }
+                        total_cost += ct;
+                        sp.last = (int64_t)st.size() - 1;
+                        st[(size_t)sp.first].mt_flags |= STEP_FIRST;
+                        st[(size_t)sp.last].mt_flags |= STEP_LAST;
+                        spans.push_back(sp);
+                    }
+                    jo2 += nb;
+                    mo2 += nb * h * w;
+                }
+            }
+            if ((int64_t)st.size() > INT32_MAX - 64)
+                return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: matrix too large for 32-bit step indexing");
+            const int64_t S = (int64_t)st.size();
+            if (S == 0) continue;
+            cum.push_back(total_cost);
+            // boundaries: worker (x, j) = the j-th of the P/8 sub-ranges of XCD x's eighth; workgroup id = x + 8 j
+            const int per_x = n_workers / 8;
+            std::vector<int64_t> bnd((size_t)n_workers + 1, S);
+            bnd[0] = 0;
+            // Share of a worker.  The two (three) workgroups that share a CU do not progress at the same rate: the SIMD arbiter
+            // serves the OLDER wave first, so the workgroup dispatched first (j < #CU per XCD) runs ahead -- measured on equal
+            // ranges: the older one finished 512 steps in ~780 us, the younger one in 1030 us, the last 250 us alone on the CU at
+            // single-occupancy speed.  Give the older one `slot_bias` more work and the younger one as much less.
+            std::vector<double> wpos((size_t)n_workers, 1.0), wcum((size_t)n_workers + 1, 0.0);
+            {
+                const int cus_x = std::max(1, per_x / per_cu);
+                for (int pos = 0; pos < n_workers; pos++) {
+                    const int slot = std::min(per_cu - 1, (pos % per_x) / cus_x);
+                    wpos[(size_t)pos] = per_cu == 1 ? 1.0 : 1.0 + slot_bias * (1.0 - 2.0 * slot / (double)(per_cu - 1));
+                }
+                for (int pos = 0; pos < n_workers; pos++) wcum[(size_t)pos + 1] = wcum[(size_t)pos] + wpos[(size_t)pos];
+            }
+            for (int k = 1; k < n_workers; k++) {
+                const int64_t target = (int64_t)((double)total_cost * wcum[(size_t)k] / wcum[(size_t)n_workers]);
+                int64_t pos = std::lower_bound(cum.begin(), cum.end(), target) - cum.begin();
+                bnd[(size_t)k] = std::min<int64_t>(std::max(pos, bnd[(size_t)k - 1]), S);
+            }
+            // Alternative: ranges that end on tile boundaries (no split tile, no fix-up launch).  Splitting balances to one
+            // step but pays the fix-up (a second launch that re-reads the partial images: ~10 us measured, `split_penalty`
+            // cost units); whole tiles cost at most one tile of imbalance.  Many short tiles -> aligned; few long -> split.
+            {
+                const int64_t step_cost = ty ? c2 : c1;
+                auto tile_cost = [&](size_t t) { return (spans[t].last - spans[t].first + 1) * step_cost + ct; };
+                int64_t lo = 0, hi = total_cost * 2;
+                for (size_t t = 0; t < spans.size(); t++) lo = std::max(lo, tile_cost(t));
+                auto cap = [&](int64_t L, int64_t bin) { return bin < n_workers ? (int64_t)((double)L * wpos[(size_t)bin]) : L; };
+                auto bins_needed = [&](int64_t L) {                 // bin b holds at most L x (its worker's share)
+                    int64_t bins = 1, cur = 0;
+                    for (size_t t = 0; t < spans.size(); t++) {
+                        const int64_t c = tile_cost(t);
+                        if (cur > 0 && cur + c > cap(L, bins - 1)) { bins++; cur = 0; }
+                        cur += c;
+                    }
+                    return bins;
+                };
+                while (lo < hi) {                                   // smallest makespan L that fits n_workers contiguous bins
+                    const int64_t mid = lo + (hi - lo) / 2;
+                    if (bins_needed(mid) <= n_workers) hi = mid; else lo = mid + 1;
+                }
+                const int64_t split_makespan = (total_cost + n_workers - 1) / n_workers + split_penalty;
+                const bool aligned = align_mode == 1 || (align_mode < 0 && lo <= split_makespan);
+                if (aligned) {
+                    std::fill(bnd.begin(), bnd.end(), S);
+                    bnd[0] = 0;
+                    int64_t bin = 0, cur = 0;
+                    for (size_t t = 0; t < spans.size(); t++) {
+                        const int64_t c = tile_cost(t);
+                        if (cur > 0 && cur + c > cap(lo, bin) && bin + 1 < n_workers) { bin++; bnd[(size_t)bin] = spans[t].first; cur = 0; }
+                        cur += c;
+                    }
+                    if (interleave) {
+                        // Whole tiles can go to any worker.  Keep the 64 workers of an XCD close together in the matrix at every
+                        // moment: the XCD takes a contiguous eighth of the tiles (by cost) and deals them, in matrix order, to
+                        // its least-loaded worker (uniform tiles: worker j gets tiles j, j+64, ...).  The B rows the XCD
+                        // touches at one time are then a narrow moving window that stays in its 4 MB L2, instead of 64
+                        // windows spread over the whole eighth.  The step list is rebuilt in worker order.
+                        std::vector<std::vector<size_t>> mine((size_t)n_workers);
+                        size_t t = 0;
+                        int64_t seen = 0;
+                        for (int x = 0; x < 8; x++) {
+                            const int64_t upto = total_cost * (x + 1) / 8;
+                            std::vector<int64_t> load((size_t)per_x, 0);
+                            while (t < spans.size() && (x == 7 || seen + tile_cost(t) / 2 <= upto)) {
+                                size_t best = 0;
+                                for (size_t j = 1; j < load.size(); j++) if (load[j] < load[best]) best = j;
+                                mine[(size_t)x * per_x + best].push_back(t);
+                                load[best] += tile_cost(t);
+                                seen += tile_cost(t);
+                                t++;
+                            }
+                        }
+                        std::vector<StepRec> ns;
+                        std::vector<TileSpan> nspans;
+                        ns.reserve(st.size());
+                        nspans.reserve(spans.size());
+                        for (int pos = 0; pos < n_workers; pos++) {
+                            bnd[(size_t)pos] = (int64_t)ns.size();
+                            for (size_t tt : mine[(size_t)pos]) {
+                                TileSpan sp = spans[tt];
+                                const int64_t len = sp.last - sp.first + 1;
+                                ns.insert(ns.end(), st.begin() + sp.first, st.begin() + sp.last + 1);
+                                sp.first = (int64_t)ns.size() - len;
+                                sp.last = (int64_t)ns.size() - 1;
+                                nspans.push_back(sp);
+                            }
+                        }
+                        bnd[(size_t)n_workers] = S;
+                        st.swap(ns);
+                        spans.swap(nspans);
+                    }
+                }
+                plan_aligned[ty] = aligned ? 1 : 0;
+            }
+            wrange[ty].assign((size_t)n_workers * 2, 0);
+            std::vector<int32_t> wid_of_pos((size_t)n_workers);
+            for (int pos = 0; pos < n_workers; pos++) {
+                const int x = pos / per_x, j = pos % per_x;
+                const int wid = x + 8 * j;
+                wid_of_pos[(size_t)pos] = wid;
+                wrange[ty][(size_t)wid * 2] = (int32_t)bnd[(size_t)pos];
+                wrange[ty][(size_t)wid * 2 + 1] = (int32_t)bnd[(size_t)pos + 1];
+            }
+            // segments: a tile cut by a boundary is split; every segment writes one workspace image
+            // (slots are numbered densely over both types: both launches finish before the fix-up kernel reads them)
+            size_t ti = 0;
+            for (int pos = 0; pos < n_workers; pos++) {
+                const int64_t s0 = bnd[(size_t)pos], s1 = bnd[(size_t)pos + 1];
+                if (s0 >= s1) continue;
+                while (ti < spans.size() && spans[ti].last < s0) ti++;
+                for (size_t t = ti; t < spans.size() && spans[t].first < s1; t++) {
+                    const int64_t a = std::max(spans[t].first, s0), b = std::min(spans[t].last, s1 - 1);
+                    const bool whole = a == spans[t].first && b == spans[t].last;
+                    st[(size_t)a].mt_flags |= STEP_FIRST;
+                    st[(size_t)b].mt_flags |= STEP_LAST;
+                    if (!whole) {
+                        const int32_t slot = (int32_t)fix_slots.size();          // dense: one image per segment, both types
+                        st[(size_t)b].mt_flags |= STEP_SPLIT;
+                        st[(size_t)b].slot = slot;
+                        if (a == spans[t].first) {                          // first segment of the tile opens its fix-up record
+                            fix.push_back(FixRec{spans[t].c_row, spans[t].mt, (int32_t)fix_slots.size(), 0});
+                            n_split++;
+                        }
+                        fix_slots.push_back(slot);
+                        fix.back().n_slots++;
+                    }
+                }
+            }
+        }
+    }
+
+    return SPARTA_OK;
+}
+
+}  // namespace sparta_dev

@@ -138,10 +138,15 @@ class DeviceVBS:
         want_b = {_lib.F32: torch.float32, _lib.F16: torch.float16, _lib.BF16: torch.bfloat16}[self.dtype]
         if not (B_gathered.is_cuda and C_out.is_cuda and B_gathered.dtype == want_b and C_out.dtype == torch.float32):
             raise ValueError("B_gathered must be a %s tensor and C a float32 tensor, both on the GPU" % want_b)
+        if B_gathered.device.index != self.device or C_out.device.index != self.device:
+            raise ValueError("B_gathered and C must live on device %d" % self.device)
         shard_stride = shard_rows * n_cols if shard_stride is None else shard_stride
         if B_gathered.numel() < (self.cols // shard_rows) * shard_stride:
             raise ValueError("B_gathered too small")
         ldc = self.rows if c_layout == _lib.COL_MAJOR else n_cols
+        need_c = ldc * (n_cols if c_layout == _lib.COL_MAJOR else self.rows)
+        if C_out.numel() < need_c or not B_gathered.is_contiguous() or not C_out.is_contiguous():
+            raise ValueError("C too small / B_gathered or C not contiguous")
         st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
         dt = C.c_float(0)
         check(lib.sparta_vbs_spmm_gathered(self.h, C.c_void_p(B_gathered.data_ptr()), int(shard_rows), int(shard_stride), int(n_cols),

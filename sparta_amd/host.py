@@ -207,7 +207,15 @@ class VBR:
         self.block_col_size = 0
         self.nztot = 0
         self.nzcount = self.jab = self.row_part = self.mab = None
-        self._dev = None
+        self._dev = self._dev_t = None
+
+    def _drop_device_images(self):
+        """the cached device handles (of A for multiply, of A^T for multiply_BA) describe the OLD arrays: close and forget both"""
+        for name in ("_dev", "_dev_t"):
+            d = getattr(self, name, None)
+            if d is not None:
+                d.close()
+            setattr(self, name, None)
 
     def fill_from_CSR_inplace(self, cmat, grouping, col_block_size, row_block_size=0, force_fixed_size=False):
         """VBR::fill_from_CSR_inplace (include/matrices.h:118, vbr.cpp:135-237)"""
@@ -227,8 +235,43 @@ class VBR:
             self.mab = np.ctypeslib.as_array(h.mab, (max(h.nztot, 1),))[:h.nztot].copy()
         finally:
             lib.sparta_vbs_host_free(C.byref(h))
-        self._dev = None
+        self._drop_device_images()
         return self
+
+    def _take(self, h):
+        self.rows, self.cols = h.rows, h.cols
+        self.block_rows, self.block_cols = h.block_rows, h.block_cols
+        self.block_col_size, self.nztot = h.block_col_size, h.nztot
+        self.row_part = np.ctypeslib.as_array(h.row_part, (h.block_rows + 1,)).copy()
+        self.nzcount = np.ctypeslib.as_array(h.nzcount, (max(h.block_rows, 1),))[:h.block_rows].copy()
+        self.jab = np.ctypeslib.as_array(h.jab, (max(h.nblocks, 1),))[:h.nblocks].copy()
+        self.mab = np.ctypeslib.as_array(h.mab, (max(h.nztot, 1),))[:h.nztot].copy()
+
+    def fill_from_CSR(self, cmat, row_partition, block_size):
+        """VBR::fill_from_CSR (include/matrices.h:117, vbr.cpp:239-321): rows stay in their order, block-rows from a row partition"""
+        rp = np.ascontiguousarray(row_partition, np.int64)
+        h = _lib.VbsHost()
+        check(lib.sparta_vbs_build_partition(cmat.rows, cmat.cols, _p64(cmat.rowptr), _p32(cmat.colidx), _pf(cmat.vals), _p64(rp), len(rp),
+                                             int(block_size), C.byref(h)))
+        try:
+            self._take(h)
+        finally:
+            lib.sparta_vbs_host_free(C.byref(h))
+        self._drop_device_images()
+        return self
+
+    def get_block_start(self, row_block_idx):
+        """VBR::get_block_start (vbr.cpp:33-49): element offset into mab of block-row `row_block_idx`; out of range -> 0 (the
+        reference prints "[RANGE ERROR]" and returns mab itself)"""
+        if row_block_idx < 0 or row_block_idx >= self.block_rows:
+            return 0
+        h = np.diff(self.row_part[:row_block_idx + 1])
+        return int((h * self.nzcount[:row_block_idx]).sum() * self.block_col_size)
+
+    def partition_check(self, candidate_part):
+        """VBR::partition_check (vbr.cpp:108-118): 0 valid, 1 empty, 2 last entry != rows, 3 decreasing"""
+        p = np.ascontiguousarray(candidate_part, np.int64)
+        return int(lib.sparta_vbs_partition_check(_p64(p), len(p), int(self.rows)))
 
     def fill_from_CSR_inplace_fixed(self, cmat, row_block_size, col_block_size, force_fixed_size=False):
         """the fixed-grid overload (vbr.cpp:121-132): grouping[i] = i / row_block_size"""
@@ -246,6 +289,7 @@ class VBR:
         v.block_rows = len(v.nzcount)
         v.block_cols = (v.cols - 1) // v.block_col_size + 1
         v.nztot = len(v.mab)
+        v._drop_device_images()
         return v
 
     def _host_struct(self):

@@ -20,15 +20,23 @@ def _kernel_metadata(tmp_path):
     tools = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
     if not os.path.exists(lib) or not all(os.path.exists(t) for t in tools):
         pytest.skip("library or LLVM binutils not available")
-    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    fat = str(tmp_path / "fat.bin")
     subprocess.run([tools[0], "--dump-section", ".hip_fatbin=" + fat, lib], check=True)
-    subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co], check=True)
-    notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
+    # one offload bundle per kernel translation unit (k_*.hip), back to back in the section
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert starts, "no offload bundle in libsparta_amd.so"
     kernels = {}
-    for block in re.split(r"\n  - \.agpr_count:", notes)[1:]:
-        name = re.search(r"\.name:\s+(\S+)", block).group(1)
-        kernels[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
-                         for k in ("private_segment_fixed_size", "group_segment_fixed_size", "vgpr_spill_count", "vgpr_count")}
+    for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+        piece, co = str(tmp_path / ("bundle%d.bin" % n)), str(tmp_path / ("dev%d.co" % n))
+        open(piece, "wb").write(blob[a:b])
+        subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + piece, "--output=" + co], check=True)
+        notes = subprocess.run([tools[2], "--notes", co], check=True, capture_output=True, text=True).stdout
+        for block in re.split(r"\n  - \.agpr_count:", notes)[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block).group(1)
+            kernels[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
+                             for k in ("private_segment_fixed_size", "group_segment_fixed_size", "vgpr_spill_count", "vgpr_count")}
     return kernels
 
 

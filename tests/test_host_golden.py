@@ -243,3 +243,62 @@ def test_minhash_regression_fixture():
         g, cmp_, mrg = mod.run(c)
         assert bytes(fx["sha%d" % i]) == hashlib.sha256(g.tobytes()).digest(), c
         assert fx["stat%d" % i].tolist() == [cmp_, mrg, len(np.unique(g))]
+
+
+# ---- VBR::fill_from_CSR / get_block_start / partition_check (vbr.cpp:239-321, 33-49, 108-118) --------------------------------
+def _random_partition(rng, rows, n_cuts, repeats=0):
+    cuts = np.sort(rng.choice(np.arange(1, rows), size=min(n_cuts, rows - 1), replace=False))
+    part = np.concatenate([[0], cuts, [rows]]).astype(np.int64)
+    if repeats:                                   # repeated entries = block-rows of height 0
+        part = np.sort(np.concatenate([part, rng.choice(part, size=repeats)]))
+    return part
+
+
+@pytest.mark.parametrize("name,bs", [("u256", 16), ("rect", 7), ("band1k", 32), ("fem", 3)])
+def test_fill_from_csr_partition_matches_the_compiled_reference(name, bs):
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("compiled reference not present")
+    m = U.matrices()[name]
+    rng = np.random.default_rng(5)
+    for trial in range(3):
+        part = _random_partition(rng, m.rows, 9 + 20 * trial, repeats=2 * trial)
+        vb = sa.VBR().fill_from_CSR(m, part, bs)
+        rc = ref.RefCSR(m.rows, m.cols, m.rowptr, m.colidx.astype(np.int64), m.vals)
+        rv = ref.RefVBR(rc, None, bs, row_partition=part)
+        rp, nz, jab, mab = rv.export()
+        assert (vb.rows, vb.cols, vb.block_rows, vb.block_cols, vb.block_col_size, vb.nztot) == \
+               (rv.rows, rv.cols, rv.block_rows, rv.block_cols, rv.block_col_size, rv.nztot)
+        assert np.array_equal(vb.row_part, rp) and np.array_equal(vb.nzcount, nz) and np.array_equal(vb.jab, jab)
+        assert np.array_equal(vb.mab, mab)
+        for ib in (0, 1, vb.block_rows // 2, vb.block_rows - 1, vb.block_rows, vb.block_rows + 3):
+            assert vb.get_block_start(ib) == rv.block_start(ib), ib
+        for cand in (part, part[:-1], part[::-1].copy(), np.zeros(0, np.int64), np.array([0, m.rows], np.int64)):
+            assert vb.partition_check(cand) == rv.partition_check(cand)
+
+
+def test_fill_from_csr_partition_properties():
+    """no compiled reference needed: the partition build holds exactly the matrix (rows in place, column-major blocks, vbr.cpp:307),
+    and bad partitions are refused"""
+    m = U.matrices()["u256"]
+    part = np.arange(0, m.rows + 1, 8, dtype=np.int64)
+    w = 16
+    vb = sa.VBR().fill_from_CSR(m, part, w)
+    dense = np.zeros((m.rows, m.cols), np.float32)
+    for i in range(m.rows):
+        dense[i, m.colidx[m.rowptr[i]:m.rowptr[i + 1]]] = m.vals[m.rowptr[i]:m.rowptr[i + 1]]
+    back = np.zeros_like(dense)
+    jo = mo = 0
+    for ib in range(vb.block_rows):
+        r0, r1 = int(vb.row_part[ib]), int(vb.row_part[ib + 1])
+        for b in range(int(vb.nzcount[ib])):
+            jb = int(vb.jab[jo + b])
+            blk = vb.mab[mo:mo + (r1 - r0) * w].reshape(w, r1 - r0).T          # column-major h x w
+            back[r0:r1, jb * w:(jb + 1) * w] = blk[:, :min(w, m.cols - jb * w)]
+            mo += (r1 - r0) * w
+        jo += int(vb.nzcount[ib])
+    assert np.array_equal(back, dense) and mo == vb.nztot
+    assert vb.partition_check(part) == 0 and vb.partition_check(part[:-1]) == 2 and vb.partition_check(part[::-1].copy()) == 2
+    assert vb.partition_check(np.array([0, 9, 5, m.rows], np.int64)) == 3 and vb.partition_check(np.zeros(0, np.int64)) == 1
+    with pytest.raises(sa.SpartaError):
+        sa.VBR().fill_from_CSR(m, part[:-1], 16)
