@@ -9,18 +9,29 @@
 A "step" is one pass of the hot path over one batch of synthetic input: C = A_vbs * B with A already reordered
 (Jaccard row clustering), built into VBS and resident in HBM, B and C resident in HBM.
 
-  N = 1  : BASELINE.json configs[1] -- SuiteSparse `cant` shape (62 451^2, 3-dof FEM, ~4.3 M nnz; generated, there is no
-           network), B = 128 dense columns, fp32, reference layouts (B, C column-major).
-  N > 1  : weak scaling of the same workload: the mesh grows N x along z, rank r owns row slab r of A and the matching
-           row shard of B; each step = ONE collective on B over RCCL/xGMI + the local SpMM; no collective on C.
-           --exchange allgather : B replicated by one all-gather (what a slab that touches all of B needs);
-           --exchange blocks    : one all-to-all of only the row-blocks of B each slab touches (plan-time lists), overlapped
-                                  with the product against the rank's own shard (sparta_amd/dist.py: RowBlockExchange);
-           --exchange auto      : blocks when the slabs need < 50 % of the other shards, else allgather (default).
+Workloads (--workload; BASELINE.json `configs`):
+  cant       configs[1] (THE DEFAULT, what `value` is quoted on): SuiteSparse `cant` shape (62 451^2, 3-dof FEM, ~4.3 M nnz;
+             generated, there is no network), B = 128 dense columns, fp32, reference layouts (B, C column-major).
+             N > 1: weak scaling of the same workload (the mesh grows N x along z; one collective on B per step).
+  ogbn-like  configs[2]: ogbn-products-sized power-law graph (2 449 029^2, ~124 M nnz, values 1; the leading corner of an
+             R-MAT 2^22 graph, generated on the GPU), B = 256 columns, fp16 storage, fp32 accumulation.
+  rmat       configs[3] / configs[4]: R-MAT 2^scale (a, b, c = 0.57, 0.19, 0.19), --rmat-density D (e.g. 0.001 = 0.1 %: D * n^2
+             distinct nonzeros, generated on the GPU) or, without it, the round-1 miniature (10 edges per row, symmetrised);
+             B = --ncols columns in --dtype.  Reorder ON = blocking_algo 7 (LSH-bucketed Jaccard clustering), reorder OFF =
+             --fixed-height H (the reference's `-a 2 -F 1` arm: FixedBlocking, src/general/blocking.cpp:554-562); both arms go
+             through the same entry (sparta_vbs_create_from_csr) and the same multiply.
+             N > 1: STRONG scaling -- every rank generates the same seeded matrix and runs the same reorder, the block-rows
+             are split into N contiguous ranges of equal cost, B is row-sharded, ONE all-gather of B per step over RCCL, no
+             collective on C (configs[4]: --rmat-scale 23).
 
-value = useful GFLOP/s of the whole job = 2 * nnz * n_cols * n_gpus_units / time (dense-block padding is NOT counted).
-The JSON line also carries the roofline of the dominant kernel and a CPU baseline (the reference's own
-VBR::multiply, compiled from its sources into oracle/_ref, timed on this box's host).
+value = useful GFLOP/s of the whole job = 2 * nnz * n_cols / time (dense-block padding is NOT counted).  The JSON line also
+carries the roofline of the dominant kernel and a CPU baseline (the reference's own VBR::multiply compiled into oracle/_ref, or
+the oracle's restatement of it, timed on this box's host: 1 thread and all cores).
+
+Timing: a short untimed pre-roll (--settle-ms, default 300 ms of steps) brings the GPU out of its idle clock state -- a freshly
+leased board runs the first few thousand microseconds 20 % below its steady clock -- then W untimed warm-up steps, then
+EXACTLY K timed steps between barrier + synchronize fences.  HIP events recorded on the launch stream bracket the same K steps
+(`roofline.kernel_ms` when a step is one kernel launch).
 """
 import argparse
 import json
@@ -33,20 +44,22 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
-PEAK_CLOCK_MHZ = 2400.0        # the clock that peak is quoted at (256 CUs x 4 SIMD x 64 lanes x 2 flop x 2.4 GHz)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
+PEAK_MFMA_H16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: fp16 / bf16 dense MFMA peak (~2.5 PF; the 5 PF headline is 2:1 sparse)
+PEAK_CLOCK_MHZ = 2400.0        # the clock the MFMA peaks are quoted at
+HBM_BYTES = 288e9
 
 
-def mixed_roofline_seconds(row_part, nzcount, w, n_cols, cols, accumulate=False):
+def mixed_roofline_seconds(row_part, nzcount, w, n_cols, cols, accumulate=False, s_a=4.0, s_b=4.0, peak_tflops=PEAK_MFMA_F32_TFLOPS):
     """T_lb = sum over block-rows of max(bytes_alg / BW, flops_exec / P) + |B| / BW."""
     h = np.diff(np.asarray(row_part, np.int64)).astype(np.float64)
     nb = np.asarray(nzcount, np.float64)
     flops = 2.0 * nb * h * w * n_cols
-    byts = nb * h * w * 4.0 + nb * 4.0 + 16.0 + h * n_cols * 4.0 * (2.0 if accumulate else 1.0)
-    t = np.maximum(byts / (PEAK_HBM_GBS * 1e9), flops / (PEAK_MFMA_F32_TFLOPS * 1e12)).sum()
-    t += cols * n_cols * 4.0 / (PEAK_HBM_GBS * 1e9)
-    return float(t), float(flops.sum()), float(byts.sum() + cols * n_cols * 4.0)
+    byts = nb * h * w * s_a + nb * 4.0 + 16.0 + h * n_cols * 4.0 * (2.0 if accumulate else 1.0)
+    t = np.maximum(byts / (PEAK_HBM_GBS * 1e9), flops / (peak_tflops * 1e12)).sum()
+    t += cols * n_cols * s_b / (PEAK_HBM_GBS * 1e9)
+    return float(t), float(flops.sum()), float(byts.sum() + cols * n_cols * s_b)
 
 
 def _stage_collectives_through_host(dist, sa):
@@ -81,36 +94,51 @@ def _stage_collectives_through_host(dist, sa):
     sa.dist.RowBlockExchange._all_to_all = a2a
 
 
+def _emit(out):
+    # RCCL writes its version banner to C stdout (fully buffered when redirected: it would surface AFTER our line at exit).
+    # Flush C stdio first so that the JSON line is the last thing this process prints.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--tau", type=float, default=0.6)
-    ap.add_argument("--algo", type=int, default=5, help="reference BlockingType: 3 iterative_clocked, 5 iterative_max_size (Keeper)")
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="untimed pre-roll before the warm-up steps: run steps for about this long so that the GPU has left its idle clock state")
+    ap.add_argument("--tau", type=float, default=None)
+    ap.add_argument("--algo", type=int, default=None, help="reference BlockingType: 3 iterative_clocked, 5 iterative_max_size (Keeper); 7 = LSH-bucketed extension")
     ap.add_argument("--row-block", type=int, default=32, help="max / fixed block-row height (-B)")
-    ap.add_argument("--force-fixed", type=int, default=1, help="-F: re-chunk clusters into equal heights")
-    ap.add_argument("--col-block", type=int, default=32)
-    ap.add_argument("--dtype", choices=["f32", "f16", "bf16"], default="f32",
-                    help="storage type of A and B on the device (accumulation and C are always fp32)")
-    ap.add_argument("--ncols", type=int, default=128)
-    ap.add_argument("--fixed-height", type=int, default=0, help="reorder OFF: fixed block-row height instead of clustering")
+    ap.add_argument("--force-fixed", type=int, default=None, help="-F: re-chunk clusters into equal heights")
+    ap.add_argument("--col-block", type=int, default=None)
+    ap.add_argument("--dtype", choices=["f32", "f16", "bf16"], default=None,
+                    help="storage type of A and B on the device (accumulation and C are always fp32); default per workload")
+    ap.add_argument("--ncols", type=int, default=None)
+    ap.add_argument("--fixed-height", type=int, default=0, help="reorder OFF: fixed block-row height instead of clustering (-a 2 -F 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the steps from a captured HIP graph (measured: no gain -- the step is one 60 us kernel and eager launches already queue ahead)")
-    ap.add_argument("--workload", choices=["cant", "rmat"], default="cant",
-                    help="cant: BASELINE configs[1] (the default, what `value` is quoted on); rmat: configs[3] in miniature -- R-MAT 2^scale rows, "
-                         "10 edges per row symmetrised, reordered by blocking_algo 7 (single GPU; carried by the sparse-row kernels: roofline.bound = hbm)")
+    ap.add_argument("--workload", choices=["cant", "rmat", "ogbn-like"], default="cant")
     ap.add_argument("--rmat-scale", type=int, default=20)
+    ap.add_argument("--rmat-density", type=float, default=0.0, help="distinct nonzeros / n^2 (0.001 = 0.1 %%); 0 = 10 edges per row, symmetrised")
+    ap.add_argument("--host-gen", action="store_true", help="generate R-MAT on the host with numpy (small cases / no GPU generator)")
     ap.add_argument("--matrix", default=None,
                     help="run the single-GPU pipeline on a matrix file instead of the synthetic workload (.mtx MatrixMarket or .el edge list, read as "
                          "documented = SPARTA_IO_STRICT): e.g. the real SuiteSparse cant.mtx where a copy is at hand (none can be fetched here)")
     ap.add_argument("--exchange", choices=["auto", "allgather", "blocks"], default="auto",
-                    help="N > 1: how the ranks' shards of B reach the slabs (see the module docstring)")
+                    help="N > 1, workload cant: how the ranks' shards of B reach the slabs")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: DEBUG ONLY -- several ranks on ONE GPU (a one-GPU box), collectives staged through host memory; checks the "
                          "multi-rank logic end to end, its timings mean nothing")
-    ap.add_argument("--dist-path", action="store_true", help="run the multi-GPU code path (slab + all-gather + gathered SpMM) even with one rank")
+    ap.add_argument("--dist-path", action="store_true", help="run the multi-GPU code path even with one rank")
+    ap.add_argument("--check-rows", type=int, default=64, help="rmat / ogbn-like: rows of C checked against a float64 evaluation before timing")
     args = ap.parse_args()
 
     import torch
@@ -142,31 +170,75 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    # ---- per-workload defaults ----------------------------------------------------------------------------------------
+    power_law = args.workload in ("rmat", "ogbn-like") and not args.matrix
+    dflt = {"cant": dict(algo=5, tau=0.6, force_fixed=1, col_block=32, dtype="f32", ncols=128),
+            "rmat": dict(algo=7, tau=0.4, force_fixed=0, col_block=64, dtype="f32", ncols=128),
+            "ogbn-like": dict(algo=7, tau=0.4, force_fixed=0, col_block=64, dtype="f16", ncols=256)}[args.workload]
+    for k, v in dflt.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
     w, N = args.col_block, args.ncols
-    t0 = time.time()
+    h16 = args.dtype != "f32"
+    esz = 2.0 if h16 else 4.0
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
+    sdt = {"f32": sa.F32, "f16": sa.F16, "bf16": sa.BF16}[args.dtype]
+    if args.matrix and distributed:
+        raise SystemExit("--matrix is a single-GPU option")
+    if args.workload == "ogbn-like" and distributed:
+        raise SystemExit("--workload ogbn-like is a single-GPU option")
+
     # ---- workload ------------------------------------------------------------------------------------------------
-    rmat = args.workload == "rmat"
-    if rmat and distributed:
-        raise SystemExit("--workload rmat is a single-GPU option")
+    t0 = time.time()
+    gen_stats, n_local, shard_rows = None, None, None
     if args.matrix:
-        if distributed:
-            raise SystemExit("--matrix is a single-GPU option")
         fmt = sa._lib.FMT_MTX if args.matrix.lower().endswith(".mtx") else sa._lib.FMT_EL
         m = sa.CSR.read_from_edgelist(args.matrix, mat_fmt=fmt, mode=sa._lib.IO_STRICT)
-        n_local, shard_rows = m.rows, None
-        rmat = False
-    elif rmat:
-        m = sa.gen.rmat(args.rmat_scale, 10 << args.rmat_scale, seed=3, symmetrize=True, pattern_only=False)
-        n_local, shard_rows = m.rows, None
-        if args.algo == 5 and args.tau == 0.6 and w == 32:       # untouched defaults: the settings this workload is meant for
-            args.algo, args.tau, args.force_fixed, w = 7, 0.4, 0, 64
-            args.col_block = 64
+        wl_name = "%s (%d x %d, %d nnz)" % (os.path.basename(args.matrix), m.rows, m.cols, m.nztot())
+    elif args.workload == "ogbn-like":
+        m, gen_stats = sa.gen.ogbn_products_like(seed=3, device=local_rank, return_stats=True)
+        wl_name = "ogbn-products-like power-law graph (leading %d^2 corner of R-MAT 2^22, symmetrised, values 1: %d nnz)" % (m.rows, m.nztot())
+    elif args.workload == "rmat":
+        n = 1 << args.rmat_scale
+        if args.rmat_density > 0.0:
+            target = int(args.rmat_density * float(n) * float(n))
+            # what one GPU must hold for this density: the CSR on the device (column + 16/32-bit value per nonzero) + the generator's sort
+            need = target * (4.0 + esz) + 3.0 * 8.0 * target / max(1, 1)
+            if target * (4.0 + esz) > 0.8 * HBM_BYTES:
+                if rank == 0:
+                    _emit({"metric": "Block-sparse SpMM GFLOP/s", "value": None, "unit": "GFLOP/s", "n_gpus": n_gpus, "steps": 0, "warmup": 0,
+                           "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if distributed else "weak", "vs_baseline": None,
+                           "dtype": args.dtype, "data": "synthetic",
+                           "config": {"workload": "R-MAT 2^%d at density %g (%d nnz), B = %d cols, %s" % (args.rmat_scale, args.rmat_density, target, N, args.dtype),
+                                      "infeasible": "the CSR image alone is %.0f GB (column + value per nonzero): does not fit the 288 GB of one MI355X; "
+                                                    "not run, not shrunk" % (target * (4.0 + esz) / 1e9)},
+                           "roofline": None, "cpu_baseline": None})
+                if distributed:
+                    dist.destroy_process_group()
+                return
+            del need
+            if args.host_gen:
+                raise SystemExit("--host-gen has no density mode")
+            m, gen_stats = sa.gen.rmat_device(args.rmat_scale, target_nnz=target, seed=3, values="uniform", device=local_rank, return_stats=True)
+            wl_name = ("R-MAT 2^%d (a,b,c = 0.57,0.19,0.19) at density %.4g %% (%d^2, %d distinct nnz)"
+                       % (args.rmat_scale, 100.0 * m.nztot() / float(n) / float(n), m.rows, m.nztot()))
+        else:
+            if args.host_gen:
+                m = sa.gen.rmat(args.rmat_scale, 10 << args.rmat_scale, seed=3, symmetrize=True, pattern_only=False)
+            else:
+                m, gen_stats = sa.gen.rmat_device(args.rmat_scale, n_edges=10 << args.rmat_scale, seed=3, symmetrize=True, values="uniform",
+                                                  device=local_rank, return_stats=True)
+            wl_name = "R-MAT 2^%d (a,b,c = 0.57,0.19,0.19; 10 edges per row, symmetrised: %d^2, %d nnz)" % (args.rmat_scale, m.rows, m.nztot())
     elif not distributed:
         m = sa.gen.cant_like(seed=2)
-        n_local, shard_rows = m.rows, None
+        wl_name = "cant-like FEM 9x9x257 mesh x 3 dof (62451^2, %d nnz)" % m.nztot()
     else:
         m, n_local, shard_rows = sa.gen.fem3d_slab(9, 9, 257, rank, world, dof=3, pad_to=w, seed=2)
+        wl_name = None
     t_gen = time.time() - t0
+    nnz_global = m.nztot()
+
+    # ---- reorder (host) -------------------------------------------------------------------------------------------------
     t0 = time.time()
     if args.fixed_height:
         eng = sa.BlockingEngine(blocking_algo="fixed_size", row_block_size=args.fixed_height, col_block_size=w)
@@ -175,52 +247,88 @@ def main():
                                 force_fixed_size=bool(args.force_fixed), sim_measure=1)
     grouping = eng.GetGrouping(m)
     t_reorder = time.time() - t0
+    ff = bool(args.force_fixed) and not args.fixed_height
+    rbs = args.fixed_height if args.fixed_height else args.row_block
+
+    # ---- strong scaling over block-row ranges (power-law workloads, N > 1): this rank's slab --------------------------------
+    strong = power_law and distributed
+    perm_global = None
+    if strong:
+        perm_global = sa.get_permutation(grouping)
+        part = sa.get_partition(grouping)
+        rows_of = np.diff(m.rowptr)[perm_global]
+        cost_row = rows_of.astype(np.float64) + 1.0                       # nonzeros (gather traffic) + the row of C
+        cost_br = np.add.reduceat(cost_row, part[:-1]) if len(part) > 1 else np.zeros(0)
+        ranges = sa.dist.partition_by_cost(cost_br, world)
+        b0, b1 = ranges[rank]
+        my_rows = perm_global[part[b0]:part[b1]]                          # original row ids, in reordered order
+        shard_rows = sa.dist.padded_shard_rows(-(-m.cols // world), w)
+        m_full_cols = m.cols
+        m = sa.dist.row_slab(m, my_rows, world * shard_rows)              # rows of this rank, columns padded to world * shard_rows
+        gl = np.repeat(np.arange(b1 - b0, dtype=np.int64), np.diff(part[b0:b1 + 1]))
+        grouping = gl
+        n_local = m.rows
+    nnz_local = m.nztot()
+
+    # ---- VBS image on the device ------------------------------------------------------------------------------------------
     t0 = time.time()
-    vb = sa.VBR().fill_from_CSR_inplace(m, grouping, w, args.row_block, bool(args.force_fixed) and not args.fixed_height)
+    vb = None
+    if power_law or (args.matrix and args.workload != "cant"):
+        d = sa.DeviceVBS.from_csr(m, grouping, w, rbs, ff, device=local_rank, dtype=sdt)        # hybrid: nearly empty block-rows stay (column, value)
+        eng.grouping_result, eng.col_block_size = grouping, w
+        eng.CollectBlockingInfo(m)                                         # block count / stored area of the FULL VBS the reference would build
+        vbs_area_ref, vbs_blocks_ref = int(eng.VBR_nzcount), int(eng.VBR_nzblocks_count)
+        n_block_rows = len(np.unique(grouping)) if not args.fixed_height else -(-m.rows // args.fixed_height)
+    else:
+        vb = sa.VBR().fill_from_CSR_inplace(m, grouping, w, rbs, ff)
+        d = vb.to_device(local_rank, dtype=sdt)
+        vbs_area_ref, vbs_blocks_ref, n_block_rows = int(vb.nztot), int(len(vb.jab)), int(vb.block_rows)
     t_build = time.time() - t0
-    h16 = args.dtype != "f32"
-    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
-    d = vb.to_device(local_rank, dtype={"f32": sa.F32, "f16": sa.F16, "bf16": sa.BF16}[args.dtype])
     info = d.info()
+    rows_c, cols_a = info["rows"], info["cols"]
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    ldb = vb.cols
+    ldb = cols_a
+    B_shard = B_gath = None
     if not distributed:
-        B = (torch.rand(vb.cols * N, generator=g, dtype=torch.float32) - 0.5).to(dev)      # column-major, ld = cols
-        if h16:                                                # 16-bit B, leading dimension padded to a multiple of 8 elements
-            ldb = (vb.cols + 7) // 8 * 8
-            B32 = B
-            B = torch.zeros(ldb * N, dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16, device=dev)
-            B.view(N, ldb)[:, :vb.cols] = B32.view(N, vb.cols).to(B.dtype)
-        B_shard = B_gath = None
+        B32 = None
+        ldb = (cols_a + 7) // 8 * 8 if h16 else cols_a        # 16-bit B: leading dimension padded to a multiple of 8 elements
+        if cols_a * N <= (1 << 28):
+            B32 = (torch.rand(cols_a * N, generator=g, dtype=torch.float32) - 0.5).to(dev)      # column-major, ld = cols
+        else:                                                   # large B: generated on the device
+            gd = torch.Generator(device=dev).manual_seed(1234 + rank)
+            B32 = torch.rand(cols_a * N, generator=gd, dtype=torch.float32, device=dev) - 0.5
+        if h16:
+            B = torch.zeros(ldb * N, dtype=tdt, device=dev)
+            B.view(N, ldb)[:, :cols_a] = B32.view(N, cols_a).to(tdt)
+            del B32
+        else:
+            B = B32
     else:
         B_shard = (torch.rand(shard_rows * N, generator=g, dtype=torch.float32) - 0.5).to(dev).to(tdt)   # column-major, ld = shard_rows
         B_gath = torch.empty(world * shard_rows * N, dtype=tdt, device=dev)
-    C = torch.zeros(vb.rows * N, dtype=torch.float32, device=dev)
+        B = None
+    C = torch.zeros(rows_c * N, dtype=torch.float32, device=dev)
 
     # ---- N > 1: which exchange ------------------------------------------------------------------------------------
     ex, exchange, exchange_note, B_tiles = None, None, "", None
     if distributed:
         dist.all_gather_into_tensor(B_gath, B_shard)              # setup: reference result for the self-check, B for the CPU baseline
-        exchange = args.exchange
+        exchange = "allgather" if strong else args.exchange
         if exchange != "allgather":
             # the same shard in the row-block-tiled layout (block jb = one contiguous w x N column-major tile)
             B_tiles = B_shard.view(N, shard_rows // w, w).permute(1, 0, 2).contiguous().view(-1)
-            ex = sa.dist.RowBlockExchange(vb, rank, world, shard_rows, N, device=local_rank,
-                                          dtype={"f32": sa.F32, "f16": sa.F16, "bf16": sa.BF16}[args.dtype])      # collective: need lists
+            ex = sa.dist.RowBlockExchange(vb, rank, world, shard_rows, N, device=local_rank, dtype=sdt)      # collective: need lists
             if exchange == "auto":
                 exchange = "blocks" if ex.needed_fraction < 0.5 else "allgather"
         if exchange == "blocks":
-            # self-check on the real collective: both exchanges must give the same C (two partial sums vs one: fp32 re-association)
+            # self-check on the real collective: both exchanges must give the same C (two partial sums vs one: fp32 re-association).
+            # The collectives stay OUTSIDE any try block: a rank that failed locally still enters every collective its peers enter.
             d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False)
             C_chk = torch.empty_like(C)
-            err = float("inf")
-            try:
-                ex.step(B_tiles, C_chk)
-                torch.cuda.synchronize()
-                err = float((C_chk - C).abs().max() / C.abs().max().clamp_min(1e-30))
-            except Exception as e:                                 # reported, never silent: the line below names the fallback
-                print("rank %d: row-block exchange raised %r" % (rank, e), file=sys.stderr)
+            ex.step(B_tiles, C_chk)
+            torch.cuda.synchronize()
+            err = float((C_chk - C).abs().max() / C.abs().max().clamp_min(1e-30))
             ok = torch.tensor([1.0 if err < 1e-4 else 0.0], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if float(ok.item()) < 1.0:
@@ -252,11 +360,58 @@ def main():
     # sparta_vbs_create makes -- it must not land in the timed region when the caller asks for no warm-up.
     step()
     fence()
+
+    # ---- parity spot check for the generated power-law inputs (full-size parity lives in tests/; this guards the bench line) ----
+    check = None
+    if power_law and args.check_rows > 0:
+        Ch = None
+        rng = np.random.Generator(np.random.PCG64(11 + rank))
+        perm_l = sa.get_permutation(grouping)
+        pick = rng.integers(0, m.rows, size=min(args.check_rows, m.rows))
+        if distributed:
+            Bh_cols = lambda cols_i: sa.dist.gathered_rows(B_gath, cols_i, world, shard_rows, N)
+        else:
+            Bv = B.view(N, ldb)
+            Bh_cols = lambda cols_i: Bv[:, torch.from_numpy(cols_i.astype(np.int64)).to(dev)].float().cpu().numpy().astype(np.float64)
+        Cv = C.view(N, rows_c)
+        worst = 0.0
+        for r in pick:
+            i = perm_l[r]
+            cols_i = m.colidx[m.rowptr[i]:m.rowptr[i + 1]]
+            if len(cols_i) == 0:
+                got = Cv[:, int(r)].cpu().numpy()
+                worst = max(worst, float(np.abs(got).max()))
+                continue
+            a = (m.vals[m.rowptr[i]:m.rowptr[i + 1]] if m.vals is not None else np.ones(len(cols_i), np.float32))
+            a = torch.from_numpy(np.ascontiguousarray(a)).to(tdt).float().numpy().astype(np.float64)      # the stored (rounded) values
+            bb = Bh_cols(cols_i)                                                                          # N x nnz_i
+            want = bb @ a
+            scale_ = np.abs(bb) @ np.abs(a) + 1e-30
+            got = Cv[:, int(r)].cpu().numpy().astype(np.float64)
+            worst = max(worst, float((np.abs(got - want) / scale_).max()))
+        check = {"rows": int(len(pick)), "max_err_over_sum_abs": worst, "tolerance": 1e-5}
+        if not (worst <= 1e-5):
+            raise SystemExit("rank %d: parity spot check failed: %.3e of sum|a||b| (tolerance 1e-5)" % (rank, worst))
+        del Ch
+
+    # ---- pre-roll: leave the idle clock state (untimed, counted in `config.preroll_steps`) ------------------------------
+    preroll = 0
+    if args.settle_ms > 0:
+        t_pr = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        preroll = 1
+        batch = 8 if (time.perf_counter() - t_pr) < 2e-3 else 1
+        while (time.perf_counter() - t_pr) * 1e3 < args.settle_ms and preroll < 20000:
+            for _ in range(batch):
+                step()
+            preroll += batch
+            torch.cuda.synchronize()
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
-    # Optional: capture G consecutive steps in a HIP graph (sparta_vbs_spmm is stream-ordered and capture-safe once the
-    # plan-time autotune of the first call is over) and replay it K / G times: EXACTLY K steps in the timed region.
+    # Optional: capture G consecutive steps in a HIP graph and replay it K / G times: EXACTLY K steps in the timed region.
     graph, G = None, 1
     if not distributed and args.graph:
         G = max(g_ for g_ in range(1, 11) if args.steps % g_ == 0)
@@ -277,14 +432,18 @@ def main():
             print("HIP graph capture failed (%s); launching eagerly" % e, file=sys.stderr)
             graph, G = None, 1
     fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t_start = time.perf_counter()
+    ev0.record()                                             # HIP events on the launch stream around the same K steps
     if graph is not None:
         for _ in range(args.steps // G):
             graph.replay()
     for _ in range(0 if graph is not None else args.steps):
         step()
+    ev1.record()
     fence()
     elapsed = time.perf_counter() - t_start
+    event_ms_per_step = ev0.elapsed_time(ev1) / args.steps
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -294,7 +453,7 @@ def main():
     # ---- per-kernel device time (HIP events on the launch stream, one pair per kernel launch) ----------------------
     dmain.set_class_timing(True)
     kt, kc = {}, {}
-    for _ in range(min(args.steps, 50)):
+    for _ in range(min(max(args.steps, 10), 50)):
         step()
         for k, v in dmain.class_times().items():
             kt.setdefault(k, []).append(v)
@@ -304,30 +463,28 @@ def main():
     dmain.set_class_timing(False)
     kernel_ms = {k: float(np.mean(v)) for k, v in kt.items()}
     kernel_mhz = {k: float(np.mean(v)) for k, v in kc.items()}
-    # A step that is ONE kernel launch (aligned stream plan, one tile type): time a run of launches with one event pair on the
-    # launch stream instead of one pair per launch -- the per-launch pairs above add ~2 us of event traffic to a 60 us kernel.
+    # A step that is ONE kernel launch (aligned stream plan, one tile type, no sparse part): its duration is the event time
+    # around the timed region / K -- the per-launch pairs above add ~2 us of event traffic to a 60 us kernel.
     live = [k for k, v in kernel_ms.items() if v > 0]
     ntypes = int(info["tiles64"] > 0) + int(info["tiles16"] + info["tiles32"] > 0)
-    if not distributed and len(live) == 1 and (live[0] != "stream" or ntypes == 1):
-        reps = min(args.steps, 500)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(10):
-            step()
-        e0.record()
-        for _ in range(reps):
-            step()
-        e1.record()
-        torch.cuda.synchronize()
-        kernel_ms[live[0]] = e0.elapsed_time(e1) / reps
+    one_kernel = not distributed and len(live) == 1 and live[0] != "sparse" and (live[0] != "stream" or ntypes == 1)
+    if one_kernel:
+        kernel_ms[live[0]] = event_ms_per_step
     path = {1: "stream", 2: "class", 3: "generic"}.get(dmain.info()["last_path"], "?")
 
-    nnz_local = m.nztot()
-    nnz_total = nnz_local
-    if distributed:
+    nnz_total = float(nnz_global)
+    if distributed and not strong:
         tt = torch.tensor([float(nnz_local)], dtype=torch.float64, device=dev)
         dist.all_reduce(tt)
         nnz_total = float(tt.item())
     useful_gflops = 2.0 * nnz_total * N / (ms_per_step * 1e-3) / 1e9
+    imbalance = None
+    if strong:
+        tt = torch.tensor([float(sum(kernel_ms.values()))], dtype=torch.float64, device=dev)
+        mx, sm = tt.clone(), tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm)
+        imbalance = float(mx.item()) / max(float(sm.item()) / world, 1e-30)
 
     if rank != 0:
         if distributed:
@@ -335,33 +492,46 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (rank 0's launch) ------------------------------------------------------
-    h = np.diff(vb.row_part)
-    flops_exec_full = 2.0 * float(vb.nztot) * N
-    # stored area handled by each kernel: the stream kernel takes everything; the per-class kernels take the tiles of
-    # their height class (block-rows are cut into <=64-row tiles; a remainder <=32 / <=16 rows goes to the thinner class)
-    area = {"stream": float(vbm.nztot), "fixup": 0.0, "class16": 0.0, "class32": 0.0, "class64": 0.0}
-    for hh, nb in zip(h, vbm.nzcount):
-        r = int(hh)
-        while r > 0:
-            mt = min(r, 64) if r > 32 else r
-            c = "class64" if r > 32 else ("class32" if r > 16 else "class16")
-            area[c] += float(mt) * w * float(nb)
-            r -= mt
-    t_lb, flops_exec, bytes_alg = mixed_roofline_seconds(vbm.row_part, vbm.nzcount, w, N, vbm.cols)
+    sp = dmain.sparse_info()
+    peak_mfma = PEAK_MFMA_H16_TFLOPS if h16 else PEAK_MFMA_F32_TFLOPS
     kernel_ms_total = sum(kernel_ms.values())
     dom = max(kernel_ms, key=lambda k: kernel_ms[k]) if kernel_ms else "stream"
+    dense_area = float(info["nztot"])                              # stored area of the block-rows that are MFMA tiles on this handle
+    flops_exec_dense = 2.0 * dense_area * N
+    if vbm is not None:
+        hh_ = np.diff(vbm.row_part)
+        area = {"stream": float(vbm.nztot), "fixup": 0.0, "class16": 0.0, "class32": 0.0, "class64": 0.0}
+        for hh, nb in zip(hh_, vbm.nzcount):
+            r = int(hh)
+            while r > 0:
+                mt = min(r, 64) if r > 32 else r
+                c = "class64" if r > 32 else ("class32" if r > 16 else "class16")
+                area[c] += float(mt) * w * float(nb)
+                r -= mt
+        t_lb, flops_exec, bytes_alg = mixed_roofline_seconds(vbm.row_part, vbm.nzcount, w, N, vbm.cols, s_a=esz, s_b=esz, peak_tflops=peak_mfma)
+        mean_h = float(hh_.mean())
+    else:
+        # hybrid handle (no host image): aggregate section-8(d) bound -- MFMA part max(bytes, flops), sparse rows as (column, value)
+        # pairs + their rows of C, B ONCE
+        area = {"stream": dense_area}
+        dense_rows = rows_c - sp["rows"]
+        bytes_dense = dense_area * esz + info["nblocks"] * 4.0 + dense_rows * N * 4.0
+        bytes_sparse = float(sp["nnz"]) * (esz + 4.0) + float(sp["rows"]) * (N * 4.0 + 8.0)
+        bytes_b = float(cols_a) * N * esz
+        t_lb = max(bytes_dense / (PEAK_HBM_GBS * 1e9), flops_exec_dense / (peak_mfma * 1e12)) + (bytes_sparse + bytes_b) / (PEAK_HBM_GBS * 1e9)
+        flops_exec, bytes_alg = flops_exec_dense, bytes_dense + bytes_sparse + bytes_b
+        mean_h = float(m.rows) / max(n_block_rows, 1)
     dom_tflops = 2.0 * area.get(dom, 0.0) * N / (kernel_ms[dom] * 1e-3) / 1e12 if kernel_ms.get(dom, 0) > 0 else 0.0
     kname = {"stream": "vbs_spmm_f32_stream_kernel", "fixup": "vbs_spmm_f32_fixup_kernel", "class16": "vbs_spmm_f32_kernel<16,...>",
              "class32": "vbs_spmm_f32_kernel<32,1,4,1,1,...>", "class64": "vbs_spmm_f32_kernel<32,2,2,1,2,...>"}.get(dom, dom)
-    # HBM bytes per launch of that kernel from rocprofv3 PMC passes (profiles/traffic.json, produced by
-    # scripts/profile_bench.sh on the same command; FETCH_SIZE doubled per MI355X_MICROARCH.md) -- only reported when the
-    # profiled workload is the one running now
+    # HBM bytes per launch of that kernel from rocprofv3 PMC passes (profiles/traffic*.json, produced by scripts/profile_bench.sh on
+    # the same command; FETCH_SIZE doubled per MI355X_MICROARCH.md) -- only reported when the profiled workload is the one running now
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json" if args.dtype == "f32" else "traffic_%s.json" % args.dtype)))
         wk = tj.get("workload", {})
-        if (wk.get("vbs_area") == int(vb.nztot) and wk.get("n_cols") == N and wk.get("kernel_path") == path and not distributed
-                and wk.get("dtype", "f32") == args.dtype):
+        if (vb is not None and wk.get("vbs_area") == int(vb.nztot) and wk.get("n_cols") == N and wk.get("kernel_path") == path and not distributed
+                and wk.get("dtype", "f32") == args.dtype and wk.get("kernel_rev", "") == sa.KERNEL_REV):
             traffic = round(float(tj["hbm_bytes_per_launch"]))
     except Exception:
         traffic = None
@@ -374,29 +544,36 @@ def main():
         "mixed_roofline_frac": round(t_lb / (kernel_ms_total * 1e-3), 4) if kernel_ms_total > 0 else 0.0,
         "algorithmic_gbs": round(bytes_alg / (kernel_ms_total * 1e-3) / 1e9, 1) if kernel_ms_total > 0 else 0.0,
         "algorithmic_bytes": round(bytes_alg),
+        "kernel_ms_source": "HIP events on the launch stream around the K timed steps / K" if one_kernel else "HIP event pair per kernel launch, mean of %d steps" % min(max(args.steps, 10), 50),
     }
-    sp = dmain.sparse_info()
     if dom == "sparse":
         try:                                   # PMC-measured HBM-side bytes per step of these kernels (scripts/pmc_rmat.sh), same workload only
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_rmat.json")))
             wk = tj.get("workload", {})
-            if wk.get("vbs_area") == int(vb.nztot) and wk.get("n_cols") == N and wk.get("dtype") == args.dtype:
+            if wk.get("nnz") == int(nnz_global) and wk.get("n_cols") == N and wk.get("dtype") == args.dtype and wk.get("kernel_rev", "") == sa.KERNEL_REV:
                 traffic = round(float(tj["hbm_bytes_per_step"]))
         except Exception:
             pass
-        # the matrix is carried by the sparse-row kernels: HBM-bound.  Algorithmic bytes: one N-float row of B per nonzero + its
-        # (column, value) + the rows of C once (the transposes of a column-major B / C are implementation traffic, not counted)
-        bytes_sp = float(sp["nnz"]) * (N * (2.0 if h16 else 4.0) + 8.0) + float(sp["rows"]) * N * 4.0
-        gbs = bytes_sp / (kernel_ms["sparse"] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
+        # The matrix is carried by the sparse-row kernels: HBM-bound.  `frac` is the section-8(d) figure -- B counted ONCE (the whole
+        # step: MFMA part + sparse rows + B + C, all kernels of the step including the layout transposes) -- and `gather_frac` the
+        # bandwidth the gather kernels see: one N-wide row of B per nonzero (re-reads served by L2 / Infinity Cache included).
+        bytes_gather = float(sp["nnz"]) * (N * esz + 8.0) + float(sp["rows"]) * N * 4.0
+        gbs_gather = bytes_gather / (kernel_ms["sparse"] * 1e-3) / 1e9
+        gbs_once = bytes_alg / (kernel_ms_total * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(gbs_once, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs_once / PEAK_HBM_GBS, 4),
+                    "traffic": traffic,
                     "kernel": "sparse_rows_kernel + sparse_segments_kernel (+ b_to_row_major / sparse_c_scatter transposes)",
                     "kernel_ms": round(kernel_ms["sparse"], 5), "path": path, "kernels_ms": {k: round(v_, 5) for k, v_ in kernel_ms.items()},
-                    "algorithmic_bytes": round(bytes_sp), "sparse_rows": sp["rows"], "sparse_nnz": sp["nnz"], "hub_rows": sp["hub_rows"],
-                    "note": "B rows of hub columns are served by L2 / Infinity Cache: the rate can exceed what HBM alone delivers"}
+                    "algorithmic_bytes": round(bytes_alg), "frac_b_once": round(gbs_once / PEAK_HBM_GBS, 4),
+                    "gather_bytes": round(bytes_gather), "gather_gbs": round(gbs_gather, 1), "gather_frac": round(gbs_gather / PEAK_HBM_GBS, 4),
+                    "mixed_roofline_frac": round(t_lb / (kernel_ms_total * 1e-3), 4) if kernel_ms_total > 0 else 0.0,
+                    "sparse_rows": sp["rows"], "sparse_nnz": sp["nnz"], "hub_rows": sp["hub_rows"],
+                    "note": "frac = section-8(d) algorithmic bytes (A once, B ONCE, C once) / all kernels of the step; gather_frac counts one row of B per "
+                            "nonzero (hub rows of B are served by L2 / Infinity Cache: it can exceed what HBM alone delivers)"}
     if h16 and dom != "sparse":
         # 16-bit storage: the MFMAs take 1/8 (fp16 / bf16 dense peak ~2.5 PFLOP/s) of the fp32 time while the bytes only halve:
         # the kernel is bound by memory traffic.  Algorithmic bytes: packed 16-bit A (read once) + 16-bit B (once) + fp32 C.
-        bytes16 = float(info["a_bytes"]) + 2.0 * ldb * N + 4.0 * vb.rows * N
+        bytes16 = float(info["a_bytes"]) + 2.0 * ldb * N + 4.0 * rows_c * N
         gbs = bytes16 / (kernel_ms_total * 1e-3) / 1e9 if kernel_ms_total > 0 else 0.0
         roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                          "kernel": ("vbs_spmm_h16_direct_kernel" if (w % 64 != 0 and info["tiles64"] == 0 and os.environ.get("SPARTA_H16_PATH", "a")[0] != "l")
@@ -408,99 +585,155 @@ def main():
     # measured shader clock and the fraction of the matrix peak AT THAT CLOCK are reported next to it (informational)
     if kernel_mhz.get(dom, 0) > 0:
         roofline["shader_clock_mhz"] = round(kernel_mhz[dom], 0)
-    if kernel_mhz.get(dom, 0) > 0 and not h16:
+    if kernel_mhz.get(dom, 0) > 0 and not h16 and dom != "sparse":
         roofline["frac_at_measured_clock"] = round(dom_tflops / (PEAK_MFMA_F32_TFLOPS * kernel_mhz[dom] / PEAK_CLOCK_MHZ), 4)
 
-    # ---- CPU baseline: the reference's own VBR::multiply on this host, 1 thread -----------------------------------
+    # ---- CPU baseline: the reference's VBR::multiply on this host -- 1 thread (the reference is single-threaded) and all cores -----
     cpu = None
     if not args.no_cpu_baseline:
         try:
-            from oracle import ref, oracle as O
-            if not distributed:
-                Bh = (B.view(N, ldb)[:, :vb.cols].float().contiguous().view(-1) if h16 else B).cpu().numpy()
-            else:
-                Bh = sa.dist.gathered_to_colmajor(B_gath.float().cpu().numpy(), world, shard_rows, N)
-            # bounded sample: a prefix of block-rows worth <= ~2e10 executed flops (about 10-20 s of scalar CPU work)
-            per_row = 2.0 * np.diff(vb.row_part) * w * vb.nzcount * N
-            cum = np.cumsum(per_row)
-            nbr = int(np.searchsorted(cum, 2.0e10, side="right"))
-            nbr = max(1, min(nbr, vb.block_rows))
-            rows_s = int(vb.row_part[nbr])
-            # useful flops of the sample: nnz of the (reordered) rows it covers
-            perm = sa.get_permutation(grouping)
-            nnz_s = int(np.diff(m.rowptr)[perm[:rows_s]].sum())
-            cpu_reps = 1
-            if ref.available():
-                kind = "reference"
-                if nbr == vb.block_rows:
-                    rc = ref.RefCSR(m.rows, m.cols, m.rowptr, m.colidx.astype(np.int64), m.vals)
-                    rv = ref.RefVBR(rc, grouping, w, args.row_block, bool(args.force_fixed) and not args.fixed_height)
-                    t1 = time.perf_counter()
-                    rv.multiply(Bh, N)
-                    t_cpu = time.perf_counter() - t1
-                    while t_cpu * cpu_reps < 10.0 and cpu_reps < 50:       # ~10 s of CPU work in all: repeat the whole multiply
-                        t1 = time.perf_counter()
-                        rv.multiply(Bh, N)
-                        t_cpu = (t_cpu * cpu_reps + time.perf_counter() - t1) / (cpu_reps + 1)
-                        cpu_reps += 1
-                else:
-                    kind = "port"
-                    rv = None
-            else:
-                kind = "port"
-                rv = None
-            if rv is None:
-                t1 = time.perf_counter()
-                O.vbr_multiply(vb.rows, vb.cols, w, vb.row_part, vb.nzcount, vb.jab, vb.mab, Bh, N, block_row_range=(0, nbr))
-                t_cpu = time.perf_counter() - t1
-            cpu = {"value": round(2.0 * nnz_s * N / t_cpu / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": kind,
-                   "sample": "block-rows [0,%d) of %d (%d rows, %d nnz), %d repetition%s, %.2f s each; executed dense-block rate %.2f GFLOP/s"
-                             % (nbr, vb.block_rows, rows_s, nnz_s, cpu_reps, "" if cpu_reps == 1 else "s", t_cpu, float(cum[nbr - 1]) / t_cpu / 1e9)}
+            cpu = cpu_baseline(sa, args, m, grouping, vb, w, rbs, ff, N, B, ldb, B_gath, world, shard_rows, distributed, h16, torch)
         except Exception as e:  # the baseline is a report, never a reason to lose the measurement
             cpu = {"value": None, "unit": "GFLOP/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
 
+    if wl_name is None:
+        wl_name = "row-partitioned FEM 9x9x%d mesh x 3 dof (%d^2 padded, %d nnz)" % (257 * world, world * shard_rows, int(nnz_total))
+    how = "" if not distributed else (", 1 all-gather of B per step" if ex is None else ", 1 all-to-all of the needed row-blocks of B per step")
     out = {
         "metric": "Block-sparse SpMM GFLOP/s", "value": round(useful_gflops, 2), "unit": "GFLOP/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "file" if args.matrix else "synthetic",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "file" if args.matrix else "synthetic",
         "config": {
-            "workload": ("%s (%d x %d, %d nnz), B = %d cols, %s" % (os.path.basename(args.matrix), m.rows, m.cols, nnz_local, N, args.dtype)) if args.matrix else
-                        ("R-MAT 2^%d (a,b,c = 0.57,0.19,0.19; 10 edges per row, symmetrised: %d^2, %d nnz), B = %d cols, %s"
-                         % (args.rmat_scale, m.rows, nnz_local, N, args.dtype)) if rmat else
-                        ("cant-like FEM 9x9x257 mesh x 3 dof (62451^2, %d nnz), B = %d cols, fp32" % (nnz_local, N)) if not distributed else
-                        ("row-partitioned FEM 9x9x%d mesh x 3 dof (%d^2 padded, %d nnz), B = %d cols, fp32, %s per step"
-                         % (257 * world, world * shard_rows, int(nnz_total), N,
-                            "1 all-gather of B" if ex is None else "1 all-to-all of the needed row-blocks of B")),
-            "reorder": ("fixed height %d (reorder off)" % args.fixed_height) if args.fixed_height else
+            "workload": "%s, B = %d cols, %s%s" % (wl_name, N, {"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[args.dtype], how),
+            "reorder": ("fixed height %d (reorder off: reference flags -a 2 -F 1 -B %d -b %d)" % (args.fixed_height, args.fixed_height, w)) if args.fixed_height else
                        ("Jaccard %s tau=%.2f row_block=%d force_fixed=%d (reference flags -a %d -t %.2f -B %d -F %d -b %d)"
                         % ({3: "iterative_clocked", 5: "iterative_max_size/Keeper", 7: "LSH-bucketed (extension)"}.get(args.algo, str(args.algo)), args.tau, args.row_block,
                            args.force_fixed, args.algo, args.tau, args.row_block, args.force_fixed, w)),
-            "col_block_size": w, "n_cols": N, "block_rows": int(vb.block_rows), "nonzero_blocks": int(len(vb.jab)),
-            "vbs_area": int(vb.nztot), "fill": round(nnz_local / max(vb.nztot, 1), 4),
-            "mean_block_row_height": round(float(h.mean()), 2),
+            "col_block_size": w, "n_cols": N, "block_rows": int(n_block_rows), "nonzero_blocks": vbs_blocks_ref,
+            "vbs_area": vbs_area_ref, "fill": round(nnz_local / max(vbs_area_ref, 1), 6),
+            "mean_block_row_height": round(mean_h, 2),
+            "device_image": {"mfma_tile_area": int(info["nztot"]), "mfma_blocks": int(info["nblocks"]), "sparse_rows": sp["rows"], "sparse_nnz": sp["nnz"],
+                             "a_bytes": int(info["a_bytes"])},
             "tiles": {"16": info["tiles16"], "32": info["tiles32"], "64": info["tiles64"]}, "kernel_path": path,
-            "executed_gflops": round(flops_exec_full * world / (ms_per_step * 1e-3) / 1e9, 1),
+            "executed_gflops": round(flops_exec * (world if not strong else 1) / (ms_per_step * 1e-3) / 1e9, 1),
             "host_seconds": {"generate": round(t_gen, 2), "reorder": round(t_reorder, 2), "vbs_build": round(t_build, 2)},
             "parallelism": ("single GPU" if not distributed else
+                            ("row-range partition x%d by cost (nnz + rows), identical seeded generation + reorder on every rank, B row-sharded, one all-gather "
+                             "per step; kernel-time imbalance max/mean %.3f" % (world, imbalance)) if strong else
                             ("row-partition x%d, B all-gather%s" % (world, exchange_note)) if ex is None else
                             ("row-partition x%d, B row-block all-to-all (%d blocks sent / %d received by rank 0 per step = %.2f %% of the "
                              "all-gather's traffic), own-shard product overlapped" % (world, ex.n_send, ex.n_recv, 100.0 * ex.needed_fraction))),
             "launch": ("HIP graph of %d steps, replayed %d times" % (G, args.steps // G)) if graph is not None else "eager",
+            "preroll_steps": preroll, "event_ms_per_step": round(event_ms_per_step, 5),
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    if gen_stats is not None:
+        out["config"]["generator"] = gen_stats
+    if check is not None:
+        out["config"]["parity_spot_check"] = check
     if distributed:
         dist.destroy_process_group()
-    # RCCL writes its version banner to C stdout (fully buffered when redirected: it would surface AFTER our line at exit).
-    # Flush C stdio first so that the JSON line is the last thing this process prints.
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    sys.stdout.flush()
-    print(json.dumps(out), flush=True)
+    _emit(out)
+
+
+def cpu_baseline(sa, args, m, grouping, vb, w, rbs, ff, N, B, ldb, B_gath, world, shard_rows, distributed, h16, torch):
+    """Reported baseline, not the target: the reference's CPU multiply (VBR::multiply, src/general/vbr.cpp:323-372) on this box's
+    host, on a bounded sample of the same workload -- a prefix of block-rows worth ~2e10 executed flops for the single thread (10-20 s)."""
+    from oracle import ref, oracle as O
+    cols = m.cols
+    if not distributed:
+        Bh = (B.view(N, ldb)[:, :cols].float().contiguous().view(-1) if h16 else B).cpu().numpy()
+    else:
+        Bh = sa.dist.gathered_to_colmajor(B_gath.float().cpu().numpy(), world, shard_rows, N)
+    perm = sa.get_permutation(grouping)
+    kind = "reference"
+    if vb is None:
+        # hybrid handle: no dense host image of the whole matrix.  Sample = the first block-rows (in reordered order) whose dense VBS
+        # executes <= ~2e10 flops; their VBS is built by the product's own host builder (bit-identical to the reference's: tests/).
+        part = sa.get_partition(grouping)
+        nnz_rows = np.diff(m.rowptr)[perm]
+        hts = np.diff(part)
+        nnz_br = np.add.reduceat(nnz_rows.astype(np.float64), part[:-1])
+        # executed flops of a block-row <= 2 * h * min(nnz, block columns) * w * N.  The sample is a seeded RANDOM set of block-rows (a
+        # prefix would be the hub clusters of a power-law matrix), taken in random order while the budget lasts.
+        est = 2.0 * hts * np.minimum(nnz_br, float(-(-cols // w))) * w * N
+        order = np.random.Generator(np.random.PCG64(5)).permutation(len(hts))
+        take, spent = [], 0.0
+        for ib in order:
+            if spent + est[ib] <= 2.0e10 or not take:
+                take.append(int(ib))
+                spent += est[ib]
+            if spent >= 1.9e10 or len(take) >= 200000:
+                break
+        take = np.sort(np.asarray(take, np.int64))
+        nbr = len(take)
+        sel = np.concatenate([np.arange(part[ib], part[ib + 1]) for ib in take]) if nbr else np.zeros(0, np.int64)
+        rows_s = int(len(sel))
+        sub = sa.dist.row_slab(m, perm[sel], cols)
+        gsub = np.repeat(np.arange(nbr, dtype=np.int64), hts[take])
+        vb = sa.VBR().fill_from_CSR_inplace(sub, gsub, w, rbs, False)
+        kind = "port"
+        nbr_total = len(part) - 1
+        nnz_s = int(nnz_rows[sel].sum())
+        total_rows = m.rows
+        sample_what = "a seeded random set of %d of %d block-rows" % (nbr, nbr_total)
+    else:
+        per_row = 2.0 * np.diff(vb.row_part) * w * vb.nzcount * N
+        cum = np.cumsum(per_row)
+        nbr = max(1, min(int(np.searchsorted(cum, 2.0e10, side="right")), vb.block_rows))
+        rows_s = int(vb.row_part[nbr])
+        nnz_s = int(np.diff(m.rowptr)[perm[:min(rows_s, m.rows)]].sum())
+        nbr_total, total_rows = vb.block_rows, vb.rows
+        sample_what = "block-rows [0,%d) of %d" % (nbr, nbr_total)
+    exec_flops = float((2.0 * np.diff(vb.row_part)[:nbr] * w * vb.nzcount[:nbr] * N).sum())
+    cpu_reps = 1
+    rv = None
+    if kind == "reference" and ref.available() and nbr == vb.block_rows:
+        rc = ref.RefCSR(m.rows, m.cols, m.rowptr, m.colidx.astype(np.int64), m.vals)
+        rv = ref.RefVBR(rc, grouping, w, rbs, ff)
+        t1 = time.perf_counter()
+        rv.multiply(Bh, N)
+        t_cpu = time.perf_counter() - t1
+        while t_cpu * cpu_reps < 10.0 and cpu_reps < 50:       # ~10 s of CPU work in all: repeat the whole multiply
+            t1 = time.perf_counter()
+            rv.multiply(Bh, N)
+            t_cpu = (t_cpu * cpu_reps + time.perf_counter() - t1) / (cpu_reps + 1)
+            cpu_reps += 1
+    else:
+        kind = "port"
+        t1 = time.perf_counter()
+        O.vbr_multiply(vb.rows, vb.cols, w, vb.row_part, vb.nzcount, vb.jab, vb.mab, Bh, N, block_row_range=(0, nbr))
+        t_cpu = time.perf_counter() - t1
+    # all host cores: the same loop nest, block-row ranges on separate threads (each writes its own rows of C, vbr.cpp:355); always the
+    # oracle's restatement (the compiled reference has one entry point for the whole matrix)
+    reps_mt, t_mt, n_thr = 0, 0.0, 1
+    Cbuf = np.zeros(vb.rows * N, np.float32)
+    while reps_mt < 20 and t_mt < 3.0:
+        _, t_once, n_thr = O.vbr_multiply_mt(vb.rows, vb.cols, w, vb.row_part, vb.nzcount, vb.jab, vb.mab, Bh, N, block_row_range=(0, nbr), C_out=Cbuf)
+        t_mt += t_once
+        reps_mt += 1
+    t_mt /= max(reps_mt, 1)
+    csr_ref = None
+    if kind == "port" and total_rows == m.rows and m.rows >= 100000:
+        # large power-law inputs: the dense-block loop above only affords a sliver of the matrix, so the reference's OTHER CPU SpMM,
+        # CSR::multiply (src/general/csr.cpp:49-65; oracle restatement), is timed too, on a seeded random 1 % of the rows
+        pick = np.sort(np.random.Generator(np.random.PCG64(6)).choice(m.rows, size=max(1, m.rows // 100), replace=False))
+        sub = sa.dist.row_slab(m, pick, cols)
+        t1 = time.perf_counter()
+        O.csr_multiply(sub.rows, sub.rowptr, sub.colidx.astype(np.int64), sub.vals, Bh, cols, N)
+        t_csr = time.perf_counter() - t1
+        csr_ref = {"value": round(2.0 * sub.nztot() * N / t_csr / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+                   "sample": "CSR::multiply on a seeded random 1 %% of the rows (%d rows, %d nnz), %.2f s" % (sub.rows, sub.nztot(), t_csr)}
+    return {"csr_multiply": csr_ref, "value": round(2.0 * nnz_s * N / t_cpu / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": kind,
+            "sample": "%s (%d of %d rows = %.2f %%, %d nnz), %d repetition%s, %.2f s each; executed dense-block rate %.2f GFLOP/s"
+                      % (sample_what, rows_s, total_rows, 100.0 * rows_s / max(total_rows, 1), nnz_s, cpu_reps, "" if cpu_reps == 1 else "s", t_cpu,
+                         exec_flops / t_cpu / 1e9),
+            "all_cores": {"value": round(2.0 * nnz_s * N / t_mt / 1e9, 4), "unit": "GFLOP/s", "cores": int(n_thr), "kind": "port",
+                          "sample": "same block-rows, %d threads over block-row ranges (nproc = %d), %d repetitions, %.3f s each; executed %.2f GFLOP/s"
+                                    % (n_thr, os.cpu_count() or 0, reps_mt, t_mt, exec_flops / t_mt / 1e9)}}
 
 
 if __name__ == "__main__":

@@ -157,3 +157,35 @@ def collect_blocking_info(rows, cols, rowptr, colidx, grouping, col_block_size):
     lib().oracle_collect_blocking_info(rows, cols, _lp(rp), _lp(ci), _lp(g), col_block_size, _lp(info), C.byref(avg))
     return dict(VBR_nzcount=int(info[0]), VBR_nzblocks_count=int(info[1]), VBR_longest_row=int(info[2]),
                 VBR_average_height=float(avg.value))
+
+
+def vbr_multiply_mt(rows, cols, block_col_size, row_part, nzcount, jab, mab, B, n_cols, block_row_range=None, n_threads=None, C_out=None):
+    """The same restatement of VBR::multiply on several host threads: block-rows are independent (each writes its own rows of C,
+    vbr.cpp:355), so contiguous ranges of them -- balanced by executed multiply-adds -- run concurrently (ctypes releases the
+    GIL).  TEST / BASELINE INFRASTRUCTURE: the "all host cores" figure next to the reference-faithful single-thread one.
+    Returns (C, seconds of the threaded region)."""
+    import os
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    rp, nz, jb = _l(row_part), _l(nzcount), _l(jab)
+    m = np.ascontiguousarray(mab, np.float32)
+    Bc = np.ascontiguousarray(B, np.float32)
+    Cm = np.zeros(rows * n_cols, np.float32) if C_out is None else C_out
+    b0, b1 = (0, len(nz)) if block_row_range is None else block_row_range
+    if n_threads is None:
+        n_threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_threads = max(1, min(int(n_threads), b1 - b0))
+    work = (np.diff(rp)[b0:b1] * nz[b0:b1]).astype(np.float64) + 1.0
+    cum = np.concatenate([[0.0], np.cumsum(work)])
+    cuts = [b0 + int(np.searchsorted(cum, cum[-1] * t / n_threads, side="left")) for t in range(n_threads)] + [b1]
+    fn = lib().oracle_vbr_multiply_range
+    args = (rows, cols, block_col_size, _lp(rp), _lp(nz), _lp(jb), _fp(m))
+
+    def run(t):
+        if cuts[t] < cuts[t + 1]:
+            fn(*args, cuts[t], cuts[t + 1], _fp(Bc), n_cols, _fp(Cm))
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=n_threads) as ex:
+        list(ex.map(run, range(n_threads)))
+    return Cm, time.perf_counter() - t0, n_threads

@@ -121,8 +121,9 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     if (nblocks > 0 && (!jab || !mab)) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: jab / mab is NULL");
 
     int ndev = sparta_device_count();
-    if (ndev <= 0) return fail(SPARTA_ERR_NO_DEVICE, "sparta_vbs_create: no HIP device visible (this path has no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: device index out of range");
+    const bool plan_debug = std::getenv("SPARTA_PLAN_DEBUG") != nullptr && ndev <= 0;   // developer aid: print the plan statistics on a host without a GPU, then fail as usual
+    if (ndev <= 0 && !plan_debug) return fail(SPARTA_ERR_NO_DEVICE, "sparta_vbs_create: no HIP device visible (this path has no CPU fallback)");
+    if (!plan_debug && (device < 0 || device >= ndev)) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: device index out of range");
 
     // ---- sparse-row path: which block-rows are better served as rows of (column, value) --------------------------------
     // An MFMA step (one <=32-row tile x 32 k x 128 columns) takes the time of ~12 nonzeros on the sparse-row path (2.1 ns per
@@ -322,10 +323,12 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     // device allocation made so far
     struct VbsDeleter { void operator()(sparta_vbs* q) const { destroy_impl(q); } };
     std::unique_ptr<sparta_vbs, VbsDeleter> hold(new (std::nothrow) sparta_vbs);
+    if (plan_debug) return fail(SPARTA_ERR_NO_DEVICE, "sparta_vbs_create: no HIP device visible (this path has no CPU fallback)");
     sparta_vbs* v = hold.get();
     if (!v) return fail(SPARTA_ERR_ALLOC, "sparta_vbs_create: out of host memory");
     v->device = device; v->dtype = dtype;
     v->zero_ranges = plan.zero_ranges;
+    v->pair_plan = plan.pair_plan;
     v->rows = row_part[br1] - row_part[br0]; v->cols = cols; v->block_rows = br1 - br0; v->w = w;
     v->nblocks = nblocks; v->nztot = nztot; v->exec_area = exec_area;
 
@@ -855,7 +858,8 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                     if (A->n_steps[ty] == 0) continue;
                     sp.steps = shard_rows > 0 ? A->d_steps_g[ty] : A->d_steps[ty]; sp.worker_range = A->d_wrange[ty];
                     sp.clk = (prof && ty == probe_ty) ? A->d_clk : nullptr;
-                    launch_f32_stream(ty != 0, b_layout == SPARTA_ROW_MAJOR, shard_rows > 0, grid, st, sp);
+                    if (A->pair_plan) launch_f32_pair(b_layout == SPARTA_ROW_MAJOR, shard_rows > 0, grid, st, sp);
+                    else launch_f32_stream(ty != 0, b_layout == SPARTA_ROW_MAJOR, shard_rows > 0, grid, st, sp);
                 }
                 if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
             }

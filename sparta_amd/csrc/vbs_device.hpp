@@ -66,6 +66,8 @@ constexpr int SK_TM = 64;                 // max rows of a tile
 constexpr int32_t STEP_FIRST = 1 << 16;   // first step of a (segment of a) tile: accumulators start at zero
 constexpr int32_t STEP_LAST = 1 << 17;    // last step of a (segment of a) tile: run the epilogue
 constexpr int32_t STEP_SPLIT = 1 << 18;   // the tile is shared with another worker: epilogue goes to the workspace
+constexpr int32_t STEP_HAS0 = 1 << 20;    // pair plan: the upper half (rows 0..31 of the pair) has a block in this step
+constexpr int32_t STEP_HAS1 = 1 << 21;    // pair plan: the lower half (rows 32..63) has one
 constexpr int32_t STEP_TAIL = 1 << 19;    // panel of the zero-padded last block column: read from StreamParams::B_tail, b_row = k offset in it
 constexpr int SK_SLOT_FLOATS = 32 * kThreads;   // one partial accumulator image: 32 registers x 256 threads
 
@@ -182,6 +184,7 @@ struct sparta_vbs {
     int32_t n_big_fix = 0;
     void* d_ws = nullptr;
     size_t d_ws_bytes = 0;
+    bool pair_plan = false;                // fp32: d_steps[0] holds the pair plan (one launch of vbs_spmm_f32_pair_kernel)
     bool has_tail = false;                 // cols % w != 0: the stream path needs B_tail
     void* d_btail = nullptr;
     size_t d_btail_bytes = 0;
@@ -227,6 +230,7 @@ void launch_f32_exact(unsigned n_brows, hipStream_t st, const BlockRowDesc* rows
                       int64_t shard_stride);
 // k_f32_stream.hip
 void launch_f32_stream(bool mi2, bool b_row_major, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
+void launch_f32_pair(bool b_row_major, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
 void launch_fixup_group(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* big, const int32_t* fix_slots, float* ws_all, int64_t ws_slab_stride);
 void launch_fixup(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* fix_slots, const float* ws_all, int64_t ws_slab_stride, float* C, int64_t ldc,
                   int c_row_major, int accumulate);
@@ -262,6 +266,7 @@ struct StreamPlanHost {
     int n_workers = 0, n_split = 0;
     int plan_aligned[2] = {0, 0};
     int64_t kp = SK_KP;
+    bool pair_plan = false;                   // fp32: steps[0] is the pair plan (vbs_plan.cpp, build_pair_plan), steps[1] is empty
 };
 constexpr int64_t kZeroRangeRows = 2048;    // block-rows without blocks at least this tall are zero-filled by vbs_zero_rows_kernel
 int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P);

@@ -27,16 +27,50 @@ def partition_block_rows(row_part, nzcount, block_col_size, world_size):
     h = np.diff(row_part)
     # +h so that empty block-rows (which still write zeros into C) carry a little weight
     work = h * int(block_col_size) * nzcount + h
-    cum = np.concatenate([[0], np.cumsum(work)])
+    return partition_by_cost(work, world_size)
+
+
+def partition_by_cost(cost, world_size):
+    """Contiguous ranges [(b0, b1), ...] of the items (block-rows), one per rank, cut at the ideal cumulative targets of
+    `cost` (any non-negative per-item cost: executed dense work for MFMA-carried matrices, nonzeros + rows for the
+    sparse-row-carried power-law ones).  Ranks at the end may get an empty range when there are fewer items than ranks."""
+    cost = np.asarray(cost, np.float64)
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
     total = cum[-1]
     bounds = [0]
     for r in range(1, world_size):
         target = total * r / world_size
         b = int(np.searchsorted(cum, target, side="left"))
-        b = min(max(b, bounds[-1]), len(work))
-        bounds.append(b)
-    bounds.append(len(work))
+        if 0 < b <= len(cost) and target - cum[b - 1] < cum[min(b, len(cost))] - target:
+            b -= 1                                                           # the cut nearer to the target (a heavy item goes to the emptier side)
+        bounds.append(min(max(b, bounds[-1]), len(cost)))
+    bounds.append(len(cost))
     return [(bounds[i], bounds[i + 1]) for i in range(world_size)]
+
+
+def row_slab(cmat, rows, n_cols=None):
+    """The CSR made of the given rows of `cmat` (original row ids, in the order given), columns unchanged; `n_cols` widens the
+    column space (padding up to world * shard_rows).  One rank's slab of a row-range partition."""
+    from .host import CSR
+    rows = np.asarray(rows, np.int64)
+    rp = np.asarray(cmat.rowptr, np.int64)
+    cnt = rp[rows + 1] - rp[rows]
+    rowptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    total = int(rowptr[-1])
+    # position of every kept nonzero in the source arrays
+    src = np.repeat(rp[rows] - rowptr[:-1], cnt) + np.arange(total, dtype=np.int64)
+    colidx = np.asarray(cmat.colidx)[src]
+    vals = None if cmat.vals is None else np.asarray(cmat.vals)[src]
+    return CSR(len(rows), int(cmat.cols if n_cols is None else n_cols), rowptr, colidx, vals)
+
+
+def gathered_rows(B_gathered, row_ids, world_size, shard_rows, n_cols):
+    """(checks) rows `row_ids` of B out of the gathered device buffer: returns an n_cols x len(row_ids) float64 numpy array"""
+    import torch
+    ids = torch.as_tensor(np.asarray(row_ids, np.int64), device=B_gathered.device)
+    g = B_gathered.view(world_size, n_cols, shard_rows)                      # slab s, column j, local row
+    out = g[ids // shard_rows, :, ids % shard_rows]                          # len(ids) x n_cols
+    return out.float().cpu().numpy().astype(np.float64).T
 
 
 def padded_shard_rows(n_local, block_col_size):

@@ -138,3 +138,95 @@ def fem3d_slab(nx, ny, nz_per_rank, rank, world, dof=3, pad_to=64, seed=2, patte
     r, c = np.concatenate(rr), np.concatenate(cc)
     v = None if pattern_only else rng.uniform(-1.0, 1.0, size=len(r)).astype(np.float32)
     return _csr_from_coo(n_local, world * n_pad, r, c, v), n_local, n_pad
+
+
+# ---- large power-law inputs, generated on the GPU (BASELINE configs[2]-[4]: 10^8 .. 10^10 nonzeros) -----------------------------
+def rmat_device(scale, n_edges=None, target_nnz=None, a=0.57, b=0.19, c=0.19, seed=3, symmetrize=False, values="uniform", n=None,
+                device=0, chunk=1 << 26, max_rounds=12, return_stats=False):
+    """R-MAT graph with 2**scale vertices (optionally only the leading n x n corner), sampled, sorted and de-duplicated on the
+    GPU with torch (numpy needs minutes for 10^9 edges); the CSR comes back as host arrays (sparta_amd.CSR).
+
+    n_edges     : raw edges to draw (before removing duplicates), or
+    target_nnz  : keep drawing until at least this many DISTINCT entries exist (a stated density = target_nnz / n^2); the result
+                  has slightly more (the last round's surplus is kept: dropping entries of a sorted list would bias the rows).
+    symmetrize  : every edge (r, c) also gives (c, r).
+    values      : "uniform" U(-1, 1) fp32, "ones", or None (pattern only).
+    Same seed, same torch build, same GPU model -> same matrix; the seed of chunk k is seed * 1000003 + k."""
+    import torch
+    from .host import CSR
+    if not torch.cuda.is_available():
+        raise RuntimeError("rmat_device needs a GPU (use gen.rmat on the host for small cases)")
+    dev = torch.device("cuda", device)
+    full = 1 << scale
+    n = full if n is None else int(n)
+    ab, abc = a + b, a + b + c
+    state = {"chunk": 0, "drawn": 0}
+
+    def draw(m):
+        """m raw edges -> int64 keys r * n + c (edges outside the n x n corner rejected)"""
+        out = []
+        left = int(m)
+        while left > 0:
+            k = min(left, chunk)
+            g = torch.Generator(device=dev).manual_seed(int(seed) * 1000003 + state["chunk"])
+            state["chunk"] += 1
+            r = torch.zeros(k, dtype=torch.int64, device=dev)
+            col = torch.zeros(k, dtype=torch.int64, device=dev)
+            for lvl in range(scale):
+                u = torch.rand(k, generator=g, device=dev)
+                right = ((u >= a) & (u < ab)) | (u >= abc)        # quadrants b, d -> column bit set
+                down = u >= ab                                     # quadrants c, d -> row bit set
+                r |= down.to(torch.int64) << lvl
+                col |= right.to(torch.int64) << lvl
+            if n < full:
+                keep = (r < n) & (col < n)
+                r, col = r[keep], col[keep]
+            key = r * n + col
+            out.append(key)
+            if symmetrize:
+                out.append(col * n + r)
+            left -= k
+            state["drawn"] += k
+        return torch.cat(out) if len(out) > 1 else out[0]
+
+    if target_nnz is None:
+        keys = torch.unique(draw(int(n_edges)))
+    else:
+        keys = torch.empty(0, dtype=torch.int64, device=dev)
+        want = int(target_nnz)
+        for _ in range(max_rounds):
+            missing = want - keys.numel()
+            if missing <= 0:
+                break
+            # duplicates: assume the next batch is at best as fresh as the last one was (first round: 1 / 0.7)
+            m = int(missing * 1.35 / (2 if symmetrize else 1)) + 1024
+            fresh = draw(m)
+            keys = torch.unique(torch.cat([keys, fresh]))
+            del fresh
+    nnz = int(keys.numel())
+    r = keys // n
+    counts = torch.bincount(r, minlength=n)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=rowptr[1:])
+    colidx = (keys - r * n).to(torch.int32)
+    del keys, r, counts
+    vals = None
+    if values == "uniform":
+        g = torch.Generator(device=dev).manual_seed(int(seed) * 7919 + 17)
+        vals = torch.rand(nnz, generator=g, device=dev) * 2.0 - 1.0
+    elif values == "ones":
+        vals = torch.ones(nnz, dtype=torch.float32, device=dev)
+    m = CSR(n, n, rowptr.cpu().numpy(), colidx.cpu().numpy(), None if vals is None else vals.cpu().numpy())
+    del rowptr, colidx, vals
+    torch.cuda.empty_cache()
+    if return_stats:
+        return m, {"raw_edges_drawn": state["drawn"], "nnz": nnz, "density": nnz / float(n) / float(n)}
+    return m
+
+
+def ogbn_products_like(seed=3, device=0, **kw):
+    """BASELINE configs[2] stand-in (ogbn-products itself cannot be fetched): 2 449 029 vertices, ~61.86 M undirected edges
+    symmetrised (~124 M nonzeros, values 1), degrees power-law: the leading 2 449 029^2 corner of an R-MAT 2^22 graph
+    (SURVEY.md section 8(d))."""
+    n = 2449029
+    return rmat_device(22, target_nnz=2 * 61859140, seed=seed, symmetrize=True, values="ones", n=n, device=device, **kw)
