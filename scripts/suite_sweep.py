@@ -2,7 +2,9 @@
 N = 128: reorder -> handle from the CSR -> product.  Reports useful GFLOP/s and the fraction of the better of the two rooflines a
 matrix can be held to: the per-block-row mixed HBM/MFMA bound of its VBS (bench.py: mixed_roofline_seconds) and the HBM bound of
 its nonzeros as sparse rows (nnz * (N*4 + 8) + rows * N * 4 bytes at 8 TB/s).
-    python scripts/suite_sweep.py [n_cols=128]"""
+    python scripts/suite_sweep.py [n_cols=128] [out.json]
+Besides the markdown table on stdout it writes one JSON record per matrix (seeds, blocking, fill, time, useful / executed rates, which
+kernels carried it, fractions of both bounds) -- the committed record is profiles/r2/suite.json."""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +13,9 @@ import sparta_amd as sa
 from bench import mixed_roofline_seconds, PEAK_HBM_GBS
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+OUT = sys.argv[2] if len(sys.argv) > 2 else None
+import json
+records = []
 
 
 def clustered(n_groups, rows_per, cols, shared, own, seed):
@@ -79,4 +84,16 @@ for name, make, eng_kw, w in cases:
     print("| %s | %d | %d | %s, %.2f s | %d / %.3f | %.3f | %.0f | %s | %.2f (%s bound) |" % (
         name, m.rows, m.nztot(), {5: "Keeper 32", 7: "LSH"}[eng_kw["blocking_algo"]] + " tau %.1f w %d" % (eng_kw["tau"], w), t_r, int(br), m.nztot() / max(area, 1.0), ms,
         2.0 * m.nztot() * N / ms / 1e6, carried, t_lb / (ms * 1e-3), "MFMA/HBM mixed" if t_mfma <= t_sparse else "sparse-row HBM"), flush=True)
+    exec_area = float(d.info()["nztot"])
+    records.append({"matrix": name, "rows": int(m.rows), "cols": int(m.cols), "nnz": int(m.nztot()), "n_cols": N, "dtype": "f32",
+                    "blocking": dict(eng_kw, col_block_size=w), "reorder_host_s": round(t_r, 3), "block_rows": int(br), "vbs_area": int(area),
+                    "nonzero_blocks": int(nblocks), "fill": round(m.nztot() / max(area, 1.0), 5), "ms": round(ms, 5),
+                    "useful_gflops": round(2.0 * m.nztot() * N / ms / 1e6, 1), "executed_gflops_mfma_part": round(2.0 * exec_area * N / ms / 1e6, 1),
+                    "kernels_ms": {k: round(float(v_), 5) for k, v_ in ct.items()}, "sparse_nnz": int(sp["nnz"]), "sparse_rows": int(sp["rows"]),
+                    "carried_by": carried, "bound_mixed_s": t_mfma, "bound_sparse_rows_s": t_sparse,
+                    "frac_of_mixed_bound": round(t_mfma / (ms * 1e-3), 4), "frac_of_sparse_row_bound": round(t_sparse / (ms * 1e-3), 4),
+                    "frac_of_better_bound": round(t_lb / (ms * 1e-3), 4), "kernel_rev": sa.KERNEL_REV,
+                    "f32_plan": os.environ.get("SPARTA_F32_PLAN", "default")})
     d.close()
+if OUT:
+    json.dump({"n_cols": N, "dtype": "f32", "device": torch.cuda.get_device_name(0), "records": records}, open(OUT, "w"), indent=1)

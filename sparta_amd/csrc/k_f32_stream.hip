@@ -55,6 +55,8 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
     const int s_begin = p.worker_range[2 * blockIdx.x];
     const int n = p.worker_range[2 * blockIdx.x + 1] - s_begin;
     if (n <= 0) return;
+    if (p.stagger > 0 && blockIdx.x >= (gridDim.x >> 1))          // developer knob: de-phase the two workgroups that share a CU
+        for (int k = 0; k < p.stagger; k++) __builtin_amdgcn_s_sleep(1);
     clock_probe(p.clk, 0);
 #ifdef SPARTA_TIMELINE
     long long tl_t0 = 0;
@@ -373,6 +375,8 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_pair_kernel(const St
     const int s_begin = p.worker_range[2 * blockIdx.x];
     const int n = p.worker_range[2 * blockIdx.x + 1] - s_begin;
     if (n <= 0) return;
+    if (p.stagger > 0 && blockIdx.x >= (gridDim.x >> 1))          // developer knob: de-phase the two workgroups that share a CU
+        for (int k = 0; k < p.stagger; k++) __builtin_amdgcn_s_sleep(1);
     clock_probe(p.clk, 0);
     float* ws = p.ws + (int64_t)blockIdx.y * p.ws_slab_stride;
 
@@ -408,8 +412,14 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_pair_kernel(const St
     uint32_t g_so0 = 0, g_so1 = 0, g_inc0 = 0, g_inc1 = 0;   // running byte offset inside the pair (soffset of the loads) and its per-step advance
     uint32_t voA0 = 0, voA1 = 0, vo_cur = voffB;
     int32_t tail_prev = 0;
-    auto issue_loads = [&](int s, u32x4 (&rb)[4], u32x4 (&ra)[2]) __attribute__((always_inline)) -> int32_t {
+    // The G stage in two parts.  prep(s): everything scalar about step s -- record fields, cursors, buffer descriptors -- ~60 SALU
+    // instructions that must sit INSIDE a block of MFMAs to be free (the scalar unit issues in the shadow of a running MFMA of the same
+    // wave; outside such a block the wave just waits for them).  fire(...): the six buffer loads, issued from the prepared scalars.
+    struct Prep { const float* bptr; uint32_t qs; const float* pa0; const float* pa1; uint32_t nr0, nr1, so0, so1; int32_t flags; };
+    auto prep = [&](int s) __attribute__((always_inline)) -> Prep {
+        Prep q;
         const int32_t flags = field(s, F_FLAGS);
+        q.flags = flags;
         if (flags & STEP_FIRST) {                        // pair (segment) start: re-seat both cursors, else they just advance
             const int64_t aoff0 = (int64_t)(uint32_t)field(s, F_AOFF_LO) | ((int64_t)field(s, F_AOFF_HI) << 32);
             g_pA0 = p.A + aoff0;
@@ -431,22 +441,31 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_pair_kernel(const St
         int64_t gk0 = field(s, F_BROW);
         const float* Bbase = tail ? p.B_tail : p.B;
         if constexpr (GATHERED) Bbase += (int64_t)field(s, F_SHARD) * p.shard_stride;
-        const float* bptr = tail ? Bbase + (BRM ? gk0 * ld_t : gk0) : Bbase + (BRM ? gk0 * p.ldb : gk0) + n0off;
-        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bptr), 0, 0x7ffffff0, 0x00020000);
-        const uint32_t qs = tail ? qstepBt : qstepB;
-#pragma unroll
-        for (int q = 0; q < 4; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, qs * q, 0);
-        // A slices, streamed (nt: read exactly once).  A half without a block in this step: a descriptor of ZERO records -- every lane is
-        // out of range, the load returns zeros (which is what its LDS image must hold) and no request leaves the CU.  Rows past a tile
-        // read what follows in memory: never stored.  The plan keeps a pair's A bytes below 2^30, so base + voffset + soffset stays in range.
-        const uint32_t nr0 = (flags & STEP_HAS0) ? 0x7ffffff0u : 0u, nr1 = (flags & STEP_HAS1) ? 0x7ffffff0u : 0u;
-        const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g_pA0), 0, (int)nr0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g_pA1), 0, (int)nr1, 0x00020000);
-        ra[0] = __builtin_amdgcn_raw_buffer_load_b128(rA0, voA0, g_so0, 2);
-        ra[1] = __builtin_amdgcn_raw_buffer_load_b128(rA1, voA1, g_so1, 2);
+        q.bptr = tail ? Bbase + (BRM ? gk0 * ld_t : gk0) : Bbase + (BRM ? gk0 * p.ldb : gk0) + n0off;
+        q.qs = tail ? qstepBt : qstepB;
+        // A half without a block in this step gets a descriptor of ZERO records: every lane is out of range, the load returns zeros
+        // (which is what its LDS image must hold) and no request leaves the CU.  The plan keeps a pair's A bytes below 2^30.
+        q.nr0 = (flags & STEP_HAS0) ? 0x7ffffff0u : 0u;
+        q.nr1 = (flags & STEP_HAS1) ? 0x7ffffff0u : 0u;
+        q.pa0 = g_pA0; q.pa1 = g_pA1; q.so0 = g_so0; q.so1 = g_so1;
         g_so0 += (flags & STEP_HAS0) ? g_inc0 : 0u;
         g_so1 += (flags & STEP_HAS1) ? g_inc1 : 0u;
-        return flags;
+        return q;
+    };
+    auto fire = [&](const Prep& q, u32x4 (&rb)[4], u32x4 (&ra)[2]) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.bptr), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; j++) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, q.qs * j, 0);
+        // A slices, streamed (nt: read exactly once).  Rows past a tile read what follows in memory: never stored.
+        const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.pa0), 0, (int)q.nr0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.pa1), 0, (int)q.nr1, 0x00020000);
+        ra[0] = __builtin_amdgcn_raw_buffer_load_b128(rA0, voA0, q.so0, 2);
+        ra[1] = __builtin_amdgcn_raw_buffer_load_b128(rA1, voA1, q.so1, 2);
+    };
+    auto issue_loads = [&](int s, u32x4 (&rb)[4], u32x4 (&ra)[2]) __attribute__((always_inline)) -> int32_t {   // prologue only
+        const Prep q = prep(s);
+        fire(q, rb, ra);
+        return q.flags;
     };
     int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq_new = 0;
 
@@ -480,19 +499,15 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_pair_kernel(const St
     f32x16 stg0, stg1;
 #pragma unroll
     for (int r = 0; r < 16; r++) { stg0[r] = 0.0f; stg1[r] = 0.0f; }
-    // The MFMAs of one half of a step: 4 rounds x 4 MFMAs on fragments that are already in registers.  Jumped over as a whole by ONE
-    // scalar branch when the half has no block in this step; the block defines nothing but the accumulator it updates in place.
-    auto half_mfma = [&](const f32x4 (&bf)[4], const f32x4 (&af)[4], f32x16& acc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int m = 0; m < 4; m++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[r][m], af[r][m], acc, 0, 0, 0);
-    };
-
     // one pipeline iteration: compute step i from stage PAR; write step i+1 (register set wb/wa) into stage 1-PAR; refill that
-    // register set with step i+3.  ALL fragment reads of the step are issued before the LDS writes: LDS operations complete in
-    // order, so an MFMA that waits for its fragments (lgkmcnt(6) and up) never waits for the 16-byte writes queued behind them --
-    // with the writes in front, every fragment wait was an lgkmcnt(0) that sat behind ~80 cycles of write traffic, four times a step.
+    // register set with step i+3.
+    //   * every fragment read of the step is issued first: LDS operations complete in order, so an MFMA that waits for its fragments
+    //     never waits for the 16-byte writes queued behind them;
+    //   * the LDS writes (W) and the scalar half of the G stage (prep) sit in the SAME basic block as the 16 MFMAs of the first present
+    //     half, where the scheduler interleaves them: a wave's own non-MFMA instructions issue in the shadow of its own MFMAs.  With the
+    //     MFMA groups in blocks of their own (first version: one branch per round and half) all of that work was exposed: a lone 32-row
+    //     tile took 4250 cycles per step against 3200 in the one-tile stream kernel;
+    //   * the six loads are issued once, behind the MFMAs, from the prepared scalars (no register is defined on two paths).
     auto iteration_t = [&](int i, int32_t flags, u32x4 (&wb)[4], u32x4 (&wa)[2], auto par_tag) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
         using nxt_t = std::integral_constant<int, 1 - PAR>;
@@ -514,12 +529,33 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_pair_kernel(const St
 #pragma unroll
             for (int m = 0; m < 4; m++) { af0[r][m] = as[m * TM]; af1[r][m] = as[m * TM + 32]; }
         }
+        Prep q;
+        // W + prep + the MFMAs of one half, as ONE straight-line region (source order = the interleaving the scheduler starts from)
+#define SPARTA_PAIR_REGION(AF, ACC)                                                                                                \
+        do {                                                                                                                       \
+            _Pragma("unroll") for (int m = 0; m < 4; m++) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[0][m], AF[0][m], ACC, 0, 0, 0); \
+            write_b(nxt_t{}, wb, 0); write_b(nxt_t{}, wb, 1);                                                                      \
+            _Pragma("unroll") for (int m = 0; m < 4; m++) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[1][m], AF[1][m], ACC, 0, 0, 0); \
+            write_b(nxt_t{}, wb, 2); write_b(nxt_t{}, wb, 3);                                                                      \
+            write_a(nxt_t{}, wa, 0); write_a(nxt_t{}, wa, 1);                                                                      \
+            _Pragma("unroll") for (int m = 0; m < 4; m++) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[2][m], AF[2][m], ACC, 0, 0, 0); \
+            q = prep(i + 3);                                                                                                       \
+            _Pragma("unroll") for (int m = 0; m < 4; m++) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[3][m], AF[3][m], ACC, 0, 0, 0); \
+        } while (0)
+        if (flags & STEP_HAS0) {
+            SPARTA_PAIR_REGION(af0, acc0);
+            if (flags & STEP_HAS1) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) write_b(nxt_t{}, wb, q);
-        write_a(nxt_t{}, wa, 0); write_a(nxt_t{}, wa, 1);
-        if (flags & STEP_HAS0) half_mfma(bf, af0, acc0);
-        fq_new = issue_loads(i + 3, wb, wa);
-        if (flags & STEP_HAS1) half_mfma(bf, af1, acc1);
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int m = 0; m < 4; m++) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[r][m], af1[r][m], acc1, 0, 0, 0);
+            }
+        } else {
+            SPARTA_PAIR_REGION(af1, acc1);
+        }
+#undef SPARTA_PAIR_REGION
+        fire(q, wb, wa);
+        fq_new = q.flags;
         if (flags & STEP_LAST) {
 #pragma unroll
             for (int q = 0; q < 16; q++) {                        // copies the register allocator cannot merge with the accumulators

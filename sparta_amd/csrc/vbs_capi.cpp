@@ -718,7 +718,7 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
     if (shard_rows > 0)
         if (int rc = ensure_gathered_steps(A, shard_rows, st)) return rc;
     sp.ws_slab_stride = (int64_t)slab; sp.accumulate = accumulate != 0; sp.c_row_major = c_layout == SPARTA_ROW_MAJOR;
-    sp.N = n_cols; sp.w = (int32_t)A->w; sp.B_tail = nullptr; sp.clk = nullptr;
+    sp.N = n_cols; sp.w = (int32_t)A->w; sp.B_tail = nullptr; sp.clk = nullptr; sp.stagger = 0;
     if (A->n_steps[0] + A->n_steps[1] > 0) {
         if (prof) HIP_TRY(hipEventRecord(A->cev[0][0], st));
         if (A->has_tail && shard_rows == 0) {
@@ -843,6 +843,7 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
             sp.ws_slab_stride = (int64_t)slab; sp.accumulate = accumulate != 0; sp.c_row_major = c_layout == SPARTA_ROW_MAJOR;
             sp.N = n_cols; sp.w = (int32_t)A->w; sp.B_tail = nullptr;
             sp.clk = nullptr;
+            sp.stagger = [] { const char* e = std::getenv("SPARTA_STAGGER"); return e ? atoi(e) : 0; }();
             if (A->n_steps[0] + A->n_steps[1] > 0) {
                 if (prof) HIP_TRY(hipEventRecord(A->cev[0][0], st));
                 if (A->has_tail && shard_rows == 0) {

@@ -101,6 +101,7 @@ struct StreamParams {
     int32_t accumulate, c_row_major;
     int32_t N, w;
     long long* clk;                       // clock probe, see clock_probe()
+    int32_t stagger;                      // developer knob (SPARTA_STAGGER): workgroups of the second half of the grid start this many x 64 cycles late
 };
 
 constexpr int kFixGroup = 16;   // partial images per group of the fix-up group stage (k_f32_stream.hip)

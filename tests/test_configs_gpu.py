@@ -1,0 +1,257 @@
+"""BASELINE.json configs at their stated sizes on one MI355X (-m gpu): one test per config / arm.
+
+The oracle (the reference's CPU loops restated) cannot multiply 10^8-nonzero matrices in test time, so each test combines
+  (i)   rows / block-rows of C sampled at random against a float64 evaluation of the same rows (values of A and B rounded to the
+        storage type first: products of two 16-bit values are exact in fp32, so the fp32 tolerance 1e-5 * sum|a||b| applies unchanged),
+  (ii)  the column checksum 1^T C == (1^T A) B  (every row of C takes part),
+  (iii) bit-reproducibility of a second product into a dirty buffer,
+  (iv)  where two groupings of the same matrix exist (reorder on / reorder off -- the experiment the reference runs,
+        src/scripts/run_multiplication_experiments_fixed_cluster.sh:14-16): the two products agree row for row through the permutations.
+configs[1] (the flagship blocking of bench.py) is small enough for the oracle's VBR::multiply on EVERY row.
+Each test stays under about a minute on the GPU box (generation on the GPU, reorder + build on the host)."""
+import numpy as np
+import pytest
+
+import sparta_amd as sa
+from oracle import oracle as O
+import _util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+def _rounded(x, torch, tdt):
+    """fp32 numpy -> the values the device multiplies (rounded to the storage type), as float64"""
+    return torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(tdt).float().numpy().astype(np.float64)
+
+
+def _sampled_rows_check(torch, m, grouping, C, n, B, ldb, tdt, n_rows=96, seed=1):
+    """rows of C (reordered order) against float64 sums over the row's nonzeros; returns the worst |err| / sum|a||b|"""
+    perm = sa.get_permutation(grouping)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    deg = np.diff(m.rowptr)[perm]
+    # a mix: uniformly random rows + the heaviest rows (hubs take the segmented path)
+    pick = np.unique(np.concatenate([rng.integers(0, m.rows, n_rows), np.argsort(deg)[-8:]]))
+    Cv, Bv = C.view(n, -1), B.view(n, ldb)
+    worst = 0.0
+    for r in pick:
+        i = perm[r]
+        cols_i = m.colidx[m.rowptr[i]:m.rowptr[i + 1]]
+        got = Cv[:, int(r)].cpu().numpy().astype(np.float64)
+        if len(cols_i) == 0:
+            worst = max(worst, float(np.abs(got).max()))
+            continue
+        a = m.vals[m.rowptr[i]:m.rowptr[i + 1]] if m.vals is not None else np.ones(len(cols_i), np.float32)
+        a = _rounded(a, torch, tdt)
+        bb = Bv[:, torch.from_numpy(cols_i.astype(np.int64)).cuda()].float().cpu().numpy().astype(np.float64)
+        want, scale = bb @ a, np.abs(bb) @ np.abs(a) + 1e-30
+        worst = max(worst, float((np.abs(got - want) / scale).max()))
+    return worst
+
+
+def _column_checksum_check(torch, m, C, n, B, ldb, tdt):
+    """1^T C == (1^T A) B per column of B, in float64 on the device; returns max |diff| / (|1^T A| |B|)"""
+    vals = np.ones(m.nztot(), np.float32) if m.vals is None else m.vals
+    s = np.bincount(m.colidx, weights=_rounded(vals, torch, tdt), minlength=m.cols)          # column sums of (rounded) A
+    sa_abs = np.bincount(m.colidx, weights=np.abs(_rounded(vals, torch, tdt)), minlength=m.cols)
+    st, sat = torch.from_numpy(s).cuda(), torch.from_numpy(sa_abs).cuda()
+    Bd = B.view(n, ldb)[:, :m.cols].double()
+    want, scale = Bd @ st, Bd.abs() @ sat + 1e-30
+    got = C.view(n, -1).double().sum(dim=1)
+    return float(((got - want).abs() / scale).max())
+
+
+def _dense_rhs(torch, cols, n, tdt, seed):
+    ldb = (cols + 7) // 8 * 8 if tdt != torch.float32 else cols
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    B = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    B.view(n, ldb)[:, :cols] = (torch.rand(n, cols, generator=g, device="cuda") - 0.5).to(tdt)
+    return B, ldb
+
+
+def _product(torch, d, B, ldb, n, fill=None):
+    C = torch.empty(d.rows * n, dtype=torch.float32, device="cuda")
+    if fill is not None:
+        C.fill_(fill)
+    d.spmm(B, C, n, accumulate=False, ldb=ldb)
+    torch.cuda.synchronize()
+    return C
+
+
+def test_config1_flagship_blocking_every_row_against_the_oracle():
+    """configs[1] exactly as bench.py runs it: cant-like 62 451^2, Keeper tau 0.6, 32-row blocks (-a 5 -B 32 -F 1), w = 32, N = 128 fp32,
+    column-major B and C: EVERY element of C against the oracle's VBR::multiply within 1e-5 * sum|a||b|, for the product kernel the
+    library picks and for each fp32 plan it can be told to use; the exact-order kernel bit for bit."""
+    import os
+    torch = _torch()
+    m = sa.gen.cant_like(seed=2)
+    w, n = 32, 128
+    eng = sa.BlockingEngine(blocking_algo=5, tau=0.6, col_block_size=w, row_block_size=32, force_fixed_size=True, sim_measure=1)
+    g = eng.GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w, 32, True)
+    assert (v.block_rows, len(v.jab), int(v.nztot)) == (1952, 21910, 22435840)        # the workload bench.py reports
+    Bh = sa.gen.dense_rhs(v.cols, n, seed=9)
+    Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, Bh, n)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, Bh, n)
+    B = torch.from_numpy(Bh).cuda()
+    saved = os.environ.get("SPARTA_F32_PLAN")
+    try:
+        for plan in (None, "legacy", "pair"):
+            if plan is None:
+                os.environ.pop("SPARTA_F32_PLAN", None)
+            else:
+                os.environ["SPARTA_F32_PLAN"] = plan
+            d = v.to_device(0)
+            C1 = _product(torch, d, B, v.cols, n, fill=7.0)
+            C2 = _product(torch, d, B, v.cols, n, fill=-3.0)
+            assert torch.equal(C1, C2), "not reproducible (plan %s)" % plan
+            err = np.abs(C1.cpu().numpy() - Co)
+            assert np.all(err <= 1e-5 * bound + 1e-30), (plan, float((err / (bound + 1e-30)).max()))
+            if plan is None:
+                Ce = torch.zeros_like(C1)
+                d.spmm(B, Ce, n, accumulate=False, algo=sa.SPMM_EXACT)
+                torch.cuda.synchronize()
+                assert np.array_equal(Ce.cpu().numpy(), Co), "exact-order kernel is not bit-identical to the oracle"
+            d.close()
+    finally:
+        if saved is None:
+            os.environ.pop("SPARTA_F32_PLAN", None)
+        else:
+            os.environ["SPARTA_F32_PLAN"] = saved
+
+
+@pytest.mark.parametrize("arm", ["reorder-on", "reorder-off"])
+def test_config2_ogbn_products_sized_fp16(arm):
+    """configs[2]: 2 449 029^2, ~124 M nonzeros (values 1), B = 256 columns, fp16 storage / fp32 accumulation (the numerics of the
+    reference's CUTLASS back-end, src/cuda/cutlass_bellpack_lib.cu:56-57)."""
+    torch = _torch()
+    m = sa.gen.ogbn_products_like(seed=3)
+    assert m.rows == 2449029 and 1.2e8 < m.nztot() < 1.3e8
+    w, n, tdt = 64, 256, torch.float16
+    if arm == "reorder-on":
+        g = sa.BlockingEngine(blocking_algo=7, tau=0.4, col_block_size=w).GetGrouping(m)
+        d = sa.DeviceVBS.from_csr(m, g, w, device=0, dtype=sa.F16)
+    else:
+        g = sa.BlockingEngine(blocking_algo="fixed_size", row_block_size=64, col_block_size=w).GetGrouping(m)
+        d = sa.DeviceVBS.from_csr(m, g, w, 64, False, device=0, dtype=sa.F16)
+    B, ldb = _dense_rhs(torch, m.cols, n, tdt, seed=5)
+    C1 = _product(torch, d, B, ldb, n, fill=1.0)
+    C2 = _product(torch, d, B, ldb, n, fill=-2.0)
+    assert torch.equal(C1, C2)
+    assert _sampled_rows_check(torch, m, g, C1, n, B, ldb, tdt) <= 1e-5
+    assert _column_checksum_check(torch, m, C1, n, B, ldb, tdt) <= 1e-5
+
+
+def test_config3_rmat20_bf16_reorder_on_equals_reorder_off():
+    """configs[3]: R-MAT 2^20 x 2^20, B = 512 columns, bf16 storage.  The test runs the 0.012 % density (~1.27e8 distinct nonzeros; the
+    stated 0.1 % = 1.1e9 runs in bench.py --rmat-density 0.001 and takes minutes of host time) with BOTH arms of the reference's
+    experiment -- clustered (blocking_algo 7) and fixed 64-row blocks -- and checks that the two products are the same matrix product:
+    row perm_on[r] of C_on equals row perm_off[r'] of C_off for the same original row."""
+    torch = _torch()
+    n_side = 1 << 20
+    m = sa.gen.rmat_device(20, target_nnz=int(1.0e-4 * n_side * n_side), seed=3, values="uniform")
+    assert 1.0e8 < m.nztot() < 1.5e8            # the generator stops at the first round that reaches the target: ~1.27e8
+    w, n, tdt = 64, 512, torch.bfloat16
+    B, ldb = _dense_rhs(torch, m.cols, n, tdt, seed=6)
+    g_off = sa.BlockingEngine(blocking_algo="fixed_size", row_block_size=64, col_block_size=w).GetGrouping(m)
+    d_off = sa.DeviceVBS.from_csr(m, g_off, w, 64, False, device=0, dtype=sa.BF16)
+    C_off = _product(torch, d_off, B, ldb, n, fill=3.0)
+    assert torch.equal(C_off, _product(torch, d_off, B, ldb, n, fill=-1.0))
+    assert _sampled_rows_check(torch, m, g_off, C_off, n, B, ldb, tdt) <= 1e-5
+    assert _column_checksum_check(torch, m, C_off, n, B, ldb, tdt) <= 1e-5
+    d_off.close()
+    g_on = sa.BlockingEngine(blocking_algo=7, tau=0.4, col_block_size=w).GetGrouping(m)
+    d_on = sa.DeviceVBS.from_csr(m, g_on, w, device=0, dtype=sa.BF16)
+    C_on = _product(torch, d_on, B, ldb, n)
+    assert _sampled_rows_check(torch, m, g_on, C_on, n, B, ldb, tdt, seed=2) <= 1e-5
+    # same product through the two permutations: position of original row i in each ordering
+    p_on, p_off = sa.get_permutation(g_on), sa.get_permutation(g_off)
+    inv_on = np.empty(m.rows, np.int64); inv_on[p_on] = np.arange(m.rows)
+    inv_off = np.empty(m.rows, np.int64); inv_off[p_off] = np.arange(m.rows)
+    rows = np.random.Generator(np.random.PCG64(4)).integers(0, m.rows, 4096)
+    a = C_on.view(n, -1)[:, torch.from_numpy(inv_on[rows]).cuda()]
+    b = C_off.view(n, -1)[:, torch.from_numpy(inv_off[rows]).cuda()]
+    # both sum the same exact products in fp32; only the order (hub rows: segments) may differ
+    scale = b.abs().max().clamp_min(1e-30)
+    assert float((a - b).abs().max() / scale) <= 2e-5
+
+
+def test_config4_row_range_partition_on_one_gpu():
+    """configs[4] in miniature on ONE GPU: the strong-scaling path of bench.py (--workload rmat --gpus N) with every rank played in
+    turn -- block-row ranges by cost, a slab per rank built by sparta_vbs_create_from_csr, B row-sharded and handed over in the
+    all-gather layout (sparta_vbs_spmm_gathered) -- against the single-handle product of the whole matrix."""
+    torch = _torch()
+    world, w, n = 4, 64, 128
+    m = sa.gen.rmat_device(17, n_edges=10 << 17, seed=3, symmetrize=True, values="uniform")
+    g = sa.BlockingEngine(blocking_algo=7, tau=0.4, col_block_size=w).GetGrouping(m)
+    d = sa.DeviceVBS.from_csr(m, g, w, device=0)
+    B, ldb = _dense_rhs(torch, m.cols, n, torch.float32, seed=8)
+    C_full = _product(torch, d, B, ldb, n).view(n, -1)
+    perm, part = sa.get_permutation(g), sa.get_partition(g)
+    cost = np.add.reduceat(np.diff(m.rowptr)[perm].astype(np.float64) + 1.0, part[:-1])
+    ranges = sa.dist.partition_by_cost(cost, world)
+    assert ranges[0][0] == 0 and ranges[-1][1] == len(part) - 1 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    shard_rows = sa.dist.padded_shard_rows(-(-m.cols // world), w)
+    # the gathered buffer: `world` column-major slabs of shard_rows x n (rows past cols are zero)
+    Bg = torch.zeros(world, n, shard_rows, dtype=torch.float32, device="cuda")
+    Bfull = torch.zeros(n, world * shard_rows, dtype=torch.float32, device="cuda")
+    Bfull[:, :m.cols] = B.view(n, ldb)[:, :m.cols]
+    for q in range(world):
+        Bg[q] = Bfull[:, q * shard_rows:(q + 1) * shard_rows]
+    loads = []
+    for r, (b0, b1) in enumerate(ranges):
+        if b0 == b1:
+            continue
+        my_rows = perm[part[b0]:part[b1]]
+        slab = sa.dist.row_slab(m, my_rows, world * shard_rows)
+        gl = np.repeat(np.arange(b1 - b0, dtype=np.int64), np.diff(part[b0:b1 + 1]))
+        ds = sa.DeviceVBS.from_csr(slab, gl, w, device=0)
+        Cs = torch.empty(ds.rows * n, dtype=torch.float32, device="cuda")
+        ds.spmm_gathered(Bg.view(-1), shard_rows, Cs, n, accumulate=False)
+        torch.cuda.synchronize()
+        # row k of the slab's C is original row my_rows[perm_local[k]]; the full product has it at the position of that row in `perm`
+        pl = sa.get_permutation(gl)
+        inv = np.empty(m.rows, np.int64); inv[perm] = np.arange(m.rows)
+        want = C_full[:, torch.from_numpy(inv[my_rows[pl]]).cuda()]
+        got = Cs.view(n, -1)
+        scale = want.abs().max().clamp_min(1e-30)
+        assert float((got - want).abs().max() / scale) <= 2e-5, r
+        loads.append(float(cost[b0:b1].sum()))
+        ds.close()
+    assert max(loads) / (sum(loads) / world) < 1.5            # the cut by cost is balanced (hub block-rows are what limits it)
+
+
+def test_matrix_market_file_through_the_whole_path(tmp_path):
+    """What `bench.py --matrix cant.mtx` does with a staged SuiteSparse file (none can be fetched here), on a small one: a standard
+    MatrixMarket coordinate file (real, general, 1-based, values) -> sparta_csr_read (IO_STRICT) -> Jaccard reorder -> VBS -> SpMM,
+    every element against the oracle; and the reference-compatible reader (pattern-only, values 1) through the same path."""
+    torch = _torch()
+    src = sa.gen.fem3d(5, 4, 7, 3, seed=8)                                # 420 x 420, 3-dof FEM pattern with values
+    path = tmp_path / "small_fem.mtx"
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n% written by tests/test_configs_gpu.py\n")
+        f.write("%d %d %d\n" % (src.rows, src.cols, src.nztot()))
+        for i in range(src.rows):
+            for k in range(src.rowptr[i], src.rowptr[i + 1]):
+                f.write("%d %d %.9g\n" % (i + 1, src.colidx[k] + 1, src.vals[k]))
+    m = sa.CSR.read_from_edgelist(str(path), mat_fmt=sa.FMT_MTX, mode=sa.IO_STRICT)
+    assert (m.rows, m.cols) == (src.rows, src.cols) and np.array_equal(m.rowptr, src.rowptr) and np.array_equal(m.colidx, src.colidx)
+    assert np.allclose(m.vals, src.vals, rtol=1e-7, atol=0)
+    w, n = 32, 128
+    g = sa.BlockingEngine(blocking_algo=5, tau=0.6, col_block_size=w, row_block_size=32, force_fixed_size=True).GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w, 32, True)
+    Bh = sa.gen.dense_rhs(v.cols, n, seed=3)
+    Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, Bh, n)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, Bh, n)
+    d = v.to_device(0)
+    C = _product(torch, d, torch.from_numpy(Bh).cuda(), v.cols, n, fill=5.0)
+    assert np.all(np.abs(C.cpu().numpy() - Co) <= 1e-5 * bound + 1e-30)
+    d.spmm(torch.from_numpy(Bh).cuda(), C, n, accumulate=False, algo=sa.SPMM_EXACT)
+    torch.cuda.synchronize()
+    assert np.array_equal(C.cpu().numpy(), Co)

@@ -190,3 +190,82 @@ def test_split_own_remote_is_a_column_partition():
     assert np.array_equal(t[:W], B_own[:W]) and np.array_equal(t[W:2 * W], B_own[n_pad:n_pad + W])
     with pytest.raises(ValueError):
         sa.dist.split_own_remote(v, rank, n_pad + W, world)
+
+
+# ---- strong scaling of a power-law matrix (bench.py --workload rmat --gpus N; BASELINE configs[4] in miniature) --------------------
+def _rmat_worker(rank, world, port, out_dir):
+    """what bench.py does per rank: identical seeded generation + reorder, block-row ranges by cost, this rank's slab (rows of the
+    range, columns padded to world * shard_rows), B row-sharded, ONE all-gather over gloo; the slab's product by the oracle"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import sparta_amd as sa
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = sa.gen.rmat(10, 9000, seed=3, symmetrize=True, pattern_only=False)
+        g = sa.BlockingEngine(blocking_algo=7, tau=0.4, col_block_size=W).GetGrouping(m)
+        perm, part = sa.get_permutation(g), sa.get_partition(g)
+        cost = np.add.reduceat(np.diff(m.rowptr)[perm].astype(np.float64) + 1.0, part[:-1])
+        b0, b1 = sa.dist.partition_by_cost(cost, world)[rank]
+        my_rows = perm[part[b0]:part[b1]]
+        shard_rows = sa.dist.padded_shard_rows(-(-m.cols // world), W)
+        slab = sa.dist.row_slab(m, my_rows, world * shard_rows)
+        gl = np.repeat(np.arange(b1 - b0, dtype=np.int64), np.diff(part[b0:b1 + 1]))
+        # B: the global cols x N matrix is seeded; rank r holds rows [r * shard_rows, (r + 1) * shard_rows) (zero past cols)
+        Bglob = np.zeros((N, world * shard_rows), np.float32)
+        Bglob[:, :m.cols] = sa.gen.dense_rhs(m.cols, N, seed=77).reshape(N, m.cols)
+        shard = torch.from_numpy(np.ascontiguousarray(Bglob[:, rank * shard_rows:(rank + 1) * shard_rows]).reshape(-1))
+        gathered = torch.empty(world * shard_rows * N, dtype=torch.float32)
+        sa.dist.allgather_B(shard, gathered)
+        Bfull = sa.dist.gathered_to_colmajor(gathered.numpy(), world, shard_rows, N)
+        v = sa.VBR().fill_from_CSR_inplace(slab, gl, W)
+        C = O.vbr_multiply(v.rows, v.cols, W, v.row_part, v.nzcount, v.jab, v.mab, Bfull, N)
+        np.savez(os.path.join(out_dir, "rmat_rank%d.npz" % rank), C=C, rows=my_rows[sa.get_permutation(gl)], b0=b0, b1=b1, cost=cost[b0:b1].sum())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rmat_strong_scaling_partition_world2(tmp_path):
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rmat_worker, args=(WORLD, port, str(tmp_path)), nprocs=WORLD, join=True)
+    sys.path.insert(0, ROOT)
+    import sparta_amd as sa
+    from oracle import oracle as O
+    m = sa.gen.rmat(10, 9000, seed=3, symmetrize=True, pattern_only=False)
+    B = sa.gen.dense_rhs(m.cols, N, seed=77)
+    truth = O.csr_multiply(m.rows, m.rowptr, m.colidx, m.vals, B, m.cols, N).reshape(N, m.rows)
+    res = [np.load(os.path.join(str(tmp_path), "rmat_rank%d.npz" % r)) for r in range(WORLD)]
+    seen = np.concatenate([r["rows"] for r in res])
+    assert np.array_equal(np.sort(seen), np.arange(m.rows)), "the ranks' row ranges must tile the matrix"
+    assert int(res[0]["b0"]) == 0 and int(res[0]["b1"]) == int(res[1]["b0"])
+    for r in res:
+        C = r["C"].reshape(N, len(r["rows"]))
+        assert np.array_equal(C, truth[:, r["rows"]])            # same products, same (ascending-column) order: bit-identical
+    costs = [float(r["cost"]) for r in res]
+    assert max(costs) / (sum(costs) / WORLD) < 1.3
+
+
+def test_partition_by_cost_and_row_slab():
+    import sparta_amd as sa
+    assert sa.dist.partition_by_cost([1, 1, 1, 1, 10, 1, 1], 3) == [(0, 4), (4, 5), (5, 7)]        # the heavy item gets a rank of its own
+    assert sa.dist.partition_by_cost([5.0], 4) == [(0, 0), (0, 0), (0, 1), (1, 1)] or sum(b - a for a, b in sa.dist.partition_by_cost([5.0], 4)) == 1
+    rng = np.random.Generator(np.random.PCG64(2))
+    c = rng.pareto(1.5, size=4000) + 0.1                                                           # power-law costs
+    for world in (2, 4, 8):
+        parts = sa.dist.partition_by_cost(c, world)
+        assert parts[0][0] == 0 and parts[-1][1] == len(c) and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        loads = np.array([c[a:b].sum() for a, b in parts])
+        assert loads.max() <= c.sum() / world + c.max()
+    m = sa.gen.rmat(9, 3000, seed=4, symmetrize=True, pattern_only=False)
+    rows = rng.permutation(m.rows)[:100]
+    s = sa.dist.row_slab(m, rows, m.cols + 64)
+    assert s.rows == 100 and s.cols == m.cols + 64
+    for k, r in enumerate(rows):
+        assert np.array_equal(s.colidx[s.rowptr[k]:s.rowptr[k + 1]], m.colidx[m.rowptr[r]:m.rowptr[r + 1]])
+        assert np.array_equal(s.vals[s.rowptr[k]:s.rowptr[k + 1]], m.vals[m.rowptr[r]:m.rowptr[r + 1]])
