@@ -119,6 +119,20 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
             asm volatile("" : "+v"(vo_cur));
             tail_prev = tail;
         }
+#ifdef SPARTA_EXTRA_VALU
+        {   // developer probe: what one more VALU instruction per step costs (the loop's VALU work competes with the co-resident wave's MFMAs)
+            int dummy = 0;
+#pragma unroll
+            for (int e = 0; e < SPARTA_EXTRA_VALU; e++) asm volatile("v_mov_b32 %0, %1" : "+v"(dummy) : "v"(vo_cur));
+        }
+#endif
+#ifdef SPARTA_EXTRA_SALU
+        {
+            int dummy = 0;
+#pragma unroll
+            for (int e = 0; e < SPARTA_EXTRA_SALU; e++) asm volatile("s_add_i32 %0, %0, 1" : "+s"(dummy));
+        }
+#endif
         int64_t gk0 = field(s, F_BROW);
         const float* Bbase = tail ? p.B_tail : p.B;
         if constexpr (GATHERED) {                        // a panel never straddles slabs (shard_rows % w == 0); the host split b_row into
@@ -741,6 +755,214 @@ __global__ __launch_bounds__(kThreads) void vbs_zero_rows_kernel(float* C, int64
     }
 }
 
+
+// =====================================================================================================
+// 64-deep steps for tiles of <= 32 rows: vbs_spmm_f32_k64_kernel
+//
+// The one-tile stream kernel restarts its pipeline every 32 k: one barrier, one record, one round of fragment-read latency and
+// ~55 scalar instructions per 16 MFMAs of a wave -- 1100 of its 3200 cycles per step (two co-resident workgroups) are not MFMA
+// time, and a third workgroup per CU does not hide them (measured, round 2).  Here a step is TWO consecutive 32-deep steps of the
+// same tile: 32 MFMAs per wave between barriers, half the records, half the scalar work, half the fragment restarts per flop.
+//   * the two halves of a step are consecutive in A (blocks of a block-row are back to back: k * h addresses 64 k just as well as
+//     32), but gather their B panels from two different block columns (w = 32) or from the two halves of one (w = 64): the record
+//     carries both rows (b_row, slot);
+//   * LDS: the B image of a step is 128 columns x 64 k = 32 KB -- WITHOUT the +4 padding of the 32-deep kernels, or two workgroups
+//     would not fit a CU: stage = 32 KB (B) + 8 KB (A, 64 k x 32 rows), two stages = 80 KB per workgroup, 160 KB per CU exactly.
+//     Conflict-free reads come from an XOR swizzle instead: 16-byte chunk q of column c lives at chunk position q ^ (c & 15);
+//   * waves 0-1 stage the first panel, waves 2-3 the second: the panel base stays a wave-uniform scalar;
+//   * a tile with an odd number of 32-deep steps ends in a step whose second half is absent: its panel and its A slice are loaded
+//     through zero-record descriptors (zeros, no memory traffic) and multiplied as zeros -- < 5 % extra MFMA work on the flagship.
+// Column-major B only, no gathered B, no zero-padded tail block column (cols % w == 0): everything else stays on the 32-deep kernels.
+// Record = StepRec: a_off, b_row = rows of the first panel, slot = rows of the second panel (-1: absent), h, c_row, mt_flags.
+// =====================================================================================================
+__global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_k64_kernel(const StreamParams p) {
+    constexpr int KP = 64, TN = kTN, TM = 32;
+    constexpr int BSZ = TN * KP;                    // floats of the B image: Bs[c][chunk ^ (c & 15)][4]
+    constexpr int STAGE = BSZ + KP * TM;            // 10 240 floats = 40 960 bytes
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+    static_assert(2 * STAGE * 4 == 81920, "two workgroups of 80 KB fill the 160 KB of a CU exactly");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 31, g = lane >> 5;
+    const int n0 = blockIdx.y * TN;
+    const int s_begin = p.worker_range[2 * blockIdx.x];
+    const int n = p.worker_range[2 * blockIdx.x + 1] - s_begin;
+    if (n <= 0) return;
+    clock_probe(p.clk, 0);
+
+    const int32_t* srec = reinterpret_cast<const int32_t*>(p.steps + s_begin);
+    int vrec0 = srec[lane];
+    int vrec1 = srec[64 + lane];
+    int vnext = 0;
+#define field(s, f) sk_field(vrec0, vrec1, (s), (f))
+    enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_BROW1 = 6, F_SHARD = 7 };
+
+    // B staging: this wave's panel = wave >> 1 (scalar); thread t' = tid & 127 of the wave pair: 16-byte chunk t' & 7 (k = 4 chunk ..),
+    // column (t' >> 3) + 16 q, q = 0..7
+    const int panel = __builtin_amdgcn_readfirstlane(wave >> 1);
+    const int tp = tid & 127, chunk = tp & 7, col0 = tp >> 3;
+    const uint32_t voffB = (uint32_t)((4 * chunk + col0 * p.ldb) * 4);
+    const uint32_t qstepB = (uint32_t)(16 * p.ldb * 4);
+    const int64_t n0off = (int64_t)n0 * p.ldb;
+    const uint32_t lwB = (uint32_t)((col0 * KP + (((panel * 8 + chunk) ^ col0) * 4)) * 4);          // + q * 16 * KP * 4 (col & 15 == col0 for every q)
+    // A staging: k = ak0 + 32 q (q = 0, 1), rows ai .. ai + 3
+    const int ak0 = tid >> 3, ai = (tid & 7) * 4;
+    const uint32_t lwA = (uint32_t)((BSZ + ak0 * TM + ai) * 4);                                       // + q * 32 * TM * 4
+    // fragment reads: B column c = 32 wave + lm, round r: chunk 2r + g at position (2r + g) ^ (c & 15); A: As[8r + 4g + m][lm]
+    const int cfr = 32 * wave + lm;
+    uint32_t b_addr[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        b_addr[r] = (uint32_t)((cfr * KP + (((2 * r + g) ^ (cfr & 15)) * 4)) * 4);
+        asm volatile("" : "+v"(b_addr[r]));
+    }
+    uint32_t lrA = (uint32_t)((BSZ + 4 * g * TM + lm) * 4);
+    asm volatile("" : "+v"(lrA));
+    const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 32 * wave + 4 * g) * 4) : (uint32_t)((lm + (32 * wave + 4 * g) * p.ldc) * 4);
+    char* const ldsb = reinterpret_cast<char*>(lds);
+
+    u32x4 b0[8], a0[2], b1[8], a1[2];                   // register sets 0 / 1 of the staging pipeline (raw bits)
+
+    int64_t g_aoff = 0;
+    int32_t g_h = 1;
+    uint32_t voA_cur = 0;
+    auto issue_loads = [&](int s, u32x4 (&rb)[8], u32x4 (&ra)[2]) __attribute__((always_inline)) -> int32_t {
+        const int32_t flags = field(s, F_FLAGS);
+        if (flags & STEP_FIRST) {
+            g_aoff = (int64_t)(uint32_t)field(s, F_AOFF_LO) | ((int64_t)field(s, F_AOFF_HI) << 32);
+            g_h = field(s, F_H);
+            voA_cur = (uint32_t)(ak0 * g_h + ai) * 4u;
+        } else {
+            g_aoff += (int64_t)KP * g_h;                 // consecutive steps of a block-row are contiguous in A
+        }
+        const int32_t br0 = field(s, F_BROW), br1 = field(s, F_BROW1);
+        const int32_t has1 = br1 >= 0;
+        const int64_t gk = panel ? (int64_t)(has1 ? br1 : 0) : (int64_t)br0;
+        const uint32_t nrB = (panel && !has1) ? 0u : 0x7ffffff0u;              // absent second half: zeros, no traffic
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B + gk + n0off), 0, (int)nrB, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 8; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, voffB, qstepB * q, 0);
+        const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + g_aoff), 0, 0x7ffffff0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + g_aoff), 0, has1 ? 0x7ffffff0 : 0, 0x00020000);
+        ra[0] = __builtin_amdgcn_raw_buffer_load_b128(rA0, voA_cur, 0, 2);
+        ra[1] = __builtin_amdgcn_raw_buffer_load_b128(rA1, voA_cur, (uint32_t)(32 * g_h) * 4u, 2);
+        return flags;
+    };
+    int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq_new = 0;
+
+    auto write_b = [&](auto stage_tag, const u32x4 (&rb)[8], int q) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_tag)::value;
+        *reinterpret_cast<u32x4*>(ldsb + lwB + (ST * STAGE + 16 * q * KP) * 4) = rb[q];
+    };
+    auto write_a = [&](auto stage_tag, const u32x4 (&ra)[2], int q) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_tag)::value;
+        *reinterpret_cast<u32x4*>(ldsb + lwA + (ST * STAGE + 32 * q * TM) * 4) = ra[q];
+    };
+
+    f32x16 acc0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc0[r] = 0.0f;
+    f32x16 stg0;                                         // store staging, see vbs_spmm_f32_pair_kernel
+#pragma unroll
+    for (int r = 0; r < 16; r++) stg0[r] = 0.0f;
+
+    auto round = [&](auto stage_tag, auto r_tag) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_tag)::value;
+        constexpr int r = decltype(r_tag)::value;
+        const f32x4 bf = *reinterpret_cast<const f32x4*>(ldsb + b_addr[r] + ST * STAGE * 4);
+        const float* as = reinterpret_cast<const float*>(ldsb + lrA + (ST * STAGE + 8 * r * TM) * 4);
+        float a[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) a[m] = as[m * TM];
+#pragma unroll
+        for (int m = 0; m < 4; m++) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[m], a[m], acc0, 0, 0, 0);
+    };
+
+    auto iteration_t = [&](int i, int32_t flags, u32x4 (&wb)[8], u32x4 (&wa)[2], auto par_tag) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_tag)::value;
+        using cur_t = std::integral_constant<int, PAR>;
+        using nxt_t = std::integral_constant<int, 1 - PAR>;
+        asm volatile("" : : "v"(stg0));
+        // rounds with the W / G work that rides along (the scheduler interleaves inside the basic block)
+        round(cur_t{}, std::integral_constant<int, 0>{});
+        write_b(nxt_t{}, wb, 0); write_b(nxt_t{}, wb, 1);
+        round(cur_t{}, std::integral_constant<int, 1>{});
+        write_b(nxt_t{}, wb, 2); write_b(nxt_t{}, wb, 3);
+        round(cur_t{}, std::integral_constant<int, 2>{});
+        write_b(nxt_t{}, wb, 4); write_b(nxt_t{}, wb, 5);
+        round(cur_t{}, std::integral_constant<int, 3>{});
+        write_b(nxt_t{}, wb, 6); write_b(nxt_t{}, wb, 7);
+        round(cur_t{}, std::integral_constant<int, 4>{});
+        write_a(nxt_t{}, wa, 0); write_a(nxt_t{}, wa, 1);
+        round(cur_t{}, std::integral_constant<int, 5>{});
+        round(cur_t{}, std::integral_constant<int, 6>{});
+        fq_new = issue_loads(i + 3, wb, wa);
+        round(cur_t{}, std::integral_constant<int, 7>{});
+        if (flags & STEP_LAST) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) asm volatile("v_mov_b32 %0, %1" : "=v"(stg0[q]) : "v"(acc0[q]));
+            const int mt = flags & 0xffff;
+            const int64_t c_row = field(i, F_CROW);
+            float* cbase = p.c_row_major ? p.C + c_row * p.ldc + n0 : p.C + c_row + (int64_t)n0 * p.ldc;
+            const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
+            const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;          // bytes per output column
+            if (lm < mt) {
+                if (p.accumulate) {
+                    uint32_t old[16];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) old[q] = __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 0);
+#pragma unroll
+                    for (int q = 0; q < 16; q++) stg0[q] += __uint_as_float(old[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(stg0[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc0[q] = 0.0f;
+        }
+        __syncthreads();
+    };
+    using st0 = std::integral_constant<int, 0>;
+    using st1 = std::integral_constant<int, 1>;
+    fq0 = issue_loads(0, b0, a0);
+    fq1 = issue_loads(1, b1, a1);
+#pragma unroll
+    for (int q = 0; q < 8; q++) write_b(st0{}, b0, q);
+#pragma unroll
+    for (int q = 0; q < 2; q++) write_a(st0{}, a0, q);
+    fq2 = issue_loads(2, b0, a0);
+    __syncthreads();
+    // record batches: request at step 8k, touch at 8k + 4: 4 steps x 10 loads in between, vmcnt(10) is free
+    auto batch_upkeep = [&](int i) __attribute__((always_inline)) {
+        if ((i & 7) == 0 && i > 0) {
+            const int32_t* nb = srec + (int64_t)((i >> 3) + 1) * 64 + lane;
+            asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
+        }
+        if ((i & 7) == 4 && i > 4) {
+            asm volatile("s_waitcnt vmcnt(10)" : "+v"(vnext) : : "memory");
+            const bool odd = (((i >> 3) + 1) & 1) != 0;
+            vrec1 = odd ? vnext : vrec1;
+            vrec0 = odd ? vrec0 : vnext;
+        }
+    };
+    const int n_even = n & ~1;
+    for (int i = 0; i < n_even; i += 2) {
+        batch_upkeep(i);
+        iteration_t(i, fq0, b1, a1, st0{});
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+        iteration_t(i + 1, fq0, b0, a0, st1{});
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+    }
+    if (n & 1) {
+        batch_upkeep(n_even);
+        iteration_t(n_even, fq0, b1, a1, st0{});
+    }
+    clock_probe(p.clk, 2);
+#undef field
+}
+
 }  // namespace
 
 namespace sparta_dev {
@@ -761,6 +983,10 @@ void launch_f32_pair(bool b_row_major, bool gathered, dim3 grid, hipStream_t st,
     if (gathered) hipLaunchKernelGGL((vbs_spmm_f32_pair_kernel<false, true>), grid, dim3(kThreads), 0, st, sp);
     else if (b_row_major) hipLaunchKernelGGL((vbs_spmm_f32_pair_kernel<true, false>), grid, dim3(kThreads), 0, st, sp);
     else hipLaunchKernelGGL((vbs_spmm_f32_pair_kernel<false, false>), grid, dim3(kThreads), 0, st, sp);
+}
+
+void launch_f32_k64(dim3 grid, hipStream_t st, const StreamParams& sp) {
+    hipLaunchKernelGGL(vbs_spmm_f32_k64_kernel, grid, dim3(kThreads), 0, st, sp);
 }
 
 void launch_fixup_group(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* big, const int32_t* fix_slots, float* ws_all, int64_t ws_slab_stride) {

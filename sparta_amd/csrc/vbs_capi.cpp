@@ -47,6 +47,8 @@ void destroy_impl(sparta_vbs* v) {
         if (v->d_steps_g[ty]) (void)hipFree(v->d_steps_g[ty]);
         if (v->d_wrange[ty]) (void)hipFree(v->d_wrange[ty]);
     }
+    if (v->d_steps_k64) (void)hipFree(v->d_steps_k64);
+    if (v->d_wrange_k64) (void)hipFree(v->d_wrange_k64);
     if (v->d_fix) (void)hipFree(v->d_fix);
     if (v->d_fix_slots) (void)hipFree(v->d_fix_slots);
     if (v->d_big_fix) (void)hipFree(v->d_big_fix);
@@ -394,6 +396,15 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             v->h_steps[ty] = st;
             CREATE_TRY(hipMalloc((void**)&v->d_wrange[ty], wrange[ty].size() * sizeof(int32_t)));
             CREATE_TRY(hipMemcpy(v->d_wrange[ty], wrange[ty].data(), wrange[ty].size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        if (!plan.steps_k64.empty()) {
+            std::vector<StepRec>& k = plan.steps_k64;
+            v->n_steps_k64 = (int64_t)k.size();
+            for (int q = 0; q < 32; q++) { StepRec d = k[(size_t)v->n_steps_k64 - 1]; d.mt_flags = (d.mt_flags & ~(STEP_LAST | STEP_SPLIT)) | STEP_FIRST; k.push_back(d); }
+            CREATE_TRY(hipMalloc((void**)&v->d_steps_k64, k.size() * sizeof(StepRec)));
+            CREATE_TRY(hipMemcpy(v->d_steps_k64, k.data(), k.size() * sizeof(StepRec), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc((void**)&v->d_wrange_k64, plan.wrange_k64.size() * sizeof(int32_t)));
+            CREATE_TRY(hipMemcpy(v->d_wrange_k64, plan.wrange_k64.data(), plan.wrange_k64.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
         if (!fix.empty()) {
             CREATE_TRY(hipMalloc((void**)&v->d_fix, fix.size() * sizeof(FixRec)));
@@ -860,7 +871,11 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                     sp.steps = shard_rows > 0 ? A->d_steps_g[ty] : A->d_steps[ty]; sp.worker_range = A->d_wrange[ty];
                     sp.clk = (prof && ty == probe_ty) ? A->d_clk : nullptr;
                     if (A->pair_plan) launch_f32_pair(b_layout == SPARTA_ROW_MAJOR, shard_rows > 0, grid, st, sp);
-                    else launch_f32_stream(ty != 0, b_layout == SPARTA_ROW_MAJOR, shard_rows > 0, grid, st, sp);
+                    else if (ty == 0 && A->d_steps_k64 && b_layout == SPARTA_COL_MAJOR && shard_rows == 0) {
+                        StreamParams sk = sp;                 // the <= 32-row tiles as 64-deep steps
+                        sk.steps = A->d_steps_k64; sk.worker_range = A->d_wrange_k64;
+                        launch_f32_k64(grid, st, sk);
+                    } else launch_f32_stream(ty != 0, b_layout == SPARTA_ROW_MAJOR, shard_rows > 0, grid, st, sp);
                 }
                 if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
             }

@@ -558,6 +558,43 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                     }
                 }
             }
+            // ---- the same one-tile plan as 64-deep steps (vbs_spmm_f32_k64_kernel): fp32, no zero-padded tail block column, and an
+            // aligned plan (no split tile: the 64-deep kernel has no workspace epilogue).  A tile's 64-deep steps are its 32-deep steps
+            // taken two at a time (A is contiguous across consecutive steps; the two B panels are named separately); a tile with an odd
+            // count ends in a step whose second half is absent (slot = -1).
+            {
+                const char* ke = std::getenv("SPARTA_F32_K64");
+                const bool want = ke && atoi(ke) != 0;     // opt-in: measured SLOWER than the 32-deep kernel on the flagship (65.6 vs 58.1 us) -- what bounds these tiles is bytes per flop, not steps
+                if (want && ty == 0 && !h16 && plan_aligned[0] && cols % w == 0 && !P.pair_plan) {
+                    std::vector<StepRec>& k = P.steps_k64;
+                    std::vector<int64_t> kb((size_t)n_workers + 1, 0);
+                    size_t t = 0;
+                    for (int pos = 0; pos < n_workers; pos++) {
+                        kb[(size_t)pos] = (int64_t)k.size();
+                        const int64_t s0 = bnd[(size_t)pos], s1 = bnd[(size_t)pos + 1];
+                        while (t < spans.size() && spans[t].first < s1) {
+                            if (spans[t].first < s0) { t++; continue; }
+                            const TileSpan& sp = spans[t];
+                            for (int64_t q = sp.first; q <= sp.last; q += 2) {
+                                StepRec r = st[(size_t)q];
+                                r.mt_flags &= ~(STEP_FIRST | STEP_LAST | STEP_SPLIT);
+                                r.slot = q + 1 <= sp.last ? st[(size_t)q + 1].b_row : -1;
+                                if (q == sp.first) r.mt_flags |= STEP_FIRST;
+                                if (q + 2 > sp.last) r.mt_flags |= STEP_LAST;
+                                k.push_back(r);
+                            }
+                            t++;
+                        }
+                    }
+                    kb[(size_t)n_workers] = (int64_t)k.size();
+                    P.wrange_k64.assign((size_t)n_workers * 2, 0);
+                    for (int pos = 0; pos < n_workers; pos++) {
+                        const int wid = wid_of_pos[(size_t)pos];
+                        P.wrange_k64[(size_t)wid * 2] = (int32_t)kb[(size_t)pos];
+                        P.wrange_k64[(size_t)wid * 2 + 1] = (int32_t)kb[(size_t)pos + 1];
+                    }
+                }
+            }
         }
     }
 
