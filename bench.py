@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--workload", choices=["cant", "rmat", "ogbn-like"], default="cant")
     ap.add_argument("--rmat-scale", type=int, default=20)
     ap.add_argument("--rmat-density", type=float, default=0.0, help="distinct nonzeros / n^2 (0.001 = 0.1 %%); 0 = 10 edges per row, symmetrised")
+    ap.add_argument("--force-large", action="store_true", help="run R-MAT densities above 2.5e9 nonzeros anyway (not feasible inside one GPU lease)")
     ap.add_argument("--host-gen", action="store_true", help="generate R-MAT on the host with numpy (small cases / no GPU generator)")
     ap.add_argument("--matrix", default=None,
                     help="run the single-GPU pipeline on a matrix file instead of the synthetic workload (.mtx MatrixMarket or .el edge list, read as "
@@ -217,6 +218,21 @@ def main():
                     dist.destroy_process_group()
                 return
             del need
+            if target > 2.5e9 and not args.force_large:
+                # fits the HBM as a CSR image, but not the tools around it on one box: say so, do not shrink
+                if rank == 0:
+                    _emit({"metric": "Block-sparse SpMM GFLOP/s", "value": None, "unit": "GFLOP/s", "n_gpus": n_gpus, "steps": 0, "warmup": 0,
+                           "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if distributed else "weak", "vs_baseline": None,
+                           "dtype": args.dtype, "data": "synthetic",
+                           "config": {"workload": "R-MAT 2^%d at density %g (%d nnz), B = %d cols, %s" % (args.rmat_scale, args.rmat_density, target, N, args.dtype),
+                                      "not_run": "the CSR image (%.0f GB) fits one MI355X, but the generator sorts %d 64-bit keys on the GPU (~%.0f GB with the sort's "
+                                                 "scratch) and the host-side reorder + hybrid build of this many nonzeros take longer than a 20-minute GPU lease "
+                                                 "(measured at 1.1e9 nnz: generate 4.5 s, reorder 74 s, build 28-79 s); --force-large runs it anyway"
+                                                 % (target * (4.0 + esz) / 1e9, target, 3.0 * 8.0 * target / 1e9)},
+                           "roofline": None, "cpu_baseline": None})
+                if distributed:
+                    dist.destroy_process_group()
+                return
             if args.host_gen:
                 raise SystemExit("--host-gen has no density mode")
             m, gen_stats = sa.gen.rmat_device(args.rmat_scale, target_nnz=target, seed=3, values="uniform", device=local_rank, return_stats=True)
@@ -625,7 +641,7 @@ def main():
                             ("row-partition x%d, B row-block all-to-all (%d blocks sent / %d received by rank 0 per step = %.2f %% of the "
                              "all-gather's traffic), own-shard product overlapped" % (world, ex.n_send, ex.n_recv, 100.0 * ex.needed_fraction))),
             "launch": ("HIP graph of %d steps, replayed %d times" % (G, args.steps // G)) if graph is not None else "eager",
-            "preroll_steps": preroll, "event_ms_per_step": round(event_ms_per_step, 5),
+            "preroll_steps": preroll, "event_ms_per_step": round(event_ms_per_step, 5), "kernel_rev": sa.KERNEL_REV,
         },
         "roofline": roofline,
         "cpu_baseline": cpu,

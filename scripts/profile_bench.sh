@@ -18,7 +18,7 @@ out = sys.argv[1]
 res = {"kernel_stats": [], "pmc": {}}
 for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "vbs_" in r["Name"]:
+        if "vbs_" in r["Name"] or "sparse_" in r["Name"] or "b_to_row_major" in r["Name"]:
             res["kernel_stats"].append({"name": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])})
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
@@ -42,7 +42,8 @@ try:
     json.dump({
         "note": "HBM bytes per launch of the dominant kernel of the default bench.py workload, from rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs, counters only). Correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE (KB) reports 1/2 of a wide coalesced read on gfx950 -> doubled; WRITE_SIZE (KB) exact.",
         "command": "scripts/profile_bench.sh <tag>  (rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE -- python3 bench.py ...; rocprofv3 --pmc WRITE_SIZE TCC_HIT TCC_MISS -- python3 bench.py ...)",
-        "workload": {"vbs_area": bj["config"]["vbs_area"], "n_cols": bj["config"]["n_cols"], "kernel_path": bj["config"]["kernel_path"], "dtype": bj["dtype"]},
+        "workload": {"vbs_area": bj["config"]["vbs_area"], "n_cols": bj["config"]["n_cols"], "kernel_path": bj["config"]["kernel_path"], "dtype": bj["dtype"],
+                     "kernel_rev": bj["config"].get("kernel_rev", "")},
         "kernel": key, "kernel_avg_ns_in_trace": dom["avg_ns"],
         "FETCH_SIZE_KB": p["FETCH_SIZE"], "WRITE_SIZE_KB": p["WRITE_SIZE"], "hbm_bytes_per_launch": p["hbm_bytes_per_launch_corrected"],
     }, open(out + "/traffic.json", "w"), indent=1)
