@@ -34,8 +34,16 @@ __device__ __forceinline__ float sp_widen(unsigned short u, bool bf16) {
     return bf16 ? __builtin_bit_cast(float, (uint32_t)u << 16) : (float)__builtin_bit_cast(_Float16, u);
 }
 
+// lane t < SP_BATCH takes nonzero q + t of [q, p1) (column 0 / value 0 beyond the end: a valid row of B, never used)
+__device__ __forceinline__ void sp_batch_load(const SparseParams& p, int64_t q, int64_t p1, int lane, int& cl, float& vl) {
+    cl = 0; vl = 0.0f;
+    if (lane < SP_BATCH && q + lane < p1) { cl = p.col[q + lane]; vl = p.val[q + lane]; }
+}
+
+// (cl, vl) = the first batch of the row, already requested by the caller (sp_batch_load at p0): the (column, value) pairs of batch
+// i + 1 are requested BEFORE the rows of B of batch i, so a batch costs one memory latency, not two in a row
 template <int VEC, int BK>
-__device__ __forceinline__ typename SpVec<VEC>::T sparse_row_partial(const SparseParams& p, int64_t p0, int64_t p1, int n0, int lane) {
+__device__ __forceinline__ typename SpVec<VEC>::T sparse_row_partial(const SparseParams& p, int64_t p0, int64_t p1, int n0, int lane, int cl, float vl) {
     typedef typename SpVec<VEC>::T V;
     typedef typename std::conditional<BK == 0, float, unsigned short>::type E;
     typedef typename std::conditional<BK == 0, V, typename SpRaw16<VEC>::T>::type L;
@@ -44,9 +52,9 @@ __device__ __forceinline__ typename SpVec<VEC>::T sparse_row_partial(const Spars
     const E* Bl = (const E*)p.B + (in ? n0 : 0);
     for (int64_t q = p0; q < p1; q += SP_BATCH) {
         const int n = (int)(p1 - q < SP_BATCH ? p1 - q : SP_BATCH);            // wave-uniform
-        int cl = 0;
-        float vl = 0.0f;
-        if (lane < n) { cl = p.col[q + lane]; vl = p.val[q + lane]; }
+        int cn;
+        float vn;
+        sp_batch_load(p, q + SP_BATCH, p1, lane, cn, vn);
         L b[SP_BATCH];
         if (VEC == 1 && p.b_col_stride > 0) {                    // column-major B in place (few sparse rows: cheaper than transposing all of B)
             const E* Bc = (const E*)p.B + (in ? (int64_t)n0 * p.b_col_stride : 0);
@@ -75,6 +83,7 @@ __device__ __forceinline__ typename SpVec<VEC>::T sparse_row_partial(const Spars
                 }
             }
         }
+        cl = cn; vl = vn;
     }
     return acc;
 }
@@ -83,8 +92,8 @@ template <int VEC>
 __device__ __forceinline__ void sparse_row_store(const SparseParams& p, int ord, typename SpVec<VEC>::T acc, int n0) {
     typedef typename SpVec<VEC>::T V;
     if (VEC == 1 && n0 >= p.N) return;
-    float* o = p.out + (int64_t)(p.out_is_c ? p.crow[ord] : ord) * p.ldo + n0;
-    if (p.out_is_c && p.accumulate) acc += *reinterpret_cast<const V*>(o);
+    float* o = p.out + (int64_t)p.crow[ord] * p.ldo + n0;
+    if (p.accumulate) acc += *reinterpret_cast<const V*>(o);
     *reinterpret_cast<V*>(o) = acc;
 }
 
@@ -97,7 +106,100 @@ __global__ __launch_bounds__(kThreads) void sparse_rows_kernel(SparseParams p) {
     const int ord = p.list[slot];
     const int n0 = (blockIdx.y * 64 + lane) * VEC;
     const int64_t p0 = p.rowptr[ord], p1 = p.rowptr[ord + 1];
-    sparse_row_store<VEC>(p, ord, sparse_row_partial<VEC, BK>(p, p0, p1, n0, lane), n0);
+    int cl;
+    float vl;
+    sp_batch_load(p, p0, p1, lane, cl, vl);
+    sparse_row_store<VEC>(p, ord, sparse_row_partial<VEC, BK>(p, p0, p1, n0, lane, cl, vl), n0);
+}
+
+// kCmRows partial rows of one chunk of columns meet in LDS (element (row j, column l * VEC + e) at ((e * kCmRows + j) * 65 + l)) and leave
+// as pieces of kCmRows consecutive rows of one column of the column-major C: thread (j, cg) stores row j of columns cg, cg + CG, ...
+template <int VEC, int kCmRows>
+__device__ __forceinline__ void sp_cm_flush(const SparseParams& p, const float* tile, bool valid, int32_t crow) {
+    constexpr int W = 64 * VEC;
+    constexpr int CG = kThreads / kCmRows;                       // columns written at a time (one per group of kCmRows threads)
+    constexpr int NQ = W / CG < 8 ? W / CG : 8;                  // stores of a thread in flight
+    static_assert(W % (CG * NQ) == 0, "chunk width must be a whole number of store rounds");
+    const int j = threadIdx.x & (kCmRows - 1), cg = threadIdx.x / kCmRows;
+    if (!valid) return;
+    const int cbase = blockIdx.y * W;
+    float* o = p.out + crow + (int64_t)cbase * p.ldo;
+#pragma unroll 1
+    for (int c0 = 0; c0 < W; c0 += NQ * CG) {
+        float x[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int c = c0 + cg + CG * q;
+            x[q] = tile[((c % VEC) * kCmRows + j) * 65 + c / VEC];
+        }
+        if (p.accumulate) {
+            float old[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const int c = c0 + cg + CG * q;
+                old[q] = o[(int64_t)(cbase + c < p.N ? c : 0) * p.ldo];
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; q++) x[q] += old[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int c = c0 + cg + CG * q;
+            if (VEC > 1 || cbase + c < p.N) o[(int64_t)c * p.ldo] = x[q];
+        }
+    }
+}
+
+// the same for a COLUMN-major C (the reference's layout): a workgroup takes kCmRows consecutive rows of the list (mostly consecutive rows
+// of C), each wave walks kCmRows / 4 of them one after the other, the partial rows meet in LDS and leave as pieces of kCmRows consecutive
+// rows of one column (kCmRows * 4 contiguous bytes where the C rows are consecutive).  Replaces "row-major scratch + scatter launch": the product
+// is written once instead of written, read back and written again.
+template <int VEC, int BK, int kCmRows>
+__global__ __launch_bounds__(kThreads) void sparse_rows_cm_kernel(SparseParams p) {
+    typedef typename SpVec<VEC>::T V;
+    __shared__ float tile[VEC * kCmRows * 65];                   // 64 * VEC columns of kCmRows rows, layout in sp_cm_flush
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot0 = blockIdx.x * kCmRows;
+    const int n0 = (blockIdx.y * 64 + lane) * VEC;
+    // the wave's rows: lane i holds the nonzero range of row j = wave + 4 i (one chain of dependent loads for all of them, not one per row)
+    int mlo = 0, mhi = 0, mcnt = 0;
+    if (lane < kCmRows / 4 && slot0 + wave + 4 * lane < p.n_list) {
+        const int ord = p.list[slot0 + wave + 4 * lane];
+        const int64_t a = p.rowptr[ord];
+        mlo = (int)(uint32_t)a; mhi = (int)(a >> 32); mcnt = (int)(p.rowptr[ord + 1] - a);
+    }
+    auto row_p0 = [&](int i) {
+        return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mhi, i) << 32) | (uint32_t)__builtin_amdgcn_readlane(mlo, i));
+    };
+    int cl;
+    float vl;
+    {
+        const int64_t a = row_p0(0);
+        sp_batch_load(p, a, a + __builtin_amdgcn_readlane(mcnt, 0), lane, cl, vl);
+    }
+#pragma unroll 1
+    for (int i = 0; i < kCmRows / 4; i++) {
+        const int j = wave + 4 * i;
+        const int64_t p0 = row_p0(i), p1 = p0 + __builtin_amdgcn_readlane(mcnt, i);
+        int cn = 0;
+        float vn = 0.0f;
+        if (i + 1 < kCmRows / 4) {                               // first batch of the next row, requested before this row's rows of B
+            const int64_t a = row_p0(i + 1);
+            sp_batch_load(p, a, a + __builtin_amdgcn_readlane(mcnt, i + 1), lane, cn, vn);
+        }
+        const V acc = sparse_row_partial<VEC, BK>(p, p0, p1, n0, lane, cl, vl);      // an empty range (slot past the list) gives zeros
+        cl = cn; vl = vn;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            float x;
+            if constexpr (VEC == 1) x = acc; else x = acc[e];
+            tile[(e * kCmRows + j) * 65 + lane] = x;
+        }
+    }
+    __syncthreads();
+    const int fj = threadIdx.x & (kCmRows - 1);
+    const bool valid = slot0 + fj < p.n_list;
+    sp_cm_flush<VEC, kCmRows>(p, tile, valid, valid ? p.crow[p.list[slot0 + fj]] : 0);
 }
 
 // long rows (hubs): cut into segments of <= kSpSeg nonzeros, one wave per segment writes a partial row; a second launch adds
@@ -110,7 +212,10 @@ __global__ __launch_bounds__(kThreads) void sparse_segments_kernel(SparseParams 
     if (slot >= n_segs) return;
     const SpSegRec sg = segs[slot];
     const int n0 = (blockIdx.y * 64 + lane) * VEC;
-    typename SpVec<VEC>::T acc = sparse_row_partial<VEC, BK>(p, sg.p0, sg.p0 + sg.cnt, n0, lane);
+    int cl;
+    float vl;
+    sp_batch_load(p, sg.p0, sg.p0 + sg.cnt, lane, cl, vl);
+    typename SpVec<VEC>::T acc = sparse_row_partial<VEC, BK>(p, sg.p0, sg.p0 + sg.cnt, n0, lane, cl, vl);
     if (VEC == 1 && n0 >= p.N) return;
     *reinterpret_cast<typename SpVec<VEC>::T*>(part + (int64_t)slot * p.N + n0) = acc;
 }
@@ -127,6 +232,37 @@ __global__ __launch_bounds__(kThreads) void sparse_reduce_kernel(SparseParams p,
     V acc = (V)(0.0f);
     for (int sgi = 0; sgi < r.n_seg; sgi++) acc += *reinterpret_cast<const V*>(part + (int64_t)(r.seg_begin + sgi) * p.N + n0);
     sparse_row_store<VEC>(p, r.ord, acc, n0);
+}
+
+// the same for a column-major C: kCmRows long rows per workgroup through LDS (where most rows are long - dense power-law inputs - this
+// kernel writes most of C)
+template <int VEC, int kCmRows>
+__global__ __launch_bounds__(kThreads) void sparse_reduce_cm_kernel(SparseParams p, const SpLongRec* rows, int32_t n_rows, const float* part) {
+    typedef typename SpVec<VEC>::T V;
+    __shared__ float tile[VEC * kCmRows * 65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot0 = blockIdx.x * kCmRows;
+    const int n0 = (blockIdx.y * 64 + lane) * VEC;
+    const bool in = VEC > 1 || n0 < p.N;
+#pragma unroll 1
+    for (int i = 0; i < kCmRows / 4; i++) {
+        const int j = wave + 4 * i;
+        V acc = (V)(0.0f);
+        if (slot0 + j < n_rows && in) {
+            const SpLongRec r = rows[slot0 + j];
+            for (int sgi = 0; sgi < r.n_seg; sgi++) acc += *reinterpret_cast<const V*>(part + (int64_t)(r.seg_begin + sgi) * p.N + n0);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            float x;
+            if constexpr (VEC == 1) x = acc; else x = acc[e];
+            tile[(e * kCmRows + j) * 65 + lane] = x;
+        }
+    }
+    __syncthreads();
+    const int fj = threadIdx.x & (kCmRows - 1);
+    const bool valid = slot0 + fj < n_rows;
+    sp_cm_flush<VEC, kCmRows>(p, tile, valid, valid ? p.crow[rows[slot0 + fj].ord] : 0);
 }
 
 // B (column-major, ld = ldb, or the gathered slabs) -> row-major rows x N (ld = N); 64 x 64 tiles through LDS: a wave reads 64
@@ -165,51 +301,6 @@ __global__ __launch_bounds__(kThreads) void b_to_row_major_kernel(const E* __res
     }
 }
 
-// scratch (row-major, one row per sparse row) -> the column-major C rows they belong to
-__global__ __launch_bounds__(kThreads) void sparse_c_scatter_kernel(const float* __restrict__ src, const int32_t* __restrict__ crow, int64_t n_rows, int N,
-                                                                    float* __restrict__ C, int64_t ldc, int accumulate) {
-    __shared__ float tile[64][65];                               // 64 sparse rows x 64 columns
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n_ct = (N + 63) / 64;                              // 1-D grid, column tile fastest (see b_to_row_major_kernel)
-    const int64_t t0 = (int64_t)(blockIdx.x / n_ct) * 64;
-    const int n0 = (int)(blockIdx.x % n_ct) * 64;
-    const int64_t t = t0 + lane;
-    const int32_t r = crow[t < n_rows ? t : n_rows - 1];         // consecutive sparse rows are mostly consecutive rows of C (requested with the tile's loads)
-    {
-        const int n = n0 + lane;
-        const int nc = n < N ? n : N - 1;
-        float v[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {                           // read: lanes along the columns of one scratch row; 16 loads in flight (clamped, not guarded)
-            const int64_t t = t0 + wave + 4 * q;
-            v[q] = src[(t < n_rows ? t : n_rows - 1) * N + nc];
-        }
-#pragma unroll
-        for (int q = 0; q < 16; q++) tile[wave + 4 * q][lane] = (t0 + wave + 4 * q < n_rows && n < N) ? v[q] : 0.0f;
-    }
-    __syncthreads();
-    if (t >= n_rows) return;
-    if (accumulate) {
-        float old[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int n = n0 + wave + 4 * q;
-            old[q] = C[r + (int64_t)(n < N ? n : N - 1) * ldc];
-        }
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int n = n0 + wave + 4 * q;
-            if (n < N) C[r + (int64_t)n * ldc] = old[q] + tile[lane][wave + 4 * q];
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 16; q++) {                           // write: lanes along the rows of one column of C
-            const int n = n0 + wave + 4 * q;
-            if (n < N) C[r + (int64_t)n * ldc] = tile[lane][wave + 4 * q];
-        }
-    }
-}
-
 // ---- row-block pack (multi-GPU exchange of only the needed rows of B) ---------------------------------
 // dst chunk i <- src chunk ids[i]; a chunk is one w x N tile of B (block_bytes, a multiple of 16).  One workgroup per
 // chunk and grid.y slice; 16-byte loads / stores, fully coalesced: HBM-bound, bytes = 2 x n_blocks x block_bytes.
@@ -239,11 +330,17 @@ void launch_sparse_t(SparseParams q, unsigned gy, hipStream_t st, const int32_t*
                      const SpLongRec* longs, int64_t n_long, float* part) {
     if (n_short > 0) {
         q.list = list; q.n_list = (int32_t)n_short;
-        hipLaunchKernelGGL((sparse_rows_kernel<VEC, BK>), dim3((unsigned)((n_short + 3) / 4), gy), dim3(kThreads), 0, st, q);
+        // rows of C per workgroup: 16 (64-byte pieces of a column) measured >= 32 (128-byte pieces, half the workgroups) from R-MAT 2^14 to 2^20;
+        // SPARTA_SP_CMROWS=32 is the developer's switch
+        static const int cm_rows = [] { const char* e = std::getenv("SPARTA_SP_CMROWS"); return e ? atoi(e) : 16; }();
+        if (q.out_is_c == 2 && cm_rows == 16) hipLaunchKernelGGL((sparse_rows_cm_kernel<VEC, BK, 16>), dim3((unsigned)((n_short + 15) / 16), gy), dim3(kThreads), 0, st, q);
+        else if (q.out_is_c == 2) hipLaunchKernelGGL((sparse_rows_cm_kernel<VEC, BK, 32>), dim3((unsigned)((n_short + 31) / 32), gy), dim3(kThreads), 0, st, q);
+        else hipLaunchKernelGGL((sparse_rows_kernel<VEC, BK>), dim3((unsigned)((n_short + 3) / 4), gy), dim3(kThreads), 0, st, q);
     }
     if (n_long > 0) {
         hipLaunchKernelGGL((sparse_segments_kernel<VEC, BK>), dim3((unsigned)((n_segs + 3) / 4), gy), dim3(kThreads), 0, st, q, segs, (int32_t)n_segs, part);
-        hipLaunchKernelGGL(sparse_reduce_kernel<VEC>, dim3((unsigned)((n_long + 3) / 4), gy), dim3(kThreads), 0, st, q, longs, (int32_t)n_long, (const float*)part);
+        if (q.out_is_c == 2) hipLaunchKernelGGL((sparse_reduce_cm_kernel<VEC, 16>), dim3((unsigned)((n_long + 15) / 16), gy), dim3(kThreads), 0, st, q, longs, (int32_t)n_long, (const float*)part);
+        else hipLaunchKernelGGL(sparse_reduce_kernel<VEC>, dim3((unsigned)((n_long + 3) / 4), gy), dim3(kThreads), 0, st, q, longs, (int32_t)n_long, (const float*)part);
     }
 }
 }  // namespace
@@ -264,10 +361,6 @@ void launch_b_to_row_major(bool is16, unsigned grid, hipStream_t st, const void*
                            void* out) {
     if (!is16) hipLaunchKernelGGL(b_to_row_major_kernel<float>, dim3(grid), dim3(kThreads), 0, st, (const float*)B, ldb, shard_rows, shard_stride, rows, N, (float*)out);
     else hipLaunchKernelGGL(b_to_row_major_kernel<unsigned short>, dim3(grid), dim3(kThreads), 0, st, (const unsigned short*)B, ldb, shard_rows, shard_stride, rows, N, (unsigned short*)out);
-}
-
-void launch_c_scatter(unsigned grid, hipStream_t st, const float* src, const int32_t* crow, int64_t n_rows, int N, float* C, int64_t ldc, int accumulate) {
-    hipLaunchKernelGGL(sparse_c_scatter_kernel, dim3(grid), dim3(kThreads), 0, st, src, crow, n_rows, N, C, ldc, accumulate);
 }
 
 void launch_pack_blocks(dim3 grid, hipStream_t st, const void* src, const int32_t* ids, void* dst, int64_t block_vec) {

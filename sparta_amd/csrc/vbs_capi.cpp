@@ -68,7 +68,6 @@ void destroy_impl(sparta_vbs* v) {
     if (v->d_sp_long) (void)hipFree(v->d_sp_long);
     if (v->d_sp_part) (void)hipFree(v->d_sp_part);
     if (v->d_Brm) (void)hipFree(v->d_Brm);
-    if (v->d_spC) (void)hipFree(v->d_spC);
     if (v->d_B) (void)hipFree(v->d_B);
     if (v->d_C) (void)hipFree(v->d_C);
     if (v->ev0) (void)hipEventDestroy(v->ev0);
@@ -661,24 +660,29 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
         launch_b_to_row_major(bk != 0, (unsigned)n_wg, st, dB, ldb, shard_rows, shard_stride, A->cols, (int)n_cols, A->d_Brm);
         q.B = A->d_Brm; q.ldb = n_cols;
     }
-    if (c_row_major) { q.out = dC; q.ldo = ldc; q.out_is_c = 1; }
-    else {
-        if (int rc = ensure_scratch(&A->d_spC, &A->d_spC_bytes, (size_t)A->n_sp_rows * (size_t)n_cols * sizeof(float))) return rc;
-        q.out = (float*)A->d_spC; q.ldo = n_cols; q.out_is_c = 0;
-    }
+    // the kernels write C themselves: rows of a row-major C, or 16-row pieces of the columns of the reference's column-major C
+    q.out = dC; q.ldo = ldc; q.out_is_c = c_row_major ? 1 : 2;
     if (A->n_sp_long > 0)
         if (int rc = ensure_scratch(&A->d_sp_part, &A->d_sp_part_bytes, (size_t)A->n_sp_segs * (size_t)n_cols * sizeof(float))) return rc;
     // widest vector the shapes allow: every row start VEC-element aligned, N a multiple of 64 * VEC (no ragged chunk)
     auto aligned = [&](int v) {
-        return n_cols % (64 * v) == 0 && q.ldb % v == 0 && q.ldo % v == 0 && ((uintptr_t)q.B % (esz * v)) == 0 && ((uintptr_t)q.out % (4 * v)) == 0;
+        const bool out_ok = q.out_is_c == 2 || (q.ldo % v == 0 && ((uintptr_t)q.out % (4 * v)) == 0);
+        return n_cols % (64 * v) == 0 && q.ldb % v == 0 && out_ok && ((uintptr_t)q.B % (esz * v)) == 0;
     };
-    const int vec = in_place ? 1 : (aligned(4) ? 4 : (aligned(2) ? 2 : 1));
+    // How many columns of C a wave takes = how many bytes of a row of B one gather instruction reads.  A workgroup column (grid y) is walked
+    // to the end before the next starts, so the bytes per row set how many rows of B an XCD's 4 MiB L2 holds while the rows that reference
+    // them go by: on power-law inputs the hub rows of B stay resident with narrow chunks and are pushed out by wide ones.  Measured
+    // (R-MAT, 10 edges per row, fp32 N = 256 | bf16 N = 512; ms per product at 1024 / 512 / 256 bytes per row): 2^20 rows (|B| = 1 GiB)
+    // 4.33 / 3.92 / 3.77 | - / 4.54 / 4.27; 2^18 rows (256 MiB) 0.93 / 0.87 / 0.89 | - / 1.02 / 1.03; 2^16 rows and below: widest wins
+    // by 3-10 %.  2-byte loads (one bf16 per lane) are slow whatever the size (6.6 ms) and never chosen.  SPARTA_SP_VEC caps the width.
+    static const int vec_cap = [] { const char* e = std::getenv("SPARTA_SP_VEC"); return e ? atoi(e) : 4; }();
+    const double b_bytes = (double)A->cols * (double)n_cols * (double)esz;
+    const int row_bytes = b_bytes > 384e6 ? 256 : (b_bytes > 96e6 ? 512 : 1024);
+    const int vec_want = std::max(esz == 2 ? 2 : 1, std::min(vec_cap, (int)(row_bytes / (64 * (int)esz))));
+    const int vec = in_place ? 1 : (vec_want >= 4 && aligned(4) ? 4 : (vec_want >= 2 && aligned(2) ? 2 : 1));
     const unsigned gy = (unsigned)((n_cols + 64 * vec - 1) / (64 * vec));
     launch_sparse_kernels(vec, bk, q, gy, st, A->d_sp_list, A->n_sp_short, (const SpSegRec*)A->d_sp_segs, A->n_sp_segs, (const SpLongRec*)A->d_sp_long,
                           A->n_sp_long, (float*)A->d_sp_part);
-    if (!q.out_is_c)
-        launch_c_scatter((unsigned)(((A->n_sp_rows + 63) / 64) * (int64_t)((n_cols + 63) / 64)), st, (const float*)A->d_spC, A->d_sp_crow, A->n_sp_rows,
-                         (int)n_cols, dC, ldc, (int)accumulate);
     HIP_TRY(hipGetLastError());
     return SPARTA_OK;
 }

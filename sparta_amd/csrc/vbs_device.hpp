@@ -117,7 +117,7 @@ struct SparseParams {
     int64_t b_col_stride;      // 0: row-major B as above.  > 0: B is COLUMN-major (element (k, n) at slab(k) + k % shard_rows + n * b_col_stride),
     int64_t shard_rows, shard_stride;   //      read in place, one 4-byte gather per element: only worth it for a handful of sparse rows
     int64_t ldb;
-    float* out;                // row-major out: C itself (ld = ldc, row = crow) or the scratch (ld = N, row = ordinal)
+    float* out;                // out_is_c 1: row-major C (ld = ldc, row = crow); 2: COLUMN-major C (ld = ldc)
     int64_t ldo;
     int32_t out_is_c, accumulate, N;
 };
@@ -216,8 +216,6 @@ struct sparta_vbs {
     size_t d_sp_part_bytes = 0;
     void* d_Brm = nullptr;                 // row-major copy of a column-major / gathered B
     size_t d_Brm_bytes = 0;
-    void* d_spC = nullptr;                 // row-major results awaiting the scatter into a column-major C
-    size_t d_spC_bytes = 0;
     void* d_B = nullptr;
     size_t d_B_bytes = 0;
     void* d_C = nullptr;
@@ -251,7 +249,6 @@ void launch_sparse_kernels(int vec, int bk, const SparseParams& q, unsigned gy, 
                            int64_t n_segs, const SpLongRec* longs, int64_t n_long, float* part);
 void launch_b_to_row_major(bool is16, unsigned grid, hipStream_t st, const void* B, int64_t ldb, int64_t shard_rows, int64_t shard_stride, int64_t rows, int N,
                            void* out);
-void launch_c_scatter(unsigned grid, hipStream_t st, const float* src, const int32_t* crow, int64_t n_rows, int N, float* C, int64_t ldc, int accumulate);
 void launch_pack_blocks(dim3 grid, hipStream_t st, const void* src, const int32_t* ids, void* dst, int64_t block_vec);
 
 // vbs_plan.cpp
