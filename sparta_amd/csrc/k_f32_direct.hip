@@ -1,0 +1,215 @@
+// k_f32_direct.hip -- fp32 stream kernel without a workgroup-wide stage: A arrives in MFMA fragment order straight from global memory,
+// every wave converts its own 32 columns of the B panel in a wave-private LDS image; no barrier.  Part of the device side of
+// libsparta_amd.so; see vbs_device.hpp for the translation-unit map and DESIGN.md section 3.2.
+#include "vbs_kernel_common.hpp"
+
+using namespace sparta_dev;
+
+namespace {
+
+// =====================================================================================================
+// vbs_spmm_f32_direct_kernel: the one-tile fp32 stream kernel with NO workgroup-wide stage and NO barrier.
+//
+// A step multiplies a <= 32-row x 32 slice of A with a 32 x 128 panel of B; wave v owns columns [32v, 32v+32).  No element of
+// the panel is used by more than ONE wave: the only thing the four waves share is the 4 KB slice of A.  So
+//   * A arrives in MFMA fragment order straight from global memory into registers: the host lays every step's slice out as
+//     a_frag [j = 0..3][g][row][4] = A[row][k = 16 g + 4 j + e] (k may be summed in any order as long as both operands agree), each
+//     wave loads it itself with four contiguous 1 KB loads (L1 / L2 hits for three of the four waves);
+//   * B is column-major (k contiguous): the MFMA wants lane (i = lane & 31, g = lane >> 5) to hold 16 k of column i, but a load
+//     in that shape touches 32 different 128-byte lines per instruction and the texture addresser, not the MFMA pipe, then sets
+//     the pace (measured on the flagship: 60.4 us; the same bytes loaded 8 lanes per line: 50.6 us).  So every wave loads ITS 32
+//     columns 8 lanes per line, writes them to a wave-PRIVATE LDS image Bs[column][k] (+4 padding) and reads its fragments back
+//     with ds_read_b128: a layout conversion inside one wave -- program order and lgkmcnt are all the synchronisation there is.
+// The waves of a workgroup never meet: each walks the worker's step list on its own (records through v_readlane as in
+// vbs_spmm_f32_stream_kernel), loads three steps ahead (A: four register sets, B: two staging sets + two LDS stages), same
+// epilogue and same workspace images for split tiles, so plans, fix-up kernel and step records are shared with the LDS kernel.
+// Column-major B only, no gathered B; tiles of <= 32 rows (the one-tile plan).
+// =====================================================================================================
+__global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const StreamParams p) {
+    constexpr int TN = kTN, LDBW = 36;                  // Bs[column][k], 32 k + 4 padding: conflict-free ds_read_b128 / ds_write_b128
+    constexpr int WSTAGE = 32 * LDBW;                   // floats per wave and stage
+    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * WSTAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 31, g = lane >> 5;
+    const int n0 = blockIdx.y * TN;
+    const int s_begin = p.worker_range[2 * blockIdx.x];
+    const int n = p.worker_range[2 * blockIdx.x + 1] - s_begin;
+    if (n <= 0) return;
+    clock_probe(p.clk, 0);
+    float* ws = p.ws + (int64_t)blockIdx.y * p.ws_slab_stride;
+
+    const int32_t* srec = reinterpret_cast<const int32_t*>(p.steps + s_begin);
+    int vrec0 = srec[lane];
+    int vrec1 = srec[64 + lane];
+    int vnext = 0;
+#define field(s, f) sk_field(vrec0, vrec1, (s), (f))
+    enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6, F_SHARD = 7 };
+
+    // per-lane constants.  B load q (0..3): column 8 q + (lane >> 3) of the wave's 32, k = 4 (lane & 7) .. + 3
+    const int bc = lane >> 3, bk = (lane & 7) * 4;
+    const int64_t ld_t = (int64_t)p.w;                                            // leading dimension of B_tail (column-major, w rows)
+    const uint32_t voffB = (uint32_t)(((32 * wave + bc) * p.ldb + bk) * 4);
+    const uint32_t voffBt = (uint32_t)(((n0 + 32 * wave + bc) * ld_t + bk) * 4);
+    const uint32_t qstepB = (uint32_t)(8 * p.ldb * 4), qstepBt = (uint32_t)(8 * ld_t * 4);
+    const uint32_t voffA = (uint32_t)((g * 32 + lm) * 16);                        // a_frag: [j][g][row][4]; j advances by 1 KB (soffset)
+    const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 32 * wave + 4 * g) * 4) : (uint32_t)((lm + (32 * wave + 4 * g) * p.ldc) * 4);
+    const int64_t n0off = (int64_t)n0 * p.ldb;
+    char* const ldsw = reinterpret_cast<char*>(lds) + wave * (2 * WSTAGE * 4);   // this wave's two stages
+    const uint32_t lwB = (uint32_t)((bc * LDBW + bk) * 4);                        // write: column bc + 8 q -> + 8 q LDBW floats
+    const uint32_t lrB = (uint32_t)((lm * LDBW + 16 * g) * 4);                    // read: column lm, k = 16 g + 4 j .. + 3
+
+    u32x4 bs0[4], bs1[4];                                // B staging sets (steps of even / odd index)
+    u32x4 as0[4], as1[4], as2[4], as3[4];                // A fragment sets (step index mod 4)
+
+    const float* a_cur = p.A + (int64_t)s_begin * 1024;  // a_frag slice of the next step to be requested (steps are requested in order)
+    uint32_t vo_cur = voffB;
+    int32_t tail_prev = 0;
+    auto issue_loads = [&](int s, u32x4 (&rb)[4], u32x4 (&ra)[4]) __attribute__((always_inline)) -> int32_t {
+        const int32_t flags = field(s, F_FLAGS);
+        const int32_t tail = (flags & STEP_TAIL) != 0;
+        if (tail != tail_prev) {
+            vo_cur = tail ? voffBt : voffB;
+            asm volatile("" : "+v"(vo_cur));
+            tail_prev = tail;
+        }
+        const int64_t gk0 = field(s, F_BROW);
+        const float* bptr = tail ? p.B_tail + gk0 : p.B + gk0 + n0off;
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bptr), 0, 0x7ffffff0, 0x00020000);
+        const uint32_t qs = tail ? qstepBt : qstepB;
+#pragma unroll
+        for (int q = 0; q < 4; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, qs * q, 0);
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_cur), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; j++) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA, 1024 * j, 0);
+        a_cur += 1024;
+        return flags;
+    };
+    int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq_new = 0;
+
+    auto write_b = [&](auto stage_tag, const u32x4 (&rb)[4]) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_tag)::value;
+#pragma unroll
+        for (int q = 0; q < 4; q++) *reinterpret_cast<u32x4*>(ldsw + lwB + (ST * WSTAGE + 8 * q * LDBW) * 4) = rb[q];
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+
+    // one step: fragments of B from LDS stage PAR, the next step's panel into the other stage, 16 MFMAs, then the staging set that was
+    // just written out and the A set of step i - 1 are refilled with step i + 3
+    // one step: fragments of B from LDS stage PAR, the next step's panel into the other stage, 16 MFMAs, then the staging set that was
+    // just written out and the A set of step i - 1 are refilled with step i + 3.  (Measured and dropped: reading the fragments of step
+    // i + 1 during step i -- 16 more registers, 56.0 us against 54.1.)
+    auto step = [&](int i, int32_t flags, auto par_tag, u32x4 (&wa)[4], u32x4 (&nb)[4], u32x4 (&na)[4]) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_tag)::value;
+        f32x4 fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const f32x4*>(ldsw + lrB + (PAR * WSTAGE + 4 * j) * 4);
+        write_b(std::integral_constant<int, 1 - PAR>{}, nb);             // W(i + 1)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][e], __uint_as_float(wa[j][e]), acc, 0, 0, 0);
+        fq_new = issue_loads(i + 3, nb, na);                              // G(i + 3)
+        if (flags & STEP_LAST) {
+            // epilogue (as in vbs_spmm_f32_stream_kernel): stored from copies, accumulators cleared here
+            if (flags & STEP_SPLIT) {
+                const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_SLOT) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[q]), rW, (uint32_t)tid * 4u, (uint32_t)(q * kThreads * 4), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(0u, rW, (uint32_t)tid * 4u, (uint32_t)((16 + q) * kThreads * 4), 0);   // rows 32..63 of the image: none
+                }
+            } else {
+                const int mt = flags & 0xffff;
+                const int64_t c_row = field(i, F_CROW);
+                float* cbase = p.c_row_major ? p.C + c_row * p.ldc + n0 : p.C + c_row + (int64_t)n0 * p.ldc;
+                const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
+                const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;          // bytes per output column
+                if (lm < mt) {
+                    float v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) v[q] = acc[q];
+                    if (p.accumulate) {
+                        uint32_t old[16];
+#pragma unroll
+                        for (int q = 0; q < 16; q++) old[q] = __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 0);
+#pragma unroll
+                        for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; q++)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[q] = 0.0f;
+        }
+    };
+
+    // step-record batches: requested at step 8k, placed at step 8k + 4 (see vbs_spmm_f32_stream_kernel; 32 loads are issued in between)
+    auto batch_upkeep = [&](int i) __attribute__((always_inline)) {
+        if ((i & 7) == 0 && i > 0) {
+            const int32_t* nb = srec + (int64_t)((i >> 3) + 1) * 64 + lane;
+            asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
+        }
+        if ((i & 7) == 4 && i > 4) {
+            asm volatile("s_waitcnt vmcnt(6)" : "+v"(vnext) : : "memory");
+            const bool odd = (((i >> 3) + 1) & 1) != 0;
+            vrec1 = odd ? vnext : vrec1;
+            vrec0 = odd ? vrec0 : vnext;
+        }
+    };
+
+    using p0 = std::integral_constant<int, 0>;
+    using p1 = std::integral_constant<int, 1>;
+    fq0 = issue_loads(0, bs0, as0);
+    fq1 = issue_loads(1, bs1, as1);
+    write_b(p0{}, bs0);                                  // W(0)
+    fq2 = issue_loads(2, bs0, as2);
+    // step i: LDS stage i & 1, A set i & 3; writes out staging set (i + 1) & 1 and refills it, and A set (i + 3) & 3, with step i + 3
+    const int n4 = n & ~3;
+    for (int i = 0; i < n4; i += 4) {
+        batch_upkeep(i);
+        step(i, fq0, p0{}, as0, bs1, as3);
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+        batch_upkeep(i + 1);
+        step(i + 1, fq0, p1{}, as1, bs0, as0);
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+        batch_upkeep(i + 2);
+        step(i + 2, fq0, p0{}, as2, bs1, as1);
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+        batch_upkeep(i + 3);
+        step(i + 3, fq0, p1{}, as3, bs0, as2);
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+    }
+    if (n - n4 >= 1) {
+        batch_upkeep(n4);
+        step(n4, fq0, p0{}, as0, bs1, as3);
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+    }
+    if (n - n4 >= 2) {
+        batch_upkeep(n4 + 1);
+        step(n4 + 1, fq0, p1{}, as1, bs0, as0);
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+    }
+    if (n - n4 == 3) {
+        batch_upkeep(n4 + 2);
+        step(n4 + 2, fq0, p0{}, as2, bs1, as1);
+    }
+    clock_probe(p.clk, 2);
+#undef field
+}
+
+}  // namespace
+
+namespace sparta_dev {
+
+void launch_f32_direct(dim3 grid, hipStream_t st, const StreamParams& sp) {
+    hipLaunchKernelGGL(vbs_spmm_f32_direct_kernel, grid, dim3(kThreads), 0, st, sp);
+}
+
+}  // namespace sparta_dev

@@ -47,6 +47,7 @@ void destroy_impl(sparta_vbs* v) {
         if (v->d_steps_g[ty]) (void)hipFree(v->d_steps_g[ty]);
         if (v->d_wrange[ty]) (void)hipFree(v->d_wrange[ty]);
     }
+    if (v->d_a_frag) (void)hipFree(v->d_a_frag);
     if (v->d_steps_k64) (void)hipFree(v->d_steps_k64);
     if (v->d_wrange_k64) (void)hipFree(v->d_wrange_k64);
     if (v->d_fix) (void)hipFree(v->d_fix);
@@ -395,6 +396,10 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             v->h_steps[ty] = st;
             CREATE_TRY(hipMalloc((void**)&v->d_wrange[ty], wrange[ty].size() * sizeof(int32_t)));
             CREATE_TRY(hipMemcpy(v->d_wrange[ty], wrange[ty].data(), wrange[ty].size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        if (!plan.a_frag.empty()) {
+            CREATE_TRY(hipMalloc((void**)&v->d_a_frag, plan.a_frag.size() * sizeof(float)));
+            CREATE_TRY(hipMemcpy(v->d_a_frag, plan.a_frag.data(), plan.a_frag.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         if (!plan.steps_k64.empty()) {
             std::vector<StepRec>& k = plan.steps_k64;
@@ -875,7 +880,11 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                     sp.steps = shard_rows > 0 ? A->d_steps_g[ty] : A->d_steps[ty]; sp.worker_range = A->d_wrange[ty];
                     sp.clk = (prof && ty == probe_ty) ? A->d_clk : nullptr;
                     if (A->pair_plan) launch_f32_pair(b_layout == SPARTA_ROW_MAJOR, shard_rows > 0, grid, st, sp);
-                    else if (ty == 0 && A->d_steps_k64 && b_layout == SPARTA_COL_MAJOR && shard_rows == 0) {
+                    else if (ty == 0 && A->d_a_frag && b_layout == SPARTA_COL_MAJOR && shard_rows == 0) {
+                        StreamParams sd = sp;                 // the <= 32-row tiles without the LDS stage
+                        sd.A = A->d_a_frag;
+                        launch_f32_direct(grid, st, sd);
+                    } else if (ty == 0 && A->d_steps_k64 && b_layout == SPARTA_COL_MAJOR && shard_rows == 0) {
                         StreamParams sk = sp;                 // the <= 32-row tiles as 64-deep steps
                         sk.steps = A->d_steps_k64; sk.worker_range = A->d_wrange_k64;
                         launch_f32_k64(grid, st, sk);

@@ -189,6 +189,7 @@ struct sparta_vbs {
     sparta_dev::StepRec* d_steps_k64 = nullptr;   // 64-deep step list of the <= 32-row tiles (column-major, non-gathered B) or nullptr
     int32_t* d_wrange_k64 = nullptr;
     int64_t n_steps_k64 = 0;
+    float* d_a_frag = nullptr;                    // A of the one-tile plan in fragment order (k_f32_direct.hip) or nullptr
     bool has_tail = false;                 // cols % w != 0: the stream path needs B_tail
     void* d_btail = nullptr;
     size_t d_btail_bytes = 0;
@@ -233,6 +234,7 @@ void launch_f32_exact(unsigned n_brows, hipStream_t st, const BlockRowDesc* rows
 // k_f32_stream.hip
 void launch_f32_stream(bool mi2, bool b_row_major, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
 void launch_f32_pair(bool b_row_major, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
+void launch_f32_direct(dim3 grid, hipStream_t st, const StreamParams& sp);
 void launch_f32_k64(dim3 grid, hipStream_t st, const StreamParams& sp);
 void launch_fixup_group(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* big, const int32_t* fix_slots, float* ws_all, int64_t ws_slab_stride);
 void launch_fixup(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* fix_slots, const float* ws_all, int64_t ws_slab_stride, float* C, int64_t ldc,
@@ -271,6 +273,7 @@ struct StreamPlanHost {
     bool pair_plan = false;                   // fp32: steps[0] is the pair plan (vbs_plan.cpp, build_pair_plan), steps[1] is empty
     std::vector<StepRec> steps_k64;           // fp32, aligned one-tile plan, cols % w == 0: the same tiles as 64-deep steps (vbs_spmm_f32_k64_kernel)
     std::vector<int32_t> wrange_k64;
+    std::vector<float> a_frag;                // fp32 one-tile plan: A per step in MFMA fragment order (vbs_spmm_f32_direct_kernel), or empty
 };
 constexpr int64_t kZeroRangeRows = 2048;    // block-rows without blocks at least this tall are zero-filled by vbs_zero_rows_kernel
 int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P);

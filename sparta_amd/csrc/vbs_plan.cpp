@@ -558,6 +558,25 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                     }
                 }
             }
+            // ---- A in MFMA fragment order for vbs_spmm_f32_direct_kernel (k_f32_direct.hip): one 4 KB slice per step of the one-tile plan,
+            // [j = 0..3][g = 0..1][row = 0..31][e = 0..3] = A[row][k = 16 g + 4 j + e], rows past the tile zero.  Opt-in (SPARTA_F32_PLAN=direct).
+            {
+                const char* de = std::getenv("SPARTA_F32_PLAN");
+                if (de && std::strcmp(de, "direct") == 0 && ty == 0 && !h16 && !P.pair_plan) {
+                    std::vector<float>& af = P.a_frag;
+                    af.assign(((size_t)S + 4) * 1024, 0.0f);                    // + 4: the pipeline requests three steps past a range end
+                    for (int64_t q = 0; q < S; q++) {
+                        const StepRec& r = st[(size_t)q];
+                        const float* blk = mab + mab_lo + r.a_off;              // element (row, k) of the slice at blk[k * h + row]
+                        const int64_t hh = r.h, mt = r.mt_flags & 0xffff;
+                        float* dst = af.data() + (size_t)q * 1024;
+                        for (int j = 0; j < 4; j++)
+                            for (int g = 0; g < 2; g++)
+                                for (int64_t m = 0; m < mt; m++)
+                                    for (int e = 0; e < 4; e++) dst[((j * 2 + g) * 32 + m) * 4 + e] = blk[(int64_t)(16 * g + 4 * j + e) * hh + m];
+                    }
+                }
+            }
             // ---- the same one-tile plan as 64-deep steps (vbs_spmm_f32_k64_kernel): fp32, no zero-padded tail block column, and an
             // aligned plan (no split tile: the 64-deep kernel has no workspace epilogue).  A tile's 64-deep steps are its 32-deep steps
             // taken two at a time (A is contiguous across consecutive steps; the two B panels are named separately); a tile with an odd

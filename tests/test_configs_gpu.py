@@ -102,7 +102,7 @@ def test_config1_flagship_blocking_every_row_against_the_oracle():
     B = torch.from_numpy(Bh).cuda()
     saved = os.environ.get("SPARTA_F32_PLAN")
     try:
-        for plan in (None, "legacy", "pair"):
+        for plan in (None, "legacy", "pair", "direct"):
             if plan is None:
                 os.environ.pop("SPARTA_F32_PLAN", None)
             else:
