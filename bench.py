@@ -538,7 +538,10 @@ def main():
         flops_exec, bytes_alg = flops_exec_dense, bytes_dense + bytes_sparse + bytes_b
         mean_h = float(m.rows) / max(n_block_rows, 1)
     dom_tflops = 2.0 * area.get(dom, 0.0) * N / (kernel_ms[dom] * 1e-3) / 1e12 if kernel_ms.get(dom, 0) > 0 else 0.0
-    kname = {"stream": "vbs_spmm_f32_stream_kernel", "fixup": "vbs_spmm_f32_fixup_kernel", "class16": "vbs_spmm_f32_kernel<16,...>",
+    # the <= 32-row tiles of an fp32 handle run the no-barrier kernel (k_f32_direct.hip) for a column-major B unless SPARTA_F32_PLAN says otherwise
+    f32_direct = (args.dtype == "f32" and os.environ.get("SPARTA_F32_PLAN", "") not in ("legacy", "pair")
+                  and info["tiles16"] + info["tiles32"] >= info["tiles64"])
+    kname = {"stream": "vbs_spmm_f32_direct_kernel" if f32_direct else "vbs_spmm_f32_stream_kernel", "fixup": "vbs_spmm_f32_fixup_kernel", "class16": "vbs_spmm_f32_kernel<16,...>",
              "class32": "vbs_spmm_f32_kernel<32,1,4,1,1,...>", "class64": "vbs_spmm_f32_kernel<32,2,2,1,2,...>"}.get(dom, dom)
     # HBM bytes per launch of that kernel from rocprofv3 PMC passes (profiles/traffic*.json, produced by scripts/profile_bench.sh on
     # the same command; FETCH_SIZE doubled per MI355X_MICROARCH.md) -- only reported when the profiled workload is the one running now

@@ -40,10 +40,13 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
     float* ws = p.ws + (int64_t)blockIdx.y * p.ws_slab_stride;
 
     const int32_t* srec = reinterpret_cast<const int32_t*>(p.steps + s_begin);
-    int vrec0 = srec[lane];
-    int vrec1 = srec[64 + lane];
+    // Step records: ONE VGPR holds the 8 records [4k, 4k + 8) (lane = 8 * record + field) while steps 4k .. 4k + 3 run -- they need the
+    // records of steps i (epilogue) and i + 3 (loads), positions 0 .. 6 of the window.  The loop is unrolled by four, so every field is
+    // ONE v_readlane with a constant lane (the two-batch scheme of the LDS kernels costs two readlanes and a select per field: VALU work
+    // that takes the pipe away from the MFMAs).  The next window is requested at step 4k and swapped in at step 4k + 4.
+    int vwin = srec[lane];
     int vnext = 0;
-#define field(s, f) sk_field(vrec0, vrec1, (s), (f))
+#define field(pos, f) __builtin_amdgcn_readlane(vwin, 8 * (pos) + (f))
     enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6, F_SHARD = 7 };
 
     // per-lane constants.  B load q (0..3): column 8 q + (lane >> 3) of the wave's 32, k = 4 (lane & 7) .. + 3
@@ -65,7 +68,8 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
     const float* a_cur = p.A + (int64_t)s_begin * 1024;  // a_frag slice of the next step to be requested (steps are requested in order)
     uint32_t vo_cur = voffB;
     int32_t tail_prev = 0;
-    auto issue_loads = [&](int s, u32x4 (&rb)[4], u32x4 (&ra)[4]) __attribute__((always_inline)) -> int32_t {
+    auto issue_loads = [&](auto pos_tag, u32x4 (&rb)[4], u32x4 (&ra)[4]) __attribute__((always_inline)) -> int32_t {
+        constexpr int s = decltype(pos_tag)::value;      // position of the step's record in the window
         const int32_t flags = field(s, F_FLAGS);
         const int32_t tail = (flags & STEP_TAIL) != 0;
         if (tail != tail_prev) {
@@ -77,11 +81,24 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
         const float* bptr = tail ? p.B_tail + gk0 : p.B + gk0 + n0off;
         const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bptr), 0, 0x7ffffff0, 0x00020000);
         const uint32_t qs = tail ? qstepBt : qstepB;
+#ifndef SPARTA_DIRECT_PROBE
+#define SPARTA_DIRECT_PROBE 0     /* developer probes, TIMING ONLY (results wrong): 1 no B loads, 2 no A loads, 4 no epilogue, 8 no LDS round trip */
+#endif
+#ifndef SPARTA_DIRECT_BLOAD_AUX
+#define SPARTA_DIRECT_BLOAD_AUX 0
+#endif
+        if (!(SPARTA_DIRECT_PROBE & 1)) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, qs * q, 0);
+            for (int q = 0; q < 4; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, qs * q, SPARTA_DIRECT_BLOAD_AUX);
+        }
         const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_cur), 0, 0x7ffffff0, 0x00020000);
+        if (!(SPARTA_DIRECT_PROBE & 2)) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA, 1024 * j, 0);
+#ifndef SPARTA_DIRECT_ALOAD_AUX
+#define SPARTA_DIRECT_ALOAD_AUX 0
+#endif
+            for (int j = 0; j < 4; j++) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA, 1024 * j, SPARTA_DIRECT_ALOAD_AUX);
+        }
         a_cur += 1024;
         return flags;
     };
@@ -102,19 +119,31 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
     // one step: fragments of B from LDS stage PAR, the next step's panel into the other stage, 16 MFMAs, then the staging set that was
     // just written out and the A set of step i - 1 are refilled with step i + 3.  (Measured and dropped: reading the fragments of step
     // i + 1 during step i -- 16 more registers, 56.0 us against 54.1.)
-    auto step = [&](int i, int32_t flags, auto par_tag, u32x4 (&wa)[4], u32x4 (&nb)[4], u32x4 (&na)[4]) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par_tag)::value;
+    auto step = [&](auto u_tag, int32_t flags, u32x4 (&wa)[4], u32x4 (&nb)[4], u32x4 (&na)[4]) __attribute__((always_inline)) {
+        constexpr int i = decltype(u_tag)::value;        // step index mod 4 = position of its record in the window
+        constexpr int PAR = i & 1;
         f32x4 fb[4];
+        if (SPARTA_DIRECT_PROBE & 8) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const f32x4*>(ldsw + lrB + (PAR * WSTAGE + 4 * j) * 4);
-        write_b(std::integral_constant<int, 1 - PAR>{}, nb);             // W(i + 1)
+            for (int j = 0; j < 4; j++) fb[j] = __builtin_bit_cast(f32x4, nb[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const f32x4*>(ldsw + lrB + (PAR * WSTAGE + 4 * j) * 4);
+            write_b(std::integral_constant<int, 1 - PAR>{}, nb);         // W(i + 1)
+        }
+#ifdef SPARTA_DIRECT_SETPRIO
+        __builtin_amdgcn_s_setprio(SPARTA_DIRECT_SETPRIO);
+#endif
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int e = 0; e < 4; e++)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][e], __uint_as_float(wa[j][e]), acc, 0, 0, 0);
-        fq_new = issue_loads(i + 3, nb, na);                              // G(i + 3)
-        if (flags & STEP_LAST) {
+#ifdef SPARTA_DIRECT_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        fq_new = issue_loads(std::integral_constant<int, i + 3>{}, nb, na);                              // G(i + 3).  (Four steps ahead, four staging sets: 57.7 us against 55.0 -- latency is not what these steps wait for.)
+        if ((flags & STEP_LAST) && !(SPARTA_DIRECT_PROBE & 4)) {
             // epilogue (as in vbs_spmm_f32_stream_kernel): stored from copies, accumulators cleared here
             if (flags & STEP_SPLIT) {
                 const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_SLOT) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
@@ -141,8 +170,11 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
                         for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
                     }
 #pragma unroll
+#ifndef SPARTA_DIRECT_CSTORE_AUX
+#define SPARTA_DIRECT_CSTORE_AUX 2     /* nt: C is written once and never read back by this product -- it must not push panels of B out of the L2s (54.2 -> 52.2 us) */
+#endif
                     for (int q = 0; q < 16; q++)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, SPARTA_DIRECT_CSTORE_AUX);
                 }
             }
 #pragma unroll
@@ -150,55 +182,47 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
         }
     };
 
-    // step-record batches: requested at step 8k, placed at step 8k + 4 (see vbs_spmm_f32_stream_kernel; 32 loads are issued in between)
-    auto batch_upkeep = [&](int i) __attribute__((always_inline)) {
-        if ((i & 7) == 0 && i > 0) {
-            const int32_t* nb = srec + (int64_t)((i >> 3) + 1) * 64 + lane;
-            asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
-        }
-        if ((i & 7) == 4 && i > 4) {
-            asm volatile("s_waitcnt vmcnt(6)" : "+v"(vnext) : : "memory");
-            const bool odd = (((i >> 3) + 1) & 1) != 0;
-            vrec1 = odd ? vnext : vrec1;
-            vrec0 = odd ? vrec0 : vnext;
-        }
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    using c2 = std::integral_constant<int, 2>;
+    using c3 = std::integral_constant<int, 3>;
+    // the window of steps [i, i + 4): requested one round earlier (32 loads are issued in between: vmcnt(16) is a free wait).  Both sides
+    // are inline asm on purpose, see vbs_spmm_f32_stream_kernel.
+    auto window_swap = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(16)" : "+v"(vnext) : : "memory");
+        vwin = vnext;
     };
-
-    using p0 = std::integral_constant<int, 0>;
-    using p1 = std::integral_constant<int, 1>;
-    fq0 = issue_loads(0, bs0, as0);
-    fq1 = issue_loads(1, bs1, as1);
-    write_b(p0{}, bs0);                                  // W(0)
-    fq2 = issue_loads(2, bs0, as2);
+    auto window_request = [&](int i) __attribute__((always_inline)) {
+        const int32_t* nb = srec + (int64_t)(i + 4) * 8 + lane;
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
+    };
+    fq0 = issue_loads(c0{}, bs0, as0);
+    fq1 = issue_loads(c1{}, bs1, as1);
+    write_b(c0{}, bs0);                                  // W(0)
+    fq2 = issue_loads(c2{}, bs0, as2);
     // step i: LDS stage i & 1, A set i & 3; writes out staging set (i + 1) & 1 and refills it, and A set (i + 3) & 3, with step i + 3
     const int n4 = n & ~3;
     for (int i = 0; i < n4; i += 4) {
-        batch_upkeep(i);
-        step(i, fq0, p0{}, as0, bs1, as3);
+        if (i > 0) window_swap();
+        window_request(i);
+        step(c0{}, fq0, as0, bs1, as3);
         fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-        batch_upkeep(i + 1);
-        step(i + 1, fq0, p1{}, as1, bs0, as0);
+        step(c1{}, fq0, as1, bs0, as0);
         fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-        batch_upkeep(i + 2);
-        step(i + 2, fq0, p0{}, as2, bs1, as1);
+        step(c2{}, fq0, as2, bs1, as1);
         fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-        batch_upkeep(i + 3);
-        step(i + 3, fq0, p1{}, as3, bs0, as2);
+        step(c3{}, fq0, as3, bs0, as2);
         fq0 = fq1; fq1 = fq2; fq2 = fq_new;
     }
-    if (n - n4 >= 1) {
-        batch_upkeep(n4);
-        step(n4, fq0, p0{}, as0, bs1, as3);
+    if (n > n4) {
+        if (n4 > 0) window_swap();
+        step(c0{}, fq0, as0, bs1, as3);
         fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-    }
-    if (n - n4 >= 2) {
-        batch_upkeep(n4 + 1);
-        step(n4 + 1, fq0, p1{}, as1, bs0, as0);
-        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-    }
-    if (n - n4 == 3) {
-        batch_upkeep(n4 + 2);
-        step(n4 + 2, fq0, p0{}, as2, bs1, as1);
+        if (n - n4 >= 2) {
+            step(c1{}, fq0, as1, bs0, as0);
+            fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+        }
+        if (n - n4 == 3) step(c2{}, fq0, as2, bs1, as1);
     }
     clock_probe(p.clk, 2);
 #undef field

@@ -400,6 +400,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         if (!plan.a_frag.empty()) {
             CREATE_TRY(hipMalloc((void**)&v->d_a_frag, plan.a_frag.size() * sizeof(float)));
             CREATE_TRY(hipMemcpy(v->d_a_frag, plan.a_frag.data(), plan.a_frag.size() * sizeof(float), hipMemcpyHostToDevice));
+            v->a_bytes += (int64_t)(plan.a_frag.size() * sizeof(float));    // the device image holds the one-tile part of A twice (two layouts)
         }
         if (!plan.steps_k64.empty()) {
             std::vector<StepRec>& k = plan.steps_k64;

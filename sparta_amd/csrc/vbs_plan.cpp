@@ -323,8 +323,12 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
         if (const char* e = std::getenv("SPARTA_COST_MODEL")) sscanf(e, "%d,%d,%d", &c2, &c1, &ct);
         int64_t split_penalty = 120;                     // cost units (~0.11 us each) the fix-up launch adds to a split plan
         if (const char* e = std::getenv("SPARTA_SPLIT_PENALTY")) split_penalty = atoll(e);
-        bool interleave = false;                         // SPARTA_STREAM_INTERLEAVE=1: deal whole tiles round-robin inside an XCD (measured: +-2 %, L2 locality is not the limit)
-        if (const char* e = std::getenv("SPARTA_STREAM_INTERLEAVE")) interleave = atoi(e) != 0;
+        bool interleave = false;
+        // whole-tile plans: 0 = contiguous ranges of tiles, 1 = an XCD's tiles dealt in matrix order to its least loaded worker (measured:
+        // +-2 %), 2 (default) = longest tile first: flagship 52.3 -> 49.7 us (3-4 tiles of 4..14 steps per worker: makespan 1.10 -> 1.05 x mean)
+        int interleave_mode = 2;
+        if (const char* e = std::getenv("SPARTA_STREAM_INTERLEAVE")) interleave_mode = atoi(e);
+        interleave = interleave_mode != 0;
         double slot_bias = 0.0;                          // SPARTA_SLOT_BIAS: extra share of the workgroup dispatched first onto a CU
         if (const char* e = std::getenv("SPARTA_SLOT_BIAS")) slot_bias = std::max(-0.9, std::min(0.9, atof(e)));
         int align_mode = -1;                             // SPARTA_STREAM_ALIGN=0 always split, 1 never split, unset: cheaper one
@@ -493,14 +497,24 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                         for (int x = 0; x < 8; x++) {
                             const int64_t upto = total_cost * (x + 1) / 8;
                             std::vector<int64_t> load((size_t)per_x, 0);
+                            std::vector<size_t> share;                       // the tiles of this XCD's eighth
                             while (t < spans.size() && (x == 7 || seen + tile_cost(t) / 2 <= upto)) {
-                                size_t best = 0;
-                                for (size_t j = 1; j < load.size(); j++) if (load[j] < load[best]) best = j;
-                                mine[(size_t)x * per_x + best].push_back(t);
-                                load[best] += tile_cost(t);
+                                share.push_back(t);
                                 seen += tile_cost(t);
                                 t++;
                             }
+                            // interleave == 2: longest tile first (LPT) -- the makespan of 3-4 tiles of 4..14 steps per worker drops from
+                            // 1.10 x the mean (contiguous whole tiles) to 1.05 x; each worker then walks its tiles in matrix order
+                            if (interleave_mode == 2)
+                                std::stable_sort(share.begin(), share.end(), [&](size_t a, size_t b) { return tile_cost(a) > tile_cost(b); });
+                            for (size_t tt : share) {
+                                size_t best = 0;
+                                for (size_t j = 1; j < load.size(); j++) if (load[j] < load[best]) best = j;
+                                mine[(size_t)x * per_x + best].push_back(tt);
+                                load[best] += tile_cost(tt);
+                            }
+                            if (interleave_mode == 2)
+                                for (int j = 0; j < per_x; j++) std::sort(mine[(size_t)x * per_x + j].begin(), mine[(size_t)x * per_x + j].end());
                         }
                         std::vector<StepRec> ns;
                         std::vector<TileSpan> nspans;
@@ -559,10 +573,11 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                 }
             }
             // ---- A in MFMA fragment order for vbs_spmm_f32_direct_kernel (k_f32_direct.hip): one 4 KB slice per step of the one-tile plan,
-            // [j = 0..3][g = 0..1][row = 0..31][e = 0..3] = A[row][k = 16 g + 4 j + e], rows past the tile zero.  Opt-in (SPARTA_F32_PLAN=direct).
+            // [j = 0..3][g = 0..1][row = 0..31][e = 0..3] = A[row][k = 16 g + 4 j + e], rows past the tile zero.  The legacy image of A stays: row-major / gathered B calls run the LDS-staged kernel on the same plan.
             {
                 const char* de = std::getenv("SPARTA_F32_PLAN");
-                if (de && std::strcmp(de, "direct") == 0 && ty == 0 && !h16 && !P.pair_plan) {
+                const bool off = de && std::strcmp(de, "legacy") == 0;         // SPARTA_F32_PLAN=legacy: the LDS-staged kernel for every call
+                if (!off && ty == 0 && !h16 && !P.pair_plan && S <= ((int64_t)2 << 20)) {   // <= 8 GiB of slices (a second copy of the one-tile part of A)
                     std::vector<float>& af = P.a_frag;
                     af.assign(((size_t)S + 4) * 1024, 0.0f);                    // + 4: the pipeline requests three steps past a range end
                     for (int64_t q = 0; q < S; q++) {
