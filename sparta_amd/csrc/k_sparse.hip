@@ -114,10 +114,10 @@ __global__ __launch_bounds__(kThreads) void sparse_rows_kernel(SparseParams p) {
 
 // kCmRows partial rows of one chunk of columns meet in LDS (element (row j, column l * VEC + e) at ((e * kCmRows + j) * 65 + l)) and leave
 // as pieces of kCmRows consecutive rows of one column of the column-major C: thread (j, cg) stores row j of columns cg, cg + CG, ...
-template <int VEC, int kCmRows>
+template <int VEC, int kCmRows, int NT = kThreads>
 __device__ __forceinline__ void sp_cm_flush(const SparseParams& p, const float* tile, bool valid, int32_t crow) {
     constexpr int W = 64 * VEC;
-    constexpr int CG = kThreads / kCmRows;                       // columns written at a time (one per group of kCmRows threads)
+    constexpr int CG = NT / kCmRows;                             // columns written at a time (one per group of kCmRows threads)
     constexpr int NQ = W / CG < 8 ? W / CG : 8;                  // stores of a thread in flight
     static_assert(W % (CG * NQ) == 0, "chunk width must be a whole number of store rounds");
     const int j = threadIdx.x & (kCmRows - 1), cg = threadIdx.x / kCmRows;
@@ -154,17 +154,19 @@ __device__ __forceinline__ void sp_cm_flush(const SparseParams& p, const float* 
 // of C), each wave walks kCmRows / 4 of them one after the other, the partial rows meet in LDS and leave as pieces of kCmRows consecutive
 // rows of one column (kCmRows * 4 contiguous bytes where the C rows are consecutive).  Replaces "row-major scratch + scatter launch": the product
 // is written once instead of written, read back and written again.
-template <int VEC, int BK, int kCmRows>
-__global__ __launch_bounds__(kThreads) void sparse_rows_cm_kernel(SparseParams p) {
+template <int VEC, int BK, int kCmRows, int NW>
+__global__ __launch_bounds__(64 * NW) void sparse_rows_cm_kernel(SparseParams p) {
     typedef typename SpVec<VEC>::T V;
+    constexpr int RPW = kCmRows / NW;                            // rows a wave walks one after the other
+    static_assert(RPW >= 1 && RPW * NW == kCmRows, "rows per workgroup must be a multiple of the waves");
     __shared__ float tile[VEC * kCmRows * 65];                   // 64 * VEC columns of kCmRows rows, layout in sp_cm_flush
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot0 = blockIdx.x * kCmRows;
     const int n0 = (blockIdx.y * 64 + lane) * VEC;
-    // the wave's rows: lane i holds the nonzero range of row j = wave + 4 i (one chain of dependent loads for all of them, not one per row)
+    // the wave's rows: lane i holds the nonzero range of row j = wave + NW i (one chain of dependent loads for all of them, not one per row)
     int mlo = 0, mhi = 0, mcnt = 0;
-    if (lane < kCmRows / 4 && slot0 + wave + 4 * lane < p.n_list) {
-        const int ord = p.list[slot0 + wave + 4 * lane];
+    if (lane < RPW && slot0 + wave + NW * lane < p.n_list) {
+        const int ord = p.list[slot0 + wave + NW * lane];
         const int64_t a = p.rowptr[ord];
         mlo = (int)(uint32_t)a; mhi = (int)(a >> 32); mcnt = (int)(p.rowptr[ord + 1] - a);
     }
@@ -178,12 +180,12 @@ __global__ __launch_bounds__(kThreads) void sparse_rows_cm_kernel(SparseParams p
         sp_batch_load(p, a, a + __builtin_amdgcn_readlane(mcnt, 0), lane, cl, vl);
     }
 #pragma unroll 1
-    for (int i = 0; i < kCmRows / 4; i++) {
-        const int j = wave + 4 * i;
+    for (int i = 0; i < RPW; i++) {
+        const int j = wave + NW * i;
         const int64_t p0 = row_p0(i), p1 = p0 + __builtin_amdgcn_readlane(mcnt, i);
         int cn = 0;
         float vn = 0.0f;
-        if (i + 1 < kCmRows / 4) {                               // first batch of the next row, requested before this row's rows of B
+        if (i + 1 < RPW) {                                       // first batch of the next row, requested before this row's rows of B
             const int64_t a = row_p0(i + 1);
             sp_batch_load(p, a, a + __builtin_amdgcn_readlane(mcnt, i + 1), lane, cn, vn);
         }
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void sparse_rows_cm_kernel(SparseParams p
     __syncthreads();
     const int fj = threadIdx.x & (kCmRows - 1);
     const bool valid = slot0 + fj < p.n_list;
-    sp_cm_flush<VEC, kCmRows>(p, tile, valid, valid ? p.crow[p.list[slot0 + fj]] : 0);
+    sp_cm_flush<VEC, kCmRows, 64 * NW>(p, tile, valid, valid ? p.crow[p.list[slot0 + fj]] : 0);
 }
 
 // long rows (hubs): cut into segments of <= kSpSeg nonzeros, one wave per segment writes a partial row; a second launch adds
@@ -330,11 +332,10 @@ void launch_sparse_t(SparseParams q, unsigned gy, hipStream_t st, const int32_t*
                      const SpLongRec* longs, int64_t n_long, float* part) {
     if (n_short > 0) {
         q.list = list; q.n_list = (int32_t)n_short;
-        // rows of C per workgroup: 16 (64-byte pieces of a column) measured >= 32 (128-byte pieces, half the workgroups) from R-MAT 2^14 to 2^20;
-        // SPARTA_SP_CMROWS=32 is the developer's switch
-        static const int cm_rows = [] { const char* e = std::getenv("SPARTA_SP_CMROWS"); return e ? atoi(e) : 16; }();
-        if (q.out_is_c == 2 && cm_rows == 16) hipLaunchKernelGGL((sparse_rows_cm_kernel<VEC, BK, 16>), dim3((unsigned)((n_short + 15) / 16), gy), dim3(kThreads), 0, st, q);
-        else if (q.out_is_c == 2) hipLaunchKernelGGL((sparse_rows_cm_kernel<VEC, BK, 32>), dim3((unsigned)((n_short + 31) / 32), gy), dim3(kThreads), 0, st, q);
+        // column-major C: 16 rows per workgroup (64-byte pieces of a column; 32 rows = 128-byte pieces but half the workgroups: measured 0-25 %
+        // slower from R-MAT 2^14 to 2^20), 4 waves walking 4 rows each (8 / 16 waves with 2 / 1 rows each: 15-45 % slower on R-MAT 2^20; 1 wave
+        // with 16 rows: 10-30 % slower)
+        if (q.out_is_c == 2) hipLaunchKernelGGL((sparse_rows_cm_kernel<VEC, BK, 16, 4>), dim3((unsigned)((n_short + 15) / 16), gy), dim3(256), 0, st, q);
         else hipLaunchKernelGGL((sparse_rows_kernel<VEC, BK>), dim3((unsigned)((n_short + 3) / 4), gy), dim3(kThreads), 0, st, q);
     }
     if (n_long > 0) {
