@@ -595,8 +595,7 @@ def main():
         bytes16 = float(info["a_bytes"]) + 2.0 * ldb * N + 4.0 * rows_c * N
         gbs = bytes16 / (kernel_ms_total * 1e-3) / 1e9 if kernel_ms_total > 0 else 0.0
         roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                         "kernel": ("vbs_spmm_h16_direct_kernel" if (w % 64 != 0 and info["tiles64"] == 0 and os.environ.get("SPARTA_H16_PATH", "a")[0] != "l")
-                                    or os.environ.get("SPARTA_H16_PATH", "a")[0] == "d" else "vbs_spmm_h16_stream_kernel"),
+                         "kernel": ("vbs_spmm_h16_stream_kernel" if os.environ.get("SPARTA_H16_PATH", "a")[0] == "l" else "vbs_spmm_h16_direct_kernel"),
                          "algorithmic_bytes": round(bytes16), "algorithmic_gbs": round(gbs, 1),
                          "executed_tflops": round(dom_tflops, 3)})
         roofline.pop("mixed_roofline_frac", None)

@@ -170,11 +170,8 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
                         for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
                     }
 #pragma unroll
-#ifndef SPARTA_DIRECT_CSTORE_AUX
-#define SPARTA_DIRECT_CSTORE_AUX 2     /* nt: C is written once and never read back by this product -- it must not push panels of B out of the L2s (54.2 -> 52.2 us) */
-#endif
                     for (int q = 0; q < 16; q++)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, SPARTA_DIRECT_CSTORE_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, SPARTA_CSTORE_AUX);
                 }
             }
 #pragma unroll

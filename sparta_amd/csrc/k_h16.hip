@@ -10,8 +10,9 @@ namespace {
 // =====================================================================================================
 // 16-bit (fp16 / bf16) storage, fp32 accumulation: vbs_spmm_h16_stream_kernel<KP, MI2, BF16>
 // Same persistent design, step records, plans and epilogue as the fp32 stream kernel; what changes is the operand path.
-// * A is re-laid-out ONCE at sparta_vbs_create: every step's slice is a dense row-major TM x KP chunk (k contiguous, rows
-//   past the tile zero), the chunks of a tile back to back.  The 16-bit MFMA wants 8 consecutive k of one row per lane; the
+// * A is re-laid-out ONCE at sparta_vbs_create: every step's slice is a dense TM x KP chunk stored [k chunk of 8][row][8] (rows
+//   past the tile zero) -- the order in which the direct kernel's lanes want it: lane (row, g) takes k chunk 2 q + g, so a wave
+//   load is contiguous -- the chunks of a tile back to back.  The 16-bit MFMA wants 8 consecutive k of one row per lane; the
 //   reference's column-major blocks have k strided, and transposing 16-bit data on the way into LDS costs 8 ds_write_b16 per
 //   16-byte load.  The host-side VBS (the boundary) keeps the reference's layout; only the device copy differs.
 // * B must be column-major (k contiguous per column) with an even leading dimension: Bs[j][k], As[i][k], rows padded by
@@ -67,13 +68,13 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
     enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6, F_SHARD = 7 };
 
     const int bj0 = tid / CPC, bc = tid % CPC;           // B: column bj0 + CPP q, chunk bc (k = 8 bc .. 8 bc + 7)
-    const int ac = tid % (TM * CPC);                     // A: chunk ac (+ 256 q) of the contiguous TM x KP slice (clamped: duplicates are harmless)
+    const int ac = tid % (TM * CPC);                     // A: 16-byte chunk ac (+ 256 q) of the contiguous slice (clamped: duplicates are harmless)
     const int64_t ld_t = (int64_t)p.w;                   // leading dimension of B_tail
     const uint32_t voffB = (uint32_t)((bc * 8 + bj0 * p.ldb) * 2), voffBt = (uint32_t)((bc * 8 + (n0 + bj0) * ld_t) * 2);
     const uint32_t qstepB = (uint32_t)(CPP * p.ldb * 2), qstepBt = (uint32_t)(CPP * ld_t * 2);
     const int64_t n0off = (int64_t)n0 * p.ldb;
     const uint32_t lwB = (uint32_t)((bj0 * LDK + bc * 8) * 2);
-    const uint32_t lwA = (uint32_t)((BSZ + (ac / CPC) * LDK + (ac % CPC) * 8) * 2);
+    const uint32_t lwA = (uint32_t)((BSZ + (ac % TM) * LDK + (ac / TM) * 8) * 2);   // slice in memory: [k chunk][row][8] (chunk ac = row ac % TM, k chunk ac / TM)
     const uint32_t lrB = (uint32_t)(((32 * wave + lm) * LDK + 8 * g) * 2);
     const uint32_t lrA = (uint32_t)((BSZ + lm * LDK + 8 * g) * 2);
     const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 32 * wave + 4 * g) * 4) : (uint32_t)((lm + (32 * wave + 4 * g) * p.ldc) * 4);
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
 #pragma unroll
         for (int q = 0; q < NBL; q++) *reinterpret_cast<u32x4*>(ldsb + lwB + (ST * STAGE + q * CPP * LDK) * 2) = rb[q];
 #pragma unroll
-        for (int q = 0; q < NAL; q++) *reinterpret_cast<u32x4*>(ldsb + lwA + (ST * STAGE + q * (kThreads / CPC) * LDK) * 2) = ra[q];
+        for (int q = 0; q < NAL; q++) *reinterpret_cast<u32x4*>(ldsb + lwA + (ST * STAGE + q * (kThreads / TM) * 8) * 2) = ra[q];
     };
 
     f32x16 acc0, acc1;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
                         }
 #pragma unroll
                         for (int q = 0; q < 16; q++)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, SPARTA_CSTORE_AUX);
                     }
                 }
             }
@@ -307,22 +308,31 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
 #undef field
 
 // =====================================================================================================
-// 16-bit storage, operands straight from global memory into the MFMA registers: vbs_spmm_h16_direct_kernel<KP, MI2, BF16, GATHERED>
+// 16-bit storage without a workgroup-wide stage: vbs_spmm_h16_direct_kernel<KP, MI2, BF16, GATHERED>
 // A 16-bit step has 64-256 cycles of MFMA per wave; in the LDS-staged kernel above what a step costs is its bookkeeping: the
-// register -> LDS -> register round trip, one workgroup barrier and the four waves waiting for each other (measured with the
-// in-kernel timeline: ~1300 cycles per step with every byte cache-hot).  The packed A slices (row-major, k contiguous) and a
-// column-major B (k contiguous) already ARE the per-lane operand layout of v_mfma_f32_32x32x16: lane (lm, g) needs 8 consecutive
-// k of row / column lm, one 16-byte load.  So here nothing is staged: every wave loads its own fragments (its 32 columns of B,
-// and the A slice, which the four waves of a workgroup share through the L1), keeps LOOK steps of them in flight in registers and
-// never synchronises with the other waves -- no LDS, no barrier.  Same plans, step records, accumulator layout, epilogue and
-// fix-up as the other stream kernels (a wave's accumulator image is identical, so the split-tile workspace is too).
+// register -> LDS -> register round trip of BOTH operands, one workgroup barrier and the four waves waiting for each other
+// (measured with the in-kernel timeline: ~1300 cycles per step with every byte cache-hot).  Here the four waves never meet
+// (same scheme as vbs_spmm_f32_direct_kernel, k_f32_direct.hip):
+//   * the packed A slices (row-major, k contiguous) already ARE the per-lane operand layout of v_mfma_f32_32x32x16: lane (lm, g)
+//     needs 8 consecutive k of row lm, one 16-byte load; each wave loads the slice itself (the four waves share it through L1);
+//   * B (column-major, k contiguous) is the same layout too, but loading it in MFMA shape -- lane (lm, g) its own column --
+//     touches 32 different cache lines per wave instruction, and the texture addresser then sets the pace (round 1's form of
+//     this kernel: 36.0 us on the flagship).  So a wave loads ITS 32 columns 4 (KP = 32) or 8 (KP = 64) lanes per column,
+//     writes them to a wave-PRIVATE LDS image Bs[column][k] (+8 padding) and reads its fragments back with ds_read_b128:
+//     program order and lgkmcnt are all the synchronisation there is.
+// Loads run three steps ahead (A: four register sets, B: two staging sets + two LDS stages); step records: one window VGPR,
+// constant-lane v_readlane.  Same plans, accumulator layout, epilogue and fix-up as the other stream kernels.
 // =====================================================================================================
 template <int KP, bool MI2, bool BF16, bool GATHERED>
 __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const StreamParams p) {
     constexpr int TN = kTN, TM = MI2 ? 64 : 32;
-    constexpr int NK = KP / 16;                          // MFMAs (k groups of 16) per step and 32-row tile
+    constexpr int NK = KP / 16;                          // MFMAs (k groups of 16) per step and 32-row tile = 16-byte loads per lane and operand
     constexpr int NA = MI2 ? 2 : 1;
-    constexpr int LOOK = 4;                              // register sets = steps in flight
+    constexpr int LPC = KP / 8;                          // lanes per column of a coalesced B load (16 bytes = 8 k each): 4 or 8
+    constexpr int CPI = 64 / LPC;                        // columns per wave instruction: 16 or 8 (NK instructions cover the wave's 32)
+    constexpr int RB = (KP + 8) * 2;                     // bytes per column of the LDS image (8 elements of padding: conflict-free b128)
+    constexpr int WSTAGE = 32 * RB;                      // bytes per wave and stage
+    __shared__ __attribute__((aligned(16))) char lds[4 * 2 * WSTAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -337,27 +347,35 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
     const uint16_t* B16 = reinterpret_cast<const uint16_t*>(p.B);
     const uint16_t* Bt16 = reinterpret_cast<const uint16_t*>(p.B_tail);
 
+    // step records: one window of 8 (lane = 8 * record + field) per round of four steps, see vbs_spmm_f32_direct_kernel
     const int32_t* srec = reinterpret_cast<const int32_t*>(p.steps + s_begin);
-    int vrec0 = srec[lane];
-    int vrec1 = srec[64 + lane];
+    int vwin = srec[lane];
     int vnext = 0;
-#define field(s, f) sk_field(vrec0, vrec1, (s), (f))
+#define field(pos, f) __builtin_amdgcn_readlane(vwin, 8 * (pos) + (f))
     enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6, F_SHARD = 7 };
 
+    const int bc = lane / LPC, bk = (lane % LPC) * 8;    // B load q: column CPI q + bc of the wave's 32, k = bk .. bk + 7
     const int64_t ld_t = (int64_t)p.w;                   // leading dimension of B_tail
-    const uint32_t voffB = (uint32_t)(((32 * wave + lm) * p.ldb + 8 * g) * 2);
-    const uint32_t voffBt = (uint32_t)(((n0 + 32 * wave + lm) * ld_t + 8 * g) * 2);
-    const uint32_t voffA = (uint32_t)((lm * KP + 8 * g) * 2);
+    const uint32_t voffB = (uint32_t)(((32 * wave + bc) * p.ldb + bk) * 2);
+    const uint32_t voffBt = (uint32_t)(((n0 + 32 * wave + bc) * ld_t + bk) * 2);
+    const uint32_t qstepB = (uint32_t)(CPI * p.ldb * 2), qstepBt = (uint32_t)(CPI * ld_t * 2);      // bytes from one column group to the next
+    const uint32_t voffA = (uint32_t)((g * TM + lm) * 16);     // slice in memory: [k chunk = 2 q + g][row][8]: a wave load is one (TM = 32) or two contiguous pieces
     const int64_t n0off = (int64_t)n0 * p.ldb;
     const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 32 * wave + 4 * g) * 4) : (uint32_t)((lm + (32 * wave + 4 * g) * p.ldc) * 4);
+    char* const ldsw = lds + wave * (2 * WSTAGE);        // this wave's two stages
+    const uint32_t lwB = (uint32_t)(bc * RB + bk * 2);   // write: column bc + CPI q
+    const uint32_t lrB = (uint32_t)(lm * RB + 16 * g);   // read: column lm, k = 16 q + 8 g .. + 7
 
-    struct Set { u32x4 b[NK]; u32x4 a[NA][NK]; };
-    Set r0, r1, r2, r3;
+    struct ASet { u32x4 a[NA][NK]; };
+    struct BSet { u32x4 b[NK]; };
+    ASet as0, as1, as2, as3;                             // A fragments of the steps i mod 4
+    BSet bs0, bs1;                                       // B staging (steps of even / odd index)
 
     int64_t g_aoff = 0;
     uint32_t vo_cur = voffB;
     int32_t tail_prev = 0;
-    auto issue_loads = [&](int s, Set& r) __attribute__((always_inline)) -> int32_t {
+    auto issue_loads = [&](auto pos_tag, BSet& rb, ASet& ra) __attribute__((always_inline)) -> int32_t {
+        constexpr int s = decltype(pos_tag)::value;      // position of the step's record in the window
         const int32_t flags = field(s, F_FLAGS);
         if (flags & STEP_FIRST) g_aoff = (int64_t)(uint32_t)field(s, F_AOFF_LO) | ((int64_t)field(s, F_AOFF_HI) << 32);
         else g_aoff += (int64_t)TM * KP;                 // the slices of a tile are back to back
@@ -370,14 +388,27 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
         const int64_t gk0 = field(s, F_BROW);
         const uint16_t* bptr = tail ? Bt16 + gk0 : B16 + (GATHERED ? (int64_t)field(s, F_SHARD) * p.shard_stride : (int64_t)0) + gk0 + n0off;
         const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(bptr), 0, 0x7ffffff0, 0x00020000);
+        const uint32_t qs = tail ? qstepBt : qstepB;
+#ifndef SPARTA_H16_PROBE
+#define SPARTA_H16_PROBE 0        /* developer probes, TIMING ONLY (results wrong): 1 no B loads, 2 no A loads, 4 no epilogue, 8 no LDS round trip */
+#endif
+        if (!(SPARTA_H16_PROBE & 1)) {
 #pragma unroll
-        for (int q = 0; q < NK; q++) r.b[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, (uint32_t)(q * 32), 0);
+            for (int q = 0; q < NK; q++) rb.b[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, qs * q, 0);
+        }
         const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A16 + g_aoff), 0, 0x7ffffff0, 0x00020000);
+        if (!(SPARTA_H16_PROBE & 2) && !((SPARTA_H16_PROBE & 16) && wave != 0) && !((SPARTA_H16_PROBE & 32) && (wave & 1))) {   // 16: only wave 0 loads A; 32: waves 0 and 2
 #pragma unroll
-        for (int mi = 0; mi < NA; mi++)
+            for (int mi = 0; mi < NA; mi++)
 #pragma unroll
-            for (int q = 0; q < NK; q++) r.a[mi][q] = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA, (uint32_t)(mi * 32 * KP * 2 + q * 32), 0);
+                for (int q = 0; q < NK; q++) ra.a[mi][q] = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA, (uint32_t)((2 * q * TM + 32 * mi) * 16), 0);
+        }
         return flags;
+    };
+    auto write_b = [&](auto stage_tag, const BSet& rb) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_tag)::value;
+#pragma unroll
+        for (int q = 0; q < NK; q++) *reinterpret_cast<u32x4*>(ldsw + lwB + ST * WSTAGE + q * CPI * RB) = rb.b[q];
     };
 
     f32x16 acc0, acc1;
@@ -388,15 +419,28 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
         else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf), __builtin_bit_cast(f16x8, af), acc, 0, 0, 0);
     };
 
-    int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq3 = 0, fq_new = 0;
-    // one step: multiply from register set r (step i), run the tile epilogue if it ends here, refill r with step i + LOOK
-    auto iteration_t = [&](int i, int32_t flags, Set& r) __attribute__((always_inline)) {
+    int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq_new = 0;
+    // one step (index i mod 4 = u): fragments of B from LDS stage u & 1, the next step's panel into the other stage, the MFMAs, the
+    // tile epilogue if it ends here, then staging set nb and A set na are refilled with step i + 3
+    auto step = [&](auto u_tag, int32_t flags, ASet& wa, BSet& nb, ASet& na) __attribute__((always_inline)) {
+        constexpr int i = decltype(u_tag)::value;
+        constexpr int PAR = i & 1;
+        u32x4 fb[NK];
+        if (SPARTA_H16_PROBE & 8) {
+#pragma unroll
+            for (int q = 0; q < NK; q++) fb[q] = nb.b[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < NK; q++) fb[q] = *reinterpret_cast<const u32x4*>(ldsw + lrB + PAR * WSTAGE + q * 32);
+            write_b(std::integral_constant<int, 1 - PAR>{}, nb);         // W(i + 1)
+        }
 #pragma unroll
         for (int q = 0; q < NK; q++) {
-            mfma(r.b[q], r.a[0][q], acc0);
-            if constexpr (MI2) mfma(r.b[q], r.a[1][q], acc1);
+            mfma(fb[q], wa.a[0][q], acc0);
+            if constexpr (MI2) mfma(fb[q], wa.a[1][q], acc1);
         }
-        if (flags & STEP_LAST) {
+        fq_new = issue_loads(std::integral_constant<int, i + 3>{}, nb, na);   // G(i + 3)
+        if ((flags & STEP_LAST) && !(SPARTA_H16_PROBE & 4)) {
             if (flags & STEP_SPLIT) {
                 const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_SLOT) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
 #pragma unroll
@@ -426,58 +470,54 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
                         }
 #pragma unroll
                         for (int q = 0; q < 16; q++)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, SPARTA_CSTORE_AUX);
                     }
                 }
             }
 #pragma unroll
             for (int q = 0; q < 16; q++) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
         }
-        fq_new = issue_loads(i + LOOK, r);
     };
 
-    fq0 = issue_loads(0, r0);
-    fq1 = issue_loads(1, r1);
-    fq2 = issue_loads(2, r2);
-    fq3 = issue_loads(3, r3);
-    // Record batches (8 steps each; vrec0 / vrec1 hold batches k, k + 1): step 8k + 4 is the first to look into batch k + 1 (its
-    // refill is step 8k + 8).  Batch k + 1 is requested at step 8k and touched at step 8k + 4; the register it replaces (batch
-    // k - 1) is dead from step 8k on.  The four steps in between issue 4 x (>= 4) loads and memory returns in order: vmcnt(12)
-    // at the touch is a wait the pipeline pays anyway.
-    auto batch_upkeep = [&](int i) __attribute__((always_inline)) {
-        if ((i & 7) == 0 && i > 0) {
-            const int32_t* nb = srec + (int64_t)((i >> 3) + 1) * 64 + lane;
-            asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
-        }
-        if ((i & 7) == 4 && i > 4) {
-            asm volatile("s_waitcnt vmcnt(12)" : "+v"(vnext) : : "memory");
-            const bool odd = (((i >> 3) + 1) & 1) != 0;
-            vrec1 = odd ? vnext : vrec1;
-            vrec0 = odd ? vrec0 : vnext;
-        }
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    using c2 = std::integral_constant<int, 2>;
+    using c3 = std::integral_constant<int, 3>;
+    // the window of steps [i, i + 4): requested one round earlier (>= 4 x 2 NK loads are issued in between and memory returns in order)
+    auto window_swap = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(vnext) : : "memory");
+        vwin = vnext;
     };
-    auto rotate = [&]() __attribute__((always_inline)) { fq0 = fq1; fq1 = fq2; fq2 = fq3; fq3 = fq_new; };
+    auto window_request = [&](int i) __attribute__((always_inline)) {
+        const int32_t* nb = srec + (int64_t)(i + 4) * 8 + lane;
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
+    };
+    fq0 = issue_loads(c0{}, bs0, as0);
+    fq1 = issue_loads(c1{}, bs1, as1);
+    write_b(c0{}, bs0);                                  // W(0)
+    fq2 = issue_loads(c2{}, bs0, as2);
     const int n4 = n & ~3;
     for (int i = 0; i < n4; i += 4) {
-        batch_upkeep(i);
-        iteration_t(i, fq0, r0);
-        rotate();
-        iteration_t(i + 1, fq0, r1);
-        rotate();
-        iteration_t(i + 2, fq0, r2);
-        rotate();
-        iteration_t(i + 3, fq0, r3);
-        rotate();
+        if (i > 0) window_swap();
+        window_request(i);
+        step(c0{}, fq0, as0, bs1, as3);
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+        step(c1{}, fq0, as1, bs0, as0);
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+        step(c2{}, fq0, as2, bs1, as1);
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+        step(c3{}, fq0, as3, bs0, as2);
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
     }
-    if (n & 3) {                                         // the last n & 3 steps, peeled
-        batch_upkeep(n4);
-        iteration_t(n4, fq0, r0);
-        rotate();
-        if ((n & 3) > 1) {
-            iteration_t(n4 + 1, fq0, r1);
-            rotate();
-            if ((n & 3) > 2) iteration_t(n4 + 2, fq0, r2);
+    if (n > n4) {
+        if (n4 > 0) window_swap();
+        step(c0{}, fq0, as0, bs1, as3);
+        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+        if (n - n4 >= 2) {
+            step(c1{}, fq0, as1, bs0, as0);
+            fq0 = fq1; fq1 = fq2; fq2 = fq_new;
         }
+        if (n - n4 == 3) step(c2{}, fq0, as2, bs1, as1);
     }
     clock_probe(p.clk, 2);
 #undef field
@@ -527,15 +567,13 @@ void launch_h16_d(bool bf16, bool gathered, dim3 grid, hipStream_t st, const Str
 // SPARTA_H16_DEPTH=4 selects the four-register-set pipeline (loads 5 steps ahead); default: two sets, 3 steps ahead -- measured equal
 // within 1 % on every shape (scripts/h16_depth_ab.py): the 16-bit steps are not bound by the bytes in flight
 bool h16_deep() { const char* e = std::getenv("SPARTA_H16_DEPTH"); return e && atoi(e) == 4; }   // read per launch: scripts flip it between timings
-// Which 16-bit kernel: SPARTA_H16_PATH=lds | direct forces one; default (auto): operands straight into registers
-// (vbs_spmm_h16_direct_kernel) for 32-deep steps of one 32-row MFMA tile -- 36.4 vs 38.0 us on the flagship, bit-identical --
-// and the LDS-staged kernel for everything else (64-row tiles / 64-deep steps: the four waves would each fetch the whole A
-// slice and a wave-load would touch 64 cache lines: 57 vs 29 us).  Read per launch: scripts flip it between timings.
+// Which 16-bit kernel: the no-barrier kernel (vbs_spmm_h16_direct_kernel) for every shape -- flagship 23.0 us against 36.7 for the LDS-staged
+// kernel, 64 x 64 blocks 23.7 against 27.8, (w 64, 32 rows) 22.9 against 30.9, N = 256 46 against 53-71; SPARTA_H16_PATH=lds selects the
+// LDS-staged kernel (A/B runs, tests).  Read per launch: scripts flip it between timings.
 bool h16_direct(int kp, bool mi2) {
     const char* e = std::getenv("SPARTA_H16_PATH");
     if (e && e[0] == 'l') return false;
-    if (e && e[0] == 'd') return true;
-    return kp == 32 && !mi2;
+    return true;
 }
 template <int KP, bool MI2>
 void launch_h16_direct(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {

@@ -17,6 +17,13 @@ namespace sparta_dev {
 #define TL_STAMP(k) do { } while (0)
 #endif
 
+// Cache policy of the stream kernels' C stores: non-temporal (aux 2).  The product is written once and never read back by the launch that
+// writes it; with the default policy the 32 MB of C of the flagship push panels of B out of the L2s (fp32 flagship, same box, interleaved
+// runs: 54.2 -> 53.2 us).  -DSPARTA_CSTORE_AUX=0 restores the default policy for an A/B run.
+#ifndef SPARTA_CSTORE_AUX
+#define SPARTA_CSTORE_AUX 2
+#endif
+
 __device__ __forceinline__ void clock_probe(long long* clk, int slot) {
     if (clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         clk[slot] = (long long)__builtin_readcyclecounter();

@@ -308,6 +308,8 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
     // allocator reconciles the in-flight A/B registers and the accumulators with v_mov behind s_waitcnt vmcnt(0) / the
     // MFMA drain, which collapses the 3-step prefetch (measured: 72 non-MFMA VALU per step, 69 % of the matrix peak).
     // k depth of a step: 32 for fp32; the 16-bit kernels take 64 when the block width allows (their steps are short: fewer, fatter)
+    // (Measured and dropped: 16-bit plans of 32-wide blocks walked 64 deep -- two blocks in block columns (2 c, 2 c + 1) as one step, whole
+    // 128-byte lines of B, 36 % fewer steps on the flagship -- 23.4 us against 23.1: these kernels are not bound by steps or half lines.)
     const int64_t kp = !h16 ? SK_KP : (w % 64 == 0 ? 64 : 32);
     P.kp = kp;
     if (w % SK_KP == 0) {
@@ -387,15 +389,15 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                             for (int64_t ks = 0; ks < w; ks += kp) {
                                 StepRec r;
                                 r.a_off = mo2 + r0 + (b * w + ks) * h;
-                                if (h16) {                                  // pack this step's slice: [row][k], rows past the tile zero
+                                if (h16) {                                  // pack this step's slice, rows past the tile zero
                                     const int64_t tms = ty ? 64 : 32;
                                     r.a_off = (int64_t)a16.size();
                                     a16.resize(a16.size() + (size_t)(tms * kp), 0);
                                     uint16_t* dst = a16.data() + r.a_off;
                                     const float* blk = mab + mab_lo + mo2 + b * h * w;       // column-major h x w block
-                                    for (int64_t rr = 0; rr < mt; rr++)
+                                    for (int64_t rr = 0; rr < mt; rr++)                  // [k chunk of 8][row][8]
                                         for (int64_t kk = 0; kk < kp; kk++)
-                                            dst[rr * kp + kk] = to_h16(blk[(ks + kk) * h + r0 + rr], dtype == SPARTA_BF16);
+                                            dst[((kk >> 3) * tms + rr) * 8 + (kk & 7)] = to_h16(blk[(ks + kk) * h + r0 + rr], dtype == SPARTA_BF16);
                                 }
                                 r.b_row = (int32_t)(jb * w + ks);
                                 r.h = (int32_t)h;
@@ -456,8 +458,10 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             // step but pays the fix-up (a second launch that re-reads the partial images: ~10 us measured, `split_penalty`
             // cost units); whole tiles cost at most one tile of imbalance.  Many short tiles -> aligned; few long -> split.
             {
-                const int64_t step_cost = ty ? c2 : c1;
-                auto tile_cost = [&](size_t t) { return (spans[t].last - spans[t].first + 1) * step_cost + ct; };
+                // cost of a whole tile = its steps + its epilogue (cum[s] = cost before step s; a tile's epilogue is added behind its last step)
+                const std::vector<int64_t> cum0 = cum;
+                const std::vector<TileSpan> spans0 = spans;
+                auto tile_cost = [&](size_t t) { return cum0[(size_t)spans0[t].last + 1] - cum0[(size_t)spans0[t].first]; };
                 int64_t lo = 0, hi = total_cost * 2;
                 for (size_t t = 0; t < spans.size(); t++) lo = std::max(lo, tile_cost(t));
                 auto cap = [&](int64_t L, int64_t bin) { return bin < n_workers ? (int64_t)((double)L * wpos[(size_t)bin]) : L; };

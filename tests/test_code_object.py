@@ -50,8 +50,8 @@ def test_stream_kernels_keep_their_state_in_registers(tmp_path):
         assert m["vgpr_count"] <= 256, (name, m)                          # two 256-thread workgroups per CU
         if "f32_direct_kernel" in name:                                   # 4 waves x 2 stages x 32 columns x (32 + 4) floats, private to each wave
             want = {4 * 2 * 32 * 36 * 4}
-        elif "direct_kernel" in name:
-            want = {0}
+        elif "h16_direct_kernel" in name:                                 # 4 waves x 2 stages x 32 columns x (KP + 8) 16-bit elements, private to each wave
+            want = {4 * 2 * 32 * (32 + 8) * 2} if "ILi32E" in name else {4 * 2 * 32 * (64 + 8) * 2}
         elif "h16_stream_kernel" in name:                                 # 2 stages x (128 + 64) rows x (KP + 8) 16-bit elements
             want = {2 * (128 + 64) * (32 + 8) * 2} if "ILi32E" in name else {2 * (128 + 64) * (64 + 8) * 2}
         else:                                                             # fp32: 2 stages x (B panel [+4 pad when column-major] + 32 x 64 A slice) floats
