@@ -55,9 +55,11 @@ for name, make, eng_kw, w in cases:
     d = sa.DeviceVBS.from_csr(m, g, w, rbs, ff, device=0)
     B = torch.rand(d.cols * N, device="cuda") - 0.5
     C = torch.zeros(d.rows * N, device="cuda")
-    for _ in range(5):
-        d.spmm(B, C, N)
-    torch.cuda.synchronize()
+    t_pre = time.time()                                   # untimed pre-roll: a freshly started process runs its first milliseconds below the steady clock (as bench.py)
+    while time.time() - t_pre < 0.3:
+        for _ in range(20):
+            d.spmm(B, C, N)
+        torch.cuda.synchronize()
     reps = 200 if m.nztot() < 8e6 else 20
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -2,6 +2,7 @@
 // (reorder engine, VBS builder, C-ABI glue).  Not installed; the public surface is
 // include/sparta_amd.h (C-ABI) and include/sparta_compat.hpp (reference-shaped C++ API).
 #pragma once
+#include <cstdlib>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -48,6 +49,9 @@ struct HybridSparse {
 };
 int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, bool force_fixed_size,
                      double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp, bool keep_order = false);
+// fewest MFMA steps the nearly empty block-rows of a matrix must be worth before they leave the tiles for the sparse-row kernels
+// (SPARTA_SPARSE_MIN_STEPS overrides; default 4096)
+inline int64_t sparse_min_steps() { const char* e = std::getenv("SPARTA_SPARSE_MIN_STEPS"); return e ? atoll(e) : 4096; }
 int blocking_info(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t* info_out, float* avg_height_out);
 
 }  // namespace sparta

@@ -123,6 +123,11 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
         sp->flag.assign((size_t)block_rows, 0);
         sp->rowptr.assign(1, 0);
         sp->col.clear(); sp->val.clear(); sp->crow.clear();
+        // which block-rows qualify, and how many MFMA steps they would cost as tiles: the sparse-row kernels are extra launches behind the
+        // MFMA launch (10-15 us of launch and dependency measured on a banded matrix with 119 such rows), so a handful of nearly empty
+        // block-rows stays with the tiles (sparta_sparse_min_steps(): 4096 steps ~ 8 per worker ~ 10 us)
+        std::vector<uint8_t> qualifies((size_t)block_rows, 0);
+        double steps_saved = 0.0;
         for (int64_t ib = 0; ib < block_rows; ib++) {
             const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0, nb = out->nzcount[ib];
             if (h <= 0 || nb <= 0) continue;
@@ -137,6 +142,13 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
             }
             const double steps_br = (double)nb * (double)((w + kdep - 1) / kdep) * (double)((h + 31) / 32);
             if (!((double)nnz < K * steps_br)) continue;
+            qualifies[(size_t)ib] = 1;
+            steps_saved += steps_br;
+        }
+        if (steps_saved < (double)sparta::sparse_min_steps()) std::fill(qualifies.begin(), qualifies.end(), 0);
+        for (int64_t ib = 0; ib < block_rows; ib++) {
+            if (!qualifies[(size_t)ib]) continue;
+            const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1];
             sp->flag[(size_t)ib] = 1;
             out->nzcount[ib] = 0;
             for (int64_t r = r0; r < r1; r++) {

@@ -176,15 +176,29 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             const int64_t row0 = row_part[br0];
             std::vector<int64_t> cnt;
             sp_rowptr.push_back(0);
+            // pass 1: which block-rows qualify and what they would cost as tiles (a handful stays with the tiles: see vbs_build_hybrid)
+            std::vector<uint8_t> qualifies((size_t)(br1 - br0), 0);
+            {
+                double steps_saved = 0.0;
+                int64_t mo1 = 0;
+                for (int64_t ib = br0; ib < br1; ib++) {
+                    const int64_t h = row_part[ib + 1] - row_part[ib], nb = nzcount[ib];
+                    const float* blk = mab + mab_lo + mo1;
+                    const int64_t n_el = nb * h * w;
+                    int64_t nnz = 0;
+                    for (int64_t q = 0; q < n_el; q++) nnz += stored(blk[q]) != 0.0f;
+                    const int64_t kdep = h16 && w % 64 == 0 ? 64 : 32;                 // k depth of a step of the kernels this handle would use
+                    const double steps_br = (double)nb * (double)((w + kdep - 1) / kdep) * (double)((h + 31) / 32);
+                    if (h > 0 && nb > 0 && (double)nnz < K * steps_br) { qualifies[(size_t)(ib - br0)] = 1; steps_saved += steps_br; }
+                    mo1 += n_el;
+                }
+                if (steps_saved < (double)sparta::sparse_min_steps()) std::fill(qualifies.begin(), qualifies.end(), 0);
+            }
             for (int64_t ib = br0; ib < br1; ib++) {
                 const int64_t h = row_part[ib + 1] - row_part[ib], nb = nzcount[ib];
                 const float* blk = mab + mab_lo + mo2;
                 const int64_t n_el = nb * h * w;
-                int64_t nnz = 0;
-                for (int64_t q = 0; q < n_el; q++) nnz += stored(blk[q]) != 0.0f;
-                const int64_t kdep = h16 && w % 64 == 0 ? 64 : 32;                     // k depth of a step of the kernels this handle would use
-                const double steps_br = (double)nb * (double)((w + kdep - 1) / kdep) * (double)((h + 31) / 32);
-                if (h > 0 && nb > 0 && (double)nnz < K * steps_br && (int64_t)sp_col.size() + nnz < ((int64_t)1 << 40)) {
+                if (qualifies[(size_t)(ib - br0)] && (int64_t)sp_col.size() + n_el < ((int64_t)1 << 40)) {
                     sparse_flag[(size_t)(ib - br0)] = 1;
                     n_flagged++;
                     // rows of this block-row: (column, value) in the reference's order (blocks ascending, k ascending: vbr.cpp:358-363)

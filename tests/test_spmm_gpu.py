@@ -21,6 +21,7 @@ def _sparse_row_mode(request, monkeypatch):
         monkeypatch.setenv("SPARTA_SPARSE_K", "0")
     else:
         monkeypatch.delenv("SPARTA_SPARSE_K", raising=False)
+        monkeypatch.setenv("SPARTA_SPARSE_MIN_STEPS", "0")        # the library leaves a handful of such block-rows with the tiles: the test matrices are all "a handful"
     return request.param
 TOL = 1e-5
 
@@ -1043,3 +1044,31 @@ def test_full_size_16bit_flagship_kernels_agree_and_match_the_oracle(monkeypatch
     want = colsum[:v.cols] @ B_r.astype(np.float64).reshape(n, v.cols).T
     got = Ch.astype(np.float64).sum(axis=1)
     assert np.allclose(got, want, rtol=0, atol=1e-3 * max(1.0, float(np.abs(want).max())))
+
+
+def test_a_handful_of_nearly_empty_block_rows_stays_with_the_tiles(monkeypatch, _sparse_row_mode):
+    """the sparse-row kernels are extra launches: nearly empty block-rows leave the MFMA tiles only when together they are worth
+    SPARTA_SPARSE_MIN_STEPS steps (default 4096); the product is the oracle's either way (both builders: VBS arrays and from_csr)"""
+    if _sparse_row_mode == "mfma-only":
+        pytest.skip("one mode is enough")
+    torch = _torch()
+    m, w = _mixed_matrix()
+    g = sa.BlockingEngine(tau=0.5, col_block_size=w).GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    n = 128
+    B = sa.gen.dense_rhs(v.cols, n, seed=21)
+    Co = _oracle_c(v, B, n)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+    Bt = torch.from_numpy(B).cuda()
+    for min_steps, want_sparse in (("0", True), (None, False)):
+        if min_steps is None:
+            monkeypatch.delenv("SPARTA_SPARSE_MIN_STEPS", raising=False)
+        else:
+            monkeypatch.setenv("SPARTA_SPARSE_MIN_STEPS", min_steps)
+        for d in (v.to_device(0), sa.DeviceVBS.from_csr(m, g, w, device=0)):
+            assert (d.info()["sparse_rows"] > 0) == want_sparse
+            Ct = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
+            d.spmm(Bt, Ct, n)
+            torch.cuda.synchronize()
+            _check(Ct.cpu().numpy(), Co, bound, "min steps %s" % min_steps)
+            d.close()
