@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
         const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bptr), 0, 0x7ffffff0, 0x00020000);
         const uint32_t qs = tail ? qstepBt : qstepB;
 #ifndef SPARTA_DIRECT_PROBE
-#define SPARTA_DIRECT_PROBE 0     /* developer probes, TIMING ONLY (results wrong): 1 no B loads, 2 no A loads, 4 no epilogue, 8 no LDS round trip */
+#define SPARTA_DIRECT_PROBE 0     /* developer probes, TIMING ONLY (results wrong): 1 no B loads, 2 no A loads, 4 no epilogue, 8 no LDS round trip, 64 every tile stores to the first rows of C */
 #endif
 #ifndef SPARTA_DIRECT_BLOAD_AUX
 #define SPARTA_DIRECT_BLOAD_AUX 0
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
                 }
             } else {
                 const int mt = flags & 0xffff;
-                const int64_t c_row = field(i, F_CROW);
+                const int64_t c_row = (SPARTA_DIRECT_PROBE & 64) ? 0 : field(i, F_CROW);      // probe 64: every tile stores to the first rows of C
                 float* cbase = p.c_row_major ? p.C + c_row * p.ldc + n0 : p.C + c_row + (int64_t)n0 * p.ldc;
                 const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
                 const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;          // bytes per output column
@@ -169,9 +169,13 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
 #pragma unroll
                         for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
                     }
+                    if (p.c_nt) {
 #pragma unroll
-                    for (int q = 0; q < 16; q++)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, SPARTA_CSTORE_AUX);
+                        for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 2);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 0);
+                    }
                 }
             }
 #pragma unroll

@@ -276,9 +276,13 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
 #pragma unroll
                             for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
                         }
+                        if (p.c_nt) {
 #pragma unroll
-                        for (int q = 0; q < 16; q++)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, SPARTA_CSTORE_AUX);
+                            for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 2);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
+                        }
                     }
                 }
             }

@@ -408,6 +408,8 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             CREATE_TRY(hipMalloc((void**)&v->d_steps[ty], st.size() * sizeof(StepRec)));
             CREATE_TRY(hipMemcpy(v->d_steps[ty], st.data(), st.size() * sizeof(StepRec), hipMemcpyHostToDevice));
             v->h_steps[ty] = st;
+            v->n_plan_tiles[ty] = plan.n_plan_tiles[ty];
+            v->tiles_row_aligned[ty] = plan.tiles_row_aligned[ty];
             CREATE_TRY(hipMalloc((void**)&v->d_wrange[ty], wrange[ty].size() * sizeof(int32_t)));
             CREATE_TRY(hipMemcpy(v->d_wrange[ty], wrange[ty].data(), wrange[ty].size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
@@ -634,6 +636,17 @@ int sparta_vbs_clock_mhz(sparta_vbs_t* A, double* mhz_out) {
 
 namespace {
 
+// cache policy of a stream launch's C stores (vbs_kernel_common.hpp): non-temporal for long tiles; SPARTA_C_NT=0|1 forces one
+int32_t c_store_nt(const sparta_vbs_t* A, int ty, const float* C, int64_t ldc, bool c_row_major) {
+    if (const char* e = std::getenv("SPARTA_C_NT")) return atoi(e) != 0;
+    if (A->n_plan_tiles[ty] <= 0) return 0;
+    if (A->n_steps[ty] >= 6 * A->n_plan_tiles[ty]) return 1;                    // long tiles
+    // short tiles: only when a store instruction writes whole, aligned 128-byte lines (32-row tiles starting at multiples of 32 rows of a
+    // column-major C whose columns are 128-byte aligned) -- banded 200k in fixed 32-row tiles: 63 us default, 51 non-temporal; the same
+    // matrix in tiles of 28 rows on average (misaligned pieces of lines): 67-71 default, 79 non-temporal
+    return !c_row_major && A->tiles_row_aligned[ty] && ldc % 32 == 0 && ((uintptr_t)C % 128) == 0;
+}
+
 // long runs of rows without blocks, accumulate = 0: streamed zero fill (vbs_zero_rows_kernel), one launch per run
 void launch_zero_ranges(sparta_vbs_t* A, float* C, int64_t ldc, bool c_row_major, int n_cols, hipStream_t st) {
     for (const auto& zr : A->zero_ranges) {
@@ -766,7 +779,7 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
         const int probe_ty = A->n_steps[1] >= A->n_steps[0] ? 1 : 0;
         for (int ty = 1; ty >= 0; ty--) {
             if (A->n_steps[ty] == 0) continue;
-            sp.steps = shard_rows > 0 ? A->d_steps_g[ty] : A->d_steps[ty]; sp.worker_range = A->d_wrange[ty];
+            sp.steps = shard_rows > 0 ? A->d_steps_g[ty] : A->d_steps[ty]; sp.worker_range = A->d_wrange[ty]; sp.c_nt = c_store_nt(A, ty, sp.C, sp.ldc, sp.c_row_major != 0);
             sp.clk = (prof && ty == probe_ty) ? A->d_clk : nullptr;
             const bool gth = shard_rows > 0;
             launch_h16_stream(A->kp16, ty != 0, bf16, gth, grid, st, sp);
@@ -892,7 +905,7 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                 const int probe_ty = A->n_steps[1] >= A->n_steps[0] ? 1 : 0;
                 for (int ty = 1; ty >= 0; ty--) {
                     if (A->n_steps[ty] == 0) continue;
-                    sp.steps = shard_rows > 0 ? A->d_steps_g[ty] : A->d_steps[ty]; sp.worker_range = A->d_wrange[ty];
+                    sp.steps = shard_rows > 0 ? A->d_steps_g[ty] : A->d_steps[ty]; sp.worker_range = A->d_wrange[ty]; sp.c_nt = c_store_nt(A, ty, sp.C, sp.ldc, sp.c_row_major != 0);
                     sp.clk = (prof && ty == probe_ty) ? A->d_clk : nullptr;
                     if (A->pair_plan) launch_f32_pair(b_layout == SPARTA_ROW_MAJOR, shard_rows > 0, grid, st, sp);
                     else if (ty == 0 && A->d_a_frag && b_layout == SPARTA_COL_MAJOR && shard_rows == 0) {

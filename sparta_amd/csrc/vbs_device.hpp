@@ -101,6 +101,7 @@ struct StreamParams {
     int32_t accumulate, c_row_major;
     int32_t N, w;
     long long* clk;                       // clock probe, see clock_probe()
+    int32_t c_nt;                         // 1: non-temporal C stores (long tiles), 0: default cache policy (short tiles); see vbs_kernel_common.hpp
     int32_t stagger;                      // developer knob (SPARTA_STAGGER): workgroups of the second half of the grid start this many x 64 cycles late
 };
 
@@ -189,6 +190,8 @@ struct sparta_vbs {
     sparta_dev::StepRec* d_steps_k64 = nullptr;   // 64-deep step list of the <= 32-row tiles (column-major, non-gathered B) or nullptr
     int32_t* d_wrange_k64 = nullptr;
     int64_t n_steps_k64 = 0;
+    int64_t n_plan_tiles[2] = {0, 0};             // see StreamPlanHost
+    bool tiles_row_aligned[2] = {true, true};
     float* d_a_frag = nullptr;                    // A of the one-tile plan in fragment order (k_f32_direct.hip) or nullptr
     bool has_tail = false;                 // cols % w != 0: the stream path needs B_tail
     void* d_btail = nullptr;
@@ -273,6 +276,8 @@ struct StreamPlanHost {
     bool pair_plan = false;                   // fp32: steps[0] is the pair plan (vbs_plan.cpp, build_pair_plan), steps[1] is empty
     std::vector<StepRec> steps_k64;           // fp32, aligned one-tile plan, cols % w == 0: the same tiles as 64-deep steps (vbs_spmm_f32_k64_kernel)
     std::vector<int32_t> wrange_k64;
+    int64_t n_plan_tiles[2] = {0, 0};         // tiles (with at least one block) per plan: steps per tile decides the cache policy of the C stores
+    bool tiles_row_aligned[2] = {true, true}; // every tile of the plan starts at a multiple of 32 rows of C (whole 128-byte lines of a column-major C)
     std::vector<float> a_frag;                // fp32 one-tile plan: A per step in MFMA fragment order (vbs_spmm_f32_direct_kernel), or empty
 };
 constexpr int64_t kZeroRangeRows = 2048;    // block-rows without blocks at least this tall are zero-filled by vbs_zero_rows_kernel

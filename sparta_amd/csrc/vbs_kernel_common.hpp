@@ -17,12 +17,12 @@ namespace sparta_dev {
 #define TL_STAMP(k) do { } while (0)
 #endif
 
-// Cache policy of the stream kernels' C stores: non-temporal (aux 2).  The product is written once and never read back by the launch that
-// writes it; with the default policy the 32 MB of C of the flagship push panels of B out of the L2s (fp32 flagship, same box, interleaved
-// runs: 54.2 -> 53.2 us).  -DSPARTA_CSTORE_AUX=0 restores the default policy for an A/B run.
-#ifndef SPARTA_CSTORE_AUX
-#define SPARTA_CSTORE_AUX 2
-#endif
+// Cache policy of the stream kernels' C stores, chosen per launch (StreamParams::c_nt, a scalar branch around the 16 store
+// instructions -- stores define no register, so the join costs nothing): NON-TEMPORAL where tiles are long (>= 6 steps per tile on average) --
+// C is written once and never read back, with the default policy the 32 MB of C of the flagship push panels of B out of the L2s (fp32
+// flagship, same box, interleaved runs: 54.2 -> 53.2 us) -- and the DEFAULT policy where tiles are short: a step's loads wait (vmcnt is one
+// in-order counter on gfx9) for the stores of the tile that ended two steps earlier, and non-temporal stores take longer to complete
+// (banded 200k, 1.8 steps per tile: 78-79 us non-temporal, 56-68 default; with every tile storing to the same rows of C: 37).
 
 __device__ __forceinline__ void clock_probe(long long* clk, int slot) {
     if (clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {

@@ -430,6 +430,8 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             if ((int64_t)st.size() > INT32_MAX - 64)
                 return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: matrix too large for 32-bit step indexing");
             const int64_t S = (int64_t)st.size();
+            P.n_plan_tiles[ty] = (int64_t)spans.size();
+            for (const TileSpan& sp : spans) if (sp.c_row % 32 != 0) P.tiles_row_aligned[ty] = false;
             if (S == 0) continue;
             cum.push_back(total_cost);
             // boundaries: worker (x, j) = the j-th of the P/8 sub-ranges of XCD x's eighth; workgroup id = x + 8 j
