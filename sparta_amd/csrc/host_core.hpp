@@ -42,7 +42,10 @@ int vbs_build(const CsrView& a, const int64_t* grouping, int64_t col_block_size,
               bool force_fixed_size, sparta_vbs_host* out);
 // hybrid build (sparta_vbs_create_from_csr): the block-rows left to the device's sparse-row path, as rows of (column, value)
 struct HybridSparse {
-    std::vector<uint8_t> flag;        // per block-row: 1 = not in the dense image
+    std::vector<uint8_t> flag;        // per block-row: 1 = not in the dense image at all; 2 = mixed: its well-filled blocks are in the dense image,
+                                      // the nonzeros of the others are sparse rows that ADD to what the tiles wrote (row_add)
+    std::vector<uint8_t> row_add;     // per sparse row: 1 = its block-row also has tiles: the sparse-row kernels add to C instead of storing
+    double esz = 4.0;                 // bytes per element of B on the device (what a nonzero costs against re-reading a row of C)
     std::vector<int64_t> rowptr;      // rows of the flagged block-rows, in reordered order
     std::vector<int32_t> col, crow;   // crow: reordered row index (= row of C)
     std::vector<float> val;

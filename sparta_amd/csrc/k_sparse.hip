@@ -92,8 +92,9 @@ template <int VEC>
 __device__ __forceinline__ void sparse_row_store(const SparseParams& p, int ord, typename SpVec<VEC>::T acc, int n0) {
     typedef typename SpVec<VEC>::T V;
     if (VEC == 1 && n0 >= p.N) return;
-    float* o = p.out + (int64_t)p.crow[ord] * p.ldo + n0;
-    if (p.accumulate) acc += *reinterpret_cast<const V*>(o);
+    const int32_t cr = p.crow[ord];                              // bit 31: the row also has MFMA tiles -- add to what they stored
+    float* o = p.out + (int64_t)(cr & 0x7fffffff) * p.ldo + n0;
+    if (p.accumulate || cr < 0) acc += *reinterpret_cast<const V*>(o);
     *reinterpret_cast<V*>(o) = acc;
 }
 
@@ -123,7 +124,8 @@ __device__ __forceinline__ void sp_cm_flush(const SparseParams& p, const float* 
     const int j = threadIdx.x & (kCmRows - 1), cg = threadIdx.x / kCmRows;
     if (!valid) return;
     const int cbase = blockIdx.y * W;
-    float* o = p.out + crow + (int64_t)cbase * p.ldo;
+    const bool add = p.accumulate || crow < 0;                   // bit 31 of a crow entry: the row also has MFMA tiles -- add to what they stored
+    float* o = p.out + (crow & 0x7fffffff) + (int64_t)cbase * p.ldo;
 #pragma unroll 1
     for (int c0 = 0; c0 < W; c0 += NQ * CG) {
         float x[NQ];
@@ -132,7 +134,7 @@ __device__ __forceinline__ void sp_cm_flush(const SparseParams& p, const float* 
             const int c = c0 + cg + CG * q;
             x[q] = tile[((c % VEC) * kCmRows + j) * 65 + c / VEC];
         }
-        if (p.accumulate) {
+        if (add) {
             float old[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; q++) {

@@ -37,7 +37,10 @@ struct BlockCollector {
     std::vector<int32_t> stamp;   // per column block: last block-row that touched it (+1)
     std::vector<int32_t> slot;    // per column block: position inside the current block-row
     std::vector<int32_t> touched;
-    explicit BlockCollector(int64_t block_cols) : stamp((size_t)block_cols, 0), slot((size_t)block_cols, 0) {}
+    std::vector<int32_t> count;   // per column block: stored nonzeros of the current block-row (valid for touched blocks; count_nnz = true)
+    bool count_nnz = false;
+    explicit BlockCollector(int64_t block_cols, bool counting = false)
+        : stamp((size_t)block_cols, 0), slot((size_t)block_cols, 0), count(counting ? (size_t)block_cols : 0, 0), count_nnz(counting) {}
 
     void collect(const CsrView& a, const int64_t* perm, int64_t r0, int64_t r1, int64_t w, int32_t tag) {
         touched.clear();
@@ -47,11 +50,14 @@ struct BlockCollector {
             const int32_t* cj = a.row(i);
             int64_t n = a.nnz_of(i);
             int64_t last = -1;
+            const float* v = count_nnz && a.vals ? a.vals + a.rowptr[i] : nullptr;
             for (int64_t k = 0; k < n; k++) {
                 int64_t jb = (int64_t)cj[k] / w;
-                if (jb == last) continue;
-                last = jb;
-                if (stamp[(size_t)jb] != tag) { stamp[(size_t)jb] = tag; touched.push_back((int32_t)jb); }
+                if (jb != last) {
+                    last = jb;
+                    if (stamp[(size_t)jb] != tag) { stamp[(size_t)jb] = tag; touched.push_back((int32_t)jb); if (count_nnz) count[(size_t)jb] = 0; }
+                }
+                if (count_nnz) count[(size_t)jb] += !v || v[k] != 0.0f;
             }
         }
         std::sort(touched.begin(), touched.end());                 // jab is ascending (vbr.cpp:195-198)
@@ -109,60 +115,100 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
     if (!out->row_part || !out->nzcount) { sparta_vbs_host_free(out); return fail(SPARTA_ERR_ALLOC, "sparta_vbs_build: out of host memory"); }
     std::copy(part.begin(), part.end(), out->row_part);
 
-    // pass 1: number of nonzero blocks per block-row
+    // Hybrid decision, per block-row, from the nonzeros of each of its blocks (cost unit: one nonzero on the sparse-row path; an MFMA step is
+    // worth K of them): a block is WELL FILLED when it holds at least K nonzeros per step it costs.  A block-row is
+    //   0  dense: all blocks as tiles                                      cost nb * spb * K
+    //   1  sparse: no tile at all, every nonzero a sparse-row entry         cost nnz
+    //   2  mixed: the well-filled blocks as tiles, the nonzeros of the rest as sparse rows that ADD to what the tiles stored
+    //                                                                       cost n_dense * spb * K + nnz_rest + h * (re-reading a row of C)
+    // whichever is cheapest (ties: fewer kernels).  Mode 2 is what dense power-law matrices need: the hub columns fill their blocks, the tail does
+    // not, and a whole-block-row decision sends the hub's nonzeros through the gather one by one.
+    const double rmw_cost = 4.0 / (sp ? sp->esz : 4.0) + 4.0;
+    // a block is "well filled" against a higher bar than a whole block-row (SPARTA_SPARSE_K_BLOCK nonzeros per step, default 60): the rows of B
+    // its nonzeros would gather are the hub rows -- L2-resident, where the measured break-even of tiles against sparse rows is ~60 nonzeros
+    // per step, not the ~15-24 of rows of B that come from HBM (scripts/sparse_k_sweep.py)
+    const double K_block = [] { const char* e = std::getenv("SPARTA_SPARSE_K_BLOCK"); return e ? atof(e) : 60.0; }();
+    auto spb_of = [&](int64_t h) { return (double)((w + kdep - 1) / kdep) * (double)((h + 31) / 32); };
+    struct RowMode { uint8_t mode; int64_t n_dense; double saved; };
+    auto decide = [&](const BlockCollector& bc, int64_t h) {
+        const int64_t nb = (int64_t)bc.touched.size();
+        RowMode r{0, nb, 0.0};
+        if (!hybrid || nb == 0 || h <= 0) return r;
+        const double spb = spb_of(h), kb = K * spb, kbb = K_block * spb;
+        int64_t n_dense = 0;
+        double nnz = 0.0, nnz_rest = 0.0;
+        for (int32_t jb : bc.touched) {
+            const double c = (double)bc.count[(size_t)jb];
+            nnz += c;
+            if (c >= kbb) n_dense++; else nnz_rest += c;
+        }
+        const double c_dense = (double)nb * kb, c_sparse = nnz, c_mixed = (double)n_dense * kb + nnz_rest + (double)h * rmw_cost;
+        if (c_sparse < c_dense && c_sparse <= c_mixed) { r.mode = 1; r.n_dense = 0; r.saved = (c_dense - c_sparse) / K; }
+        else if (n_dense > 0 && n_dense < nb && c_mixed < c_dense) { r.mode = 2; r.n_dense = n_dense; r.saved = (c_dense - c_mixed) / K; }
+        return r;
+    };
+
+    // pass 1: blocks per block-row (+ the hybrid mode)
+    std::vector<uint8_t> mode((size_t)block_rows, 0);
+    std::vector<double> saved_row((size_t)block_rows, 0.0);           // MFMA steps the chosen mode saves against "all tiles"
     parallel_for_blocks(block_rows, [&](int64_t lo, int64_t hi, int) {
-        BlockCollector bc(block_cols);
+        BlockCollector bc(block_cols, hybrid);
         for (int64_t ib = lo; ib < hi; ib++) {
             bc.collect(a, perm.data(), part[(size_t)ib], part[(size_t)ib + 1], w, (int32_t)(ib - lo + 1));
-            out->nzcount[ib] = (int64_t)bc.touched.size();
+            const RowMode r = decide(bc, part[(size_t)ib + 1] - part[(size_t)ib]);
+            mode[(size_t)ib] = r.mode;
+            out->nzcount[ib] = r.n_dense;
+            saved_row[(size_t)ib] = r.saved;
         }
     });
 
-    // hybrid: decide per block-row, empty the dense image of the sparse ones, collect their rows
+    // hybrid: a handful of nearly empty blocks stays with the tiles -- the sparse-row kernels are extra launches behind the MFMA launch
+    // (10-15 us of launch and dependency measured on a banded matrix with 119 such rows; sparse_min_steps(): 4096 steps ~ 8 per worker ~ 10 us);
+    // then the sparse rows are collected in row order
     if (hybrid) {
-        sp->flag.assign((size_t)block_rows, 0);
-        sp->rowptr.assign(1, 0);
-        sp->col.clear(); sp->val.clear(); sp->crow.clear();
-        // which block-rows qualify, and how many MFMA steps they would cost as tiles: the sparse-row kernels are extra launches behind the
-        // MFMA launch (10-15 us of launch and dependency measured on a banded matrix with 119 such rows), so a handful of nearly empty
-        // block-rows stays with the tiles (sparta_sparse_min_steps(): 4096 steps ~ 8 per worker ~ 10 us)
-        std::vector<uint8_t> qualifies((size_t)block_rows, 0);
         double steps_saved = 0.0;
-        for (int64_t ib = 0; ib < block_rows; ib++) {
-            const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0, nb = out->nzcount[ib];
-            if (h <= 0 || nb <= 0) continue;
-            int64_t nnz = 0;
-            for (int64_t r = r0; r < r1; r++) {
-                const int64_t i = perm[(size_t)r];
-                if (i >= a.rows) continue;
-                const float* v = a.vals ? a.vals + a.rowptr[i] : nullptr;
-                const int64_t n = a.nnz_of(i);
-                if (!v) { nnz += n; continue; }
-                for (int64_t k = 0; k < n; k++) nnz += v[k] != 0.0f;
+        for (double x : saved_row) steps_saved += x;
+        if (steps_saved < (double)sparse_min_steps()) {
+            BlockCollector bc(block_cols, false);
+            for (int64_t ib = 0; ib < block_rows; ib++) {
+                if (!mode[(size_t)ib]) continue;
+                mode[(size_t)ib] = 0;
+                bc.collect(a, perm.data(), part[(size_t)ib], part[(size_t)ib + 1], w, (int32_t)(ib % 0x7ffffff0 + 1));
+                out->nzcount[ib] = (int64_t)bc.touched.size();
             }
-            const double steps_br = (double)nb * (double)((w + kdep - 1) / kdep) * (double)((h + 31) / 32);
-            if (!((double)nnz < K * steps_br)) continue;
-            qualifies[(size_t)ib] = 1;
-            steps_saved += steps_br;
         }
-        if (steps_saved < (double)sparta::sparse_min_steps()) std::fill(qualifies.begin(), qualifies.end(), 0);
+        sp->flag.assign(mode.begin(), mode.end());
+        sp->rowptr.assign(1, 0);
+        sp->col.clear(); sp->val.clear(); sp->crow.clear(); sp->row_add.clear();
+        BlockCollector bc(block_cols, true);
+        std::vector<uint8_t> is_dense((size_t)block_cols, 0);              // valid for the touched blocks of the current (mixed) block-row
+        int32_t tag = 0;
         for (int64_t ib = 0; ib < block_rows; ib++) {
-            if (!qualifies[(size_t)ib]) continue;
-            const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1];
-            sp->flag[(size_t)ib] = 1;
-            out->nzcount[ib] = 0;
+            if (!mode[(size_t)ib]) continue;
+            const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
+            const bool mixed = mode[(size_t)ib] == 2;
+            if (mixed) {
+                if (++tag == INT32_MAX) { std::fill(bc.stamp.begin(), bc.stamp.end(), 0); tag = 1; }
+                bc.collect(a, perm.data(), r0, r1, w, tag);
+                const double kbb = K_block * spb_of(h);
+                for (int32_t jb : bc.touched) is_dense[(size_t)jb] = (double)bc.count[(size_t)jb] >= kbb;
+            }
             for (int64_t r = r0; r < r1; r++) {
                 const int64_t i = perm[(size_t)r];
+                const size_t before = sp->col.size();
                 if (i < a.rows) {
                     const int32_t* cj = a.row(i);
                     const float* v = a.vals ? a.vals + a.rowptr[i] : nullptr;
                     const int64_t n = a.nnz_of(i);
                     for (int64_t k = 0; k < n; k++) {
                         const float x = v ? v[k] : 1.0f;                  // pattern-only matrices store 1 (vbr.cpp:217)
-                        if (x != 0.0f) { sp->col.push_back(cj[k]); sp->val.push_back(x); }
+                        if (x == 0.0f || (mixed && is_dense[(size_t)(cj[k] / w)])) continue;
+                        sp->col.push_back(cj[k]); sp->val.push_back(x);
                     }
                 }
-                sp->crow.push_back((int32_t)r);                           // padded rows too: they are rows of C
+                if (mixed && sp->col.size() == before) continue;          // a row of a mixed block-row without such a nonzero: the tiles wrote all of it
+                sp->crow.push_back((int32_t)r);                           // (fully sparse block-rows: padded and empty rows too -- they are rows of C)
+                sp->row_add.push_back(mixed ? 1 : 0);
                 sp->rowptr.push_back((int64_t)sp->col.size());
             }
         }
@@ -183,11 +229,22 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
 
     // pass 2: jab + scatter the values, column-major inside each block (vbr.cpp:224)
     parallel_for_blocks(block_rows, [&](int64_t lo, int64_t hi, int) {
-        BlockCollector bc(block_cols);
+        BlockCollector bc(block_cols, hybrid);
         for (int64_t ib = lo; ib < hi; ib++) {
             const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
-            if (hybrid && sp->flag[(size_t)ib]) continue;                 // not materialised
+            if (mode[(size_t)ib] == 1) continue;                          // not materialised
             bc.collect(a, perm.data(), r0, r1, w, (int32_t)(ib - lo + 1));
+            const bool mixed = mode[(size_t)ib] == 2;
+            if (mixed) {                                                  // keep the well-filled blocks only; slot = -1 marks the others
+                const double kbb = K_block * spb_of(h);
+                int32_t s2 = 0;
+                for (size_t s = 0; s < bc.touched.size(); s++) {
+                    const int32_t jb = bc.touched[s];
+                    if ((double)bc.count[(size_t)jb] >= kbb) { bc.slot[(size_t)jb] = s2; bc.touched[(size_t)s2++] = jb; }
+                    else bc.slot[(size_t)jb] = -1;
+                }
+                bc.touched.resize((size_t)s2);
+            }
             int64_t* jab = out->jab + jab_off[(size_t)ib];
             for (size_t s = 0; s < bc.touched.size(); s++) jab[s] = bc.touched[s];
             float* base = out->mab + mab_off[(size_t)ib];
@@ -200,6 +257,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                 for (int64_t k = 0; k < n; k++) {
                     int64_t j = cj[k];
                     int64_t s = bc.slot[(size_t)(j / w)];
+                    if (mixed && s < 0) continue;                         // a nonzero of a block that went to the sparse rows
                     // pattern-only matrices store 1 (vbr.cpp:217); duplicates: last one wins (:226)
                     base[s * h * w + h * (j % w) + (r - r0)] = v ? v[k] : 1.0f;
                 }

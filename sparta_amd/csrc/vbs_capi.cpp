@@ -154,9 +154,11 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         _Float16 hh; std::memcpy(&hh, &u, 2); return (float)hh;
     };
     if (ext) {
-        sparse_flag = ext->flag;
+        // flag 1: the block-row has no tile at all (skipped by the MFMA plans); flag 2 (mixed): its well-filled blocks are tiles like any other
+        // (nzcount / jab hold only those), the nonzeros of its other blocks are sparse rows that ADD to C (bit 31 of their crow entry)
+        sparse_flag.assign(ext->flag.size(), 0);
         bool any = false;
-        for (uint8_t f : sparse_flag) any = any || f;
+        for (size_t q = 0; q < ext->flag.size(); q++) { sparse_flag[q] = ext->flag[q] == 1; any = any || sparse_flag[q]; }
         if (!any) sparse_flag.clear();
         sp_rowptr.assign(1, 0);
         for (size_t t = 0; t < ext->crow.size(); t++) {
@@ -164,7 +166,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
                 const float a = stored(ext->val[(size_t)k]);
                 if (a != 0.0f && ext->col[(size_t)k] < cols) { sp_col.push_back(ext->col[(size_t)k]); sp_val.push_back(a); }
             }
-            sp_crow.push_back(ext->crow[t]);
+            sp_crow.push_back(ext->crow[t] | (t < ext->row_add.size() && ext->row_add[t] ? (int32_t)0x80000000 : 0));
             sp_rowptr.push_back((int64_t)sp_col.size());
         }
     } else {
@@ -494,6 +496,7 @@ static int create_from_csr_impl(sparta_vbs_t** out, int64_t rows, int64_t cols, 
         if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
         const int64_t kdep = (dtype != SPARTA_F32 && col_block_size % 64 == 0) ? 64 : 32;
         sparta::HybridSparse sp;
+        sp.esz = dtype == SPARTA_F32 ? 4.0 : 2.0;
         rc = sparta::vbs_build_hybrid(a, grouping, col_block_size, row_block_size, force_fixed_size != 0, K, kdep, &h, K > 0.0 ? &sp : nullptr, keep_order);
         if (rc == SPARTA_OK)
             rc = create_core(out, h.rows, h.cols, h.block_rows, col_block_size, h.row_part, h.nzcount, h.jab, h.mab, 0, h.block_rows, dtype, device,

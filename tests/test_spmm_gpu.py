@@ -763,6 +763,7 @@ def test_create_from_csr_gives_the_same_product(monkeypatch, _sparse_row_mode, c
     handle made by sparta_vbs_build + sparta_vbs_create (same decisions, same kernels, same data), and equal to the oracle's"""
     torch = _torch()
     monkeypatch.setenv("SPARTA_PATH", "stream")              # two handles compared bit for bit: same MFMA path on both (no autotune)
+    monkeypatch.setenv("SPARTA_SPARSE_K_BLOCK", "1e30")      # whole-block-row decisions only, as sparta_vbs_create takes them (the per-block split has its own test below)
     n = 128
     if case == "mixed":
         m, w = _mixed_matrix()
@@ -1072,3 +1073,58 @@ def test_a_handful_of_nearly_empty_block_rows_stays_with_the_tiles(monkeypatch, 
             torch.cuda.synchronize()
             _check(Ct.cpu().numpy(), Co, bound, "min steps %s" % min_steps)
             d.close()
+
+
+@pytest.mark.parametrize("dtype", [sa.F32, sa.BF16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("kblock", ["2", "8", None])
+def test_create_from_csr_splits_a_block_row_into_tiles_and_sparse_rows(monkeypatch, _sparse_row_mode, dtype, kblock):
+    """sparta_vbs_create_from_csr decides per BLOCK: the well-filled blocks of a block-row stay MFMA tiles, the nonzeros of its other
+    blocks become sparse rows that ADD to what the tiles stored (dense power-law matrices: hub columns fill their blocks, the tail does
+    not).  Product against the oracle in both layouts of C, with and without accumulate, for several thresholds."""
+    if _sparse_row_mode == "mfma-only":
+        pytest.skip("needs the sparse-row path")
+    torch = _torch()
+    if kblock is None:
+        monkeypatch.delenv("SPARTA_SPARSE_K_BLOCK", raising=False)
+    else:
+        monkeypatch.setenv("SPARTA_SPARSE_K_BLOCK", kblock)
+    rng = np.random.Generator(np.random.PCG64(77))
+    rows, cols, w, n = 640, 4096 + 17, 32, 128
+    rr, cc = [], []
+    for i in range(rows):                                     # every row: a dense stripe in the first 96 columns (3 well-filled blocks) + a thin random tail
+        c = np.unique(np.concatenate([rng.choice(96, 40, replace=False), 96 + rng.choice(cols - 96, int(rng.integers(3, 30)), replace=False)]))
+        rr.append(np.full(len(c), i)); cc.append(c)
+    r, c = np.concatenate(rr), np.concatenate(cc)
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=rows))])
+    m = sa.CSR(rows, cols, rowptr, c.astype(np.int32), rng.uniform(-1, 1, len(c)).astype(np.float32))
+    g = sa.BlockingEngine(tau=0.5, col_block_size=w, blocking_algo=7).GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    d = sa.DeviceVBS.from_csr(m, g, w, device=0, dtype=dtype)
+    info, sp = d.info(), d.sparse_info()
+    if kblock is not None:                                    # at these thresholds the matrix must actually be split: tiles AND sparse rows on the same block-rows
+        assert info["tiles16"] + info["tiles32"] + info["tiles64"] > 0 and 0 < sp["nnz"] < m.nztot()
+    tdt = {sa.F32: torch.float32, sa.BF16: torch.bfloat16}[dtype]
+    ldb = (v.cols + 7) // 8 * 8
+    B = sa.gen.dense_rhs(v.cols, n, seed=41)
+    Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    Bt.view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
+    if dtype == sa.F32:
+        vo, Bo = v, B
+    else:                                                     # the oracle on the rounded inputs (products of two 16-bit values are exact in fp32)
+        rnd = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(tdt).float().numpy()
+        Bo = rnd(B)
+        vo = sa.VBR.from_arrays(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, rnd(v.mab))
+    for cl in (sa.COL_MAJOR, sa.ROW_MAJOR):
+        for acc in (False, True):
+            C0 = sa.gen.dense_rhs(v.rows, n, seed=42)
+            Ct = torch.from_numpy(C0 if cl == sa.COL_MAJOR else np.ascontiguousarray(C0.reshape(n, v.rows).T).reshape(-1)).cuda()
+            d.spmm(Bt, Ct, n, ldb=ldb, c_layout=cl, accumulate=acc)
+            torch.cuda.synchronize()
+            got = Ct.cpu().numpy()
+            if cl == sa.ROW_MAJOR:
+                got = np.ascontiguousarray(got.reshape(v.rows, n).T).reshape(-1)
+            want = _oracle_c(vo, Bo, n, C0) if acc else _oracle_c(vo, Bo, n)
+            bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, vo.mab, Bo, n)
+            _check(got, want, bound + (np.abs(C0) if acc else 0), "per-block split kblock=%s layout %d acc %d" % (kblock, cl, acc))
+    d.close()
+
