@@ -284,7 +284,12 @@ int sparta_vbs_create_from_csr(sparta_vbs_t** out, int64_t rows, int64_t cols, c
  * semantics (C += A*B); 0 overwrites C (every row of C is written).  ptr_space HOST: buffers are
  * copied to/from the device around the kernel and *dt_ms (may be NULL) covers the kernel only;
  * DEVICE: launched on `stream` (a hipStream_t, NULL = default stream); if dt_ms != NULL the call
- * records events and synchronises on them, otherwise it returns without synchronising. */
+ * records events and synchronises on them, otherwise it returns without synchronising.
+ * A handle carries per-handle scratch (split-tile workspace, layout copies of B, step lists of a gathered B): it must not run on two
+ * streams at once.  The FIRST call of a shape (n_cols, layouts, shard_rows) on a handle may allocate that scratch, and on fp32 handles
+ * times its two product paths once; every later call of the shape is kernel launches only and can be captured into a hipGraph.  A call
+ * that would have to allocate or time while its stream is being captured returns SPARTA_ERR_UNSUPPORTED (and leaves the capture
+ * intact): run it once outside the capture first. */
 int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int32_t n_cols,
                     void* C, int64_t ldc, int32_t c_layout, int32_t accumulate,
                     int32_t ptr_space, void* stream, int32_t algo, float* dt_ms);

@@ -26,8 +26,25 @@ namespace {
 
 bool force_generic() { const char* e = std::getenv("SPARTA_FORCE_GENERIC"); return e && e[0] == '1'; }
 
+// set for the duration of a product call whose stream is being captured into a graph: anything that allocates, synchronises or times
+// (scratch growth, the first-call autotune, the gathered step lists) then fails with SPARTA_ERR_UNSUPPORTED instead of breaking the
+// capture -- run the same call once outside the capture first (same n_cols, layouts and shard_rows), after which the call is launches only
+thread_local bool g_capturing = false;
+struct CaptureScope {
+    explicit CaptureScope(hipStream_t st, bool device_ptrs) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        g_capturing = device_ptrs && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    }
+    ~CaptureScope() { g_capturing = false; }
+};
+int capture_refusal(const char* what) {
+    return sparta::fail(SPARTA_ERR_UNSUPPORTED, std::string("sparta_vbs_spmm: the stream is being captured and this call still has to ") + what +
+                                                 " -- run it once outside the capture first");
+}
+
 int ensure_scratch(void** ptr, size_t* have, size_t need) {
     if (*have >= need) return SPARTA_OK;
+    if (g_capturing) return capture_refusal("allocate scratch memory");
     if (*ptr) { (void)hipFree(*ptr); *ptr = nullptr; *have = 0; }
     HIP_TRY(hipMalloc(ptr, need));
     *have = need;
@@ -663,6 +680,7 @@ void launch_zero_ranges(sparta_vbs_t* A, float* C, int64_t ldc, bool c_row_major
 // step lists for a gathered B (slab index + row inside the slab), rebuilt when the slab height changes
 int ensure_gathered_steps(sparta_vbs_t* A, int64_t shard_rows, hipStream_t st) {
     if (A->g_shard_rows == shard_rows) return SPARTA_OK;
+    if (g_capturing) return capture_refusal("build the step lists of this slab height");
     for (int ty = 0; ty < 2; ty++) {
         if (A->h_steps[ty].empty()) continue;
         std::vector<StepRec> g = A->h_steps[ty];
@@ -838,6 +856,8 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
     DeviceGuard guard(A->device);
     if (!guard.ok) return fail(SPARTA_ERR_HIP, "sparta_vbs_spmm: hipSetDevice failed");
     hipStream_t st = (hipStream_t)stream;
+    const CaptureScope capture(st, ptr_space == SPARTA_PTR_DEVICE);
+    if (g_capturing && dt_ms) return capture_refusal("time the product (dt_ms != NULL synchronises)");
     if (A->dtype != SPARTA_F32)
         return spmm16_impl(A, B, ldb, b_layout, shard_rows, shard_stride, n_cols, C, ldc, c_layout, accumulate, ptr_space, st, algo, dt_ms);
 
@@ -970,6 +990,7 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
             const int64_t key = ((int64_t)n_cols << 8) | (b_layout << 2) | (c_layout << 1) | (shard_rows > 0 ? 1 : 0);
             path = 0;
             for (const auto& kv : A->tuned) if (kv.first == key) path = kv.second;
+            if (path == 0 && g_capturing) return capture_refusal("time its two product paths");
             if (path == 0) {
                 // plan-time autotune: both paths write a scratch C (the caller's C must not be accumulated into twice)
                 if (int rc = ensure_scratch(&A->d_tune, &A->d_tune_bytes, c_elems * sizeof(float))) return rc;

@@ -1128,3 +1128,39 @@ def test_create_from_csr_splits_a_block_row_into_tiles_and_sparse_rows(monkeypat
             _check(got, want, bound + (np.abs(C0) if acc else 0), "per-block split kblock=%s layout %d acc %d" % (kblock, cl, acc))
     d.close()
 
+
+
+def test_product_inside_a_graph_capture(monkeypatch, _sparse_row_mode):
+    """a shape that has run once is kernel launches only and can be captured into a graph (replay = the eager product, bit for bit);
+    a shape that would still have to allocate scratch or time its paths refuses to run under capture instead of breaking it"""
+    if _sparse_row_mode == "with-sparse-rows":
+        pytest.skip("one mode is enough")
+    torch = _torch()
+    monkeypatch.delenv("SPARTA_PATH", raising=False)
+    m = sa.gen.fem3d(6, 6, 12, 3, 1)
+    w, n = 32, 128
+    eng = sa.BlockingEngine(blocking_algo=5, tau=0.6, col_block_size=w, row_block_size=32, force_fixed_size=True)
+    v = sa.VBR().fill_from_CSR_inplace(m, eng.GetGrouping(m), w, 32, True)
+    d = v.to_device(0)
+    B = torch.from_numpy(sa.gen.dense_rhs(v.cols, n, seed=5)).cuda()
+    C_eager = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
+    C_graph = torch.zeros_like(C_eager)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        gph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(gph, stream=s):            # first call of this shape: autotune / scratch -> refused, the capture survives
+                with pytest.raises(sa.SpartaError):
+                    d.spmm(B, C_graph, n)
+        except RuntimeError:
+            pass                                             # (an empty capture may itself be rejected by the runtime: not the subject)
+        d.spmm(B, C_eager, n)                                # once outside a capture
+        torch.cuda.synchronize()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=s):
+            d.spmm(B, C_graph, n)
+    torch.cuda.synchronize()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(C_graph, C_eager)
+    d.close()
