@@ -135,6 +135,9 @@ def main():
                          "documented = SPARTA_IO_STRICT): e.g. the real SuiteSparse cant.mtx where a copy is at hand (none can be fetched here)")
     ap.add_argument("--exchange", choices=["auto", "allgather", "blocks"], default="auto",
                     help="N > 1, workload cant: how the ranks' shards of B reach the slabs")
+    ap.add_argument("--gather", choices=["auto", "all_gather", "peer_copies"], default="auto",
+                    help="N > 1, all-gather exchange: the collective, world-1 point-to-point copies posted together, or (auto, nccl only) whichever a "
+                         "plan-time measurement finds faster (logged in config.allgather)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: DEBUG ONLY -- several ranks on ONE GPU (a one-GPU box), collectives staged through host memory; checks the "
                          "multi-rank logic end to end, its timings mean nothing")
@@ -354,6 +357,14 @@ def main():
         if exchange == "allgather" and ex is not None:
             ex.close()
             ex = None
+    # all-gather exchange: the collective or the peer copies, by a plan-time measurement on the real communicator
+    gather_pick, gather_mode = None, "all_gather"
+    if distributed and ex is None:
+        if args.gather == "auto" and args.backend == "nccl" and world > 1:
+            gather_pick = sa.dist.pick_allgather(B_shard, B_gath, rank, world, reps=5, sync=torch.cuda.synchronize)     # collective
+            gather_mode = gather_pick["mode"]
+        elif args.gather == "peer_copies" and args.backend == "nccl" and world > 1:
+            gather_mode = "peer_copies"
     dmain, vbm = (ex.d_own, ex.own) if ex is not None else (d, vb)      # the handle / matrix whose kernel dominates a step
     info = dmain.info()
 
@@ -363,7 +374,10 @@ def main():
         elif ex is not None:
             ex.step(B_tiles, C)                                    # pack + ONE all-to-all of the needed row-blocks || own product; + remote product
         else:
-            dist.all_gather_into_tensor(B_gath, B_shard)          # the one exchange step (RCCL over xGMI)
+            if gather_mode == "peer_copies":
+                sa.dist.allgather_B_peer_copies(B_shard, B_gath, rank, world)    # world - 1 copies, one per xGMI link
+            else:
+                dist.all_gather_into_tensor(B_gath, B_shard)      # the one exchange step (RCCL over xGMI)
             d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False)
 
     def fence():
@@ -648,6 +662,8 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    if distributed and ex is None:
+        out["config"]["allgather"] = dict(gather_pick or {}, mode=gather_mode)
     if gen_stats is not None:
         out["config"]["generator"] = gen_stats
     if check is not None:

@@ -88,6 +88,56 @@ def allgather_B(B_shard, B_gathered, group=None):
     return B_gathered
 
 
+def allgather_B_peer_copies(B_shard, B_gathered, rank, world_size, group=None):
+    """The same result as allgather_B by world_size - 1 point-to-point sends and receives posted together
+    (`batch_isend_irecv`): every rank sends its slab straight to each peer and receives each peer's slab into its place in the
+    gathered buffer.  On MI355X every pair of GPUs of a node has its own xGMI link, so the 7 copies of a rank run on 7 links at
+    once, where a ring all-gather moves (world - 1) / world of the buffer over one link per direction (SURVEY.md section 8(e));
+    which one wins depends on slab size and RCCL's choice of algorithm -- `pick_allgather` measures both."""
+    import torch.distributed as dist
+    n = B_shard.numel()
+    B_gathered[rank * n:(rank + 1) * n].copy_(B_shard)
+    ops = []
+    for k in range(1, world_size):                            # rank r sends to r + k while it receives from r - k: no two posts of a pair cross
+        dst, src = (rank + k) % world_size, (rank - k) % world_size
+        ops.append(dist.P2POp(dist.isend, B_shard, dst, group=group))
+        ops.append(dist.P2POp(dist.irecv, B_gathered[src * n:(src + 1) * n], src, group=group))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    return B_gathered
+
+
+def pick_allgather(B_shard, B_gathered, rank, world_size, reps=3, sync=None, group=None):
+    """Plan-time choice between the collective all-gather and the peer copies: both are run (first for equality of the result, then
+    `reps` timed repetitions each, wall clock between two `sync()` calls, maximum over the ranks); every rank returns the same
+    {'mode': 'all_gather' | 'peer_copies', 'all_gather_ms', 'peer_copies_ms', 'equal'}.  Collective: call it on every rank."""
+    import time
+    import torch
+    import torch.distributed as dist
+    sync = sync or (lambda: None)
+    ref = allgather_B(B_shard, B_gathered, group=group).clone()
+    B_gathered.zero_()
+    allgather_B_peer_copies(B_shard, B_gathered, rank, world_size, group=group)
+    sync()
+    equal = torch.tensor([1.0 if torch.equal(ref, B_gathered) else 0.0], device=B_gathered.device)
+    ms = []
+    for fn in (lambda: allgather_B(B_shard, B_gathered, group=group),
+               lambda: allgather_B_peer_copies(B_shard, B_gathered, rank, world_size, group=group)):
+        fn(); sync()
+        dist.barrier(group=group)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        sync()
+        ms.append((time.perf_counter() - t0) * 1e3 / reps)
+    t = torch.tensor(ms + [float(equal.item())], dtype=torch.float64, device=B_gathered.device)
+    dist.all_reduce(t[:2], op=dist.ReduceOp.MAX, group=group)
+    eq = t[2:3].clone()
+    dist.all_reduce(eq, op=dist.ReduceOp.MIN, group=group)
+    ag, pc, ok = float(t[0]), float(t[1]), float(eq[0]) > 0.5
+    return {"mode": "peer_copies" if ok and pc < 0.95 * ag else "all_gather", "all_gather_ms": round(ag, 4), "peer_copies_ms": round(pc, 4), "equal": ok}
+
+
 def gathered_to_colmajor(B_gathered, world_size, shard_rows, n_cols):
     """(host/numpy helper for tests) gathered slabs -> one column-major (world*shard_rows) x n_cols matrix, flat"""
     g = np.asarray(B_gathered).reshape(world_size, n_cols, shard_rows)      # slab s, column j, local row

@@ -269,3 +269,44 @@ def test_partition_by_cost_and_row_slab():
     for k, r in enumerate(rows):
         assert np.array_equal(s.colidx[s.rowptr[k]:s.rowptr[k + 1]], m.colidx[m.rowptr[r]:m.rowptr[r + 1]])
         assert np.array_equal(s.vals[s.rowptr[k]:s.rowptr[k + 1]], m.vals[m.rowptr[r]:m.rowptr[r + 1]])
+
+
+def _peer_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import sparta_amd as sa
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_pad = 48
+        shard = torch.from_numpy(sa.gen.dense_rhs(n_pad, N, seed=170 + rank))
+        a = torch.empty(world * n_pad * N, dtype=torch.float32)
+        b = torch.zeros_like(a)
+        sa.dist.allgather_B(shard, a)
+        sa.dist.allgather_B_peer_copies(shard, b, rank, world)      # world - 1 sends + receives posted together
+        pick = sa.dist.pick_allgather(shard, torch.empty_like(a), rank, world, reps=2)      # collective; every rank gets the same answer
+        np.savez(os.path.join(out_dir, "peer%d.npz" % rank), a=a.numpy(), b=b.numpy(), mode=pick["mode"], equal=pick["equal"],
+                 ag=pick["all_gather_ms"], pc=pick["peer_copies_ms"])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_copies_equal_the_all_gather_and_every_rank_picks_the_same(tmp_path, world):
+    """the alternative to the collective all-gather (world - 1 point-to-point copies per rank, one per xGMI link on the
+    GPUs) leaves the same gathered B, and the plan-time pick between the two is one decision for the whole job"""
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_peer_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    import sparta_amd as sa
+    res = [np.load(os.path.join(str(tmp_path), "peer%d.npz" % r)) for r in range(world)]
+    want = np.concatenate([sa.gen.dense_rhs(48, N, seed=170 + r) for r in range(world)])
+    for r in range(world):
+        assert np.array_equal(res[r]["a"], want) and np.array_equal(res[r]["b"], want)
+        assert bool(res[r]["equal"]) and str(res[r]["mode"]) == str(res[0]["mode"]) and str(res[r]["mode"]) in ("all_gather", "peer_copies")
+        assert float(res[r]["ag"]) == float(res[0]["ag"]) and float(res[r]["pc"]) == float(res[0]["pc"])      # the maxima over the ranks
