@@ -364,296 +364,6 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_stream_kernel(const 
 }
 #undef field
 
-// =====================================================================================================
-// Pair kernel -- the product path of fp32 handles (plan: vbs_plan.cpp, build_pair_plan).
-//
-// Same persistent pipeline as vbs_spmm_f32_stream_kernel<.., MI2 = true> (G: global -> registers three steps ahead, W:
-// registers -> the other LDS stage between the MFMA rounds, one barrier per step, records through v_readlane), but the
-// 64 rows of a step are TWO independently addressed 32-row halves: the upper and the lower tile of a pair, each with its
-// own A cursor and leading dimension.  A step record says which halves have a block in this block column (STEP_HAS0 /
-// STEP_HAS1): the B panel is staged ONCE and feeds both when both do; an absent half loads its A slice through a buffer
-// descriptor of ZERO records (the hardware returns zeros and touches no memory -- a scalar select, no branch in the load
-// path) and its 16 MFMAs are jumped over by a scalar branch around a block that defines nothing but the accumulator it
-// updates in place (no join of register sets: the trap of DESIGN.md section 3.2 does not arise).
-// Record fields (StepRec reused): a_off = slice of the upper half, slot = slice of the lower half - a_off, h = h_upper |
-// h_lower << 16, c_row = first C row of the pair (workspace slot on STEP_LAST | STEP_SPLIT), pad = slab of a gathered B.
-// =====================================================================================================
-template <bool BRM, bool GATHERED>
-__global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_pair_kernel(const StreamParams p) {
-    constexpr int KP = SK_KP, TN = kTN, TM = SK_TM;
-    constexpr int LDB = BRM ? TN : KP + 4;          // col-major B: Bs[j][k] (+4: conflict-free ds_read_b128); row-major: Bs[k][j]
-    constexpr int BSZ = BRM ? KP * TN : TN * (KP + 4);
-    constexpr int STAGE = BSZ + KP * SK_TM;         // floats per LDS stage (B panel + As[k][i], i = 0..31 upper half, 32..63 lower half)
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int lm = lane & 31, g = lane >> 5;
-    const int n0 = blockIdx.y * TN;
-    const int s_begin = p.worker_range[2 * blockIdx.x];
-    const int n = p.worker_range[2 * blockIdx.x + 1] - s_begin;
-    if (n <= 0) return;
-    if (p.stagger > 0 && blockIdx.x >= (gridDim.x >> 1))          // developer knob: de-phase the two workgroups that share a CU
-        for (int k = 0; k < p.stagger; k++) __builtin_amdgcn_s_sleep(1);
-    clock_probe(p.clk, 0);
-    float* ws = p.ws + (int64_t)blockIdx.y * p.ws_slab_stride;
-
-    // step records: see vbs_spmm_f32_stream_kernel
-    const int32_t* srec = reinterpret_cast<const int32_t*>(p.steps + s_begin);
-    int vrec0 = srec[lane];
-    int vrec1 = srec[64 + lane];
-    int vnext = 0;
-#define field(s, f) sk_field(vrec0, vrec1, (s), (f))
-    enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H01 = 3, F_CROW = 4, F_FLAGS = 5, F_ADELTA = 6, F_SHARD = 7 };
-
-    // per-thread constant byte offsets (the only vector part of any address in the loop)
-    const int bj0 = tid >> 3, bk = (tid & 7) * 4;       // col-major B: column bj0 + 32q, k = bk..bk+3   (q = 0..3)
-    const int rk0 = tid >> 5, rj = (tid & 31) * 4;      // row-major B: k = rk0 + 8q, columns rj..rj+3
-    const int ak0 = tid >> 3, ai = (tid & 7) * 4;       // A, each half: k = ak0 (0..31), rows ai..ai+3 of 32 -- one 16-byte load per lane and half
-    const int64_t ld_t = BRM ? (int64_t)p.N : (int64_t)p.w;                      // leading dimension of B_tail
-    const uint32_t voffB = BRM ? (uint32_t)((rk0 * p.ldb + rj) * 4) : (uint32_t)((bk + bj0 * p.ldb) * 4);
-    const uint32_t voffBt = BRM ? (uint32_t)((rk0 * ld_t + n0 + rj) * 4) : (uint32_t)((bk + (n0 + bj0) * ld_t) * 4);
-    const uint32_t qstepB = (uint32_t)((BRM ? 8 : 32) * p.ldb * 4), qstepBt = (uint32_t)((BRM ? 8 : 32) * ld_t * 4);
-    const int64_t n0off = BRM ? (int64_t)n0 : (int64_t)n0 * p.ldb;               // slab offset folded into the scalar base
-    const uint32_t lwB = BRM ? (uint32_t)((rk0 * LDB + rj) * 4) : (uint32_t)((bj0 * LDB + bk) * 4);   // LDS write offsets (bytes)
-    const uint32_t lwA = (uint32_t)((BSZ + ak0 * TM + ai) * 4);                                      // upper half; lower half: + 32 floats
-    const uint32_t lrA = (uint32_t)((BSZ + 4 * g * TM + lm) * 4);                                    // LDS read offsets
-    const uint32_t lrB = BRM ? (uint32_t)((4 * g * LDB + 32 * wave + lm) * 4) : (uint32_t)(((32 * wave + lm) * LDB + 4 * g) * 4);
-    const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 32 * wave + 4 * g) * 4) : (uint32_t)((lm + (32 * wave + 4 * g) * p.ldc) * 4);
-    char* const ldsb = reinterpret_cast<char*>(lds);
-
-    u32x4 b0[4], a0[2], b1[4], a1[2];                   // register sets 0 / 1 of the staging pipeline (raw bits); a[0] upper half, a[1] lower half
-
-    // ---- G: global -> registers; steps are requested strictly in order s = 0, 1, 2, ... ----------------------
-    const float* g_pA0 = p.A;                            // scalar: base of the upper / lower half's A slices of the current pair
-    const float* g_pA1 = p.A;
-    uint32_t g_so0 = 0, g_so1 = 0, g_inc0 = 0, g_inc1 = 0;   // running byte offset inside the pair (soffset of the loads) and its per-step advance
-    uint32_t voA0 = 0, voA1 = 0, vo_cur = voffB;
-    int32_t tail_prev = 0;
-    // The G stage in two parts.  prep(s): everything scalar about step s -- record fields, cursors, buffer descriptors -- ~60 SALU
-    // instructions that must sit INSIDE a block of MFMAs to be free (the scalar unit issues in the shadow of a running MFMA of the same
-    // wave; outside such a block the wave just waits for them).  fire(...): the six buffer loads, issued from the prepared scalars.
-    struct Prep { const float* bptr; uint32_t qs; const float* pa0; const float* pa1; uint32_t nr0, nr1, so0, so1; int32_t flags; };
-    auto prep = [&](int s) __attribute__((always_inline)) -> Prep {
-        Prep q;
-        const int32_t flags = field(s, F_FLAGS);
-        q.flags = flags;
-        if (flags & STEP_FIRST) {                        // pair (segment) start: re-seat both cursors, else they just advance
-            const int64_t aoff0 = (int64_t)(uint32_t)field(s, F_AOFF_LO) | ((int64_t)field(s, F_AOFF_HI) << 32);
-            g_pA0 = p.A + aoff0;
-            g_pA1 = g_pA0 + (int64_t)field(s, F_ADELTA);
-            const uint32_t h01 = (uint32_t)field(s, F_H01);
-            const uint32_t h0 = h01 & 0xffffu, h1 = h01 >> 16;
-            g_so0 = 0; g_so1 = 0;
-            g_inc0 = h0 * (uint32_t)(KP * 4);            // consecutive blocks of a block-row are contiguous in A (column-major blocks back to back)
-            g_inc1 = h1 * (uint32_t)(KP * 4);
-            voA0 = (uint32_t)(ak0 * (int)h0 + ai) * 4u;
-            voA1 = (uint32_t)(ak0 * (int)h1 + ai) * 4u;
-        }
-        const int32_t tail = (flags & STEP_TAIL) != 0;
-        if (tail != tail_prev) {
-            vo_cur = tail ? voffBt : voffB;
-            asm volatile("" : "+v"(vo_cur));
-            tail_prev = tail;
-        }
-        int64_t gk0 = field(s, F_BROW);
-        const float* Bbase = tail ? p.B_tail : p.B;
-        if constexpr (GATHERED) Bbase += (int64_t)field(s, F_SHARD) * p.shard_stride;
-        q.bptr = tail ? Bbase + (BRM ? gk0 * ld_t : gk0) : Bbase + (BRM ? gk0 * p.ldb : gk0) + n0off;
-        q.qs = tail ? qstepBt : qstepB;
-        // A half without a block in this step gets a descriptor of ZERO records: every lane is out of range, the load returns zeros
-        // (which is what its LDS image must hold) and no request leaves the CU.  The plan keeps a pair's A bytes below 2^30.
-        q.nr0 = (flags & STEP_HAS0) ? 0x7ffffff0u : 0u;
-        q.nr1 = (flags & STEP_HAS1) ? 0x7ffffff0u : 0u;
-        q.pa0 = g_pA0; q.pa1 = g_pA1; q.so0 = g_so0; q.so1 = g_so1;
-        g_so0 += (flags & STEP_HAS0) ? g_inc0 : 0u;
-        g_so1 += (flags & STEP_HAS1) ? g_inc1 : 0u;
-        return q;
-    };
-    auto fire = [&](const Prep& q, u32x4 (&rb)[4], u32x4 (&ra)[2]) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.bptr), 0, 0x7ffffff0, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < 4; j++) rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, q.qs * j, 0);
-        // A slices, streamed (nt: read exactly once).  Rows past a tile read what follows in memory: never stored.
-        const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.pa0), 0, (int)q.nr0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.pa1), 0, (int)q.nr1, 0x00020000);
-        ra[0] = __builtin_amdgcn_raw_buffer_load_b128(rA0, voA0, q.so0, 2);
-        ra[1] = __builtin_amdgcn_raw_buffer_load_b128(rA1, voA1, q.so1, 2);
-    };
-    auto issue_loads = [&](int s, u32x4 (&rb)[4], u32x4 (&ra)[2]) __attribute__((always_inline)) -> int32_t {   // prologue only
-        const Prep q = prep(s);
-        fire(q, rb, ra);
-        return q.flags;
-    };
-    int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq_new = 0;
-
-    // ---- W: registers -> LDS stage (compile-time stage => immediate offsets) -----------------------------------
-    auto write_b = [&](auto stage_tag, const u32x4 (&rb)[4], int q) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stage_tag)::value;
-        *reinterpret_cast<u32x4*>(ldsb + lwB + (ST * STAGE + (BRM ? 8 * q * LDB : 32 * q * LDB)) * 4) = rb[q];
-    };
-    auto write_a = [&](auto stage_tag, const u32x4 (&ra)[2], int q) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stage_tag)::value;
-        *reinterpret_cast<u32x4*>(ldsb + lwA + (ST * STAGE + 32 * q) * 4) = ra[q];
-    };
-
-    // ---- C: fragments + MFMA ------------------------------------------------------------------------------
-    uint32_t a_addr[2][4];
-#pragma unroll
-    for (int st = 0; st < 2; st++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            a_addr[st][r] = lrA + (uint32_t)((st * STAGE + 8 * r * TM) * 4);
-            asm volatile("" : "+v"(a_addr[st][r]));
-        }
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-    // Store staging.  The epilogue stores from COPIES of the accumulators and the copies stay untouched until the next step has passed
-    // its barrier.  Measured on MI355X (scripts/r2_pair_debug.py + the PAIR_DBG builds of round 2): with the stores reading the
-    // accumulator registers themselves and the `acc = 0` moves a few instructions behind them, 1-10 tiles per launch came out wrong
-    // and different from run to run; waiting for the stores to complete (s_waitcnt vmcnt(0)) right behind them cured it, delays in
-    // FRONT of them did not.  A buffer_store's data registers must not be rewritten while the store is in flight on this part.
-    f32x16 stg0, stg1;
-#pragma unroll
-    for (int r = 0; r < 16; r++) { stg0[r] = 0.0f; stg1[r] = 0.0f; }
-    // one pipeline iteration: compute step i from stage PAR; write step i+1 (register set wb/wa) into stage 1-PAR; refill that
-    // register set with step i+3.
-    //   * every fragment read of the step is issued first: LDS operations complete in order, so an MFMA that waits for its fragments
-    //     never waits for the 16-byte writes queued behind them;
-    //   * the LDS writes (W) and the scalar half of the G stage (prep) sit in the SAME basic block as the 16 MFMAs of the first present
-    //     half, where the scheduler interleaves them: a wave's own non-MFMA instructions issue in the shadow of its own MFMAs.  With the
-    //     MFMA groups in blocks of their own (first version: one branch per round and half) all of that work was exposed: a lone 32-row
-    //     tile took 4250 cycles per step against 3200 in the one-tile stream kernel;
-    //   * the six loads are issued once, behind the MFMAs, from the prepared scalars (no register is defined on two paths).
-    auto iteration_t = [&](int i, int32_t flags, u32x4 (&wb)[4], u32x4 (&wa)[2], auto par_tag) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par_tag)::value;
-        using nxt_t = std::integral_constant<int, 1 - PAR>;
-        asm volatile("" : : "v"(stg0), "v"(stg1));          // the staged tile of the previous epilogue is still (possibly) being read by its stores
-        f32x4 bf[4], af0[4], af1[4];                        // fragments of the 4 rounds: lane (lm, g) holds k = 8r + 4g .. + 3 of its B column / A rows
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if constexpr (!BRM) {
-                bf[r] = *reinterpret_cast<const f32x4*>(ldsb + lrB + (PAR * STAGE + 8 * r) * 4);
-            } else {
-                const float* bs = reinterpret_cast<const float*>(ldsb + lrB + (PAR * STAGE + 8 * r * LDB) * 4);
-#pragma unroll
-                for (int m = 0; m < 4; m++) bf[r][m] = bs[m * LDB];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float* as = reinterpret_cast<const float*>(ldsb + a_addr[PAR][r]);
-#pragma unroll
-            for (int m = 0; m < 4; m++) { af0[r][m] = as[m * TM]; af1[r][m] = as[m * TM + 32]; }
-        }
-        Prep q;
-        // W + prep + the MFMAs of one half, as ONE straight-line region (source order = the interleaving the scheduler starts from)
-#define SPARTA_PAIR_REGION(AF, ACC)                                                                                                \
-        do {                                                                                                                       \
-            _Pragma("unroll") for (int m = 0; m < 4; m++) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[0][m], AF[0][m], ACC, 0, 0, 0); \
-            write_b(nxt_t{}, wb, 0); write_b(nxt_t{}, wb, 1);                                                                      \
-            _Pragma("unroll") for (int m = 0; m < 4; m++) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[1][m], AF[1][m], ACC, 0, 0, 0); \
-            write_b(nxt_t{}, wb, 2); write_b(nxt_t{}, wb, 3);                                                                      \
-            write_a(nxt_t{}, wa, 0); write_a(nxt_t{}, wa, 1);                                                                      \
-            _Pragma("unroll") for (int m = 0; m < 4; m++) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[2][m], AF[2][m], ACC, 0, 0, 0); \
-            q = prep(i + 3);                                                                                                       \
-            _Pragma("unroll") for (int m = 0; m < 4; m++) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[3][m], AF[3][m], ACC, 0, 0, 0); \
-        } while (0)
-        if (flags & STEP_HAS0) {
-            SPARTA_PAIR_REGION(af0, acc0);
-            if (flags & STEP_HAS1) {
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-#pragma unroll
-                    for (int m = 0; m < 4; m++) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[r][m], af1[r][m], acc1, 0, 0, 0);
-            }
-        } else {
-            SPARTA_PAIR_REGION(af1, acc1);
-        }
-#undef SPARTA_PAIR_REGION
-        fire(q, wb, wa);
-        fq_new = q.flags;
-        if (flags & STEP_LAST) {
-#pragma unroll
-            for (int q = 0; q < 16; q++) {                        // copies the register allocator cannot merge with the accumulators
-                asm volatile("v_mov_b32 %0, %1" : "=v"(stg0[q]) : "v"(acc0[q]));
-                asm volatile("v_mov_b32 %0, %1" : "=v"(stg1[q]) : "v"(acc1[q]));
-            }
-            if (flags & STEP_SPLIT) {
-                const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_CROW) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(stg0[q]), rW, (uint32_t)tid * 4u, (uint32_t)(q * kThreads * 4), 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(stg1[q]), rW, (uint32_t)tid * 4u, (uint32_t)((16 + q) * kThreads * 4), 0);
-                }
-            } else {
-                const int mt = flags & 0xffff;
-                const int64_t c_row = field(i, F_CROW);
-                float* cbase = p.c_row_major ? p.C + c_row * p.ldc + n0 : p.C + c_row + (int64_t)n0 * p.ldc;
-                const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
-                const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;          // bytes per output column
-                const uint32_t mistep = p.c_row_major ? (uint32_t)p.ldc * 128u : 128u;     // bytes per 32 rows
-#pragma unroll
-                for (int mi = 0; mi < 2; mi++) {
-                    if (mi * 32 + lm < mt) {
-                        if (p.accumulate) {                       // all 16 loads in flight before the first add (one wait, not 16)
-                            uint32_t old[16];
-#pragma unroll
-                            for (int q = 0; q < 16; q++) old[q] = __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
-#pragma unroll
-                            for (int q = 0; q < 16; q++) { if (mi == 0) stg0[q] += __uint_as_float(old[q]); else stg1[q] += __uint_as_float(old[q]); }
-                        }
-#pragma unroll
-                        for (int q = 0; q < 16; q++)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mi == 0 ? stg0[q] : stg1[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 16; q++) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
-        }
-        __syncthreads();
-    };
-    // ---- prologue: G(0) G(1) | W(0) | G(2) ------------------------------------------------------------------
-    using st0 = std::integral_constant<int, 0>;
-    using st1 = std::integral_constant<int, 1>;
-    fq0 = issue_loads(0, b0, a0);
-    fq1 = issue_loads(1, b1, a1);
-#pragma unroll
-    for (int q = 0; q < 4; q++) write_b(st0{}, b0, q);
-#pragma unroll
-    for (int q = 0; q < 2; q++) write_a(st0{}, a0, q);
-    fq2 = issue_loads(2, b0, a0);
-    __syncthreads();
-    // record batches: see vbs_spmm_f32_stream_kernel (request at step 8k, touch at 8k+4: 4 steps x 6 loads in between, vmcnt(6) is free)
-    auto batch_upkeep = [&](int i) __attribute__((always_inline)) {
-        if ((i & 7) == 0 && i > 0) {
-            const int32_t* nb = srec + (int64_t)((i >> 3) + 1) * 64 + lane;
-            asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
-        }
-        if ((i & 7) == 4 && i > 4) {
-            const bool odd = (((i >> 3) + 1) & 1) != 0;
-            vrec1 = odd ? vnext : vrec1;
-            vrec0 = odd ? vrec0 : vnext;
-        }
-    };
-    const int n_even = n & ~1;
-    for (int i = 0; i < n_even; i += 2) {
-        batch_upkeep(i);
-        iteration_t(i, fq0, b1, a1, st0{});
-        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-        iteration_t(i + 1, fq0, b0, a0, st1{});
-        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-    }
-    if (n & 1) {
-        batch_upkeep(n_even);
-        iteration_t(n_even, fq0, b1, a1, st0{});
-    }
-    clock_probe(p.clk, 2);
-#undef field
-}
-
 // A tile that dominates the plan (a hub block-row) is split over hundreds of workers; adding its partial images one after the
 // other in ONE workgroup is a latency-bound chain (measured: 512 images, 350 us).  First stage for such plans: blockIdx.z = group
 // of kFixGroup consecutive images, summed in order into the group's first image; the fix-up kernel then adds the group leaders
@@ -760,213 +470,6 @@ __global__ __launch_bounds__(kThreads) void vbs_zero_rows_kernel(float* C, int64
 }
 
 
-// =====================================================================================================
-// 64-deep steps for tiles of <= 32 rows: vbs_spmm_f32_k64_kernel
-//
-// The one-tile stream kernel restarts its pipeline every 32 k: one barrier, one record, one round of fragment-read latency and
-// ~55 scalar instructions per 16 MFMAs of a wave -- 1100 of its 3200 cycles per step (two co-resident workgroups) are not MFMA
-// time, and a third workgroup per CU does not hide them (measured, round 2).  Here a step is TWO consecutive 32-deep steps of the
-// same tile: 32 MFMAs per wave between barriers, half the records, half the scalar work, half the fragment restarts per flop.
-//   * the two halves of a step are consecutive in A (blocks of a block-row are back to back: k * h addresses 64 k just as well as
-//     32), but gather their B panels from two different block columns (w = 32) or from the two halves of one (w = 64): the record
-//     carries both rows (b_row, slot);
-//   * LDS: the B image of a step is 128 columns x 64 k = 32 KB -- WITHOUT the +4 padding of the 32-deep kernels, or two workgroups
-//     would not fit a CU: stage = 32 KB (B) + 8 KB (A, 64 k x 32 rows), two stages = 80 KB per workgroup, 160 KB per CU exactly.
-//     Conflict-free reads come from an XOR swizzle instead: 16-byte chunk q of column c lives at chunk position q ^ (c & 15);
-//   * waves 0-1 stage the first panel, waves 2-3 the second: the panel base stays a wave-uniform scalar;
-//   * a tile with an odd number of 32-deep steps ends in a step whose second half is absent: its panel and its A slice are loaded
-//     through zero-record descriptors (zeros, no memory traffic) and multiplied as zeros -- < 5 % extra MFMA work on the flagship.
-// Column-major B only, no gathered B, no zero-padded tail block column (cols % w == 0): everything else stays on the 32-deep kernels.
-// Record = StepRec: a_off, b_row = rows of the first panel, slot = rows of the second panel (-1: absent), h, c_row, mt_flags.
-// =====================================================================================================
-__global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_k64_kernel(const StreamParams p) {
-    constexpr int KP = 64, TN = kTN, TM = 32;
-    constexpr int BSZ = TN * KP;                    // floats of the B image: Bs[c][chunk ^ (c & 15)][4]
-    constexpr int STAGE = BSZ + KP * TM;            // 10 240 floats = 40 960 bytes
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
-    static_assert(2 * STAGE * 4 == 81920, "two workgroups of 80 KB fill the 160 KB of a CU exactly");
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int lm = lane & 31, g = lane >> 5;
-    const int n0 = blockIdx.y * TN;
-    const int s_begin = p.worker_range[2 * blockIdx.x];
-    const int n = p.worker_range[2 * blockIdx.x + 1] - s_begin;
-    if (n <= 0) return;
-    clock_probe(p.clk, 0);
-
-    const int32_t* srec = reinterpret_cast<const int32_t*>(p.steps + s_begin);
-    int vrec0 = srec[lane];
-    int vrec1 = srec[64 + lane];
-    int vnext = 0;
-#define field(s, f) sk_field(vrec0, vrec1, (s), (f))
-    enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_BROW1 = 6, F_SHARD = 7 };
-
-    // B staging: this wave's panel = wave >> 1 (scalar); thread t' = tid & 127 of the wave pair: 16-byte chunk t' & 7 (k = 4 chunk ..),
-    // column (t' >> 3) + 16 q, q = 0..7
-    const int panel = __builtin_amdgcn_readfirstlane(wave >> 1);
-    const int tp = tid & 127, chunk = tp & 7, col0 = tp >> 3;
-    const uint32_t voffB = (uint32_t)((4 * chunk + col0 * p.ldb) * 4);
-    const uint32_t qstepB = (uint32_t)(16 * p.ldb * 4);
-    const int64_t n0off = (int64_t)n0 * p.ldb;
-    const uint32_t lwB = (uint32_t)((col0 * KP + (((panel * 8 + chunk) ^ col0) * 4)) * 4);          // + q * 16 * KP * 4 (col & 15 == col0 for every q)
-    // A staging: k = ak0 + 32 q (q = 0, 1), rows ai .. ai + 3
-    const int ak0 = tid >> 3, ai = (tid & 7) * 4;
-    const uint32_t lwA = (uint32_t)((BSZ + ak0 * TM + ai) * 4);                                       // + q * 32 * TM * 4
-    // fragment reads: B column c = 32 wave + lm, round r: chunk 2r + g at position (2r + g) ^ (c & 15); A: As[8r + 4g + m][lm]
-    const int cfr = 32 * wave + lm;
-    uint32_t b_addr[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        b_addr[r] = (uint32_t)((cfr * KP + (((2 * r + g) ^ (cfr & 15)) * 4)) * 4);
-        asm volatile("" : "+v"(b_addr[r]));
-    }
-    uint32_t lrA = (uint32_t)((BSZ + 4 * g * TM + lm) * 4);
-    asm volatile("" : "+v"(lrA));
-    const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 32 * wave + 4 * g) * 4) : (uint32_t)((lm + (32 * wave + 4 * g) * p.ldc) * 4);
-    char* const ldsb = reinterpret_cast<char*>(lds);
-
-    u32x4 b0[8], a0[2], b1[8], a1[2];                   // register sets 0 / 1 of the staging pipeline (raw bits)
-
-    int64_t g_aoff = 0;
-    int32_t g_h = 1;
-    uint32_t voA_cur = 0;
-    auto issue_loads = [&](int s, u32x4 (&rb)[8], u32x4 (&ra)[2]) __attribute__((always_inline)) -> int32_t {
-        const int32_t flags = field(s, F_FLAGS);
-        if (flags & STEP_FIRST) {
-            g_aoff = (int64_t)(uint32_t)field(s, F_AOFF_LO) | ((int64_t)field(s, F_AOFF_HI) << 32);
-            g_h = field(s, F_H);
-            voA_cur = (uint32_t)(ak0 * g_h + ai) * 4u;
-        } else {
-            g_aoff += (int64_t)KP * g_h;                 // consecutive steps of a block-row are contiguous in A
-        }
-        const int32_t br0 = field(s, F_BROW), br1 = field(s, F_BROW1);
-        const int32_t has1 = br1 >= 0;
-        const int64_t gk = panel ? (int64_t)(has1 ? br1 : 0) : (int64_t)br0;
-        const uint32_t nrB = (panel && !has1) ? 0u : 0x7ffffff0u;              // absent second half: zeros, no traffic
-        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B + gk + n0off), 0, (int)nrB, 0x00020000);
-#pragma unroll
-        for (int q = 0; q < 8; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, voffB, qstepB * q, 0);
-        const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + g_aoff), 0, 0x7ffffff0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + g_aoff), 0, has1 ? 0x7ffffff0 : 0, 0x00020000);
-        ra[0] = __builtin_amdgcn_raw_buffer_load_b128(rA0, voA_cur, 0, 2);
-        ra[1] = __builtin_amdgcn_raw_buffer_load_b128(rA1, voA_cur, (uint32_t)(32 * g_h) * 4u, 2);
-        return flags;
-    };
-    int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq_new = 0;
-
-    auto write_b = [&](auto stage_tag, const u32x4 (&rb)[8], int q) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stage_tag)::value;
-        *reinterpret_cast<u32x4*>(ldsb + lwB + (ST * STAGE + 16 * q * KP) * 4) = rb[q];
-    };
-    auto write_a = [&](auto stage_tag, const u32x4 (&ra)[2], int q) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stage_tag)::value;
-        *reinterpret_cast<u32x4*>(ldsb + lwA + (ST * STAGE + 32 * q * TM) * 4) = ra[q];
-    };
-
-    f32x16 acc0;
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc0[r] = 0.0f;
-    f32x16 stg0;                                         // store staging, see vbs_spmm_f32_pair_kernel
-#pragma unroll
-    for (int r = 0; r < 16; r++) stg0[r] = 0.0f;
-
-    auto round = [&](auto stage_tag, auto r_tag) __attribute__((always_inline)) {
-        constexpr int ST = decltype(stage_tag)::value;
-        constexpr int r = decltype(r_tag)::value;
-        const f32x4 bf = *reinterpret_cast<const f32x4*>(ldsb + b_addr[r] + ST * STAGE * 4);
-        const float* as = reinterpret_cast<const float*>(ldsb + lrA + (ST * STAGE + 8 * r * TM) * 4);
-        float a[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) a[m] = as[m * TM];
-#pragma unroll
-        for (int m = 0; m < 4; m++) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[m], a[m], acc0, 0, 0, 0);
-    };
-
-    auto iteration_t = [&](int i, int32_t flags, u32x4 (&wb)[8], u32x4 (&wa)[2], auto par_tag) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par_tag)::value;
-        using cur_t = std::integral_constant<int, PAR>;
-        using nxt_t = std::integral_constant<int, 1 - PAR>;
-        asm volatile("" : : "v"(stg0));
-        // rounds with the W / G work that rides along (the scheduler interleaves inside the basic block)
-        round(cur_t{}, std::integral_constant<int, 0>{});
-        write_b(nxt_t{}, wb, 0); write_b(nxt_t{}, wb, 1);
-        round(cur_t{}, std::integral_constant<int, 1>{});
-        write_b(nxt_t{}, wb, 2); write_b(nxt_t{}, wb, 3);
-        round(cur_t{}, std::integral_constant<int, 2>{});
-        write_b(nxt_t{}, wb, 4); write_b(nxt_t{}, wb, 5);
-        round(cur_t{}, std::integral_constant<int, 3>{});
-        write_b(nxt_t{}, wb, 6); write_b(nxt_t{}, wb, 7);
-        round(cur_t{}, std::integral_constant<int, 4>{});
-        write_a(nxt_t{}, wa, 0); write_a(nxt_t{}, wa, 1);
-        round(cur_t{}, std::integral_constant<int, 5>{});
-        round(cur_t{}, std::integral_constant<int, 6>{});
-        fq_new = issue_loads(i + 3, wb, wa);
-        round(cur_t{}, std::integral_constant<int, 7>{});
-        if (flags & STEP_LAST) {
-#pragma unroll
-            for (int q = 0; q < 16; q++) asm volatile("v_mov_b32 %0, %1" : "=v"(stg0[q]) : "v"(acc0[q]));
-            const int mt = flags & 0xffff;
-            const int64_t c_row = field(i, F_CROW);
-            float* cbase = p.c_row_major ? p.C + c_row * p.ldc + n0 : p.C + c_row + (int64_t)n0 * p.ldc;
-            const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
-            const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;          // bytes per output column
-            if (lm < mt) {
-                if (p.accumulate) {
-                    uint32_t old[16];
-#pragma unroll
-                    for (int q = 0; q < 16; q++) old[q] = __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 0);
-#pragma unroll
-                    for (int q = 0; q < 16; q++) stg0[q] += __uint_as_float(old[q]);
-                }
-#pragma unroll
-                for (int q = 0; q < 16; q++)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(stg0[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 16; q++) acc0[q] = 0.0f;
-        }
-        __syncthreads();
-    };
-    using st0 = std::integral_constant<int, 0>;
-    using st1 = std::integral_constant<int, 1>;
-    fq0 = issue_loads(0, b0, a0);
-    fq1 = issue_loads(1, b1, a1);
-#pragma unroll
-    for (int q = 0; q < 8; q++) write_b(st0{}, b0, q);
-#pragma unroll
-    for (int q = 0; q < 2; q++) write_a(st0{}, a0, q);
-    fq2 = issue_loads(2, b0, a0);
-    __syncthreads();
-    // record batches: request at step 8k, touch at 8k + 4: 4 steps x 10 loads in between, vmcnt(10) is free
-    auto batch_upkeep = [&](int i) __attribute__((always_inline)) {
-        if ((i & 7) == 0 && i > 0) {
-            const int32_t* nb = srec + (int64_t)((i >> 3) + 1) * 64 + lane;
-            asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
-        }
-        if ((i & 7) == 4 && i > 4) {
-            asm volatile("s_waitcnt vmcnt(10)" : "+v"(vnext) : : "memory");
-            const bool odd = (((i >> 3) + 1) & 1) != 0;
-            vrec1 = odd ? vnext : vrec1;
-            vrec0 = odd ? vrec0 : vnext;
-        }
-    };
-    const int n_even = n & ~1;
-    for (int i = 0; i < n_even; i += 2) {
-        batch_upkeep(i);
-        iteration_t(i, fq0, b1, a1, st0{});
-        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-        iteration_t(i + 1, fq0, b0, a0, st1{});
-        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-    }
-    if (n & 1) {
-        batch_upkeep(n_even);
-        iteration_t(n_even, fq0, b1, a1, st0{});
-    }
-    clock_probe(p.clk, 2);
-#undef field
-}
-
 }  // namespace
 
 namespace sparta_dev {
@@ -981,16 +484,6 @@ void launch_f32_stream(bool mi2, bool b_row_major, bool gathered, dim3 grid, hip
         else if (b_row_major) hipLaunchKernelGGL((vbs_spmm_f32_stream_kernel<true, false, false>), grid, dim3(kThreads), 0, st, sp);
         else hipLaunchKernelGGL((vbs_spmm_f32_stream_kernel<false, false, false>), grid, dim3(kThreads), 0, st, sp);
     }
-}
-
-void launch_f32_pair(bool b_row_major, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
-    if (gathered) hipLaunchKernelGGL((vbs_spmm_f32_pair_kernel<false, true>), grid, dim3(kThreads), 0, st, sp);
-    else if (b_row_major) hipLaunchKernelGGL((vbs_spmm_f32_pair_kernel<true, false>), grid, dim3(kThreads), 0, st, sp);
-    else hipLaunchKernelGGL((vbs_spmm_f32_pair_kernel<false, false>), grid, dim3(kThreads), 0, st, sp);
-}
-
-void launch_f32_k64(dim3 grid, hipStream_t st, const StreamParams& sp) {
-    hipLaunchKernelGGL(vbs_spmm_f32_k64_kernel, grid, dim3(kThreads), 0, st, sp);
 }
 
 void launch_fixup_group(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* big, const int32_t* fix_slots, float* ws_all, int64_t ws_slab_stride) {

@@ -65,8 +65,6 @@ void destroy_impl(sparta_vbs* v) {
         if (v->d_wrange[ty]) (void)hipFree(v->d_wrange[ty]);
     }
     if (v->d_a_frag) (void)hipFree(v->d_a_frag);
-    if (v->d_steps_k64) (void)hipFree(v->d_steps_k64);
-    if (v->d_wrange_k64) (void)hipFree(v->d_wrange_k64);
     if (v->d_fix) (void)hipFree(v->d_fix);
     if (v->d_fix_slots) (void)hipFree(v->d_fix_slots);
     if (v->d_big_fix) (void)hipFree(v->d_big_fix);
@@ -363,7 +361,6 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     if (!v) return fail(SPARTA_ERR_ALLOC, "sparta_vbs_create: out of host memory");
     v->device = device; v->dtype = dtype;
     v->zero_ranges = plan.zero_ranges;
-    v->pair_plan = plan.pair_plan;
     v->rows = row_part[br1] - row_part[br0]; v->cols = cols; v->block_rows = br1 - br0; v->w = w;
     v->nblocks = nblocks; v->nztot = nztot; v->exec_area = exec_area;
 
@@ -436,15 +433,6 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             CREATE_TRY(hipMalloc((void**)&v->d_a_frag, plan.a_frag.size() * sizeof(float)));
             CREATE_TRY(hipMemcpy(v->d_a_frag, plan.a_frag.data(), plan.a_frag.size() * sizeof(float), hipMemcpyHostToDevice));
             v->a_bytes += (int64_t)(plan.a_frag.size() * sizeof(float));    // the device image holds the one-tile part of A twice (two layouts)
-        }
-        if (!plan.steps_k64.empty()) {
-            std::vector<StepRec>& k = plan.steps_k64;
-            v->n_steps_k64 = (int64_t)k.size();
-            for (int q = 0; q < 32; q++) { StepRec d = k[(size_t)v->n_steps_k64 - 1]; d.mt_flags = (d.mt_flags & ~(STEP_LAST | STEP_SPLIT)) | STEP_FIRST; k.push_back(d); }
-            CREATE_TRY(hipMalloc((void**)&v->d_steps_k64, k.size() * sizeof(StepRec)));
-            CREATE_TRY(hipMemcpy(v->d_steps_k64, k.data(), k.size() * sizeof(StepRec), hipMemcpyHostToDevice));
-            CREATE_TRY(hipMalloc((void**)&v->d_wrange_k64, plan.wrange_k64.size() * sizeof(int32_t)));
-            CREATE_TRY(hipMemcpy(v->d_wrange_k64, plan.wrange_k64.data(), plan.wrange_k64.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
         if (!fix.empty()) {
             CREATE_TRY(hipMalloc((void**)&v->d_fix, fix.size() * sizeof(FixRec)));
@@ -930,15 +918,10 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                     if (A->n_steps[ty] == 0) continue;
                     sp.steps = shard_rows > 0 ? A->d_steps_g[ty] : A->d_steps[ty]; sp.worker_range = A->d_wrange[ty]; sp.c_nt = c_store_nt(A, ty, sp.C, sp.ldc, sp.c_row_major != 0);
                     sp.clk = (prof && ty == probe_ty) ? A->d_clk : nullptr;
-                    if (A->pair_plan) launch_f32_pair(b_layout == SPARTA_ROW_MAJOR, shard_rows > 0, grid, st, sp);
-                    else if (ty == 0 && A->d_a_frag && b_layout == SPARTA_COL_MAJOR && shard_rows == 0) {
-                        StreamParams sd = sp;                 // the <= 32-row tiles without the LDS stage
+                    if (ty == 0 && A->d_a_frag && b_layout == SPARTA_COL_MAJOR && shard_rows == 0) {
+                        StreamParams sd = sp;                 // the <= 32-row tiles without the workgroup stage
                         sd.A = A->d_a_frag;
                         launch_f32_direct(grid, st, sd);
-                    } else if (ty == 0 && A->d_steps_k64 && b_layout == SPARTA_COL_MAJOR && shard_rows == 0) {
-                        StreamParams sk = sp;                 // the <= 32-row tiles as 64-deep steps
-                        sk.steps = A->d_steps_k64; sk.worker_range = A->d_wrange_k64;
-                        launch_f32_k64(grid, st, sk);
                     } else launch_f32_stream(ty != 0, b_layout == SPARTA_ROW_MAJOR, shard_rows > 0, grid, st, sp);
                 }
                 if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }

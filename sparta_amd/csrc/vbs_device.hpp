@@ -66,8 +66,6 @@ constexpr int SK_TM = 64;                 // max rows of a tile
 constexpr int32_t STEP_FIRST = 1 << 16;   // first step of a (segment of a) tile: accumulators start at zero
 constexpr int32_t STEP_LAST = 1 << 17;    // last step of a (segment of a) tile: run the epilogue
 constexpr int32_t STEP_SPLIT = 1 << 18;   // the tile is shared with another worker: epilogue goes to the workspace
-constexpr int32_t STEP_HAS0 = 1 << 20;    // pair plan: the upper half (rows 0..31 of the pair) has a block in this step
-constexpr int32_t STEP_HAS1 = 1 << 21;    // pair plan: the lower half (rows 32..63) has one
 constexpr int32_t STEP_TAIL = 1 << 19;    // panel of the zero-padded last block column: read from StreamParams::B_tail, b_row = k offset in it
 constexpr int SK_SLOT_FLOATS = 32 * kThreads;   // one partial accumulator image: 32 registers x 256 threads
 
@@ -186,10 +184,6 @@ struct sparta_vbs {
     int32_t n_big_fix = 0;
     void* d_ws = nullptr;
     size_t d_ws_bytes = 0;
-    bool pair_plan = false;                // fp32: d_steps[0] holds the pair plan (one launch of vbs_spmm_f32_pair_kernel)
-    sparta_dev::StepRec* d_steps_k64 = nullptr;   // 64-deep step list of the <= 32-row tiles (column-major, non-gathered B) or nullptr
-    int32_t* d_wrange_k64 = nullptr;
-    int64_t n_steps_k64 = 0;
     int64_t n_plan_tiles[2] = {0, 0};             // see StreamPlanHost
     bool tiles_row_aligned[2] = {true, true};
     float* d_a_frag = nullptr;                    // A of the one-tile plan in fragment order (k_f32_direct.hip) or nullptr
@@ -236,9 +230,7 @@ void launch_f32_exact(unsigned n_brows, hipStream_t st, const BlockRowDesc* rows
                       int64_t shard_stride);
 // k_f32_stream.hip
 void launch_f32_stream(bool mi2, bool b_row_major, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
-void launch_f32_pair(bool b_row_major, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
 void launch_f32_direct(dim3 grid, hipStream_t st, const StreamParams& sp);
-void launch_f32_k64(dim3 grid, hipStream_t st, const StreamParams& sp);
 void launch_fixup_group(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* big, const int32_t* fix_slots, float* ws_all, int64_t ws_slab_stride);
 void launch_fixup(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* fix_slots, const float* ws_all, int64_t ws_slab_stride, float* C, int64_t ldc,
                   int c_row_major, int accumulate);
@@ -273,9 +265,6 @@ struct StreamPlanHost {
     int n_workers = 0, n_split = 0;
     int plan_aligned[2] = {0, 0};
     int64_t kp = SK_KP;
-    bool pair_plan = false;                   // fp32: steps[0] is the pair plan (vbs_plan.cpp, build_pair_plan), steps[1] is empty
-    std::vector<StepRec> steps_k64;           // fp32, aligned one-tile plan, cols % w == 0: the same tiles as 64-deep steps (vbs_spmm_f32_k64_kernel)
-    std::vector<int32_t> wrange_k64;
     int64_t n_plan_tiles[2] = {0, 0};         // tiles (with at least one block) per plan: steps per tile decides the cache policy of the C stores
     bool tiles_row_aligned[2] = {true, true}; // every tile of the plan starts at a multiple of 32 rows of C (whole 128-byte lines of a column-major C)
     std::vector<float> a_frag;                // fp32 one-tile plan: A per step in MFMA fragment order (vbs_spmm_f32_direct_kernel), or empty

@@ -21,272 +21,10 @@ uint16_t to_h16(float v, bool bf16) {
     return o;
 }
 
-// =====================================================================================================================
-// Pair plan (fp32 handles): ONE step list, ONE launch of vbs_spmm_f32_pair_kernel for every MFMA tile of the handle.
-//
-// A 32-row tile x 128 columns of C is bound by the load path, not by MFMA: every (tile, block) pair stages its own 16 KB
-// panel of B for 2 x 32 x 32 x 128 flop.  Two vertically adjacent tiles (consecutive block-rows of a clustered matrix) share
-// most of their block columns (FEM: ~3/4), so they are walked TOGETHER as one 64-row "pair": the steps of the pair are the
-// union of the two tiles' steps in ascending block-column order; a step carries HAS0 / HAS1 -- which half has a block there.
-// The panel is staged once per step and feeds both halves when both are present (half the L2 -> LDS traffic, half the LDS
-// writes and half the barriers per flop); a half without a block loads nothing (zero-sized buffer range) and its MFMAs are
-// skipped by a scalar branch, so no flop is executed that the two separate tiles would not execute.  A tile of 33..64 rows
-// of ONE block-row is the special case "both halves always present, same block-row"; a tile that finds no partner is a pair
-// whose lower half never is.  Pairs are formed inside a worker's range, from its start: worker boundaries stay at single-tile
-// granularity.
-//
-// Record = StepRec with these meanings (see the kernel): a_off = offset of the UPPER half's slice for this step, slot =
-// (offset of the LOWER half's slice) - a_off, h = h_upper | h_lower << 16 (leading dimensions of the two A blocks), c_row =
-// first row of C of the pair -- or, on a STEP_LAST | STEP_SPLIT record, the workspace slot --, mt_flags = rows of the pair
-// (32 + rows of the lower half, or the rows of a lone upper half) | STEP_* | STEP_HAS0 | STEP_HAS1, pad = slab (gathered B).
-// =====================================================================================================================
-namespace {
-
-struct PTile {                 // one <= 32-row piece: a whole tile of <= 32 rows, or the upper / lower half of a 33..64-row tile
-    int64_t a_off;             // offset into A of (row 0 of the piece, first k of the block-row's first block)
-    int64_t jab0;              // index into jab of the block-row's first block
-    int32_t nb, h, c_row, mt;
-    int32_t lower_of_prev;     // 1: this piece is rows 32.. of the SAME block-row as the previous piece (always paired with it)
-    int32_t tail;              // the block-row's last block lies in the zero-padded last block column
-};
-
-}  // namespace
-
-static int build_pair_plan(const StreamPlanIn& in, StreamPlanHost& P, int n_workers, int per_x, int c2, int c1, int ct, int64_t split_penalty,
-                           int align_mode) {
-    using sparta::fail;
-    const int64_t cols = in.cols, w = in.w, br0 = in.br0, br1 = in.br1, jab_lo = in.jab_lo;
-    const int64_t* row_part = in.row_part; const int64_t* nzcount = in.nzcount; const int64_t* jab = in.jab;
-    const int64_t spb = w / SK_KP;                     // steps per block
-    const int64_t block_cols = (cols - 1) / w + 1;
-    std::vector<StepRec>& st = P.steps[0];
-    std::vector<FixRec>& fix = P.fix;
-    std::vector<int32_t>& fix_slots = P.fix_slots;
-
-    // ---- pieces, in matrix order ----
-    std::vector<PTile> tiles;
-    {
-        int64_t jo2 = 0, mo2 = 0;
-        const int64_t row0 = row_part[br0];
-        for (int64_t ib = br0; ib < br1; ib++) {
-            const int64_t h = row_part[ib + 1] - row_part[ib], nb = nzcount[ib];
-            const bool skipped = in.skip && in.skip[ib - br0];
-            const bool zero_range = nb == 0 && !skipped && h >= kZeroRangeRows;
-            if (zero_range) P.zero_ranges.emplace_back(row_part[ib] - row0, h);
-            for (int64_t r0 = 0; r0 < h && !skipped && !zero_range; r0 += SK_TM) {
-                const int32_t mt = (int32_t)std::min<int64_t>(SK_TM, h - r0);
-                const int32_t c_row = (int32_t)(row_part[ib] - row0 + r0);
-                if (nb == 0) { fix.push_back(FixRec{c_row, mt, 0, 0}); continue; }       // nothing to multiply: the fix-up kernel writes the zeros
-                if (h > 65535) return 1;                                                   // h_upper | h_lower << 16 cannot hold it: legacy plans
-                if (nb * h * w * 4 >= (int64_t(1) << 30)) return 1;                        // the kernel walks a block-row's slices with a 32-bit byte offset
-                const int32_t tail = (cols % w != 0) && jab[jab_lo + jo2 + nb - 1] == block_cols - 1;
-                tiles.push_back(PTile{mo2 + r0, jo2, (int32_t)nb, (int32_t)h, c_row, std::min(mt, 32), 0, tail});
-                if (mt > 32) tiles.push_back(PTile{mo2 + r0 + 32, jo2, (int32_t)nb, (int32_t)h, c_row + 32, mt - 32, 1, tail});
-            }
-            jo2 += nb;
-            mo2 += nb * h * w;
-        }
-    }
-    if (tiles.empty()) return SPARTA_OK;
-    const size_t T = tiles.size();
-    auto n_steps_of = [&](const PTile& t) { return (int64_t)t.nb * spb; };
-    auto key_of = [&](const PTile& t, int64_t s) { return jab[jab_lo + t.jab0 + s / spb] * w + (s % spb) * SK_KP; };
-    // may piece t+1 be the lower half of a pair whose upper half is piece t?
-    const bool no_pairs = [] { const char* e = std::getenv("SPARTA_PAIR_MODE"); return e && atoi(e) == 0; }();   // developer switch: every piece on its own
-    auto pairable = [&](size_t t) {
-        if (t + 1 >= T) return false;
-        if (no_pairs && !tiles[t + 1].lower_of_prev) return false;
-        const PTile& a = tiles[t]; const PTile& b = tiles[t + 1];
-        if (a.lower_of_prev) return false;                               // a lower half never starts a pair
-        if (b.lower_of_prev) return true;                                // the two halves of one tall tile
-        if (a.mt != 32 || b.c_row != a.c_row + 32) return false;         // the accumulator image is a 64-row tile: rows 32.. must be C rows c_row + 32 ..
-        const int64_t d = b.a_off - a.a_off;                             // grows by at most nb * 32 * h while the cursors advance: keep a wide margin
-        return d > -(int64_t(1) << 30) && d < (int64_t(1) << 30);
-    };
-    // cost and step count of the unit that starts at piece t (pair = true: pieces t, t+1)
-    auto unit_cost = [&](size_t t, bool pair, int64_t* n_out) {
-        const PTile& a = tiles[t];
-        int64_t both = 0, half = 0;
-        if (!pair) half = n_steps_of(a);
-        else {
-            const PTile& b = tiles[t + 1];
-            const int64_t na = n_steps_of(a), nb_ = n_steps_of(b);
-            int64_t i = 0, j = 0;
-            while (i < na || j < nb_) {
-                const int64_t ka = i < na ? key_of(a, i) : INT64_MAX, kb = j < nb_ ? key_of(b, j) : INT64_MAX;
-                if (ka == kb) { both++; i++; j++; } else if (ka < kb) { half++; i++; } else { half++; j++; }
-            }
-        }
-        if (n_out) *n_out = both + half;
-        return both * c2 + half * c1 + ct;
-    };
-    // lower halves of tall tiles must stay with their upper half: a range may not start at one
-    // ---- units (pairs formed greedily from `from`) and their cumulative cost, for a candidate range start ----
-    struct Unit { size_t t; bool pair; int64_t cost, n; };
-    auto units_from = [&](size_t from, size_t to, std::vector<Unit>& out) {
-        for (size_t t = from; t < to;) {
-            const bool pr = t + 1 < to && pairable(t);
-            int64_t n = 0;
-            const int64_t c = unit_cost(t, pr, &n);
-            out.push_back(Unit{t, pr, c, n});
-            t += pr ? 2 : 1;
-        }
-    };
-    std::vector<Unit> all_units;
-    units_from(0, T, all_units);
-    int64_t total_cost = 0, max_unit = 0;
-    for (const Unit& u : all_units) { total_cost += u.cost; max_unit = std::max(max_unit, u.cost); }
-
-    // ---- aligned plan: contiguous ranges of pieces, pairs formed from each range's start; smallest makespan by bisection ----
-    // greedy(L): extend the current range unit by unit while its cost stays <= L; a pair that does not fit is tried as a lone
-    // upper piece (unless its lower piece belongs to the same tall tile) before the range is closed.
-    std::vector<size_t> cut;                         // piece index where worker k's range starts; cut[n_workers] = T
-    auto greedy = [&](int64_t L, std::vector<size_t>* cuts) -> int64_t {
-        int64_t bins = 1, cur = 0;
-        if (cuts) { cuts->clear(); cuts->push_back(0); }
-        for (size_t t = 0; t < T;) {
-            bool pr = pairable(t);
-            int64_t c = unit_cost(t, pr, nullptr);
-            if (cur > 0 && cur + c > L) {
-                bool placed = false;
-                if (pr && !tiles[t + 1].lower_of_prev) {           // try the upper piece alone; the lower one opens the next range
-                    const int64_t c1only = unit_cost(t, false, nullptr);
-                    if (cur + c1only <= L) { cur += c1only; t += 1; placed = true; }
-                }
-                bins++; cur = 0;
-                if (cuts) cuts->push_back(t);
-                if (placed) continue;
-                pr = pairable(t);
-                c = unit_cost(t, pr, nullptr);
-            }
-            cur += c;
-            t += pr ? 2 : 1;
-        }
-        return bins;
-    };
-    int64_t lo = max_unit, hi = total_cost + ct;
-    while (lo < hi) {
-        const int64_t mid = lo + (hi - lo) / 2;
-        if (greedy(mid, nullptr) <= n_workers) hi = mid; else lo = mid + 1;
-    }
-    const int64_t split_makespan = (total_cost + n_workers - 1) / n_workers + split_penalty;
-    const bool aligned = align_mode == 1 || (align_mode < 0 && lo <= split_makespan);
-    P.plan_aligned[0] = aligned ? 1 : 0;
-
-    // ---- emit the step records ----
-    struct Span { int64_t first, last; int32_t c_row, mt; };
-    std::vector<Span> spans;
-    std::vector<int64_t> cum;                        // cumulative cost BEFORE step s (split plan)
-    int64_t run_cost = 0;
-    auto emit_unit = [&](const Unit& u) {
-        const PTile& a = tiles[u.t];
-        const PTile* b = u.pair ? &tiles[u.t + 1] : nullptr;
-        const int64_t na = n_steps_of(a), nb_ = b ? n_steps_of(*b) : 0;
-        const int32_t mt = b ? 32 + b->mt : a.mt;
-        const int32_t h01 = (int32_t)((uint32_t)a.h | ((uint32_t)(b ? b->h : a.h) << 16));
-        Span sp{(int64_t)st.size(), 0, a.c_row, mt};
-        int64_t i = 0, j = 0;
-        while (i < na || j < nb_) {
-            const int64_t ka = i < na ? key_of(a, i) : INT64_MAX, kb = j < nb_ ? key_of(*b, j) : INT64_MAX;
-            const bool h0 = ka <= kb, h1 = kb <= ka;
-            const int64_t key = h0 ? ka : kb;
-            StepRec r;
-            const int64_t off0 = a.a_off + i * SK_KP * (int64_t)a.h;
-            const int64_t off1 = b ? b->a_off + j * SK_KP * (int64_t)b->h : off0;
-            r.a_off = off0;
-            r.slot = (int32_t)(off1 - off0);
-            r.b_row = (int32_t)key;
-            r.h = h01;
-            r.c_row = a.c_row;
-            r.mt_flags = mt | (h0 ? STEP_HAS0 : 0) | (h1 && b ? STEP_HAS1 : 0);
-            const bool is_tail = (cols % w != 0) && key / w == block_cols - 1;
-            if (is_tail) { r.mt_flags |= STEP_TAIL; r.b_row = (int32_t)(key % w); }       // read from the zero-padded B_tail
-            r.pad = 0;
-            cum.push_back(run_cost);
-            run_cost += (h0 && h1 && b) ? c2 : c1;
-            st.push_back(r);
-            if (h0) i++;
-            if (h1) j++;
-        }
-        run_cost += ct;
-        sp.last = (int64_t)st.size() - 1;
-        spans.push_back(sp);
-    };
-    std::vector<int64_t> bnd((size_t)n_workers + 1, 0);        // step index where worker position k starts
-    if (aligned) {
-        std::vector<size_t> cuts;
-        greedy(lo, &cuts);
-        cuts.resize((size_t)n_workers + 1, T);
-        cuts[(size_t)n_workers] = T;
-        for (int k = 0; k < n_workers; k++) {
-            bnd[(size_t)k] = (int64_t)st.size();
-            std::vector<Unit> us;
-            units_from(cuts[(size_t)k], cuts[(size_t)k + 1], us);
-            for (const Unit& u : us) emit_unit(u);
-        }
-        bnd[(size_t)n_workers] = (int64_t)st.size();
-    } else {
-        for (const Unit& u : all_units) emit_unit(u);
-        cum.push_back(run_cost);
-        const int64_t S = (int64_t)st.size();
-        bnd[(size_t)n_workers] = S;
-        for (int k = 1; k < n_workers; k++) {
-            const int64_t target = run_cost * k / n_workers;
-            int64_t pos = std::lower_bound(cum.begin(), cum.end(), target) - cum.begin();
-            bnd[(size_t)k] = std::min<int64_t>(std::max(pos, bnd[(size_t)k - 1]), S);
-        }
-    }
-    if (const char* e = std::getenv("SPARTA_PLAN_DEBUG")) {
-        if (atoi(e)) {
-            int64_t both = 0, half = 0, pairs = 0, singles = 0, wmax = 0, wsum = 0;
-            for (const StepRec& r : st) { if ((r.mt_flags & STEP_HAS0) && (r.mt_flags & STEP_HAS1)) both++; else half++; }
-            for (const Span& sp : spans) { if (sp.mt > 32) pairs++; else singles++; }
-            for (int k = 0; k < n_workers; k++) {
-                int64_t c = 0;
-                for (int64_t q = bnd[(size_t)k]; q < bnd[(size_t)k + 1]; q++)
-                    c += ((st[(size_t)q].mt_flags & STEP_HAS0) && (st[(size_t)q].mt_flags & STEP_HAS1)) ? c2 : c1;
-                wmax = std::max(wmax, c); wsum += c;
-            }
-            fprintf(stderr, "[pair plan] pieces %zu units: %lld pairs + %lld singles; steps: %lld both + %lld half; aligned %d; worker step cost max %lld mean %.1f (c2 %d c1 %d)\n",
-                    T, (long long)pairs, (long long)singles, (long long)both, (long long)half, (int)aligned, (long long)wmax, (double)wsum / n_workers, c2, c1);
-        }
-    }
-    if ((int64_t)st.size() > INT32_MAX - 64) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: matrix too large for 32-bit step indexing");
-    for (const Span& sp : spans) { st[(size_t)sp.first].mt_flags |= STEP_FIRST; st[(size_t)sp.last].mt_flags |= STEP_LAST; }
-
-    // ---- worker ranges (position -> workgroup id: XCD x owns positions [x * per_x, (x + 1) * per_x)) and split segments ----
-    P.wrange[0].assign((size_t)n_workers * 2, 0);
-    for (int pos = 0; pos < n_workers; pos++) {
-        const int x = pos / per_x, j = pos % per_x;
-        const int wid = x + 8 * j;
-        P.wrange[0][(size_t)wid * 2] = (int32_t)bnd[(size_t)pos];
-        P.wrange[0][(size_t)wid * 2 + 1] = (int32_t)bnd[(size_t)pos + 1];
-    }
-    size_t ti = 0;
-    for (int pos = 0; pos < n_workers; pos++) {
-        const int64_t s0 = bnd[(size_t)pos], s1 = bnd[(size_t)pos + 1];
-        if (s0 >= s1) continue;
-        while (ti < spans.size() && spans[ti].last < s0) ti++;
-        for (size_t t = ti; t < spans.size() && spans[t].first < s1; t++) {
-            const int64_t a = std::max(spans[t].first, s0), b = std::min(spans[t].last, s1 - 1);
-            const bool whole = a == spans[t].first && b == spans[t].last;
-            st[(size_t)a].mt_flags |= STEP_FIRST;
-            st[(size_t)b].mt_flags |= STEP_LAST;
-            if (!whole) {
-                const int32_t slot = (int32_t)fix_slots.size();
-                st[(size_t)b].mt_flags |= STEP_SPLIT;
-                st[(size_t)b].c_row = slot;                            // a split segment's epilogue needs the slot, not the C row
-                if (a == spans[t].first) {
-                    fix.push_back(FixRec{spans[t].c_row, spans[t].mt, (int32_t)fix_slots.size(), 0});
-                    P.n_split++;
-                }
-                fix_slots.push_back(slot);
-                fix.back().n_slots++;
-            }
-        }
-    }
-    return SPARTA_OK;
-}
+// (Round 2 also built a "pair plan" + vbs_spmm_f32_pair_kernel -- two vertically adjacent 32-row tiles walked as one 64-row pair that shares
+// the B panel of a step -- and a 64-deep variant of the one-tile kernel.  Both measured slower than the kernels that stayed (62.3 and 65.6 us
+// against 58.1 on the flagship) and were removed once the no-barrier kernel (k_f32_direct.hip) took over; they are in
+// the history of this file and of k_f32_stream.hip.)
 
 int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
     using sparta::fail;
@@ -337,24 +75,6 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
         if (const char* e = std::getenv("SPARTA_STREAM_ALIGN")) align_mode = atoi(e) ? 1 : 0;
         if ((int64_t)cols > INT32_MAX)
             return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: matrix too large for 32-bit step indexing");
-        // fp32 handles: SPARTA_F32_PLAN=pair selects the pair plan (one list, one launch); default: the two per-type plans
-        {
-            const char* pe = std::getenv("SPARTA_F32_PLAN");
-            const bool legacy = !(pe && std::strcmp(pe, "pair") == 0);     // the pair kernel is opt-in until it beats the per-type kernels
-            if (!h16 && !legacy) {
-                StreamPlanHost Q;
-                Q.n_workers = n_workers;
-                const int rc = build_pair_plan(in, Q, n_workers, n_workers / 8, c2, c1, ct, split_penalty, align_mode);
-                if (rc < 0) return rc;
-                if (rc == SPARTA_OK) {
-                    P.steps[0].swap(Q.steps[0]); P.wrange[0].swap(Q.wrange[0]); P.fix.swap(Q.fix); P.fix_slots.swap(Q.fix_slots);
-                    P.zero_ranges.swap(Q.zero_ranges); P.n_split = Q.n_split; P.plan_aligned[0] = Q.plan_aligned[0];
-                    P.pair_plan = true;
-                    return SPARTA_OK;
-                }
-                // rc == 1: a block-row taller than 65535 rows -- the two per-type plans below
-            }
-        }
         for (int ty = 0; ty < 2; ty++) {
             std::vector<StepRec>& st = steps[ty];
             struct TileSpan { int64_t first, last; int32_t c_row, mt; };     // step range of a tile
@@ -583,7 +303,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             {
                 const char* de = std::getenv("SPARTA_F32_PLAN");
                 const bool off = de && std::strcmp(de, "legacy") == 0;         // SPARTA_F32_PLAN=legacy: the LDS-staged kernel for every call
-                if (!off && ty == 0 && !h16 && !P.pair_plan && S <= ((int64_t)2 << 20)) {   // <= 8 GiB of slices (a second copy of the one-tile part of A)
+                if (!off && ty == 0 && !h16 && S <= ((int64_t)2 << 20)) {   // <= 8 GiB of slices (a second copy of the one-tile part of A)
                     std::vector<float>& af = P.a_frag;
                     af.assign(((size_t)S + 4) * 1024, 0.0f);                    // + 4: the pipeline requests three steps past a range end
                     for (int64_t q = 0; q < S; q++) {
@@ -595,43 +315,6 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                             for (int g = 0; g < 2; g++)
                                 for (int64_t m = 0; m < mt; m++)
                                     for (int e = 0; e < 4; e++) dst[((j * 2 + g) * 32 + m) * 4 + e] = blk[(int64_t)(16 * g + 4 * j + e) * hh + m];
-                    }
-                }
-            }
-            // ---- the same one-tile plan as 64-deep steps (vbs_spmm_f32_k64_kernel): fp32, no zero-padded tail block column, and an
-            // aligned plan (no split tile: the 64-deep kernel has no workspace epilogue).  A tile's 64-deep steps are its 32-deep steps
-            // taken two at a time (A is contiguous across consecutive steps; the two B panels are named separately); a tile with an odd
-            // count ends in a step whose second half is absent (slot = -1).
-            {
-                const char* ke = std::getenv("SPARTA_F32_K64");
-                const bool want = ke && atoi(ke) != 0;     // opt-in: measured SLOWER than the 32-deep kernel on the flagship (65.6 vs 58.1 us) -- what bounds these tiles is bytes per flop, not steps
-                if (want && ty == 0 && !h16 && plan_aligned[0] && cols % w == 0 && !P.pair_plan) {
-                    std::vector<StepRec>& k = P.steps_k64;
-                    std::vector<int64_t> kb((size_t)n_workers + 1, 0);
-                    size_t t = 0;
-                    for (int pos = 0; pos < n_workers; pos++) {
-                        kb[(size_t)pos] = (int64_t)k.size();
-                        const int64_t s0 = bnd[(size_t)pos], s1 = bnd[(size_t)pos + 1];
-                        while (t < spans.size() && spans[t].first < s1) {
-                            if (spans[t].first < s0) { t++; continue; }
-                            const TileSpan& sp = spans[t];
-                            for (int64_t q = sp.first; q <= sp.last; q += 2) {
-                                StepRec r = st[(size_t)q];
-                                r.mt_flags &= ~(STEP_FIRST | STEP_LAST | STEP_SPLIT);
-                                r.slot = q + 1 <= sp.last ? st[(size_t)q + 1].b_row : -1;
-                                if (q == sp.first) r.mt_flags |= STEP_FIRST;
-                                if (q + 2 > sp.last) r.mt_flags |= STEP_LAST;
-                                k.push_back(r);
-                            }
-                            t++;
-                        }
-                    }
-                    kb[(size_t)n_workers] = (int64_t)k.size();
-                    P.wrange_k64.assign((size_t)n_workers * 2, 0);
-                    for (int pos = 0; pos < n_workers; pos++) {
-                        const int wid = wid_of_pos[(size_t)pos];
-                        P.wrange_k64[(size_t)wid * 2] = (int32_t)kb[(size_t)pos];
-                        P.wrange_k64[(size_t)wid * 2 + 1] = (int32_t)kb[(size_t)pos + 1];
                     }
                 }
             }

@@ -87,7 +87,7 @@ def _product(torch, d, B, ldb, n, fill=None):
 def test_config1_flagship_blocking_every_row_against_the_oracle():
     """configs[1] exactly as bench.py runs it: cant-like 62 451^2, Keeper tau 0.6, 32-row blocks (-a 5 -B 32 -F 1), w = 32, N = 128 fp32,
     column-major B and C: EVERY element of C against the oracle's VBR::multiply within 1e-5 * sum|a||b|, for the product kernel the
-    library picks and for each fp32 plan it can be told to use; the exact-order kernel bit for bit."""
+    library picks (no-barrier) and for the LDS-staged one it can be told to use; the exact-order kernel bit for bit."""
     import os
     torch = _torch()
     m = sa.gen.cant_like(seed=2)
@@ -102,7 +102,7 @@ def test_config1_flagship_blocking_every_row_against_the_oracle():
     B = torch.from_numpy(Bh).cuda()
     saved = os.environ.get("SPARTA_F32_PLAN")
     try:
-        for plan in (None, "legacy", "pair", "direct"):
+        for plan in (None, "legacy"):
             if plan is None:
                 os.environ.pop("SPARTA_F32_PLAN", None)
             else:
