@@ -57,3 +57,54 @@ def test_stream_kernels_keep_their_state_in_registers(tmp_path):
         else:                                                             # fp32: 2 stages x (B panel [+4 pad when column-major] + 32 x 64 A slice) floats
             want = {2 * (128 * 36 + 32 * 64) * 4, 2 * (32 * 128 + 32 * 64) * 4}
         assert m["group_segment_fixed_size"] in want, (name, m, want)
+
+
+def _disassemble(tmp_path):
+    """text of llvm-objdump -d for every gfx950 code object in the library, split per kernel symbol"""
+    lib = os.path.join(ROOT, "sparta_amd", "libsparta_amd.so")
+    tools = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not os.path.exists(lib) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("library or LLVM binutils not available")
+    fat = str(tmp_path / "fat.bin")
+    subprocess.run([tools[0], "--dump-section", ".hip_fatbin=" + fat, lib], check=True)
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    kernels = {}
+    for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+        piece, co = str(tmp_path / ("dbundle%d.bin" % n)), str(tmp_path / ("ddev%d.co" % n))
+        open(piece, "wb").write(blob[a:b])
+        subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + piece, "--output=" + co], check=True)
+        txt = subprocess.run([tools[2], "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+        for block in re.split(r"\n(?=[0-9a-f]+ <[^>]+>:)", txt):
+            m = re.match(r"[0-9a-f]+ <([^>]+)>:", block)
+            if m and not m.group(1).startswith((".", "$")) and "LBB" not in m.group(1):
+                kernels[m.group(1)] = kernels.get(m.group(1), "") + block
+    return kernels
+
+
+def test_steady_state_of_the_one_tile_kernels_keeps_its_prefetch_and_its_valu_budget(tmp_path):
+    """what cost these kernels their speed in the past shows in the ISA: a full `s_waitcnt vmcnt(0)` in the step (the
+    prefetch distance is gone), accumulators or in-flight registers copied with `v_mov` at a join, pipeline state in scratch.  Pinned for the
+    fp32 and 16-bit no-barrier kernels of the flagship shape: full waits only where the source has them (the C += path of the epilogue and the
+    window swap), register moves within the epilogue's budget, step waits that leave the loads of the following steps in flight."""
+    ks = _disassemble(tmp_path)
+    f32 = [t for n, t in ks.items() if "vbs_spmm_f32_direct_kernel" in n]
+    h16 = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n]
+    assert len(f32) == 1 and len(h16) >= 4, sorted(ks)[:8]
+    for txt, n_mfma_step, loads_per_step in [(f32[0], 16, 8)] + [(t, 2, 4) for t in h16]:
+        ins = [l.split("//")[0].strip() for l in txt.splitlines() if l.startswith(("\t", " "))]
+        ins = [i for i in ins if i]
+        assert not any(i.startswith("scratch_") for i in ins)
+        n_mfma = sum(i.startswith("v_mfma") for i in ins)
+        steps = n_mfma / n_mfma_step                                   # unrolled step bodies in the kernel (loop of 4 + up to 3 peeled + prologue pieces)
+        assert 7 <= steps <= 12, steps
+        # register moves: 16 copies + 16 clears per epilogue body (v_mov_b64 counts two), nothing per step
+        n_mov = sum(2 if i.startswith("v_mov_b64") else 1 for i in ins if i.startswith("v_mov_b"))
+        assert n_mov <= 32 * steps, (n_mov, steps)                    # (28 per body today)
+        # full waits: only in the epilogue bodies' C += path (one per body)
+        n_full = sum(bool(re.match(r"s_waitcnt vmcnt\(0\)", i)) for i in ins)
+        assert n_full <= 1.5 * steps, (n_full, steps)                 # (13 in 11 bodies today)
+        # the waits in front of the LDS writes of a step leave at least one step's loads in flight
+        waits = [int(m.group(1)) for i in ins for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", i)] if m]
+        assert sum(w >= loads_per_step for w in waits) >= 4 * steps, (waits, steps)
