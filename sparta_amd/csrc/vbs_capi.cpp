@@ -645,14 +645,15 @@ int sparta_vbs_clock_mhz(sparta_vbs_t* A, double* mhz_out) {
 namespace {
 
 // cache policy of a stream launch's C stores (vbs_kernel_common.hpp): non-temporal for long tiles; SPARTA_C_NT=0|1 forces one
-int32_t c_store_nt(const sparta_vbs_t* A, int ty, const float* C, int64_t ldc, bool c_row_major) {
+int32_t c_store_nt(const sparta_vbs_t* A, int ty, const float* C, int64_t ldc, bool c_row_major, bool ring = false) {
     if (const char* e = std::getenv("SPARTA_C_NT")) return atoi(e) != 0;
     if (A->n_plan_tiles[ty] <= 0) return 0;
     if (A->n_steps[ty] >= 6 * A->n_plan_tiles[ty]) return 1;                    // long tiles
     // short tiles: only when a store instruction writes whole, aligned 128-byte lines (32-row tiles starting at multiples of 32 rows of a
     // column-major C whose columns are 128-byte aligned) -- banded 200k in fixed 32-row tiles: 63 us default, 51 non-temporal; the same
     // matrix in tiles of 28 rows on average (misaligned pieces of lines): 67-71 default, 79 non-temporal
-    return !c_row_major && A->tiles_row_aligned[ty] && ldc % 32 == 0 && ((uintptr_t)C % 128) == 0;
+    // (`ring`: the no-barrier fp32 kernel parks tiles of arbitrary height in LDS and stores aligned blocks of 32 rows: banded 200k 51 us default, 45 non-temporal)
+    return !c_row_major && (A->tiles_row_aligned[ty] || ring) && ldc % 32 == 0 && ((uintptr_t)C % 128) == 0;
 }
 
 // long runs of rows without blocks, accumulate = 0: streamed zero fill (vbs_zero_rows_kernel), one launch per run
@@ -921,7 +922,11 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                     if (ty == 0 && A->d_a_frag && b_layout == SPARTA_COL_MAJOR && shard_rows == 0) {
                         StreamParams sd = sp;                 // the <= 32-row tiles without the workgroup stage
                         sd.A = A->d_a_frag;
-                        launch_f32_direct(grid, st, sd);
+                        // tiles of arbitrary height + column-major C: finished tiles wait in an LDS ring for whole aligned blocks of 32 rows (k_f32_direct.hip)
+                        const int cst = [] { const char* e = std::getenv("SPARTA_F32_CSTAGE"); return e ? atoi(e) : -1; }();     // (read per launch: tests flip it)
+                        const bool c_stage = c_layout == SPARTA_COL_MAJOR && (cst >= 0 ? cst != 0 : !A->tiles_row_aligned[0]);
+                        sd.c_nt = c_store_nt(A, ty, sd.C, sd.ldc, sd.c_row_major != 0, c_stage);
+                        launch_f32_direct(c_stage, grid, st, sd);
                     } else launch_f32_stream(ty != 0, b_layout == SPARTA_ROW_MAJOR, shard_rows > 0, grid, st, sp);
                 }
                 if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }

@@ -230,7 +230,7 @@ void launch_f32_exact(unsigned n_brows, hipStream_t st, const BlockRowDesc* rows
                       int64_t shard_stride);
 // k_f32_stream.hip
 void launch_f32_stream(bool mi2, bool b_row_major, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
-void launch_f32_direct(dim3 grid, hipStream_t st, const StreamParams& sp);
+void launch_f32_direct(bool c_stage, dim3 grid, hipStream_t st, const StreamParams& sp);
 void launch_fixup_group(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* big, const int32_t* fix_slots, float* ws_all, int64_t ws_slab_stride);
 void launch_fixup(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* fix_slots, const float* ws_all, int64_t ws_slab_stride, float* C, int64_t ldc,
                   int c_row_major, int accumulate);

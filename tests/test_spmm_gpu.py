@@ -1164,3 +1164,51 @@ def test_product_inside_a_graph_capture(monkeypatch, _sparse_row_mode):
     torch.cuda.synchronize()
     assert torch.equal(C_graph, C_eager)
     d.close()
+
+
+@pytest.mark.parametrize("align", ["aligned", "split"])
+@pytest.mark.parametrize("n", [128, 384])
+def test_tiles_parked_in_the_lds_ring_store_the_same_c(monkeypatch, _sparse_row_mode, align, n):
+    """fp32, column-major C, tiles of arbitrary height: the no-barrier kernel parks finished tiles in a wave-private LDS ring and stores aligned
+    blocks of 32 rows (k_f32_direct.hip, CSTAGE).  Same sums, other stores: C must be bit-identical to the direct-store form of the same kernel
+    (SPARTA_F32_CSTAGE=0) for whole-tile plans, within the tolerance for split plans, with and without accumulate, around gaps (empty block-rows, sparse rows, split tiles),
+    and equal to the oracle's."""
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_PATH", "stream")
+    monkeypatch.setenv("SPARTA_STREAM_ALIGN", "1" if align == "aligned" else "0")
+    rng = np.random.Generator(np.random.PCG64(123))
+    rows, cols, w = 3000, 2048 + 5, 32
+    rr, cc = [], []
+    for i in range(rows):                                     # a band with holes: runs of similar rows (tiles of 5..30 rows), every 40th row empty, a few scattered singletons
+        if i % 40 == 39:
+            continue
+        c0 = (i // 7) * 3 % (cols - 200)
+        c = np.unique(np.concatenate([c0 + rng.choice(160, 60, replace=False), rng.choice(cols, 1)]))
+        rr.append(np.full(len(c), i)); cc.append(c)
+    r, c = np.concatenate(rr), np.concatenate(cc)
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=rows))])
+    m = sa.CSR(rows, cols, rowptr, c.astype(np.int32), rng.uniform(-1, 1, len(c)).astype(np.float32))
+    g = sa.BlockingEngine(tau=0.6, col_block_size=w, blocking_algo=7, minhash_max_rows=32).GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    heights = np.diff(v.row_part)
+    assert len(np.unique(heights)) > 3 and np.any(np.cumsum(heights)[:-1] % 32 != 0)      # tiles of several heights, not all starting on multiples of 32
+    B = sa.gen.dense_rhs(v.cols, n, seed=51)
+    Bt = torch.from_numpy(B).cuda()
+    Co = _oracle_c(v, B, n)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+    got = {}
+    for ring in ("1", "0"):
+        monkeypatch.setenv("SPARTA_F32_CSTAGE", ring)          # read at create time (plan: contiguous ranges) and per process at the first launch
+        d = v.to_device(0)
+        for acc in (False, True):
+            C0 = sa.gen.dense_rhs(v.rows, n, seed=52)
+            Ct = torch.from_numpy(C0).cuda()
+            d.spmm(Bt, Ct, n, accumulate=acc)
+            torch.cuda.synchronize()
+            got[(ring, acc)] = Ct.cpu().numpy()
+            want = _oracle_c(v, B, n, C0) if acc else Co
+            _check(got[(ring, acc)], want, bound + (np.abs(C0) if acc else 0), "ring %s acc %d" % (ring, acc))
+        d.close()
+    if align == "aligned":                                    # whole tiles: the same sums in the same order, whatever the stores do
+        for acc in (False, True):
+            assert np.array_equal(got[("1", acc)], got[("0", acc)])
