@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import sparta_amd as sa
 
+os.environ["SPARTA_SPARSE_MIN_STEPS"] = "0"          # small matrices: let the sparse-row path take the nearly empty block-rows whatever they are worth
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 1))
 bad = 0
@@ -61,6 +62,25 @@ for case in range(n_cases):
                     bad += 1
                     print("MISMATCH case", case, dict(rows=rows, cols=cols, nnz=nnz, w=w, n=n, kind=kind, path=path, align=align, acc=acc, sparse_k=spk),
                           "max err", float(err.max()), "last_path", d2.info()["last_path"])
+    # handles made straight from the CSR with the per-block split (tiles + sparse rows that add to them on the same block-rows): tolerance
+    for kb in ("1", "4", None):
+        os.environ.pop("SPARTA_SPARSE_K", None)
+        if kb is None:
+            os.environ.pop("SPARTA_SPARSE_K_BLOCK", None)
+        else:
+            os.environ["SPARTA_SPARSE_K_BLOCK"] = kb
+        os.environ["SPARTA_PATH"] = "auto"
+        os.environ.pop("SPARTA_STREAM_ALIGN", None)
+        d3 = sa.DeviceVBS.from_csr(m, g, w, device=0)
+        for acc in (False, True):
+            C = torch.full_like(Ce, 2.0)
+            d3.spmm(B, C, n, accumulate=acc)
+            torch.cuda.synchronize()
+            err = (C - (Ce + (2.0 if acc else 0.0))).abs()
+            if bool((err > tol + (1e-6 if acc else 0.0)).any()):
+                bad += 1
+                print("MISMATCH (per-block split) case", case, dict(rows=rows, cols=cols, nnz=nnz, w=w, n=n, kind=kind, kblock=kb, acc=acc), "max err", float(err.max()), d3.sparse_info())
+    os.environ["SPARTA_SPARSE_K_BLOCK"] = "1e30"         # whole-block-row decisions only from here on: the two builders must agree
     # handles made straight from the CSR (nearly empty block-rows never expanded) must reproduce the two-step handle bit for bit
     for spk in (None, "1e9"):
         if spk is None:
