@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--dist-path", action="store_true", help="run the multi-GPU code path even with one rank")
     ap.add_argument("--check-rows", type=int, default=64, help="rmat / ogbn-like: rows of C checked against a float64 evaluation before timing")
     args = ap.parse_args()
+    if os.environ.get("SPARTA_BENCH_WATCHDOG"):               # developer aid: dump every thread's Python stack and exit if the run takes longer than this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SPARTA_BENCH_WATCHDOG"]), exit=True)
 
     import torch
     import sparta_amd as sa
@@ -420,8 +423,13 @@ def main():
             got = Cv[:, int(r)].cpu().numpy().astype(np.float64)
             worst = max(worst, float((np.abs(got - want) / scale_).max()))
         check = {"rows": int(len(pick)), "max_err_over_sum_abs": worst, "tolerance": 1e-5}
-        if not (worst <= 1e-5):
-            raise SystemExit("rank %d: parity spot check failed: %.3e of sum|a||b| (tolerance 1e-5)" % (rank, worst))
+        worst_all = worst
+        if distributed:                                      # every rank learns the verdict: a rank that left alone would strand its peers in the next collective
+            tw = torch.tensor([worst if np.isfinite(worst) else 1e30], dtype=torch.float64, device=dev)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            worst_all = float(tw.item())
+        if not (worst_all <= 1e-5):
+            raise SystemExit("rank %d: parity spot check failed: %.3e of sum|a||b| on this rank, %.3e worst over the ranks (tolerance 1e-5)" % (rank, worst, worst_all))
         del Ch
 
     # ---- pre-roll: leave the idle clock state (untimed, counted in `config.preroll_steps`) ------------------------------
@@ -431,12 +439,23 @@ def main():
         step()
         torch.cuda.synchronize()
         preroll = 1
-        batch = 8 if (time.perf_counter() - t_pr) < 2e-3 else 1
-        while (time.perf_counter() - t_pr) * 1e3 < args.settle_ms and preroll < 20000:
-            for _ in range(batch):
+        if distributed:
+            # a step is a collective: every rank must run the SAME number of them -- a clock-driven loop per rank ends one step apart on two ranks
+            # and the job deadlocks (one rank in the barrier, its peer in the all-gather).  The count comes from the slowest rank's first step.
+            t1 = torch.tensor([time.perf_counter() - t_pr], dtype=torch.float64, device=dev)
+            dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+            n_more = int(min(20000, max(0, np.ceil(args.settle_ms * 1e-3 / max(float(t1.item()), 1e-6)) - 1)))
+            for _ in range(n_more):
                 step()
-            preroll += batch
+            preroll += n_more
             torch.cuda.synchronize()
+        else:
+            batch = 8 if (time.perf_counter() - t_pr) < 2e-3 else 1
+            while (time.perf_counter() - t_pr) * 1e3 < args.settle_ms and preroll < 20000:
+                for _ in range(batch):
+                    step()
+                preroll += batch
+                torch.cuda.synchronize()
     fence()
     for _ in range(args.warmup):
         step()
@@ -553,7 +572,7 @@ def main():
         mean_h = float(m.rows) / max(n_block_rows, 1)
     dom_tflops = 2.0 * area.get(dom, 0.0) * N / (kernel_ms[dom] * 1e-3) / 1e12 if kernel_ms.get(dom, 0) > 0 else 0.0
     # the <= 32-row tiles of an fp32 handle run the no-barrier kernel (k_f32_direct.hip) for a column-major B unless SPARTA_F32_PLAN says otherwise
-    f32_direct = (args.dtype == "f32" and os.environ.get("SPARTA_F32_PLAN", "") not in ("legacy", "pair")
+    f32_direct = (args.dtype == "f32" and not distributed and os.environ.get("SPARTA_F32_PLAN", "") != "legacy"
                   and info["tiles16"] + info["tiles32"] >= info["tiles64"])
     kname = {"stream": "vbs_spmm_f32_direct_kernel" if f32_direct else "vbs_spmm_f32_stream_kernel", "fixup": "vbs_spmm_f32_fixup_kernel", "class16": "vbs_spmm_f32_kernel<16,...>",
              "class32": "vbs_spmm_f32_kernel<32,1,4,1,1,...>", "class64": "vbs_spmm_f32_kernel<32,2,2,1,2,...>"}.get(dom, dom)
