@@ -84,6 +84,9 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             {
                 int64_t jo2 = 0, mo2 = 0;
                 const int64_t row0 = row_part[br0];
+                // (Measured and dropped, 16-bit handles of 32-wide blocks: two vertically adjacent block-rows walked as ONE 64-row tile over the union of
+                // their block columns, a block one of them lacks being a zero half of the A slice -- the B panel of a step feeds both: -34 % steps and
+                // panel traffic, +29 % bytes of A; flagship 23.0 -> 22.5 us.  Not worth the second copy of the tile loop.)
                 for (int64_t ib = br0; ib < br1; ib++) {
                     const int64_t h = row_part[ib + 1] - row_part[ib];
                     const int64_t nb = nzcount[ib];
