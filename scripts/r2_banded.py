@@ -6,9 +6,10 @@ import sparta_amd as sa
 m = sa.gen.banded(200000, 16, density=0.5, seed=4)
 eng = sa.BlockingEngine(col_block_size=32, blocking_algo=7, tau=0.5, minhash_max_rows=32)
 g = eng.GetGrouping(m)
-d = sa.DeviceVBS.from_csr(m, g, 32, 0, False, device=0)
+DT = {"f32": sa.F32, "f16": sa.F16, "bf16": sa.BF16}[os.environ.get("DTYPE", "f32")]
+d = sa.DeviceVBS.from_csr(m, g, 32, 0, False, device=0, dtype=DT)
 N = 128
-B = torch.rand(d.cols * N, device="cuda") - 0.5
+B = (torch.rand(d.cols * N, device="cuda") - 0.5).to({sa.F32: torch.float32, sa.F16: torch.float16, sa.BF16: torch.bfloat16}[DT])
 C = torch.zeros(d.rows * N, device="cuda")
 import time
 t_pre = time.time()

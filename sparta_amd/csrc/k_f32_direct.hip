@@ -25,18 +25,12 @@ namespace {
 // epilogue and same workspace images for split tiles, so plans, fix-up kernel and step records are shared with the LDS kernel.
 // Column-major B only, no gathered B; tiles of <= 32 rows (the one-tile plan).
 // =====================================================================================================
-// CSTAGE (column-major C, tiles of arbitrary height): a wave does not store a finished tile straight away but parks it in a wave-private
-// ring of 64 rows x its 32 columns in LDS (row of the ring = row of C & 63) and stores ALIGNED blocks of 32 rows once the tiles that
-// follow -- a worker walks vertically adjacent tiles -- have completed them: whole 128-byte pieces of a column instead of the 28-row
-// pieces of two neighbouring tiles, which the memory side has to read, merge and write back and acknowledges late (one in-order counter
-// for loads and stores: the loads of step i + 4 wait for the stores of the tile that ended at step i; banded 200k).
-// The block a worker's range starts or ends in, and blocks around a gap between tiles, are stored partially, as before.
+// CSTAGE (column-major C, tiles of arbitrary height): finished tiles are parked in the C ring (vbs_kernel_common.hpp, CRing) and stored as aligned blocks.
 template <bool CSTAGE>
 __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const StreamParams p) {
     constexpr int TN = kTN, LDBW = 36;                  // Bs[column][k], 32 k + 4 padding: conflict-free ds_read_b128 / ds_write_b128
     constexpr int WSTAGE = 32 * LDBW;                   // floats per wave and stage
-    constexpr int CRS = 65;                             // floats per column of the C ring (64 rows + 1)
-    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * WSTAGE + (CSTAGE ? 4 * 32 * CRS : 0)];
+    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * WSTAGE + (CSTAGE ? 4 * kCRingFloats : 0)];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int lm = lane & 31, g = lane >> 5;
@@ -122,43 +116,8 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 
-    // ---- CSTAGE: the ring and its flush --------------------------------------------------------------------------------------------
-    float* const cring = lds + 4 * 2 * WSTAGE + wave * (32 * CRS);               // this wave's ring: element (column j, row r) at j * CRS + (r & 63)
-    int32_t win_base = 0, pend_lo = 0, pend_hi = 0;      // rows [pend_lo, pend_hi) of C are parked; win_base = pend_lo & ~31 (first block not yet stored)
-    // stores rows [max(b, lo), min(b + 32, hi)) of the aligned block b from the ring (lane lm = row b + lm), the way the direct epilogue stores a tile
-    auto flush_block = [&](int32_t b, int32_t lo, int32_t hi) __attribute__((always_inline)) {
-        float* cbase = p.C + (int64_t)b + (int64_t)n0 * p.ldc;
-        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
-        const uint32_t jstep = (uint32_t)p.ldc * 4u;
-        const int32_t row = b + lm;
-        if (row >= lo && row < hi) {
-            float v[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) v[q] = cring[((q & 3) + 8 * (q >> 2) + 4 * g) * CRS + (row & 63)];
-            if (p.accumulate) {
-                uint32_t old[16];
-#pragma unroll
-                for (int q = 0; q < 16; q++) old[q] = __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 0);
-#pragma unroll
-                for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
-            }
-            if (p.c_nt) {
-#pragma unroll
-                for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 2);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 0);
-            }
-        }
-    };
-    // stores what can be stored: everything parked (`all`: the next tile is not adjacent, or the range ends), else the blocks that are complete
-    auto flush_ring = [&](bool all) __attribute__((always_inline)) {
-        while (pend_lo < pend_hi && (all || pend_hi - win_base >= 32)) {
-            flush_block(win_base, pend_lo, pend_hi);
-            win_base += 32;
-            pend_lo = win_base < pend_hi ? win_base : pend_hi;
-        }
-    };
+    CRing cr;                                            // CSTAGE: finished tiles wait here for whole aligned blocks of 32 rows (vbs_kernel_common.hpp)
+    cr.ring = lds + 4 * 2 * WSTAGE + wave * kCRingFloats;
 
     // one step: fragments of B from LDS stage PAR, the next step's panel into the other stage, 16 MFMAs, then the staging set that was
     // just written out and the A set of step i - 1 are refilled with step i + 3.  (Measured and dropped: reading the fragments of step
@@ -197,14 +156,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
                     __builtin_amdgcn_raw_buffer_store_b32(0u, rW, (uint32_t)tid * 4u, (uint32_t)((16 + q) * kThreads * 4), 0);   // rows 32..63 of the image: none
                 }
             } else if (CSTAGE) {
-                const int32_t mt = flags & 0xffff, c_row = field(i, F_CROW);
-                flush_ring(pend_lo < pend_hi && c_row != pend_hi);                  // (a gap: drain first, the ring restarts at this tile)
-                if (pend_lo >= pend_hi) { win_base = c_row & ~31; pend_lo = c_row; }
-                if (lm < mt) {
-#pragma unroll
-                    for (int q = 0; q < 16; q++) cring[((q & 3) + 8 * (q >> 2) + 4 * g) * CRS + ((c_row + lm) & 63)] = acc[q];
-                }
-                pend_hi = c_row + mt;
+                cr.park(p, n0, lm, g, voffC, acc, field(i, F_CROW), flags & 0xffff);
             } else {
                 const int mt = flags & 0xffff;
                 const int64_t c_row = (SPARTA_DIRECT_PROBE & 64) ? 0 : field(i, F_CROW);      // probe 64: every tile stores to the first rows of C
@@ -278,7 +230,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
         }
         if (n - n4 == 3) step(c2{}, fq0, as2, bs1, as1);
     }
-    if (CSTAGE) flush_ring(true);
+    if (CSTAGE) cr.flush(p, n0, lm, g, voffC, true);
     clock_probe(p.clk, 2);
 #undef field
 }

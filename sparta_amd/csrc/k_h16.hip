@@ -327,8 +327,9 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
 // Loads run three steps ahead (A: four register sets, B: two staging sets + two LDS stages); step records: one window VGPR,
 // constant-lane v_readlane.  Same plans, accumulator layout, epilogue and fix-up as the other stream kernels.
 // =====================================================================================================
-template <int KP, bool MI2, bool BF16, bool GATHERED>
+template <int KP, bool MI2, bool BF16, bool GATHERED, bool CSTAGE = false>
 __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const StreamParams p) {
+    static_assert(!(CSTAGE && MI2), "the C ring holds 64 rows: tiles of <= 32 rows only");
     constexpr int TN = kTN, TM = MI2 ? 64 : 32;
     constexpr int NK = KP / 16;                          // MFMAs (k groups of 16) per step and 32-row tile = 16-byte loads per lane and operand
     constexpr int NA = MI2 ? 2 : 1;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
     constexpr int CPI = 64 / LPC;                        // columns per wave instruction: 16 or 8 (NK instructions cover the wave's 32)
     constexpr int RB = (KP + 8) * 2;                     // bytes per column of the LDS image (8 elements of padding: conflict-free b128)
     constexpr int WSTAGE = 32 * RB;                      // bytes per wave and stage
-    __shared__ __attribute__((aligned(16))) char lds[4 * 2 * WSTAGE];
+    __shared__ __attribute__((aligned(16))) char lds[4 * 2 * WSTAGE + (CSTAGE ? 4 * kCRingFloats * 4 : 0)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -369,6 +370,9 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
     char* const ldsw = lds + wave * (2 * WSTAGE);        // this wave's two stages
     const uint32_t lwB = (uint32_t)(bc * RB + bk * 2);   // write: column bc + CPI q
     const uint32_t lrB = (uint32_t)(lm * RB + 16 * g);   // read: column lm, k = 16 q + 8 g .. + 7
+
+    CRing cr;                                            // CSTAGE: finished tiles wait here for whole aligned blocks of 32 rows (vbs_kernel_common.hpp)
+    cr.ring = reinterpret_cast<float*>(lds + 4 * 2 * WSTAGE) + wave * kCRingFloats;
 
     struct ASet { u32x4 a[NA][NK]; };
     struct BSet { u32x4 b[NK]; };
@@ -452,6 +456,8 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc0[q]), rW, (uint32_t)tid * 4u, (uint32_t)(q * kThreads * 4), 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1[q]), rW, (uint32_t)tid * 4u, (uint32_t)((16 + q) * kThreads * 4), 0);
                 }
+            } else if (CSTAGE) {
+                if constexpr (CSTAGE) cr.park(p, n0, lm, g, voffC, acc0, field(i, F_CROW), flags & 0xffff);
             } else {
                 const int mt = flags & 0xffff;
                 const int64_t c_row = field(i, F_CROW);
@@ -527,6 +533,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
         }
         if (n - n4 == 3) step(c2{}, fq0, as2, bs1, as1);
     }
+    if constexpr (CSTAGE) cr.flush(p, n0, lm, g, voffC, true);
     clock_probe(p.clk, 2);
 #undef field
 }
@@ -584,7 +591,14 @@ bool h16_direct(int kp, bool mi2) {
     return true;
 }
 template <int KP, bool MI2>
-void launch_h16_direct(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
+void launch_h16_direct(bool bf16, bool gathered, bool c_stage, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if constexpr (!MI2) {
+        if (c_stage && !gathered) {                      // tiles of arbitrary height, column-major C: through the C ring
+            if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, false, true, false, true>), grid, dim3(kThreads), 0, st, sp);
+            else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, false, false, false, true>), grid, dim3(kThreads), 0, st, sp);
+            return;
+        }
+    }
     if (gathered) {
         if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, true, true>), grid, dim3(kThreads), 0, st, sp);
         else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, false, true>), grid, dim3(kThreads), 0, st, sp);
@@ -594,8 +608,8 @@ void launch_h16_direct(bool bf16, bool gathered, dim3 grid, hipStream_t st, cons
     }
 }
 template <int KP, bool MI2>
-void launch_h16(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
-    if (h16_direct(KP, MI2)) { launch_h16_direct<KP, MI2>(bf16, gathered, grid, st, sp); return; }
+void launch_h16(bool bf16, bool gathered, bool c_stage, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (h16_direct(KP, MI2)) { launch_h16_direct<KP, MI2>(bf16, gathered, c_stage, grid, st, sp); return; }
     if (h16_deep()) launch_h16_d<KP, MI2, true>(bf16, gathered, grid, st, sp);
     else launch_h16_d<KP, MI2, false>(bf16, gathered, grid, st, sp);
 }
@@ -606,9 +620,9 @@ namespace sparta_dev {
 
 bool h16_uses_direct_kernel(int kp, bool mi2) { return h16_direct(kp, mi2); }
 
-void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
-    if (kp == 64) { if (mi2) launch_h16<64, true>(bf16, gathered, grid, st, sp); else launch_h16<64, false>(bf16, gathered, grid, st, sp); }
-    else { if (mi2) launch_h16<32, true>(bf16, gathered, grid, st, sp); else launch_h16<32, false>(bf16, gathered, grid, st, sp); }
+void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, bool c_stage, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (kp == 64) { if (mi2) launch_h16<64, true>(bf16, gathered, false, grid, st, sp); else launch_h16<64, false>(bf16, gathered, c_stage, grid, st, sp); }
+    else { if (mi2) launch_h16<32, true>(bf16, gathered, false, grid, st, sp); else launch_h16<32, false>(bf16, gathered, c_stage, grid, st, sp); }
 }
 
 void launch_tail_copy_h16(hipStream_t st, const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N, uint16_t* B_tail) {

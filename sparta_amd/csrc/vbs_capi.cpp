@@ -792,7 +792,11 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
             sp.steps = shard_rows > 0 ? A->d_steps_g[ty] : A->d_steps[ty]; sp.worker_range = A->d_wrange[ty]; sp.c_nt = c_store_nt(A, ty, sp.C, sp.ldc, sp.c_row_major != 0);
             sp.clk = (prof && ty == probe_ty) ? A->d_clk : nullptr;
             const bool gth = shard_rows > 0;
-            launch_h16_stream(A->kp16, ty != 0, bf16, gth, grid, st, sp);
+            // tiles of <= 32 rows of arbitrary height + column-major C: finished tiles wait in the LDS ring for whole aligned blocks (CRing)
+            const int cst = [] { const char* e = std::getenv("SPARTA_F32_CSTAGE"); return e ? atoi(e) : -1; }();
+            const bool c_stage = ty == 0 && !gth && c_layout == SPARTA_COL_MAJOR && (cst >= 0 ? cst != 0 : !A->tiles_row_aligned[0]) && h16_uses_direct_kernel(A->kp16, false);
+            if (c_stage) sp.c_nt = c_store_nt(A, ty, sp.C, sp.ldc, false, true);
+            launch_h16_stream(A->kp16, ty != 0, bf16, gth, c_stage, grid, st, sp);
         }
         if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
     }

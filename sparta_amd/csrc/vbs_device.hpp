@@ -237,7 +237,7 @@ void launch_fixup(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* f
 void launch_tail_copy(hipStream_t st, const float* B, int64_t ldb, int b_row_major, int64_t row0, int64_t cols, int w, int N, float* B_tail);
 void launch_zero_rows(dim3 grid, hipStream_t st, float* C, int64_t ldc, int c_row_major, int64_t row0, int64_t nrows, int N);
 // k_h16.hip
-void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
+void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, bool c_stage, dim3 grid, hipStream_t st, const StreamParams& sp);
 bool h16_uses_direct_kernel(int kp, bool mi2);
 void launch_tail_copy_h16(hipStream_t st, const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N, uint16_t* B_tail);
 void launch_convert_h16(bool bf16, hipStream_t st, const float* src, int64_t ld_in, int64_t rows, int64_t n_cols, uint16_t* dst, int64_t ld_out);

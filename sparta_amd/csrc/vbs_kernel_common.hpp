@@ -62,4 +62,64 @@ __device__ __forceinline__ void sk_store_tile(const f32x16& acc0, const f32x16& 
     }
 }
 
+// ---- the C ring of the no-barrier kernels (CSTAGE: column-major C, tiles of <= 32 rows of arbitrary height) -------------------------------
+// A wave does not store a finished tile straight away but parks it in a wave-private ring of 64 rows x its 32 columns in LDS (row of the ring
+// = row of C & 63) and stores ALIGNED blocks of 32 rows once the tiles that follow -- a worker walks vertically adjacent tiles -- have
+// completed them: whole 128-byte pieces of a column instead of the 28-row pieces of two neighbouring tiles, which the memory side has to
+// read, merge and write back and acknowledges late (gfx9 has one in-order counter for loads and stores: the loads of step i + 4 wait for the
+// stores of the tile that ended at step i; banded 200k).  The flush is lazy -- at the next tile's epilogue, one site in a
+// scalar loop; the block a worker's range starts or ends in, and blocks around a gap between tiles (an empty block-row, sparse rows, a split
+// tile), are stored partially, as before.  All state is wave-uniform (scalar registers).
+constexpr int kCRingStride = 65;                                 // floats per column of the ring (64 rows + 1)
+constexpr int kCRingFloats = 32 * kCRingStride;                  // per wave
+struct CRing {
+    float* ring;                                                 // element (column j, row r) at j * kCRingStride + (r & 63)
+    int32_t win_base = 0, pend_lo = 0, pend_hi = 0;              // rows [pend_lo, pend_hi) of C are parked; win_base = first aligned block not yet stored
+
+    // stores rows [max(b, lo), min(b + 32, hi)) of the aligned block b (lane lm = row b + lm), the way the direct epilogue stores a tile
+    __device__ __forceinline__ void flush_block(const StreamParams& p, int n0, int lm, int g, uint32_t voffC, int32_t b, int32_t lo, int32_t hi) {
+        float* cbase = p.C + (int64_t)b + (int64_t)n0 * p.ldc;
+        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
+        const uint32_t jstep = (uint32_t)p.ldc * 4u;
+        const int32_t row = b + lm;
+        if (row >= lo && row < hi) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[q] = ring[((q & 3) + 8 * (q >> 2) + 4 * g) * kCRingStride + (row & 63)];
+            if (p.accumulate) {
+                uint32_t old[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) old[q] = __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 0);
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
+            }
+            if (p.c_nt) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 2);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep, 0);
+            }
+        }
+    }
+    // stores what can be stored: everything parked (`all`: the next tile is not adjacent, or the range ends), else the blocks that are complete
+    __device__ __forceinline__ void flush(const StreamParams& p, int n0, int lm, int g, uint32_t voffC, bool all) {
+        while (pend_lo < pend_hi && (all || pend_hi - win_base >= 32)) {
+            flush_block(p, n0, lm, g, voffC, win_base, pend_lo, pend_hi);
+            win_base += 32;
+            pend_lo = win_base < pend_hi ? win_base : pend_hi;
+        }
+    }
+    // a finished tile (rows [c_row, c_row + mt) of C, mt <= 32, accumulator image `acc` of this wave's 32 columns) goes into the ring
+    __device__ __forceinline__ void park(const StreamParams& p, int n0, int lm, int g, uint32_t voffC, const f32x16& acc, int32_t c_row, int32_t mt) {
+        flush(p, n0, lm, g, voffC, pend_lo < pend_hi && c_row != pend_hi);          // (a gap: drain first, the ring restarts at this tile)
+        if (pend_lo >= pend_hi) { win_base = c_row & ~31; pend_lo = c_row; }
+        if (lm < mt) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) ring[((q & 3) + 8 * (q >> 2) + 4 * g) * kCRingStride + ((c_row + lm) & 63)] = acc[q];
+        }
+        pend_hi = c_row + mt;
+    }
+};
+
 }  // namespace sparta_dev

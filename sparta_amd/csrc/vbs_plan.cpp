@@ -214,10 +214,10 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                         if (cur > 0 && cur + c > cap(lo, bin) && bin + 1 < n_workers) { bin++; bnd[(size_t)bin] = spans[t].first; cur = 0; }
                         cur += c;
                     }
-                    // fp32 one-tile plans whose tiles do not start on multiples of 32 rows keep CONTIGUOUS ranges: the no-barrier kernel then parks
+                    // one-tile plans whose tiles do not start on multiples of 32 rows keep CONTIGUOUS ranges: the no-barrier kernels then park
                     // finished tiles in its LDS ring and stores whole aligned blocks of C, which only works when a worker's tiles are vertically
                     // adjacent (k_f32_direct.hip, CSTAGE; banded 200k: 66 us dealt longest-first with direct stores)
-                    const bool ring_plan = !h16 && ty == 0 && !P.tiles_row_aligned[ty] &&
+                    const bool ring_plan = ty == 0 && !P.tiles_row_aligned[ty] &&
                                            [] { const char* e = std::getenv("SPARTA_F32_CSTAGE"); return !e || atoi(e) != 0; }();
                     if (interleave && !ring_plan) {
                         // Whole tiles can go to any worker.  Keep the 64 workers of an XCD close together in the matrix at every
