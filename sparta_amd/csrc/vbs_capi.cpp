@@ -644,6 +644,10 @@ int sparta_vbs_clock_mhz(sparta_vbs_t* A, double* mhz_out) {
 
 namespace {
 
+// do the <= 32-row tiles of this handle go through the C ring (CRing)?  Tiles that do not start on multiples of 32 rows AND are short (the plan kept
+// contiguous worker ranges for exactly these: vbs_plan.cpp, ring_plan)
+bool ring_tiles(const sparta_vbs_t* A) { return !A->tiles_row_aligned[0] && A->n_steps[0] < 6 * A->n_plan_tiles[0]; }
+
 // cache policy of a stream launch's C stores (vbs_kernel_common.hpp): non-temporal for long tiles; SPARTA_C_NT=0|1 forces one
 int32_t c_store_nt(const sparta_vbs_t* A, int ty, const float* C, int64_t ldc, bool c_row_major, bool ring = false) {
     if (const char* e = std::getenv("SPARTA_C_NT")) return atoi(e) != 0;
@@ -794,7 +798,7 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
             const bool gth = shard_rows > 0;
             // tiles of <= 32 rows of arbitrary height + column-major C: finished tiles wait in the LDS ring for whole aligned blocks (CRing)
             const int cst = [] { const char* e = std::getenv("SPARTA_F32_CSTAGE"); return e ? atoi(e) : -1; }();
-            const bool c_stage = ty == 0 && !gth && c_layout == SPARTA_COL_MAJOR && (cst >= 0 ? cst != 0 : !A->tiles_row_aligned[0]) && h16_uses_direct_kernel(A->kp16, false);
+            const bool c_stage = ty == 0 && !gth && c_layout == SPARTA_COL_MAJOR && (cst >= 0 ? cst != 0 : ring_tiles(A)) && h16_uses_direct_kernel(A->kp16, false);
             if (c_stage) sp.c_nt = c_store_nt(A, ty, sp.C, sp.ldc, false, true);
             launch_h16_stream(A->kp16, ty != 0, bf16, gth, c_stage, grid, st, sp);
         }
@@ -928,7 +932,7 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                         sd.A = A->d_a_frag;
                         // tiles of arbitrary height + column-major C: finished tiles wait in an LDS ring for whole aligned blocks of 32 rows (k_f32_direct.hip)
                         const int cst = [] { const char* e = std::getenv("SPARTA_F32_CSTAGE"); return e ? atoi(e) : -1; }();     // (read per launch: tests flip it)
-                        const bool c_stage = c_layout == SPARTA_COL_MAJOR && (cst >= 0 ? cst != 0 : !A->tiles_row_aligned[0]);
+                        const bool c_stage = c_layout == SPARTA_COL_MAJOR && (cst >= 0 ? cst != 0 : ring_tiles(A));
                         sd.c_nt = c_store_nt(A, ty, sd.C, sd.ldc, sd.c_row_major != 0, c_stage);
                         launch_f32_direct(c_stage, grid, st, sd);
                     } else launch_f32_stream(ty != 0, b_layout == SPARTA_ROW_MAJOR, shard_rows > 0, grid, st, sp);

@@ -217,7 +217,10 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                     // one-tile plans whose tiles do not start on multiples of 32 rows keep CONTIGUOUS ranges: the no-barrier kernels then park
                     // finished tiles in its LDS ring and stores whole aligned blocks of C, which only works when a worker's tiles are vertically
                     // adjacent (k_f32_direct.hip, CSTAGE; banded 200k: 66 us dealt longest-first with direct stores)
-                    const bool ring_plan = ty == 0 && !P.tiles_row_aligned[ty] &&
+                    // -- and only SHORT tiles (fewer than 6 steps per tile on average: the regime where a step's loads wait for stores): with long tiles
+                    // the stores are rare and the longest-first dealing is worth more (cant-like in tiles of 31.99 rows on average: 63.9 us as a ring
+                    // plan, 56.5 dealt longest-first with direct stores)
+                    const bool ring_plan = ty == 0 && !P.tiles_row_aligned[ty] && S < 6 * (int64_t)spans.size() &&
                                            [] { const char* e = std::getenv("SPARTA_F32_CSTAGE"); return !e || atoi(e) != 0; }();
                     if (interleave && !ring_plan) {
                         // Whole tiles can go to any worker.  Keep the 64 workers of an XCD close together in the matrix at every
