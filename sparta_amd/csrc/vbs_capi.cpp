@@ -797,7 +797,7 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
             sp.clk = (prof && ty == probe_ty) ? A->d_clk : nullptr;
             const bool gth = shard_rows > 0;
             // tiles of <= 32 rows of arbitrary height + column-major C: finished tiles wait in the LDS ring for whole aligned blocks (CRing)
-            const int cst = [] { const char* e = std::getenv("SPARTA_F32_CSTAGE"); return e ? atoi(e) : -1; }();
+            const int cst = [] { const char* e = std::getenv("SPARTA_CSTAGE"); return e ? atoi(e) : -1; }();
             const bool c_stage = ty == 0 && !gth && c_layout == SPARTA_COL_MAJOR && (cst >= 0 ? cst != 0 : ring_tiles(A)) && h16_uses_direct_kernel(A->kp16, false);
             if (c_stage) sp.c_nt = c_store_nt(A, ty, sp.C, sp.ldc, false, true);
             launch_h16_stream(A->kp16, ty != 0, bf16, gth, c_stage, grid, st, sp);
@@ -931,7 +931,7 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                         StreamParams sd = sp;                 // the <= 32-row tiles without the workgroup stage
                         sd.A = A->d_a_frag;
                         // tiles of arbitrary height + column-major C: finished tiles wait in an LDS ring for whole aligned blocks of 32 rows (k_f32_direct.hip)
-                        const int cst = [] { const char* e = std::getenv("SPARTA_F32_CSTAGE"); return e ? atoi(e) : -1; }();     // (read per launch: tests flip it)
+                        const int cst = [] { const char* e = std::getenv("SPARTA_CSTAGE"); return e ? atoi(e) : -1; }();     // (read per launch: tests flip it)
                         const bool c_stage = c_layout == SPARTA_COL_MAJOR && (cst >= 0 ? cst != 0 : ring_tiles(A));
                         sd.c_nt = c_store_nt(A, ty, sd.C, sd.ldc, sd.c_row_major != 0, c_stage);
                         launch_f32_direct(c_stage, grid, st, sd);

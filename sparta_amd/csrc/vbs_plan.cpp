@@ -221,7 +221,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                     // the stores are rare and the longest-first dealing is worth more (cant-like in tiles of 31.99 rows on average: 63.9 us as a ring
                     // plan, 56.5 dealt longest-first with direct stores)
                     const bool ring_plan = ty == 0 && !P.tiles_row_aligned[ty] && S < 6 * (int64_t)spans.size() &&
-                                           [] { const char* e = std::getenv("SPARTA_F32_CSTAGE"); return !e || atoi(e) != 0; }();
+                                           [] { const char* e = std::getenv("SPARTA_CSTAGE"); return !e || atoi(e) != 0; }();
                     if (interleave && !ring_plan) {
                         // Whole tiles can go to any worker.  Keep the 64 workers of an XCD close together in the matrix at every
                         // moment: the XCD takes a contiguous eighth of the tiles (by cost) and deals them, in matrix order, to

@@ -1171,7 +1171,7 @@ def test_product_inside_a_graph_capture(monkeypatch, _sparse_row_mode):
 def test_tiles_parked_in_the_lds_ring_store_the_same_c(monkeypatch, _sparse_row_mode, align, n):
     """fp32, column-major C, tiles of arbitrary height: the no-barrier kernel parks finished tiles in a wave-private LDS ring and stores aligned
     blocks of 32 rows (k_f32_direct.hip, CSTAGE).  Same sums, other stores: C must be bit-identical to the direct-store form of the same kernel
-    (SPARTA_F32_CSTAGE=0) for whole-tile plans, within the tolerance for split plans, with and without accumulate, around gaps (empty block-rows, sparse rows, split tiles),
+    (SPARTA_CSTAGE=0) for whole-tile plans, within the tolerance for split plans, with and without accumulate, around gaps (empty block-rows, sparse rows, split tiles),
     and equal to the oracle's."""
     torch = _torch()
     monkeypatch.setenv("SPARTA_PATH", "stream")
@@ -1198,7 +1198,7 @@ def test_tiles_parked_in_the_lds_ring_store_the_same_c(monkeypatch, _sparse_row_
     bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
     got = {}
     for ring in ("1", "0"):
-        monkeypatch.setenv("SPARTA_F32_CSTAGE", ring)          # read at create time (plan: contiguous ranges) and per process at the first launch
+        monkeypatch.setenv("SPARTA_CSTAGE", ring)          # read at create time (plan: contiguous ranges) and per process at the first launch
         d = v.to_device(0)
         for acc in (False, True):
             C0 = sa.gen.dense_rhs(v.rows, n, seed=52)
