@@ -128,6 +128,12 @@ def main():
     ap.add_argument("--workload", choices=["cant", "rmat", "ogbn-like"], default="cant")
     ap.add_argument("--rmat-scale", type=int, default=20)
     ap.add_argument("--rmat-density", type=float, default=0.0, help="distinct nonzeros / n^2 (0.001 = 0.1 %%); 0 = 10 edges per row, symmetrised")
+    ap.add_argument("--row-slab", default=None, metavar="K/P",
+                    help="rmat with --rmat-density, one GPU: only the rows [K, K+1) * 2^scale / P of the graph (P a power of two), sampled without the rest -- "
+                         "one rank's share of a graph too large for one GPU (configs[4]: --rmat-scale 23 --rmat-density 1e-4 --row-slab 0/128)")
+    ap.add_argument("--slab-ranks", type=int, default=8,
+                    help="--row-slab: B is held the way this rank would see it after the all-gather of that many ranks (slabs of cols / ranks rows, read "
+                         "through sparta_vbs_spmm_gathered)")
     ap.add_argument("--force-large", action="store_true", help="run R-MAT densities above 2.5e9 nonzeros anyway (not feasible inside one GPU lease)")
     ap.add_argument("--host-gen", action="store_true", help="generate R-MAT on the host with numpy (small cases / no GPU generator)")
     ap.add_argument("--matrix", default=None,
@@ -207,8 +213,16 @@ def main():
         wl_name = "ogbn-products-like power-law graph (leading %d^2 corner of R-MAT 2^22, symmetrised, values 1: %d nnz)" % (m.rows, m.nztot())
     elif args.workload == "rmat":
         n = 1 << args.rmat_scale
+        slab, slab_share = None, 1.0
+        if args.row_slab:
+            if distributed or not args.rmat_density > 0.0:
+                raise SystemExit("--row-slab is a single-GPU option of --workload rmat --rmat-density")
+            k_, p_ = (int(x) for x in args.row_slab.split("/"))
+            slab = (k_, p_)
+            for bit in range(p_.bit_length() - 1):               # expected share of the graph's edges: the row bits are independent, P(bit = 1) = c + d = 0.24
+                slab_share *= 0.24 if (k_ >> bit) & 1 else 0.76
         if args.rmat_density > 0.0:
-            target = int(args.rmat_density * float(n) * float(n))
+            target = int(args.rmat_density * float(n) * float(n) * slab_share)
             # what one GPU must hold for this density: the CSR on the device (column + 16/32-bit value per nonzero) + the generator's sort
             need = target * (4.0 + esz) + 3.0 * 8.0 * target / max(1, 1)
             if target * (4.0 + esz) > 0.8 * HBM_BYTES:
@@ -241,9 +255,15 @@ def main():
                 return
             if args.host_gen:
                 raise SystemExit("--host-gen has no density mode")
-            m, gen_stats = sa.gen.rmat_device(args.rmat_scale, target_nnz=target, seed=3, values="uniform", device=local_rank, return_stats=True)
-            wl_name = ("R-MAT 2^%d (a,b,c = 0.57,0.19,0.19) at density %.4g %% (%d^2, %d distinct nnz)"
-                       % (args.rmat_scale, 100.0 * m.nztot() / float(n) / float(n), m.rows, m.nztot()))
+            m, gen_stats = sa.gen.rmat_device(args.rmat_scale, target_nnz=target, seed=3, values="uniform", device=local_rank, return_stats=True, row_slab=slab)
+            if slab is None:
+                wl_name = ("R-MAT 2^%d (a,b,c = 0.57,0.19,0.19) at density %.4g %% (%d^2, %d distinct nnz)"
+                           % (args.rmat_scale, 100.0 * m.nztot() / float(n) / float(n), m.rows, m.nztot()))
+            else:
+                wl_name = ("rows [%d, %d) of R-MAT 2^%d (a,b,c = 0.57,0.19,0.19) at graph density %.4g %%: a %d x %d slab with %d distinct nnz = %.3f of the graph's "
+                           "%.3g (one rank's share of a row partition by cost; sampled without the rest of the graph)"
+                           % (slab[0] * m.rows, (slab[0] + 1) * m.rows, args.rmat_scale, 100.0 * args.rmat_density, m.rows, m.cols, m.nztot(), slab_share,
+                              args.rmat_density * float(n) * float(n)))
         else:
             if args.host_gen:
                 m = sa.gen.rmat(args.rmat_scale, 10 << args.rmat_scale, seed=3, symmetrize=True, pattern_only=False)
@@ -312,7 +332,17 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     ldb = cols_a
     B_shard = B_gath = None
-    if not distributed:
+    emul = args.slab_ranks if (args.row_slab and not distributed) else 0      # a rank's slab alone: B in the gathered layout of `emul` ranks
+    if emul:
+        shard_rows = sa.dist.padded_shard_rows(-(-cols_a // emul), max(w, 64))
+        if emul * shard_rows != cols_a:
+            raise SystemExit("--row-slab: the columns (%d) must split into --slab-ranks = %d slabs of a multiple of %d rows" % (cols_a, emul, max(w, 64)))
+        gd = torch.Generator(device=dev).manual_seed(1234)
+        B_gath = torch.empty(emul * shard_rows * N, dtype=tdt, device=dev)
+        for s_ in range(emul):                                   # slab by slab: the fp32 draw of the whole B would be 4 x its 16-bit size at once
+            B_gath[s_ * shard_rows * N:(s_ + 1) * shard_rows * N] = (torch.rand(shard_rows * N, generator=gd, dtype=torch.float32, device=dev) - 0.5).to(tdt)
+        B = None
+    elif not distributed:
         B32 = None
         ldb = (cols_a + 7) // 8 * 8 if h16 else cols_a        # 16-bit B: leading dimension padded to a multiple of 8 elements
         if cols_a * N <= (1 << 28):
@@ -372,7 +402,9 @@ def main():
     info = dmain.info()
 
     def step():
-        if not distributed:
+        if emul:
+            d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False)       # what the rank runs behind its all-gather
+        elif not distributed:
             d.spmm(B, C, N, accumulate=False, ldb=ldb)
         elif ex is not None:
             ex.step(B_tiles, C)                                    # pack + ONE all-to-all of the needed row-blocks || own product; + remote product
@@ -401,8 +433,8 @@ def main():
         rng = np.random.Generator(np.random.PCG64(11 + rank))
         perm_l = sa.get_permutation(grouping)
         pick = rng.integers(0, m.rows, size=min(args.check_rows, m.rows))
-        if distributed:
-            Bh_cols = lambda cols_i: sa.dist.gathered_rows(B_gath, cols_i, world, shard_rows, N)
+        if distributed or emul:
+            Bh_cols = lambda cols_i: sa.dist.gathered_rows(B_gath, cols_i, emul or world, shard_rows, N)
         else:
             Bv = B.view(N, ldb)
             Bh_cols = lambda cols_i: Bv[:, torch.from_numpy(cols_i.astype(np.int64)).to(dev)].float().cpu().numpy().astype(np.float64)
@@ -643,7 +675,7 @@ def main():
     cpu = None
     if not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(sa, args, m, grouping, vb, w, rbs, ff, N, B, ldb, B_gath, world, shard_rows, distributed, h16, torch)
+            cpu = cpu_baseline(sa, args, m, grouping, vb, w, rbs, ff, N, B, ldb, B_gath, emul or world, shard_rows, distributed or bool(emul), h16, torch)
         except Exception as e:  # the baseline is a report, never a reason to lose the measurement
             cpu = {"value": None, "unit": "GFLOP/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
 

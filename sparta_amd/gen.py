@@ -142,7 +142,7 @@ def fem3d_slab(nx, ny, nz_per_rank, rank, world, dof=3, pad_to=64, seed=2, patte
 
 # ---- large power-law inputs, generated on the GPU (BASELINE configs[2]-[4]: 10^8 .. 10^10 nonzeros) -----------------------------
 def rmat_device(scale, n_edges=None, target_nnz=None, a=0.57, b=0.19, c=0.19, seed=3, symmetrize=False, values="uniform", n=None,
-                device=0, chunk=1 << 26, max_rounds=12, return_stats=False):
+                device=0, chunk=1 << 26, max_rounds=12, return_stats=False, row_slab=None):
     """R-MAT graph with 2**scale vertices (optionally only the leading n x n corner), sampled, sorted and de-duplicated on the
     GPU with torch (numpy needs minutes for 10^9 edges); the CSR comes back as host arrays (sparta_amd.CSR).
 
@@ -151,6 +151,10 @@ def rmat_device(scale, n_edges=None, target_nnz=None, a=0.57, b=0.19, c=0.19, se
                   has slightly more (the last round's surplus is kept: dropping entries of a sorted list would bias the rows).
     symmetrize  : every edge (r, c) also gives (c, r).
     values      : "uniform" U(-1, 1) fp32, "ones", or None (pattern only).
+    row_slab    : (k, parts), parts a power of two: only the rows [k * 2**scale / parts, (k + 1) * 2**scale / parts) of the graph, as a
+                  (2**scale / parts) x 2**scale matrix -- the top log2(parts) bits of the row are fixed and the column bits of those levels are
+                  drawn from the conditional distribution, so a slab of a graph too large for one GPU is sampled without the rest (the
+                  R-MAT bits are independent across levels).  `target_nnz` / `n_edges` then refer to the slab.  No symmetrize, no corner.
     Same seed, same torch build, same GPU model -> same matrix; the seed of chunk k is seed * 1000003 + k."""
     import torch
     from .host import CSR
@@ -161,6 +165,13 @@ def rmat_device(scale, n_edges=None, target_nnz=None, a=0.57, b=0.19, c=0.19, se
     n = full if n is None else int(n)
     ab, abc = a + b, a + b + c
     state = {"chunk": 0, "drawn": 0}
+    slab_bits, slab_k, n_rows = 0, 0, n
+    if row_slab is not None:
+        slab_k, parts = int(row_slab[0]), int(row_slab[1])
+        slab_bits = parts.bit_length() - 1
+        if (1 << slab_bits) != parts or not (0 <= slab_k < parts) or symmetrize or n != full or slab_bits > scale:
+            raise ValueError("row_slab = (k, parts): parts a power of two <= 2**scale, 0 <= k < parts, no symmetrize, no corner")
+        n_rows = full >> slab_bits
 
     def draw(m):
         """m raw edges -> int64 keys r * n + c (edges outside the n x n corner rejected)"""
@@ -174,6 +185,11 @@ def rmat_device(scale, n_edges=None, target_nnz=None, a=0.57, b=0.19, c=0.19, se
             col = torch.zeros(k, dtype=torch.int64, device=dev)
             for lvl in range(scale):
                 u = torch.rand(k, generator=g, device=dev)
+                if lvl >= scale - slab_bits:                       # a level whose row bit the slab fixes: the column bit given that row bit
+                    down_bit = (slab_k >> (lvl - (scale - slab_bits))) & 1
+                    p_right = (1.0 - abc) / (1.0 - ab) if down_bit else b / ab
+                    col |= (u < p_right).to(torch.int64) << lvl
+                    continue                                       # (the row bits of the slab are implicit: rows are numbered inside the slab)
                 right = ((u >= a) & (u < ab)) | (u >= abc)        # quadrants b, d -> column bit set
                 down = u >= ab                                     # quadrants c, d -> row bit set
                 r |= down.to(torch.int64) << lvl
@@ -205,8 +221,8 @@ def rmat_device(scale, n_edges=None, target_nnz=None, a=0.57, b=0.19, c=0.19, se
             del fresh
     nnz = int(keys.numel())
     r = keys // n
-    counts = torch.bincount(r, minlength=n)
-    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    counts = torch.bincount(r, minlength=n_rows)
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
     torch.cumsum(counts, 0, out=rowptr[1:])
     colidx = (keys - r * n).to(torch.int32)
     del keys, r, counts
@@ -216,11 +232,11 @@ def rmat_device(scale, n_edges=None, target_nnz=None, a=0.57, b=0.19, c=0.19, se
         vals = torch.rand(nnz, generator=g, device=dev) * 2.0 - 1.0
     elif values == "ones":
         vals = torch.ones(nnz, dtype=torch.float32, device=dev)
-    m = CSR(n, n, rowptr.cpu().numpy(), colidx.cpu().numpy(), None if vals is None else vals.cpu().numpy())
+    m = CSR(n_rows, n, rowptr.cpu().numpy(), colidx.cpu().numpy(), None if vals is None else vals.cpu().numpy())
     del rowptr, colidx, vals
     torch.cuda.empty_cache()
     if return_stats:
-        return m, {"raw_edges_drawn": state["drawn"], "nnz": nnz, "density": nnz / float(n) / float(n)}
+        return m, {"raw_edges_drawn": state["drawn"], "nnz": nnz, "density": nnz / float(n_rows) / float(n)}
     return m
 
 

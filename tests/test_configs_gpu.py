@@ -255,3 +255,30 @@ def test_matrix_market_file_through_the_whole_path(tmp_path):
     d.spmm(torch.from_numpy(Bh).cuda(), C, n, accumulate=False, algo=sa.SPMM_EXACT)
     torch.cuda.synchronize()
     assert np.array_equal(C.cpu().numpy(), Co)
+
+
+def test_rmat_row_slab_is_sampled_without_the_rest_of_the_graph():
+    """configs[4] is too large to generate on one GPU; a rank's rows are sampled alone (gen.rmat_device(row_slab=(k, parts))): the top bits of
+    the row are fixed, the column bits of those levels come from the conditional distribution.  Structure of the slab, its share of the edges
+    (row bits are independent: 0.76 / 0.24 per bit) and the column marginals of the fixed levels against the same rows of a whole graph."""
+    _torch()
+    scale, parts = 14, 4
+    n = 1 << scale
+    whole = sa.gen.rmat_device(scale, n_edges=40 << scale, seed=5, values=None)
+    share = []
+    for k in range(parts):
+        m = sa.gen.rmat_device(scale, n_edges=int((40 << scale) * [0.76 * 0.76, 0.24 * 0.76, 0.76 * 0.24, 0.24 * 0.24][k]), seed=5, values="uniform", row_slab=(k, parts))
+        assert (m.rows, m.cols) == (n // parts, n) and len(m.rowptr) == m.rows + 1 and m.rowptr[-1] == m.nztot()
+        assert m.colidx.min() >= 0 and m.colidx.max() < n and np.all(np.diff(m.rowptr) >= 0)
+        for i in (0, m.rows // 2, m.rows - 1):                # columns ascending and distinct inside a row (sorted, de-duplicated keys)
+            c = m.colidx[m.rowptr[i]:m.rowptr[i + 1]]
+            assert np.all(np.diff(c) > 0)
+        lo, hi = whole.rowptr[k * m.rows], whole.rowptr[(k + 1) * m.rows]
+        share.append((m.nztot(), int(hi - lo)))
+        # column marginal of the top level (bit scale - 1 of the column) given the slab's top row bit: b / (a + b) = 0.25 for row bit 0, d / (c + d) = 0.208 for row bit 1
+        top = float(np.mean(m.colidx >= n // 2))
+        top_whole = float(np.mean(whole.colidx[lo:hi] >= n // 2))
+        want = 0.05 / 0.24 if k >= 2 else 0.19 / 0.76        # (of the raw edges; removing duplicates shifts it towards the sparser half, equally in both)
+        assert abs(top - top_whole) < 0.01 and abs(top - want) < 0.06, (k, top, top_whole, want)
+    for k, (got, ref_cnt) in enumerate(share):                # same expected edge count as the same rows of the whole graph (duplicates removed in both)
+        assert abs(got - ref_cnt) < 0.05 * ref_cnt + 500, (k, got, ref_cnt)
