@@ -361,12 +361,15 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
 
     const int bc = lane / LPC, bk = (lane % LPC) * 8;    // B load q: column CPI q + bc of the wave's 32, k = bk .. bk + 7
     const int64_t ld_t = (int64_t)p.w;                   // leading dimension of B_tail
-    const uint32_t voffB = (uint32_t)(((32 * wave + bc) * p.ldb + bk) * 2);
+    // this wave's 32 columns start at column nw of B / C: folded into the SCALAR bases, so that the 32-bit per-lane offsets only span 32 columns
+    // (a column-major B or C with a leading dimension of 2^23 -- configs[4] on one GPU -- is 2 GB per 128 columns, beyond a 32-bit offset)
+    const int nw = n0 + 32 * __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t voffB = (uint32_t)((bc * p.ldb + bk) * 2);
     const uint32_t voffBt = (uint32_t)(((n0 + 32 * wave + bc) * ld_t + bk) * 2);
     const uint32_t qstepB = (uint32_t)(CPI * p.ldb * 2), qstepBt = (uint32_t)(CPI * ld_t * 2);      // bytes from one column group to the next
     const uint32_t voffA = (uint32_t)((g * TM + lm) * 16);     // slice in memory: [k chunk = 2 q + g][row][8]: a wave load is one (TM = 32) or two contiguous pieces
-    const int64_t n0off = (int64_t)n0 * p.ldb;
-    const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 32 * wave + 4 * g) * 4) : (uint32_t)((lm + (32 * wave + 4 * g) * p.ldc) * 4);
+    const int64_t n0off = (int64_t)nw * p.ldb;
+    const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 4 * g) * 4) : (uint32_t)((lm + (4 * g) * p.ldc) * 4);
     char* const ldsw = lds + wave * (2 * WSTAGE);        // this wave's two stages
     const uint32_t lwB = (uint32_t)(bc * RB + bk * 2);   // write: column bc + CPI q
     const uint32_t lrB = (uint32_t)(lm * RB + 16 * g);   // read: column lm, k = 16 q + 8 g .. + 7
@@ -457,11 +460,11 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1[q]), rW, (uint32_t)tid * 4u, (uint32_t)((16 + q) * kThreads * 4), 0);
                 }
             } else if (CSTAGE) {
-                if constexpr (CSTAGE) cr.park(p, n0, lm, g, voffC, acc0, field(i, F_CROW), flags & 0xffff);
+                if constexpr (CSTAGE) cr.park(p, nw, lm, g, voffC, acc0, field(i, F_CROW), flags & 0xffff);
             } else {
                 const int mt = flags & 0xffff;
                 const int64_t c_row = field(i, F_CROW);
-                float* cbase = p.c_row_major ? p.C + c_row * p.ldc + n0 : p.C + c_row + (int64_t)n0 * p.ldc;
+                float* cbase = p.c_row_major ? p.C + c_row * p.ldc + nw : p.C + c_row + (int64_t)nw * p.ldc;
                 const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
                 const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;
                 const uint32_t mistep = p.c_row_major ? (uint32_t)p.ldc * 128u : 128u;
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
         }
         if (n - n4 == 3) step(c2{}, fq0, as2, bs1, as1);
     }
-    if constexpr (CSTAGE) cr.flush(p, n0, lm, g, voffC, true);
+    if constexpr (CSTAGE) cr.flush(p, nw, lm, g, voffC, true);
     clock_probe(p.clk, 2);
 #undef field
 }

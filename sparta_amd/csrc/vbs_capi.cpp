@@ -764,9 +764,14 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
     } else if (ldb % 2 != 0) {
         return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit B needs an even leading dimension (16-byte loads start on 4-byte boundaries)");
     }
-    // 32-bit byte offsets inside a 128-column slab (see the fp32 path): 127 x ld x element size < 2^31
-    if (ldb16 * 128 * 2 >= ((int64_t)1 << 31) - 65536 || (c_layout == SPARTA_ROW_MAJOR ? ldc * 64 : ldc * 128) * 4 >= ((int64_t)1 << 31) - 65536)
-        return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: leading dimension too large for the 16-bit stream kernels (ldb < 8.3 M, ldc < 4.1 M elements)");
+    // 32-bit byte offsets: the no-barrier kernel keeps them inside ONE WAVE's 32 columns (31 x ld x element size < 2^31: ldb < 34 M, ldc < 17 M elements);
+    // the LDS-staged kernel (SPARTA_H16_PATH=lds) inside the 128-column slab (ldb < 8.3 M, ldc < 4.1 M)
+    {
+        const int64_t span = h16_uses_direct_kernel(A->kp16, false) ? 32 : 128;
+        if (ldb16 * span * 2 >= ((int64_t)1 << 31) - 65536 || (c_layout == SPARTA_ROW_MAJOR ? ldc * 32 : ldc * span) * 4 >= ((int64_t)1 << 31) - 65536)
+            return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: leading dimension too large for the 16-bit stream kernels (ldb < 34 M, ldc < 17 M elements; "
+                                                "8.3 M / 4.1 M with SPARTA_H16_PATH=lds)");
+    }
     if (dt_ms) HIP_TRY(hipEventRecord(A->ev0, st));
     const int n_nt = n_cols / kTN;
     const bool prof = A->class_timing;

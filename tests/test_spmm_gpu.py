@@ -1212,3 +1212,35 @@ def test_tiles_parked_in_the_lds_ring_store_the_same_c(monkeypatch, _sparse_row_
     if align == "aligned":                                    # whole tiles: the same sums in the same order, whatever the stores do
         for acc in (False, True):
             assert np.array_equal(got[("1", acc)], got[("0", acc)])
+
+
+@pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
+def test_16bit_handles_take_leading_dimensions_of_2_to_the_23(monkeypatch, _sparse_row_mode, dtype):
+    """configs[4] on one GPU has a column-major B with 2^23 rows: 128 columns of it are 2 GB, beyond a 32-bit byte offset.  The 16-bit
+    no-barrier kernel folds its wave's column base into the scalar descriptor, so only 32 columns have to fit (ldb < 34 M, ldc < 17 M); the
+    LDS-staged kernel keeps the limit of the 128-column slab and says so."""
+    torch = _torch()
+    m = sa.gen.uniform_random(700, 900, 30000, seed=33)
+    v = sa.VBR().fill_from_CSR_inplace_fixed(m, 32, 64)
+    n, ldb, ldc = 128, (1 << 23) + 8, 4_400_000
+    tdt = {sa.F16: torch.float16, sa.BF16: torch.bfloat16}[dtype]
+    B = sa.gen.dense_rhs(v.cols, n, seed=2)
+    rnd = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(tdt).float().numpy()
+    vo = sa.VBR.from_arrays(v.rows, v.cols, 64, v.row_part, v.nzcount, v.jab, rnd(v.mab))
+    Bo = rnd(B)
+    Co = _oracle_c(vo, Bo, n)
+    bound = U.abs_bound(v.rows, v.cols, 64, v.row_part, v.nzcount, v.jab, vo.mab, Bo, n)
+    d = v.to_device(0, dtype=dtype)
+    Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    Bt.view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
+    Ct = torch.full((ldc * n,), 3.0, dtype=torch.float32, device="cuda")
+    d.spmm(Bt, Ct, n, ldb=ldb, ldc=ldc)
+    torch.cuda.synchronize()
+    got = Ct.view(n, ldc)[:, :v.rows].contiguous().view(-1).cpu().numpy()
+    _check(got, Co, bound, "16-bit, ldb 2^23")
+    assert float(Ct.view(n, ldc)[:, v.rows:v.rows + 8].min()) == 3.0          # nothing written outside the rows of C
+    monkeypatch.setenv("SPARTA_H16_PATH", "lds")
+    with pytest.raises(sa.SpartaError):
+        d.spmm(Bt, Ct, n, ldb=ldb, ldc=ldc)
+    del Bt, Ct
+    torch.cuda.empty_cache()
