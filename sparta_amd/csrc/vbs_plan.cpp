@@ -54,7 +54,10 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
         hipDeviceProp_t prop;
         int cus = 256;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        int per_cu = 2;
+        // workers (persistent workgroups) per CU: fp32 two -- the MFMAs of one hide the loads of the other (one: 60.8 us against 54 on the flagship);
+        // 16-bit ONE -- these kernels are bound by the L2 / HBM side, a second workgroup per CU only adds cache pressure (flagship 23.4 -> 23.1 us, 64 x 64
+        // blocks 23.8 -> 23.1, N = 256 46.7 -> 42.9, banded 32.2 -> 30.6; three: slower still) and 256 workers balance better than 512
+        int per_cu = h16 ? 1 : 2;
         if (const char* e = std::getenv("SPARTA_WORKERS_PER_CU")) per_cu = std::max(1, std::min(3, atoi(e)));
         n_workers = ((cus * per_cu + 7) / 8) * 8;
         // modelled cost of a step and of a tile's epilogue, per type
