@@ -307,6 +307,10 @@ __global__ __launch_bounds__(kThreads) void b_to_row_major_kernel(const E* __res
     }
 }
 
+// Measured and dropped (round 2): a 16-bit variant with 8-byte loads (4 rows of a column per thread) and 16-byte stores (16 columns of a row) --
+// 4 + 2 accesses per thread instead of 16 + 16 two-byte ones.  R-MAT 2^20 bf16 N = 512: 4.36 / 4.37 ms with it, 4.33 ms without; ogbn-shaped: 10.73 /
+// 10.70 against 10.59 ms.  The transpose is not bound by the width of its accesses.
+
 // ---- row-block pack (multi-GPU exchange of only the needed rows of B) ---------------------------------
 // dst chunk i <- src chunk ids[i]; a chunk is one w x N tile of B (block_bytes, a multiple of 16).  One workgroup per
 // chunk and grid.y slice; 16-byte loads / stores, fully coalesced: HBM-bound, bytes = 2 x n_blocks x block_bytes.
