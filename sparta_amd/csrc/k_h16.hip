@@ -327,9 +327,23 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
 // Loads run three steps ahead (A: four register sets, B: two staging sets + two LDS stages); step records: one window VGPR,
 // constant-lane v_readlane.  Same plans, accumulator layout, epilogue and fix-up as the other stream kernels.
 // =====================================================================================================
-template <int KP, bool MI2, bool BF16, bool GATHERED, bool CSTAGE = false>
+#ifndef SPARTA_H16_PROBE
+#define SPARTA_H16_PROBE 0        /* developer probes, TIMING ONLY (results wrong): 1 no B loads, 2 no A loads, 4 no epilogue, 8 no LDS round trip, 64 every tile stores to the first rows of C, 128 every step reads the first slice of A, 256 every step reads the first rows of B */
+#endif
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+// DEEP: loads 7 steps ahead of their MFMAs instead of 3 (eight A sets, six live B staging sets, two record windows, rounds of eight steps).  A 16-bit
+// step of a 32-wide block is two MFMAs (64 cycles) and ~300 cycles of a wave's time: three steps ahead are ~0.4 us, less than a loaded HBM access.
+// TAIL = false: no block column hangs over the last row of B (cols % w == 0), the steps never read B_tail -- with the slices of A in step order
+// (vbs_plan.cpp) a step then costs 30 scalar / vector instructions around its loads and MFMAs instead of 50, and ONE wave per SIMD issues one
+// instruction per ~5 cycles: with neither A nor B loaded the flagship's kernel still took 11.9 of its 22.2 us (SPARTA_H16_PROBE = 3).
+template <int KP, bool MI2, bool BF16, bool GATHERED, bool CSTAGE = false, bool DEEP = false, bool TAIL = true>
 __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const StreamParams p) {
     static_assert(!(CSTAGE && MI2), "the C ring holds 64 rows: tiles of <= 32 rows only");
+    constexpr int D = DEEP ? 7 : 3;                      // steps between a step's loads and its MFMAs
     constexpr int TN = kTN, TM = MI2 ? 64 : 32;
     constexpr int NK = KP / 16;                          // MFMAs (k groups of 16) per step and 32-row tile = 16-byte loads per lane and operand
     constexpr int NA = MI2 ? 2 : 1;
@@ -355,8 +369,9 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
     // step records: one window of 8 (lane = 8 * record + field) per round of four steps, see vbs_spmm_f32_direct_kernel
     const int32_t* srec = reinterpret_cast<const int32_t*>(p.steps + s_begin);
     int vwin = srec[lane];
+    int vwin1 = DEEP ? srec[64 + lane] : 0;              // DEEP: the following eight records (positions 8 .. 15)
     int vnext = 0;
-#define field(pos, f) __builtin_amdgcn_readlane(vwin, 8 * (pos) + (f))
+#define field(pos, f) ((pos) < 8 ? __builtin_amdgcn_readlane(vwin, 8 * ((pos) & 7) + (f)) : __builtin_amdgcn_readlane(vwin1, 8 * ((pos) & 7) + (f)))
     enum { F_AOFF_LO = 0, F_AOFF_HI = 1, F_BROW = 2, F_H = 3, F_CROW = 4, F_FLAGS = 5, F_SLOT = 6, F_SHARD = 7 };
 
     const int bc = lane / LPC, bk = (lane % LPC) * 8;    // B load q: column CPI q + bc of the wave's 32, k = bk .. bk + 7
@@ -382,27 +397,25 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
     ASet as0, as1, as2, as3;                             // A fragments of the steps i mod 4
     BSet bs0, bs1;                                       // B staging (steps of even / odd index)
 
-    int64_t g_aoff = 0;
+    // the slices of A are laid out in step order: one running offset, taken from the first record of the range
+    int64_t g_aoff = ((int64_t)(uint32_t)field(0, F_AOFF_LO) | ((int64_t)field(0, F_AOFF_HI) << 32)) - (int64_t)TM * KP;
     uint32_t vo_cur = voffB;
     int32_t tail_prev = 0;
     auto issue_loads = [&](auto pos_tag, BSet& rb, ASet& ra) __attribute__((always_inline)) -> int32_t {
         constexpr int s = decltype(pos_tag)::value;      // position of the step's record in the window
         const int32_t flags = field(s, F_FLAGS);
-        if (flags & STEP_FIRST) g_aoff = (int64_t)(uint32_t)field(s, F_AOFF_LO) | ((int64_t)field(s, F_AOFF_HI) << 32);
-        else g_aoff += (int64_t)TM * KP;                 // the slices of a tile are back to back
-        const int32_t tail = (flags & STEP_TAIL) != 0;
+        g_aoff += (int64_t)TM * KP;
+        const int32_t tail = TAIL && (flags & STEP_TAIL) != 0;
         if (tail != tail_prev) {
             vo_cur = tail ? voffBt : voffB;
             asm volatile("" : "+v"(vo_cur));
             tail_prev = tail;
         }
-        const int64_t gk0 = field(s, F_BROW);
+        const int64_t gk0 = (SPARTA_H16_PROBE & 256) ? 0 : field(s, F_BROW);
         const uint16_t* bptr = tail ? Bt16 + gk0 : B16 + (GATHERED ? (int64_t)field(s, F_SHARD) * p.shard_stride : (int64_t)0) + gk0 + n0off;
         const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(bptr), 0, 0x7ffffff0, 0x00020000);
         const uint32_t qs = tail ? qstepBt : qstepB;
-#ifndef SPARTA_H16_PROBE
-#define SPARTA_H16_PROBE 0        /* developer probes, TIMING ONLY (results wrong): 1 no B loads, 2 no A loads, 4 no epilogue, 8 no LDS round trip */
-#endif
+        if (SPARTA_H16_PROBE & 128) g_aoff = 0;
         if (!(SPARTA_H16_PROBE & 1)) {
 #pragma unroll
             for (int q = 0; q < NK; q++) rb.b[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, qs * q, 0);
@@ -432,25 +445,25 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
 
     int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq_new = 0;
     // one step (index i mod 4 = u): fragments of B from LDS stage u & 1, the next step's panel into the other stage, the MFMAs, the
-    // tile epilogue if it ends here, then staging set nb and A set na are refilled with step i + 3
-    auto step = [&](auto u_tag, int32_t flags, ASet& wa, BSet& nb, ASet& na) __attribute__((always_inline)) {
+    // tile epilogue if it ends here, then staging set nb and A set na are refilled with step i + D (wb = the set that holds step i + 1: the same as nb for D = 3)
+    auto step = [&](auto u_tag, int32_t flags, ASet& wa, BSet& wb, BSet& nb, ASet& na) __attribute__((always_inline)) {
         constexpr int i = decltype(u_tag)::value;
         constexpr int PAR = i & 1;
         u32x4 fb[NK];
         if (SPARTA_H16_PROBE & 8) {
 #pragma unroll
-            for (int q = 0; q < NK; q++) fb[q] = nb.b[q];
+            for (int q = 0; q < NK; q++) fb[q] = wb.b[q];
         } else {
 #pragma unroll
             for (int q = 0; q < NK; q++) fb[q] = *reinterpret_cast<const u32x4*>(ldsw + lrB + PAR * WSTAGE + q * 32);
-            write_b(std::integral_constant<int, 1 - PAR>{}, nb);         // W(i + 1)
+            write_b(std::integral_constant<int, 1 - PAR>{}, wb);         // W(i + 1)
         }
 #pragma unroll
         for (int q = 0; q < NK; q++) {
             mfma(fb[q], wa.a[0][q], acc0);
             if constexpr (MI2) mfma(fb[q], wa.a[1][q], acc1);
         }
-        fq_new = issue_loads(std::integral_constant<int, i + 3>{}, nb, na);   // G(i + 3)
+        fq_new = issue_loads(std::integral_constant<int, i + D>{}, nb, na);   // G(i + D)
         if ((flags & STEP_LAST) && !(SPARTA_H16_PROBE & 4)) {
             if (flags & STEP_SPLIT) {
                 const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_SLOT) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
                 if constexpr (CSTAGE) cr.park(p, nw, lm, g, voffC, acc0, field(i, F_CROW), flags & 0xffff);
             } else {
                 const int mt = flags & 0xffff;
-                const int64_t c_row = field(i, F_CROW);
+                const int64_t c_row = (SPARTA_H16_PROBE & 64) ? 0 : field(i, F_CROW);
                 float* cbase = p.c_row_major ? p.C + c_row * p.ldc + nw : p.C + c_row + (int64_t)nw * p.ldc;
                 const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
                 const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;
@@ -509,32 +522,76 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
         const int32_t* nb = srec + (int64_t)(i + 4) * 8 + lane;
         asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
     };
-    fq0 = issue_loads(c0{}, bs0, as0);
-    fq1 = issue_loads(c1{}, bs1, as1);
-    write_b(c0{}, bs0);                                  // W(0)
-    fq2 = issue_loads(c2{}, bs0, as2);
-    const int n4 = n & ~3;
-    for (int i = 0; i < n4; i += 4) {
-        if (i > 0) window_swap();
-        window_request(i);
-        step(c0{}, fq0, as0, bs1, as3);
-        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-        step(c1{}, fq0, as1, bs0, as0);
-        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-        step(c2{}, fq0, as2, bs1, as1);
-        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-        step(c3{}, fq0, as3, bs0, as2);
-        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-    }
-    if (n > n4) {
-        if (n4 > 0) window_swap();
-        step(c0{}, fq0, as0, bs1, as3);
-        fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-        if (n - n4 >= 2) {
-            step(c1{}, fq0, as1, bs0, as0);
+    if constexpr (DEEP) {
+        // step i: LDS stage i & 1, A set i & 7; writes out staging set (i + 1) & 7 and fills staging set and A set (i + 7) & 7 with step i + 7.  Records:
+        // window 0 = [8 k, 8 k + 8), window 1 = the next eight (step i + 7 is position 7 of window 0 or 0 .. 6 of window 1); the window after that
+        // is requested at the head of a round and swapped in at the head of the next (8 steps' loads are issued in between, memory returns in order:
+        // the wait below leaves the loads of seven steps in flight)
+        constexpr int kLoadsAhead = D * NK * (1 + NA);
+        static_assert(kLoadsAhead <= 63, "vmcnt holds 6 bits");
+        ASet asd[8];
+        BSet bsd[8];
+        int32_t fqd[8];
+        auto swap8 = [&]() __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(vnext) : "n"(kLoadsAhead) : "memory");
+            vwin = vwin1;
+            vwin1 = vnext;
+        };
+        auto request8 = [&](int i) __attribute__((always_inline)) {
+            const int32_t* nb = srec + (int64_t)(i + 16) * 8 + lane;
+            asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
+        };
+        static_for<0, 7>([&](auto j) __attribute__((always_inline)) { fqd[j] = issue_loads(j, bsd[j], asd[j]); });
+        write_b(c0{}, bsd[0]);                           // W(0)
+        const int n8 = n & ~7;
+        for (int i = 0; i < n8; i += 8) {
+            if (i > 0) swap8();
+            request8(i);
+            static_for<0, 8>([&](auto u) __attribute__((always_inline)) {
+                constexpr int U = decltype(u)::value;
+                step(u, fqd[U], asd[U], bsd[(U + 1) & 7], bsd[(U + 7) & 7], asd[(U + 7) & 7]);
+                fqd[(U + 7) & 7] = fq_new;
+            });
+        }
+        if (n > n8) {
+            if (n8 > 0) swap8();
+            const int r = n - n8;
+            static_for<0, 7>([&](auto u) __attribute__((always_inline)) {
+                constexpr int U = decltype(u)::value;
+                if (U < r) {
+                    step(u, fqd[U], asd[U], bsd[(U + 1) & 7], bsd[(U + 7) & 7], asd[(U + 7) & 7]);
+                    fqd[(U + 7) & 7] = fq_new;
+                }
+            });
+        }
+    } else {
+        fq0 = issue_loads(c0{}, bs0, as0);
+        fq1 = issue_loads(c1{}, bs1, as1);
+        write_b(c0{}, bs0);                                  // W(0)
+        fq2 = issue_loads(c2{}, bs0, as2);
+        const int n4 = n & ~3;
+        for (int i = 0; i < n4; i += 4) {
+            if (i > 0) window_swap();
+            window_request(i);
+            step(c0{}, fq0, as0, bs1, bs1, as3);
+            fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+            step(c1{}, fq0, as1, bs0, bs0, as0);
+            fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+            step(c2{}, fq0, as2, bs1, bs1, as1);
+            fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+            step(c3{}, fq0, as3, bs0, bs0, as2);
             fq0 = fq1; fq1 = fq2; fq2 = fq_new;
         }
-        if (n - n4 == 3) step(c2{}, fq0, as2, bs1, as1);
+        if (n > n4) {
+            if (n4 > 0) window_swap();
+            step(c0{}, fq0, as0, bs1, bs1, as3);
+            fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+            if (n - n4 >= 2) {
+                step(c1{}, fq0, as1, bs0, bs0, as0);
+                fq0 = fq1; fq1 = fq2; fq2 = fq_new;
+            }
+            if (n - n4 == 3) step(c2{}, fq0, as2, bs1, bs1, as1);
+        }
     }
     if constexpr (CSTAGE) cr.flush(p, nw, lm, g, voffC, true);
     clock_probe(p.clk, 2);
@@ -593,21 +650,35 @@ bool h16_direct(int kp, bool mi2) {
     if (e && e[0] == 'l') return false;
     return true;
 }
+// SPARTA_H16_AHEAD=7: the <= 32-row tiles of 32-wide blocks load seven steps ahead instead of three (DEEP).  Measured on the flagship, interleaved
+// runs: 22.9 -> 22.1 us while a step still cost 50 instructions, 21.3 -> 21.8 us since it costs 26 (TAIL = false, slices in step order); banded 200k
+// through the C ring 30.7 -> 31.4 us.  Off by default; read per launch (scripts flip it between timings).
+bool h16_ahead7() { const char* e = std::getenv("SPARTA_H16_AHEAD"); return e && atoi(e) == 7; }
+template <int KP, bool MI2, bool GATHERED, bool CSTAGE, bool DEEP>
+void launch_h16_direct_v(bool bf16, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (sp.B_tail != nullptr) {                          // some step reads the zero-padded copy of the last rows of B
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, true, GATHERED, CSTAGE, DEEP, true>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, false, GATHERED, CSTAGE, DEEP, true>), grid, dim3(kThreads), 0, st, sp);
+    } else {
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, true, GATHERED, CSTAGE, DEEP, false>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, false, GATHERED, CSTAGE, DEEP, false>), grid, dim3(kThreads), 0, st, sp);
+    }
+}
 template <int KP, bool MI2>
 void launch_h16_direct(bool bf16, bool gathered, bool c_stage, dim3 grid, hipStream_t st, const StreamParams& sp) {
     if constexpr (!MI2) {
-        if (c_stage && !gathered) {                      // tiles of arbitrary height, column-major C: through the C ring
-            if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, false, true, false, true>), grid, dim3(kThreads), 0, st, sp);
-            else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, false, false, false, true>), grid, dim3(kThreads), 0, st, sp);
-            return;
+        if (c_stage && !gathered) {                      // tiles of arbitrary height, column-major C: through the C ring (short tiles: seven steps ahead
+            launch_h16_direct_v<KP, false, false, true, false>(bf16, grid, st, sp);     // measured slower there, banded 200k 31.4 against 30.7 us)
+        } else if (gathered) {
+            launch_h16_direct_v<KP, false, true, false, false>(bf16, grid, st, sp);
+        } else {
+            constexpr bool kCanDeep = KP == 32;          // (64-wide blocks: eight A sets + eight staging sets are 256 registers)
+            if (kCanDeep && h16_ahead7()) launch_h16_direct_v<KP, false, false, false, kCanDeep>(bf16, grid, st, sp);
+            else launch_h16_direct_v<KP, false, false, false, false>(bf16, grid, st, sp);
         }
-    }
-    if (gathered) {
-        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, true, true>), grid, dim3(kThreads), 0, st, sp);
-        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, false, true>), grid, dim3(kThreads), 0, st, sp);
     } else {
-        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, true, false>), grid, dim3(kThreads), 0, st, sp);
-        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, false, false>), grid, dim3(kThreads), 0, st, sp);
+        if (gathered) launch_h16_direct_v<KP, true, true, false, false>(bf16, grid, st, sp);
+        else launch_h16_direct_v<KP, true, false, false, false>(bf16, grid, st, sp);
     }
 }
 template <int KP, bool MI2>

@@ -91,8 +91,21 @@ def test_steady_state_of_the_one_tile_kernels_keeps_its_prefetch_and_its_valu_bu
     window swap), register moves within the epilogue's budget, step waits that leave the loads of the following steps in flight."""
     ks = _disassemble(tmp_path)
     f32 = [t for n, t in ks.items() if "vbs_spmm_f32_direct_kernelILb0E" in n]      # (the instantiation without the C ring: the flagship's)
-    h16 = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0EEEvN10sparta_dev" in n]      # (<32, one tile, *, *, CSTAGE = false>: without the C ring)
-    assert len(f32) == 1 and len(h16) >= 4, sorted(ks)[:8]
+    h16 = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb0ELb1EEEvN10sparta_dev" in n]      # (<32, one tile, *, *, CSTAGE = false, DEEP = false, TAIL = true>)
+    h16_deep = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb1ELb0EEEvN10sparta_dev" in n]  # (the same seven steps ahead, TAIL = false: the flagship's)
+    assert len(f32) == 1 and len(h16) >= 4 and len(h16_deep) == 2, sorted(ks)[:8]
+    for txt in h16_deep:
+        ins = [l.split("//")[0].strip() for l in txt.splitlines() if l.startswith(("\t", " "))]
+        ins = [i for i in ins if i]
+        assert not any(i.startswith("scratch_") for i in ins)
+        steps = sum(i.startswith("v_mfma") for i in ins) / 2          # a round of 8 + up to 7 peeled
+        assert steps == 15, steps
+        n_mov = sum(2 if i.startswith("v_mov_b64") else 1 for i in ins if i.startswith("v_mov_b"))
+        assert n_mov <= 32 * steps, (n_mov, steps)
+        waits = [int(m.group(1)) for i in ins for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", i)] if m]
+        # the step waits of the round leave the loads of five steps and more in flight (two waits per step: one per LDS write)
+        assert sum(w >= 20 for w in waits) >= 2 * 8, waits
+        assert sum(w == 0 for w in waits) <= 1.5 * steps, waits
     for txt, n_mfma_step, loads_per_step in [(f32[0], 16, 8)] + [(t, 2, 4) for t in h16]:
         ins = [l.split("//")[0].strip() for l in txt.splitlines() if l.startswith(("\t", " "))]
         ins = [i for i in ins if i]
