@@ -13,9 +13,11 @@ for e in old["lines"]:
         print("kept the old line of", e["file"], "(", ex, ")")
         line = e["line"]
     lines.append({"config": e["config"], "file": e["file"], "line": line})
-note = ("one bench.py JSON line per BASELINE config / arm, MI355X (one GPU box per gpurun call), end of round 2 (kernel revision r2b: no-barrier one-tile "
-        "kernels, longest-tile-first dealing, per-block tile / sparse-row split of sparta_vbs_create_from_csr).  The first half of the round measured, with kernel "
-        "revision r2a: driver command 59.8 us / 0.626, f16 36.5 us / 0.318, ogbn-like 11.5-13.2 ms, 0.012 % 21.5 / 21.5 ms, 0.1 % 182 / 201 ms.")
+note = ("one bench.py JSON line per BASELINE config / arm, MI355X (one GPU box per gpurun call: the c1 / c2 lines come from one box, the others from another), end of "
+        "round 2 (kernel revision r2c: no-barrier one-tile kernels, longest-tile-first dealing, per-block tile / sparse-row split of sparta_vbs_create_from_csr, "
+        "TAIL-free instantiations, 16-bit slices of A in step order).  Box to box the same binary spreads: fp32 flagship 48.7-49.8 us at 2000 steps, ogbn-like "
+        "10.3-11.7 ms (two groups of boxes, ~10.5 and ~11.6).  Earlier in the round: r2b flagship 49.3-49.9 us, f16 22.8-23.0 us; r2a driver command 59.8 us / "
+        "0.626, f16 36.5 us / 0.318, ogbn-like 11.5-13.2 ms, 0.012 % 21.5 / 21.5 ms, 0.1 % 182 / 201 ms.")
 json.dump({"note": note, "commands": old["commands"], "lines": lines}, open(path, "w"), indent=1)
 for l in lines:
     L = l["line"]

@@ -26,7 +26,9 @@ namespace {
 // Column-major B only, no gathered B; tiles of <= 32 rows (the one-tile plan).
 // =====================================================================================================
 // CSTAGE (column-major C, tiles of arbitrary height): finished tiles are parked in the C ring (vbs_kernel_common.hpp, CRing) and stored as aligned blocks.
-template <bool CSTAGE>
+// TAIL = false: no block column hangs over the last row of B (cols % w == 0, B_tail is never read): the choice between B and B_tail -- a dozen scalar
+// instructions per step -- folds away (see vbs_spmm_h16_direct_kernel).
+template <bool CSTAGE, bool TAIL = true>
 __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const StreamParams p) {
     constexpr int TN = kTN, LDBW = 36;                  // Bs[column][k], 32 k + 4 padding: conflict-free ds_read_b128 / ds_write_b128
     constexpr int WSTAGE = 32 * LDBW;                   // floats per wave and stage
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
     auto issue_loads = [&](auto pos_tag, u32x4 (&rb)[4], u32x4 (&ra)[4]) __attribute__((always_inline)) -> int32_t {
         constexpr int s = decltype(pos_tag)::value;      // position of the step's record in the window
         const int32_t flags = field(s, F_FLAGS);
-        const int32_t tail = (flags & STEP_TAIL) != 0;
+        const int32_t tail = TAIL && (flags & STEP_TAIL) != 0;
         if (tail != tail_prev) {
             vo_cur = tail ? voffBt : voffB;
             asm volatile("" : "+v"(vo_cur));
@@ -240,8 +242,14 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
 namespace sparta_dev {
 
 void launch_f32_direct(bool c_stage, dim3 grid, hipStream_t st, const StreamParams& sp) {
-    if (c_stage) hipLaunchKernelGGL(vbs_spmm_f32_direct_kernel<true>, grid, dim3(kThreads), 0, st, sp);
-    else hipLaunchKernelGGL(vbs_spmm_f32_direct_kernel<false>, grid, dim3(kThreads), 0, st, sp);
+    static const bool lean_off = [] { const char* e = std::getenv("SPARTA_F32_TAILFREE"); return e && atoi(e) == 0; }();     // (A/B runs)
+    if (sp.B_tail != nullptr || lean_off) {
+        if (c_stage) hipLaunchKernelGGL((vbs_spmm_f32_direct_kernel<true, true>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_f32_direct_kernel<false, true>), grid, dim3(kThreads), 0, st, sp);
+    } else {
+        if (c_stage) hipLaunchKernelGGL((vbs_spmm_f32_direct_kernel<true, false>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_f32_direct_kernel<false, false>), grid, dim3(kThreads), 0, st, sp);
+    }
 }
 
 }  // namespace sparta_dev

@@ -93,7 +93,7 @@ def test_steady_state_of_the_one_tile_kernels_keeps_its_prefetch_and_its_valu_bu
     f32 = [t for n, t in ks.items() if "vbs_spmm_f32_direct_kernelILb0E" in n]      # (the instantiation without the C ring: the flagship's)
     h16 = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb0ELb1EEEvN10sparta_dev" in n]      # (<32, one tile, *, *, CSTAGE = false, DEEP = false, TAIL = true>)
     h16_deep = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb1ELb0EEEvN10sparta_dev" in n]  # (the same seven steps ahead, TAIL = false: the flagship's)
-    assert len(f32) == 1 and len(h16) >= 4 and len(h16_deep) == 2, sorted(ks)[:8]
+    assert len(f32) == 2 and len(h16) >= 4 and len(h16_deep) == 2, sorted(ks)[:8]      # (f32: TAIL = true / false)
     for txt in h16_deep:
         ins = [l.split("//")[0].strip() for l in txt.splitlines() if l.startswith(("\t", " "))]
         ins = [i for i in ins if i]
@@ -106,7 +106,7 @@ def test_steady_state_of_the_one_tile_kernels_keeps_its_prefetch_and_its_valu_bu
         # the step waits of the round leave the loads of five steps and more in flight (two waits per step: one per LDS write)
         assert sum(w >= 20 for w in waits) >= 2 * 8, waits
         assert sum(w == 0 for w in waits) <= 1.5 * steps, waits
-    for txt, n_mfma_step, loads_per_step in [(f32[0], 16, 8)] + [(t, 2, 4) for t in h16]:
+    for txt, n_mfma_step, loads_per_step in [(t, 16, 8) for t in f32] + [(t, 2, 4) for t in h16]:
         ins = [l.split("//")[0].strip() for l in txt.splitlines() if l.startswith(("\t", " "))]
         ins = [i for i in ins if i]
         assert not any(i.startswith("scratch_") for i in ins)
@@ -115,7 +115,7 @@ def test_steady_state_of_the_one_tile_kernels_keeps_its_prefetch_and_its_valu_bu
         assert 7 <= steps <= 12, steps
         # register moves: 16 copies + 16 clears per epilogue body (v_mov_b64 counts two), nothing per step
         n_mov = sum(2 if i.startswith("v_mov_b64") else 1 for i in ins if i.startswith("v_mov_b"))
-        assert n_mov <= 32 * steps, (n_mov, steps)                    # (28 per body today)
+        assert n_mov <= 34 * steps, (n_mov, steps)                    # (28 per body with TAIL, 32 without: measured 1 % faster all the same)
         # full waits: only in the epilogue bodies' C += path (one per body)
         n_full = sum(bool(re.match(r"s_waitcnt vmcnt\(0\)", i)) for i in ins)
         assert n_full <= 1.5 * steps, (n_full, steps)                 # (13 in 11 bodies today)
