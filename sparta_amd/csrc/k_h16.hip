@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
 // constant-lane v_readlane.  Same plans, accumulator layout, epilogue and fix-up as the other stream kernels.
 // =====================================================================================================
 #ifndef SPARTA_H16_PROBE
-#define SPARTA_H16_PROBE 0        /* developer probes, TIMING ONLY (results wrong): 1 no B loads, 2 no A loads, 4 no epilogue, 8 no LDS round trip, 64 every tile stores to the first rows of C, 128 every step reads the first slice of A, 256 every step reads the first rows of B */
+#define SPARTA_H16_PROBE 0        /* developer probes, TIMING ONLY (results wrong): 1 no B loads, 2 no A loads, 4 no epilogue, 8 no LDS round trip, 64 every tile stores to the first rows of C, 128 every step reads the first slice of A, 256 every step reads the first rows of B, 512 one store per tile instead of 16 (non-temporal path) */
 #endif
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
                         }
                         if (p.c_nt) {
 #pragma unroll
-                            for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 2);
+                            for (int q = 0; q < ((SPARTA_H16_PROBE & 512) ? 1 : 16); q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 2);
                         } else {
 #pragma unroll
                             for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
