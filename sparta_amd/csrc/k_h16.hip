@@ -340,9 +340,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 // TAIL = false: no block column hangs over the last row of B (cols % w == 0), the steps never read B_tail -- with the slices of A in step order
 // (vbs_plan.cpp) a step then costs 30 scalar / vector instructions around its loads and MFMAs instead of 50, and ONE wave per SIMD issues one
 // instruction per ~5 cycles: with neither A nor B loaded the flagship's kernel still took 11.9 of its 22.2 us (SPARTA_H16_PROBE = 3).
-template <int KP, bool MI2, bool BF16, bool GATHERED, bool CSTAGE = false, bool DEEP = false, bool TAIL = true>
+// WC = 64 (one-tile plans of 32-wide blocks, vbs_plan.cpp `wide16`): a wave owns 64 columns of the slab, the workgroup's wave pairs (0, 1) and (2, 3) are two
+// SUB-WORKERS with their own step ranges -- two tiles per CU at a time, the slice of A through L1 twice instead of four times, and the ~20 instructions a
+// step spends on records, addresses and waits pay for four MFMAs instead of two.  Nothing else changes: there is no barrier for the pairs to meet at.
+template <int KP, bool MI2, bool BF16, bool GATHERED, bool CSTAGE = false, bool DEEP = false, bool TAIL = true, int WC = 32>
 __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const StreamParams p) {
     static_assert(!(CSTAGE && MI2), "the C ring holds 64 rows: tiles of <= 32 rows only");
+    static_assert(WC == 32 || (WC == 64 && !MI2 && !CSTAGE && !DEEP), "64-column waves: the one-tile kernel without ring, three steps ahead");
+    constexpr int NG = WC / 32;                          // column groups of 32 per wave
     constexpr int D = DEEP ? 7 : 3;                      // steps between a step's loads and its MFMAs
     constexpr int TN = kTN, TM = MI2 ? 64 : 32;
     constexpr int NK = KP / 16;                          // MFMAs (k groups of 16) per step and 32-row tile = 16-byte loads per lane and operand
@@ -351,14 +356,17 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
     constexpr int CPI = 64 / LPC;                        // columns per wave instruction: 16 or 8 (NK instructions cover the wave's 32)
     constexpr int RB = (KP + 8) * 2;                     // bytes per column of the LDS image (8 elements of padding: conflict-free b128)
     constexpr int WSTAGE = 32 * RB;                      // bytes per wave and stage
-    __shared__ __attribute__((aligned(16))) char lds[4 * 2 * WSTAGE + (CSTAGE ? 4 * kCRingFloats * 4 : 0)];
+    __shared__ __attribute__((aligned(16))) char lds[4 * 2 * NG * WSTAGE + (CSTAGE ? 4 * kCRingFloats * 4 : 0)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int lm = lane & 31, g = lane >> 5;
     const int n0 = blockIdx.y * TN;
-    const int s_begin = p.worker_range[2 * blockIdx.x];
-    const int n = p.worker_range[2 * blockIdx.x + 1] - s_begin;
+    // WC = 64: sub-worker (wave >> 1) of this workgroup, wave (wave & 1) of its two
+    const int worker = WC == 64 ? 2 * (int)blockIdx.x + __builtin_amdgcn_readfirstlane(wave >> 1) : (int)blockIdx.x;
+    const int wv = WC == 64 ? (wave & 1) : wave;
+    const int s_begin = p.worker_range[2 * worker];
+    const int n = p.worker_range[2 * worker + 1] - s_begin;
     if (n <= 0) return;
     clock_probe(p.clk, 0);
     float* ws = p.ws + (int64_t)blockIdx.y * p.ws_slab_stride;
@@ -378,22 +386,23 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
     const int64_t ld_t = (int64_t)p.w;                   // leading dimension of B_tail
     // this wave's 32 columns start at column nw of B / C: folded into the SCALAR bases, so that the 32-bit per-lane offsets only span 32 columns
     // (a column-major B or C with a leading dimension of 2^23 -- configs[4] on one GPU -- is 2 GB per 128 columns, beyond a 32-bit offset)
-    const int nw = n0 + 32 * __builtin_amdgcn_readfirstlane(wave);
+    const int nw = n0 + WC * __builtin_amdgcn_readfirstlane(wv);
     const uint32_t voffB = (uint32_t)((bc * p.ldb + bk) * 2);
-    const uint32_t voffBt = (uint32_t)(((n0 + 32 * wave + bc) * ld_t + bk) * 2);
+    const uint32_t voffBt = (uint32_t)(((n0 + WC * wv + bc) * ld_t + bk) * 2);
     const uint32_t qstepB = (uint32_t)(CPI * p.ldb * 2), qstepBt = (uint32_t)(CPI * ld_t * 2);      // bytes from one column group to the next
+    const uint32_t gstepB = (uint32_t)(32 * p.ldb * 2), gstepBt = (uint32_t)(32 * ld_t * 2);        // ... from one group of 32 columns to the next (WC = 64)
     const uint32_t voffA = (uint32_t)((g * TM + lm) * 16);     // slice in memory: [k chunk = 2 q + g][row][8]: a wave load is one (TM = 32) or two contiguous pieces
     const int64_t n0off = (int64_t)nw * p.ldb;
     const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 4 * g) * 4) : (uint32_t)((lm + (4 * g) * p.ldc) * 4);
-    char* const ldsw = lds + wave * (2 * WSTAGE);        // this wave's two stages
+    char* const ldsw = lds + wave * (2 * NG * WSTAGE);   // this wave's two stages (NG images of 32 columns each)
     const uint32_t lwB = (uint32_t)(bc * RB + bk * 2);   // write: column bc + CPI q
     const uint32_t lrB = (uint32_t)(lm * RB + 16 * g);   // read: column lm, k = 16 q + 8 g .. + 7
 
     CRing cr;                                            // CSTAGE: finished tiles wait here for whole aligned blocks of 32 rows (vbs_kernel_common.hpp)
-    cr.ring = reinterpret_cast<float*>(lds + 4 * 2 * WSTAGE) + wave * kCRingFloats;
+    cr.ring = reinterpret_cast<float*>(lds + 4 * 2 * NG * WSTAGE) + wave * kCRingFloats;
 
     struct ASet { u32x4 a[NA][NK]; };
-    struct BSet { u32x4 b[NK]; };
+    struct BSet { u32x4 b[NG * NK]; };
     ASet as0, as1, as2, as3;                             // A fragments of the steps i mod 4
     BSet bs0, bs1;                                       // B staging (steps of even / odd index)
 
@@ -415,10 +424,13 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
         const uint16_t* bptr = tail ? Bt16 + gk0 : B16 + (GATHERED ? (int64_t)field(s, F_SHARD) * p.shard_stride : (int64_t)0) + gk0 + n0off;
         const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(bptr), 0, 0x7ffffff0, 0x00020000);
         const uint32_t qs = tail ? qstepBt : qstepB;
+        const uint32_t gs = tail ? gstepBt : gstepB;
         if (SPARTA_H16_PROBE & 128) g_aoff = 0;
         if (!(SPARTA_H16_PROBE & 1)) {
 #pragma unroll
-            for (int q = 0; q < NK; q++) rb.b[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, qs * q, 0);
+            for (int c = 0; c < NG; c++)
+#pragma unroll
+                for (int q = 0; q < NK; q++) rb.b[c * NK + q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, gs * c + qs * q, 0);
         }
         const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A16 + g_aoff), 0, 0x7ffffff0, 0x00020000);
         if (!(SPARTA_H16_PROBE & 2) && !((SPARTA_H16_PROBE & 16) && wave != 0) && !((SPARTA_H16_PROBE & 32) && (wave & 1))) {   // 16: only wave 0 loads A; 32: waves 0 and 2
@@ -432,7 +444,9 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
     auto write_b = [&](auto stage_tag, const BSet& rb) __attribute__((always_inline)) {
         constexpr int ST = decltype(stage_tag)::value;
 #pragma unroll
-        for (int q = 0; q < NK; q++) *reinterpret_cast<u32x4*>(ldsw + lwB + ST * WSTAGE + q * CPI * RB) = rb.b[q];
+        for (int c = 0; c < NG; c++)
+#pragma unroll
+            for (int q = 0; q < NK; q++) *reinterpret_cast<u32x4*>(ldsw + lwB + (ST * NG + c) * WSTAGE + q * CPI * RB) = rb.b[c * NK + q];
     };
 
     f32x16 acc0, acc1;
@@ -449,19 +463,22 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
     auto step = [&](auto u_tag, int32_t flags, ASet& wa, BSet& wb, BSet& nb, ASet& na) __attribute__((always_inline)) {
         constexpr int i = decltype(u_tag)::value;
         constexpr int PAR = i & 1;
-        u32x4 fb[NK];
+        u32x4 fb[NG * NK];
         if (SPARTA_H16_PROBE & 8) {
 #pragma unroll
-            for (int q = 0; q < NK; q++) fb[q] = wb.b[q];
+            for (int q = 0; q < NG * NK; q++) fb[q] = wb.b[q];
         } else {
 #pragma unroll
-            for (int q = 0; q < NK; q++) fb[q] = *reinterpret_cast<const u32x4*>(ldsw + lrB + PAR * WSTAGE + q * 32);
+            for (int c = 0; c < NG; c++)
+#pragma unroll
+                for (int q = 0; q < NK; q++) fb[c * NK + q] = *reinterpret_cast<const u32x4*>(ldsw + lrB + (PAR * NG + c) * WSTAGE + q * 32);
             write_b(std::integral_constant<int, 1 - PAR>{}, wb);         // W(i + 1)
         }
 #pragma unroll
         for (int q = 0; q < NK; q++) {
             mfma(fb[q], wa.a[0][q], acc0);
             if constexpr (MI2) mfma(fb[q], wa.a[1][q], acc1);
+            if constexpr (WC == 64) mfma(fb[NK + q], wa.a[0][q], acc1);   // the wave's second 32 columns (acc1: free in the one-tile kernel)
         }
         fq_new = issue_loads(std::integral_constant<int, i + D>{}, nb, na);   // G(i + D)
         if ((flags & STEP_LAST) && !(SPARTA_H16_PROBE & 4)) {
@@ -469,8 +486,16 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
                 const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_SLOT) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc0[q]), rW, (uint32_t)tid * 4u, (uint32_t)(q * kThreads * 4), 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1[q]), rW, (uint32_t)tid * 4u, (uint32_t)((16 + q) * kThreads * 4), 0);
+                    if constexpr (WC == 64) {           // the image is laid out for four waves x 32 columns: this wave fills the places of waves 2 wv and 2 wv + 1; rows 32..63: none
+                        const uint32_t vt = (uint32_t)((2 * wv) * 64 + lane) * 4u;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc0[q]), rW, vt, (uint32_t)(q * kThreads * 4), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1[q]), rW, vt, (uint32_t)(q * kThreads * 4 + 256), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(0u, rW, vt, (uint32_t)((16 + q) * kThreads * 4), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(0u, rW, vt, (uint32_t)((16 + q) * kThreads * 4 + 256), 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc0[q]), rW, (uint32_t)tid * 4u, (uint32_t)(q * kThreads * 4), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1[q]), rW, (uint32_t)tid * 4u, (uint32_t)((16 + q) * kThreads * 4), 0);
+                    }
                 }
             } else if (CSTAGE) {
                 if constexpr (CSTAGE) cr.park(p, nw, lm, g, voffC, acc0, field(i, F_CROW), flags & 0xffff);
@@ -482,24 +507,28 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
                 const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;
                 const uint32_t mistep = p.c_row_major ? (uint32_t)p.ldc * 128u : 128u;
 #pragma unroll
-                for (int mi = 0; mi < (MI2 ? 2 : 1); mi++) {
-                    if (mi * 32 + lm < mt) {
+                for (int mi = 0; mi < ((MI2 || WC == 64) ? 2 : 1); mi++) {     // acc1: rows 32..63 of the tile (MI2) or columns 32..63 of the wave (WC = 64)
+                    // (WC = 64: the second group of 32 columns gets its own scalar base, so that the per-lane offsets keep spanning 32 columns of C)
+                    const uint32_t hstep = WC == 64 ? 0u : mistep;
+                    const __amdgpu_buffer_rsrc_t rCm = (WC == 64 && mi == 1)
+                        ? __builtin_amdgcn_make_buffer_rsrc(p.c_row_major ? cbase + 32 : cbase + 32 * p.ldc, 0, 0x7ffffff0, 0x00020000) : rC;
+                    if ((WC == 64 ? 0 : mi * 32) + lm < mt) {
                         float v[16];
 #pragma unroll
                         for (int q = 0; q < 16; q++) v[q] = mi == 0 ? acc0[q] : acc1[q];
                         if (p.accumulate) {
                             uint32_t old[16];
 #pragma unroll
-                            for (int q = 0; q < 16; q++) old[q] = __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
+                            for (int q = 0; q < 16; q++) old[q] = __builtin_amdgcn_raw_buffer_load_b32(rCm, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * hstep, 0);
 #pragma unroll
                             for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
                         }
                         if (p.c_nt) {
 #pragma unroll
-                            for (int q = 0; q < ((SPARTA_H16_PROBE & 512) ? 1 : 16); q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 2);
+                            for (int q = 0; q < ((SPARTA_H16_PROBE & 512) ? 1 : 16); q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rCm, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * hstep, 2);
                         } else {
 #pragma unroll
-                            for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
+                            for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rCm, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * hstep, 0);
                         }
                     }
                 }
@@ -513,9 +542,10 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
     using c1 = std::integral_constant<int, 1>;
     using c2 = std::integral_constant<int, 2>;
     using c3 = std::integral_constant<int, 3>;
-    // the window of steps [i, i + 4): requested one round earlier (>= 4 x 2 NK loads are issued in between and memory returns in order)
+    // the window of steps [i, i + 4): requested one round earlier (4 x NK (NG + NA) loads are issued in between and memory returns in order)
+    constexpr int kSwapCnt = 2 * NK * (NG + NA) < 63 ? 2 * NK * (NG + NA) : 63;      // the loads of two steps may stay in flight across the swap
     auto window_swap = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(8)" : "+v"(vnext) : : "memory");
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(vnext) : "n"(kSwapCnt) : "memory");
         vwin = vnext;
     };
     auto window_request = [&](int i) __attribute__((always_inline)) {
@@ -654,18 +684,25 @@ bool h16_direct(int kp, bool mi2) {
 // runs: 22.9 -> 22.1 us while a step still cost 50 instructions, 21.3 -> 21.8 us since it costs 26 (TAIL = false, slices in step order); banded 200k
 // through the C ring 30.7 -> 31.4 us.  Off by default; read per launch (scripts flip it between timings).
 bool h16_ahead7() { const char* e = std::getenv("SPARTA_H16_AHEAD"); return e && atoi(e) == 7; }
-template <int KP, bool MI2, bool GATHERED, bool CSTAGE, bool DEEP>
+template <int KP, bool MI2, bool GATHERED, bool CSTAGE, bool DEEP, int WC = 32>
 void launch_h16_direct_v(bool bf16, dim3 grid, hipStream_t st, const StreamParams& sp) {
     if (sp.B_tail != nullptr) {                          // some step reads the zero-padded copy of the last rows of B
-        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, true, GATHERED, CSTAGE, DEEP, true>), grid, dim3(kThreads), 0, st, sp);
-        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, false, GATHERED, CSTAGE, DEEP, true>), grid, dim3(kThreads), 0, st, sp);
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, true, GATHERED, CSTAGE, DEEP, true, WC>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, false, GATHERED, CSTAGE, DEEP, true, WC>), grid, dim3(kThreads), 0, st, sp);
     } else {
-        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, true, GATHERED, CSTAGE, DEEP, false>), grid, dim3(kThreads), 0, st, sp);
-        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, false, GATHERED, CSTAGE, DEEP, false>), grid, dim3(kThreads), 0, st, sp);
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, true, GATHERED, CSTAGE, DEEP, false, WC>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, MI2, false, GATHERED, CSTAGE, DEEP, false, WC>), grid, dim3(kThreads), 0, st, sp);
     }
 }
 template <int KP, bool MI2>
-void launch_h16_direct(bool bf16, bool gathered, bool c_stage, dim3 grid, hipStream_t st, const StreamParams& sp) {
+void launch_h16_direct(bool bf16, bool gathered, bool c_stage, bool wide, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if constexpr (!MI2 && KP == 32) {
+        if (wide) {                                      // the plan holds two sub-worker ranges per workgroup (vbs_plan.cpp, wide16): this kernel and no other
+            if (gathered) launch_h16_direct_v<KP, false, true, false, false, 64>(bf16, grid, st, sp);
+            else launch_h16_direct_v<KP, false, false, false, false, 64>(bf16, grid, st, sp);
+            return;
+        }
+    }
     if constexpr (!MI2) {
         if (c_stage && !gathered) {                      // tiles of arbitrary height, column-major C: through the C ring (short tiles: seven steps ahead
             launch_h16_direct_v<KP, false, false, true, false>(bf16, grid, st, sp);     // measured slower there, banded 200k 31.4 against 30.7 us)
@@ -682,8 +719,8 @@ void launch_h16_direct(bool bf16, bool gathered, bool c_stage, dim3 grid, hipStr
     }
 }
 template <int KP, bool MI2>
-void launch_h16(bool bf16, bool gathered, bool c_stage, dim3 grid, hipStream_t st, const StreamParams& sp) {
-    if (h16_direct(KP, MI2)) { launch_h16_direct<KP, MI2>(bf16, gathered, c_stage, grid, st, sp); return; }
+void launch_h16(bool bf16, bool gathered, bool c_stage, bool wide, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (h16_direct(KP, MI2) || wide) { launch_h16_direct<KP, MI2>(bf16, gathered, c_stage, wide, grid, st, sp); return; }
     if (h16_deep()) launch_h16_d<KP, MI2, true>(bf16, gathered, grid, st, sp);
     else launch_h16_d<KP, MI2, false>(bf16, gathered, grid, st, sp);
 }
@@ -694,9 +731,9 @@ namespace sparta_dev {
 
 bool h16_uses_direct_kernel(int kp, bool mi2) { return h16_direct(kp, mi2); }
 
-void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, bool c_stage, dim3 grid, hipStream_t st, const StreamParams& sp) {
-    if (kp == 64) { if (mi2) launch_h16<64, true>(bf16, gathered, false, grid, st, sp); else launch_h16<64, false>(bf16, gathered, c_stage, grid, st, sp); }
-    else { if (mi2) launch_h16<32, true>(bf16, gathered, false, grid, st, sp); else launch_h16<32, false>(bf16, gathered, c_stage, grid, st, sp); }
+void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, bool c_stage, bool wide, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (kp == 64) { if (mi2) launch_h16<64, true>(bf16, gathered, false, false, grid, st, sp); else launch_h16<64, false>(bf16, gathered, c_stage, false, grid, st, sp); }
+    else { if (mi2) launch_h16<32, true>(bf16, gathered, false, false, grid, st, sp); else launch_h16<32, false>(bf16, gathered, c_stage && !wide, wide, grid, st, sp); }
 }
 
 void launch_tail_copy_h16(hipStream_t st, const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N, uint16_t* B_tail) {

@@ -426,6 +426,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             v->h_steps[ty] = st;
             v->n_plan_tiles[ty] = plan.n_plan_tiles[ty];
             v->tiles_row_aligned[ty] = plan.tiles_row_aligned[ty];
+            if (ty == 0) v->wide16 = plan.wide16;
             CREATE_TRY(hipMalloc((void**)&v->d_wrange[ty], wrange[ty].size() * sizeof(int32_t)));
             CREATE_TRY(hipMemcpy(v->d_wrange[ty], wrange[ty].data(), wrange[ty].size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
@@ -764,13 +765,15 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
     } else if (ldb % 2 != 0) {
         return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit B needs an even leading dimension (16-byte loads start on 4-byte boundaries)");
     }
-    // 32-bit byte offsets: the no-barrier kernel keeps them inside ONE WAVE's 32 columns (31 x ld x element size < 2^31: ldb < 34 M, ldc < 17 M elements);
+    // 32-bit byte offsets: the no-barrier kernel keeps them inside ONE WAVE's 32 columns (31 x ld x element size < 2^31: ldb < 34 M, ldc < 17 M elements;
+    // its 64-column waves span 64 columns of B: ldb < 16 M);
     // the LDS-staged kernel (SPARTA_H16_PATH=lds) inside the 128-column slab (ldb < 8.3 M, ldc < 4.1 M)
     {
-        const int64_t span = h16_uses_direct_kernel(A->kp16, false) ? 32 : 128;
-        if (ldb16 * span * 2 >= ((int64_t)1 << 31) - 65536 || (c_layout == SPARTA_ROW_MAJOR ? ldc * 32 : ldc * span) * 4 >= ((int64_t)1 << 31) - 65536)
-            return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: leading dimension too large for the 16-bit stream kernels (ldb < 34 M, ldc < 17 M elements; "
-                                                "8.3 M / 4.1 M with SPARTA_H16_PATH=lds)");
+        const bool direct = h16_uses_direct_kernel(A->kp16, false) || A->wide16;
+        const int64_t span_b = A->wide16 ? 64 : direct ? 32 : 128, span_c = direct ? 32 : 128;       // columns a wave's 32-bit offsets span (64-column waves: B only)
+        if (ldb16 * span_b * 2 >= ((int64_t)1 << 31) - 65536 || (c_layout == SPARTA_ROW_MAJOR ? ldc * 32 : ldc * span_c) * 4 >= ((int64_t)1 << 31) - 65536)
+            return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: leading dimension too large for the 16-bit stream kernels (ldb < 34 M -- 16 M for one-tile plans of "
+                                                "32-wide blocks -- and ldc < 17 M elements; 8.3 M / 4.1 M with SPARTA_H16_PATH=lds)");
     }
     if (dt_ms) HIP_TRY(hipEventRecord(A->ev0, st));
     const int n_nt = n_cols / kTN;
@@ -805,7 +808,7 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
             const int cst = [] { const char* e = std::getenv("SPARTA_CSTAGE"); return e ? atoi(e) : -1; }();
             const bool c_stage = ty == 0 && !gth && c_layout == SPARTA_COL_MAJOR && (cst >= 0 ? cst != 0 : ring_tiles(A)) && h16_uses_direct_kernel(A->kp16, false);
             if (c_stage) sp.c_nt = c_store_nt(A, ty, sp.C, sp.ldc, false, true);
-            launch_h16_stream(A->kp16, ty != 0, bf16, gth, c_stage, grid, st, sp);
+            launch_h16_stream(A->kp16, ty != 0, bf16, gth, c_stage, ty == 0 && A->wide16, grid, st, sp);
         }
         if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
     }

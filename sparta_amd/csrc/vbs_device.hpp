@@ -186,6 +186,7 @@ struct sparta_vbs {
     size_t d_ws_bytes = 0;
     int64_t n_plan_tiles[2] = {0, 0};             // see StreamPlanHost
     bool tiles_row_aligned[2] = {true, true};
+    bool wide16 = false;                      // the 16-bit one-tile plan holds two sub-worker ranges per workgroup (vbs_spmm_h16_direct_kernel, WC = 64)
     float* d_a_frag = nullptr;                    // A of the one-tile plan in fragment order (k_f32_direct.hip) or nullptr
     bool has_tail = false;                 // cols % w != 0: the stream path needs B_tail
     void* d_btail = nullptr;
@@ -237,7 +238,7 @@ void launch_fixup(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* f
 void launch_tail_copy(hipStream_t st, const float* B, int64_t ldb, int b_row_major, int64_t row0, int64_t cols, int w, int N, float* B_tail);
 void launch_zero_rows(dim3 grid, hipStream_t st, float* C, int64_t ldc, int c_row_major, int64_t row0, int64_t nrows, int N);
 // k_h16.hip
-void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, bool c_stage, dim3 grid, hipStream_t st, const StreamParams& sp);
+void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, bool c_stage, bool wide, dim3 grid, hipStream_t st, const StreamParams& sp);
 bool h16_uses_direct_kernel(int kp, bool mi2);
 void launch_tail_copy_h16(hipStream_t st, const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N, uint16_t* B_tail);
 void launch_convert_h16(bool bf16, hipStream_t st, const float* src, int64_t ld_in, int64_t rows, int64_t n_cols, uint16_t* dst, int64_t ld_out);
@@ -264,6 +265,7 @@ struct StreamPlanHost {
     std::vector<uint16_t> a16;                // 16-bit handles: A re-laid-out as dense row-major TM x kp slices, one per step
     int n_workers = 0, n_split = 0;
     int plan_aligned[2] = {0, 0};
+    bool wide16 = false;                      // 16-bit one-tile plan with two sub-workers per workgroup (2 x n_workers ranges in wrange[0])
     int64_t kp = SK_KP;
     int64_t n_plan_tiles[2] = {0, 0};         // tiles (with at least one block) per plan: steps per tile decides the cache policy of the C stores
     bool tiles_row_aligned[2] = {true, true}; // every tile of the plan starts at a multiple of 32 rows of C (whole 128-byte lines of a column-major C)

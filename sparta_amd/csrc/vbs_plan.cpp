@@ -160,6 +160,15 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             P.n_plan_tiles[ty] = (int64_t)spans.size();
             for (const TileSpan& sp : spans) if (sp.c_row % 32 != 0) P.tiles_row_aligned[ty] = false;
             if (S == 0) continue;
+            // 16-bit one-tile plans of 32-wide blocks: TWO sub-workers per workgroup (wave pairs (0, 1) and (2, 3), each wave 64 columns of the slab:
+            // vbs_spmm_h16_direct_kernel, WC = 64) unless the plan is a ring plan (short misaligned tiles, see below): 2 x n_workers ranges, sub-worker
+            // s of workgroup g at wrange[2 (2 g + s)].  SPARTA_H16_WIDE=0: four waves x 32 columns on one tile, as every other shape.
+            const bool ring_like = ty == 0 && !P.tiles_row_aligned[ty] && S < 6 * (int64_t)spans.size() &&
+                                   [] { const char* e = std::getenv("SPARTA_CSTAGE"); return !e || atoi(e) != 0; }();
+            const bool wide = h16 && kp == 32 && ty == 0 && !ring_like && [] { const char* e = std::getenv("SPARTA_H16_WIDE"); return !e || atoi(e) != 0; }() &&
+                              [] { const char* e = std::getenv("SPARTA_H16_PATH"); return !(e && e[0] == 'l'); }();     // (the LDS-staged kernel walks one range per workgroup)
+            if (ty == 0) P.wide16 = wide;
+            const int n_workers = wide ? 2 * P.n_workers : P.n_workers;      // (shadows the handle's count inside this plan)
             cum.push_back(total_cost);
             // boundaries: worker (x, j) = the j-th of the P/8 sub-ranges of XCD x's eighth; workgroup id = x + 8 j
             const int per_x = n_workers / 8;
@@ -224,8 +233,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                     // -- and only SHORT tiles (fewer than 6 steps per tile on average: the regime where a step's loads wait for stores): with long tiles
                     // the stores are rare and the longest-first dealing is worth more (cant-like in tiles of 31.99 rows on average: 63.9 us as a ring
                     // plan, 56.5 dealt longest-first with direct stores)
-                    const bool ring_plan = ty == 0 && !P.tiles_row_aligned[ty] && S < 6 * (int64_t)spans.size() &&
-                                           [] { const char* e = std::getenv("SPARTA_CSTAGE"); return !e || atoi(e) != 0; }();
+                    const bool ring_plan = ring_like;
                     if (interleave && !ring_plan) {
                         // Whole tiles can go to any worker.  Keep the 64 workers of an XCD close together in the matrix at every
                         // moment: the XCD takes a contiguous eighth of the tiles (by cost) and deals them, in matrix order, to
@@ -283,7 +291,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             std::vector<int32_t> wid_of_pos((size_t)n_workers);
             for (int pos = 0; pos < n_workers; pos++) {
                 const int x = pos / per_x, j = pos % per_x;
-                const int wid = x + 8 * j;
+                const int wid = wide ? 2 * (x + 8 * (j / 2)) + (j % 2) : x + 8 * j;      // wide: neighbours in the matrix share a workgroup
                 wid_of_pos[(size_t)pos] = wid;
                 wrange[ty][(size_t)wid * 2] = (int32_t)bnd[(size_t)pos];
                 wrange[ty][(size_t)wid * 2 + 1] = (int32_t)bnd[(size_t)pos + 1];

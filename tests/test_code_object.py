@@ -53,6 +53,8 @@ def test_stream_kernels_keep_their_state_in_registers(tmp_path):
         elif "h16_direct_kernel" in name:                                 # 4 waves x 2 stages x 32 columns x (KP + 8) 16-bit elements, private to each wave
             ring = 4 * 32 * 65 * 4                                        # the C ring of the CSTAGE instantiations (tiles of arbitrary height)
             want = {4 * 2 * 32 * (32 + 8) * 2, 4 * 2 * 32 * (32 + 8) * 2 + ring} if "ILi32E" in name else {4 * 2 * 32 * (64 + 8) * 2, 4 * 2 * 32 * (64 + 8) * 2 + ring}
+            if "ELi64EEEvN10sparta_dev" in name:                          # WC = 64: every wave holds the images of its two groups of 32 columns
+                want = {4 * 2 * 64 * (32 + 8) * 2}
         elif "h16_stream_kernel" in name:                                 # 2 stages x (128 + 64) rows x (KP + 8) 16-bit elements
             want = {2 * (128 + 64) * (32 + 8) * 2} if "ILi32E" in name else {2 * (128 + 64) * (64 + 8) * 2}
         else:                                                             # fp32: 2 stages x (B panel [+4 pad when column-major] + 32 x 64 A slice) floats
@@ -91,9 +93,10 @@ def test_steady_state_of_the_one_tile_kernels_keeps_its_prefetch_and_its_valu_bu
     window swap), register moves within the epilogue's budget, step waits that leave the loads of the following steps in flight."""
     ks = _disassemble(tmp_path)
     f32 = [t for n, t in ks.items() if "vbs_spmm_f32_direct_kernelILb0E" in n]      # (the instantiation without the C ring: the flagship's)
-    h16 = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb0ELb1EEEvN10sparta_dev" in n]      # (<32, one tile, *, *, CSTAGE = false, DEEP = false, TAIL = true>)
-    h16_deep = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb1ELb0EEEvN10sparta_dev" in n]  # (the same seven steps ahead, TAIL = false: the flagship's)
-    assert len(f32) == 2 and len(h16) >= 4 and len(h16_deep) == 2, sorted(ks)[:8]      # (f32: TAIL = true / false)
+    h16 = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb0ELb1ELi32EEEvN10sparta_dev" in n]      # (<32, one tile, *, *, CSTAGE = false, DEEP = false, TAIL = true>)
+    h16_deep = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb1ELb0ELi32EEEvN10sparta_dev" in n]  # (the same seven steps ahead, TAIL = false: the flagship's)
+    h16_wide = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb0ELb0ELi64EEEvN10sparta_dev" in n]  # (64-column waves, TAIL = false: the flagship's)
+    assert len(f32) == 2 and len(h16) >= 4 and len(h16_deep) == 2 and len(h16_wide) == 4, sorted(ks)[:8]      # (f32: TAIL = true / false)
     for txt in h16_deep:
         ins = [l.split("//")[0].strip() for l in txt.splitlines() if l.startswith(("\t", " "))]
         ins = [i for i in ins if i]
@@ -106,7 +109,7 @@ def test_steady_state_of_the_one_tile_kernels_keeps_its_prefetch_and_its_valu_bu
         # the step waits of the round leave the loads of five steps and more in flight (two waits per step: one per LDS write)
         assert sum(w >= 20 for w in waits) >= 2 * 8, waits
         assert sum(w == 0 for w in waits) <= 1.5 * steps, waits
-    for txt, n_mfma_step, loads_per_step in [(t, 16, 8) for t in f32] + [(t, 2, 4) for t in h16]:
+    for txt, n_mfma_step, loads_per_step, mov_budget in [(t, 16, 8, 34) for t in f32] + [(t, 2, 4, 34) for t in h16] + [(t, 4, 6, 68) for t in h16_wide]:
         ins = [l.split("//")[0].strip() for l in txt.splitlines() if l.startswith(("\t", " "))]
         ins = [i for i in ins if i]
         assert not any(i.startswith("scratch_") for i in ins)
@@ -115,10 +118,10 @@ def test_steady_state_of_the_one_tile_kernels_keeps_its_prefetch_and_its_valu_bu
         assert 7 <= steps <= 12, steps
         # register moves: 16 copies + 16 clears per epilogue body (v_mov_b64 counts two), nothing per step
         n_mov = sum(2 if i.startswith("v_mov_b64") else 1 for i in ins if i.startswith("v_mov_b"))
-        assert n_mov <= 34 * steps, (n_mov, steps)                    # (28 per body with TAIL, 32 without: measured 1 % faster all the same)
+        assert n_mov <= mov_budget * steps, (n_mov, steps)            # (28 per body with TAIL, 32 without: measured 1 % faster all the same; two accumulators: twice)
         # full waits: only in the epilogue bodies' C += path (one per body)
         n_full = sum(bool(re.match(r"s_waitcnt vmcnt\(0\)", i)) for i in ins)
-        assert n_full <= 1.5 * steps, (n_full, steps)                 # (13 in 11 bodies today)
+        assert n_full <= (1.5 if mov_budget < 60 else 2.5) * steps, (n_full, steps)     # (13 in 11 bodies today; two column groups: two C += paths per body)
         # the waits in front of the LDS writes of a step leave at least one step's loads in flight
         waits = [int(m.group(1)) for i in ins for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", i)] if m]
         assert sum(w >= loads_per_step for w in waits) >= 4 * steps, (waits, steps)
