@@ -348,7 +348,6 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     std::vector<int32_t>(&wrange)[2] = plan.wrange;
     std::vector<FixRec>& fix = plan.fix;
     std::vector<int32_t>& fix_slots = plan.fix_slots;
-    std::vector<uint16_t>& a16 = plan.a16;
     const int n_workers = plan.n_workers, n_split = plan.n_split;
     const int64_t kp = plan.kp;
 
@@ -382,10 +381,13 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         if (nztot > 0) CREATE_TRY(hipMemcpy(v->d_A, mab + mab_lo, (size_t)nztot * sizeof(float), hipMemcpyHostToDevice));
     } else {
         // the look-ahead of the pipeline reads up to 5 slices past the last one (never multiplied): pad
-        v->a_bytes = ((int64_t)a16.size() + 8 * 64 * 64) * (int64_t)sizeof(uint16_t);
+        const std::vector<uint16_t>& a0 = plan.a16_steps[0];
+        const std::vector<uint16_t>& a1 = plan.a16_steps[1];
+        v->a_bytes = ((int64_t)a0.size() + (int64_t)a1.size() + 8 * 64 * 64) * (int64_t)sizeof(uint16_t);
         CREATE_TRY(hipMalloc((void**)&v->d_A, (size_t)v->a_bytes));
         CREATE_TRY(hipMemset(v->d_A, 0, (size_t)v->a_bytes));
-        if (!a16.empty()) CREATE_TRY(hipMemcpy(v->d_A, a16.data(), a16.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        if (!a0.empty()) CREATE_TRY(hipMemcpy(v->d_A, a0.data(), a0.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        if (!a1.empty()) CREATE_TRY(hipMemcpy((uint16_t*)v->d_A + a0.size(), a1.data(), a1.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         v->kp16 = (int)kp;
     }
     CREATE_TRY(hipMalloc((void**)&v->d_jab, jab32.size() * sizeof(int32_t)));

@@ -37,7 +37,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
     std::vector<FixRec>& fix = P.fix;
     std::vector<int32_t>& fix_slots = P.fix_slots;
     std::vector<uint16_t>& a16 = P.a16;
-    std::vector<uint16_t> a16_steps;                     // the same slices in step order (built per type once its plan is final)
+    std::vector<uint16_t>(&a16_steps)[2] = P.a16_steps;  // the same slices in step order, per type (built once the type's plan is final; a16 is then released)
     int& n_workers = P.n_workers; int& n_split = P.n_split;
     int(&plan_aligned)[2] = P.plan_aligned;
     // ---- stream plans (persistent kernels): flatten tiles into 32-deep steps, cut into equal-cost worker ranges ----
@@ -324,15 +324,16 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             // ---- 16-bit handles: the slices of A in STEP order (the dealing above moved whole tiles between workers): slice q of this type sits at
             // base + q x slice, so that the no-barrier kernel advances ONE pointer per step instead of reading an offset from the step record
             // (eight scalar instructions of ~50 per step; the records keep the offsets for the LDS-staged kernel)
-            if (h16) {
+            if (h16) {                                         // (a16 holds this type's slices only: the types are planned one after the other)
                 const size_t slice = (size_t)(ty ? 64 : 32) * (size_t)kp;
-                const size_t base = a16_steps.size();
-                a16_steps.resize(base + (size_t)S * slice);
+                const size_t base = ty ? a16_steps[0].size() : 0;               // offset in the device image: type 0 first
+                a16_steps[ty].resize((size_t)S * slice);
                 for (int64_t q = 0; q < S; q++) {
                     StepRec& r = st[(size_t)q];
-                    std::memcpy(a16_steps.data() + base + (size_t)q * slice, a16.data() + r.a_off, slice * sizeof(uint16_t));
+                    std::memcpy(a16_steps[ty].data() + (size_t)q * slice, a16.data() + r.a_off, slice * sizeof(uint16_t));
                     r.a_off = (int64_t)(base + (size_t)q * slice);
                 }
+                std::vector<uint16_t>().swap(a16);              // peak: one type twice, not the whole of A twice
             }
             // ---- A in MFMA fragment order for vbs_spmm_f32_direct_kernel (k_f32_direct.hip): one 4 KB slice per step of the one-tile plan,
             // [j = 0..3][g = 0..1][row = 0..31][e = 0..3] = A[row][k = 16 g + 4 j + e], rows past the tile zero.  The legacy image of A stays: row-major / gathered B calls run the LDS-staged kernel on the same plan.
@@ -357,7 +358,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
         }
     }
 
-    if (h16) a16.swap(a16_steps);                        // (the caller pads the device copy: the pipelines request a few slices past a range end)
+    // (16-bit: P.a16_steps[0] + P.a16_steps[1] is the device image; the caller pads it: the pipelines request a few slices past a range end)
     return SPARTA_OK;
 }
 
