@@ -343,8 +343,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 // WC = 64 (one-tile plans of 32-wide blocks, vbs_plan.cpp `wide16`): a wave owns 64 columns of the slab, the workgroup's wave pairs (0, 1) and (2, 3) are two
 // SUB-WORKERS with their own step ranges -- two tiles per CU at a time, the slice of A through L1 twice instead of four times, and the ~20 instructions a
 // step spends on records, addresses and waits pay for four MFMAs instead of two.  Nothing else changes: there is no barrier for the pairs to meet at.
-template <int KP, bool MI2, bool BF16, bool GATHERED, bool CSTAGE = false, bool DEEP = false, bool TAIL = true, int WC = 32>
+// SLAB (with WC = 64): the four waves work on ONE tile again, 64 columns each -- a 256-column slab per workgroup (grid.y = N / 256), so that A is read once per 256
+// columns of B instead of once per 128.  Runs on either plan (the two sub-worker ranges of a workgroup are adjacent); plans without split tiles only.
+template <int KP, bool MI2, bool BF16, bool GATHERED, bool CSTAGE = false, bool DEEP = false, bool TAIL = true, int WC = 32, bool SLAB = false>
 __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const StreamParams p) {
+    static_assert(!SLAB || WC == 64, "256-column slabs are four 64-column waves");
     static_assert(!(CSTAGE && MI2), "the C ring holds 64 rows: tiles of <= 32 rows only");
     static_assert(WC == 32 || (WC == 64 && !MI2 && !CSTAGE && !DEEP), "64-column waves: the one-tile kernel without ring, three steps ahead");
     constexpr int NG = WC / 32;                          // column groups of 32 per wave
@@ -361,12 +364,12 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int lm = lane & 31, g = lane >> 5;
-    const int n0 = blockIdx.y * TN;
-    // WC = 64: sub-worker (wave >> 1) of this workgroup, wave (wave & 1) of its two
-    const int worker = WC == 64 ? 2 * (int)blockIdx.x + __builtin_amdgcn_readfirstlane(wave >> 1) : (int)blockIdx.x;
-    const int wv = WC == 64 ? (wave & 1) : wave;
-    const int s_begin = p.worker_range[2 * worker];
-    const int n = p.worker_range[2 * worker + 1] - s_begin;
+    const int n0 = blockIdx.y * (SLAB ? 2 * TN : TN);
+    // WC = 64: sub-worker (wave >> 1) of this workgroup, wave (wave & 1) of its two; SLAB: the whole workgroup walks both sub-ranges (adjacent) or its one range
+    const int worker = (WC == 64 && !SLAB) ? 2 * (int)blockIdx.x + __builtin_amdgcn_readfirstlane(wave >> 1) : (int)blockIdx.x;
+    const int wv = (WC == 64 && !SLAB) ? (wave & 1) : wave;
+    const int s_begin = (SLAB && p.sub_ranges) ? p.worker_range[4 * worker] : p.worker_range[2 * worker];
+    const int n = ((SLAB && p.sub_ranges) ? p.worker_range[4 * worker + 3] : p.worker_range[2 * worker + 1]) - s_begin;
     if (n <= 0) return;
     clock_probe(p.clk, 0);
     float* ws = p.ws + (int64_t)blockIdx.y * p.ws_slab_stride;
@@ -734,6 +737,16 @@ bool h16_uses_direct_kernel(int kp, bool mi2) { return h16_direct(kp, mi2); }
 void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, bool c_stage, bool wide, dim3 grid, hipStream_t st, const StreamParams& sp) {
     if (kp == 64) { if (mi2) launch_h16<64, true>(bf16, gathered, false, false, grid, st, sp); else launch_h16<64, false>(bf16, gathered, c_stage, false, grid, st, sp); }
     else { if (mi2) launch_h16<32, true>(bf16, gathered, false, false, grid, st, sp); else launch_h16<32, false>(bf16, gathered, c_stage && !wide, wide, grid, st, sp); }
+}
+
+void launch_h16_slab256(bool bf16, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (sp.B_tail != nullptr) {
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<32, false, true, false, false, false, true, 64, true>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<32, false, false, false, false, false, true, 64, true>), grid, dim3(kThreads), 0, st, sp);
+    } else {
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<32, false, true, false, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<32, false, false, false, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
+    }
 }
 
 void launch_tail_copy_h16(hipStream_t st, const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N, uint16_t* B_tail) {

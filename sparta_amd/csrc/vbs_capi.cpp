@@ -810,7 +810,17 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
             const int cst = [] { const char* e = std::getenv("SPARTA_CSTAGE"); return e ? atoi(e) : -1; }();
             const bool c_stage = ty == 0 && !gth && c_layout == SPARTA_COL_MAJOR && (cst >= 0 ? cst != 0 : ring_tiles(A)) && h16_uses_direct_kernel(A->kp16, false);
             if (c_stage) sp.c_nt = c_store_nt(A, ty, sp.C, sp.ldc, false, true);
-            launch_h16_stream(A->kp16, ty != 0, bf16, gth, c_stage, ty == 0 && A->wide16, grid, st, sp);
+            // 256-column slabs for the one-tile plan of 32-wide blocks (A read once per 256 columns; flagship matrix, N = 256: 42.2 -> 35.7 us, N = 512: 88.0 -> 77.0):
+            // N % 256 == 0, no split tile, not through the ring, the plain plan (on the plan with two sub-worker ranges per workgroup a workgroup walks its tiles in
+            // two ascending passes and the gain is gone: 41.1 us; allowed there with SPARTA_H16_SLAB256=2).  SPARTA_H16_SLAB256=0: off.
+            const bool slab256 = ty == 0 && A->kp16 == 32 && !gth && !c_stage && A->n_split == 0 && n_cols % 256 == 0 && h16_uses_direct_kernel(32, false) && ldb16 * 64 * 2 < ((int64_t)1 << 31) - 65536 &&
+                                 [&] { const char* e = std::getenv("SPARTA_H16_SLAB256"); const int m = e ? atoi(e) : 1; return m == 2 || (m == 1 && !A->wide16); }();
+            if (slab256) {
+                sp.sub_ranges = A->wide16 ? 1 : 0;
+                launch_h16_slab256(bf16, dim3((unsigned)A->n_workers, (unsigned)(n_cols / 256)), st, sp);
+                sp.sub_ranges = 0;
+            } else
+                launch_h16_stream(A->kp16, ty != 0, bf16, gth, c_stage, ty == 0 && A->wide16, grid, st, sp);
         }
         if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
     }

@@ -101,6 +101,7 @@ struct StreamParams {
     long long* clk;                       // clock probe, see clock_probe()
     int32_t c_nt;                         // 1: non-temporal C stores (long tiles), 0: default cache policy (short tiles); see vbs_kernel_common.hpp
     int32_t stagger;                      // developer knob (SPARTA_STAGGER): workgroups of the second half of the grid start this many x 64 cycles late
+    int32_t sub_ranges = 0;               // 1: worker_range holds two adjacent sub-worker ranges per workgroup (16-bit `wide16` plans)
 };
 
 constexpr int kFixGroup = 16;   // partial images per group of the fix-up group stage (k_f32_stream.hip)
@@ -239,6 +240,7 @@ void launch_tail_copy(hipStream_t st, const float* B, int64_t ldb, int b_row_maj
 void launch_zero_rows(dim3 grid, hipStream_t st, float* C, int64_t ldc, int c_row_major, int64_t row0, int64_t nrows, int N);
 // k_h16.hip
 void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, bool c_stage, bool wide, dim3 grid, hipStream_t st, const StreamParams& sp);
+void launch_h16_slab256(bool bf16, dim3 grid, hipStream_t st, const StreamParams& sp);   // one-tile plans of 32-wide blocks, 256-column slabs (grid.y = N / 256), no split tile
 bool h16_uses_direct_kernel(int kp, bool mi2);
 void launch_tail_copy_h16(hipStream_t st, const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N, uint16_t* B_tail);
 void launch_convert_h16(bool bf16, hipStream_t st, const float* src, int64_t ld_in, int64_t rows, int64_t n_cols, uint16_t* dst, int64_t ld_out);

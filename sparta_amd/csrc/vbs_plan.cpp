@@ -162,10 +162,11 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             if (S == 0) continue;
             // 16-bit one-tile plans of 32-wide blocks: TWO sub-workers per workgroup (wave pairs (0, 1) and (2, 3), each wave 64 columns of the slab:
             // vbs_spmm_h16_direct_kernel, WC = 64) unless the plan is a ring plan (short misaligned tiles, see below): 2 x n_workers ranges, sub-worker
-            // s of workgroup g at wrange[2 (2 g + s)].  SPARTA_H16_WIDE=0: four waves x 32 columns on one tile, as every other shape.
+            // s of workgroup g at wrange[2 (2 g + s)].  OFF by default (SPARTA_H16_WIDE=1 selects it): N = 128 gains 0.7 % (flagship 21.3 -> 21.1 us), but the
+            // 256-column slabs that N % 256 == 0 launches take (vbs_capi.cpp: A read once per 256 columns, N = 256: 42.2 -> 35.7 us) want ONE range per workgroup.
             const bool ring_like = ty == 0 && !P.tiles_row_aligned[ty] && S < 6 * (int64_t)spans.size() &&
                                    [] { const char* e = std::getenv("SPARTA_CSTAGE"); return !e || atoi(e) != 0; }();
-            const bool wide = h16 && kp == 32 && ty == 0 && !ring_like && [] { const char* e = std::getenv("SPARTA_H16_WIDE"); return !e || atoi(e) != 0; }() &&
+            const bool wide = h16 && kp == 32 && ty == 0 && !ring_like && [] { const char* e = std::getenv("SPARTA_H16_WIDE"); return e && atoi(e) != 0; }() &&
                               [] { const char* e = std::getenv("SPARTA_H16_PATH"); return !(e && e[0] == 'l'); }();     // (the LDS-staged kernel walks one range per workgroup)
             if (ty == 0) P.wide16 = wide;
             const int n_workers = wide ? 2 * P.n_workers : P.n_workers;      // (shadows the handle's count inside this plan)

@@ -53,7 +53,7 @@ def test_stream_kernels_keep_their_state_in_registers(tmp_path):
         elif "h16_direct_kernel" in name:                                 # 4 waves x 2 stages x 32 columns x (KP + 8) 16-bit elements, private to each wave
             ring = 4 * 32 * 65 * 4                                        # the C ring of the CSTAGE instantiations (tiles of arbitrary height)
             want = {4 * 2 * 32 * (32 + 8) * 2, 4 * 2 * 32 * (32 + 8) * 2 + ring} if "ILi32E" in name else {4 * 2 * 32 * (64 + 8) * 2, 4 * 2 * 32 * (64 + 8) * 2 + ring}
-            if "ELi64EEEvN10sparta_dev" in name:                          # WC = 64: every wave holds the images of its two groups of 32 columns
+            if "ELi64ELb0EEEvN10sparta_dev" in name or "ELi64ELb1EEEvN10sparta_dev" in name:                          # WC = 64: every wave holds the images of its two groups of 32 columns
                 want = {4 * 2 * 64 * (32 + 8) * 2}
         elif "h16_stream_kernel" in name:                                 # 2 stages x (128 + 64) rows x (KP + 8) 16-bit elements
             want = {2 * (128 + 64) * (32 + 8) * 2} if "ILi32E" in name else {2 * (128 + 64) * (64 + 8) * 2}
@@ -93,9 +93,9 @@ def test_steady_state_of_the_one_tile_kernels_keeps_its_prefetch_and_its_valu_bu
     window swap), register moves within the epilogue's budget, step waits that leave the loads of the following steps in flight."""
     ks = _disassemble(tmp_path)
     f32 = [t for n, t in ks.items() if "vbs_spmm_f32_direct_kernelILb0E" in n]      # (the instantiation without the C ring: the flagship's)
-    h16 = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb0ELb1ELi32EEEvN10sparta_dev" in n]      # (<32, one tile, *, *, CSTAGE = false, DEEP = false, TAIL = true>)
-    h16_deep = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb1ELb0ELi32EEEvN10sparta_dev" in n]  # (the same seven steps ahead, TAIL = false: the flagship's)
-    h16_wide = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb0ELb0ELi64EEEvN10sparta_dev" in n]  # (64-column waves, TAIL = false: the flagship's)
+    h16 = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb0ELb1ELi32ELb0EEEvN10sparta_dev" in n]      # (<32, one tile, *, *, CSTAGE = false, DEEP = false, TAIL = true>)
+    h16_deep = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb1ELb0ELi32ELb0EEEvN10sparta_dev" in n]  # (the same seven steps ahead, TAIL = false: the flagship's)
+    h16_wide = [t for n, t in ks.items() if "vbs_spmm_h16_direct_kernel" in n and "ILi32ELb0E" in n and "Lb0ELb0ELb0ELi64ELb0EEEvN10sparta_dev" in n]  # (64-column waves, TAIL = false: the flagship's)
     assert len(f32) == 2 and len(h16) >= 4 and len(h16_deep) == 2 and len(h16_wide) == 4, sorted(ks)[:8]      # (f32: TAIL = true / false)
     for txt in h16_deep:
         ins = [l.split("//")[0].strip() for l in txt.splitlines() if l.startswith(("\t", " "))]

@@ -598,8 +598,8 @@ def test_16bit_storage_vs_oracle_on_rounded_inputs(monkeypatch, kernel, dtype, r
 @pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("rows,cols,nnz,blk", [(3000, 640, 20000, ("keeper", 32)), (900, 960, 30000, ("tau", 0.6)), (2500, 2047, 50000, ("fixed", 32))])
 def test_16bit_one_tile_kernel_variants_of_32_wide_blocks_give_the_same_bits(monkeypatch, _sparse_row_mode, align, dtype, rows, cols, nnz, blk):
-    """One-tile plans of 32-wide blocks have three forms of the no-barrier kernel: 64-column waves with two sub-workers per workgroup (the default,
-    a property of the PLAN: SPARTA_H16_WIDE), 32-column waves three steps ahead, and seven steps ahead (SPARTA_H16_AHEAD=7, per launch).  They walk
+    """One-tile plans of 32-wide blocks have three forms of the no-barrier kernel: 64-column waves with two sub-workers per workgroup (a property
+    of the PLAN: SPARTA_H16_WIDE=1), 32-column waves three steps ahead (the default), and seven steps ahead (SPARTA_H16_AHEAD=7, per launch).  They walk
     the same steps of a tile in the same order, so with whole-tile plans their products are the same bits; the default one is held to the oracle on the
     rounded inputs.  `split` forces plans whose tiles are cut between (sub-)workers - at different steps for 512 than for 256 of them, so there each form is
     held to the oracle: the partial images of the 64-column waves must land where the fix-up kernel reads.
@@ -621,7 +621,7 @@ def test_16bit_one_tile_kernel_variants_of_32_wide_blocks_give_the_same_bits(mon
     Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
     Bt.view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
     outs = {}
-    for name, env in [("wide", {}), ("narrow", {"SPARTA_H16_WIDE": "0"}), ("narrow7", {"SPARTA_H16_WIDE": "0", "SPARTA_H16_AHEAD": "7"})]:
+    for name, env in [("wide", {"SPARTA_H16_WIDE": "1"}), ("narrow", {"SPARTA_H16_WIDE": "0"}), ("narrow7", {"SPARTA_H16_WIDE": "0", "SPARTA_H16_AHEAD": "7"})]:
         for k in ("SPARTA_H16_WIDE", "SPARTA_H16_AHEAD"):
             monkeypatch.delenv(k, raising=False)
         for k, val in env.items():
@@ -646,6 +646,51 @@ def test_16bit_one_tile_kernel_variants_of_32_wide_blocks_give_the_same_bits(mon
         for name in ("narrow", "narrow7"):
             for a, b in zip(outs["wide"], outs[name]):
                 assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("plan", ["narrow", "wide"])
+@pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("rows,cols,nnz,blk,n", [(3000, 640, 20000, ("keeper", 32), 256), (1200, 2047, 50000, ("fixed", 32), 512), (900, 960, 30000, ("tau", 0.6), 256)])
+def test_16bit_256_column_slabs_give_the_bits_of_the_128_column_ones(monkeypatch, _sparse_row_mode, plan, dtype, rows, cols, nnz, blk, n):
+    """N % 256 == 0, one-tile plan of 32-wide blocks without split tiles: the four 64-column waves of a workgroup can take ONE tile over a 256-column slab
+    (SPARTA_H16_SLAB256=1; A is then read once per 256 columns).  Same steps, same order per output element: the same bits as the 128-column launch, on the
+    plan with two sub-worker ranges per workgroup as on the plain one; and the oracle's product on the rounded inputs."""
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_STREAM_ALIGN", "1")
+    monkeypatch.setenv("SPARTA_H16_WIDE", "1" if plan == "wide" else "0")
+    w = 32
+    m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + cols + n)
+    if blk[0] == "tau":
+        g = sa.BlockingEngine(tau=blk[1], col_block_size=w).GetGrouping(m)
+    elif blk[0] == "keeper":
+        g = sa.BlockingEngine(tau=0.5, col_block_size=w, row_block_size=blk[1], blocking_algo=5).GetGrouping(m)
+    else:
+        g = np.arange(rows) // blk[1]
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=5)
+    tdt = torch.float16 if dtype == sa.F16 else torch.bfloat16
+    ldb = (v.cols + 7) // 8 * 8
+    Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    Bt.view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
+    d = v.to_device(0, dtype=dtype)
+    outs = {}
+    for slab in ("0", "1"):
+        monkeypatch.setenv("SPARTA_H16_SLAB256", "2" if slab == "1" else "0")      # (2: also on the plan with two sub-worker ranges)
+        res = []
+        for cl, acc in ((sa.COL_MAJOR, False), (sa.ROW_MAJOR, False), (sa.COL_MAJOR, True)):
+            Ct = torch.full((v.rows * n,), 0.5, dtype=torch.float32, device="cuda")
+            d.spmm(Bt, Ct, n, ldb=ldb, c_layout=cl, accumulate=acc)
+            torch.cuda.synchronize()
+            res.append(Ct)
+        outs[slab] = res
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
+    mab_r, B_r = _round16(v.mab, dtype), _round16(B, dtype)
+    Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n, None)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n)
+    _check(outs["1"][0].cpu().numpy(), Co, bound, "256-column slabs, column-major C")
+    _check(np.ascontiguousarray(outs["1"][1].cpu().numpy().reshape(v.rows, n).T).reshape(-1), Co, bound, "256-column slabs, row-major C")
+    _check(outs["1"][2].cpu().numpy(), Co + 0.5, bound + 0.5, "256-column slabs, accumulate")
 
 
 def test_16bit_handles_reject_what_they_cannot_do():
