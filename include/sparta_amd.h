@@ -286,7 +286,7 @@ int sparta_vbs_create_from_csr(sparta_vbs_t** out, int64_t rows, int64_t cols, c
  * DEVICE: launched on `stream` (a hipStream_t, NULL = default stream); if dt_ms != NULL the call
  * records events and synchronises on them, otherwise it returns without synchronising.
  * Leading dimensions: the stream kernels address B and C with 32-bit byte offsets inside a column slab.  fp32 handles take the 64-bit
- * per-class kernels beyond ldb, ldc ~ 4.2 M elements (column-major; correct, slower); 16-bit handles run up to ldb < 34 M (16 M for one-tile plans of 32-wide blocks), ldc < 17 M elements
+ * per-class kernels beyond ldb, ldc ~ 4.2 M elements (column-major; correct, slower); 16-bit handles run up to ldb < 34 M (16 M for SPARTA_H16_WIDE plans), ldc < 17 M elements
  * and return SPARTA_ERR_UNSUPPORTED beyond (a gathered B has the slab height as its leading dimension).
  * A handle carries per-handle scratch (split-tile workspace, layout copies of B, step lists of a gathered B): it must not run on two
  * streams at once.  The FIRST call of a shape (n_cols, layouts, shard_rows) on a handle may allocate that scratch, and on fp32 handles
