@@ -125,8 +125,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the steps from a captured HIP graph (measured: no gain -- the step is one 60 us kernel and eager launches already queue ahead)")
-    ap.add_argument("--workload", choices=["cant", "rmat", "ogbn-like"], default="cant")
-    ap.add_argument("--rmat-scale", type=int, default=20)
+    ap.add_argument("--workload", choices=["cant", "rmat", "ogbn-like", "rmat-part", "cant-weak"], default=None,
+                    help="default: cant on one GPU (configs[1]); rmat-part = configs[4] when --gpus N > 1 (strong scaling); cant-weak = round 2's weak-scaled FEM mesh")
+    ap.add_argument("--rmat-scale", type=int, default=None)
+    ap.add_argument("--slabs", type=int, default=8,
+                    help="rmat-part on ONE GPU: the P parts of the P-rank job one after the other (the N = 1 comparator of --gpus P; a power of two)")
+    ap.add_argument("--slab-sample", type=int, default=0, help="rmat-part on one GPU: run only this many of the --slabs parts (part 0 + a seeded choice), total extrapolated by cost")
+    ap.add_argument("--reorder", choices=["off", "on", "auto"], default="off",
+                    help="rmat-part: per-part blocking -- off = fixed 64-row grid (-a 2 -F 1), on = blocking_algo 7, auto = clustering kept only where its predicted "
+                         "product time beats the fixed grid's")
     ap.add_argument("--rmat-density", type=float, default=0.0, help="distinct nonzeros / n^2 (0.001 = 0.1 %%); 0 = 10 edges per row, symmetrised")
     ap.add_argument("--row-slab", default=None, metavar="K/P",
                     help="rmat with --rmat-density, one GPU: only the rows [K, K+1) * 2^scale / P of the graph (P a power of two), sampled without the rest -- "
@@ -150,6 +157,21 @@ def main():
     ap.add_argument("--dist-path", action="store_true", help="run the multi-GPU code path even with one rank")
     ap.add_argument("--check-rows", type=int, default=64, help="rmat / ogbn-like: rows of C checked against a float64 evaluation before timing")
     args = ap.parse_args()
+    # ---- --gpus N without a launcher: start the N ranks ourselves, as a CHILD process, before anything here touches the GPU ---------
+    # (torch is not even imported yet; a process that has initialised the GPU must never be replaced by exec on these boxes)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if args.workload is None:
+        args.workload = "rmat-part" if (args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1) else "cant"
+    if args.rmat_scale is None:
+        args.rmat_scale = 23 if args.workload == "rmat-part" else 20
     if os.environ.get("SPARTA_BENCH_WATCHDOG"):               # developer aid: dump every thread's Python stack and exit if the run takes longer than this many seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["SPARTA_BENCH_WATCHDOG"]), exit=True)
@@ -184,13 +206,25 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- per-workload defaults ----------------------------------------------------------------------------------------
-    power_law = args.workload in ("rmat", "ogbn-like") and not args.matrix
+    power_law = args.workload in ("rmat", "ogbn-like", "rmat-part") and not args.matrix
     dflt = {"cant": dict(algo=5, tau=0.6, force_fixed=1, col_block=32, dtype="f32", ncols=128),
             "rmat": dict(algo=7, tau=0.4, force_fixed=0, col_block=64, dtype="f32", ncols=128),
-            "ogbn-like": dict(algo=7, tau=0.4, force_fixed=0, col_block=64, dtype="f16", ncols=256)}[args.workload]
+            "ogbn-like": dict(algo=7, tau=0.4, force_fixed=0, col_block=64, dtype="f16", ncols=256),
+            "cant-weak": dict(algo=5, tau=0.6, force_fixed=1, col_block=32, dtype="f32", ncols=128),
+            # configs[4]: 8.4 M x 8.4 M at 0.01 %, B = 256 columns (fp16: SURVEY.md section 8(d) C5); with --rmat-scale 20: configs[3] (B = 512, bf16)
+            "rmat-part": dict(algo=7, tau=0.4, force_fixed=0, col_block=64, dtype="f16" if args.rmat_scale != 20 else "bf16",
+                              ncols=256 if args.rmat_scale != 20 else 512)}[args.workload]
     for k, v in dflt.items():
         if getattr(args, k) is None:
             setattr(args, k, v)
+    if args.workload == "rmat-part":
+        if not args.rmat_density > 0.0:
+            args.rmat_density = 1e-4 if args.rmat_scale != 20 else 1e-3
+        import bench_parts
+        bench_parts.run(args, torch, sa, dist, rank, local_rank, world, dev, _emit, cpu_baseline)
+        if distributed:
+            dist.destroy_process_group()
+        return
     w, N = args.col_block, args.ncols
     h16 = args.dtype != "f32"
     esz = 2.0 if h16 else 4.0
@@ -228,7 +262,7 @@ def main():
             if target * (4.0 + esz) > 0.8 * HBM_BYTES:
                 if rank == 0:
                     _emit({"metric": "Block-sparse SpMM GFLOP/s", "value": None, "unit": "GFLOP/s", "n_gpus": n_gpus, "steps": 0, "warmup": 0,
-                           "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if distributed else "weak", "vs_baseline": None,
+                           "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if distributed else None, "vs_baseline": None,
                            "dtype": args.dtype, "data": "synthetic",
                            "config": {"workload": "R-MAT 2^%d at density %g (%d nnz), B = %d cols, %s" % (args.rmat_scale, args.rmat_density, target, N, args.dtype),
                                       "infeasible": "the CSR image alone is %.0f GB (column + value per nonzero): does not fit the 288 GB of one MI355X; "
@@ -242,7 +276,7 @@ def main():
                 # fits the HBM as a CSR image, but not the tools around it on one box: say so, do not shrink
                 if rank == 0:
                     _emit({"metric": "Block-sparse SpMM GFLOP/s", "value": None, "unit": "GFLOP/s", "n_gpus": n_gpus, "steps": 0, "warmup": 0,
-                           "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if distributed else "weak", "vs_baseline": None,
+                           "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if distributed else None, "vs_baseline": None,
                            "dtype": args.dtype, "data": "synthetic",
                            "config": {"workload": "R-MAT 2^%d at density %g (%d nnz), B = %d cols, %s" % (args.rmat_scale, args.rmat_density, target, N, args.dtype),
                                       "not_run": "the CSR image (%.0f GB) fits one MI355X, but the generator sorts %d 64-bit keys on the GPU (~%.0f GB with the sort's "
@@ -685,7 +719,7 @@ def main():
     out = {
         "metric": "Block-sparse SpMM GFLOP/s", "value": round(useful_gflops, 2), "unit": "GFLOP/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype,
+        "higher_is_better": True, "scaling": ("strong" if strong else "weak") if distributed else None, "vs_baseline": None, "dtype": args.dtype,
         "data": "file" if args.matrix else "synthetic",
         "config": {
             "workload": "%s, B = %d cols, %s%s" % (wl_name, N, {"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[args.dtype], how),

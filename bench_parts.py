@@ -1,0 +1,314 @@
+"""bench_parts.py -- the row-partitioned power-law workload of bench.py (`--workload rmat-part`): BASELINE configs[4] (8.4 M x 8.4 M R-MAT
+at 0.01 %, B = 256 columns, rows split over the GPUs by cost, ONE all-gather of B per step, strong scaling) and, on one GPU, the
+slab-streamed form of configs[3] at its stated densities (R-MAT 2^20 at 0.1 / 1 / 5 %, B = 512 columns, bf16).
+
+The graph is canonical (sparta_amd/gen.py: a pure function of (scale, raw edges, seed)); the rows are cut into P contiguous parts of equal
+EXPECTED cost from the R-MAT row marginals, so every rank finds the same cuts without seeing the graph, and nobody generates a row it does
+not own.  Reorder and VBS build are per part.
+
+  N ranks (torch.distributed.run, or bench.py --gpus N which starts them):  P = N, rank r owns part r; a step = one all-gather of B (RCCL)
+      + the product of the rank's part with the gathered B; "scaling": "strong"; value = 2 nnz_total n_cols / max-over-ranks time.
+  one GPU, --slabs P:  the SAME P parts one after the other through the same entry points (generate -> reorder -> build -> K timed
+      products against B in the layout the all-gather of P ranks leaves -> check -> free); T_1 = sum of the parts' times.  This is the
+      N = 1 comparator of the P-rank job, and the way configs[3] at 1 % / 5 % fits one GPU at all.  --slab-sample k: only k of the P parts
+      (seeded choice, always including part 0), total time extrapolated by cost and labelled so.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+PEAK_HBM_GBS = 8000.0
+PEAK_MFMA_H16_TFLOPS = 2500.0
+PEAK_MFMA_F32_TFLOPS = 157.3
+
+
+def part_roofline(info, sp, rows_c, cols_a, N, esz, peak_mfma_tflops):
+    """section-8(d) bytes of ONE product of a hybrid handle: MFMA part (A tiles once, indices, its rows of C), sparse rows as (column,
+    value) pairs + their rows of C, B ONCE.  Returns (t_lb seconds, algorithmic bytes, gather bytes, executed dense flops)."""
+    dense_area = float(info["nztot"])
+    flops_dense = 2.0 * dense_area * N
+    dense_rows = rows_c - sp["rows"]
+    bytes_dense = dense_area * esz + info["nblocks"] * 4.0 + dense_rows * N * 4.0
+    bytes_sparse = float(sp["nnz"]) * (esz + 4.0) + float(sp["rows"]) * (N * 4.0 + 8.0)
+    bytes_b = float(cols_a) * N * esz
+    t_lb = max(bytes_dense / (PEAK_HBM_GBS * 1e9), flops_dense / (peak_mfma_tflops * 1e12)) + (bytes_sparse + bytes_b) / (PEAK_HBM_GBS * 1e9)
+    bytes_gather = float(sp["nnz"]) * (N * esz + 8.0) + float(sp["rows"]) * N * 4.0
+    return t_lb, bytes_dense + bytes_sparse + bytes_b, bytes_gather, flops_dense
+
+
+def choose_parts(P, k, cost, seed=17):
+    """--slab-sample k: part 0 (the hub) + a seeded choice of k - 1 of the others"""
+    if not k or k >= P:
+        return list(range(P))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rest = sorted(int(x) for x in rng.choice(np.arange(1, P), size=k - 1, replace=False))
+    return [0] + rest
+
+
+def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline):
+    distributed = world > 1 or args.dist_path
+    scale, N, w = args.rmat_scale, args.ncols, args.col_block
+    n = 1 << scale
+    h16 = args.dtype != "f32"
+    esz = 2.0 if h16 else 4.0
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
+    sdt = {"f32": sa.F32, "f16": sa.F16, "bf16": sa.BF16}[args.dtype]
+    peak_mfma = PEAK_MFMA_H16_TFLOPS if h16 else PEAK_MFMA_F32_TFLOPS
+    P = world if distributed else max(1, args.slabs)
+    if n % P or (n // P) % max(w, 64):
+        raise SystemExit("rmat-part: 2^scale must split into %d shards of B of a multiple of %d rows" % (P, max(w, 64)))
+    shard_rows = n // P
+    gen = sa.gen
+    E = gen.rmat_raw_edges_for_density(scale, args.rmat_density)
+    raw_tab, cost_tab = gen.rmat_piece_table(scale, E)
+    cuts = gen.rmat_cuts(scale, E, P)
+    rpp = 1 << (scale - gen.rmat_piece_bits(scale))
+    part_cost = np.array([cost_tab[r0 // rpp:r1 // rpp].sum() for r0, r1 in cuts])
+    if distributed and world > 1:
+        # every rank must hold the same cuts (pure arithmetic, but a silent disagreement would overlap or drop rows): one MIN/MAX pair
+        fp = float(sum((i + 1) * (r0 * 3 + r1) for i, (r0, r1) in enumerate(cuts)) % (1 << 52)) + float(E % (1 << 20)) / (1 << 21)
+        lo = torch.tensor([fp], dtype=torch.float64, device=dev)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if float(lo.item()) != float(hi.item()):
+            raise SystemExit("rank %d: the ranks disagree on the row cuts of the graph" % rank)
+    my_parts = [rank] if distributed else choose_parts(P, args.slab_sample, part_cost)
+
+    # ---- B: canonical rows, held as the all-gather of P ranks leaves it (P column-major slabs of shard_rows x N) ------------
+    B_gath = torch.empty(P * shard_rows * N, dtype=tdt, device=dev)
+    B_shard = None
+    if distributed:
+        B_shard = gen.dense_rhs_rows(rank * shard_rows, (rank + 1) * shard_rows, N, seed=7, dtype=tdt, device=local_rank)
+        dist.all_gather_into_tensor(B_gath, B_shard)
+    else:
+        for s_ in range(P):
+            B_gath[s_ * shard_rows * N:(s_ + 1) * shard_rows * N] = gen.dense_rhs_rows(s_ * shard_rows, (s_ + 1) * shard_rows, N, seed=7, dtype=tdt,
+                                                                                       device=local_rank)
+    gather_pick, gather_mode = None, "all_gather"
+    if distributed and world > 1:
+        if args.gather == "auto" and args.backend == "nccl":
+            gather_pick = sa.dist.pick_allgather(B_shard, B_gath, rank, world, reps=3, sync=torch.cuda.synchronize)
+            gather_mode = gather_pick["mode"]
+        elif args.gather == "peer_copies" and args.backend == "nccl":
+            gather_mode = "peer_copies"
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    parts_out = []
+    tot = dict(nnz=0, ms=0.0, t_lb=0.0, bytes_alg=0.0, bytes_gather=0.0, sparse_ms=0.0, kernel_ms=0.0, flops_dense=0.0, gen=0.0, reorder=0.0, build=0.0,
+               ag_ms=0.0)
+    worst_check = 0.0
+    last = None
+    for ip in my_parts:
+        r0, r1 = cuts[ip]
+        t0 = time.time()
+        m, gstats = gen.rmat_rows(scale, E, r0, r1, seed=3, values="uniform", device=local_rank, return_stats=True)
+        t_gen = time.time() - t0
+        # ---- reorder, per part -------------------------------------------------------------------------------------------
+        t0 = time.time()
+        auto = None
+        fixed_h = args.fixed_height if args.fixed_height else 64
+        if args.reorder == "off":
+            eng = sa.BlockingEngine(blocking_algo="fixed_size", row_block_size=fixed_h, col_block_size=w)
+            grouping = eng.GetGrouping(m)
+            rbs, arm = fixed_h, "off"
+        else:
+            eng = sa.BlockingEngine(blocking_algo=args.algo, tau=args.tau, col_block_size=w, row_block_size=args.row_block, force_fixed_size=False, sim_measure=1)
+            grouping = eng.GetGrouping(m)
+            rbs, arm = args.row_block, "on"
+            if args.reorder == "auto":
+                g_off = sa.BlockingEngine(blocking_algo="fixed_size", row_block_size=fixed_h, col_block_size=w).GetGrouping(m)
+                c_on = sa.DeviceVBS.predict_cost(m, grouping, w, rbs, False, dtype=sdt, n_cols=N)
+                c_off = sa.DeviceVBS.predict_cost(m, g_off, w, fixed_h, False, dtype=sdt, n_cols=N)
+                auto = {"predicted_ms_on": round(c_on["ms"], 3), "predicted_ms_off": round(c_off["ms"], 3)}
+                if c_off["ms"] <= c_on["ms"]:
+                    grouping, rbs, arm = g_off, fixed_h, "off"
+                auto["picked"] = arm
+        t_reorder = time.time() - t0
+        t0 = time.time()
+        d = sa.DeviceVBS.from_csr(m, grouping, w, rbs, False, device=local_rank, dtype=sdt)
+        t_build = time.time() - t0
+        info, sp = d.info(), d.sparse_info()
+        rows_c = info["rows"]
+        C = torch.zeros(rows_c * N, dtype=torch.float32, device=dev)
+
+        def step():
+            if distributed and world > 1:
+                if gather_mode == "peer_copies":
+                    sa.dist.allgather_B_peer_copies(B_shard, B_gath, rank, world)
+                else:
+                    dist.all_gather_into_tensor(B_gath, B_shard)
+            d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False)
+
+        step()                                   # plan time (autotune of the MFMA path, scratch sizing): not a timed step
+        fence()
+        # ---- parity spot check: rows of C against a float64 evaluation on the stored (rounded) values -------------------------
+        worst = 0.0
+        if args.check_rows > 0:
+            rng = np.random.Generator(np.random.PCG64(11 + ip))
+            perm_l = sa.get_permutation(grouping)
+            heavy = np.argsort(np.diff(m.rowptr)[perm_l])[-2:]                 # the two heaviest rows of the part are always checked
+            pick = np.concatenate([rng.integers(0, m.rows, size=min(args.check_rows, m.rows)), heavy])
+            Cv = C.view(N, rows_c)
+            for r in pick:
+                i = perm_l[r]
+                cols_i = m.colidx[m.rowptr[i]:m.rowptr[i + 1]]
+                got = Cv[:, int(r)].cpu().numpy().astype(np.float64)
+                if len(cols_i) == 0:
+                    worst = max(worst, float(np.abs(got).max()))
+                    continue
+                a = torch.from_numpy(np.ascontiguousarray(m.vals[m.rowptr[i]:m.rowptr[i + 1]])).to(tdt).float().numpy().astype(np.float64)
+                bb = sa.dist.gathered_rows(B_gath, cols_i, P, shard_rows, N)
+                want = bb @ a
+                scale_ = np.abs(bb) @ np.abs(a) + 1e-30
+                worst = max(worst, float((np.abs(got - want) / scale_).max()))
+        worst_check = max(worst_check, worst)
+        bad = torch.tensor([worst if np.isfinite(worst) else 1e30], dtype=torch.float64, device=dev)
+        if distributed:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if not (float(bad.item()) <= 1e-5):
+            raise SystemExit("rank %d part %d: parity spot check failed: %.3e of sum|a||b| (worst over the ranks %.3e, tolerance 1e-5)"
+                             % (rank, ip, worst, float(bad.item())))
+        # ---- timing: W warm-up steps, EXACTLY K timed steps between fences ------------------------------------------------
+        for _ in range(args.warmup):
+            step()
+        fence()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_start = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps):
+            step()
+        ev1.record()
+        fence()
+        elapsed = time.perf_counter() - t_start
+        ms = elapsed / args.steps * 1e3
+        ev_ms = ev0.elapsed_time(ev1) / args.steps
+        # the all-gather alone (same stream, same fences)
+        ag_ms = 0.0
+        if distributed and world > 1:
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(min(args.steps, 5)):
+                if gather_mode == "peer_copies":
+                    sa.dist.allgather_B_peer_copies(B_shard, B_gath, rank, world)
+                else:
+                    dist.all_gather_into_tensor(B_gath, B_shard)
+            torch.cuda.synchronize()
+            ag_ms = (time.perf_counter() - t1) * 1e3 / min(args.steps, 5)
+        d.set_class_timing(True)
+        kt = {}
+        for _ in range(min(max(args.steps, 3), 10)):
+            d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False)
+            for k_, v_ in d.class_times().items():
+                kt.setdefault(k_, []).append(v_)
+        d.set_class_timing(False)
+        kernel_ms = {k_: float(np.mean(v_)) for k_, v_ in kt.items()}
+        t_lb, b_alg, b_gather, fl_dense = part_roofline(info, sp, rows_c, n, N, esz, peak_mfma)
+        po = {"part": ip, "rows": [int(r0), int(r1)], "nnz": int(m.nztot()), "expected_cost_share": round(float(part_cost[ip] / part_cost.sum()), 5),
+              "reorder": arm, "ms": round(ms, 4), "event_ms": round(ev_ms, 4), "kernels_ms": {k_: round(v_, 4) for k_, v_ in kernel_ms.items()},
+              "mfma_tile_area": int(info["nztot"]), "sparse_nnz": int(sp["nnz"]), "sparse_rows": int(sp["rows"]),
+              "host_seconds": {"generate": round(t_gen, 2), "reorder": round(t_reorder, 2), "vbs_build": round(t_build, 2)},
+              "frac_8d": round(t_lb / (ms * 1e-3), 5), "check_max_err": worst}
+        if auto:
+            po["auto"] = auto
+        if ag_ms:
+            po["allgather_ms"] = round(ag_ms, 4)
+        parts_out.append(po)
+        tot["nnz"] += m.nztot(); tot["ms"] += ms; tot["t_lb"] += t_lb; tot["bytes_alg"] += b_alg; tot["bytes_gather"] += b_gather
+        tot["sparse_ms"] += kernel_ms.get("sparse", 0.0); tot["kernel_ms"] += sum(kernel_ms.values()); tot["flops_dense"] += fl_dense
+        tot["gen"] += t_gen; tot["reorder"] += t_reorder; tot["build"] += t_build; tot["ag_ms"] += ag_ms
+        last = (m, grouping, rbs)
+        if ip != my_parts[-1]:
+            d.close()
+            del d, C, m
+            torch.cuda.empty_cache()
+
+    # ---- the job's line ------------------------------------------------------------------------------------------------------
+    if distributed:
+        # strong scaling: total nonzeros = sum over ranks, time = max over ranks
+        t = torch.tensor([float(tot["nnz"]), tot["t_lb"], tot["bytes_alg"], tot["bytes_gather"], tot["kernel_ms"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        mx = torch.tensor([tot["ms"], tot["kernel_ms"], tot["ag_ms"], tot["gen"] + tot["reorder"] + tot["build"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, parts_out[0])
+        nnz_total, ms_job = float(t[0]), float(mx[0])
+        sum_lb, sum_alg, sum_gather = float(t[1]), float(t[2]), float(t[3])
+        imbalance = float(mx[1]) / max(float(t[4]) / world, 1e-30)
+        parts_all = gathered
+        f_ex = 1.0
+        # the bound of the JOB: the slowest rank's bound is what the max-over-ranks time is held to
+        job_lb = max(p_["frac_8d"] * p_["ms"] * 1e-3 for p_ in parts_all)
+        extrap = None
+    else:
+        sampled_cost = float(part_cost[my_parts].sum())
+        f_ex = float(part_cost.sum()) / sampled_cost                              # 1.0 when every part ran
+        nnz_total, ms_job = tot["nnz"] * f_ex, tot["ms"] * f_ex
+        sum_lb, sum_alg, sum_gather = tot["t_lb"] * f_ex, tot["bytes_alg"] * f_ex, tot["bytes_gather"] * f_ex
+        imbalance = max(p_["ms"] for p_ in parts_out) / (sum(p_["ms"] for p_ in parts_out) / len(parts_out))
+        parts_all = parts_out
+        job_lb = sum_lb
+        extrap = None if len(my_parts) == P else ("extrapolated from %d of %d parts (parts %s: %.1f %% of the expected cost); nonzeros, time and bytes scaled by cost"
+                                                   % (len(my_parts), P, my_parts, 100.0 / f_ex))
+    if rank != 0:
+        return
+    useful = 2.0 * nnz_total * N / (ms_job * 1e-3) / 1e9
+    gbs_once = sum_alg / (sum(p_["ms"] for p_ in parts_all) * 1e-3) / 1e9 if not distributed else sum_alg / world / (ms_job * 1e-3) / 1e9
+    sparse_ms_all = sum(p_["kernels_ms"].get("sparse", 0.0) for p_ in parts_all)
+    gbs_gather = sum_gather / (f_ex if not distributed else 1.0) / (sparse_ms_all * 1e-3) / 1e9 if sparse_ms_all > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(gbs_once, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(job_lb / (ms_job * 1e-3), 5),
+                "traffic": None, "traffic_source": None,
+                "kernel": "sparse_rows_cm_kernel + sparse_segments_kernel (gather of one row of B per nonzero) + vbs_spmm_h16_direct_kernel (hub tiles)",
+                "algorithmic_bytes": round(sum_alg), "gather_gbs": round(gbs_gather, 1), "gather_frac": round(gbs_gather / PEAK_HBM_GBS, 4),
+                "note": "frac = section-8(d) bound (per part: A once, B once, C once; MFMA part max(bytes, flops)) / measured time"
+                        + ("; the job's bound is the slowest rank's" if distributed else "; summed over the parts")
+                        + ".  gather_frac: one row of B per nonzero (L2 / Infinity Cache re-reads included) -- the kernels sit near the gather "
+                          "ceiling and structurally far from the B-once bound: R-MAT rows do not share columns outside the hub"}
+    cpu = None
+    if not args.no_cpu_baseline and last is not None:
+        m, grouping, rbs = last
+        try:
+            cpu = cpu_baseline(sa, args, m, grouping, None, w, rbs, False, N, None, n, B_gath, P, shard_rows, True, h16, torch)
+        except Exception as e:
+            cpu = {"value": None, "unit": "GFLOP/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+    comparator = None
+    if distributed:
+        try:                                        # the one-GPU run of the same P parts (profiles/r3/slabs*.json), when one is committed for this job
+            cj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3", "slabs%d_scale%d.json" % (P, scale))))
+            if cj["config"]["n_cols"] == N and cj["dtype"] == args.dtype and abs(cj["config"]["density"] - args.rmat_density) < 1e-12 and not cj["config"].get("extrapolated"):
+                comparator = {"one_gpu_ms": cj["ms_per_step"], "speedup": round(cj["ms_per_step"] / ms_job, 3), "source": "profiles/r3/slabs%d_scale%d.json" % (P, scale)}
+        except Exception:
+            comparator = None
+    wl = ("R-MAT 2^%d (a,b,c = 0.57,0.19,0.19; canonical graph: %d raw edges, seed 3) at density %.4g %% = %.4g distinct nnz, rows cut into %d parts of equal "
+          "expected cost, B = %d cols, %s" % (scale, E, 100.0 * args.rmat_density, nnz_total, P, N, {"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[args.dtype]))
+    out = {"metric": "Block-sparse SpMM GFLOP/s", "value": round(useful, 2), "unit": "GFLOP/s", "n_gpus": max(args.gpus, 1), "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(ms_job, 5), "higher_is_better": True, "scaling": "strong" if distributed else None,
+           "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": wl + (", 1 all-gather of B per step" if distributed else ", %d parts streamed through one GPU" % P),
+                      "density": args.rmat_density, "n_cols": N, "col_block_size": w, "parts": P, "raw_edges": int(E),
+                      "reorder": {"off": "fixed height %d per part (reference flags -a 2 -F 1)" % (args.fixed_height or 64),
+                                  "on": "LSH-bucketed Jaccard clustering per part (blocking_algo 7, tau %.2f)" % args.tau,
+                                  "auto": "clustering per part, kept only where its predicted product time beats the fixed grid's"}[args.reorder],
+                      "parallelism": ("row-range partition x%d by expected cost (R-MAT row marginals: no rank sees another's rows), B row-sharded, one %s per step; "
+                                      "kernel-time imbalance max/mean %.3f" % (world, gather_mode, imbalance)) if distributed else
+                                     ("single GPU; the %d parts of the %d-rank job one after the other; time = sum over the parts; part-time max/mean %.3f" % (P, P, imbalance)),
+                      "timing": "per part: %d warm-up + EXACTLY %d timed products between fences" % (args.warmup, args.steps) + ("" if distributed else "; ms_per_step = sum over the parts"),
+                      "host_seconds": {"generate": round(tot["gen"], 2), "reorder": round(tot["reorder"], 2), "vbs_build": round(tot["build"], 2)},
+                      "parts_detail": parts_all, "parity_spot_check": {"rows_per_part": args.check_rows + 2, "max_err_over_sum_abs": worst_check, "tolerance": 1e-5},
+                      "kernel_rev": sa.KERNEL_REV},
+           "roofline": roofline, "cpu_baseline": cpu}
+    if extrap:
+        out["config"]["extrapolated"] = extrap
+    if distributed:
+        out["config"]["allgather"] = dict(gather_pick or {}, mode=gather_mode, ms_alone=round(float(mx[2]), 4))
+        out["config"]["host_seconds_max_rank"] = round(float(mx[3]), 2)
+        if comparator:
+            out["config"]["one_gpu_comparator"] = comparator
+    emit(out)

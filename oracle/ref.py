@@ -213,7 +213,12 @@ class RefVBR:
 
     def multiply(self, B, n_cols, Cin=None):
         """reference VBR::multiply: C += A*B, B col-major ld=cols, C col-major ld=rows (vbr.cpp:323-372)."""
-        B = np.ascontiguousarray(B, np.float32)
+        # VBR::multiply reads B past its end when cols % w != 0 (vbr.cpp:351,362: the zero-padded last block column is multiplied with
+        # whatever follows the last column of B in memory -- 0 * garbage, NaN if the garbage is inf / NaN).  The wrapper hands it a copy
+        # followed by zeros so that the read is defined (0 * 0): the reference's result on DEFINED inputs, which is what parity means.
+        Bp = np.zeros(np.asarray(B).size + 4096, np.float32)
+        Bp[:np.asarray(B).size] = np.asarray(B, np.float32).reshape(-1)
+        B = Bp
         Cm = np.zeros(self.rows * n_cols, np.float32) if Cin is None else np.ascontiguousarray(Cin, np.float32).copy()
         lib().ref_vbr_multiply(self.h, _fp(B), n_cols, _fp(Cm))
         return Cm

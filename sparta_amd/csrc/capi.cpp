@@ -20,16 +20,41 @@ int validate_csr(const CsrView& a, bool need_sorted) {
     if (a.rows > 0 && (!a.rowptr)) return fail(SPARTA_ERR_INVALID, "CSR: rowptr is NULL");
     if (a.rows == 0) return SPARTA_OK;
     if (a.rowptr[0] != 0) return fail(SPARTA_ERR_INVALID, "CSR: rowptr[0] must be 0");
-    for (int64_t i = 0; i < a.rows; i++) {
-        int64_t n = a.rowptr[i + 1] - a.rowptr[i];
+    // rows are checked on all host threads (10^9-nonzero inputs); the FIRST offending row is what gets reported
+    std::atomic<int64_t> bad_row{INT64_MAX};
+    std::atomic<int> bad_kind{0};
+    parallel_for_dynamic(a.rows, 4096, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; i++) {
+            int64_t n = a.rowptr[i + 1] - a.rowptr[i];
+            int kind = 0;
+            if (n < 0) kind = 1;
+            else if (n > 0 && !a.colidx) kind = 2;
+            else {
+                const int32_t* r = a.colidx + a.rowptr[i];
+                for (int64_t k = 0; k < n && !kind; k++) {
+                    if (r[k] < 0 || (int64_t)r[k] >= a.cols) kind = 3;
+                    // the reference's distance/merge code assumes ascending rows (its readers throw on unsorted
+                    // row ids, csr.cpp:259-260, and never sort columns); duplicates make merge_rows ill-defined.
+                    else if (need_sorted && k > 0 && r[k] <= r[k - 1]) kind = 4;
+                }
+            }
+            if (kind) {
+                int64_t cur = bad_row.load();
+                while (i < cur && !bad_row.compare_exchange_weak(cur, i)) {}
+                if (bad_row.load() == i) bad_kind.store(kind);
+                return;                                                    // (later rows of this chunk cannot be the first)
+            }
+        }
+    });
+    if (bad_row.load() != INT64_MAX) {
+        // re-derive the kind for the first bad row (another thread may have stored its own kind in between)
+        const int64_t i = bad_row.load();
+        const int64_t n = a.rowptr[i + 1] - a.rowptr[i];
         if (n < 0) return fail(SPARTA_ERR_INVALID, "CSR: rowptr must be non-decreasing (row " + std::to_string(i) + ")");
         if (n > 0 && !a.colidx) return fail(SPARTA_ERR_INVALID, "CSR: colidx is NULL");
         const int32_t* r = a.colidx + a.rowptr[i];
         for (int64_t k = 0; k < n; k++) {
-            if (r[k] < 0 || (int64_t)r[k] >= a.cols)
-                return fail(SPARTA_ERR_INVALID, "CSR: column index out of range in row " + std::to_string(i));
-            // the reference's distance/merge code assumes ascending rows (its readers throw on unsorted
-            // row ids, csr.cpp:259-260, and never sort columns); duplicates make merge_rows ill-defined.
+            if (r[k] < 0 || (int64_t)r[k] >= a.cols) return fail(SPARTA_ERR_INVALID, "CSR: column index out of range in row " + std::to_string(i));
             if (need_sorted && k > 0 && r[k] <= r[k - 1])
                 return fail(SPARTA_ERR_INVALID, "CSR: columns must be strictly ascending within a row (row " + std::to_string(i) + ")");
         }

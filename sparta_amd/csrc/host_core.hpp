@@ -2,13 +2,61 @@
 // (reorder engine, VBS builder, C-ABI glue).  Not installed; the public surface is
 // include/sparta_amd.h (C-ABI) and include/sparta_compat.hpp (reference-shaped C++ API).
 #pragma once
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 #include "sparta_amd.h"
 
 namespace sparta {
+
+// host threads for the builders (SPARTA_HOST_THREADS overrides; default: every hardware thread)
+inline int host_threads() {
+    if (const char* e = std::getenv("SPARTA_HOST_THREADS")) return std::max(1, atoi(e));
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)(hw ? hw : 1);
+}
+
+// f(lo, hi, thread) over [0, n) in chunks of `grain` items handed out dynamically (an atomic cursor): block-rows of a power-law matrix
+// differ by orders of magnitude in cost, static ranges leave one thread with the hubs.  f must only touch what belongs to its items.
+template <typename F>
+void parallel_for_dynamic(int64_t n, int64_t grain, F&& f) {
+    if (n <= 0) return;
+    grain = std::max<int64_t>(1, grain);
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(host_threads(), (n + grain - 1) / grain));
+    if (nt <= 1) { f((int64_t)0, n, 0); return; }
+    std::atomic<int64_t> cursor{0};
+    std::vector<std::thread> th;
+    th.reserve((size_t)nt);
+    for (int64_t t = 0; t < nt; t++)
+        th.emplace_back([&f, &cursor, n, grain, t] {
+            for (;;) {
+                const int64_t lo = cursor.fetch_add(grain, std::memory_order_relaxed);
+                if (lo >= n) break;
+                f(lo, std::min(n, lo + grain), (int)t);
+            }
+        });
+    for (auto& x : th) x.join();
+}
+
+// SPARTA_BUILD_TRACE=1: phase timings of the host builders on stderr (developer aid)
+struct BuildTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    const char* who;
+    explicit BuildTrace(const char* w) : on(std::getenv("SPARTA_BUILD_TRACE") != nullptr), t0(std::chrono::steady_clock::now()), who(w) {}
+    void lap(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[sparta build] %s: %-28s %8.3f s\n", who, what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 // Flat CSR view (the reference keeps one heap array per row: include/matrices.h:22-28; we use the
 // flat form everywhere and adapt at the compat layer).

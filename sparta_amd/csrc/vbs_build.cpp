@@ -9,28 +9,11 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
-#include <thread>
 
 #include "host_core.hpp"
 
 namespace sparta {
 namespace {
-
-template <typename F>
-void parallel_for_blocks(int64_t n, F&& f) {
-    unsigned hw = std::thread::hardware_concurrency();
-    int64_t nt = std::max<int64_t>(1, std::min<int64_t>((int64_t)(hw ? hw : 1), n / 64));
-    if (const char* e = std::getenv("SPARTA_HOST_THREADS")) nt = std::max<int64_t>(1, std::min<int64_t>(atoll(e), std::max<int64_t>(n, 1)));
-    if (nt <= 1) { f(0, n, 0); return; }
-    std::vector<std::thread> th;
-    int64_t chunk = (n + nt - 1) / nt;
-    for (int64_t t = 0; t < nt; t++) {
-        int64_t lo = t * chunk, hi = std::min(n, lo + chunk);
-        if (lo >= hi) break;
-        th.emplace_back([&f, lo, hi, t] { f(lo, hi, (int)t); });
-    }
-    for (auto& x : th) x.join();
-}
 
 // distinct column blocks touched by reordered rows [r0, r1), ascending
 struct BlockCollector {
@@ -39,6 +22,12 @@ struct BlockCollector {
     std::vector<int32_t> touched;
     std::vector<int32_t> count;   // per column block: stored nonzeros of the current block-row (valid for touched blocks; count_nnz = true)
     bool count_nnz = false;
+    int32_t tag_counter = 0;
+    // a fresh tag for the next block-row (a collector serves many block-rows, in any order)
+    int32_t next_tag() {
+        if (++tag_counter == INT32_MAX) { std::fill(stamp.begin(), stamp.end(), 0); tag_counter = 1; }
+        return tag_counter;
+    }
     explicit BlockCollector(int64_t block_cols, bool counting = false)
         : stamp((size_t)block_cols, 0), slot((size_t)block_cols, 0), count(counting ? (size_t)block_cols : 0, 0), count_nnz(counting) {}
 
@@ -88,8 +77,10 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
     const bool hybrid = sp != nullptr && K > 0.0;
     if (int rc = validate_csr(a, hybrid)) return rc;                      // the sparse rows are taken as they are: ascending, no duplicates
 
+    BuildTrace trace0("vbs_build");
     std::vector<int64_t> part = get_partition(grouping, a.rows);          // vbr.cpp:139
     std::vector<int64_t> perm = get_permutation(grouping, a.rows);        // vbr.cpp:140
+    trace0.lap("partition + permutation");
     if (keep_order) {
         // the rows stay where they are (the reference's permutation is an UNSTABLE sort by group id: it shuffles rows inside a group
         // even when the groups are already contiguous); needs a non-decreasing grouping.  Used for A^T, whose rows are columns of C.
@@ -148,70 +139,102 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
         return r;
     };
 
-    // pass 1: blocks per block-row (+ the hybrid mode)
+    BuildTrace trace("vbs_build");
+    // pass 1: blocks per block-row (+ the hybrid mode, and what the block-row would put on the sparse-row path: rows, entries)
     std::vector<uint8_t> mode((size_t)block_rows, 0);
     std::vector<double> saved_row((size_t)block_rows, 0.0);           // MFMA steps the chosen mode saves against "all tiles"
-    parallel_for_blocks(block_rows, [&](int64_t lo, int64_t hi, int) {
+    std::vector<int64_t> sp_rows_of(hybrid ? (size_t)block_rows : 0, 0), sp_ent_of(hybrid ? (size_t)block_rows : 0, 0), nb_all(hybrid ? (size_t)block_rows : 0, 0);
+    const int64_t grain = std::max<int64_t>(1, std::min<int64_t>(64, block_rows / (8 * (int64_t)host_threads()) + 1));
+    parallel_for_dynamic(block_rows, grain, [&](int64_t lo, int64_t hi, int) {
         BlockCollector bc(block_cols, hybrid);
         for (int64_t ib = lo; ib < hi; ib++) {
-            bc.collect(a, perm.data(), part[(size_t)ib], part[(size_t)ib + 1], w, (int32_t)(ib - lo + 1));
-            const RowMode r = decide(bc, part[(size_t)ib + 1] - part[(size_t)ib]);
+            const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
+            bc.collect(a, perm.data(), r0, r1, w, bc.next_tag());
+            const RowMode r = decide(bc, h);
             mode[(size_t)ib] = r.mode;
             out->nzcount[ib] = r.n_dense;
             saved_row[(size_t)ib] = r.saved;
+            if (!hybrid) continue;
+            nb_all[(size_t)ib] = (int64_t)bc.touched.size();
+            if (r.mode == 1) {                                            // every row of the block-row is a sparse row (padded and empty ones too)
+                int64_t ent = 0;
+                for (int32_t jb : bc.touched) ent += bc.count[(size_t)jb];
+                sp_rows_of[(size_t)ib] = h; sp_ent_of[(size_t)ib] = ent;
+            } else if (r.mode == 2) {                                     // the nonzeros of the blocks that are not well filled; rows without one are left out
+                const double kbb = K_block * spb_of(h);
+                int64_t ent = 0, nrows = 0;
+                for (int64_t rr = r0; rr < r1; rr++) {
+                    const int64_t i = perm[(size_t)rr];
+                    if (i >= a.rows) continue;
+                    const int32_t* cj = a.row(i);
+                    const float* v = a.vals ? a.vals + a.rowptr[i] : nullptr;
+                    const int64_t n = a.nnz_of(i);
+                    int64_t mine = 0;
+                    for (int64_t k = 0; k < n; k++)
+                        mine += (!v || v[k] != 0.0f) && (double)bc.count[(size_t)(cj[k] / w)] < kbb;
+                    ent += mine; nrows += mine > 0;
+                }
+                sp_rows_of[(size_t)ib] = nrows; sp_ent_of[(size_t)ib] = ent;
+            }
         }
     });
+    trace.lap("pass 1 (count + decide)");
 
     // hybrid: a handful of nearly empty blocks stays with the tiles -- the sparse-row kernels are extra launches behind the MFMA launch
     // (10-15 us of launch and dependency measured on a banded matrix with 119 such rows; sparse_min_steps(): 4096 steps ~ 8 per worker ~ 10 us);
-    // then the sparse rows are collected in row order
+    // then the sparse rows are collected in row order (offsets from the counts of pass 1, filled on all threads)
     if (hybrid) {
         double steps_saved = 0.0;
         for (double x : saved_row) steps_saved += x;
         if (steps_saved < (double)sparse_min_steps()) {
-            BlockCollector bc(block_cols, false);
             for (int64_t ib = 0; ib < block_rows; ib++) {
                 if (!mode[(size_t)ib]) continue;
                 mode[(size_t)ib] = 0;
-                bc.collect(a, perm.data(), part[(size_t)ib], part[(size_t)ib + 1], w, (int32_t)(ib % 0x7ffffff0 + 1));
-                out->nzcount[ib] = (int64_t)bc.touched.size();
+                out->nzcount[ib] = nb_all[(size_t)ib];
+                sp_rows_of[(size_t)ib] = sp_ent_of[(size_t)ib] = 0;
             }
         }
         sp->flag.assign(mode.begin(), mode.end());
-        sp->rowptr.assign(1, 0);
-        sp->col.clear(); sp->val.clear(); sp->crow.clear(); sp->row_add.clear();
-        BlockCollector bc(block_cols, true);
-        std::vector<uint8_t> is_dense((size_t)block_cols, 0);              // valid for the touched blocks of the current (mixed) block-row
-        int32_t tag = 0;
+        std::vector<int64_t> row_base((size_t)block_rows + 1, 0), ent_base((size_t)block_rows + 1, 0);
         for (int64_t ib = 0; ib < block_rows; ib++) {
-            if (!mode[(size_t)ib]) continue;
-            const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
-            const bool mixed = mode[(size_t)ib] == 2;
-            if (mixed) {
-                if (++tag == INT32_MAX) { std::fill(bc.stamp.begin(), bc.stamp.end(), 0); tag = 1; }
-                bc.collect(a, perm.data(), r0, r1, w, tag);
-                const double kbb = K_block * spb_of(h);
-                for (int32_t jb : bc.touched) is_dense[(size_t)jb] = (double)bc.count[(size_t)jb] >= kbb;
-            }
-            for (int64_t r = r0; r < r1; r++) {
-                const int64_t i = perm[(size_t)r];
-                const size_t before = sp->col.size();
-                if (i < a.rows) {
-                    const int32_t* cj = a.row(i);
-                    const float* v = a.vals ? a.vals + a.rowptr[i] : nullptr;
-                    const int64_t n = a.nnz_of(i);
-                    for (int64_t k = 0; k < n; k++) {
-                        const float x = v ? v[k] : 1.0f;                  // pattern-only matrices store 1 (vbr.cpp:217)
-                        if (x == 0.0f || (mixed && is_dense[(size_t)(cj[k] / w)])) continue;
-                        sp->col.push_back(cj[k]); sp->val.push_back(x);
-                    }
-                }
-                if (mixed && sp->col.size() == before) continue;          // a row of a mixed block-row without such a nonzero: the tiles wrote all of it
-                sp->crow.push_back((int32_t)r);                           // (fully sparse block-rows: padded and empty rows too -- they are rows of C)
-                sp->row_add.push_back(mixed ? 1 : 0);
-                sp->rowptr.push_back((int64_t)sp->col.size());
-            }
+            row_base[(size_t)ib + 1] = row_base[(size_t)ib] + sp_rows_of[(size_t)ib];
+            ent_base[(size_t)ib + 1] = ent_base[(size_t)ib] + sp_ent_of[(size_t)ib];
         }
+        const int64_t n_sp_rows = row_base[(size_t)block_rows], n_sp_ent = ent_base[(size_t)block_rows];
+        sp->rowptr.assign((size_t)n_sp_rows + 1, 0);
+        sp->col.resize((size_t)n_sp_ent); sp->val.resize((size_t)n_sp_ent);
+        sp->crow.resize((size_t)n_sp_rows); sp->row_add.resize((size_t)n_sp_rows);
+        parallel_for_dynamic(block_rows, grain, [&](int64_t lo, int64_t hi, int) {
+            BlockCollector bc(block_cols, true);
+            for (int64_t ib = lo; ib < hi; ib++) {
+                if (!mode[(size_t)ib]) continue;
+                const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
+                const bool mixed = mode[(size_t)ib] == 2;
+                double kbb = 0.0;
+                if (mixed) { bc.collect(a, perm.data(), r0, r1, w, bc.next_tag()); kbb = K_block * spb_of(h); }
+                int64_t t = row_base[(size_t)ib], e = ent_base[(size_t)ib];
+                for (int64_t r = r0; r < r1; r++) {
+                    const int64_t i = perm[(size_t)r];
+                    const int64_t before = e;
+                    if (i < a.rows) {
+                        const int32_t* cj = a.row(i);
+                        const float* v = a.vals ? a.vals + a.rowptr[i] : nullptr;
+                        const int64_t n = a.nnz_of(i);
+                        for (int64_t k = 0; k < n; k++) {
+                            const float x = v ? v[k] : 1.0f;                  // pattern-only matrices store 1 (vbr.cpp:217)
+                            if (x == 0.0f || (mixed && (double)bc.count[(size_t)(cj[k] / w)] >= kbb)) continue;
+                            sp->col[(size_t)e] = cj[k]; sp->val[(size_t)e] = x; e++;
+                        }
+                    }
+                    if (mixed && e == before) continue;                       // a row of a mixed block-row without such a nonzero: the tiles wrote all of it
+                    sp->crow[(size_t)t] = (int32_t)r;                         // (fully sparse block-rows: padded and empty rows too -- they are rows of C)
+                    sp->row_add[(size_t)t] = mixed ? 1 : 0;
+                    sp->rowptr[(size_t)t + 1] = e;
+                    t++;
+                }
+            }
+        });
+        trace.lap("sparse rows (collect)");
     }
 
     // offsets
@@ -228,12 +251,13 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
     if (!out->jab || !out->mab) { sparta_vbs_host_free(out); return fail(SPARTA_ERR_ALLOC, "sparta_vbs_build: out of host memory (nztot = " + std::to_string(out->nztot) + ")"); }
 
     // pass 2: jab + scatter the values, column-major inside each block (vbr.cpp:224)
-    parallel_for_blocks(block_rows, [&](int64_t lo, int64_t hi, int) {
+    trace.lap("offsets + calloc");
+    parallel_for_dynamic(block_rows, grain, [&](int64_t lo, int64_t hi, int) {
         BlockCollector bc(block_cols, hybrid);
         for (int64_t ib = lo; ib < hi; ib++) {
             const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
             if (mode[(size_t)ib] == 1) continue;                          // not materialised
-            bc.collect(a, perm.data(), r0, r1, w, (int32_t)(ib - lo + 1));
+            bc.collect(a, perm.data(), r0, r1, w, bc.next_tag());
             const bool mixed = mode[(size_t)ib] == 2;
             if (mixed) {                                                  // keep the well-filled blocks only; slot = -1 marks the others
                 const double kbb = K_block * spb_of(h);
@@ -264,6 +288,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
             }
         }
     });
+    trace.lap("pass 2 (scatter)");
     return SPARTA_OK;
 }
 

@@ -112,6 +112,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     using sparta::fail;
     if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: out is NULL");
     *out = nullptr;
+    sparta::BuildTrace trace("vbs_create");
     if (rows <= 0 || cols <= 0 || block_rows <= 0 || w <= 0 || !row_part || !nzcount)
         return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad dimensions or NULL index array");
     if (br0 < 0 || br1 > block_rows || br0 >= br1) return fail(SPARTA_ERR_INVALID, "sparta_vbs_create: bad block-row range");
@@ -175,15 +176,31 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         bool any = false;
         for (size_t q = 0; q < ext->flag.size(); q++) { sparse_flag[q] = ext->flag[q] == 1; any = any || sparse_flag[q]; }
         if (!any) sparse_flag.clear();
-        sp_rowptr.assign(1, 0);
-        for (size_t t = 0; t < ext->crow.size(); t++) {
-            for (int64_t k = ext->rowptr[t]; k < ext->rowptr[t + 1]; k++) {
-                const float a = stored(ext->val[(size_t)k]);
-                if (a != 0.0f && ext->col[(size_t)k] < cols) { sp_col.push_back(ext->col[(size_t)k]); sp_val.push_back(a); }
+        // the entries that survive the storage type (a value that rounds to zero is a zero) and lie inside the matrix: counted, then
+        // copied, on all host threads (10^8..10^9 entries on the power-law configs)
+        const int64_t n_ext = (int64_t)ext->crow.size();
+        std::vector<int64_t> keep((size_t)n_ext + 1, 0);
+        sparta::parallel_for_dynamic(n_ext, 2048, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t t = lo; t < hi; t++) {
+                int64_t c = 0;
+                for (int64_t k = ext->rowptr[(size_t)t]; k < ext->rowptr[(size_t)t + 1]; k++)
+                    c += stored(ext->val[(size_t)k]) != 0.0f && ext->col[(size_t)k] < cols;
+                keep[(size_t)t + 1] = c;
             }
-            sp_crow.push_back(ext->crow[t] | (t < ext->row_add.size() && ext->row_add[t] ? (int32_t)0x80000000 : 0));
-            sp_rowptr.push_back((int64_t)sp_col.size());
-        }
+        });
+        for (int64_t t = 0; t < n_ext; t++) keep[(size_t)t + 1] += keep[(size_t)t];
+        sp_rowptr.swap(keep);
+        sp_col.resize((size_t)sp_rowptr.back()); sp_val.resize((size_t)sp_rowptr.back()); sp_crow.resize((size_t)n_ext);
+        sparta::parallel_for_dynamic(n_ext, 2048, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t t = lo; t < hi; t++) {
+                int64_t o = sp_rowptr[(size_t)t];
+                for (int64_t k = ext->rowptr[(size_t)t]; k < ext->rowptr[(size_t)t + 1]; k++) {
+                    const float a = stored(ext->val[(size_t)k]);
+                    if (a != 0.0f && ext->col[(size_t)k] < cols) { sp_col[(size_t)o] = ext->col[(size_t)k]; sp_val[(size_t)o] = a; o++; }
+                }
+                sp_crow[(size_t)t] = ext->crow[(size_t)t] | ((size_t)t < ext->row_add.size() && ext->row_add[(size_t)t] ? (int32_t)0x80000000 : 0);
+            }
+        });
     } else {
         double K = 24.0;
         if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
@@ -260,6 +277,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         sp_long.push_back(lr);
     }
     n_sp_short = (int64_t)sp_list.size(); n_sp_long = (int64_t)sp_long.size();
+    trace.lap("sparse rows (device form)");
     const uint8_t* skip = sparse_flag.empty() ? nullptr : sparse_flag.data();
 
     // ---- plan: row tiles per class -----------------------------------------------------------------
@@ -342,7 +360,9 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     StreamPlanHost plan;
     {
         StreamPlanIn pin{cols, w, br0, br1, jab_lo, mab_lo, row_part, nzcount, jab, mab, dtype, device, skip};
+        trace.lap("tile lists");
         if (int rc = build_stream_plans(pin, plan)) return rc;
+        trace.lap("stream plans");
     }
     std::vector<StepRec>(&steps)[2] = plan.steps;
     std::vector<int32_t>(&wrange)[2] = plan.wrange;
@@ -475,6 +495,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     CREATE_TRY(hipEventCreate(&v->tev0));
     CREATE_TRY(hipEventCreate(&v->tev1));
 #undef CREATE_TRY
+    trace.lap("upload");
     *out = hold.release();
     return SPARTA_OK;
 }

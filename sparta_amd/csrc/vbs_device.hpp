@@ -264,7 +264,6 @@ struct StreamPlanHost {
     std::vector<FixRec> fix;                  // split tiles + tiles of block-rows without blocks (zero fill)
     std::vector<std::pair<int64_t, int64_t>> zero_ranges;   // (first row, rows) of long block-rows without blocks: vbs_zero_rows_kernel instead of fix-up tiles
     std::vector<int32_t> fix_slots;
-    std::vector<uint16_t> a16;                // 16-bit handles, scratch of the planner: the slices of the type being planned, in matrix order
     std::vector<uint16_t> a16_steps[2];       // 16-bit handles: A as TM x kp slices ([k chunk of 8][row][8]), one per step, in STEP order; device image = [0] then [1]
     int n_workers = 0, n_split = 0;
     int plan_aligned[2] = {0, 0};

@@ -36,8 +36,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
     std::vector<int32_t>(&wrange)[2] = P.wrange;
     std::vector<FixRec>& fix = P.fix;
     std::vector<int32_t>& fix_slots = P.fix_slots;
-    std::vector<uint16_t>& a16 = P.a16;
-    std::vector<uint16_t>(&a16_steps)[2] = P.a16_steps;  // the same slices in step order, per type (built once the type's plan is final; a16 is then released)
+    std::vector<uint16_t>(&a16_steps)[2] = P.a16_steps;  // A as per-step slices in step order, per type (packed once the type's plan is final)
     int& n_workers = P.n_workers; int& n_split = P.n_split;
     int(&plan_aligned)[2] = P.plan_aligned;
     // ---- stream plans (persistent kernels): flatten tiles into 32-deep steps, cut into equal-cost worker ranges ----
@@ -116,16 +115,6 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                             for (int64_t ks = 0; ks < w; ks += kp) {
                                 StepRec r;
                                 r.a_off = mo2 + r0 + (b * w + ks) * h;
-                                if (h16) {                                  // pack this step's slice, rows past the tile zero
-                                    const int64_t tms = ty ? 64 : 32;
-                                    r.a_off = (int64_t)a16.size();
-                                    a16.resize(a16.size() + (size_t)(tms * kp), 0);
-                                    uint16_t* dst = a16.data() + r.a_off;
-                                    const float* blk = mab + mab_lo + mo2 + b * h * w;       // column-major h x w block
-                                    for (int64_t rr = 0; rr < mt; rr++)                  // [k chunk of 8][row][8]
-                                        for (int64_t kk = 0; kk < kp; kk++)
-                                            dst[((kk >> 3) * tms + rr) * 8 + (kk & 7)] = to_h16(blk[(ks + kk) * h + r0 + rr], dtype == SPARTA_BF16);
-                                }
                                 r.b_row = (int32_t)(jb * w + ks);
                                 r.h = (int32_t)h;
                                 r.c_row = c_row;
@@ -135,7 +124,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                                 r.pad = 0;
                                 if (dbg_probe) {                            // developer probe (timing only, results are wrong): which stream bounds a step
                                     if (dbg_probe & 1) r.b_row = (int32_t)ks;                                   // every panel of B is the same (cache-hot) one
-                                    if ((dbg_probe & 2) && h16) r.a_off = (b * w + ks) / kp * (ty ? 64 : 32) * kp;   // every tile reads the first slices of A
+                                    if ((dbg_probe & 2) && h16) r.a_off = (ks) * h;                                  // every tile reads the first block of A
                                     if ((dbg_probe & 2) && !h16) r.a_off = r0 + (b * w + ks) * h;
                                     if (dbg_probe & 4) r.c_row = 0;                                             // every tile writes the first rows of C
                                 }
@@ -325,16 +314,29 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             // ---- 16-bit handles: the slices of A in STEP order (the dealing above moved whole tiles between workers): slice q of this type sits at
             // base + q x slice, so that the no-barrier kernel advances ONE pointer per step instead of reading an offset from the step record
             // (eight scalar instructions of ~50 per step; the records keep the offsets for the LDS-staged kernel)
-            if (h16) {                                         // (a16 holds this type's slices only: the types are planned one after the other)
+            if (h16) {
+                // packed on all host threads straight from the fp32 blocks (column-major h x w, element (row, k) of the slice at blk[k * h + row]):
+                // slice = [k chunk of 8][row][8], rows past the tile zero
                 const size_t slice = (size_t)(ty ? 64 : 32) * (size_t)kp;
+                const int64_t tms = ty ? 64 : 32;
                 const size_t base = ty ? a16_steps[0].size() : 0;               // offset in the device image: type 0 first
-                a16_steps[ty].resize((size_t)S * slice);
-                for (int64_t q = 0; q < S; q++) {
-                    StepRec& r = st[(size_t)q];
-                    std::memcpy(a16_steps[ty].data() + (size_t)q * slice, a16.data() + r.a_off, slice * sizeof(uint16_t));
-                    r.a_off = (int64_t)(base + (size_t)q * slice);
-                }
-                std::vector<uint16_t>().swap(a16);              // peak: one type twice, not the whole of A twice
+                a16_steps[ty].assign((size_t)S * slice, 0);
+                const bool bf = dtype == SPARTA_BF16;
+                uint16_t* all = a16_steps[ty].data();
+                sparta::parallel_for_dynamic(S, 256, [&](int64_t lo, int64_t hi, int) {
+                    for (int64_t q = lo; q < hi; q++) {
+                        StepRec& r = st[(size_t)q];
+                        const float* blk = mab + mab_lo + r.a_off;
+                        const int64_t hh = r.h, mt = r.mt_flags & 0xffff;
+                        uint16_t* dst = all + (size_t)q * slice;
+                        for (int64_t kk = 0; kk < kp; kk++) {
+                            const float* colp = blk + kk * hh;
+                            uint16_t* d2 = dst + (kk >> 3) * tms * 8 + (kk & 7);
+                            for (int64_t rr = 0; rr < mt; rr++) d2[rr * 8] = to_h16(colp[rr], bf);
+                        }
+                        r.a_off = (int64_t)(base + (size_t)q * slice);
+                    }
+                });
             }
             // ---- A in MFMA fragment order for vbs_spmm_f32_direct_kernel (k_f32_direct.hip): one 4 KB slice per step of the one-tile plan,
             // [j = 0..3][g = 0..1][row = 0..31][e = 0..3] = A[row][k = 16 g + 4 j + e], rows past the tile zero.  The legacy image of A stays: row-major / gathered B calls run the LDS-staged kernel on the same plan.
@@ -344,16 +346,18 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                 if (!off && ty == 0 && !h16 && S <= ((int64_t)2 << 20)) {   // <= 8 GiB of slices (a second copy of the one-tile part of A)
                     std::vector<float>& af = P.a_frag;
                     af.assign(((size_t)S + 4) * 1024, 0.0f);                    // + 4: the pipeline requests three steps past a range end
-                    for (int64_t q = 0; q < S; q++) {
-                        const StepRec& r = st[(size_t)q];
-                        const float* blk = mab + mab_lo + r.a_off;              // element (row, k) of the slice at blk[k * h + row]
-                        const int64_t hh = r.h, mt = r.mt_flags & 0xffff;
-                        float* dst = af.data() + (size_t)q * 1024;
-                        for (int j = 0; j < 4; j++)
-                            for (int g = 0; g < 2; g++)
-                                for (int64_t m = 0; m < mt; m++)
-                                    for (int e = 0; e < 4; e++) dst[((j * 2 + g) * 32 + m) * 4 + e] = blk[(int64_t)(16 * g + 4 * j + e) * hh + m];
-                    }
+                    sparta::parallel_for_dynamic(S, 256, [&](int64_t lo, int64_t hi, int) {
+                        for (int64_t q = lo; q < hi; q++) {
+                            const StepRec& r = st[(size_t)q];
+                            const float* blk = mab + mab_lo + r.a_off;              // element (row, k) of the slice at blk[k * h + row]
+                            const int64_t hh = r.h, mt = r.mt_flags & 0xffff;
+                            float* dst = af.data() + (size_t)q * 1024;
+                            for (int j = 0; j < 4; j++)
+                                for (int g = 0; g < 2; g++)
+                                    for (int64_t m = 0; m < mt; m++)
+                                        for (int e = 0; e < 4; e++) dst[((j * 2 + g) * 32 + m) * 4 + e] = blk[(int64_t)(16 * g + 4 * j + e) * hh + m];
+                        }
+                    });
                 }
             }
         }

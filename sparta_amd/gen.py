@@ -246,3 +246,239 @@ def ogbn_products_like(seed=3, device=0, **kw):
     (SURVEY.md section 8(d))."""
     n = 2449029
     return rmat_device(22, target_nnz=2 * 61859140, seed=seed, symmetrize=True, values="ones", n=n, device=device, **kw)
+
+
+# ---- canonical R-MAT: the graph is a pure function of (scale, raw_edges, seed); any row range can be sampled alone -------------
+# BASELINE configs[3] / configs[4] at their stated sizes do not fit one generator pass (7e9 .. 5.5e10 nonzeros), and a row-partitioned
+# job must not make every rank generate the whole graph.  Here the 2**scale rows are cut into canonical PIECES of PIECE_ROWS rows (an
+# aligned dyadic range: the top bits of the row are fixed).  Piece p receives round(raw_edges * P(piece p)) raw edges -- its expected
+# share, the R-MAT bits being independent across levels -- and every raw edge of a piece is a pure function of (seed, piece, index in the
+# piece): a counter-based hash (splitmix64 finaliser) supplies 16 bits per level; at the levels the piece fixes only the column bit is
+# drawn, from its conditional distribution given the row bit.  Duplicates are removed per piece; the value of an entry is a hash of
+# (seed, row, column).  So rank r of an N-rank job and slab r of a one-GPU run produce bit-identical rows, whatever N is.
+PIECE_ROWS_LOG2 = 10
+_M64 = (1 << 64) - 1
+
+
+def _s64(x):
+    """python int -> the int64 with the same low 64 bits"""
+    x &= _M64
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+_GOLD, _MIX1, _MIX2 = _s64(0x9E3779B97F4A7C15), _s64(0xBF58476D1CE4E5B9), _s64(0x94D049BB133111EB)
+_K_PIECE, _K_SEED, _K_VAL = _s64(0xD6E8FEB86659FD93), _s64(0xA0761D6478BD642F), _s64(0xE7037ED1A0B428DB)
+
+
+def _mix64(z):
+    """splitmix64 finaliser on an int64 torch tensor (wrapping arithmetic, logical shifts)"""
+    z = z + _GOLD
+    z = (z ^ ((z >> 30) & ((1 << 34) - 1))) * _MIX1
+    z = (z ^ ((z >> 27) & ((1 << 37) - 1))) * _MIX2
+    return z ^ ((z >> 31) & ((1 << 33) - 1))
+
+
+def rmat_piece_bits(scale):
+    """number of row bits a canonical piece fixes (pieces = 2**that): pieces of 1024 rows from 2^20 rows up, of 64 rows below (tests,
+    miniatures: the hub piece must stay a small share of the graph for the cuts to balance)"""
+    return max(0, int(scale) - (PIECE_ROWS_LOG2 if int(scale) >= 20 else 6))
+
+
+def rmat_row_model(scale, raw_edges, a=0.57, b=0.19, c=0.19):
+    """Expected number of DISTINCT entries of a row as a function of its popcount k (k = 0 .. scale), for `raw_edges` raw R-MAT edges:
+    sum over the columns j of 1 - exp(-raw_edges * p_ij); the columns are grouped by (ones at the row's zero levels, ones at its one
+    levels).  Returns (distinct[k], raw_share[k]) -- everything a rank needs to cut the rows by cost WITHOUT seeing the graph."""
+    from math import comb
+    s = int(scale)
+    d = 1.0 - a - b - c
+    p1 = c + d                                            # P(row bit = 1)
+    q0, q1 = b / (a + b), d / (c + d)                     # P(column bit = 1 | row bit = 0 / 1)
+    distinct = np.zeros(s + 1)
+    share = np.zeros(s + 1)
+    for k in range(s + 1):
+        prow = (p1 ** k) * ((1.0 - p1) ** (s - k))
+        share[k] = prow
+        u = np.arange(s - k + 1)
+        v = np.arange(k + 1)
+        mu = np.array([comb(s - k, int(x)) for x in u], np.float64)
+        mv = np.array([comb(k, int(x)) for x in v], np.float64)
+        qu = (q0 ** u) * ((1.0 - q0) ** (s - k - u))
+        qv = (q1 ** v) * ((1.0 - q1) ** (k - v))
+        lam = float(raw_edges) * prow * np.outer(qu, qv)
+        distinct[k] = float((np.outer(mu, mv) * (-np.expm1(-lam))).sum())
+    return distinct, share
+
+
+def rmat_raw_edges_for_density(scale, density, a=0.57, b=0.19, c=0.19):
+    """raw edge count whose expected number of distinct entries is density * 4**scale (bisection on the row model)"""
+    from math import comb
+    s = int(scale)
+    want = float(density) * float(1 << s) * float(1 << s)
+    mult = np.array([comb(s, k) for k in range(s + 1)], np.float64)
+    lo, hi = want, want * 64.0 + 1024.0
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        got = float((mult * rmat_row_model(s, mid, a, b, c)[0]).sum())
+        if got < want:
+            lo = mid
+        else:
+            hi = mid
+        if hi - lo <= max(1.0, 1e-9 * hi):
+            break
+    return int(round(hi))
+
+
+def _popcount_np(x):
+    x = np.asarray(x, np.uint64)
+    out = np.zeros(x.shape, np.int64)
+    while True:
+        nz = x != 0
+        if not nz.any():
+            return out
+        out += (x & np.uint64(1)).astype(np.int64)
+        x = x >> np.uint64(1)
+
+
+def rmat_piece_table(scale, raw_edges, a=0.57, b=0.19, c=0.19):
+    """Per canonical piece: (raw edges it receives, expected cost = expected distinct entries + rows).  Pure arithmetic: every rank
+    computes the same table."""
+    s = int(scale)
+    f = rmat_piece_bits(s)
+    distinct, _ = rmat_row_model(s, raw_edges, a, b, c)
+    p1 = 1.0 - a - b
+    pc = _popcount_np(np.arange(1 << f, dtype=np.uint64))
+    share = (p1 ** pc) * ((1.0 - p1) ** (f - pc))
+    raw = np.floor(float(raw_edges) * share + 0.5).astype(np.int64)
+    # expected distinct entries of a piece: sum over the popcounts of its low bits
+    from math import comb
+    low = s - f
+    low_mult = np.array([comb(low, k) for k in range(low + 1)], np.float64)
+    per_pc = np.array([float((low_mult * distinct[t:t + low + 1]).sum()) for t in range(f + 1)])
+    cost = per_pc[pc] + float(1 << low)
+    return raw, cost
+
+
+def rmat_cuts(scale, raw_edges, parts, a=0.57, b=0.19, c=0.19):
+    """`parts` contiguous row ranges [(row0, row1), ...] of equal expected cost (distinct entries + rows), cut at piece boundaries."""
+    from .dist import partition_by_cost
+    _, cost = rmat_piece_table(scale, raw_edges, a, b, c)
+    rows_per_piece = 1 << (int(scale) - rmat_piece_bits(scale))
+    return [(p0 * rows_per_piece, p1 * rows_per_piece) for p0, p1 in partition_by_cost(cost, parts)]
+
+
+def rmat_rows(scale, raw_edges, row0, row1, seed=3, a=0.57, b=0.19, c=0.19, values="uniform", device=0, chunk=1 << 26, group=1 << 28,
+              return_stats=False):
+    """Rows [row0, row1) (piece-aligned) of THE R-MAT graph (scale, raw_edges, seed) as a (row1 - row0) x 2**scale CSR, generated with
+    torch on `device` (an int = that GPU, or "cpu" for tests) without the rest of the graph."""
+    import torch
+    from .host import CSR
+    s = int(scale)
+    f = rmat_piece_bits(s)
+    low = s - f
+    rpp = 1 << low
+    if row0 % rpp or row1 % rpp or not (0 <= row0 <= row1 <= (1 << s)):
+        raise ValueError("row range must be aligned to pieces of %d rows" % rpp)
+    dev = torch.device("cpu") if device == "cpu" else torch.device("cuda", int(device))
+    n = 1 << s
+    p0, p1 = row0 // rpp, row1 // rpp
+    raw_all, _ = rmat_piece_table(s, raw_edges, a, b, c)
+    raw = raw_all[p0:p1]
+    A16, AB16, ABC16 = int(round(a * 65536)), int(round((a + b) * 65536)), int(round((a + b + c) * 65536))
+    d = 1.0 - a - b - c
+    Q0, Q1 = int(round(b / (a + b) * 65536)), int(round(d / (c + d) * 65536))
+    seed_term = _s64(int(seed) * (_K_SEED & _M64))
+    counts_parts, col_parts = [], []
+    drawn = 0
+    # groups of whole pieces (duplicates never cross a piece: pieces are disjoint in rows), each at most `group` raw edges if possible
+    g0 = 0
+    npieces = p1 - p0
+    while g0 < npieces:
+        g1, tot = g0, 0
+        while g1 < npieces and (g1 == g0 or tot + int(raw[g1]) <= group):
+            tot += int(raw[g1])
+            g1 += 1
+        cum = torch.from_numpy(np.concatenate([[0], np.cumsum(raw[g0:g1])]).astype(np.int64)).to(dev)
+        keys = []
+        e0 = 0
+        while e0 < tot:
+            e1 = min(tot, e0 + chunk)
+            gi = torch.arange(e0, e1, dtype=torch.int64, device=dev)
+            pl = torch.searchsorted(cum, gi, right=True) - 1            # piece inside the group
+            idx = gi - cum[pl]
+            piece = pl + (p0 + g0)
+            del gi
+            x = piece * _K_PIECE + idx + seed_term
+            r = torch.zeros_like(idx)
+            col = torch.zeros_like(idx)
+            h = None
+            for lvl in range(s):
+                if lvl % 4 == 0:
+                    h = _mix64(x + _s64((lvl // 4 + 1) * (_GOLD & _M64)))
+                u = (h >> (16 * (lvl % 4))) & 0xFFFF
+                if lvl >= low:                                            # a level the piece fixes: the column bit given the row bit
+                    down = (piece >> (lvl - low)) & 1
+                    thr = torch.where(down == 1, Q1, Q0)
+                    col |= (u < thr).to(torch.int64) << lvl
+                else:
+                    right = ((u >= A16) & (u < AB16)) | (u >= ABC16)
+                    down = u >= AB16
+                    r |= down.to(torch.int64) << lvl
+                    col |= right.to(torch.int64) << lvl
+            keys.append((pl * rpp + r) * n + col)                          # row inside the group
+            del x, r, col, h, u, pl, idx, piece
+            e0 = e1
+        drawn += tot
+        if keys:
+            k = torch.unique(torch.cat(keys) if len(keys) > 1 else keys[0])
+        else:
+            k = torch.empty(0, dtype=torch.int64, device=dev)
+        del keys
+        rr = k // n
+        counts_parts.append(torch.bincount(rr, minlength=(g1 - g0) * rpp))
+        col_parts.append((k - rr * n).to(torch.int32))
+        del k, rr
+        g0 = g1
+    n_rows = row1 - row0
+    counts = torch.cat(counts_parts) if counts_parts else torch.zeros(0, dtype=torch.int64, device=dev)
+    colidx = torch.cat(col_parts) if col_parts else torch.zeros(0, dtype=torch.int32, device=dev)
+    del counts_parts, col_parts
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=rowptr[1:])
+    nnz = int(colidx.numel())
+    vals = None
+    if values is not None:
+        vals_parts = []
+        rows_of = torch.repeat_interleave(torch.arange(n_rows, dtype=torch.int64, device=dev), counts) + row0
+        for e0 in range(0, nnz, chunk):
+            e1 = min(nnz, e0 + chunk)
+            hv = _mix64((rows_of[e0:e1] * n + colidx[e0:e1].to(torch.int64)) * _K_VAL + seed_term)
+            if values == "uniform":
+                vals_parts.append((((hv >> 40) & 0xFFFFFF).to(torch.float32) + 0.5) * (2.0 / 16777216.0) - 1.0)       # 24 bits: exact in fp32
+            else:
+                vals_parts.append(torch.ones(e1 - e0, dtype=torch.float32, device=dev))
+        vals = torch.cat(vals_parts) if vals_parts else torch.zeros(0, dtype=torch.float32, device=dev)
+        del rows_of, vals_parts
+    m = CSR(n_rows, n, rowptr.cpu().numpy(), colidx.cpu().numpy(), None if vals is None else vals.cpu().numpy())
+    del rowptr, colidx, vals, counts
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()
+    if return_stats:
+        return m, {"raw_edges_drawn": int(drawn), "nnz": nnz, "rows": [int(row0), int(row1)], "pieces": [int(p0), int(p1)]}
+    return m
+
+
+def dense_rhs_rows(row0, row1, n_cols, seed=7, dtype=None, device=0, chunk_rows=None):
+    """Rows [row0, row1) of THE dense operand B (seed): B[j, c] = a hash of (seed, j, c) mapped to U(-0.5, 0.5) on a 2**-16 grid (exact in
+    fp16 / bf16 only up to their rounding; the same for every rank count).  Returned column-major (ld = row1 - row0), flat, on `device`."""
+    import torch
+    dev = torch.device("cpu") if device == "cpu" else torch.device("cuda", int(device))
+    dtype = torch.float32 if dtype is None else dtype
+    nr = int(row1) - int(row0)
+    out = torch.empty(nr * int(n_cols), dtype=dtype, device=dev)
+    ov = out.view(int(n_cols), nr)
+    seed_term = _s64(int(seed) * (_K_SEED & _M64))
+    j = torch.arange(int(row0), int(row1), dtype=torch.int64, device=dev)
+    for cix in range(int(n_cols)):
+        hv = _mix64((j * 65536 + cix) * _K_VAL + seed_term)
+        ov[cix] = ((((hv >> 40) & 0xFFFF).to(torch.float32) + 0.5) * (1.0 / 65536.0) - 0.5).to(dtype)
+    return out
