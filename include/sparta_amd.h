@@ -272,14 +272,23 @@ int sparta_vbs_create_from_csr(sparta_vbs_t** out, int64_t rows, int64_t cols, c
                                const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, int32_t force_fixed_size,
                                int32_t dtype, int32_t device);
 
+/* What sparta_vbs_create_from_csr WOULD build for this grouping, without building or uploading anything (no GPU needed): the same
+ * per-block decisions (well-filled blocks -> dense MFMA tiles, the nonzeros of the others -> rows of (column, value) for the sparse-row
+ * kernels).  stats[8] = {tile blocks, stored elements of the tiles, MFMA steps of the tiles, sparse nonzeros, sparse rows, block-rows,
+ * rows, 0}.  Lets a caller compare two blockings of one matrix -- the clustering of sparta_reorder against the fixed grid of the
+ * reference's `-a 2 -F 1` arm (src/scripts/run_multiplication_experiments_fixed_cluster.sh:14-16) -- before paying for either handle. */
+int sparta_vbs_plan_stats(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals, const int64_t* grouping,
+                          int64_t col_block_size, int64_t row_block_size, int32_t force_fixed_size, int32_t dtype, int64_t* stats);
+
 /* C (+)= A * B.  Replaces VBR::multiply(B, B_cols, C) (include/matrices.h:121) and the GPU back-ends
  *   cublas_fixed_blocks_multiply / cublas_blockmat_batched / cutlas_* (const VBR&, DataT* B, int B_cols,
  *   DataT_C* C, float& dt[, int n_streams])            (include/cuda_utilities.h:38-44,
  *                                                        include/cutlass_bellpack_lib.h:19-25).
  * B: `cols` x n_cols, C: `rows` x n_cols (rows of this handle).  fp32 handles: fp32 B and C, any layout, any n_cols.
- * 16-bit handles: C is fp32; with SPARTA_PTR_DEVICE B is in the handle's 16-bit type, column-major, ldb even, n_cols a
- * multiple of 128 (SPARTA_ERR_UNSUPPORTED otherwise); with SPARTA_PTR_HOST B is fp32 like in the reference and is rounded
- * on the device.  Tolerance of the 16-bit path: exact products of the ROUNDED inputs, fp32 accumulation -- the same bound
+ * 16-bit handles: C is fp32; with SPARTA_PTR_DEVICE B is in the handle's 16-bit type, column-major, ldb even; any n_cols (the
+ * reference's `-c` is arbitrary, include/input.h:15-42): whole 128-column slabs go through the kernels as they are, the last
+ * n_cols % 128 columns through a zero-padded slab in per-handle scratch (128 columns of B and of C); with SPARTA_PTR_HOST B is fp32
+ * like in the reference and is rounded on the device.  Tolerance of the 16-bit path: exact products of the ROUNDED inputs, fp32 accumulation -- the same bound
  * as the fp32 MFMA path relative to the reference's multiply run on the rounded inputs.  accumulate = 1 is the reference's
  * semantics (C += A*B); 0 overwrites C (every row of C is written).  ptr_space HOST: buffers are
  * copied to/from the device around the kernel and *dt_ms (may be NULL) covers the kernel only;
@@ -326,6 +335,21 @@ int sparta_vbs_create_transposed(sparta_vbs_t** out, int64_t rows, int64_t cols,
                                  int32_t dtype, int32_t device);
 int sparta_vbs_spmm_ba(sparta_vbs_t* At, const void* B, int64_t ldb, int32_t M, void* C, int64_t ldc, int32_t accumulate,
                        int32_t ptr_space, void* stream, float* dt_ms);
+
+/* A dense operand that does NOT change between products, prepared once.  The reference's drivers multiply the same B `-x` times
+ * (test/cuda/cuda_multiply.cpp:250-269); the sparse-row kernels of a handle read B row-major, so a column-major (the reference's layout)
+ * or gathered B is otherwise transposed into per-handle scratch on EVERY product (11 % of a power-law product).
+ * sparta_vbs_prepare_b makes that copy once, on `stream`, into memory the returned object owns; B itself is not copied and must stay
+ * valid and unchanged while the object is used.  shard_rows = 0: B is column-major cols x n_cols with leading dimension ldb; shard_rows >
+ * 0: the gathered layout of sparta_vbs_spmm_gathered (ldb ignored).  Device pointers only.  sparta_vbs_spmm_prepared is sparta_vbs_spmm /
+ * sparta_vbs_spmm_gathered on that B (SPARTA_SPMM_MFMA; the exception state of a failed call is a plain status code: the handle is usable
+ * again).  The implicit per-call transpose of sparta_vbs_spmm stays the default: nothing changes for a caller that never prepares. */
+typedef struct sparta_b sparta_b_t;
+int sparta_vbs_prepare_b(sparta_vbs_t* A, const void* B, int64_t ldb, int64_t shard_rows, int64_t shard_stride, int32_t n_cols, void* stream,
+                         sparta_b_t** out);
+int sparta_vbs_spmm_prepared(sparta_vbs_t* A, const sparta_b_t* Bp, void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, void* stream,
+                             float* dt_ms);
+int sparta_b_destroy(sparta_b_t* Bp);
 
 /* Per-tile-class device timing for roofline reports: when enabled, sparta_vbs_spmm brackets each class
  * launch with HIP events on the launch stream; sparta_vbs_class_times waits for them and writes the last

@@ -36,7 +36,8 @@ SYMBOLS = [
     "sparta_version",
     "sparta_csr_read", "sparta_csr_read_buffer", "sparta_csr_host_free", "sparta_csr_write_edgelist", "sparta_grouping_write", "sparta_grouping_read",
     "sparta_blocking_csv_row", "sparta_degree_permutation", "sparta_vbs_save", "sparta_vbs_load", "sparta_vbs_to_blocked_ell",
-    "sparta_vbs_build_partition", "sparta_vbs_partition_check",
+    "sparta_vbs_build_partition", "sparta_vbs_partition_check", "sparta_vbs_plan_stats",
+    "sparta_vbs_prepare_b", "sparta_vbs_spmm_prepared", "sparta_b_destroy",
 ]
 
 
@@ -114,6 +115,10 @@ def _load():
     L.sparta_vbs_create_range.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, C.c_int64, C.c_int64, i64p, i64p, i64p, f32p,
                                           C.c_int64, C.c_int64, C.c_int32, C.c_int32]
     L.sparta_vbs_create_from_csr.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, i64p, i32p, f32p, i64p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32]
+    L.sparta_vbs_plan_stats.argtypes = [C.c_int64, C.c_int64, i64p, i32p, f32p, i64p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, i64p]
+    L.sparta_vbs_prepare_b.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, vp, C.POINTER(vp)]
+    L.sparta_vbs_spmm_prepared.argtypes = [vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp, f32p]
+    L.sparta_b_destroy.argtypes = [vp]
     L.sparta_vbs_create_transposed.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, C.c_int64, C.c_int64, i64p, i64p, i64p, f32p, C.c_int32, C.c_int32]
     L.sparta_vbs_spmm_ba.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, C.c_int64, C.c_int32, C.c_int32, vp, f32p]
     L.sparta_vbs_spmm.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp,

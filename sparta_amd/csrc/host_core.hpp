@@ -98,8 +98,15 @@ struct HybridSparse {
     std::vector<int32_t> col, crow;   // crow: reordered row index (= row of C)
     std::vector<float> val;
 };
+// what the hybrid builder WOULD build (sparta_vbs_plan_stats): decided by the same pass, nothing materialised
+struct HybridStats {
+    int64_t tile_blocks = 0, tile_area = 0;   // blocks kept as dense MFMA tiles, their stored elements (h x w each)
+    double mfma_steps = 0.0;                  // steps those tiles cost (one <= 32-row tile x kdep columns of a block)
+    int64_t sparse_nnz = 0, sparse_rows = 0;  // entries / rows left to the sparse-row kernels
+    int64_t block_rows = 0, rows = 0;
+};
 int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, bool force_fixed_size,
-                     double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp, bool keep_order = false);
+                     double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp, bool keep_order = false, HybridStats* stats_only = nullptr);
 // fewest MFMA steps the nearly empty block-rows of a matrix must be worth before they leave the tiles for the sparse-row kernels
 // (SPARTA_SPARSE_MIN_STEPS overrides; default 4096)
 inline int64_t sparse_min_steps() { const char* e = std::getenv("SPARTA_SPARSE_MIN_STEPS"); return e ? atoll(e) : 4096; }

@@ -345,11 +345,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 // step spends on records, addresses and waits pay for four MFMAs instead of two.  Nothing else changes: there is no barrier for the pairs to meet at.
 // SLAB (with WC = 64): the four waves work on ONE tile again, 64 columns each -- a 256-column slab per workgroup (grid.y = N / 256), so that A is read once per 256
 // columns of B instead of once per 128.  Runs on either plan (the two sub-worker ranges of a workgroup are adjacent); plans without split tiles only.
+// SLAB with MI2 (round 3; 64-row tiles, the dense hub of a power-law matrix): FOUR accumulators per wave -- rows 0..31 / 32..63 x the wave's two groups of 32
+// columns -- so that a step's slice of A (64 x KP) and its panel of B (KP x 64 per wave) feed 4 NK MFMAs instead of 2 NK: A is read once per 256 columns of B,
+// B fragments are used twice.  One workgroup per CU (the 16-bit plans' own choice): the accumulators live in the upper half of the 512-register file.
+// Split tiles are allowed: a wave writes its 64 x 64 piece into the slot images of the two 128-column slabs its workgroup covers, in the layout the
+// fix-up kernel reads (four waves x 32 columns).
 template <int KP, bool MI2, bool BF16, bool GATHERED, bool CSTAGE = false, bool DEEP = false, bool TAIL = true, int WC = 32, bool SLAB = false>
-__global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const StreamParams p) {
+__global__ __launch_bounds__(kThreads, (MI2 && WC == 64) ? 1 : 2) void vbs_spmm_h16_direct_kernel(const StreamParams p) {
     static_assert(!SLAB || WC == 64, "256-column slabs are four 64-column waves");
     static_assert(!(CSTAGE && MI2), "the C ring holds 64 rows: tiles of <= 32 rows only");
-    static_assert(WC == 32 || (WC == 64 && !MI2 && !CSTAGE && !DEEP), "64-column waves: the one-tile kernel without ring, three steps ahead");
+    static_assert(WC == 32 || (WC == 64 && !CSTAGE && !DEEP && (!MI2 || SLAB)), "64-column waves: without ring, three steps ahead; two-tile form as 256-column slabs only");
+    constexpr bool QUAD = MI2 && WC == 64;               // four accumulators per wave
     constexpr int NG = WC / 32;                          // column groups of 32 per wave
     constexpr int D = DEEP ? 7 : 3;                      // steps between a step's loads and its MFMAs
     constexpr int TN = kTN, TM = MI2 ? 64 : 32;
@@ -372,7 +378,8 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
     const int n = ((SLAB && p.sub_ranges) ? p.worker_range[4 * worker + 3] : p.worker_range[2 * worker + 1]) - s_begin;
     if (n <= 0) return;
     clock_probe(p.clk, 0);
-    float* ws = p.ws + (int64_t)blockIdx.y * p.ws_slab_stride;
+    // split-tile workspace: one image per 128-column slab; a 256-column workgroup of the four-accumulator form covers slabs 2 y and 2 y + 1 (waves 0, 1 / 2, 3)
+    float* ws = p.ws + (int64_t)(QUAD ? 2 * (int)blockIdx.y + __builtin_amdgcn_readfirstlane(wave >> 1) : (int)blockIdx.y) * p.ws_slab_stride;
     const uint16_t* A16 = reinterpret_cast<const uint16_t*>(p.A);
     const uint16_t* B16 = reinterpret_cast<const uint16_t*>(p.B);
     const uint16_t* Bt16 = reinterpret_cast<const uint16_t*>(p.B_tail);
@@ -452,9 +459,9 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
             for (int q = 0; q < NK; q++) *reinterpret_cast<u32x4*>(ldsw + lwB + (ST * NG + c) * WSTAGE + q * CPI * RB) = rb.b[c * NK + q];
     };
 
-    f32x16 acc0, acc1;
+    f32x16 acc0, acc1, acc2, acc3;                        // QUAD: acc0 / acc1 = rows 0..31 / 32..63 of the first 32 columns, acc2 / acc3 of the second
 #pragma unroll
-    for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; acc2[r] = 0.0f; acc3[r] = 0.0f; }
     auto mfma = [&](const u32x4& bf, const u32x4& af, f32x16& acc) __attribute__((always_inline)) {
         if constexpr (BF16) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf), __builtin_bit_cast(bf16x8, af), acc, 0, 0, 0);
         else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf), __builtin_bit_cast(f16x8, af), acc, 0, 0, 0);
@@ -481,7 +488,8 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
         for (int q = 0; q < NK; q++) {
             mfma(fb[q], wa.a[0][q], acc0);
             if constexpr (MI2) mfma(fb[q], wa.a[1][q], acc1);
-            if constexpr (WC == 64) mfma(fb[NK + q], wa.a[0][q], acc1);   // the wave's second 32 columns (acc1: free in the one-tile kernel)
+            if constexpr (WC == 64 && !MI2) mfma(fb[NK + q], wa.a[0][q], acc1);   // the wave's second 32 columns (acc1: free in the one-tile kernel)
+            if constexpr (QUAD) { mfma(fb[NK + q], wa.a[0][q], acc2); mfma(fb[NK + q], wa.a[1][q], acc3); }
         }
         fq_new = issue_loads(std::integral_constant<int, i + D>{}, nb, na);   // G(i + D)
         if ((flags & STEP_LAST) && !(SPARTA_H16_PROBE & 4)) {
@@ -489,7 +497,13 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
                 const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_SLOT) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
-                    if constexpr (WC == 64) {           // the image is laid out for four waves x 32 columns: this wave fills the places of waves 2 wv and 2 wv + 1; rows 32..63: none
+                    if constexpr (QUAD) {               // this wave's 64 columns are the places of waves 2 (wv & 1) and 2 (wv & 1) + 1 in its slab's image (four waves x 32 columns)
+                        const uint32_t vt = (uint32_t)((2 * (wv & 1)) * 64 + lane) * 4u;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc0[q]), rW, vt, (uint32_t)(q * kThreads * 4), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc2[q]), rW, vt, (uint32_t)(q * kThreads * 4 + 256), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1[q]), rW, vt, (uint32_t)((16 + q) * kThreads * 4), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc3[q]), rW, vt, (uint32_t)((16 + q) * kThreads * 4 + 256), 0);
+                    } else if constexpr (WC == 64) {    // the image is laid out for four waves x 32 columns: this wave fills the places of waves 2 wv and 2 wv + 1; rows 32..63: none
                         const uint32_t vt = (uint32_t)((2 * wv) * 64 + lane) * 4u;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc0[q]), rW, vt, (uint32_t)(q * kThreads * 4), 0);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1[q]), rW, vt, (uint32_t)(q * kThreads * 4 + 256), 0);
@@ -510,34 +524,37 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_direct_kernel(const 
                 const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;
                 const uint32_t mistep = p.c_row_major ? (uint32_t)p.ldc * 128u : 128u;
 #pragma unroll
-                for (int mi = 0; mi < ((MI2 || WC == 64) ? 2 : 1); mi++) {     // acc1: rows 32..63 of the tile (MI2) or columns 32..63 of the wave (WC = 64)
-                    // (WC = 64: the second group of 32 columns gets its own scalar base, so that the per-lane offsets keep spanning 32 columns of C)
-                    const uint32_t hstep = WC == 64 ? 0u : mistep;
-                    const __amdgpu_buffer_rsrc_t rCm = (WC == 64 && mi == 1)
+                for (int cg = 0; cg < NG; cg++) {                              // the wave's groups of 32 columns (WC = 64: two), each with its own scalar base, so that
+                    // the per-lane offsets keep spanning 32 columns of C
+                    const __amdgpu_buffer_rsrc_t rCm = cg == 1
                         ? __builtin_amdgcn_make_buffer_rsrc(p.c_row_major ? cbase + 32 : cbase + 32 * p.ldc, 0, 0x7ffffff0, 0x00020000) : rC;
-                    if ((WC == 64 ? 0 : mi * 32) + lm < mt) {
-                        float v[16];
 #pragma unroll
-                        for (int q = 0; q < 16; q++) v[q] = mi == 0 ? acc0[q] : acc1[q];
-                        if (p.accumulate) {
-                            uint32_t old[16];
+                    for (int mi = 0; mi < NA; mi++) {                          // rows 0..31 / 32..63 of the tile (MI2)
+                        if (mi * 32 + lm < mt) {
+                            float v[16];
 #pragma unroll
-                            for (int q = 0; q < 16; q++) old[q] = __builtin_amdgcn_raw_buffer_load_b32(rCm, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * hstep, 0);
+                            for (int q = 0; q < 16; q++) v[q] = QUAD ? (cg == 0 ? (mi == 0 ? acc0[q] : acc1[q]) : (mi == 0 ? acc2[q] : acc3[q]))
+                                                                     : ((cg + mi) == 0 ? acc0[q] : acc1[q]);
+                            if (p.accumulate) {
+                                uint32_t old[16];
 #pragma unroll
-                            for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
-                        }
-                        if (p.c_nt) {
+                                for (int q = 0; q < 16; q++) old[q] = __builtin_amdgcn_raw_buffer_load_b32(rCm, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
 #pragma unroll
-                            for (int q = 0; q < ((SPARTA_H16_PROBE & 512) ? 1 : 16); q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rCm, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * hstep, 2);
-                        } else {
+                                for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
+                            }
+                            if (p.c_nt) {
 #pragma unroll
-                            for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rCm, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * hstep, 0);
+                                for (int q = 0; q < ((SPARTA_H16_PROBE & 512) ? 1 : 16); q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rCm, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 2);
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 16; q++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rCm, voffC, (uint32_t)((q & 3) + 8 * (q >> 2)) * jstep + (uint32_t)mi * mistep, 0);
+                            }
                         }
                     }
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 16; q++) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
+            for (int q = 0; q < 16; q++) { acc0[q] = 0.0f; acc1[q] = 0.0f; if constexpr (QUAD) { acc2[q] = 0.0f; acc3[q] = 0.0f; } }
         }
     };
 
@@ -638,6 +655,20 @@ __global__ __launch_bounds__(kThreads) void vbs_tail_copy_h16_kernel(const uint1
     for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
         const int64_t k = e % w, j = e / w;
         B_tail[e] = (row0 + k < cols) ? B[row0 + k + j * ldb] : (uint16_t)0;
+    }
+}
+
+// the column tail of a 16-bit product whose n_cols is not a multiple of 128: C[:, col0 + j] (+)= Ct[:, j], j < n_t (Ct column-major, ld = rows)
+__global__ __launch_bounds__(kThreads) void vbs_col_tail_merge_kernel(const float* Ct, int64_t rows, float* C, int64_t ldc, int c_row_major, int col0,
+                                                                      int n_t, int accumulate) {
+    const int64_t total = rows * (int64_t)n_t;
+    for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+        // column-major C: consecutive threads walk a column (coalesced on both sides); row-major C: consecutive threads walk a row of C
+        const int64_t r = c_row_major ? e / n_t : e % rows;
+        const int j = (int)(c_row_major ? e % n_t : e / rows);
+        float* dst = c_row_major ? C + r * ldc + col0 + j : C + r + (int64_t)(col0 + j) * ldc;
+        const float v = Ct[r + (int64_t)j * rows];
+        *dst = accumulate ? *dst + v : v;
     }
 }
 
@@ -749,8 +780,28 @@ void launch_h16_slab256(bool bf16, dim3 grid, hipStream_t st, const StreamParams
     }
 }
 
+// 64-row tiles of 64-wide blocks over 256-column slabs, four accumulators per wave (QUAD): grid = (workers, n_cols / 256)
+void launch_h16_quad(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (gathered) {                                      // (a gathered B has no partial last block column: cols = n_shards * shard_rows, shard_rows % w == 0)
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<64, true, true, true, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<64, true, false, true, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
+    } else if (sp.B_tail != nullptr) {
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<64, true, true, false, false, false, true, 64, true>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<64, true, false, false, false, false, true, 64, true>), grid, dim3(kThreads), 0, st, sp);
+    } else {
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<64, true, true, false, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<64, true, false, false, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
+    }
+}
+
 void launch_tail_copy_h16(hipStream_t st, const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N, uint16_t* B_tail) {
     hipLaunchKernelGGL(vbs_tail_copy_h16_kernel, dim3(32), dim3(kThreads), 0, st, B, ldb, row0, cols, w, N, B_tail);
+}
+
+void launch_col_tail_merge(hipStream_t st, const float* Ct, int64_t rows, float* C, int64_t ldc, int c_row_major, int col0, int n_t, int accumulate) {
+    const int64_t total = rows * (int64_t)n_t;
+    const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (total + kThreads - 1) / kThreads));
+    hipLaunchKernelGGL(vbs_col_tail_merge_kernel, dim3(g), dim3(kThreads), 0, st, Ct, rows, C, ldc, c_row_major, col0, n_t, accumulate);
 }
 
 void launch_convert_h16(bool bf16, hipStream_t st, const float* src, int64_t ld_in, int64_t rows, int64_t n_cols, uint16_t* dst, int64_t ld_out) {

@@ -67,7 +67,7 @@ int vbs_build(const CsrView& a, const int64_t* grouping, int64_t w, int64_t row_
 // (sparta_vbs_create_from_csr).  A clustered power-law matrix is 98 % zeros inside its blocks: the dense image of a
 // 20 M-nonzero R-MAT matrix is 4 GB, of a 124 M-nonzero one 25 GB, all of it skipped by the kernels that then run.
 int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64_t row_block_size, bool force_fixed,
-                     double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp, bool keep_order) {
+                     double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp, bool keep_order, HybridStats* stats_only) {
     if (!out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_build: out is NULL");
     std::memset(out, 0, sizeof(*out));
     if (w <= 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_build: col_block_size must be > 0");
@@ -193,6 +193,20 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                 out->nzcount[ib] = nb_all[(size_t)ib];
                 sp_rows_of[(size_t)ib] = sp_ent_of[(size_t)ib] = 0;
             }
+        }
+        if (stats_only) {                                                  // sparta_vbs_plan_stats: the decisions are all that is wanted
+            HybridStats st;
+            st.block_rows = block_rows; st.rows = rows;
+            for (int64_t ib = 0; ib < block_rows; ib++) {
+                const int64_t h = part[(size_t)ib + 1] - part[(size_t)ib];
+                st.tile_blocks += out->nzcount[ib];
+                st.tile_area += out->nzcount[ib] * h * w;
+                st.mfma_steps += (double)out->nzcount[ib] * spb_of(h);
+                st.sparse_nnz += sp_ent_of[(size_t)ib];
+                st.sparse_rows += sp_rows_of[(size_t)ib];
+            }
+            *stats_only = st;
+            return SPARTA_OK;
         }
         sp->flag.assign(mode.begin(), mode.end());
         std::vector<int64_t> row_base((size_t)block_rows + 1, 0), ent_base((size_t)block_rows + 1, 0);

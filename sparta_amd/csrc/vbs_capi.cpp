@@ -72,6 +72,8 @@ void destroy_impl(sparta_vbs* v) {
     if (v->d_btail) (void)hipFree(v->d_btail);
     if (v->d_tune) (void)hipFree(v->d_tune);
     if (v->d_B16) (void)hipFree(v->d_B16);
+    if (v->d_Bt) (void)hipFree(v->d_Bt);
+    if (v->d_Ct) (void)hipFree(v->d_Ct);
     if (v->d_clk) (void)hipFree(v->d_clk);
     if (v->tev0) (void)hipEventDestroy(v->tev0);
     if (v->tev1) (void)hipEventDestroy(v->tev1);
@@ -540,6 +542,32 @@ static int create_from_csr_impl(sparta_vbs_t** out, int64_t rows, int64_t cols, 
     return rc;
 }
 
+int sparta_vbs_plan_stats(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals, const int64_t* grouping,
+                          int64_t col_block_size, int64_t row_block_size, int32_t force_fixed_size, int32_t dtype, int64_t* stats) {
+    SPARTA_GUARD_BEGIN
+    using sparta::fail;
+    if (!stats) return fail(SPARTA_ERR_INVALID, "sparta_vbs_plan_stats: stats is NULL");
+    if (dtype != SPARTA_F32 && dtype != SPARTA_F16 && dtype != SPARTA_BF16) return fail(SPARTA_ERR_INVALID, "sparta_vbs_plan_stats: bad dtype");
+    sparta::CsrView a;
+    a.rows = rows; a.cols = cols; a.rowptr = rowptr; a.colidx = colidx; a.vals = vals;
+    double K = 24.0;
+    if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
+    if (!(K > 0.0)) K = 1e-9;                                             // the sparse-row path switched off: everything is a tile
+    const int64_t kdep = (dtype != SPARTA_F32 && col_block_size % 64 == 0) ? 64 : 32;
+    sparta::HybridSparse sp;
+    sp.esz = dtype == SPARTA_F32 ? 4.0 : 2.0;
+    sparta::HybridStats st;
+    sparta_vbs_host h;
+    std::memset(&h, 0, sizeof(h));
+    const int rc = sparta::vbs_build_hybrid(a, grouping, col_block_size, row_block_size, force_fixed_size != 0, K, kdep, &h, &sp, false, &st);
+    sparta_vbs_host_free(&h);
+    if (rc != SPARTA_OK) return rc;
+    stats[0] = st.tile_blocks; stats[1] = st.tile_area; stats[2] = (int64_t)(st.mfma_steps + 0.5); stats[3] = st.sparse_nnz; stats[4] = st.sparse_rows;
+    stats[5] = st.block_rows; stats[6] = st.rows; stats[7] = 0;
+    return SPARTA_OK;
+    SPARTA_GUARD_END("sparta_vbs_plan_stats")
+}
+
 int sparta_vbs_create_from_csr(sparta_vbs_t** out, int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals,
                                const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, int32_t force_fixed_size,
                                int32_t dtype, int32_t device) {
@@ -724,6 +752,7 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     const bool in_place = !(b_row_major && shard_rows == 0) && A->sp_nnz * 8 < A->cols;
     if (b_row_major && shard_rows == 0) { q.B = dB; q.ldb = ldb; }
     else if (in_place) { q.B = dB; q.ldb = 0; q.b_col_stride = ldb; q.shard_rows = shard_rows; q.shard_stride = shard_stride; }
+    else if (A->prepared_brm) { q.B = A->prepared_brm; q.ldb = n_cols; }        // sparta_vbs_prepare_b: transposed once, not per product
     else {
         if (int rc = ensure_scratch(&A->d_Brm, &A->d_Brm_bytes, (size_t)A->cols * (size_t)n_cols * esz)) return rc;
         const int64_t n_wg = ((A->cols + 63) / 64) * (int64_t)((n_cols + 63) / 64);
@@ -760,14 +789,15 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
 
 // 16-bit handles (SPARTA_F16 / SPARTA_BF16): A and B in the 16-bit type, fp32 accumulation, fp32 C.  Device pointers: B is a
 // 16-bit column-major matrix (ldb in elements, even).  Host pointers keep the reference's contract (fp32 B in, fp32 C out):
-// B is converted on the device (round to nearest even).
-int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int64_t shard_rows, int64_t shard_stride, int32_t n_cols, void* C,
+// B is converted on the device (round to nearest even).  This is the product over whole 128-column slabs; spmm16_impl (below) cuts a
+// call with any other n_cols into whole slabs + one padded tail slab.
+int spmm16_core(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int64_t shard_rows, int64_t shard_stride, int32_t n_cols, void* C,
                 int64_t ldc, int32_t c_layout, int32_t accumulate, int32_t ptr_space, hipStream_t st, int32_t algo, float* dt_ms) {
     using sparta::fail;
     if (algo != SPARTA_SPMM_MFMA) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: SPARTA_SPMM_EXACT needs an fp32 handle");
     if (shard_rows != 0 && ptr_space != SPARTA_PTR_DEVICE) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: device pointers only");
     if (b_layout != SPARTA_COL_MAJOR) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit handles need a column-major B (k contiguous)");
-    if (n_cols % kTN != 0) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit handles need n_cols % 128 == 0");
+    if (n_cols % kTN != 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm: internal: the 16-bit core takes whole 128-column slabs");
     const bool bf16 = A->dtype == SPARTA_BF16;
     const size_t c_elems = (size_t)ldc * (size_t)(c_layout == SPARTA_COL_MAJOR ? n_cols : A->rows);
     const uint16_t* dB = (const uint16_t*)B;
@@ -836,7 +866,14 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
             // two ascending passes and the gain is gone: 41.1 us; allowed there with SPARTA_H16_SLAB256=2).  SPARTA_H16_SLAB256=0: off.
             const bool slab256 = ty == 0 && A->kp16 == 32 && !gth && !c_stage && A->n_split == 0 && n_cols % 256 == 0 && h16_uses_direct_kernel(32, false) && ldb16 * 64 * 2 < ((int64_t)1 << 31) - 65536 &&
                                  [&] { const char* e = std::getenv("SPARTA_H16_SLAB256"); const int m = e ? atoi(e) : 1; return m == 2 || (m == 1 && !A->wide16); }();
-            if (slab256) {
+            // 64-row tiles of 64-wide blocks (the dense hub of a power-law matrix under the fixed 64 x 64 grid), N % 256 == 0: four accumulators per wave over
+            // 256-column slabs -- A read once per 256 columns, every B fragment used twice (k_h16.hip, QUAD); split tiles allowed.  SPARTA_H16_QUAD=0: off.
+            const bool quad = ty == 1 && A->kp16 == 64 && n_cols % 256 == 0 && h16_uses_direct_kernel(64, true) && ldb16 * 64 * 2 < ((int64_t)1 << 31) - 65536 &&
+                              [] { const char* e = std::getenv("SPARTA_H16_QUAD"); return !e || atoi(e) != 0; }();
+            if (quad) {
+                sp.sub_ranges = 0;
+                launch_h16_quad(bf16, gth, dim3((unsigned)A->n_workers, (unsigned)(n_cols / 256)), st, sp);
+            } else if (slab256) {
                 sp.sub_ranges = A->wide16 ? 1 : 0;
                 launch_h16_slab256(bf16, dim3((unsigned)A->n_workers, (unsigned)(n_cols / 256)), st, sp);
                 sp.sub_ranges = 0;
@@ -869,6 +906,71 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
         HIP_TRY(hipEventRecord(A->ev1, st));
         HIP_TRY(hipEventSynchronize(A->ev1));
         HIP_TRY(hipEventElapsedTime(dt_ms, A->ev0, A->ev1));
+    }
+    if (ptr_space == SPARTA_PTR_HOST) {
+        HIP_TRY(hipMemcpyAsync(C, A->d_C, c_elems * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SPARTA_OK;
+}
+
+// Any n_cols on a 16-bit handle (the reference's `-c` is arbitrary, include/input.h:15-42): the whole 128-column slabs go through the
+// kernels as they are; the last n_cols % 128 columns of B are copied (they are contiguous in a column-major B: one copy, per slab of a
+// gathered B one row of a 2-D copy) into a zero-padded 128-column slab, multiplied by the same kernels into a scratch slab of C, and their
+// n_cols % 128 columns merged into the caller's C (either layout, accumulate or not).  Costs scratch of 128 columns of B and of C, only
+// on calls that have such a tail.
+int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int64_t shard_rows, int64_t shard_stride, int32_t n_cols, void* C,
+                int64_t ldc, int32_t c_layout, int32_t accumulate, int32_t ptr_space, hipStream_t st, int32_t algo, float* dt_ms) {
+    using sparta::fail;
+    if (n_cols % kTN == 0) return spmm16_core(A, B, ldb, b_layout, shard_rows, shard_stride, n_cols, C, ldc, c_layout, accumulate, ptr_space, st, algo, dt_ms);
+    if (algo != SPARTA_SPMM_MFMA) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: SPARTA_SPMM_EXACT needs an fp32 handle");
+    if (shard_rows != 0 && ptr_space != SPARTA_PTR_DEVICE) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: device pointers only");
+    if (b_layout != SPARTA_COL_MAJOR) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit handles need a column-major B (k contiguous)");
+    const bool bf16 = A->dtype == SPARTA_BF16;
+    const int32_t n_main = n_cols / kTN * kTN, n_t = n_cols - n_main;
+    const size_t c_elems = (size_t)ldc * (size_t)(c_layout == SPARTA_COL_MAJOR ? n_cols : A->rows);
+    const uint16_t* dB = (const uint16_t*)B;
+    float* dC = (float*)C;
+    int64_t ldb16 = ldb;
+    if (ptr_space == SPARTA_PTR_HOST) {                    // stage here (the core's own staging assumes whole slabs)
+        const size_t b_elems = (size_t)ldb * (size_t)n_cols;
+        ldb16 = (A->cols + 7) / 8 * 8;
+        if (int rc = ensure_scratch(&A->d_B, &A->d_B_bytes, b_elems * sizeof(float))) return rc;
+        if (int rc = ensure_scratch(&A->d_B16, &A->d_B16_bytes, (size_t)ldb16 * n_cols * sizeof(uint16_t))) return rc;
+        if (int rc = ensure_scratch(&A->d_C, &A->d_C_bytes, c_elems * sizeof(float))) return rc;
+        HIP_TRY(hipMemcpyAsync(A->d_B, B, b_elems * sizeof(float), hipMemcpyHostToDevice, st));
+        if (accumulate) HIP_TRY(hipMemcpyAsync(A->d_C, C, c_elems * sizeof(float), hipMemcpyHostToDevice, st));
+        else if (c_elems > 0) HIP_TRY(hipMemsetAsync(A->d_C, 0, c_elems * sizeof(float), st));
+        launch_convert_h16(bf16, st, (const float*)A->d_B, ldb, A->cols, (int64_t)n_cols, (uint16_t*)A->d_B16, ldb16);
+        dB = (const uint16_t*)A->d_B16;
+        dC = (float*)A->d_C;
+    } else if (ldb % 2 != 0 && shard_rows == 0) {
+        return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: 16-bit B needs an even leading dimension (16-byte loads start on 4-byte boundaries)");
+    }
+    if (dt_ms) HIP_TRY(hipEventRecord(A->tev0, st));
+    // (1) the whole slabs
+    if (n_main > 0)
+        if (int rc = spmm16_core(A, dB, ldb16, b_layout, shard_rows, shard_stride, n_main, dC, ldc, c_layout, accumulate, SPARTA_PTR_DEVICE, st, algo, nullptr)) return rc;
+    // (2) the tail slab: n_t columns of B + zero columns
+    const int64_t n_shards = shard_rows > 0 ? A->cols / shard_rows : 1;
+    const int64_t ld_t = shard_rows > 0 ? shard_rows : ldb16;                     // rows of a column of the tail slab of B
+    const size_t bt_elems = (size_t)ld_t * kTN * (size_t)n_shards;
+    if (int rc = ensure_scratch(&A->d_Bt, &A->d_Bt_bytes, bt_elems * sizeof(uint16_t))) return rc;
+    if (int rc = ensure_scratch(&A->d_Ct, &A->d_Ct_bytes, (size_t)A->rows * kTN * sizeof(float))) return rc;
+    HIP_TRY(hipMemsetAsync(A->d_Bt, 0, bt_elems * sizeof(uint16_t), st));
+    if (shard_rows > 0)
+        HIP_TRY(hipMemcpy2DAsync(A->d_Bt, (size_t)shard_rows * kTN * sizeof(uint16_t), dB + (size_t)n_main * shard_rows, (size_t)shard_stride * sizeof(uint16_t),
+                                 (size_t)n_t * shard_rows * sizeof(uint16_t), (size_t)n_shards, hipMemcpyDeviceToDevice, st));
+    else
+        HIP_TRY(hipMemcpyAsync(A->d_Bt, dB + (size_t)n_main * ldb16, (size_t)n_t * ldb16 * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
+    if (int rc = spmm16_core(A, A->d_Bt, ld_t, b_layout, shard_rows, shard_rows > 0 ? shard_rows * kTN : 0, kTN, A->d_Ct, A->rows, SPARTA_COL_MAJOR, 0,
+                             SPARTA_PTR_DEVICE, st, algo, nullptr)) return rc;
+    launch_col_tail_merge(st, (const float*)A->d_Ct, A->rows, dC, ldc, (int)(c_layout == SPARTA_ROW_MAJOR), n_main, n_t, (int)(accumulate != 0));
+    HIP_TRY(hipGetLastError());
+    if (dt_ms) {
+        HIP_TRY(hipEventRecord(A->tev1, st));
+        HIP_TRY(hipEventSynchronize(A->tev1));
+        HIP_TRY(hipEventElapsedTime(dt_ms, A->tev0, A->tev1));
     }
     if (ptr_space == SPARTA_PTR_HOST) {
         HIP_TRY(hipMemcpyAsync(C, A->d_C, c_elems * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1100,6 +1202,69 @@ int sparta_vbs_spmm_gathered(sparta_vbs_t* A, const void* B_gathered, int64_t sh
     return spmm_impl(A, B_gathered, shard_rows, SPARTA_COL_MAJOR, shard_rows, shard_stride, n_cols, C, ldc, c_layout, accumulate,
                      SPARTA_PTR_DEVICE, stream, algo, dt_ms);
     SPARTA_GUARD_END("sparta_vbs_spmm_gathered")
+}
+
+// ---- a B that does not change between products, prepared once ------------------------------------------------------------
+struct sparta_b {
+    const void* B = nullptr;
+    int64_t ldb = 0, shard_rows = 0, shard_stride = 0, cols = 0;
+    int32_t n_cols = 0, dtype = 0, device = 0;
+    void* d_Brm = nullptr;                 // row-major copy for the sparse-row kernels (nullptr: this handle / shape does not need one)
+};
+
+int sparta_vbs_prepare_b(sparta_vbs_t* A, const void* B, int64_t ldb, int64_t shard_rows, int64_t shard_stride, int32_t n_cols, void* stream,
+                         sparta_b_t** out) {
+    using sparta::fail;
+    SPARTA_GUARD_BEGIN
+    if (!A || !B || !out) return fail(SPARTA_ERR_INVALID, "sparta_vbs_prepare_b: NULL argument");
+    *out = nullptr;
+    if (n_cols <= 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_prepare_b: n_cols must be > 0");
+    if (shard_rows == 0 && ldb < A->cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_prepare_b: ldb too small");
+    if (shard_rows != 0 && (shard_rows < 0 || shard_rows % A->w != 0 || A->cols % shard_rows != 0 || shard_stride < shard_rows * (int64_t)n_cols))
+        return fail(SPARTA_ERR_INVALID, "sparta_vbs_prepare_b: bad gathered layout");
+    if (g_capturing) return capture_refusal("prepare a copy of B");
+    DeviceGuard guard(A->device);
+    sparta_b* p = new (std::nothrow) sparta_b;
+    if (!p) return fail(SPARTA_ERR_ALLOC, "sparta_vbs_prepare_b: out of host memory");
+    p->B = B; p->ldb = shard_rows ? shard_rows : ldb; p->shard_rows = shard_rows; p->shard_stride = shard_stride; p->cols = A->cols;
+    p->n_cols = n_cols; p->dtype = A->dtype; p->device = A->device;
+    const size_t esz = A->dtype == SPARTA_F32 ? 4 : 2;
+    // the sparse-row kernels of this handle would transpose this B per product (launch_sparse_rows: not when a handful of rows reads it in place)
+    const bool needs_copy = A->n_sp_rows > 0 && !(A->sp_nnz * 8 < A->cols);
+    if (needs_copy) {
+        hipStream_t st = (hipStream_t)stream;
+        const int64_t n_wg = ((A->cols + 63) / 64) * (int64_t)((n_cols + 63) / 64);
+        if (n_wg > INT32_MAX) { delete p; return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_prepare_b: B too large for the transpose grid"); }
+        if (hipMalloc(&p->d_Brm, (size_t)A->cols * (size_t)n_cols * esz) != hipSuccess) { delete p; return fail(SPARTA_ERR_ALLOC, "sparta_vbs_prepare_b: out of device memory"); }
+        launch_b_to_row_major(A->dtype != SPARTA_F32, (unsigned)n_wg, st, B, p->ldb, shard_rows, shard_stride, A->cols, (int)n_cols, p->d_Brm);
+        if (hipGetLastError() != hipSuccess) { (void)hipFree(p->d_Brm); delete p; return fail(SPARTA_ERR_HIP, "sparta_vbs_prepare_b: launch failed"); }
+    }
+    *out = p;
+    return SPARTA_OK;
+    SPARTA_GUARD_END("sparta_vbs_prepare_b")
+}
+
+int sparta_vbs_spmm_prepared(sparta_vbs_t* A, const sparta_b_t* Bp, void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, void* stream,
+                             float* dt_ms) {
+    using sparta::fail;
+    if (!A || !Bp || !C) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_prepared: NULL argument");
+    if (Bp->cols != A->cols || Bp->dtype != A->dtype || Bp->device != A->device)
+        return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_prepared: this B was prepared for another handle shape / type / device");
+    SPARTA_GUARD_BEGIN
+    A->prepared_brm = Bp->d_Brm;
+    const int rc = spmm_impl(A, Bp->B, Bp->ldb, SPARTA_COL_MAJOR, Bp->shard_rows, Bp->shard_stride, Bp->n_cols, C, ldc, c_layout, accumulate,
+                             SPARTA_PTR_DEVICE, stream, SPARTA_SPMM_MFMA, dt_ms);
+    A->prepared_brm = nullptr;
+    return rc;
+    SPARTA_GUARD_END("sparta_vbs_spmm_prepared")
+}
+
+int sparta_b_destroy(sparta_b_t* Bp) {
+    if (!Bp) return SPARTA_OK;
+    DeviceGuard guard(Bp->device);
+    if (Bp->d_Brm) (void)hipFree(Bp->d_Brm);
+    delete Bp;
+    return SPARTA_OK;
 }
 
 int sparta_vbs_set_class_timing(sparta_vbs_t* A, int32_t enable) {

@@ -199,6 +199,10 @@ struct sparta_vbs {
     size_t d_tune_bytes = 0;
     void* d_B16 = nullptr;                 // 16-bit handles, host-pointer calls: B converted on the device
     size_t d_B16_bytes = 0;
+    void* d_Bt = nullptr;                  // 16-bit handles, n_cols % 128 != 0: the last n_cols % 128 columns of B, zero-padded to a 128-column slab
+    size_t d_Bt_bytes = 0;
+    void* d_Ct = nullptr;                  // ... and the 128-column slab of C they produce (column-major, ld = rows), merged into C afterwards
+    size_t d_Ct_bytes = 0;
     long long* d_clk = nullptr;           // clock probe: [4 launches][4] = {s_memtime, s_memrealtime} at entry, at exit
     hipEvent_t tev0 = nullptr, tev1 = nullptr;
     // sparse-row path (fp32 handles): the block-rows taken out of the MFMA plans, as rows of (column, value)
@@ -216,6 +220,7 @@ struct sparta_vbs {
     size_t d_sp_part_bytes = 0;
     void* d_Brm = nullptr;                 // row-major copy of a column-major / gathered B
     size_t d_Brm_bytes = 0;
+    const void* prepared_brm = nullptr;    // set for the duration of a sparta_vbs_spmm_prepared call: the caller's row-major copy, made once
     void* d_B = nullptr;
     size_t d_B_bytes = 0;
     void* d_C = nullptr;
@@ -242,8 +247,11 @@ void launch_zero_rows(dim3 grid, hipStream_t st, float* C, int64_t ldc, int c_ro
 void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, bool c_stage, bool wide, dim3 grid, hipStream_t st, const StreamParams& sp);
 void launch_h16_slab256(bool bf16, dim3 grid, hipStream_t st, const StreamParams& sp);   // one-tile plans of 32-wide blocks, 256-column slabs (grid.y = N / 256), no split tile
 bool h16_uses_direct_kernel(int kp, bool mi2);
+void launch_h16_quad(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
 void launch_tail_copy_h16(hipStream_t st, const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N, uint16_t* B_tail);
 void launch_convert_h16(bool bf16, hipStream_t st, const float* src, int64_t ld_in, int64_t rows, int64_t n_cols, uint16_t* dst, int64_t ld_out);
+// C[:, col0 + j] (+)= Ct[:, j] for j < n_t: the column tail of a 16-bit product (Ct column-major, ld = rows)
+void launch_col_tail_merge(hipStream_t st, const float* Ct, int64_t rows, float* C, int64_t ldc, int c_row_major, int col0, int n_t, int accumulate);
 // k_sparse.hip
 void launch_sparse_kernels(int vec, int bk, const SparseParams& q, unsigned gy, hipStream_t st, const int32_t* list, int64_t n_short, const SpSegRec* segs,
                            int64_t n_segs, const SpLongRec* longs, int64_t n_long, float* part);

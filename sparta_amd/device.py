@@ -51,6 +51,37 @@ class DeviceVBS:
         self.rows, self.cols = info["rows"], info["cols"]
         return self
 
+    @staticmethod
+    def plan_stats(cmat, grouping, col_block_size, row_block_size=0, force_fixed_size=False, dtype=_lib.F32):
+        """sparta_vbs_plan_stats: what from_csr WOULD build for this grouping (no GPU, nothing built): tiles, their area and MFMA
+        steps, and what is left to the sparse-row kernels."""
+        g = np.ascontiguousarray(grouping, np.int64)
+        if g.shape != (cmat.rows,):
+            raise ValueError("grouping must have one entry per row")
+        rp = np.ascontiguousarray(cmat.rowptr, np.int64)
+        ci = np.ascontiguousarray(cmat.colidx, np.int32)
+        vals = None if cmat.vals is None else np.ascontiguousarray(cmat.vals, np.float32)
+        st = np.zeros(8, np.int64)
+        check(lib.sparta_vbs_plan_stats(cmat.rows, cmat.cols, rp.ctypes.data_as(_i64p), ci.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        None if vals is None else vals.ctypes.data_as(_f32p), g.ctypes.data_as(_i64p), int(col_block_size),
+                                        int(row_block_size), int(bool(force_fixed_size)), int(dtype), st.ctypes.data_as(_i64p)))
+        keys = ["tile_blocks", "tile_area", "mfma_steps", "sparse_nnz", "sparse_rows", "block_rows", "rows"]
+        return {k: int(st[i]) for i, k in enumerate(keys)}
+
+    @staticmethod
+    def predict_cost(cmat, grouping, col_block_size, row_block_size=0, force_fixed_size=False, dtype=_lib.F32, n_cols=128):
+        """Predicted time of one product of the handle from_csr would build (plan_stats x measured rates on one MI355X): the dense tiles at
+        the executed rate of the stream kernels on power-law hubs (16-bit: 220 TFLOP/s = 13.6 ms for 5.8e9 stored elements x 256 columns;
+        fp32: 100), the sparse rows at the gather rate (one n_cols-wide row of B per nonzero at 5.9 TB/s) + their rows of C.  Good to
+        ~10 % on R-MAT parts (profiles/r3): enough to choose between two blockings of one matrix, which is all it is for."""
+        st = DeviceVBS.plan_stats(cmat, grouping, col_block_size, row_block_size, force_fixed_size, dtype)
+        esz = 4.0 if dtype == _lib.F32 else 2.0
+        t_tiles = 2.0 * st["tile_area"] * n_cols / ((100e12 if dtype == _lib.F32 else 220e12))
+        t_sparse = st["sparse_nnz"] * (n_cols * esz + 8.0) / 5.9e12 + st["sparse_rows"] * n_cols * 4.0 / 5.9e12
+        st["ms_tiles"], st["ms_sparse"] = t_tiles * 1e3, t_sparse * 1e3
+        st["ms"] = (t_tiles + t_sparse) * 1e3
+        return st
+
     @classmethod
     def transposed_of(cls, vbmat, device=0, dtype=_lib.F32):
         """sparta_vbs_create_transposed: the handle of A^T, for the B * A product (spmm_BA)"""
@@ -154,6 +185,42 @@ class DeviceVBS:
                                            int(algo), C.byref(dt) if timed else None))
         return dt.value if timed else None
 
+    def prepare_b(self, B, n_cols, ldb=None, shard_rows=0, shard_stride=None, stream=None):
+        """sparta_vbs_prepare_b: a B that stays the same over many products, prepared once (its row-major copy for the sparse-row kernels is
+        made now instead of on every product).  Returns a PreparedB; B itself is referenced, not copied: keep it alive and unchanged."""
+        import torch
+        want_b = {_lib.F32: torch.float32, _lib.F16: torch.float16, _lib.BF16: torch.bfloat16}[self.dtype]
+        if not (B.is_cuda and B.dtype == want_b and B.device.index == self.device and B.is_contiguous()):
+            raise ValueError("B must be a contiguous %s tensor on device %d" % (want_b, self.device))
+        ldb = self.cols if ldb is None else int(ldb)
+        if shard_rows:
+            shard_stride = shard_rows * n_cols if shard_stride is None else int(shard_stride)
+            need = (self.cols // shard_rows) * shard_stride
+        else:
+            shard_stride, need = 0, ldb * n_cols
+        if B.numel() < need:
+            raise ValueError("B too small for the stated layout")
+        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        h = C.c_void_p(None)
+        check(lib.sparta_vbs_prepare_b(self.h, C.c_void_p(B.data_ptr()), int(ldb), int(shard_rows), int(shard_stride), int(n_cols), C.c_void_p(st), C.byref(h)))
+        return PreparedB(self, h, B, int(n_cols))
+
+    def spmm_prepared(self, Bp, C_out, accumulate=False, c_layout=_lib.COL_MAJOR, ldc=None, timed=False, stream=None):
+        """sparta_vbs_spmm_prepared: C (+)= A * B for a PreparedB of this handle"""
+        import torch
+        if Bp.owner is not self or not Bp.h:
+            raise ValueError("this B was prepared for another handle (or already closed)")
+        if not (C_out.is_cuda and C_out.dtype == torch.float32 and C_out.device.index == self.device and C_out.is_contiguous()):
+            raise ValueError("C must be a contiguous float32 tensor on device %d" % self.device)
+        ldc = (self.rows if c_layout == _lib.COL_MAJOR else Bp.n_cols) if ldc is None else ldc
+        if C_out.numel() < ldc * (Bp.n_cols if c_layout == _lib.COL_MAJOR else self.rows):
+            raise ValueError("C too small")
+        st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        dt = C.c_float(0)
+        check(lib.sparta_vbs_spmm_prepared(self.h, Bp.h, C.c_void_p(C_out.data_ptr()), int(ldc), c_layout, int(bool(accumulate)), C.c_void_p(st),
+                                           C.byref(dt) if timed else None))
+        return dt.value if timed else None
+
     def set_class_timing(self, enable=True):
         check(lib.sparta_vbs_set_class_timing(self.h, int(bool(enable))))
 
@@ -179,6 +246,24 @@ class DeviceVBS:
     def close(self):
         if self.h:
             lib.sparta_vbs_destroy(self.h)
+            self.h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PreparedB:
+    """sparta_b_t: a constant dense operand prepared for one handle (DeviceVBS.prepare_b)"""
+
+    def __init__(self, owner, h, B, n_cols):
+        self.owner, self.h, self.B, self.n_cols = owner, h, B, n_cols          # (keeps B alive)
+
+    def close(self):
+        if self.h:
+            lib.sparta_b_destroy(self.h)
             self.h = C.c_void_p(None)
 
     def __del__(self):

@@ -256,6 +256,10 @@ def ogbn_products_like(seed=3, device=0, **kw):
 # piece): a counter-based hash (splitmix64 finaliser) supplies 16 bits per level; at the levels the piece fixes only the column bit is
 # drawn, from its conditional distribution given the row bit.  Duplicates are removed per piece; the value of an entry is a hash of
 # (seed, row, column).  So rank r of an N-rank job and slab r of a one-GPU run produce bit-identical rows, whatever N is.
+# SATURATED pieces (configs[3] at 1 % and 5 %: the hub rows are nearly full, a piece would draw 2 .. 40 raw edges per cell) are sampled
+# cell by cell instead: cell (i, j) is present with probability 1 - exp(-raw_edges * p_ij) -- the Poisson limit of the same model, the one
+# rmat_row_model counts with -- decided by a hash of (seed, i, j).  A piece is saturated when its raw edges reach half its cells: a rule of
+# (scale, raw_edges) alone, so every rank agrees.
 PIECE_ROWS_LOG2 = 10
 _M64 = (1 << 64) - 1
 
@@ -339,23 +343,112 @@ def _popcount_np(x):
         x = x >> np.uint64(1)
 
 
-def rmat_piece_table(scale, raw_edges, a=0.57, b=0.19, c=0.19):
-    """Per canonical piece: (raw edges it receives, expected cost = expected distinct entries + rows).  Pure arithmetic: every rank
-    computes the same table."""
+def rmat_block_model(scale, raw_edges, a=0.57, b=0.19, c=0.19, block=64, tile_min_nnz=120.0):
+    """What the fixed block x block grid of the graph looks like, per popcount kr of a block-row's top (scale - log2 block) row bits:
+    (expected nonzeros in blocks with fewer than tile_min_nnz expected nonzeros, expected number of the other -- well-filled -- blocks,
+    expected nonzeros of the block-row).  The hybrid builder keeps the well-filled blocks as MFMA tiles and sends the nonzeros of the
+    others through the sparse-row kernels (vbs_build.cpp: SPARTA_SPARSE_K_BLOCK = 60 per step, two steps per 64 x 64 16-bit block);
+    a tile costs about as much as tile_min_nnz gathered nonzeros, so the two shares are what a part's product time is made of."""
+    from math import comb, factorial
+    s = int(scale)
+    lb = int(block).bit_length() - 1
+    T = s - lb
+    d = 1.0 - a - b - c
+    # the cells of one block: the low lb levels, grouped by how many levels fall in each quadrant
+    comps = []
+    for n00 in range(lb + 1):
+        for n01 in range(lb + 1 - n00):
+            for n10 in range(lb + 1 - n00 - n01):
+                n11 = lb - n00 - n01 - n10
+                mult = factorial(lb) / (factorial(n00) * factorial(n01) * factorial(n10) * factorial(n11))
+                comps.append((mult, (a ** n00) * (b ** n01) * (c ** n10) * (d ** n11)))
+    cm = np.array([x[0] for x in comps])
+    cp = np.array([x[1] for x in comps])
+    out = np.zeros((T + 1, 3))
+    for kr in range(T + 1):
+        u = np.arange(T - kr + 1)
+        v = np.arange(kr + 1)
+        mu = np.array([comb(T - kr, int(x)) for x in u], np.float64)
+        mv = np.array([comb(kr, int(x)) for x in v], np.float64)
+        F = float(raw_edges) * np.outer((a ** (T - kr - u)) * (b ** u), (c ** (kr - v)) * (d ** v))          # (u, v): the block's factor
+        mult = np.outer(mu, mv)
+        blk_nnz = (cm[None, None, :] * (-np.expm1(-F[:, :, None] * cp[None, None, :]))).sum(axis=2)
+        tile = blk_nnz >= tile_min_nnz
+        out[kr, 0] = float((mult * blk_nnz * ~tile).sum())
+        out[kr, 1] = float((mult * tile).sum())
+        out[kr, 2] = float((mult * blk_nnz).sum())
+    return out
+
+
+def rmat_piece_table(scale, raw_edges, a=0.57, b=0.19, c=0.19, tile_block_cost=55.0, row_cost=1.0):
+    """Per canonical piece: (raw edges it receives, expected cost of its product).  Cost unit: one nonzero on the sparse-row path (one
+    gathered row of B); a well-filled 64 x 64 block kept as an MFMA tile costs `tile_block_cost` of them, a row of C `row_cost` (least
+    squares over the eight parts of configs[4] on one MI355X, fp16, N = 256: 0.102 ns per gathered nonzero, 5.6 ns per tile, rows ~ 0;
+    the model's own counts match the builder's: part 0 predicted 432.86 M sparse nonzeros + 1.4208 M tiles, built 432.82 M + 1.4212 M).  Pure arithmetic on the R-MAT marginals: every
+    rank computes the same table without seeing the graph."""
     s = int(scale)
     f = rmat_piece_bits(s)
-    distinct, _ = rmat_row_model(s, raw_edges, a, b, c)
     p1 = 1.0 - a - b
     pc = _popcount_np(np.arange(1 << f, dtype=np.uint64))
     share = (p1 ** pc) * ((1.0 - p1) ** (f - pc))
     raw = np.floor(float(raw_edges) * share + 0.5).astype(np.int64)
-    # expected distinct entries of a piece: sum over the popcounts of its low bits
     from math import comb
-    low = s - f
-    low_mult = np.array([comb(low, k) for k in range(low + 1)], np.float64)
-    per_pc = np.array([float((low_mult * distinct[t:t + low + 1]).sum()) for t in range(f + 1)])
-    cost = per_pc[pc] + float(1 << low)
+    low = s - f                                           # row bits inside a piece
+    lb = 6                                                # a 64-row block-row fixes all but the low 6 row bits
+    if low < lb:
+        raise ValueError("pieces must hold whole 64-row block-rows")
+    bm = rmat_block_model(s, raw_edges, a, b, c)
+    per_blockrow = bm[:, 0] + tile_block_cost * bm[:, 1] + row_cost * 64.0         # by popcount of the block-row's top bits
+    mid = low - lb                                        # row bits of a block-row's id that vary inside the piece
+    mid_mult = np.array([comb(mid, k) for k in range(mid + 1)], np.float64)
+    per_pc = np.array([float((mid_mult * per_blockrow[t:t + mid + 1]).sum()) for t in range(f + 1)])
+    cost = per_pc[pc]
     return raw, cost
+
+
+def _popcount_t(x):
+    """popcount of the low 32 bits of an int64 torch tensor (SWAR)"""
+    x = x - ((x >> 1) & 0x55555555)
+    x = (x & 0x33333333) + ((x >> 2) & 0x33333333)
+    x = (x + (x >> 4)) & 0x0F0F0F0F
+    return ((x * 0x01010101) >> 24) & 0xFF
+
+
+def _rmat_piece_cellwise(torch, dev, s, raw_edges, row0, rpp, seed_term, a, b, c, rows_per_chunk=None):
+    """A saturated piece, cell by cell: returns (counts per row, column ids int32) of rows [row0, row0 + rpp)."""
+    import math
+    n = 1 << s
+    d = 1.0 - a - b - c
+    la, lb, lc, ld = (math.log(x) for x in (a, b, c, d))
+    cols = torch.arange(n, dtype=torch.int64, device=dev)
+    pc_c = _popcount_t(cols).to(torch.float32)
+    rows_per_chunk = rows_per_chunk or max(1, (1 << 26) // n)
+    counts, out = [], []
+    for q0 in range(0, rpp, rows_per_chunk):
+        r = torch.arange(row0 + q0, row0 + min(rpp, q0 + rows_per_chunk), dtype=torch.int64, device=dev)
+        n11 = _popcount_t(r[:, None] & cols[None, :]).to(torch.float32)
+        pc_r = _popcount_t(r).to(torch.float32)[:, None]
+        n10 = pc_r - n11                                                   # row bit 1, column bit 0: quadrant c
+        n01 = pc_c[None, :] - n11                                          # row bit 0, column bit 1: quadrant b
+        n00 = float(s) - pc_r - pc_c[None, :] + n11
+        lam = torch.exp(n00 * la + n01 * lb + n10 * lc + n11 * ld + math.log(float(raw_edges)))
+        p = -torch.expm1(-lam)
+        del n11, n10, n01, n00, lam
+        hv = _mix64((r[:, None] * n + cols[None, :]) * _K_PIECE + seed_term)
+        u = (((hv >> 40) & 0xFFFFFF).to(torch.float32) + 0.5) * (1.0 / 16777216.0)
+        present = u < p
+        del hv, u, p
+        counts.append(present.sum(dim=1))
+        out.append(present.nonzero()[:, 1].to(torch.int32))               # row-major order: rows ascending, columns ascending inside a row
+        del present
+    return torch.cat(counts), torch.cat(out)
+
+
+def rmat_piece_is_cellwise(scale, raw_of_piece):
+    """the canonical rule: a piece whose raw edges reach half its cells is sampled cell by cell"""
+    s = int(scale)
+    rpp = 1 << (s - rmat_piece_bits(s))
+    return np.asarray(raw_of_piece, np.float64) * 2.0 >= float(rpp) * float(1 << s)
 
 
 def rmat_cuts(scale, raw_edges, parts, a=0.57, b=0.19, c=0.19):
@@ -389,12 +482,20 @@ def rmat_rows(scale, raw_edges, row0, row1, seed=3, a=0.57, b=0.19, c=0.19, valu
     seed_term = _s64(int(seed) * (_K_SEED & _M64))
     counts_parts, col_parts = [], []
     drawn = 0
+    cellwise = rmat_piece_is_cellwise(s, raw)
+    n_cellwise = int(cellwise.sum())
     # groups of whole pieces (duplicates never cross a piece: pieces are disjoint in rows), each at most `group` raw edges if possible
     g0 = 0
     npieces = p1 - p0
     while g0 < npieces:
+        if cellwise[g0]:
+            cnt_, col_ = _rmat_piece_cellwise(torch, dev, s, raw_edges, (p0 + g0) * rpp, rpp, seed_term, a, b, c)
+            counts_parts.append(cnt_)
+            col_parts.append(col_)
+            g0 += 1
+            continue
         g1, tot = g0, 0
-        while g1 < npieces and (g1 == g0 or tot + int(raw[g1]) <= group):
+        while g1 < npieces and not cellwise[g1] and (g1 == g0 or tot + int(raw[g1]) <= group):
             tot += int(raw[g1])
             g1 += 1
         cum = torch.from_numpy(np.concatenate([[0], np.cumsum(raw[g0:g1])]).astype(np.int64)).to(dev)
@@ -463,7 +564,7 @@ def rmat_rows(scale, raw_edges, row0, row1, seed=3, a=0.57, b=0.19, c=0.19, valu
     if dev.type == "cuda":
         torch.cuda.empty_cache()
     if return_stats:
-        return m, {"raw_edges_drawn": int(drawn), "nnz": nnz, "rows": [int(row0), int(row1)], "pieces": [int(p0), int(p1)]}
+        return m, {"raw_edges_drawn": int(drawn), "nnz": nnz, "rows": [int(row0), int(row1)], "pieces": [int(p0), int(p1)], "cellwise_pieces": n_cellwise}
     return m
 
 

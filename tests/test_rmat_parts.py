@@ -56,12 +56,26 @@ def test_any_row_range_is_generated_without_the_rest_of_the_graph():
 
 
 def test_cuts_by_expected_cost_balance_the_real_costs():
+    """the cost model behind the cuts (nonzeros of sparsely filled 64 x 64 blocks + 55 per well-filled block kept as an MFMA tile + rows)
+    evaluated on the REAL graph: the parts cut from the marginals alone carry equal shares of it"""
     sa, E = _graph()
     full = sa.gen.rmat_rows(SCALE, E, 0, 1 << SCALE, device="cpu")
+    rows_of = np.repeat(np.arange(full.rows), np.diff(full.rowptr))
+    blk = (rows_of // 64) * ((1 << SCALE) // 64) + full.colidx // 64
+    ids, cnt = np.unique(blk, return_counts=True)
+    br = ids // ((1 << SCALE) // 64)
+    cost_br = np.bincount(br, weights=np.where(cnt >= 120, 55.0, cnt.astype(np.float64)), minlength=full.rows // 64) + 64.0
+    model = sa.gen.rmat_block_model(SCALE, E)
+    # the model's totals against the graph's: nonzeros outside well-filled blocks, number of well-filled blocks
+    from math import comb
+    T = SCALE - 6
+    pred_sparse = sum(comb(T, k) * model[k, 0] for k in range(T + 1))
+    pred_tiles = sum(comb(T, k) * model[k, 1] for k in range(T + 1))
+    assert abs(pred_sparse - cnt[cnt < 120].sum()) / pred_sparse < 0.05 and abs(pred_tiles - (cnt >= 120).sum()) / max(pred_tiles, 1.0) < 0.15
     for parts in (2, 4, 8):
         cuts = sa.gen.rmat_cuts(SCALE, E, parts)
         assert cuts[0][0] == 0 and cuts[-1][1] == 1 << SCALE and all(cuts[i][1] == cuts[i + 1][0] for i in range(parts - 1))
-        real = np.array([full.rowptr[r1] - full.rowptr[r0] + (r1 - r0) for r0, r1 in cuts], np.float64)
+        real = np.array([cost_br[r0 // 64:r1 // 64].sum() for r0, r1 in cuts], np.float64)
         assert real.max() / real.mean() < 1.3, (parts, real)           # granularity of a piece at this small scale; ~1.03 at 2^23
         # the hub: the first part has far fewer rows than the last
         assert (cuts[0][1] - cuts[0][0]) * 2 < (cuts[-1][1] - cuts[-1][0])
@@ -139,7 +153,7 @@ def test_bench_gpus_n_starts_its_own_ranks_before_touching_the_gpu():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--rmat-scale", "12"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode != 0
-    assert p.stderr.count("bench.py needs a GPU") >= 2, p.stderr[-2000:]
+    assert p.stderr.count("bench.py needs a GPU") >= 1 and "ChildFailedError" in p.stderr, p.stderr[-2000:]     # (torchrun may stop the second rank before it prints)
     src = open(os.path.join(ROOT, "bench.py")).read()
     main = src[src.index("def main():"):]
     assert main.index("torch.distributed.run\", \"--nnodes=1\"") < main.index("    import torch\n"), "the ranks must be started before this process imports torch"

@@ -693,6 +693,109 @@ def test_16bit_256_column_slabs_give_the_bits_of_the_128_column_ones(monkeypatch
     _check(outs["1"][2].cpu().numpy(), Co + 0.5, bound + 0.5, "256-column slabs, accumulate")
 
 
+@pytest.mark.parametrize("align", ["whole-tiles", "split"])
+@pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("rows,cols,nnz,n", [(640, 6400, 260000, 256), (200, 12800, 300000, 512), (1000, 2047, 150000, 256)])
+def test_16bit_four_accumulator_slabs_give_the_bits_of_the_128_column_launch(monkeypatch, _sparse_row_mode, align, dtype, rows, cols, nnz, n):
+    """64-row tiles of 64-wide blocks, N % 256 == 0 (the dense hub of a power-law matrix under the fixed 64 x 64 grid): four accumulators per wave over
+    256-column slabs (k_h16.hip, QUAD; A read once per 256 columns).  Same steps in the same order per output element: the bits of the 128-column launch
+    (SPARTA_H16_QUAD=0) -- on whole-tile plans and on split (stream-K) plans, whose partial images go through the same fix-up -- with a partial last block
+    column (cols % 64 != 0), both layouts of C, accumulate, and a gathered B; and the oracle's product on the rounded inputs."""
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_STREAM_ALIGN", "1" if align == "whole-tiles" else "0")
+    w = 64
+    m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + cols + n)
+    g = np.arange(rows) // 64
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=5)
+    tdt = torch.float16 if dtype == sa.F16 else torch.bfloat16
+    ldb = (v.cols + 7) // 8 * 8
+    Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    Bt.view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
+    d = v.to_device(0, dtype=dtype)
+    info = d.info()
+    assert info["tiles64"] > 0
+    if align == "split":
+        assert info["split_tiles"] > 0, "this shape was meant to give a split plan"
+    world = 2
+    shard_rows = v.cols // world if v.cols % (world * w) == 0 else 0
+    Bg = None
+    if shard_rows:
+        Bg = torch.zeros(world * shard_rows * n, dtype=tdt, device="cuda")
+        for s_ in range(world):
+            Bg[s_ * shard_rows * n:(s_ + 1) * shard_rows * n].view(n, shard_rows)[:] = Bt.view(n, ldb)[:, s_ * shard_rows:(s_ + 1) * shard_rows]
+    outs = {}
+    for quad in ("0", "1"):
+        monkeypatch.setenv("SPARTA_H16_QUAD", quad)
+        res = []
+        for cl, acc in ((sa.COL_MAJOR, False), (sa.ROW_MAJOR, False), (sa.COL_MAJOR, True)):
+            Ct = torch.full((v.rows * n,), 0.5, dtype=torch.float32, device="cuda")
+            d.spmm(Bt, Ct, n, ldb=ldb, c_layout=cl, accumulate=acc)
+            torch.cuda.synchronize()
+            res.append(Ct)
+        if Bg is not None:
+            Ct = torch.full((v.rows * n,), 0.5, dtype=torch.float32, device="cuda")
+            d.spmm_gathered(Bg, shard_rows, Ct, n)
+            torch.cuda.synchronize()
+            res.append(Ct)
+        outs[quad] = res
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
+    mab_r, B_r = _round16(v.mab, dtype), _round16(B, dtype)
+    Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n, None)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n)
+    _check(outs["1"][0].cpu().numpy(), Co, bound, "four accumulators, column-major C")
+    _check(np.ascontiguousarray(outs["1"][1].cpu().numpy().reshape(v.rows, n).T).reshape(-1), Co, bound, "four accumulators, row-major C")
+    _check(outs["1"][2].cpu().numpy(), Co + 0.5, bound + 0.5, "four accumulators, accumulate")
+    if Bg is not None:
+        _check(outs["1"][3].cpu().numpy(), Co, bound, "four accumulators, gathered B")
+
+
+@pytest.mark.parametrize("dtype", [sa.F32, sa.F16, sa.BF16], ids=["f32", "f16", "bf16"])
+def test_a_constant_b_prepared_once_gives_the_bits_of_the_plain_product(dtype):
+    """sparta_vbs_prepare_b / sparta_vbs_spmm_prepared: the row-major copy of B the sparse-row kernels read is made once instead of per product; everything
+    else is the same call -- the same bits, column-major B and the gathered layout; a B prepared for one handle is refused by another shape."""
+    torch = _torch()
+    n, w = 256, 64
+    m = sa.gen.rmat(13, 60000, seed=5, symmetrize=True, pattern_only=False)
+    g = sa.BlockingEngine(blocking_algo=7, tau=0.4, col_block_size=w, row_block_size=32).GetGrouping(m)
+    d = sa.DeviceVBS.from_csr(m, g, w, device=0, dtype=dtype)
+    if d.sparse_info()["nnz"] == 0:
+        pytest.skip("no sparse rows in this mode (SPARTA_SPARSE_K=0): nothing to prepare")
+    tdt = {sa.F32: torch.float32, sa.F16: torch.float16, sa.BF16: torch.bfloat16}[dtype]
+    B = (torch.rand(d.cols * n, generator=torch.Generator().manual_seed(3)) - 0.5).to(tdt).cuda()
+    C1 = torch.full((d.rows * n,), 2.0, dtype=torch.float32, device="cuda")
+    C2 = torch.full((d.rows * n,), 3.0, dtype=torch.float32, device="cuda")
+    d.spmm(B, C1, n)
+    Bp = d.prepare_b(B, n)
+    for _ in range(2):                                                      # prepared once, used twice
+        d.spmm_prepared(Bp, C2)
+    torch.cuda.synchronize()
+    assert torch.equal(C1, C2)
+    d.spmm(B, C1, n, accumulate=True)
+    d.spmm_prepared(Bp, C2, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(C1, C2)
+    # gathered layout (two shards)
+    shard_rows = d.cols // 2
+    Bg = torch.empty_like(B)
+    for s_ in range(2):
+        Bg[s_ * shard_rows * n:(s_ + 1) * shard_rows * n].view(n, shard_rows)[:] = B.view(n, d.cols)[:, s_ * shard_rows:(s_ + 1) * shard_rows]
+    Bpg = d.prepare_b(Bg, n, shard_rows=shard_rows)
+    C3 = torch.full((d.rows * n,), 4.0, dtype=torch.float32, device="cuda")
+    C4 = torch.full((d.rows * n,), 5.0, dtype=torch.float32, device="cuda")
+    d.spmm_gathered(Bg, shard_rows, C3, n)
+    d.spmm_prepared(Bpg, C4)
+    torch.cuda.synchronize()
+    assert torch.equal(C3, C4)
+    other = sa.DeviceVBS.from_csr(sa.gen.uniform_random(300, 512, 4000, seed=1), np.arange(300) // 32, w, device=0, dtype=dtype)
+    with pytest.raises(ValueError):
+        other.spmm_prepared(Bp, C2)
+    Bp.close(); Bpg.close()
+    with pytest.raises(ValueError):
+        d.spmm_prepared(Bp, C2)
+
+
 def test_16bit_handles_reject_what_they_cannot_do():
     torch = _torch()
     m = sa.gen.uniform_random(256, 256, 3000, seed=2)
@@ -710,8 +813,71 @@ def test_16bit_handles_reject_what_they_cannot_do():
     with pytest.raises(ValueError):
         d.spmm(B.float(), C, 128)                                     # fp32 B on a 16-bit handle
     B96 = torch.zeros(v.cols * 96, dtype=torch.float16, device="cuda")
+    d.spmm(B96, C, 96)                                                # n_cols % 128 != 0 is NOT one of them any more (round 3: tail slab)
+    Bodd = torch.zeros((v.cols + 1) * 128, dtype=torch.float16, device="cuda")
     with pytest.raises(sa.SpartaError):
-        d.spmm(B96, C, 96)                                            # n_cols % 128 != 0
+        d.spmm(Bodd, C, 128, ldb=v.cols + 1)                          # odd leading dimension
+
+
+H16_ANY_N = [
+    (1500, 1500, 60000, 64, ("tau", 0.5)),            # KP 64, both tile types, tail block column (cols % w != 0)
+    (900, 960, 30000, 32, ("keeper", 32)),            # KP 32, one-tile plan
+    (700, 2048, 9000, 64, ("csr", 0.5)),              # handle straight from the CSR: most block-rows on the sparse-row kernels
+]
+
+
+@pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("n", [1, 37, 200, 300])
+@pytest.mark.parametrize("rows,cols,nnz,w,blk", H16_ANY_N)
+def test_16bit_handles_take_any_number_of_columns(dtype, n, rows, cols, nnz, w, blk):
+    """the reference's -c (columns of B) is arbitrary (include/input.h:15-42): whole 128-column slabs + one zero-padded tail slab through the
+    same kernels, both layouts of C, accumulate, host pointers, and the gathered layout of a multi-GPU B"""
+    torch = _torch()
+    m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + cols + w + 1)
+    if blk[0] == "keeper":
+        g = sa.BlockingEngine(tau=0.5, col_block_size=w, row_block_size=blk[1], blocking_algo=5).GetGrouping(m)
+    else:
+        g = sa.BlockingEngine(tau=blk[1], col_block_size=w).GetGrouping(m)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    d = sa.DeviceVBS.from_csr(m, g, w, device=0, dtype=dtype) if blk[0] == "csr" else v.to_device(0, dtype=dtype)
+    B = sa.gen.dense_rhs(v.cols, n, seed=5)
+    mab_r, B_r = _round16(v.mab, dtype), _round16(B, dtype)
+    Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n, None)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n)
+    tdt = torch.float16 if dtype == sa.F16 else torch.bfloat16
+    ldb = (v.cols + 7) // 8 * 8
+    Bt = torch.zeros(ldb * n + 64, dtype=tdt, device="cuda")
+    Bt[ldb * n:] = float("nan")                                       # what follows B in memory must never be read into the product
+    Bt[:ldb * n].view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
+    for cl in (sa.COL_MAJOR, sa.ROW_MAJOR):
+        Ct = torch.full((v.rows * n + 32,), 7.0, dtype=torch.float32, device="cuda")
+        d.spmm(Bt, Ct, n, ldb=ldb, c_layout=cl)
+        torch.cuda.synchronize()
+        got = Ct[:v.rows * n].cpu().numpy()
+        assert float(Ct[v.rows * n:].min()) == 7.0 and float(Ct[v.rows * n:].max()) == 7.0, "wrote past the end of C"
+        if cl == sa.ROW_MAJOR:
+            got = np.ascontiguousarray(got.reshape(v.rows, n).T).reshape(-1)
+        _check(got, Co, bound, "16-bit n_cols %d c_layout %d" % (n, cl))
+    C0 = sa.gen.dense_rhs(v.rows, n, seed=11)
+    Ct = torch.from_numpy(C0).cuda()
+    d.spmm(Bt, Ct, n, ldb=ldb, accumulate=True)
+    torch.cuda.synchronize()
+    _check(Ct.cpu().numpy(), C0 + Co, bound + np.abs(C0), "16-bit n_cols %d accumulate" % n)
+    Ch = np.zeros(v.rows * n, np.float32)
+    d.spmm_host(B, n, Ch, accumulate=False)
+    _check(Ch, Co, bound, "16-bit n_cols %d host pointers" % n)
+    # gathered B: `world` column-major slabs of shard_rows x n (shard_rows a multiple of w; the matrix is padded with zero columns up to it)
+    world = 2
+    shard_rows = -(-v.cols // (world * w)) * w
+    if world * shard_rows == v.cols:
+        Bg = torch.zeros(world * shard_rows * n, dtype=tdt, device="cuda")
+        Bfull = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
+        for s_ in range(world):
+            Bg[s_ * shard_rows * n:(s_ + 1) * shard_rows * n].view(n, shard_rows)[:] = Bfull[:, s_ * shard_rows:(s_ + 1) * shard_rows]
+        Ct = torch.full((v.rows * n,), 7.0, dtype=torch.float32, device="cuda")
+        d.spmm_gathered(Bg, shard_rows, Ct, n)
+        torch.cuda.synchronize()
+        _check(Ct.cpu().numpy(), Co, bound, "16-bit n_cols %d gathered" % n)
 
 
 def test_huge_leading_dimensions_take_the_64bit_kernels():
