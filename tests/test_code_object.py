@@ -43,18 +43,22 @@ def _kernel_metadata(tmp_path):
 def test_stream_kernels_keep_their_state_in_registers(tmp_path):
     kernels = _kernel_metadata(tmp_path)
     stream = {n: m for n, m in kernels.items() if "stream_kernel" in n or "direct_kernel" in n}
-    assert len(stream) >= 6 + 2 + 32 + 16, sorted(stream)                 # fp32: 6 LDS-staged instantiations + the no-barrier kernel, 16-bit LDS-staged: 32, direct: 16
+    assert len(stream) >= 6 + 2 + 32 + 16 + 6, sorted(stream)                 # fp32: 6 LDS-staged instantiations + the no-barrier kernel, 16-bit LDS-staged: 32, direct: 16
     for name, m in stream.items():
         assert m["private_segment_fixed_size"] == 0, (name, m)
         assert m["vgpr_spill_count"] == 0, (name, m)
-        assert m["vgpr_count"] <= 256, (name, m)                          # two 256-thread workgroups per CU
+        quad = "h16_direct_kernelILi64ELb1E" in name and "ELi64ELb1EEEvN10sparta_dev" in name      # <64, two tiles, ..., WC = 64, SLAB>: four accumulators per wave
+        if quad:
+            assert m["vgpr_count"] <= 512, (name, m)                      # ONE workgroup per CU (the 16-bit plans' own choice): accumulators in the upper half of the file
+        else:
+            assert m["vgpr_count"] <= 256, (name, m)                      # two 256-thread workgroups per CU
         if "f32_direct_kernel" in name:                                   # 4 waves x 2 stages x 32 columns x (32 + 4) floats, private to each wave
             want = {4 * 2 * 32 * 36 * 4, 4 * 2 * 32 * 36 * 4 + 4 * 32 * 65 * 4}     # (+ the C ring of the CSTAGE instantiation: 4 waves x 32 columns x 65 floats)
         elif "h16_direct_kernel" in name:                                 # 4 waves x 2 stages x 32 columns x (KP + 8) 16-bit elements, private to each wave
             ring = 4 * 32 * 65 * 4                                        # the C ring of the CSTAGE instantiations (tiles of arbitrary height)
             want = {4 * 2 * 32 * (32 + 8) * 2, 4 * 2 * 32 * (32 + 8) * 2 + ring} if "ILi32E" in name else {4 * 2 * 32 * (64 + 8) * 2, 4 * 2 * 32 * (64 + 8) * 2 + ring}
             if "ELi64ELb0EEEvN10sparta_dev" in name or "ELi64ELb1EEEvN10sparta_dev" in name:                          # WC = 64: every wave holds the images of its two groups of 32 columns
-                want = {4 * 2 * 64 * (32 + 8) * 2}
+                want = {4 * 2 * 64 * (32 + 8) * 2} if "ILi32E" in name else {4 * 2 * 64 * (64 + 8) * 2}
         elif "h16_stream_kernel" in name:                                 # 2 stages x (128 + 64) rows x (KP + 8) 16-bit elements
             want = {2 * (128 + 64) * (32 + 8) * 2} if "ILi32E" in name else {2 * (128 + 64) * (64 + 8) * 2}
         else:                                                             # fp32: 2 stages x (B panel [+4 pad when column-major] + 32 x 64 A slice) floats
