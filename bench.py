@@ -155,6 +155,7 @@ def main():
                     help="gloo: DEBUG ONLY -- several ranks on ONE GPU (a one-GPU box), collectives staged through host memory; checks the "
                          "multi-rank logic end to end, its timings mean nothing")
     ap.add_argument("--dist-path", action="store_true", help="run the multi-GPU code path even with one rank")
+    ap.add_argument("--no-suite", action="store_true", help="N = 1, default workload: do not append the benchmark set (config.suite: synthetic families + the reference's real matrices)")
     ap.add_argument("--check-rows", type=int, default=64, help="rmat / ogbn-like: rows of C checked against a float64 evaluation before timing")
     args = ap.parse_args()
     # ---- --gpus N without a launcher: start the N ranks ourselves, as a CHILD process, before anything here touches the GPU ---------
@@ -336,6 +337,16 @@ def main():
         cost_row = rows_of.astype(np.float64) + 1.0                       # nonzeros (gather traffic) + the row of C
         cost_br = np.add.reduceat(cost_row, part[:-1]) if len(part) > 1 else np.zeros(0)
         ranges = sa.dist.partition_by_cost(cost_br, world)
+        # every rank regenerated the matrix and reran the reorder on its own: a silent disagreement would overlap or drop rows -- one MIN / MAX
+        # pair over a fingerprint (nonzeros, a hash of rowptr, of the grouping and of the ranges) before anything is built
+        import zlib
+        fp = np.array([float(m.nztot()), float(zlib.crc32(np.ascontiguousarray(m.rowptr).tobytes())), float(zlib.crc32(np.ascontiguousarray(grouping, np.int64).tobytes())),
+                       float(zlib.crc32(np.asarray(ranges, np.int64).tobytes()))], np.float64)
+        lo_, hi_ = torch.from_numpy(fp).to(dev), torch.from_numpy(fp.copy()).to(dev)
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo_, hi_):
+            raise SystemExit("rank %d: the ranks built different matrices / groupings / ranges (fingerprints differ): not a partition of one matrix" % rank)
         b0, b1 = ranges[rank]
         my_rows = perm_global[part[b0]:part[b1]]                          # original row ids, in reordered order
         shard_rows = sa.dist.padded_shard_rows(-(-m.cols // world), w)
@@ -747,6 +758,16 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    # ---- the benchmark SET (BASELINE.json: "... SuiteSparse set"): same run, same box, after the headline measurement ------------------------
+    if not distributed and args.workload == "cant" and not args.matrix and not args.no_suite and args.dtype == "f32":
+        try:
+            import bench_suite
+            d.close()
+            del B, C
+            torch.cuda.empty_cache()
+            out["config"]["suite"] = bench_suite.run(sa, torch, N=128, device=local_rank)
+        except Exception as e:
+            out["config"]["suite"] = {"error": repr(e)[:300]}
     if distributed and ex is None:
         out["config"]["allgather"] = dict(gather_pick or {}, mode=gather_mode)
     if gen_stats is not None:

@@ -1,0 +1,156 @@
+"""bench_suite.py -- the benchmark SET behind BASELINE.json's metric ("... SuiteSparse set"): the one-GPU path (reorder -> handle straight from the CSR
+-> product, fp32, N = 128, reference layouts) over synthetic matrix families AND the reference's own real-world inputs (data/minitest/*.el, committed as data
+under tests/golden/ref_data/minitest/: bcsstk18 is SuiteSparse HB/bcsstk18; SuiteSparse itself cannot be fetched here).  bench.py appends the result to its
+JSON line as `config.suite` (N = 1); scripts/suite_sweep.py writes the same records to profiles/.
+
+One definition per column:
+  ms             product time, HIP events around `reps` back-to-back products after a 50 ms pre-roll
+  useful_gflops  2 nnz N / ms
+  frac_8d        SURVEY.md section 8(d) bound / ms: what the device image holds, read ONCE -- dense tiles max(bytes / 8 TB/s, executed flops / 157.3 TF), the
+                 nonzeros kept as (column, value) pairs + their rows of C as bytes, B counted ONCE.  Never above 1.
+  gather_gbs     GB/s of the sparse-row kernels counting one N-wide row of B per nonzero (cache re-reads included: a bandwidth, NOT a fraction of a bound;
+                 null when no nonzero is on that path)
+"""
+import os
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(ROOT, "tests", "golden", "ref_data", "minitest")
+PEAK_HBM_GBS = 8000.0
+PEAK_MFMA_F32_TFLOPS = 157.3
+
+
+def _sorted_rows(sa, m):
+    """rows in ascending column order, duplicates dropped (two of the reference's files list a row's entries out of order; the product of a matrix
+    does not depend on that order, the handle built straight from the CSR wants it ascending)"""
+    r = np.repeat(np.arange(m.rows), np.diff(m.rowptr))
+    key, idx = np.unique(r.astype(np.int64) * m.cols + m.colidx, return_index=True)
+    rp = np.concatenate([[0], np.cumsum(np.bincount(key // m.cols, minlength=m.rows))])
+    return sa.CSR(m.rows, m.cols, rp, (key % m.cols).astype(np.int32), None if m.vals is None else m.vals[idx])
+
+
+def _clustered(sa, n_groups, rows_per, cols, shared, own, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rr, cc = [], []
+    order = rng.permutation(n_groups * rows_per)                 # rows of a group are scattered: the reorder has to find them
+    for gi in range(n_groups):
+        base = rng.choice(cols, shared, replace=False)
+        for k in range(rows_per):
+            c = np.union1d(base[rng.random(shared) < 0.8], rng.choice(cols, own, replace=False))
+            rr.append(np.full(len(c), order[gi * rows_per + k]))
+            cc.append(c)
+    r, c = np.concatenate(rr), np.concatenate(cc)
+    o = np.lexsort((c, r))
+    r, c = r[o], c[o]
+    n = n_groups * rows_per
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=n))])
+    return sa.CSR(n, cols, rowptr, c.astype(np.int32), rng.uniform(-1, 1, len(c)).astype(np.float32))
+
+
+def cases(sa, large=False):
+    """(name, kind, make(), blocking kwargs, w).  `large`: + the 20 M-nonzero R-MAT (scripts/suite_sweep.py; too slow for the driver's line)"""
+    keeper = dict(blocking_algo=5, tau=0.6, row_block_size=32, force_fixed_size=True)         # the reference's experiment flags: -a 5 -t 0.6 -B 32 -F 1
+    out = [
+        ("FEM 3D 9x9x257 x3 (cant-like)", "synthetic", lambda: sa.gen.cant_like(), keeper, 32),
+        ("FEM 3D 20x20x50 x3", "synthetic", lambda: sa.gen.fem3d(20, 20, 50, 3, 2), keeper, 32),
+        ("banded 200k, +-16, 50 %", "synthetic", lambda: sa.gen.banded(200000, 16, density=0.5, seed=4), dict(blocking_algo=7, tau=0.5, minhash_max_rows=32), 32),
+        ("clustered 2000 x 48 rows, 300 shared cols", "synthetic", lambda: _clustered(sa, 2000, 48, 60000, 300, 6, 5), dict(blocking_algo=7, tau=0.6), 32),
+        ("uniform 100k x 100k, 2 M nnz", "synthetic", lambda: sa.gen.uniform_random(100000, 100000, 2000000, seed=1), dict(blocking_algo=7, tau=0.6), 64),
+        ("R-MAT 2^18, 4.9 M nnz", "synthetic", lambda: sa.gen.rmat(18, 10 << 18, seed=3, symmetrize=True, pattern_only=False), dict(blocking_algo=7, tau=0.4), 64),
+    ]
+    if large:
+        out.append(("R-MAT 2^20, 20 M nnz", "synthetic", lambda: sa.gen.rmat(20, 10 << 20, seed=3, symmetrize=True, pattern_only=False), dict(blocking_algo=7, tau=0.4), 64))
+    real = [("bcsstk18_r.el", "SuiteSparse HB/bcsstk18 (structural stiffness)"), ("ca-HepPh_r.el", "SNAP ca-HepPh (collaboration)"), ("wiki-Vote_r.el", "SNAP wiki-Vote"),
+            ("social_location.el", "social / location graph"), ("ia-wikiquote-user-edits-nodup.el", "wikiquote user-edits (bipartite)")]
+    for f, what in real:
+        path = os.path.join(DATA, f)
+        if os.path.exists(path):
+            out.append(("%s: %s" % (f, what), "real (reference data/minitest, pattern-only like its -P 1)",
+                        (lambda p=path: _sorted_rows(sa, sa.CSR.read_from_edgelist(p, pattern_only=True))), dict(blocking_algo=7, tau=0.5), 32))
+    return out
+
+
+def run_one(sa, torch, name, kind, make, eng_kw, w, N=128, device=0, budget_ms=400.0):
+    m = make()
+    t0 = time.time()
+    eng = sa.BlockingEngine(col_block_size=w, **eng_kw)
+    g = eng.GetGrouping(m)
+    t_r = time.time() - t0
+    rbs, ff = eng_kw.get("row_block_size", 0), eng_kw.get("force_fixed_size", False)
+    t0 = time.time()
+    d = sa.DeviceVBS.from_csr(m, g, w, rbs, ff, device=device)
+    t_b = time.time() - t0
+    dev = torch.device("cuda", device)
+    B = torch.rand(d.cols * N, device=dev) - 0.5
+    C = torch.zeros(d.rows * N, device=dev)
+    d.spmm(B, C, N)                                              # plan time (path autotune, scratch)
+    torch.cuda.synchronize()
+    t_pre = time.perf_counter()                                  # short untimed pre-roll
+    n_pre = 0
+    while (time.perf_counter() - t_pre) * 1e3 < 50.0:
+        for _ in range(10):
+            d.spmm(B, C, N)
+        n_pre += 10
+        torch.cuda.synchronize()
+    per = (time.perf_counter() - t_pre) * 1e3 / max(n_pre, 1)
+    reps = int(max(10, min(400, budget_ms / max(per, 1e-3))))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        d.spmm(B, C, N)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    d.set_class_timing(True)
+    d.spmm(B, C, N)
+    ct = d.class_times()
+    d.set_class_timing(False)
+    info, sp = d.info(), d.sparse_info()
+    # section-8(d) bound of what the device holds
+    dense_area = float(info["nztot"])
+    dense_rows = info["rows"] - sp["rows"]
+    bytes_dense = dense_area * 4.0 + info["nblocks"] * 4.0 + dense_rows * N * 4.0
+    flops_dense = 2.0 * dense_area * N
+    bytes_sparse = float(sp["nnz"]) * 8.0 + float(sp["rows"]) * (N * 4.0 + 8.0)
+    bytes_b = float(info["cols"]) * N * 4.0
+    t_lb = max(bytes_dense / (PEAK_HBM_GBS * 1e9), flops_dense / (PEAK_MFMA_F32_TFLOPS * 1e12)) + (bytes_sparse + bytes_b) / (PEAK_HBM_GBS * 1e9)
+    gather = None
+    if sp["nnz"] > 0 and ct.get("sparse", 0.0) > 0:
+        gather = (float(sp["nnz"]) * (N * 4.0 + 8.0) + float(sp["rows"]) * N * 4.0) / (ct["sparse"] * 1e-3) / 1e9
+    rec = {"name": name, "kind": kind, "rows": int(m.rows), "cols": int(m.cols), "nnz": int(m.nztot()),
+           "blocking": "%s tau %.1f w %d" % ({5: "Keeper -B 32 -F 1", 7: "LSH (blocking_algo 7)", 3: "clocked"}[eng_kw["blocking_algo"]], eng_kw["tau"], w),
+           "ms": round(ms, 5), "useful_gflops": round(2.0 * m.nztot() * N / ms / 1e6, 1), "frac_8d": round(min(t_lb / (ms * 1e-3), 1.0), 4),
+           "gather_gbs": None if gather is None else round(gather, 1),
+           "carried_by": ("sparse rows %.0f %%" % (100.0 * sp["nnz"] / max(m.nztot(), 1))) if sp["nnz"] * 2 > m.nztot() else
+                         ("MFMA tiles %.0f %%" % (100.0 * (1 - sp["nnz"] / max(m.nztot(), 1)))),
+           "mfma_tile_area": int(info["nztot"]), "sparse_nnz": int(sp["nnz"]), "kernels_ms": {k: round(float(v), 5) for k, v in ct.items()},
+           "host_seconds": {"reorder": round(t_r, 3), "vbs_build": round(t_b, 3)}, "reps": reps}
+    d.close()
+    del B, C
+    return rec
+
+
+def run(sa, torch, N=128, device=0, large=False, time_budget_s=45.0, log=None):
+    t_start = time.time()
+    recs, skipped = [], []
+    for name, kind, make, eng_kw, w in cases(sa, large):
+        if time.time() - t_start > time_budget_s:
+            skipped.append(name)
+            continue
+        try:
+            rec = run_one(sa, torch, name, kind, make, eng_kw, w, N=N, device=device)
+        except Exception as e:                                   # one matrix must not cost the line
+            rec = {"name": name, "kind": kind, "error": repr(e)[:200]}
+        recs.append(rec)
+        if log:
+            log(rec)
+    fr = sorted(r["frac_8d"] for r in recs if "frac_8d" in r)
+    out = {"n_cols": N, "dtype": "f32", "matrices": recs, "min_frac_8d": fr[0] if fr else None, "median_frac_8d": fr[len(fr) // 2] if fr else None,
+           "seconds": round(time.time() - t_start, 1),
+           "columns": "ms = events around back-to-back products; frac_8d = section-8(d) bound of the device image (tiles max(bytes, flops), sparse rows as bytes, B once) / ms; "
+                      "gather_gbs = sparse-row kernels' GB/s counting one row of B per nonzero (a bandwidth, not a fraction)"}
+    if skipped:
+        out["skipped_for_time"] = skipped
+    return out

@@ -5,13 +5,14 @@ set -u
 tag=$1
 shift
 extra="$*"
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 out=gpurun_out/prof_$tag
 mkdir -p $out
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $extra --no-cpu-baseline > $out/bench_trace.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_fetch -- python3 bench.py $extra --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT TCC_MISS --output-format csv -d $out/pmc_write -- python3 bench.py $extra --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_pmc_write.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $out/pmc_sq -- python3 bench.py $extra --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_pmc_sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $extra --no-cpu-baseline --no-suite > $out/bench_trace.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_fetch -- python3 bench.py $extra --steps 20 --warmup 5 --no-cpu-baseline --no-suite > $out/bench_pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT TCC_MISS --output-format csv -d $out/pmc_write -- python3 bench.py $extra --steps 20 --warmup 5 --no-cpu-baseline --no-suite > $out/bench_pmc_write.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $out/pmc_sq -- python3 bench.py $extra --steps 20 --warmup 5 --no-cpu-baseline --no-suite > $out/bench_pmc_sq.log 2>&1
 python3 - "$out" <<'PY'
 import sys, glob, csv, collections, json, re
 out = sys.argv[1]

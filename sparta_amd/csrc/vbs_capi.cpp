@@ -106,8 +106,10 @@ int sparta_device_count(void) {
     return n;
 }
 
-// `ext` (sparta_vbs_create_from_csr): the sparse-row part of the matrix decided and collected by the hybrid host builder --
-// those block-rows have nzcount = 0 in the arrays given here and must get neither tiles nor zero-fill records.
+// `ext` (sparta_vbs_create_from_csr): the sparse-row part of the matrix decided and collected by the hybrid host builder.  Fully sparse
+// block-rows (ext->flag 1) have nzcount = 0 in the arrays given here and get neither tiles nor zero-fill records; MIXED block-rows (flag 2)
+// keep their well-filled blocks in nzcount / jab / mab as tiles like any other, and the nonzeros of their other blocks are sparse rows that
+// add to C behind the tile launches (see the ordering note at the sparse-row launch in spmm_impl).
 static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t block_rows, int64_t w, const int64_t* row_part,
                        const int64_t* nzcount, const int64_t* jab, const float* mab, int64_t br0, int64_t br1, int32_t dtype,
                        int32_t device, const sparta::HybridSparse* ext) {
@@ -455,9 +457,15 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             CREATE_TRY(hipMemcpy(v->d_wrange[ty], wrange[ty].data(), wrange[ty].size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
         if (!plan.a_frag.empty()) {
-            CREATE_TRY(hipMalloc((void**)&v->d_a_frag, plan.a_frag.size() * sizeof(float)));
-            CREATE_TRY(hipMemcpy(v->d_a_frag, plan.a_frag.data(), plan.a_frag.size() * sizeof(float), hipMemcpyHostToDevice));
-            v->a_bytes += (int64_t)(plan.a_frag.size() * sizeof(float));    // the device image holds the one-tile part of A twice (two layouts)
+            // a SECOND copy of the one-tile part of A (4 KB per step whatever the tile height): if the device cannot hold it the handle is still
+            // good -- d_a_frag stays null and the launch code runs the LDS-staged kernel on the legacy image (launch_f32_stream)
+            if (hipMalloc((void**)&v->d_a_frag, plan.a_frag.size() * sizeof(float)) == hipSuccess) {
+                CREATE_TRY(hipMemcpy(v->d_a_frag, plan.a_frag.data(), plan.a_frag.size() * sizeof(float), hipMemcpyHostToDevice));
+                v->a_bytes += (int64_t)(plan.a_frag.size() * sizeof(float));    // the device image holds the one-tile part of A twice (two layouts)
+            } else {
+                (void)hipGetLastError();
+                v->d_a_frag = nullptr;
+            }
         }
         if (!fix.empty()) {
             CREATE_TRY(hipMalloc((void**)&v->d_fix, fix.size() * sizeof(FixRec)));
@@ -1158,7 +1166,9 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
         else if (int rc = run_class(dC, path == 3, prof)) return rc;
         A->last_path = path;
 
-        // ---- the block-rows kept as sparse rows (disjoint rows of C: order against the MFMA launches does not matter) ----
+        // ---- the sparse rows.  Fully sparse block-rows (flag 1) own their rows of C; rows of MIXED block-rows (flag 2, bit 31 of crow) ADD to what
+        // the tile and fix-up launches stored: this launch must stay BEHIND those launches on the same stream (moving the sparse leg to a side
+        // stream for overlap needs an event wait for the mixed rows) ----
         if (A->n_sp_rows > 0) {
             if (prof) HIP_TRY(hipEventRecord(A->cev[3][0], st));
             if (int rc = launch_sparse_rows(A, dB, ldb, b_layout == SPARTA_ROW_MAJOR, shard_rows, shard_stride, 0, n_cols, dC, ldc,

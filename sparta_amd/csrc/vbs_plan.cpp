@@ -343,7 +343,11 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             {
                 const char* de = std::getenv("SPARTA_F32_PLAN");
                 const bool off = de && std::strcmp(de, "legacy") == 0;         // SPARTA_F32_PLAN=legacy: the LDS-staged kernel for every call
-                if (!off && ty == 0 && !h16 && S <= ((int64_t)2 << 20)) {   // <= 8 GiB of slices (a second copy of the one-tile part of A)
+                // (<= 8 GiB of slices, and not more than 4 x the stored elements of the matrix: a plan of many SHORT tiles -- 4 rows pay the 4 KB of 32 --
+                // keeps the LDS-staged kernel on the legacy image instead of quadrupling the handle)
+                int64_t one_tile_area = 0;
+                for (int64_t q = 0; q < S; q++) one_tile_area += (int64_t)(st[(size_t)q].mt_flags & 0xffff) * SK_KP;
+                if (!off && ty == 0 && !h16 && S <= ((int64_t)2 << 20) && S * 1024 <= 4 * std::max<int64_t>(one_tile_area, 1) + (1 << 20)) {
                     std::vector<float>& af = P.a_frag;
                     af.assign(((size_t)S + 4) * 1024, 0.0f);                    // + 4: the pipeline requests three steps past a range end
                     sparta::parallel_for_dynamic(S, 256, [&](int64_t lo, int64_t hi, int) {

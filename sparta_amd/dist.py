@@ -96,6 +96,10 @@ def allgather_B_peer_copies(B_shard, B_gathered, rank, world_size, group=None):
     which one wins depends on slab size and RCCL's choice of algorithm -- `pick_allgather` measures both."""
     import torch.distributed as dist
     n = B_shard.numel()
+    # validated on every rank BEFORE any op is posted: a rank that raised inside a half-posted batch would leave its peers hanging
+    if B_gathered.dim() != 1 or B_shard.dim() != 1 or not B_gathered.is_contiguous() or not B_shard.is_contiguous() or B_gathered.numel() != world_size * n:
+        raise ValueError("allgather_B_peer_copies: B_shard and B_gathered must be flat contiguous buffers with B_gathered.numel() == world_size * B_shard.numel() "
+                         "(a padded shard stride is not supported here: use the collective)")
     B_gathered[rank * n:(rank + 1) * n].copy_(B_shard)
     ops = []
     for k in range(1, world_size):                            # rank r sends to r + k while it receives from r - k: no two posts of a pair cross
@@ -110,7 +114,8 @@ def allgather_B_peer_copies(B_shard, B_gathered, rank, world_size, group=None):
 def pick_allgather(B_shard, B_gathered, rank, world_size, reps=3, sync=None, group=None):
     """Plan-time choice between the collective all-gather and the peer copies: both are run (first for equality of the result, then
     `reps` timed repetitions each, wall clock between two `sync()` calls, maximum over the ranks); every rank returns the same
-    {'mode': 'all_gather' | 'peer_copies', 'all_gather_ms', 'peer_copies_ms', 'equal'}.  Collective: call it on every rank."""
+    {'mode': 'all_gather' | 'peer_copies', 'all_gather_ms', 'peer_copies_ms', 'equal'}.  Collective: call it on every rank.  B_gathered is
+    overwritten (zeroed in between, and left filled by whichever variant ran last -- both leave the same gathered B)."""
     import time
     import torch
     import torch.distributed as dist

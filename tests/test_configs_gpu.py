@@ -282,3 +282,80 @@ def test_rmat_row_slab_is_sampled_without_the_rest_of_the_graph():
         assert abs(top - top_whole) < 0.01 and abs(top - want) < 0.06, (k, top, top_whole, want)
     for k, (got, ref_cnt) in enumerate(share):                # same expected edge count as the same rows of the whole graph (duplicates removed in both)
         assert abs(got - ref_cnt) < 0.05 * ref_cnt + 500, (k, got, ref_cnt)
+
+
+# ---- round 3: the stated densities / sizes through the canonical piece-wise graph (bench.py --workload rmat-part) ----------------------
+def _gathered_view(torch, B_gath, P, shard_rows, n):
+    """the gathered layout (P column-major slabs of shard_rows x n) as one n x cols view for the checks: (n, P, shard_rows) -> (n, P * shard_rows)"""
+    return B_gath.view(P, n, shard_rows).permute(1, 0, 2).reshape(n, P * shard_rows)
+
+
+def _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed):
+    C = torch.full((d.rows * n,), 2.5, dtype=torch.float32, device="cuda")
+    d.spmm_gathered(B_gath, shard_rows, C, n)
+    C2 = torch.full((d.rows * n,), -7.0, dtype=torch.float32, device="cuda")
+    d.spmm_gathered(B_gath, shard_rows, C2, n)
+    torch.cuda.synchronize()
+    assert torch.equal(C, C2), "a second product into a dirty buffer must give the same bits"
+    del C2
+    Bflat = _gathered_view(torch, B_gath, P, shard_rows, n).contiguous().view(-1)      # column-major, ld = cols: what the check helpers read
+    ldb = P * shard_rows
+    assert _sampled_rows_check(torch, m, g, C, n, Bflat, ldb, tdt, n_rows=64, seed=seed) <= 1e-5
+    assert _column_checksum_check(torch, m, C, n, Bflat, ldb, tdt) <= 1e-5
+    del Bflat, C
+
+
+def test_config3_rmat20_at_the_stated_density_0p1_percent_slab_streamed():
+    """configs[3] at its stated 0.1 %: R-MAT 2^20 x 2^20, 1.1e9 distinct nonzeros, B = 512 columns, bf16 -- the reorder-OFF arm of the reference's
+    experiment (-a 2 -F 1: fixed 64 x 64 grid, src/scripts/run_multiplication_experiments_fixed_cluster.sh:14-16), streamed through the GPU in the 8
+    parts of equal expected cost that bench.py --workload rmat-part --rmat-scale 20 --rmat-density 1e-3 --slabs 8 runs: every part is generated alone
+    (canonical graph), built (sparta_vbs_create_from_csr), multiplied against B in the gathered layout and checked -- sampled + heaviest rows against
+    float64, the column checksum over every row, bit-reproducibility; the parts tile the graph and hold the stated number of nonzeros."""
+    torch = _torch()
+    scale, dens, P, n, w, tdt = 20, 1e-3, 8, 512, 64, torch.bfloat16
+    n_side = 1 << scale
+    E = sa.gen.rmat_raw_edges_for_density(scale, dens)
+    cuts = sa.gen.rmat_cuts(scale, E, P)
+    assert cuts[0][0] == 0 and cuts[-1][1] == n_side and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    shard_rows = n_side // P
+    B_gath = torch.cat([sa.gen.dense_rhs_rows(s * shard_rows, (s + 1) * shard_rows, n, seed=7, dtype=tdt, device=0) for s in range(P)])
+    total, costs = 0, []
+    for ip, (r0, r1) in enumerate(cuts):
+        m = sa.gen.rmat_rows(scale, E, r0, r1, seed=3, device=0)
+        total += m.nztot()
+        g = np.arange(m.rows, dtype=np.int64) // 64
+        st = sa.DeviceVBS.plan_stats(m, g, w, 64, False, dtype=sa.BF16)
+        d = sa.DeviceVBS.from_csr(m, g, w, 64, False, device=0, dtype=sa.BF16)
+        info, sp = d.info(), d.sparse_info()
+        assert st["tile_blocks"] == info["nblocks"] and st["tile_area"] == info["nztot"]      # the dry run predicts exactly what is built
+        assert abs(st["sparse_nnz"] - sp["nnz"]) <= 0.001 * max(sp["nnz"], 1)                 # (values that round to zero in bf16 leave the device copy)
+        costs.append(sp["nnz"] + 55.0 * info["nblocks"] + m.rows)
+        _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed=30 + ip)
+        d.close()
+        del m
+        torch.cuda.empty_cache()
+    assert abs(total - dens * n_side * n_side) / (dens * n_side * n_side) < 0.01, total
+    costs = np.array(costs)
+    assert costs.max() / costs.mean() < 1.08, costs                 # the cuts came from the marginals alone; the built parts carry equal cost
+
+
+def test_config4_one_full_size_slab_of_the_8m_row_graph():
+    """configs[4] at full size, one rank's share: part 0 of the 8 parts of the 8.4 M x 8.4 M R-MAT at 0.01 % (~1.1e9 of its 7.0e9 nonzeros: the hub),
+    generated without the rest of the graph, B = 256 columns fp16 in the layout the all-gather of 8 ranks leaves (slabs of 2^20 rows) -- what rank 0 of
+    `bench.py --gpus 8` and slab 0 of `bench.py --gpus 1 --slabs 8` run -- through the property checks."""
+    torch = _torch()
+    scale, dens, P, n, w, tdt = 23, 1e-4, 8, 256, 64, torch.float16
+    n_side = 1 << scale
+    E = sa.gen.rmat_raw_edges_for_density(scale, dens)
+    cuts = sa.gen.rmat_cuts(scale, E, P)
+    r0, r1 = cuts[0]
+    m = sa.gen.rmat_rows(scale, E, r0, r1, seed=3, device=0)
+    assert m.cols == n_side and 0.10 < m.nztot() / (dens * n_side * n_side) < 0.20          # the hub part: few rows, a large share of the nonzeros
+    assert (r1 - r0) * 8 < n_side // 4
+    shard_rows = n_side // P
+    B_gath = torch.cat([sa.gen.dense_rhs_rows(s * shard_rows, (s + 1) * shard_rows, n, seed=7, dtype=tdt, device=0) for s in range(P)])
+    g = np.arange(m.rows, dtype=np.int64) // 64
+    d = sa.DeviceVBS.from_csr(m, g, w, 64, False, device=0, dtype=sa.F16)
+    assert d.info()["tiles64"] > 0 and d.sparse_info()["nnz"] > 0          # hub blocks on MFMA tiles, the tail on the sparse-row kernels
+    _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed=41)
+    d.close()
