@@ -72,10 +72,11 @@ def _stage_collectives_through_host(dist, sa):
 
     real_ag, real_ar, real_bar = dist.all_gather_into_tensor, dist.all_reduce, dist.barrier
 
-    def all_gather_into_tensor(out, inp, group=None):
+    def all_gather_into_tensor(out, inp, group=None, async_op=False):
         o = torch.empty(out.shape, dtype=out.dtype)
         real_ag(o, inp.cpu(), group=group)
         out.copy_(o)
+        return _Done() if async_op else None
 
     def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
         c = t.cpu()
@@ -131,6 +132,9 @@ def main():
     ap.add_argument("--slabs", type=int, default=8,
                     help="rmat-part on ONE GPU: the P parts of the P-rank job one after the other (the N = 1 comparator of --gpus P; a power of two)")
     ap.add_argument("--slab-sample", type=int, default=0, help="rmat-part on one GPU: run only this many of the --slabs parts (part 0 + a seeded choice), total extrapolated by cost")
+    ap.add_argument("--ag-chunks", type=int, default=1,
+                    help="rmat-part, N > 1: all-gather + product in this many column chunks, the collective of the next chunk overlapped with the kernels of this one "
+                         "(1 = north_star's single all-gather per step; the chunked step is checked bit for bit against it)")
     ap.add_argument("--reorder", choices=["off", "on", "auto"], default="off",
                     help="rmat-part: per-part blocking -- off = fixed 64-row grid (-a 2 -F 1), on = blocking_algo 7, auto = clustering kept only where its predicted "
                          "product time beats the fixed grid's")
@@ -655,18 +659,21 @@ def main():
              "class32": "vbs_spmm_f32_kernel<32,1,4,1,1,...>", "class64": "vbs_spmm_f32_kernel<32,2,2,1,2,...>"}.get(dom, dom)
     # HBM bytes per launch of that kernel from rocprofv3 PMC passes (profiles/traffic*.json, produced by scripts/profile_bench.sh on
     # the same command; FETCH_SIZE doubled per MI355X_MICROARCH.md) -- only reported when the profiled workload is the one running now
-    traffic = None
+    # (`traffic` is a committed counter measurement, not one made in this run: `traffic_source` says which file and revision it is from)
+    traffic, traffic_source = None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json" if args.dtype == "f32" else "traffic_%s.json" % args.dtype)))
+        tname = "traffic.json" if args.dtype == "f32" else "traffic_%s.json" % args.dtype
+        tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
         wk = tj.get("workload", {})
         if (vb is not None and wk.get("vbs_area") == int(vb.nztot) and wk.get("n_cols") == N and wk.get("kernel_path") == path and not distributed
                 and wk.get("dtype", "f32") == args.dtype and wk.get("kernel_rev", "") == sa.KERNEL_REV):
             traffic = round(float(tj["hbm_bytes_per_launch"]))
+            traffic_source = "profiles/%s@%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scripts/profile_bench.sh)" % (tname, wk.get("kernel_rev", ""))
     except Exception:
-        traffic = None
+        traffic, traffic_source = None, None
     roofline = {
         "bound": "mfma", "achieved": round(dom_tflops, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(dom_tflops / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
+        "frac": round(dom_tflops / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
         "kernel": kname, "kernel_ms": round(kernel_ms.get(dom, 0.0), 5), "path": path,
         "kernels_ms": {k: round(v, 5) for k, v in kernel_ms.items()},
         "all_kernels_tflops_exec": round(flops_exec / (kernel_ms_total * 1e-3) / 1e12, 3) if kernel_ms_total > 0 else 0.0,
@@ -681,6 +688,7 @@ def main():
             wk = tj.get("workload", {})
             if wk.get("nnz") == int(nnz_global) and wk.get("n_cols") == N and wk.get("dtype") == args.dtype and wk.get("kernel_rev", "") == sa.KERNEL_REV:
                 traffic = round(float(tj["hbm_bytes_per_step"]))
+                traffic_source = "profiles/traffic_rmat.json@%s" % wk.get("kernel_rev", "")
         except Exception:
             pass
         # The matrix is carried by the sparse-row kernels: HBM-bound.  `frac` is the section-8(d) figure -- B counted ONCE (the whole
@@ -690,7 +698,7 @@ def main():
         gbs_gather = bytes_gather / (kernel_ms["sparse"] * 1e-3) / 1e9
         gbs_once = bytes_alg / (kernel_ms_total * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(gbs_once, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs_once / PEAK_HBM_GBS, 4),
-                    "traffic": traffic,
+                    "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": "sparse_rows_kernel + sparse_segments_kernel (+ b_to_row_major / sparse_c_scatter transposes)",
                     "kernel_ms": round(kernel_ms["sparse"], 5), "path": path, "kernels_ms": {k: round(v_, 5) for k, v_ in kernel_ms.items()},
                     "algorithmic_bytes": round(bytes_alg), "frac_b_once": round(gbs_once / PEAK_HBM_GBS, 4),

@@ -139,7 +139,21 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
         rows_c = info["rows"]
         C = torch.zeros(rows_c * N, dtype=torch.float32, device=dev)
 
+        # --ag-chunks K > 1: the all-gather and the product in K column chunks, the collective of chunk c + 1 running (RCCL's own stream) while the
+        # kernels of chunk c run -- a column chunk of a column-major shard, and of C, is contiguous; every chunk has its own gathered buffer
+        K_ag = max(1, int(getattr(args, "ag_chunks", 1))) if (distributed and world > 1) else 1
+        if K_ag > 1 and (N % (128 * K_ag) != 0 or gather_mode == "peer_copies"):
+            K_ag = 1
+        Nc = N // K_ag
+        B_gath_c = [torch.empty(P * shard_rows * Nc, dtype=tdt, device=dev) for _ in range(K_ag)] if K_ag > 1 else None
+
         def step():
+            if K_ag > 1:
+                works = [dist.all_gather_into_tensor(B_gath_c[c_], B_shard[c_ * Nc * shard_rows:(c_ + 1) * Nc * shard_rows], async_op=True) for c_ in range(K_ag)]
+                for c_ in range(K_ag):
+                    works[c_].wait()                                  # the compute stream waits for chunk c_ only
+                    d.spmm_gathered(B_gath_c[c_], shard_rows, C[c_ * Nc * rows_c:(c_ + 1) * Nc * rows_c], Nc, accumulate=False)
+                return
             if distributed and world > 1:
                 if gather_mode == "peer_copies":
                     sa.dist.allgather_B_peer_copies(B_shard, B_gath, rank, world)
@@ -149,6 +163,15 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
 
         step()                                   # plan time (autotune of the MFMA path, scratch sizing): not a timed step
         fence()
+        if K_ag > 1:                             # the chunked step must give the bits of the one-collective step
+            C_one = torch.empty_like(C)
+            d.spmm_gathered(B_gath, shard_rows, C_one, N, accumulate=False)
+            torch.cuda.synchronize()
+            same = torch.tensor([1.0 if torch.equal(C_one, C) else 0.0], device=dev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            if float(same.item()) < 1.0:
+                raise SystemExit("rank %d: the chunked all-gather + product differs from the single all-gather + product" % rank)
+            del C_one
         # ---- parity spot check: rows of C against a float64 evaluation on the stored (rounded) values -------------------------
         worst = 0.0
         if args.check_rows > 0:
@@ -307,7 +330,7 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
     if extrap:
         out["config"]["extrapolated"] = extrap
     if distributed:
-        out["config"]["allgather"] = dict(gather_pick or {}, mode=gather_mode, ms_alone=round(float(mx[2]), 4))
+        out["config"]["allgather"] = dict(gather_pick or {}, mode=gather_mode, ms_alone=round(float(mx[2]), 4), chunks=int(getattr(args, "ag_chunks", 1)))
         out["config"]["host_seconds_max_rank"] = round(float(mx[3]), 2)
         if comparator:
             out["config"]["one_gpu_comparator"] = comparator

@@ -9,6 +9,8 @@ for job in "$@"; do
     c4) run slabs8_scale23 --workload rmat-part --slabs 8 --steps 10 --warmup 3 || exit 1 ;;
     c3_01) run c3_0p1pct_off --workload rmat-part --rmat-scale 20 --rmat-density 1e-3 --slabs 8 --steps 10 --warmup 3 || exit 1 ;;
     c3_1) run c3_1pct_off --workload rmat-part --rmat-scale 20 --rmat-density 1e-2 --slabs 16 --steps 5 --warmup 2 --no-cpu-baseline || exit 1 ;;
+    c3_01_on) SPARTA_MINHASH_VERBOSE=1 run c3_0p1pct_on --workload rmat-part --rmat-scale 20 --rmat-density 1e-3 --slabs 8 --steps 10 --warmup 3 --reorder on --no-cpu-baseline || exit 1; grep minhash gpurun_out/r3/c3_0p1pct_on.err | tail -12 ;;
+    c3_01_auto) run c3_0p1pct_auto --workload rmat-part --rmat-scale 20 --rmat-density 1e-3 --slabs 8 --steps 10 --warmup 3 --reorder auto --no-cpu-baseline || exit 1 ;;
     c3_5) run c3_5pct_off --workload rmat-part --rmat-scale 20 --rmat-density 5e-2 --slabs 64 --slab-sample 6 --steps 5 --warmup 2 --no-cpu-baseline || exit 1 ;;
   esac
 done

@@ -144,6 +144,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
     std::vector<uint8_t> mode((size_t)block_rows, 0);
     std::vector<double> saved_row((size_t)block_rows, 0.0);           // MFMA steps the chosen mode saves against "all tiles"
     std::vector<int64_t> sp_rows_of(hybrid ? (size_t)block_rows : 0, 0), sp_ent_of(hybrid ? (size_t)block_rows : 0, 0), nb_all(hybrid ? (size_t)block_rows : 0, 0);
+    std::vector<int64_t> nnz_all(hybrid ? (size_t)block_rows : 0, 0);  // stored nonzeros of the block-row (all blocks)
     const int64_t grain = std::max<int64_t>(1, std::min<int64_t>(64, block_rows / (8 * (int64_t)host_threads()) + 1));
     parallel_for_dynamic(block_rows, grain, [&](int64_t lo, int64_t hi, int) {
         BlockCollector bc(block_cols, hybrid);
@@ -156,6 +157,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
             saved_row[(size_t)ib] = r.saved;
             if (!hybrid) continue;
             nb_all[(size_t)ib] = (int64_t)bc.touched.size();
+            for (int32_t jb : bc.touched) nnz_all[(size_t)ib] += bc.count[(size_t)jb];
             if (r.mode == 1) {                                            // every row of the block-row is a sparse row (padded and empty ones too)
                 int64_t ent = 0;
                 for (int32_t jb : bc.touched) ent += bc.count[(size_t)jb];
@@ -192,6 +194,30 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                 mode[(size_t)ib] = 0;
                 out->nzcount[ib] = nb_all[(size_t)ib];
                 sp_rows_of[(size_t)ib] = sp_ent_of[(size_t)ib] = 0;
+            }
+        }
+        // SMALL matrices: every launch of a product costs ~5-10 us whatever it does, and the MFMA part needs up to five (panel tail copy, one per tile
+        // type, fix-up, zero fill) where the sparse-row kernels need the ones they run anyway.  When the tiles of the whole matrix hold fewer nonzeros than
+        // their steps + those launches are worth (a launch ~ SPARTA_LAUNCH_NNZ = 50 000 gathered nonzeros ~ 5 us), EVERYTHING goes to the sparse rows:
+        // ca-HepPh (118 k nonzeros, 11 tile blocks): 110 -> ~40 us per product, bcsstk18 (80 k nonzeros in 3002 thin blocks): 48 -> ~25 us.
+        {
+            const double launch_nnz = [] { const char* e = std::getenv("SPARTA_LAUNCH_NNZ"); return e ? atof(e) : 50000.0; }();
+            double tile_steps = 0.0, tile_nnz = 0.0;
+            for (int64_t ib = 0; ib < block_rows; ib++) {
+                if (mode[(size_t)ib] == 1) continue;
+                tile_steps += (double)out->nzcount[ib] * spb_of(part[(size_t)ib + 1] - part[(size_t)ib]);
+                tile_nnz += (double)(nnz_all[(size_t)ib] - sp_ent_of[(size_t)ib]);
+            }
+            if (tile_steps > 0.0 && tile_nnz < K * tile_steps + 3.0 * launch_nnz) {
+                for (int64_t ib = 0; ib < block_rows; ib++) {
+                    const int64_t h = part[(size_t)ib + 1] - part[(size_t)ib];
+                    if (mode[(size_t)ib] == 1 || h <= 0) continue;
+                    // (block-rows without blocks too: as sparse rows without entries they get their zeros from the same launch instead of a fix-up / zero-fill launch)
+                    mode[(size_t)ib] = 1;
+                    out->nzcount[ib] = 0;
+                    sp_rows_of[(size_t)ib] = h;
+                    sp_ent_of[(size_t)ib] = nnz_all[(size_t)ib];
+                }
             }
         }
         if (stats_only) {                                                  // sparta_vbs_plan_stats: the decisions are all that is wanted

@@ -9,6 +9,7 @@
 //
 #include <memory>
 
+#include <cmath>
 #include "vbs_device.hpp"
 
 using namespace sparta_dev;
@@ -270,14 +271,21 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     // short rows: one wave each; rows with more than kSpLong nonzeros (hubs): segments of kSpSeg, one wave each + a reduction
     if (kSpSeg == 0) {
         const int64_t total = sp_rowptr.empty() ? 0 : sp_rowptr.back();
-        kSpSeg = total < ((int64_t)4 << 20) ? 128 : (total < ((int64_t)16 << 20) ? 256 : 512);
+        // (below 1 M nonzeros the GPU has more idle waves than rows: 32-nonzero segments -- ca-HepPh: rows of up to 256 nonzeros on one wave each took
+        // 57 us for 115 k nonzeros, 16 batches of gathers one after the other)
+        kSpSeg = total < ((int64_t)1 << 20) ? 32 : (total < ((int64_t)4 << 20) ? 128 : (total < ((int64_t)16 << 20) ? 256 : 512));
     }
     const int64_t kSpLong = 2 * kSpSeg;
     for (size_t t = 0; t < sp_crow.size(); t++) {
         const int64_t p0 = sp_rowptr[t], n = sp_rowptr[t + 1] - p0;
         if (n <= kSpLong) { sp_list.push_back((int32_t)t); continue; }
+        // a hub row's segments run in parallel, its partial rows are added one after the other: with segments of L nonzeros the chain is L / 16 gather
+        // batches + n / L additions -- shortest near L = sqrt(1.6 n) (a batch ~ 10 additions), never below the size-dependent base, never above 512
+        // (ia-wikiquote, 239 k nonzeros with rows of 10^4: 32-nonzero segments everywhere took 271 us, mostly the reduction of its hub rows)
+        int64_t L = ((int64_t)std::sqrt(1.6 * (double)n) + 15) / 16 * 16;
+        L = std::max(kSpSeg, std::min<int64_t>(512, L));
         SpLongRec lr{(int32_t)t, (int32_t)sp_segs.size(), 0, 0};
-        for (int64_t o = 0; o < n; o += kSpSeg) { sp_segs.push_back(SpSegRec{p0 + o, (int32_t)std::min<int64_t>(kSpSeg, n - o), 0}); lr.n_seg++; }
+        for (int64_t o = 0; o < n; o += L) { sp_segs.push_back(SpSegRec{p0 + o, (int32_t)std::min<int64_t>(L, n - o), 0}); lr.n_seg++; }
         sp_long.push_back(lr);
     }
     n_sp_short = (int64_t)sp_list.size(); n_sp_long = (int64_t)sp_long.size();

@@ -22,6 +22,9 @@ def _sparse_row_mode(request, monkeypatch):
     else:
         monkeypatch.delenv("SPARTA_SPARSE_K", raising=False)
         monkeypatch.setenv("SPARTA_SPARSE_MIN_STEPS", "0")        # the library leaves a handful of such block-rows with the tiles: the test matrices are all "a handful"
+    # ... and sends a SMALL matrix to the sparse-row kernels altogether when its tiles are not worth their launches (vbs_build.cpp, SPARTA_LAUNCH_NNZ): the test
+    # matrices are all small, and these tests are about the tiles (tests/test_real_matrices.py and test_small_matrices_* run with the library's own rule)
+    monkeypatch.setenv("SPARTA_LAUNCH_NNZ", "0")
     return request.param
 TOL = 1e-5
 
@@ -794,6 +797,33 @@ def test_a_constant_b_prepared_once_gives_the_bits_of_the_plain_product(dtype):
     Bp.close(); Bpg.close()
     with pytest.raises(ValueError):
         d.spmm_prepared(Bp, C2)
+
+
+def test_small_matrices_whose_tiles_are_not_worth_their_launches_go_to_the_sparse_rows(monkeypatch):
+    """every launch of a product costs 5-10 us whatever it does: a small matrix whose tiles hold fewer nonzeros than their steps + three launches are worth is
+    multiplied by the sparse-row kernels alone (one launch chain instead of two); a small DENSE matrix keeps its tiles.  Same product either way."""
+    torch = _torch()
+    monkeypatch.delenv("SPARTA_LAUNCH_NNZ", raising=False)
+    monkeypatch.delenv("SPARTA_SPARSE_K", raising=False)
+    monkeypatch.delenv("SPARTA_SPARSE_MIN_STEPS", raising=False)
+    n, w = 128, 32
+    thin = sa.gen.banded(6000, 40, density=0.08, seed=3)                    # ~39 k nonzeros in thin blocks
+    dense = sa.gen.uniform_random(1024, 1024, 600000, seed=4)               # 57 % fill: tiles
+    for m, want_tiles in ((thin, False), (dense, True)):
+        g = np.arange(m.rows) // 32
+        st = sa.DeviceVBS.plan_stats(m, g, w, 32, False)
+        assert (st["tile_blocks"] > 0) == want_tiles, st
+        d = sa.DeviceVBS.from_csr(m, g, w, 32, False, device=0)
+        assert (d.info()["nblocks"] > 0) == want_tiles and d.info()["nblocks"] == st["tile_blocks"]
+        v = sa.VBR().fill_from_CSR_inplace(m, g, w, 32, False)
+        B = sa.gen.dense_rhs(v.cols, n, seed=5)
+        Co = _oracle_c(v, B, n)
+        bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+        C = torch.full((v.rows * n,), 9.0, dtype=torch.float32, device="cuda")
+        d.spmm(torch.from_numpy(B).cuda(), C, n)
+        torch.cuda.synchronize()
+        _check(C.cpu().numpy(), Co, bound, "small matrix, tiles %s" % want_tiles)
+        d.close()
 
 
 def test_16bit_handles_reject_what_they_cannot_do():
