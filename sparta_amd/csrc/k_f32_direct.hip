@@ -63,16 +63,17 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
     const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 32 * wave + 4 * g) * 4) : (uint32_t)((lm + (32 * wave + 4 * g) * p.ldc) * 4);
     const int64_t n0off = (int64_t)n0 * p.ldb;
     char* const ldsw = reinterpret_cast<char*>(lds) + wave * (2 * WSTAGE * 4);   // this wave's two stages
-    const uint32_t lwB = (uint32_t)((bc * LDBW + bk) * 4);                        // write: column bc + 8 q -> + 8 q LDBW floats
+    const uint32_t lwC = (uint32_t)(bc * LDBW * 4);                               // write: column bc + 8 q -> + 8 q LDBW floats, + 4 x the position of the k
     const uint32_t lrB = (uint32_t)((lm * LDBW + 16 * g) * 4);                    // read: column lm, k = 16 g + 4 j .. + 3
 
     u32x4 bs0[4], bs1[4];                                // B staging sets (steps of even / odd index)
     u32x4 as0[4], as1[4], as2[4], as3[4];                // A fragment sets (step index mod 4)
+    uint32_t kt0 = 0, kt1 = 0, kt2 = 0, kt3 = 0;         // ... and the LDS positions of this lane's four k of that step (k-compaction, vbs_plan.cpp): one byte each
 
-    const float* a_cur = p.A + (int64_t)s_begin * 1024;  // a_frag slice of the next step to be requested (steps are requested in order)
+    const float* a_cur = p.A + (int64_t)s_begin * kAFragSlice;  // slice of the next step to be requested (steps are requested in order): [32-byte table, padding][fragments]
     uint32_t vo_cur = voffB;
     int32_t tail_prev = 0;
-    auto issue_loads = [&](auto pos_tag, u32x4 (&rb)[4], u32x4 (&ra)[4]) __attribute__((always_inline)) -> int32_t {
+    auto issue_loads = [&](auto pos_tag, u32x4 (&rb)[4], u32x4 (&ra)[4], uint32_t& kt) __attribute__((always_inline)) -> int32_t {
         constexpr int s = decltype(pos_tag)::value;      // position of the step's record in the window
         const int32_t flags = field(s, F_FLAGS);
         const int32_t tail = TAIL && (flags & STEP_TAIL) != 0;
@@ -95,7 +96,12 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
 #pragma unroll
             for (int q = 0; q < 4; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, qs * q, SPARTA_DIRECT_BLOAD_AUX);
         }
-        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_cur), 0, 0x7ffffff0, 0x00020000);
+        // the fragments this step's MFMAs will read: 1 KB per group of four MFMAs; the groups behind (columns of zeros, compacted away) are
+        // not fetched -- loads past the end of the descriptor return zeros without touching memory
+        const int32_t n_quads = (((flags >> STEP_KPAIRS_SHIFT) & 7) >> 1) + 1;
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_cur + 16), 0, n_quads * 1024, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_cur), 0, 32, 0x00020000);
+        kt = __builtin_amdgcn_raw_buffer_load_b32(rT, (uint32_t)((lane & 7) * 4), 0, 0);
         if (!(SPARTA_DIRECT_PROBE & 2)) {
 #pragma unroll
 #ifndef SPARTA_DIRECT_ALOAD_AUX
@@ -103,15 +109,21 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
 #endif
             for (int j = 0; j < 4; j++) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA, 1024 * j, SPARTA_DIRECT_ALOAD_AUX);
         }
-        a_cur += 1024;
+        a_cur += kAFragSlice;
         return flags;
     };
     int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq_new = 0;
 
-    auto write_b = [&](auto stage_tag, const u32x4 (&rb)[4]) __attribute__((always_inline)) {
+    // the lane's four k of a column (k = bk + e) go to the step's compacted positions: Bs[column][pos[k]]
+    auto write_b = [&](auto stage_tag, const u32x4 (&rb)[4], uint32_t kt) __attribute__((always_inline)) {
         constexpr int ST = decltype(stage_tag)::value;
+        char* wp[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) *reinterpret_cast<u32x4*>(ldsw + lwB + (ST * WSTAGE + 8 * q * LDBW) * 4) = rb[q];
+        for (int e = 0; e < 4; e++) wp[e] = ldsw + lwC + ((kt >> (8 * e)) & 0xffu) * 4u;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) *reinterpret_cast<uint32_t*>(wp[e] + (ST * WSTAGE + 8 * q * LDBW) * 4) = rb[q][e];
     };
 
     f32x16 acc;
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
     // one step: fragments of B from LDS stage PAR, the next step's panel into the other stage, 16 MFMAs, then the staging set that was
     // just written out and the A set of step i - 1 are refilled with step i + 3.  (Measured and dropped: reading the fragments of step
     // i + 1 during step i -- 16 more registers, 56.0 us against 54.1.)
-    auto step = [&](auto u_tag, int32_t flags, u32x4 (&wa)[4], u32x4 (&nb)[4], u32x4 (&na)[4]) __attribute__((always_inline)) {
+    auto step = [&](auto u_tag, int32_t flags, u32x4 (&wa)[4], u32x4 (&nb)[4], u32x4 (&na)[4], uint32_t ktw, uint32_t& ktn) __attribute__((always_inline)) {
         constexpr int i = decltype(u_tag)::value;        // step index mod 4 = position of its record in the window
         constexpr int PAR = i & 1;
         f32x4 fb[4];
@@ -134,20 +146,24 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const f32x4*>(ldsw + lrB + (PAR * WSTAGE + 4 * j) * 4);
-            write_b(std::integral_constant<int, 1 - PAR>{}, nb);         // W(i + 1)
+            write_b(std::integral_constant<int, 1 - PAR>{}, nb, ktw);    // W(i + 1): the panel of step i + 1 to that step's positions
         }
 #ifdef SPARTA_DIRECT_SETPRIO
         __builtin_amdgcn_s_setprio(SPARTA_DIRECT_SETPRIO);
 #endif
+        // MFMA t = 4 j + e multiplies the compacted columns 2 t (lanes g = 0) and 2 t + 1 (g = 1): pairs of MFMAs, as many as the step needs
+        const int32_t n_pairs = ((flags >> STEP_KPAIRS_SHIFT) & 7) + 1;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][e], __uint_as_float(wa[j][e]), acc, 0, 0, 0);
+        for (int t2 = 0; t2 < 8; t2++) {
+            if (t2 < n_pairs) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[t2 >> 1][2 * (t2 & 1)], __uint_as_float(wa[t2 >> 1][2 * (t2 & 1)]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[t2 >> 1][2 * (t2 & 1) + 1], __uint_as_float(wa[t2 >> 1][2 * (t2 & 1) + 1]), acc, 0, 0, 0);
+            }
+        }
 #ifdef SPARTA_DIRECT_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
-        fq_new = issue_loads(std::integral_constant<int, i + 3>{}, nb, na);                              // G(i + 3).  (Four steps ahead, four staging sets: 57.7 us against 55.0 -- latency is not what these steps wait for.)
+        fq_new = issue_loads(std::integral_constant<int, i + 3>{}, nb, na, ktn);                              // G(i + 3).  (Four steps ahead, four staging sets: 57.7 us against 55.0 -- latency is not what these steps wait for.)
         if ((flags & STEP_LAST) && !(SPARTA_DIRECT_PROBE & 4)) {
             // epilogue (as in vbs_spmm_f32_stream_kernel): stored from copies, accumulators cleared here
             if (flags & STEP_SPLIT) {
@@ -204,33 +220,33 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
         const int32_t* nb = srec + (int64_t)(i + 4) * 8 + lane;
         asm volatile("global_load_dword %0, %1, off" : "=&v"(vnext) : "v"(nb) : "memory");
     };
-    fq0 = issue_loads(c0{}, bs0, as0);
-    fq1 = issue_loads(c1{}, bs1, as1);
-    write_b(c0{}, bs0);                                  // W(0)
-    fq2 = issue_loads(c2{}, bs0, as2);
+    fq0 = issue_loads(c0{}, bs0, as0, kt0);
+    fq1 = issue_loads(c1{}, bs1, as1, kt1);
+    write_b(c0{}, bs0, kt0);                             // W(0)
+    fq2 = issue_loads(c2{}, bs0, as2, kt2);
     // step i: LDS stage i & 1, A set i & 3; writes out staging set (i + 1) & 1 and refills it, and A set (i + 3) & 3, with step i + 3
     const int n4 = n & ~3;
     for (int i = 0; i < n4; i += 4) {
         if (i > 0) window_swap();
         window_request(i);
-        step(c0{}, fq0, as0, bs1, as3);
+        step(c0{}, fq0, as0, bs1, as3, kt1, kt3);
         fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-        step(c1{}, fq0, as1, bs0, as0);
+        step(c1{}, fq0, as1, bs0, as0, kt2, kt0);
         fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-        step(c2{}, fq0, as2, bs1, as1);
+        step(c2{}, fq0, as2, bs1, as1, kt3, kt1);
         fq0 = fq1; fq1 = fq2; fq2 = fq_new;
-        step(c3{}, fq0, as3, bs0, as2);
+        step(c3{}, fq0, as3, bs0, as2, kt0, kt2);
         fq0 = fq1; fq1 = fq2; fq2 = fq_new;
     }
     if (n > n4) {
         if (n4 > 0) window_swap();
-        step(c0{}, fq0, as0, bs1, as3);
+        step(c0{}, fq0, as0, bs1, as3, kt1, kt3);
         fq0 = fq1; fq1 = fq2; fq2 = fq_new;
         if (n - n4 >= 2) {
-            step(c1{}, fq0, as1, bs0, as0);
+            step(c1{}, fq0, as1, bs0, as0, kt2, kt0);
             fq0 = fq1; fq1 = fq2; fq2 = fq_new;
         }
-        if (n - n4 == 3) step(c2{}, fq0, as2, bs1, as1);
+        if (n - n4 == 3) step(c2{}, fq0, as2, bs1, as1, kt3, kt1);
     }
     if (CSTAGE) cr.flush(p, n0, lm, g, voffC, true);
     clock_probe(p.clk, 2);

@@ -343,7 +343,10 @@ void launch_sparse_t(SparseParams q, unsigned gy, hipStream_t st, const int32_t*
         // column-major C: 16 rows per workgroup (64-byte pieces of a column; 32 rows = 128-byte pieces but half the workgroups: measured 0-25 %
         // slower from R-MAT 2^14 to 2^20), 4 waves walking 4 rows each (8 / 16 waves with 2 / 1 rows each: 15-45 % slower on R-MAT 2^20; 1 wave
         // with 16 rows: 10-30 % slower)
-        if (q.out_is_c == 2) hipLaunchKernelGGL((sparse_rows_cm_kernel<VEC, BK, 16, 4>), dim3((unsigned)((n_short + 15) / 16), gy), dim3(256), 0, st, q);
+        // ... on LARGE sparse parts.  A small one (about as many rows as the GPU has wave slots: the smaller of the reference's real inputs, 10^4 rows; at 5 x 10^4 rows the 16-row form is ahead again) is a
+        // latency chain, not a bandwidth problem: one row per wave, 4 rows per workgroup, so that no wave walks four rows one after the other
+        if (q.out_is_c == 2 && n_short < 16384) hipLaunchKernelGGL((sparse_rows_cm_kernel<VEC, BK, 4, 4>), dim3((unsigned)((n_short + 3) / 4), gy), dim3(256), 0, st, q);
+        else if (q.out_is_c == 2) hipLaunchKernelGGL((sparse_rows_cm_kernel<VEC, BK, 16, 4>), dim3((unsigned)((n_short + 15) / 16), gy), dim3(256), 0, st, q);
         else hipLaunchKernelGGL((sparse_rows_kernel<VEC, BK>), dim3((unsigned)((n_short + 3) / 4), gy), dim3(kThreads), 0, st, q);
     }
     if (n_long > 0) {

@@ -66,6 +66,9 @@ constexpr int SK_TM = 64;                 // max rows of a tile
 constexpr int32_t STEP_FIRST = 1 << 16;   // first step of a (segment of a) tile: accumulators start at zero
 constexpr int32_t STEP_LAST = 1 << 17;    // last step of a (segment of a) tile: run the epilogue
 constexpr int32_t STEP_SPLIT = 1 << 18;   // the tile is shared with another worker: epilogue goes to the workspace
+constexpr int32_t STEP_KPAIRS_SHIFT = 24;  // bits 24..26: (MFMA pairs this step needs) - 1, fp32 one-tile plans with a fragment image (k-compaction: the
+                                           // non-empty columns of the step's slice of A come first, vbs_plan.cpp); read by vbs_spmm_f32_direct_kernel only
+constexpr int64_t kAFragSlice = 1040;      // floats per step of the fragment image: 16 (the step's LDS position table: 32 bytes + padding) + 1024 (fragments)
 constexpr int32_t STEP_TAIL = 1 << 19;    // panel of the zero-padded last block column: read from StreamParams::B_tail, b_row = k offset in it
 constexpr int SK_SLOT_FLOATS = 32 * kThreads;   // one partial accumulator image: 32 registers x 256 threads
 

@@ -347,21 +347,53 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                 // keeps the LDS-staged kernel on the legacy image instead of quadrupling the handle)
                 int64_t one_tile_area = 0;
                 for (int64_t q = 0; q < S; q++) one_tile_area += (int64_t)(st[(size_t)q].mt_flags & 0xffff) * SK_KP;
-                if (!off && ty == 0 && !h16 && S <= ((int64_t)2 << 20) && S * 1024 <= 4 * std::max<int64_t>(one_tile_area, 1) + (1 << 20)) {
+                if (!off && ty == 0 && !h16 && S <= ((int64_t)2 << 20) && S * kAFragSlice <= 4 * std::max<int64_t>(one_tile_area, 1) + (1 << 20)) {
+                    // k-COMPACTION.  A stored 32 x 32 block of a FEM matrix has 23 non-empty columns on average (the flagship: 27 % of the MFMAs would
+                    // multiply columns of zeros).  The sum over k may run in any order as long as both operands agree, so per step the non-empty columns
+                    // K[0..nk) of the slice go FIRST: compact index c sits at fragment position k' = (c >> 1) + 16 (c & 1), i.e. MFMA t (t = 4 j + e) takes
+                    // c = 2 t from the lanes g = 0 and c = 2 t + 1 from g = 1, and only ceil(nk / 2) MFMAs -- issued in pairs -- are needed.  The kernel
+                    // writes the B panel to the SAME positions: every step carries its table pos[k] (32 bytes, a permutation of 0..31: the empty columns
+                    // fill the positions behind), chosen so that the eight lanes of a ds_write_b32 that hold the same e of their four k's land in different
+                    // LDS banks (residues of pos mod 4 balanced inside each class k mod 4).
                     std::vector<float>& af = P.a_frag;
-                    af.assign(((size_t)S + 4) * 1024, 0.0f);                    // + 4: the pipeline requests three steps past a range end
+                    af.assign(((size_t)S + 4) * (size_t)kAFragSlice, 0.0f);                    // + 4: the pipeline requests three steps past a range end
                     sparta::parallel_for_dynamic(S, 256, [&](int64_t lo, int64_t hi, int) {
                         for (int64_t q = lo; q < hi; q++) {
-                            const StepRec& r = st[(size_t)q];
+                            StepRec& r = st[(size_t)q];
                             const float* blk = mab + mab_lo + r.a_off;              // element (row, k) of the slice at blk[k * h + row]
                             const int64_t hh = r.h, mt = r.mt_flags & 0xffff;
-                            float* dst = af.data() + (size_t)q * 1024;
-                            for (int j = 0; j < 4; j++)
-                                for (int g = 0; g < 2; g++)
-                                    for (int64_t m = 0; m < mt; m++)
-                                        for (int e = 0; e < 4; e++) dst[((j * 2 + g) * 32 + m) * 4 + e] = blk[(int64_t)(16 * g + 4 * j + e) * hh + m];
+                            bool nonempty[32];
+                            int nk = 0;
+                            for (int k = 0; k < 32; k++) {
+                                bool any = false;
+                                for (int64_t m = 0; m < mt && !any; m++) any = blk[(int64_t)k * hh + m] != 0.0f;
+                                nonempty[k] = any; nk += any;
+                            }
+                            // positions: the first nk compact indices for the non-empty columns, the rest for the empty ones; inside each group the
+                            // columns are handed out class by class (k mod 4 = e) so that a class spreads over the four residues of pos mod 4
+                            uint8_t pos[32];
+                            int order[32], no = 0;
+                            for (int pass = 0; pass < 2; pass++)
+                                for (int m = 0; m < 8; m++)
+                                    for (int e = 0; e < 4; e++) { const int k = 4 * m + ((e + m) & 3); if (nonempty[k] == (pass == 0)) order[no++] = k; }
+                            for (int c = 0; c < 32; c++) pos[order[c]] = (uint8_t)((c >> 1) + 16 * (c & 1));
+                            float* dst = af.data() + (size_t)q * (size_t)kAFragSlice;
+                            std::memcpy(dst, pos, 32);
+                            float* frag = dst + 16;
+                            for (int k = 0; k < 32; k++) {
+                                if (!nonempty[k]) continue;
+                                const int kp = pos[k], g = kp >> 4, j = (kp & 15) >> 2, e = kp & 3;     // k' = 16 g + 4 j + e
+                                for (int64_t m = 0; m < mt; m++) frag[((j * 2 + g) * 32 + m) * 4 + e] = blk[(int64_t)k * hh + m];
+                            }
+                            const int n_mfma = std::max(1, (nk + 1) / 2), pairs = (n_mfma + 1) / 2;
+                            r.mt_flags = (r.mt_flags & ~(7 << STEP_KPAIRS_SHIFT)) | ((pairs - 1) << STEP_KPAIRS_SHIFT);
                         }
                     });
+                    for (size_t q = (size_t)S; q < (size_t)S + 4; q++) {              // the slices behind the end: identity table (never multiplied)
+                        uint8_t pos[32];
+                        for (int k = 0; k < 32; k++) pos[k] = (uint8_t)k;
+                        std::memcpy(af.data() + q * (size_t)kAFragSlice, pos, 32);
+                    }
                 }
             }
         }

@@ -113,7 +113,7 @@ def test_steady_state_of_the_one_tile_kernels_keeps_its_prefetch_and_its_valu_bu
         # the step waits of the round leave the loads of five steps and more in flight (two waits per step: one per LDS write)
         assert sum(w >= 20 for w in waits) >= 2 * 8, waits
         assert sum(w == 0 for w in waits) <= 1.5 * steps, waits
-    for txt, n_mfma_step, loads_per_step, mov_budget in [(t, 16, 8, 34) for t in f32] + [(t, 2, 4, 34) for t in h16] + [(t, 4, 6, 68) for t in h16_wide]:
+    for txt, n_mfma_step, loads_per_step, mov_budget in [(t, 16, 9, 44) for t in f32] + [(t, 2, 4, 34) for t in h16] + [(t, 4, 6, 68) for t in h16_wide]:
         ins = [l.split("//")[0].strip() for l in txt.splitlines() if l.startswith(("\t", " "))]
         ins = [i for i in ins if i]
         assert not any(i.startswith("scratch_") for i in ins)
@@ -125,7 +125,7 @@ def test_steady_state_of_the_one_tile_kernels_keeps_its_prefetch_and_its_valu_bu
         assert n_mov <= mov_budget * steps, (n_mov, steps)            # (28 per body with TAIL, 32 without: measured 1 % faster all the same; two accumulators: twice)
         # full waits: only in the epilogue bodies' C += path (one per body)
         n_full = sum(bool(re.match(r"s_waitcnt vmcnt\(0\)", i)) for i in ins)
-        assert n_full <= (1.5 if mov_budget < 60 else 2.5) * steps, (n_full, steps)     # (13 in 11 bodies today; two column groups: two C += paths per body)
+        assert n_full <= (1.5 if mov_budget < 40 else 2.5) * steps, (n_full, steps)     # (13 in 11 bodies today; two column groups: two C += paths per body)
         # the waits in front of the LDS writes of a step leave at least one step's loads in flight
         waits = [int(m.group(1)) for i in ins for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", i)] if m]
         assert sum(w >= loads_per_step for w in waits) >= 4 * steps, (waits, steps)
