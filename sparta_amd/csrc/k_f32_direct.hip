@@ -73,7 +73,8 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
     const float* a_cur = p.A + (int64_t)s_begin * kAFragSlice;  // slice of the next step to be requested (steps are requested in order): [32-byte table, padding][fragments]
     uint32_t vo_cur = voffB;
     int32_t tail_prev = 0;
-    auto issue_loads = [&](auto pos_tag, u32x4 (&rb)[4], u32x4 (&ra)[4], uint32_t& kt) __attribute__((always_inline)) -> int32_t {
+    // G(step) in two halves (B panel; A fragments + position table) so that a step can place them between its MFMA pairs
+    auto issue_loads_b = [&](auto pos_tag, u32x4 (&rb)[4]) __attribute__((always_inline)) -> int32_t {
         constexpr int s = decltype(pos_tag)::value;      // position of the step's record in the window
         const int32_t flags = field(s, F_FLAGS);
         const int32_t tail = TAIL && (flags & STEP_TAIL) != 0;
@@ -96,6 +97,9 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
 #pragma unroll
             for (int q = 0; q < 4; q++) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, qs * q, SPARTA_DIRECT_BLOAD_AUX);
         }
+        return flags;
+    };
+    auto issue_loads_a = [&](int32_t flags, u32x4 (&ra)[4], uint32_t& kt) __attribute__((always_inline)) {
         // the fragments this step's MFMAs will read: 1 KB per group of four MFMAs; the groups behind (columns of zeros, compacted away) are
         // not fetched -- loads past the end of the descriptor return zeros without touching memory
         const int32_t n_quads = (((flags >> STEP_KPAIRS_SHIFT) & 7) >> 1) + 1;
@@ -110,6 +114,10 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
             for (int j = 0; j < 4; j++) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA, 1024 * j, SPARTA_DIRECT_ALOAD_AUX);
         }
         a_cur += kAFragSlice;
+    };
+    auto issue_loads = [&](auto pos_tag, u32x4 (&rb)[4], u32x4 (&ra)[4], uint32_t& kt) __attribute__((always_inline)) -> int32_t {
+        const int32_t flags = issue_loads_b(pos_tag, rb);
+        issue_loads_a(flags, ra, kt);
         return flags;
     };
     int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq_new = 0;
@@ -124,6 +132,12 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
         for (int q = 0; q < 4; q++)
 #pragma unroll
             for (int e = 0; e < 4; e++) *reinterpret_cast<uint32_t*>(wp[e] + (ST * WSTAGE + 8 * q * LDBW) * 4) = rb[q][e];
+    };
+    // the same, one group of 8 columns at a time (wp[e] = the four write addresses of the step, computed once)
+    auto write_b_q = [&](auto stage_tag, auto q_tag, const u32x4 (&rb)[4], char* const (&wp)[4]) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_tag)::value, q = decltype(q_tag)::value;
+#pragma unroll
+        for (int e = 0; e < 4; e++) *reinterpret_cast<uint32_t*>(wp[e] + (ST * WSTAGE + 8 * q * LDBW) * 4) = rb[q][e];
     };
 
     f32x16 acc;
@@ -146,24 +160,31 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const f32x4*>(ldsw + lrB + (PAR * WSTAGE + 4 * j) * 4);
-            write_b(std::integral_constant<int, 1 - PAR>{}, nb, ktw);    // W(i + 1): the panel of step i + 1 to that step's positions
         }
-#ifdef SPARTA_DIRECT_SETPRIO
-        __builtin_amdgcn_s_setprio(SPARTA_DIRECT_SETPRIO);
-#endif
-        // MFMA t = 4 j + e multiplies the compacted columns 2 t (lanes g = 0) and 2 t + 1 (g = 1): pairs of MFMAs, as many as the step needs
-        const int32_t n_pairs = ((flags >> STEP_KPAIRS_SHIFT) & 7) + 1;
+        // The step's other work sits BETWEEN its MFMA pairs: a wave issues in order, and an MFMA of this chain waits 64 cycles for the one before it -- whatever
+        // independent instruction comes next in program order issues inside that wait.  Pairs 0..3 are followed by the LDS writes of one group of eight columns of
+        // the NEXT step's panel (W(i + 1); the wait for that panel's loads now hides behind the first pair), pair 4 by the B loads of step i + 3, pair 5 by its A
+        // loads.  The pairs a step does not need are skipped (scalar branches); the work between them always runs.
+        char* wp[4];
 #pragma unroll
-        for (int t2 = 0; t2 < 8; t2++) {
+        for (int e = 0; e < 4; e++) wp[e] = ldsw + lwC + ((ktw >> (8 * e)) & 0xffu) * 4u;
+        const int32_t n_pairs = ((flags >> STEP_KPAIRS_SHIFT) & 7) + 1;
+        int32_t flags_new = 0;
+        static_for<0, 8>([&](auto t2_tag) __attribute__((always_inline)) {
+            constexpr int t2 = decltype(t2_tag)::value;
             if (t2 < n_pairs) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[t2 >> 1][2 * (t2 & 1)], __uint_as_float(wa[t2 >> 1][2 * (t2 & 1)]), acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[t2 >> 1][2 * (t2 & 1) + 1], __uint_as_float(wa[t2 >> 1][2 * (t2 & 1) + 1]), acc, 0, 0, 0);
             }
-        }
-#ifdef SPARTA_DIRECT_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        fq_new = issue_loads(std::integral_constant<int, i + 3>{}, nb, na, ktn);                              // G(i + 3).  (Four steps ahead, four staging sets: 57.7 us against 55.0 -- latency is not what these steps wait for.)
+            if constexpr (t2 < 4) {
+                if (!(SPARTA_DIRECT_PROBE & 8)) write_b_q(std::integral_constant<int, 1 - PAR>{}, t2_tag, nb, wp);
+            } else if constexpr (t2 == 4) {
+                flags_new = issue_loads_b(std::integral_constant<int, i + 3>{}, nb);          // G(i + 3), B half: refills the staging set just written out
+            } else if constexpr (t2 == 5) {
+                issue_loads_a(flags_new, na, ktn);                                            // G(i + 3), A half
+            }
+        });
+        fq_new = flags_new;
         if ((flags & STEP_LAST) && !(SPARTA_DIRECT_PROBE & 4)) {
             // epilogue (as in vbs_spmm_f32_stream_kernel): stored from copies, accumulators cleared here
             if (flags & STEP_SPLIT) {

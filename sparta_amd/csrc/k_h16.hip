@@ -330,10 +330,6 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
 #ifndef SPARTA_H16_PROBE
 #define SPARTA_H16_PROBE 0        /* developer probes, TIMING ONLY (results wrong): 1 no B loads, 2 no A loads, 4 no epilogue, 8 no LDS round trip, 64 every tile stores to the first rows of C, 128 every step reads the first slice of A, 256 every step reads the first rows of B, 512 one store per tile instead of 16 (non-temporal path) */
 #endif
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
 
 // DEEP: loads 7 steps ahead of their MFMAs instead of 3 (eight A sets, six live B staging sets, two record windows, rounds of eight steps).  A 16-bit
 // step of a 32-wide block is two MFMAs (64 cycles) and ~300 cycles of a wave's time: three steps ahead are ~0.4 us, less than a loaded HBM access.

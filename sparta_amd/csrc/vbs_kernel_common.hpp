@@ -24,6 +24,12 @@ namespace sparta_dev {
 // in-order counter on gfx9) for the stores of the tile that ended two steps earlier, and non-temporal stores take longer to complete
 // (banded 200k, 1.8 steps per tile: 78-79 us non-temporal, 56-68 default; with every tile storing to the same rows of C: 37).
 
+// f(integral_constant<0>) ... f(integral_constant<N - 1>): a loop whose index is a compile-time constant in every iteration
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
 __device__ __forceinline__ void clock_probe(long long* clk, int slot) {
     if (clk != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         clk[slot] = (long long)__builtin_readcyclecounter();
