@@ -140,9 +140,12 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
         for (int e = 0; e < 4; e++) *reinterpret_cast<uint32_t*>(wp[e] + (ST * WSTAGE + 8 * q * LDBW) * 4) = rb[q][e];
     };
 
-    f32x16 acc;
+#ifndef SPARTA_DIRECT_TWOACC
+#define SPARTA_DIRECT_TWOACC 0     /* 1: the MFMA pairs alternate between two accumulators (two chains in flight per wave), added in the epilogue */
+#endif
+    f32x16 acc, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    for (int r = 0; r < 16; r++) { acc[r] = 0.0f; acc2[r] = 0.0f; }
 
     CRing cr;                                            // CSTAGE: finished tiles wait here for whole aligned blocks of 32 rows (vbs_kernel_common.hpp)
     cr.ring = lds + 4 * 2 * WSTAGE + wave * kCRingFloats;
@@ -150,14 +153,20 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
     // one step: fragments of B from LDS stage PAR, the next step's panel into the other stage, 16 MFMAs, then the staging set that was
     // just written out and the A set of step i - 1 are refilled with step i + 3.  (Measured and dropped: reading the fragments of step
     // i + 1 during step i -- 16 more registers, 56.0 us against 54.1.)
+#ifndef SPARTA_DIRECT_FBPRE
+#define SPARTA_DIRECT_FBPRE 0      /* 1: the B fragments of step i + 1 are read from LDS behind pair 6 of step i (two fragment sets) instead of at the head of step i + 1 */
+#endif
+    f32x4 fbE[4], fbO[4];                                // SPARTA_DIRECT_FBPRE: fragments of the even / odd steps
     auto step = [&](auto u_tag, int32_t flags, u32x4 (&wa)[4], u32x4 (&nb)[4], u32x4 (&na)[4], uint32_t ktw, uint32_t& ktn) __attribute__((always_inline)) {
         constexpr int i = decltype(u_tag)::value;        // step index mod 4 = position of its record in the window
         constexpr int PAR = i & 1;
-        f32x4 fb[4];
+        f32x4 fbl[4];
+        f32x4 (&fb)[4] = SPARTA_DIRECT_FBPRE ? (PAR ? fbO : fbE) : fbl;
+        f32x4 (&fbn)[4] = PAR ? fbE : fbO;
         if (SPARTA_DIRECT_PROBE & 8) {
 #pragma unroll
             for (int j = 0; j < 4; j++) fb[j] = __builtin_bit_cast(f32x4, nb[j]);
-        } else {
+        } else if (!SPARTA_DIRECT_FBPRE) {
 #pragma unroll
             for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const f32x4*>(ldsw + lrB + (PAR * WSTAGE + 4 * j) * 4);
         }
@@ -173,20 +182,47 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
         static_for<0, 8>([&](auto t2_tag) __attribute__((always_inline)) {
             constexpr int t2 = decltype(t2_tag)::value;
             if (t2 < n_pairs) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[t2 >> 1][2 * (t2 & 1)], __uint_as_float(wa[t2 >> 1][2 * (t2 & 1)]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[t2 >> 1][2 * (t2 & 1) + 1], __uint_as_float(wa[t2 >> 1][2 * (t2 & 1) + 1]), acc, 0, 0, 0);
+                if constexpr (SPARTA_DIRECT_TWOACC) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[t2 >> 1][2 * (t2 & 1)], __uint_as_float(wa[t2 >> 1][2 * (t2 & 1)]), acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[t2 >> 1][2 * (t2 & 1) + 1], __uint_as_float(wa[t2 >> 1][2 * (t2 & 1) + 1]), acc2, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[t2 >> 1][2 * (t2 & 1)], __uint_as_float(wa[t2 >> 1][2 * (t2 & 1)]), acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[t2 >> 1][2 * (t2 & 1) + 1], __uint_as_float(wa[t2 >> 1][2 * (t2 & 1) + 1]), acc, 0, 0, 0);
+                }
             }
-            if constexpr (t2 < 4) {
-                if (!(SPARTA_DIRECT_PROBE & 8)) write_b_q(std::integral_constant<int, 1 - PAR>{}, t2_tag, nb, wp);
-            } else if constexpr (t2 == 4) {
-                flags_new = issue_loads_b(std::integral_constant<int, i + 3>{}, nb);          // G(i + 3), B half: refills the staging set just written out
-            } else if constexpr (t2 == 5) {
-                issue_loads_a(flags_new, na, ktn);                                            // G(i + 3), A half
+#ifndef SPARTA_DIRECT_ORDER
+#define SPARTA_DIRECT_ORDER 0
+#endif
+            if constexpr (SPARTA_DIRECT_ORDER == 0) {
+                if constexpr (t2 < 4) {
+                    if (!(SPARTA_DIRECT_PROBE & 8)) write_b_q(std::integral_constant<int, 1 - PAR>{}, t2_tag, nb, wp);
+                } else if constexpr (t2 == 4) {
+                    flags_new = issue_loads_b(std::integral_constant<int, i + 3>{}, nb);          // G(i + 3), B half: refills the staging set just written out
+                } else if constexpr (t2 == 5) {
+                    issue_loads_a(flags_new, na, ktn);                                            // G(i + 3), A half
+                }
+                if constexpr (SPARTA_DIRECT_FBPRE && t2 == 6) {                                   // W(i + 1) is complete (program order, one wave): its fragments for the next step
+#pragma unroll
+                    for (int j = 0; j < 4; j++) fbn[j] = *reinterpret_cast<const f32x4*>(ldsw + lrB + ((1 - PAR) * WSTAGE + 4 * j) * 4);
+                }
+            } else {                                     // A loads first (they depend on nothing), then the writes, then the B loads
+                if constexpr (t2 == 0) {
+                    flags_new = field(i + 3, F_FLAGS);
+                    issue_loads_a(flags_new, na, ktn);
+                } else if constexpr (t2 < 5) {
+                    if (!(SPARTA_DIRECT_PROBE & 8)) write_b_q(std::integral_constant<int, 1 - PAR>{}, std::integral_constant<int, t2 - 1>{}, nb, wp);
+                } else if constexpr (t2 == 5) {
+                    flags_new = issue_loads_b(std::integral_constant<int, i + 3>{}, nb);
+                }
             }
         });
         fq_new = flags_new;
         if ((flags & STEP_LAST) && !(SPARTA_DIRECT_PROBE & 4)) {
             // epilogue (as in vbs_spmm_f32_stream_kernel): stored from copies, accumulators cleared here
+            if constexpr (SPARTA_DIRECT_TWOACC) {
+#pragma unroll
+                for (int q = 0; q < 16; q++) { acc[q] += acc2[q]; acc2[q] = 0.0f; }
+            }
             if (flags & STEP_SPLIT) {
                 const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_SLOT) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
 #pragma unroll
@@ -244,6 +280,10 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const 
     fq0 = issue_loads(c0{}, bs0, as0, kt0);
     fq1 = issue_loads(c1{}, bs1, as1, kt1);
     write_b(c0{}, bs0, kt0);                             // W(0)
+    if (SPARTA_DIRECT_FBPRE) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) fbE[j] = *reinterpret_cast<const f32x4*>(ldsw + lrB + (4 * j) * 4);
+    }
     fq2 = issue_loads(c2{}, bs0, as2, kt2);
     // step i: LDS stage i & 1, A set i & 3; writes out staging set (i + 1) & 1 and refills it, and A set (i + 3) & 3, with step i + 3
     const int n4 = n & ~3;
