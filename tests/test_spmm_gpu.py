@@ -799,6 +799,54 @@ def test_a_constant_b_prepared_once_gives_the_bits_of_the_plain_product(dtype):
         d.spmm_prepared(Bp, C2)
 
 
+@pytest.mark.parametrize("rows_per_tile", [32, 19, 5])
+def test_fp32_k_compaction_every_count_of_non_empty_columns(monkeypatch, rows_per_tile):
+    """the fp32 no-barrier kernel multiplies only the non-empty columns of a step's 32 x 32 slice of A (vbs_plan.cpp: compacted fragment image, position table,
+    MFMA pairs per step): blocks with exactly 1, 2, 3, ..., 32 non-empty columns in scattered positions, full and short tiles, a partial last block column --
+    every element against the oracle, and bit-identical to the LDS-staged kernel's... tolerance class (same products, another order of the k sum)."""
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_PATH", "stream")                           # the no-barrier kernel, not whichever path the autotune likes on this small case
+    w, n = 32, 128
+    rng = np.random.Generator(np.random.PCG64(77 + rows_per_tile))
+    n_tiles, n_bcols = 40, 33
+    cols = n_bcols * w - 11                                               # cols % w != 0: the last block column is partial (B_tail steps)
+    rr, cc = [], []
+    for t in range(n_tiles):
+        for jb in rng.choice(n_bcols, size=6, replace=False):
+            nk = int(rng.integers(1, 33)) if jb != n_bcols - 1 else int(rng.integers(1, w - 11 + 1))
+            width = w if jb != n_bcols - 1 else w - 11
+            ks = rng.choice(width, size=nk, replace=False)              # exactly nk non-empty columns, anywhere in the block
+            for k in ks:
+                rws = rng.choice(rows_per_tile, size=int(rng.integers(1, rows_per_tile + 1)), replace=False)
+                rr.append(t * rows_per_tile + rws)
+                cc.append(np.full(len(rws), jb * w + k))
+    r, c = np.concatenate(rr), np.concatenate(cc)
+    m = sa.gen._csr_from_coo(n_tiles * rows_per_tile, cols, r, c, rng.uniform(-1, 1, len(r)).astype(np.float32))
+    g = np.arange(m.rows) // rows_per_tile
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    nk_hist = set()
+    off = 0
+    for ib in range(v.block_rows):
+        h = int(v.row_part[ib + 1] - v.row_part[ib])
+        for _ in range(int(v.nzcount[ib])):
+            nk_hist.add(int((v.mab[off:off + h * w].reshape(w, h) != 0).any(axis=1).sum()))
+            off += h * w
+    assert len(nk_hist) >= 20, sorted(nk_hist)                          # the case really covers the range of column counts
+    B = sa.gen.dense_rhs(v.cols, n, seed=9)
+    Co = _oracle_c(v, B, n)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+    d = v.to_device(0)
+    info = d.info()
+    for acc in (False, True):
+        C0 = sa.gen.dense_rhs(v.rows, n, seed=12) if acc else np.full(v.rows * n, 5.0, np.float32)
+        Ct = torch.from_numpy(C0.copy()).cuda()
+        d.spmm(torch.from_numpy(B).cuda(), Ct, n, accumulate=acc)
+        torch.cuda.synchronize()
+        _check(Ct.cpu().numpy(), Co + (C0 if acc else 0.0), bound + (np.abs(C0) if acc else 0.0), "k-compaction, %d rows per tile, accumulate %s" % (rows_per_tile, acc))
+    if info["sparse_rows"] == 0:
+        assert d.info()["last_path"] == 1, "the stream kernels were meant to run"
+
+
 def test_small_matrices_whose_tiles_are_not_worth_their_launches_go_to_the_sparse_rows(monkeypatch):
     """every launch of a product costs 5-10 us whatever it does: a small matrix whose tiles hold fewer nonzeros than their steps + three launches are worth is
     multiplied by the sparse-row kernels alone (one launch chain instead of two); a small DENSE matrix keeps its tiles.  Same product either way."""
