@@ -28,8 +28,11 @@ namespace {
 // CSTAGE (column-major C, tiles of arbitrary height): finished tiles are parked in the C ring (vbs_kernel_common.hpp, CRing) and stored as aligned blocks.
 // TAIL = false: no block column hangs over the last row of B (cols % w == 0, B_tail is never read): the choice between B and B_tail -- a dozen scalar
 // instructions per step -- folds away (see vbs_spmm_h16_direct_kernel).
+#ifndef SPARTA_DIRECT_WAVES
+#define SPARTA_DIRECT_WAVES 2      /* workgroups per CU the register budget allows (developer builds: 3 with SPARTA_WORKERS_PER_CU=3) */
+#endif
 template <bool CSTAGE, bool TAIL = true>
-__global__ __launch_bounds__(kThreads, 2) void vbs_spmm_f32_direct_kernel(const StreamParams p) {
+__global__ __launch_bounds__(kThreads, SPARTA_DIRECT_WAVES) void vbs_spmm_f32_direct_kernel(const StreamParams p) {
     constexpr int TN = kTN, LDBW = 36;                  // Bs[column][k], 32 k + 4 padding: conflict-free ds_read_b128 / ds_write_b128
     constexpr int WSTAGE = 32 * LDBW;                   // floats per wave and stage
     __shared__ __attribute__((aligned(16))) float lds[4 * 2 * WSTAGE + (CSTAGE ? 4 * kCRingFloats : 0)];
