@@ -312,7 +312,7 @@ def main():
             wl_name = "R-MAT 2^%d (a,b,c = 0.57,0.19,0.19; 10 edges per row, symmetrised: %d^2, %d nnz)" % (args.rmat_scale, m.rows, m.nztot())
     elif not distributed:
         m = sa.gen.cant_like(seed=2)
-        wl_name = "cant-like FEM 9x9x257 mesh x 3 dof (62451^2, %d nnz)" % m.nztot()
+        wl_name = "cant-like FEM 9x9x257 mesh x 3 dof (62451^2, %d nnz; a synthetic STAND-IN for SuiteSparse cant, which cannot be fetched here)" % m.nztot()
     else:
         m, n_local, shard_rows = sa.gen.fem3d_slab(9, 9, 257, rank, world, dof=3, pad_to=w, seed=2)
         wl_name = None
