@@ -710,7 +710,7 @@ def main():
     if h16 and dom != "sparse":
         # 16-bit storage: the MFMAs take 1/8 (fp16 / bf16 dense peak ~2.5 PFLOP/s) of the fp32 time while the bytes only halve:
         # the kernel is bound by memory traffic.  Algorithmic bytes: packed 16-bit A (read once) + 16-bit B (once) + fp32 C.
-        bytes16 = float(info["a_bytes"]) + 2.0 * ldb * N + 4.0 * rows_c * N
+        bytes16 = 2.0 * float(info["nztot"]) + 2.0 * ldb * N + 4.0 * rows_c * N      # (the stored blocks, 2 bytes per element: padding and the unfetched zero halves of pair tiles are not algorithmic)
         gbs = bytes16 / (kernel_ms_total * 1e-3) / 1e9 if kernel_ms_total > 0 else 0.0
         roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                          "kernel": ("vbs_spmm_h16_stream_kernel" if os.environ.get("SPARTA_H16_PATH", "a")[0] == "l" else "vbs_spmm_h16_direct_kernel"),

@@ -438,12 +438,14 @@ __global__ __launch_bounds__(kThreads, (MI2 && WC == 64) ? 1 : 2) void vbs_spmm_
 #pragma unroll
                 for (int q = 0; q < NK; q++) rb.b[c * NK + q] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, gs * c + qs * q, 0);
         }
-        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A16 + g_aoff), 0, 0x7ffffff0, 0x00020000);
+        // (pair tiles, vbs_plan.cpp: a half of the slice whose block-row has no block in this column is zeros -- a descriptor of zero records returns them without a fetch)
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A16 + g_aoff), 0, (MI2 && (flags & STEP_LO_ABSENT)) ? 0 : 0x7ffffff0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A16 + g_aoff), 0, (MI2 && (flags & STEP_HI_ABSENT)) ? 0 : 0x7ffffff0, 0x00020000);
         if (!(SPARTA_H16_PROBE & 2) && !((SPARTA_H16_PROBE & 16) && wave != 0) && !((SPARTA_H16_PROBE & 32) && (wave & 1))) {   // 16: only wave 0 loads A; 32: waves 0 and 2
 #pragma unroll
             for (int mi = 0; mi < NA; mi++)
 #pragma unroll
-                for (int q = 0; q < NK; q++) ra.a[mi][q] = __builtin_amdgcn_raw_buffer_load_b128(rA, voffA, (uint32_t)((2 * q * TM + 32 * mi) * 16), 0);
+                for (int q = 0; q < NK; q++) ra.a[mi][q] = __builtin_amdgcn_raw_buffer_load_b128(mi == 0 ? rA : rA1, voffA, (uint32_t)((2 * q * TM + 32 * mi) * 16), 0);
         }
         return flags;
     };
@@ -776,18 +778,24 @@ void launch_h16_slab256(bool bf16, dim3 grid, hipStream_t st, const StreamParams
     }
 }
 
-// 64-row tiles of 64-wide blocks over 256-column slabs, four accumulators per wave (QUAD): grid = (workers, n_cols / 256)
-void launch_h16_quad(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
+// 64-row tiles over 256-column slabs, four accumulators per wave (QUAD): grid = (workers, n_cols / 256).  KP = 64: 64-wide blocks (the hub of a power-law matrix);
+// KP = 32: the pair tiles of 32-wide blocks (vbs_plan.cpp)
+template <int KP>
+static void launch_h16_quad_t(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
     if (gathered) {                                      // (a gathered B has no partial last block column: cols = n_shards * shard_rows, shard_rows % w == 0)
-        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<64, true, true, true, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
-        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<64, true, false, true, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, true, true, true, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, true, false, true, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
     } else if (sp.B_tail != nullptr) {
-        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<64, true, true, false, false, false, true, 64, true>), grid, dim3(kThreads), 0, st, sp);
-        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<64, true, false, false, false, false, true, 64, true>), grid, dim3(kThreads), 0, st, sp);
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, true, true, false, false, false, true, 64, true>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, true, false, false, false, false, true, 64, true>), grid, dim3(kThreads), 0, st, sp);
     } else {
-        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<64, true, true, false, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
-        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<64, true, false, false, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
+        if (bf16) hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, true, true, false, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
+        else hipLaunchKernelGGL((vbs_spmm_h16_direct_kernel<KP, true, false, false, false, false, false, 64, true>), grid, dim3(kThreads), 0, st, sp);
     }
+}
+void launch_h16_quad(int kp, bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp) {
+    if (kp == 64) launch_h16_quad_t<64>(bf16, gathered, grid, st, sp);
+    else launch_h16_quad_t<32>(bf16, gathered, grid, st, sp);
 }
 
 void launch_tail_copy_h16(hipStream_t st, const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N, uint16_t* B_tail) {

@@ -884,11 +884,11 @@ int spmm16_core(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
                                  [&] { const char* e = std::getenv("SPARTA_H16_SLAB256"); const int m = e ? atoi(e) : 1; return m == 2 || (m == 1 && !A->wide16); }();
             // 64-row tiles of 64-wide blocks (the dense hub of a power-law matrix under the fixed 64 x 64 grid), N % 256 == 0: four accumulators per wave over
             // 256-column slabs -- A read once per 256 columns, every B fragment used twice (k_h16.hip, QUAD); split tiles allowed.  SPARTA_H16_QUAD=0: off.
-            const bool quad = ty == 1 && A->kp16 == 64 && n_cols % 256 == 0 && h16_uses_direct_kernel(64, true) && ldb16 * 64 * 2 < ((int64_t)1 << 31) - 65536 &&
+            const bool quad = ty == 1 && n_cols % 256 == 0 && h16_uses_direct_kernel(A->kp16, true) && ldb16 * 64 * 2 < ((int64_t)1 << 31) - 65536 &&
                               [] { const char* e = std::getenv("SPARTA_H16_QUAD"); return !e || atoi(e) != 0; }();
             if (quad) {
                 sp.sub_ranges = 0;
-                launch_h16_quad(bf16, gth, dim3((unsigned)A->n_workers, (unsigned)(n_cols / 256)), st, sp);
+                launch_h16_quad(A->kp16, bf16, gth, dim3((unsigned)A->n_workers, (unsigned)(n_cols / 256)), st, sp);
             } else if (slab256) {
                 sp.sub_ranges = A->wide16 ? 1 : 0;
                 launch_h16_slab256(bf16, dim3((unsigned)A->n_workers, (unsigned)(n_cols / 256)), st, sp);

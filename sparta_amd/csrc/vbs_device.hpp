@@ -66,6 +66,8 @@ constexpr int SK_TM = 64;                 // max rows of a tile
 constexpr int32_t STEP_FIRST = 1 << 16;   // first step of a (segment of a) tile: accumulators start at zero
 constexpr int32_t STEP_LAST = 1 << 17;    // last step of a (segment of a) tile: run the epilogue
 constexpr int32_t STEP_SPLIT = 1 << 18;   // the tile is shared with another worker: epilogue goes to the workspace
+constexpr int32_t STEP_LO_ABSENT = 1 << 27;  // 16-bit pair tiles (two vertically adjacent 32-row block-rows walked as ONE 64-row tile over the union of their block
+constexpr int32_t STEP_HI_ABSENT = 1 << 28;  // columns, vbs_plan.cpp): the lower / upper block-row has no block in this step's column -- that half of the slice is zeros and is not fetched
 constexpr int32_t STEP_KPAIRS_SHIFT = 24;  // bits 24..26: (MFMA pairs this step needs) - 1, fp32 one-tile plans with a fragment image (k-compaction: the
                                            // non-empty columns of the step's slice of A come first, vbs_plan.cpp); read by vbs_spmm_f32_direct_kernel only
 constexpr int64_t kAFragSlice = 1040;      // floats per step of the fragment image: 16 (the step's LDS position table: 32 bytes + padding) + 1024 (fragments)
@@ -250,7 +252,7 @@ void launch_zero_rows(dim3 grid, hipStream_t st, float* C, int64_t ldc, int c_ro
 void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, bool c_stage, bool wide, dim3 grid, hipStream_t st, const StreamParams& sp);
 void launch_h16_slab256(bool bf16, dim3 grid, hipStream_t st, const StreamParams& sp);   // one-tile plans of 32-wide blocks, 256-column slabs (grid.y = N / 256), no split tile
 bool h16_uses_direct_kernel(int kp, bool mi2);
-void launch_h16_quad(bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
+void launch_h16_quad(int kp, bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
 void launch_tail_copy_h16(hipStream_t st, const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N, uint16_t* B_tail);
 void launch_convert_h16(bool bf16, hipStream_t st, const float* src, int64_t ld_in, int64_t rows, int64_t n_cols, uint16_t* dst, int64_t ld_out);
 // C[:, col0 + j] (+)= Ct[:, j] for j < n_t: the column tail of a 16-bit product (Ct column-major, ld = rows)

@@ -78,6 +78,30 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
         if (const char* e = std::getenv("SPARTA_STREAM_ALIGN")) align_mode = atoi(e) ? 1 : 0;
         if ((int64_t)cols > INT32_MAX)
             return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: matrix too large for 32-bit step indexing");
+        // ---- 16-bit handles of 32-wide blocks: PAIR TILES.  Two vertically adjacent block-rows (the upper one exactly 32 rows tall) are walked as ONE 64-row tile
+        // over the union of their block columns: the B panel of a step feeds both halves (a third fewer steps and panels on a FEM matrix), and a block one of them
+        // lacks is a half of the A slice that is stored as zeros and NOT FETCHED (the kernel gives that half a descriptor of zero records: loads return zeros
+        // without touching memory).  Round 2 measured the merge with the zero halves fetched (+29 % bytes of A: 23.0 -> 22.5 us) and dropped it.
+        // SPARTA_H16_PAIR=0 switches it off.
+        struct PairSrc { int64_t a_off_hi; int32_t h_hi, rows_hi, lo_present, hi_present; };
+        std::vector<PairSrc> pair_tab(1);                                 // [0] unused: StepRec::pad carries the index while the plan is built
+        std::vector<uint8_t> pair_role((size_t)(br1 - br0), 0);          // 1 = first of a pair, 2 = second
+        std::vector<int64_t> jo_of((size_t)(br1 - br0) + 1, 0), mo_of((size_t)(br1 - br0) + 1, 0);
+        for (int64_t ib = br0; ib < br1; ib++) {
+            jo_of[(size_t)(ib - br0) + 1] = jo_of[(size_t)(ib - br0)] + nzcount[ib];
+            mo_of[(size_t)(ib - br0) + 1] = mo_of[(size_t)(ib - br0)] + nzcount[ib] * (row_part[ib + 1] - row_part[ib]) * w;
+        }
+        const bool pair_on = h16 && kp == 32 && [] { const char* e = std::getenv("SPARTA_H16_PAIR"); return !e || atoi(e) != 0; }();
+        if (pair_on) {
+            for (int64_t ib = br0; ib + 1 < br1; ib++) {
+                const int64_t h1 = row_part[ib + 1] - row_part[ib], h2 = row_part[ib + 2] - row_part[ib + 1];
+                const bool s1 = in.skip && in.skip[ib - br0], s2 = in.skip && in.skip[ib + 1 - br0];
+                if (!s1 && !s2 && h1 == 32 && h2 >= 1 && h2 <= 32 && nzcount[ib] > 0 && nzcount[ib + 1] > 0) {
+                    pair_role[(size_t)(ib - br0)] = 1; pair_role[(size_t)(ib + 1 - br0)] = 2;
+                    ib++;
+                }
+            }
+        }
         for (int ty = 0; ty < 2; ty++) {
             std::vector<StepRec>& st = steps[ty];
             struct TileSpan { int64_t first, last; int32_t c_row, mt; };     // step range of a tile
@@ -101,6 +125,41 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
 #endif
                     const bool zero_range = nb == 0 && !skipped && h >= kZeroRangeRows;     // one streamed fill instead of h / 64 fix-up tiles
                     if (zero_range && ty == 0) P.zero_ranges.emplace_back(row_part[ib] - row0, h);
+                    const uint8_t role = pair_role[(size_t)(ib - br0)];
+                    if (role == 1 && ty == 1) {                              // the pair (ib, ib + 1) as one 64-row tile
+                        const int64_t h2 = row_part[ib + 2] - row_part[ib + 1], nb2 = nzcount[ib + 1];
+                        const int64_t jo_b = jo_of[(size_t)(ib + 1 - br0)], mo_b = mo_of[(size_t)(ib + 1 - br0)];
+                        const int32_t c_row = (int32_t)(row_part[ib] - row0), mt = (int32_t)(32 + h2);
+                        TileSpan sp{(int64_t)st.size(), 0, c_row, mt};
+                        int64_t a = 0, b2 = 0;
+                        while (a < nb || b2 < nb2) {
+                            const int64_t ja = a < nb ? jab[jab_lo + jo2 + a] : INT64_MAX, jb2 = b2 < nb2 ? jab[jab_lo + jo_b + b2] : INT64_MAX;
+                            const int64_t jb = std::min(ja, jb2);
+                            const bool lo = ja == jb, hi = jb2 == jb;
+                            for (int64_t ks = 0; ks < w; ks += kp) {
+                                StepRec r;
+                                r.a_off = lo ? mo2 + (a * w + ks) * h : 0;
+                                r.b_row = (int32_t)(jb * w + ks);
+                                r.h = (int32_t)h;
+                                r.c_row = c_row;
+                                r.mt_flags = mt | (lo ? 0 : STEP_LO_ABSENT) | (hi ? 0 : STEP_HI_ABSENT);
+                                if ((jb + 1) * w > cols) { r.mt_flags |= STEP_TAIL; r.b_row = (int32_t)ks; }
+                                r.slot = -1;
+                                r.pad = (int32_t)pair_tab.size();
+                                pair_tab.push_back(PairSrc{hi ? mo_b + (b2 * w + ks) * h2 : 0, (int32_t)h2, (int32_t)h2, lo ? 1 : 0, hi ? 1 : 0});
+                                cum.push_back(total_cost);
+                                total_cost += c2;
+                                st.push_back(r);
+                            }
+                            a += lo; b2 += hi;
+                        }
+                        total_cost += ct;
+                        sp.last = (int64_t)st.size() - 1;
+                        st[(size_t)sp.first].mt_flags |= STEP_FIRST;
+                        st[(size_t)sp.last].mt_flags |= STEP_LAST;
+                        spans.push_back(sp);
+                    }
+                    if (role != 0) { jo2 += nb; mo2 += nb * h * w; continue; }   // block-rows of a pair: no tiles of their own
                     for (int64_t r0 = 0; r0 < h && !skipped && !zero_range; r0 += SK_TM) {
                         const int32_t mt = (int32_t)std::min<int64_t>(SK_TM, h - r0);
                         if ((mt > 32 ? 1 : 0) != ty) continue;
@@ -326,9 +385,26 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                 sparta::parallel_for_dynamic(S, 256, [&](int64_t lo, int64_t hi, int) {
                     for (int64_t q = lo; q < hi; q++) {
                         StepRec& r = st[(size_t)q];
+                        uint16_t* dst = all + (size_t)q * slice;
+                        if (r.pad != 0) {                                    // pair tile: rows 0..31 from the upper block-row's block, rows 32.. from the lower one's (either may be absent: zeros)
+                            const PairSrc& ps = pair_tab[(size_t)r.pad];
+                            for (int64_t kk = 0; kk < kp; kk++) {
+                                uint16_t* d2 = dst + (kk >> 3) * tms * 8 + (kk & 7);
+                                if (ps.lo_present) {
+                                    const float* colp = mab + mab_lo + r.a_off + kk * (int64_t)r.h;
+                                    for (int64_t rr = 0; rr < 32; rr++) d2[rr * 8] = to_h16(colp[rr], bf);
+                                }
+                                if (ps.hi_present) {
+                                    const float* colp = mab + mab_lo + ps.a_off_hi + kk * (int64_t)ps.h_hi;
+                                    for (int64_t rr = 0; rr < ps.rows_hi; rr++) d2[(32 + rr) * 8] = to_h16(colp[rr], bf);
+                                }
+                            }
+                            r.pad = 0;
+                            r.a_off = (int64_t)(base + (size_t)q * slice);
+                            continue;
+                        }
                         const float* blk = mab + mab_lo + r.a_off;
                         const int64_t hh = r.h, mt = r.mt_flags & 0xffff;
-                        uint16_t* dst = all + (size_t)q * slice;
                         for (int64_t kk = 0; kk < kp; kk++) {
                             const float* colp = blk + kk * hh;
                             uint16_t* d2 = dst + (kk >> 3) * tms * 8 + (kk & 7);
