@@ -91,7 +91,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             jo_of[(size_t)(ib - br0) + 1] = jo_of[(size_t)(ib - br0)] + nzcount[ib];
             mo_of[(size_t)(ib - br0) + 1] = mo_of[(size_t)(ib - br0)] + nzcount[ib] * (row_part[ib + 1] - row_part[ib]) * w;
         }
-        const bool pair_on = h16 && kp == 32 && [] { const char* e = std::getenv("SPARTA_H16_PAIR"); return !e || atoi(e) != 0; }();
+        const bool pair_on = h16 && [] { const char* e = std::getenv("SPARTA_H16_PAIR"); return !e || atoi(e) != 0; }();
         if (pair_on) {
             for (int64_t ib = br0; ib + 1 < br1; ib++) {
                 const int64_t h1 = row_part[ib + 1] - row_part[ib], h2 = row_part[ib + 2] - row_part[ib + 1];
