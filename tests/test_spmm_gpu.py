@@ -874,6 +874,64 @@ def test_small_matrices_whose_tiles_are_not_worth_their_launches_go_to_the_spars
         d.close()
 
 
+@pytest.mark.parametrize("align", ["whole-tiles", "split"])
+@pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("w,h2,n", [(32, 32, 128), (32, 7, 128), (32, 1, 256), (64, 32, 256), (64, 19, 128)])
+def test_16bit_pair_tiles_against_the_oracle_and_the_unpaired_plan(monkeypatch, _sparse_row_mode, align, dtype, w, h2, n):
+    """pair tiles (vbs_plan.cpp): block-rows of 32 rows followed by block-rows of h2 rows are walked in pairs as 64-row tiles over the union of their block columns;
+    a block only one of the two has = a zero half that is not fetched.  Blocks present in the upper row only, the lower only, both; a partial last block column;
+    whole-tile and split plans; both layouts of C, accumulate, gathered B -- against the oracle on the rounded inputs and against the plan without pairs."""
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_STREAM_ALIGN", "1" if align == "whole-tiles" else "0")
+    rng = np.random.Generator(np.random.PCG64(w + h2 + n))
+    n_pairs, n_bcols = (24 if align == "whole-tiles" else 3), (40 if align == "whole-tiles" else 150)
+    cols = n_bcols * w - 5
+    rows = n_pairs * (32 + h2) + 13                                       # + a last block-row that finds no partner
+    bounds = np.concatenate([[0], np.cumsum(np.tile([32, h2], n_pairs)), [rows]])
+    g = np.repeat(np.arange(len(bounds) - 1), np.diff(bounds))
+    rr, cc = [], []
+    for ib in range(len(bounds) - 1):
+        h = int(bounds[ib + 1] - bounds[ib])
+        for jb in np.flatnonzero(rng.random(n_bcols) < 0.45):               # ~45 % of the block columns per block-row: every presence pattern occurs
+            width = min(w, cols - jb * w)
+            cnt = int(h * width * 0.4) + 1
+            flat = rng.choice(h * width, size=min(cnt, h * width), replace=False)
+            rr.append(bounds[ib] + flat // width)
+            cc.append(jb * w + flat % width)
+    r, c = np.concatenate(rr), np.concatenate(cc)
+    m = sa.gen._csr_from_coo(rows, cols, r, c, rng.uniform(-1, 1, len(r)).astype(np.float32))
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=5)
+    mab_r, B_r = _round16(v.mab, dtype), _round16(B, dtype)
+    Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n, None)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n)
+    tdt = torch.float16 if dtype == sa.F16 else torch.bfloat16
+    ldb = (v.cols + 7) // 8 * 8
+    Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    Bt.view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
+    outs = {}
+    for pair in ("1", "0"):
+        monkeypatch.setenv("SPARTA_H16_PAIR", pair)
+        d = v.to_device(0, dtype=dtype)
+        info = d.info()
+        if _sparse_row_mode == "mfma-only":
+            assert (info["stream_steps"] < sum(int(x) for x in v.nzcount) * (w // (64 if w % 64 == 0 else 32))) == (pair == "1"), "pairs share steps"
+        if align == "split":
+            assert info["split_tiles"] > 0
+        res = []
+        for cl, acc in ((sa.COL_MAJOR, False), (sa.ROW_MAJOR, False), (sa.COL_MAJOR, True)):
+            Ct = torch.full((v.rows * n,), 0.5, dtype=torch.float32, device="cuda")
+            d.spmm(Bt, Ct, n, ldb=ldb, c_layout=cl, accumulate=acc)
+            torch.cuda.synchronize()
+            res.append(Ct.cpu().numpy())
+        outs[pair] = res
+        d.close()
+    for res in outs.values():
+        _check(res[0], Co, bound, "pair tiles, column-major C")
+        _check(np.ascontiguousarray(res[1].reshape(v.rows, n).T).reshape(-1), Co, bound, "pair tiles, row-major C")
+        _check(res[2], Co + 0.5, bound + 0.5, "pair tiles, accumulate")
+
+
 def test_16bit_handles_reject_what_they_cannot_do():
     torch = _torch()
     m = sa.gen.uniform_random(256, 256, 3000, seed=2)
