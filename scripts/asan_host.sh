@@ -23,7 +23,9 @@ LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=dete
 # the hybrid builder of sparta_vbs_create_from_csr (per-block tile / sparse-row split) runs on the host before the first device call: without a GPU the
 # call ends in SPARTA_ERR_NO_DEVICE -- after the builder has done all its work under the sanitizers
 LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 SPARTA_AMD_LIB="$OUT/libsparta_amd_asan.so" \
-  SPARTA_SPARSE_MIN_STEPS=0 python - <<'PY' 2>&1 | grep -E "runtime error|AddressSanitizer|SUMMARY|builder" || true
+  SPARTA_SPARSE_MIN_STEPS=0 SPARTA_PLAN_DEBUG=1 SPARTA_LAUNCH_NNZ=0 python - <<'PY' 2>&1 | grep -E "runtime error|AddressSanitizer|SUMMARY|builder" || true
+# (SPARTA_PLAN_DEBUG: without a GPU create goes on through the tile lists and the stream plans -- pair tiles, the k-compacted fragment image, the 16-bit slices --
+#  before it fails with NO_DEVICE)
 import numpy as np, sparta_amd as sa
 for kb in ("1", "8", "60", "1e30"):
     import os
@@ -31,10 +33,23 @@ for kb in ("1", "8", "60", "1e30"):
     for seed in range(3):
         m = sa.gen.rmat(12, 40000, seed=seed, symmetrize=True, pattern_only=False)
         for g, rbs, ff in ((sa.BlockingEngine(tau=0.4, col_block_size=32, blocking_algo=7).GetGrouping(m), 0, False), (np.arange(m.rows) // 64, 64, True)):
+            for dt in (sa.F32, sa.F16, sa.BF16):
+                try:
+                    sa.DeviceVBS.from_csr(m, g, 32, rbs, ff, device=0, dtype=dt)
+                except sa.SpartaError as e:
+                    pass
+# well-filled matrices: every block a tile (plans of 32-row and 64-row tiles, pair tiles of the 16-bit handles, split and whole-tile cuts)
+for w, hgt in ((32, 32), (32, 20), (64, 64), (64, 32)):
+    m = sa.gen.fem3d(5, 5, 12, 3, seed=3)
+    g = np.arange(m.rows) // hgt
+    for dt in (sa.F32, sa.F16):
+        for al in ("0", "1"):
+            os.environ["SPARTA_STREAM_ALIGN"] = al
             try:
-                sa.DeviceVBS.from_csr(m, g, 32, rbs, ff, device=0)
-            except sa.SpartaError as e:
+                sa.VBR().fill_from_CSR_inplace(m, g, w).to_device(0, dtype=dt)
+            except sa.SpartaError:
                 pass
+os.environ.pop("SPARTA_STREAM_ALIGN", None)
 print("hybrid builder exercised")
 PY
 
