@@ -327,6 +327,12 @@ __global__ __launch_bounds__(kThreads, 2) void vbs_spmm_h16_stream_kernel(const 
 // Loads run three steps ahead (A: four register sets, B: two staging sets + two LDS stages); step records: one window VGPR,
 // constant-lane v_readlane.  Same plans, accumulator layout, epilogue and fix-up as the other stream kernels.
 // =====================================================================================================
+#ifndef SPARTA_H16_ACCA
+#define SPARTA_H16_ACCA 1     // four-accumulator kernels: accumulators pinned to AGPRs (inline-assembly MFMA)
+#endif
+#ifndef SPARTA_H16_ILV
+#define SPARTA_H16_ILV 1      /* two-tile (pair / hub) instantiations: the step's LDS writes and loads between its MFMAs, held there by scheduling barriers */
+#endif
 #ifndef SPARTA_H16_PROBE
 #define SPARTA_H16_PROBE 0        /* developer probes, TIMING ONLY (results wrong): 1 no B loads, 2 no A loads, 4 no epilogue, 8 no LDS round trip, 64 every tile stores to the first rows of C, 128 every step reads the first slice of A, 256 every step reads the first rows of B, 512 one store per tile instead of 16 (non-temporal path) */
 #endif
@@ -460,9 +466,23 @@ __global__ __launch_bounds__(kThreads, (MI2 && WC == 64) ? 1 : 2) void vbs_spmm_
     f32x16 acc0, acc1, acc2, acc3;                        // QUAD: acc0 / acc1 = rows 0..31 / 32..63 of the first 32 columns, acc2 / acc3 of the second
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; acc2[r] = 0.0f; acc3[r] = 0.0f; }
+    if constexpr (SPARTA_H16_ACCA && QUAD) asm volatile("" : "+a"(acc0), "+a"(acc1), "+a"(acc2), "+a"(acc3));
+    // The four-accumulator instantiations run one work-group per CU (up to 512 registers a lane: 256 VGPRs + 256 AGPRs).  Left to itself the register allocator keeps the
+    // accumulators in VGPRs between steps and copies all of them into AGPRs and back around every step's MFMAs (16 x NA x NG v_accvgpr_write + as many reads per
+    // step).  ACC_A pins them: the MFMA is issued as inline assembly whose accumulator operand is constrained to the AGPRs ("+a"), so the accumulators never leave
+    // them until the tile's epilogue.  The hazard recogniser does not look inside inline assembly: the wait states an MFMA result needs before a VALU read
+    // (v_accvgpr_read in the epilogue) and a VALU write needs before an MFMA read (the zeroing) are written out as s_nop below.
+    constexpr bool ACC_A = SPARTA_H16_ACCA && QUAD;
     auto mfma = [&](const u32x4& bf, const u32x4& af, f32x16& acc) __attribute__((always_inline)) {
-        if constexpr (BF16) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf), __builtin_bit_cast(bf16x8, af), acc, 0, 0, 0);
-        else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf), __builtin_bit_cast(f16x8, af), acc, 0, 0, 0);
+        if constexpr (ACC_A) {
+            // (s_nop 1: a fragment the allocator parked in AGPRs comes back through v_accvgpr_read right in front of the MFMA: a VALU write needs two wait states
+            // before an MFMA reads the register)
+            if constexpr (BF16) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(bf), "v"(af));
+            else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(bf), "v"(af));
+        } else {
+            if constexpr (BF16) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf), __builtin_bit_cast(bf16x8, af), acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf), __builtin_bit_cast(f16x8, af), acc, 0, 0, 0);
+        }
     };
 
     int32_t fq0 = 0, fq1 = 0, fq2 = 0, fq_new = 0;
@@ -480,17 +500,63 @@ __global__ __launch_bounds__(kThreads, (MI2 && WC == 64) ? 1 : 2) void vbs_spmm_
             for (int c = 0; c < NG; c++)
 #pragma unroll
                 for (int q = 0; q < NK; q++) fb[c * NK + q] = *reinterpret_cast<const u32x4*>(ldsw + lrB + (PAR * NG + c) * WSTAGE + q * 32);
-            write_b(std::integral_constant<int, 1 - PAR>{}, wb);         // W(i + 1)
+            if constexpr (!(SPARTA_H16_ILV && MI2 && !DEEP && !TAIL)) write_b(std::integral_constant<int, 1 - PAR>{}, wb);         // W(i + 1)  (two-tile instantiations: between the MFMAs, below)
         }
+        constexpr bool ILV = SPARTA_H16_ILV && MI2 && !DEEP && !TAIL && !(SPARTA_H16_PROBE & 8);
+        if constexpr (!ILV) {
 #pragma unroll
-        for (int q = 0; q < NK; q++) {
-            mfma(fb[q], wa.a[0][q], acc0);
-            if constexpr (MI2) mfma(fb[q], wa.a[1][q], acc1);
-            if constexpr (WC == 64 && !MI2) mfma(fb[NK + q], wa.a[0][q], acc1);   // the wave's second 32 columns (acc1: free in the one-tile kernel)
-            if constexpr (QUAD) { mfma(fb[NK + q], wa.a[0][q], acc2); mfma(fb[NK + q], wa.a[1][q], acc3); }
+            for (int q = 0; q < NK; q++) {
+                mfma(fb[q], wa.a[0][q], acc0);
+                if constexpr (MI2) mfma(fb[q], wa.a[1][q], acc1);
+                if constexpr (WC == 64 && !MI2) mfma(fb[NK + q], wa.a[0][q], acc1);   // the wave's second 32 columns (acc1: free in the one-tile kernel)
+                if constexpr (QUAD) { mfma(fb[NK + q], wa.a[0][q], acc2); mfma(fb[NK + q], wa.a[1][q], acc3); }
+            }
+            fq_new = issue_loads(std::integral_constant<int, i + D>{}, nb, na);   // G(i + D)
+        } else {
+            // ONE wave per SIMD here: nothing but this wave's own instruction order overlaps its MFMAs with the rest of its step.  An MFMA occupies the pipe for 32
+            // cycles and takes four to issue: the instruction behind it in program order issues into the other 28.  So: MFMA, one LDS write of the next step's panel
+            // (W(i + 1)) or one or two loads of step i + D, MFMA, ... -- kept in that order by scheduling barriers (it is one basic block: the scheduler would
+            // cluster the MFMAs again).  TAIL = false instantiations only (no B_tail switch: no branch inside the step).
+            constexpr int NM = NK * NA * NG;                 // MFMAs of the step: 4 (pair tiles of 32-wide blocks), 8, 16 (hub tiles)
+            constexpr int NW = NG * NK, NLB = NG * NK, NLA = NA * NK;
+            const int32_t flags_n = field(i + D, F_FLAGS);
+            g_aoff += (int64_t)TM * KP;
+            if (SPARTA_H16_PROBE & 128) g_aoff = 0;
+            const int64_t gk0 = (SPARTA_H16_PROBE & 256) ? 0 : field(i + D, F_BROW);
+            const uint16_t* bptr = B16 + (GATHERED ? (int64_t)field(i + D, F_SHARD) * p.shard_stride : (int64_t)0) + gk0 + n0off;
+            const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(bptr), 0, 0x7ffffff0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A16 + g_aoff), 0, (flags_n & STEP_LO_ABSENT) ? 0 : 0x7ffffff0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A16 + g_aoff), 0, (flags_n & STEP_HI_ABSENT) ? 0 : 0x7ffffff0, 0x00020000);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, NM>([&](auto t_tag) __attribute__((always_inline)) {
+                constexpr int t = decltype(t_tag)::value;
+                constexpr int q = t / (NA * NG), c = (t / NA) % NG, mi = t % NA;       // k group, column group, row half
+                f32x16& acc = (c == 0) ? (mi == 0 ? acc0 : acc1) : (mi == 0 ? acc2 : acc3);
+                mfma(fb[c * NK + q], wa.a[mi][q], acc);
+                __builtin_amdgcn_sched_barrier(0);
+                // what goes behind MFMA t: first the NW writes of W(i + 1), then the loads of step i + D spread over the remaining MFMAs
+                constexpr int slots = NM;
+                constexpr int per_w = (NW + slots / 2 - 1) / (slots / 2);             // writes per slot in the first half
+                if constexpr (t < slots / 2) {
+#pragma unroll
+                    for (int x = t * per_w; x < (t + 1) * per_w && x < NW; x++)
+                        *reinterpret_cast<u32x4*>(ldsw + lwB + ((1 - PAR) * NG + x / NK) * WSTAGE + (x % NK) * CPI * RB) = wb.b[x];
+                } else {
+                    constexpr int h = t - slots / 2, nh = slots - slots / 2;
+                    constexpr int lb0 = h * NLB / nh, lb1 = (h + 1) * NLB / nh, la0 = h * NLA / nh, la1 = (h + 1) * NLA / nh;
+#pragma unroll
+                    for (int x = lb0; x < lb1; x++) nb.b[x] = __builtin_amdgcn_raw_buffer_load_b128(rB, vo_cur, gstepB * (x / NK) + qstepB * (x % NK), 0);
+#pragma unroll
+                    for (int x = la0; x < la1; x++) na.a[x / NK][x % NK] = __builtin_amdgcn_raw_buffer_load_b128((x / NK) == 0 ? rA : rA1, voffA, (uint32_t)((2 * (x % NK) * TM + 32 * (x / NK)) * 16), 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            fq_new = flags_n;
         }
-        fq_new = issue_loads(std::integral_constant<int, i + D>{}, nb, na);   // G(i + D)
         if ((flags & STEP_LAST) && !(SPARTA_H16_PROBE & 4)) {
+            // the last MFMA's 8 passes + 3 before its accumulator may be read.  The accumulators are operands of the statement: their reads below depend on it
+            // (without that the compiler hoists the v_accvgpr_reads common to the branches of the epilogue above it, right behind the last MFMA)
+            if constexpr (ACC_A) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc0), "+a"(acc1), "+a"(acc2), "+a"(acc3));
             if (flags & STEP_SPLIT) {
                 const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(ws + (int64_t)field(i, F_SLOT) * SK_SLOT_FLOATS, 0, SK_SLOT_FLOATS * 4, 0x00020000);
 #pragma unroll
@@ -553,6 +619,7 @@ __global__ __launch_bounds__(kThreads, (MI2 && WC == 64) ? 1 : 2) void vbs_spmm_
             }
 #pragma unroll
             for (int q = 0; q < 16; q++) { acc0[q] = 0.0f; acc1[q] = 0.0f; if constexpr (QUAD) { acc2[q] = 0.0f; acc3[q] = 0.0f; } }
+            if constexpr (ACC_A) asm volatile("s_nop 4" : "+a"(acc0), "+a"(acc1), "+a"(acc2), "+a"(acc3));
         }
     };
 
