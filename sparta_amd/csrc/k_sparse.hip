@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kThreads) void sparse_segments_kernel(SparseParams 
     sp_batch_load(p, sg.p0, sg.p0 + sg.cnt, lane, cl, vl);
     typename SpVec<VEC>::T acc = sparse_row_partial<VEC, BK>(p, sg.p0, sg.p0 + sg.cnt, n0, lane, cl, vl);
     if (VEC == 1 && n0 >= p.N) return;
-    *reinterpret_cast<typename SpVec<VEC>::T*>(part + (int64_t)slot * p.N + n0) = acc;
+    *reinterpret_cast<typename SpVec<VEC>::T*>(part + (int64_t)sg.pad * p.N + n0) = acc;
 }
 
 template <int VEC>

@@ -275,10 +275,46 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         // 57 us for 115 k nonzeros, 16 batches of gathers one after the other)
         kSpSeg = total < ((int64_t)1 << 20) ? 32 : (total < ((int64_t)4 << 20) ? 128 : (total < ((int64_t)16 << 20) ? 256 : 512));
     }
-    const int64_t kSpLong = 2 * kSpSeg;
+    int64_t kSpLong = 2 * kSpSeg;
+    // Column windows.  The rows of B a launch gathers at any one time should lie close together: on a power-law matrix with millions of columns the nonzeros of the
+    // rows in flight are spread over all of B (GBs), every gather is an HBM access (measured with FETCH_SIZE: 327 of 336 GB gathered came from HBM on a part of
+    // the 8 M-row R-MAT) and the kernels run at the random-row rate of HBM.  So the columns are cut into windows of win_cols columns (~64 MB of B at N = 256..512
+    // in 16 bits), a row of more than 128 nonzeros is cut into segments that also end where its columns cross into another window (once a segment holds sp_minseg
+    // nonzeros), and the segments are PROCESSED window by window -- all rows' segments of window 0, then of window 1, ... (workgroups start in the order of the
+    // list).  What is in flight then gathers from one window, which the Infinity Cache and the L2s hold: the same part 62.4 -> 35.1 ms, R-MAT 2^20 at 0.1 %
+    // (B = 512, bf16) 11.6 -> 8.1 ms per part.  A row's partial rows are still added in segment order (the sum does not depend on the processing order).
+    // SPARTA_SP_WINDOW_COLS: unset = automatic (on from 4 windows and 4 M nonzeros on this path), 0 = off, > 0 = the window width in columns;
+    // SPARTA_SP_LONG / SPARTA_SP_MINSEG: the row length above which a row is cut / the nonzeros a segment holds before a window boundary ends it.
+    const int64_t sp_total = sp_rowptr.empty() ? 0 : sp_rowptr.back();
+    int64_t win_w = (cols >= 4 * 65536 && sp_total >= ((int64_t)4 << 20)) ? 65536 : 0, sp_minseg = 64;
+    if (const char* e = std::getenv("SPARTA_SP_WINDOW_COLS")) win_w = std::max(0, atoi(e));
+    if (win_w > 0) kSpLong = 128;
+    if (const char* e = std::getenv("SPARTA_SP_LONG")) kSpLong = std::max(8, atoi(e));
+    if (const char* e = std::getenv("SPARTA_SP_MINSEG")) sp_minseg = std::max(1, atoi(e));
     for (size_t t = 0; t < sp_crow.size(); t++) {
         const int64_t p0 = sp_rowptr[t], n = sp_rowptr[t + 1] - p0;
         if (n <= kSpLong) { sp_list.push_back((int32_t)t); continue; }
+        if (win_w > 0) {
+            const int64_t L = std::max<int64_t>(kSpSeg, 512);
+            SpLongRec lr{(int32_t)t, (int32_t)sp_segs.size(), 0, 0};
+            int64_t o = 0;
+            while (o < n) {
+                // the segment [o, e): up to L nonzeros, ending early at the first window boundary behind its first sp_minseg nonzeros
+                int64_t e = std::min(n, o + L);
+                if (e - o > sp_minseg) {
+                    const int64_t wend = ((int64_t)sp_col[(size_t)(p0 + o + sp_minseg - 1)] / win_w + 1) * win_w;      // end of the window of the sp_minseg-th nonzero
+                    const int32_t* b = sp_col.data() + p0 + o + sp_minseg;
+                    const int32_t* bend = sp_col.data() + p0 + e;
+                    const int32_t* f = std::lower_bound(b, bend, (int32_t)std::min<int64_t>(wend, INT32_MAX));
+                    e = o + sp_minseg + (f - b);
+                }
+                sp_segs.push_back(SpSegRec{p0 + o, (int32_t)(e - o), 0});
+                lr.n_seg++;
+                o = e;
+            }
+            sp_long.push_back(lr);
+            continue;
+        }
         // a hub row's segments run in parallel, its partial rows are added one after the other: with segments of L nonzeros the chain is L / 16 gather
         // batches + n / L additions -- shortest near L = sqrt(1.6 n) (a batch ~ 10 additions), never below the size-dependent base, never above 512
         // (ia-wikiquote, 239 k nonzeros with rows of 10^4: 32-nonzero segments everywhere took 271 us, mostly the reduction of its hub rows)
@@ -288,6 +324,10 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         for (int64_t o = 0; o < n; o += L) { sp_segs.push_back(SpSegRec{p0 + o, (int32_t)std::min<int64_t>(L, n - o), 0}); lr.n_seg++; }
         sp_long.push_back(lr);
     }
+    // a segment's partial row lives at its index in row order (pad); the order of the list is the order the waves take them in
+    for (size_t i = 0; i < sp_segs.size(); i++) sp_segs[i].pad = (int32_t)i;
+    if (win_w > 0)
+        std::stable_sort(sp_segs.begin(), sp_segs.end(), [&](const SpSegRec& a, const SpSegRec& b) { return sp_col[(size_t)a.p0] / win_w < sp_col[(size_t)b.p0] / win_w; });
     n_sp_short = (int64_t)sp_list.size(); n_sp_long = (int64_t)sp_long.size();
     trace.lap("sparse rows (device form)");
     const uint8_t* skip = sparse_flag.empty() ? nullptr : sparse_flag.data();

@@ -1157,6 +1157,64 @@ def test_sparse_row_path_16bit(_sparse_row_mode, dtype, n):
     _check(Ch, Co, bound, "16-bit sparse rows, host pointers")
 
 
+@pytest.mark.parametrize("dtype", [sa.F32, sa.BF16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("win,long_,minseg", [(512, 16, 4), (2048, 64, 16), (64, 8, 1)])
+def test_sparse_rows_cut_at_column_windows_and_taken_window_by_window(monkeypatch, _sparse_row_mode, dtype, win, long_, minseg):
+    """SPARTA_SP_WINDOW_COLS (automatic on large power-law parts): the long rows' segments end at column-window boundaries and the segment list is processed
+    window by window; a row's partial rows are still added in its own segment order.  Same product as the oracle's (every layout, accumulate, host pointers)
+    and as the handle without windows up to the rounding of the regrouped sums; rows of every length around the cut (SPARTA_SP_LONG) and the segment minimum."""
+    if _sparse_row_mode != "with-sparse-rows":
+        pytest.skip("the sparse-row path is what is tested")
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_SP_WINDOW_COLS", str(win))
+    monkeypatch.setenv("SPARTA_SP_LONG", str(long_))
+    monkeypatch.setenv("SPARTA_SP_MINSEG", str(minseg))
+    rng = np.random.Generator(np.random.PCG64(win + long_))
+    rows, cols, w, n = 600, 9000 + 13, 32, 128
+    rr, cc = [], []
+    for i in range(rows - 10):                                # row lengths 0 .. ~300 around the cut, columns skewed towards the low ones (power law)
+        k = int(rng.integers(0, 4 * long_ + 40)) if i % 7 else 0
+        c = np.unique(np.minimum((cols * rng.random(k) ** 2.5).astype(np.int64), cols - 1))
+        rr.append(np.full(len(c), i)); cc.append(c)
+    rr.append(np.full(7000, rows - 10)); cc.append(rng.choice(cols, 7000, replace=False))      # a hub row through every window
+    r, c = np.concatenate(rr), np.concatenate(cc)
+    order = np.lexsort((c, r))
+    r, c = r[order], c[order]
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=rows))])
+    m = sa.CSR(rows, cols, rowptr, c.astype(np.int32), rng.uniform(-1, 1, len(c)).astype(np.float32))
+    g = np.arange(rows) // 32
+    B = sa.gen.dense_rhs(cols, n, seed=31)
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    f32 = dtype == sa.F32
+    mab_r, B_r = (v.mab, B) if f32 else (_round16(v.mab, dtype), _round16(B, dtype))
+    Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n, None)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n)
+    tdt = torch.float32 if f32 else torch.bfloat16
+    ldb = (cols + 7) // 8 * 8
+    Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    Bt.view(n, ldb)[:, :cols] = torch.from_numpy(B.reshape(n, cols)).cuda().to(tdt)
+    outs = []
+    for on in (True, False):
+        if not on:
+            monkeypatch.setenv("SPARTA_SP_WINDOW_COLS", "0")
+        d = sa.DeviceVBS.from_csr(m, g, w, 0, False, device=0, dtype=dtype)
+        assert d.sparse_info()["hub_rows"] > (10 if on else 0)
+        for cl in (sa.COL_MAJOR, sa.ROW_MAJOR):
+            for acc in (False, True):
+                C0 = sa.gen.dense_rhs(rows, n, seed=32)
+                Ct = torch.from_numpy(C0 if cl == sa.COL_MAJOR else np.ascontiguousarray(C0.reshape(n, rows).T).reshape(-1)).cuda()
+                d.spmm(Bt, Ct, n, ldb=ldb, c_layout=cl, accumulate=acc)
+                torch.cuda.synchronize()
+                got = Ct.cpu().numpy()
+                if cl == sa.ROW_MAJOR:
+                    got = np.ascontiguousarray(got.reshape(rows, n).T).reshape(-1)
+                _check(got, Co + (C0 if acc else 0), bound + (np.abs(C0) if acc else 0), "sparse rows, windows %s, c_layout %d acc %d" % (on, cl, acc))
+                if cl == sa.COL_MAJOR and not acc:
+                    outs.append(got)
+        d.close()
+    assert np.max(np.abs(outs[0] - outs[1])) <= 1e-5 * np.max(bound)
+
+
 @pytest.mark.parametrize("dtype", [sa.F32, sa.F16], ids=["f32", "f16"])
 @pytest.mark.parametrize("case", ["mixed", "rmat", "rmat-fixed"])
 def test_create_from_csr_gives_the_same_product(monkeypatch, _sparse_row_mode, case, dtype):
