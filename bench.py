@@ -692,7 +692,7 @@ def main():
         except Exception:
             pass
         # The matrix is carried by the sparse-row kernels: HBM-bound.  `frac` is the section-8(d) figure -- B counted ONCE (the whole
-        # step: MFMA part + sparse rows + B + C, all kernels of the step including the layout transposes) -- and `gather_frac` the
+        # step: MFMA part + sparse rows + B + C, all kernels of the step including the layout transposes) -- and `gather_gbs` the
         # bandwidth the gather kernels see: one N-wide row of B per nonzero (re-reads served by L2 / Infinity Cache included).
         bytes_gather = float(sp["nnz"]) * (N * esz + 8.0) + float(sp["rows"]) * N * 4.0
         gbs_gather = bytes_gather / (kernel_ms["sparse"] * 1e-3) / 1e9
@@ -702,11 +702,11 @@ def main():
                     "kernel": "sparse_rows_kernel + sparse_segments_kernel (+ b_to_row_major / sparse_c_scatter transposes)",
                     "kernel_ms": round(kernel_ms["sparse"], 5), "path": path, "kernels_ms": {k: round(v_, 5) for k, v_ in kernel_ms.items()},
                     "algorithmic_bytes": round(bytes_alg), "frac_b_once": round(gbs_once / PEAK_HBM_GBS, 4),
-                    "gather_bytes": round(bytes_gather), "gather_gbs": round(gbs_gather, 1), "gather_frac": round(gbs_gather / PEAK_HBM_GBS, 4),
+                    "gather_bytes": round(bytes_gather), "gather_gbs": round(gbs_gather, 1),
                     "mixed_roofline_frac": round(t_lb / (kernel_ms_total * 1e-3), 4) if kernel_ms_total > 0 else 0.0,
                     "sparse_rows": sp["rows"], "sparse_nnz": sp["nnz"], "hub_rows": sp["hub_rows"],
-                    "note": "frac = section-8(d) algorithmic bytes (A once, B ONCE, C once) / all kernels of the step; gather_frac counts one row of B per "
-                            "nonzero (hub rows of B are served by L2 / Infinity Cache: it can exceed what HBM alone delivers)"}
+                    "note": "frac = section-8(d) algorithmic bytes (A once, B ONCE, C once) / all kernels of the step; gather_gbs counts one row of B per "
+                            "nonzero (a bandwidth, not a fraction: rows of B served by L2 / Infinity Cache let it exceed what HBM alone delivers)"}
     if h16 and dom != "sparse":
         # 16-bit storage: the MFMAs take 1/8 (fp16 / bf16 dense peak ~2.5 PFLOP/s) of the fp32 time while the bytes only halve:
         # the kernel is bound by memory traffic.  Algorithmic bytes: packed 16-bit A (read once) + 16-bit B (once) + fp32 C.

@@ -289,11 +289,12 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
     roofline = {"bound": "hbm", "achieved": round(gbs_once, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(job_lb / (ms_job * 1e-3), 5),
                 "traffic": None, "traffic_source": None,
                 "kernel": "sparse_rows_cm_kernel + sparse_segments_kernel (gather of one row of B per nonzero) + vbs_spmm_h16_direct_kernel (hub tiles)",
-                "algorithmic_bytes": round(sum_alg), "gather_gbs": round(gbs_gather, 1), "gather_frac": round(gbs_gather / PEAK_HBM_GBS, 4),
+                "algorithmic_bytes": round(sum_alg), "gather_gbs": round(gbs_gather, 1),
                 "note": "frac = section-8(d) bound (per part: A once, B once, C once; MFMA part max(bytes, flops)) / measured time"
                         + ("; the job's bound is the slowest rank's" if distributed else "; summed over the parts")
-                        + ".  gather_frac: one row of B per nonzero (L2 / Infinity Cache re-reads included) -- the kernels sit near the gather "
-                          "ceiling and structurally far from the B-once bound: R-MAT rows do not share columns outside the hub"}
+                        + ".  gather_gbs: the sparse-row kernels' GB/s counting one row of B per nonzero (re-reads served by L2 / Infinity Cache included: a "
+                          "bandwidth, not a fraction of a bound -- with the long rows taken column window by column window it passes what HBM alone delivers).  "
+                          "Structurally far from the B-once bound: R-MAT rows do not share columns outside the hub"}
     cpu = None
     if not args.no_cpu_baseline and last is not None:
         m, grouping, rbs = last

@@ -291,12 +291,12 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     if (win_w > 0) kSpLong = 128;
     if (const char* e = std::getenv("SPARTA_SP_LONG")) kSpLong = std::max(8, atoi(e));
     if (const char* e = std::getenv("SPARTA_SP_MINSEG")) sp_minseg = std::max(1, atoi(e));
-    for (size_t t = 0; t < sp_crow.size(); t++) {
+    // the segments of row t (appended to out, or only counted when out is null)
+    auto cut_row = [&](size_t t, std::vector<SpSegRec>* out) -> int32_t {
         const int64_t p0 = sp_rowptr[t], n = sp_rowptr[t + 1] - p0;
-        if (n <= kSpLong) { sp_list.push_back((int32_t)t); continue; }
+        int32_t n_seg = 0;
         if (win_w > 0) {
             const int64_t L = std::max<int64_t>(kSpSeg, 512);
-            SpLongRec lr{(int32_t)t, (int32_t)sp_segs.size(), 0, 0};
             int64_t o = 0;
             while (o < n) {
                 // the segment [o, e): up to L nonzeros, ending early at the first window boundary behind its first sp_minseg nonzeros
@@ -308,26 +308,59 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
                     const int32_t* f = std::lower_bound(b, bend, (int32_t)std::min<int64_t>(wend, INT32_MAX));
                     e = o + sp_minseg + (f - b);
                 }
-                sp_segs.push_back(SpSegRec{p0 + o, (int32_t)(e - o), 0});
-                lr.n_seg++;
+                if (out) out->push_back(SpSegRec{p0 + o, (int32_t)(e - o), 0});
+                n_seg++;
                 o = e;
             }
-            sp_long.push_back(lr);
-            continue;
+            return n_seg;
         }
         // a hub row's segments run in parallel, its partial rows are added one after the other: with segments of L nonzeros the chain is L / 16 gather
         // batches + n / L additions -- shortest near L = sqrt(1.6 n) (a batch ~ 10 additions), never below the size-dependent base, never above 512
         // (ia-wikiquote, 239 k nonzeros with rows of 10^4: 32-nonzero segments everywhere took 271 us, mostly the reduction of its hub rows)
         int64_t L = ((int64_t)std::sqrt(1.6 * (double)n) + 15) / 16 * 16;
         L = std::max(kSpSeg, std::min<int64_t>(512, L));
-        SpLongRec lr{(int32_t)t, (int32_t)sp_segs.size(), 0, 0};
-        for (int64_t o = 0; o < n; o += L) { sp_segs.push_back(SpSegRec{p0 + o, (int32_t)std::min<int64_t>(L, n - o), 0}); lr.n_seg++; }
-        sp_long.push_back(lr);
+        for (int64_t o = 0; o < n; o += L) { if (out) out->push_back(SpSegRec{p0 + o, (int32_t)std::min<int64_t>(L, n - o), 0}); n_seg++; }
+        return n_seg;
+    };
+    {
+        // rows in order; the segments of the long ones are cut on all threads (chunks of rows, concatenated in row order)
+        const int64_t n_rows_sp = (int64_t)sp_crow.size();
+        const int nt = sparta::host_threads();
+        const int64_t chunk = std::max<int64_t>(1024, (n_rows_sp + 4 * nt - 1) / (4 * std::max(nt, 1)));
+        const int64_t n_chunks = (n_rows_sp + chunk - 1) / std::max<int64_t>(chunk, 1);
+        std::vector<std::vector<SpSegRec>> segs_of((size_t)n_chunks);
+        std::vector<std::vector<SpLongRec>> long_of((size_t)n_chunks);
+        std::vector<std::vector<int32_t>> short_of((size_t)n_chunks);
+        sparta::parallel_for_dynamic(n_chunks, 1, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t c = lo; c < hi; c++)
+                for (int64_t t = c * chunk; t < std::min(n_rows_sp, (c + 1) * chunk); t++) {
+                    if (sp_rowptr[(size_t)t + 1] - sp_rowptr[(size_t)t] <= kSpLong) { short_of[(size_t)c].push_back((int32_t)t); continue; }
+                    SpLongRec lr{(int32_t)t, (int32_t)segs_of[(size_t)c].size(), 0, 0};      // seg_begin: within the chunk for now
+                    lr.n_seg = cut_row((size_t)t, &segs_of[(size_t)c]);
+                    long_of[(size_t)c].push_back(lr);
+                }
+        });
+        for (int64_t c = 0; c < n_chunks; c++) {
+            const int32_t base = (int32_t)sp_segs.size();
+            if ((int64_t)sp_segs.size() + (int64_t)segs_of[(size_t)c].size() > INT32_MAX)
+                return sparta::fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: too many sparse-row segments for 32-bit indexing");
+            sp_list.insert(sp_list.end(), short_of[(size_t)c].begin(), short_of[(size_t)c].end());
+            sp_segs.insert(sp_segs.end(), segs_of[(size_t)c].begin(), segs_of[(size_t)c].end());
+            for (SpLongRec lr : long_of[(size_t)c]) { lr.seg_begin += base; sp_long.push_back(lr); }
+        }
     }
-    // a segment's partial row lives at its index in row order (pad); the order of the list is the order the waves take them in
+    // a segment's partial row lives at its index in row order (pad); the order of the list is the order the waves take them in: window by window
+    // (a stable counting sort on the window of the segment's first column)
     for (size_t i = 0; i < sp_segs.size(); i++) sp_segs[i].pad = (int32_t)i;
-    if (win_w > 0)
-        std::stable_sort(sp_segs.begin(), sp_segs.end(), [&](const SpSegRec& a, const SpSegRec& b) { return sp_col[(size_t)a.p0] / win_w < sp_col[(size_t)b.p0] / win_w; });
+    if (win_w > 0 && !sp_segs.empty()) {
+        const int64_t n_win = (cols + win_w - 1) / win_w;
+        std::vector<int64_t> start((size_t)n_win + 1, 0);
+        for (const SpSegRec& g : sp_segs) start[(size_t)(sp_col[(size_t)g.p0] / win_w) + 1]++;
+        for (int64_t k = 0; k < n_win; k++) start[(size_t)k + 1] += start[(size_t)k];
+        std::vector<SpSegRec> sorted(sp_segs.size());
+        for (const SpSegRec& g : sp_segs) sorted[(size_t)start[(size_t)(sp_col[(size_t)g.p0] / win_w)]++] = g;
+        sp_segs.swap(sorted);
+    }
     n_sp_short = (int64_t)sp_list.size(); n_sp_long = (int64_t)sp_long.size();
     trace.lap("sparse rows (device form)");
     const uint8_t* skip = sparse_flag.empty() ? nullptr : sparse_flag.data();

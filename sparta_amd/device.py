@@ -72,12 +72,14 @@ class DeviceVBS:
     def predict_cost(cmat, grouping, col_block_size, row_block_size=0, force_fixed_size=False, dtype=_lib.F32, n_cols=128):
         """Predicted time of one product of the handle from_csr would build (plan_stats x measured rates on one MI355X): the dense tiles at
         the executed rate of the stream kernels on power-law hubs (16-bit: 220 TFLOP/s = 13.6 ms for 5.8e9 stored elements x 256 columns;
-        fp32: 100), the sparse rows at the gather rate (one n_cols-wide row of B per nonzero at 5.9 TB/s) + their rows of C.  Good to
-        ~10 % on R-MAT parts (profiles/r3): enough to choose between two blockings of one matrix, which is all it is for."""
+        fp32: 100), the sparse rows at the gather rate (one n_cols-wide row of B per nonzero: 5.9 TB/s when every gather goes to HBM, 9.5 TB/s
+        where the library takes the long rows column window by column window -- from 4 windows of 65536 columns and 4 M nonzeros, vbs_capi.cpp)
+        + their rows of C.  Good to ~10 % on R-MAT parts (profiles/r3): enough to choose between two blockings of one matrix, which is all it is for."""
         st = DeviceVBS.plan_stats(cmat, grouping, col_block_size, row_block_size, force_fixed_size, dtype)
         esz = 4.0 if dtype == _lib.F32 else 2.0
         t_tiles = 2.0 * st["tile_area"] * n_cols / ((100e12 if dtype == _lib.F32 else 220e12))
-        t_sparse = st["sparse_nnz"] * (n_cols * esz + 8.0) / 5.9e12 + st["sparse_rows"] * n_cols * 4.0 / 5.9e12
+        rate = 9.5e12 if (cmat.cols >= 4 * 65536 and st["sparse_nnz"] >= (4 << 20)) else 5.9e12
+        t_sparse = st["sparse_nnz"] * (n_cols * esz + 8.0) / rate + st["sparse_rows"] * n_cols * 4.0 / 5.9e12
         st["ms_tiles"], st["ms_sparse"] = t_tiles * 1e3, t_sparse * 1e3
         st["ms"] = (t_tiles + t_sparse) * 1e3
         return st
