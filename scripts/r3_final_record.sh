@@ -3,8 +3,10 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
 mkdir -p gpurun_out/r3
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r3/gputest.log 2>&1 || { tail -40 gpurun_out/r3/gputest.log; exit 1; }
-tail -2 gpurun_out/r3/gputest.log
+if [ -z "${SKIP_TESTS:-}" ]; then
+  timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r3/gputest.log 2>&1 || { tail -40 gpurun_out/r3/gputest.log; exit 1; }
+  tail -2 gpurun_out/r3/gputest.log
+fi
 timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r3/bench_driver_cmd.json 2> gpurun_out/r3/bench_driver_cmd.err || { tail -20 gpurun_out/r3/bench_driver_cmd.err; exit 1; }
 timeout -k 10 600 python bench.py --no-suite > gpurun_out/r3/bench_default.json 2> gpurun_out/r3/bench_default.err || { tail -20 gpurun_out/r3/bench_default.err; exit 1; }
 timeout -k 10 600 python bench.py --no-suite --dtype f16 --no-cpu-baseline > gpurun_out/r3/bench_f16.json 2> gpurun_out/r3/bench_f16.err || { tail -20 gpurun_out/r3/bench_f16.err; exit 1; }
@@ -16,4 +18,4 @@ for f in ("bench_driver_cmd", "bench_default", "bench_f16"):
     print(f, "value", j["value"], "ms", j["ms_per_step"], "frac", j["roofline"]["frac"], "mixed", j["roofline"].get("mixed_roofline_frac"), "cpu", (j.get("cpu_baseline") or {}).get("value"))
 PY
 tail -14 gpurun_out/r3/suite.md | cut -c1-200
-bash scripts/r3_profiles.sh
+[ -n "${SKIP_PROFILES:-}" ] || bash scripts/r3_profiles.sh
