@@ -281,6 +281,7 @@ struct StreamPlanHost {
     int n_workers = 0, n_split = 0;
     int plan_aligned[2] = {0, 0};
     bool wide16 = false;                      // 16-bit one-tile plan with two sub-workers per workgroup (2 x n_workers ranges in wrange[0])
+    bool window_plan = false;                 // 64-row tiles dealt as (window, tile) pieces (SPARTA_TILE_WINDOW_COLS, experiment)
     int64_t kp = SK_KP;
     int64_t n_plan_tiles[2] = {0, 0};         // tiles (with at least one block) per plan: steps per tile decides the cache policy of the C stores
     bool tiles_row_aligned[2] = {true, true}; // every tile of the plan starts at a multiple of 32 rows of C (whole 128-byte lines of a column-major C)

@@ -2,6 +2,7 @@
 // into step lists, cuts them into worker ranges (aligned / split), records the split tiles for the fix-up and, for 16-bit
 // handles, packs A into per-step slices.  Plain host C++ (no kernel, no HIP call).  See DESIGN.md section 3.2 (2).
 #include <cstdio>
+#include <queue>
 
 #include "vbs_device.hpp"
 
@@ -223,6 +224,81 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             const int per_x = n_workers / 8;
             std::vector<int64_t> bnd((size_t)n_workers + 1, S);
             bnd[0] = 0;
+            // ---- WINDOW PLAN (16-bit handles, 64-row tiles; EXPERIMENT, SPARTA_TILE_WINDOW_COLS = columns per window, default off) --------------------------
+            // The B panels a worker streams are the kernel's L2 misses (rocprofv3 FETCH_SIZE on a part of the 8 M-row R-MAT: 30 GB per launch = 6.5 x |B|): with
+            // contiguous step ranges every worker sits at its own k position of its own tile.  Here a tile is cut into PIECES where its block columns cross into
+            // another window of `win` columns (a piece holds at least min_steps steps), the pieces are taken window by window - (window, tile) order - and dealt
+            // whole to the least loaded worker, so that at any time all workers walk the same window from its first block column on: the first one to touch a
+            // panel takes the miss, the others of its XCD hit.  Every piece of a tile with more than one piece is a partial image for the fix-up, which adds a
+            // tile's images in k order whatever worker produced them.
+            int64_t win_cols = 0;
+            if (const char* e = std::getenv("SPARTA_TILE_WINDOW_COLS")) win_cols = std::max(0, atoi(e));
+            const bool win_plan = h16 && ty == 1 && !wide && win_cols >= w && S >= 4 * (int64_t)n_workers;
+            std::vector<int32_t> sp_tile, sp_seq, tile_pieces;               // per span (= piece): its tile and place in it; per tile: pieces
+            std::vector<TileSpan> tile_spans;                                // the tiles as they were (c_row, mt)
+            if (win_plan) {
+                int64_t min_steps = 64;
+                if (const char* e = std::getenv("SPARTA_TILE_WINDOW_MIN")) min_steps = std::max(1, atoi(e));
+                struct Piece { int64_t first, last, win; int32_t tile, seq; };
+                std::vector<Piece> pieces;
+                auto win_of = [&](int64_t q) { const StepRec& r = st[(size_t)q]; return ((r.mt_flags & STEP_TAIL) ? cols - 1 : (int64_t)r.b_row) / win_cols; };
+                tile_spans = spans;
+                tile_pieces.assign(spans.size(), 0);
+                for (size_t t = 0; t < spans.size(); t++) {
+                    int64_t a = spans[t].first;
+                    int32_t seq = 0;
+                    while (a <= spans[t].last) {
+                        int64_t b = a, wcur = win_of(a);
+                        while (b < spans[t].last) {
+                            const int64_t wn = win_of(b + 1);
+                            if (wn != wcur) { if (b - a + 1 >= min_steps) break; wcur = wn; }
+                            b++;
+                        }
+                        if (spans[t].last - b < min_steps) b = spans[t].last;           // no short tail piece
+                        pieces.push_back(Piece{a, b, win_of(a), (int32_t)t, seq++});
+                        a = b + 1;
+                    }
+                    tile_pieces[t] = seq;
+                }
+                std::stable_sort(pieces.begin(), pieces.end(), [](const Piece& x, const Piece& y) { return x.win < y.win; });       // (window, tile)
+                // deal: whole pieces, in that order, to the least loaded worker
+                std::vector<std::vector<size_t>> mine((size_t)n_workers);
+                {
+                    typedef std::pair<int64_t, int> LW;                      // (load, worker)
+                    std::priority_queue<LW, std::vector<LW>, std::greater<LW>> heap;
+                    for (int pos = 0; pos < n_workers; pos++) heap.push(LW(0, pos));
+                    for (size_t i = 0; i < pieces.size(); i++) {
+                        LW lw = heap.top();
+                        heap.pop();
+                        mine[(size_t)lw.second].push_back(i);
+                        lw.first += (pieces[i].last - pieces[i].first + 1) * (int64_t)c2 + ct;
+                        heap.push(lw);
+                    }
+                }
+                std::vector<StepRec> ns;
+                std::vector<TileSpan> nspans;
+                ns.reserve(st.size());
+                for (int pos = 0; pos < n_workers; pos++) {
+                    bnd[(size_t)pos] = (int64_t)ns.size();
+                    for (size_t i : mine[(size_t)pos]) {
+                        const Piece& pc = pieces[i];
+                        TileSpan sp = tile_spans[(size_t)pc.tile];
+                        sp.first = (int64_t)ns.size();
+                        ns.insert(ns.end(), st.begin() + pc.first, st.begin() + pc.last + 1);
+                        sp.last = (int64_t)ns.size() - 1;
+                        nspans.push_back(sp);
+                        sp_tile.push_back(pc.tile);
+                        sp_seq.push_back(pc.seq);
+                    }
+                }
+                bnd[(size_t)n_workers] = S;
+                for (StepRec& r : ns) r.mt_flags &= ~(STEP_FIRST | STEP_LAST);          // set again per piece below
+                st.swap(ns);
+                spans.swap(nspans);
+                plan_aligned[ty] = 0;
+                P.window_plan = true;
+            }
+            if (!win_plan) {
             // Share of a worker.  The two (three) workgroups that share a CU do not progress at the same rate: the SIMD arbiter
             // serves the OLDER wave first, so the workgroup dispatched first (j < #CU per XCD) runs ahead -- measured on equal
             // ranges: the older one finished 512 steps in ~780 us, the younger one in 1030 us, the last 250 us alone on the CU at
@@ -336,6 +412,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                 }
                 plan_aligned[ty] = aligned ? 1 : 0;
             }
+            }   // !win_plan
             wrange[ty].assign((size_t)n_workers * 2, 0);
             std::vector<int32_t> wid_of_pos((size_t)n_workers);
             for (int pos = 0; pos < n_workers; pos++) {
@@ -348,16 +425,24 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             // segments: a tile cut by a boundary is split; every segment writes one workspace image
             // (slots are numbered densely over both types: both launches finish before the fix-up kernel reads them)
             size_t ti = 0;
+            const int32_t slot_base = (int32_t)fix_slots.size();
+            std::vector<std::vector<std::pair<int32_t, int32_t>>> tile_slots(win_plan ? tile_spans.size() : 0);      // window plan: (place in the tile, slot)
+            int32_t n_win_slots = 0;
             for (int pos = 0; pos < n_workers; pos++) {
                 const int64_t s0 = bnd[(size_t)pos], s1 = bnd[(size_t)pos + 1];
                 if (s0 >= s1) continue;
                 while (ti < spans.size() && spans[ti].last < s0) ti++;
                 for (size_t t = ti; t < spans.size() && spans[t].first < s1; t++) {
                     const int64_t a = std::max(spans[t].first, s0), b = std::min(spans[t].last, s1 - 1);
-                    const bool whole = a == spans[t].first && b == spans[t].last;
+                    const bool whole = a == spans[t].first && b == spans[t].last && (!win_plan || tile_pieces[(size_t)sp_tile[t]] == 1);
                     st[(size_t)a].mt_flags |= STEP_FIRST;
                     st[(size_t)b].mt_flags |= STEP_LAST;
-                    if (!whole) {
+                    if (!whole && win_plan) {                                // pieces are dealt whole: one image per piece, grouped per tile below
+                        const int32_t slot = slot_base + n_win_slots++;
+                        st[(size_t)b].mt_flags |= STEP_SPLIT;
+                        st[(size_t)b].slot = slot;
+                        tile_slots[(size_t)sp_tile[t]].push_back(std::make_pair(sp_seq[t], slot));
+                    } else if (!whole) {
                         const int32_t slot = (int32_t)fix_slots.size();          // dense: one image per segment, both types
                         st[(size_t)b].mt_flags |= STEP_SPLIT;
                         st[(size_t)b].slot = slot;
@@ -370,6 +455,14 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                     }
                 }
             }
+            if (win_plan)                                                    // a tile's images in k order (its pieces' places), whatever worker made them
+                for (size_t t = 0; t < tile_slots.size(); t++) {
+                    if (tile_slots[t].empty()) continue;
+                    std::sort(tile_slots[t].begin(), tile_slots[t].end());
+                    fix.push_back(FixRec{tile_spans[t].c_row, tile_spans[t].mt, (int32_t)fix_slots.size(), (int32_t)tile_slots[t].size()});
+                    for (const auto& ps : tile_slots[t]) fix_slots.push_back(ps.second);
+                    n_split++;
+                }
             // ---- 16-bit handles: the slices of A in STEP order (the dealing above moved whole tiles between workers): slice q of this type sits at
             // base + q x slice, so that the no-barrier kernel advances ONE pointer per step instead of reading an offset from the step record
             // (eight scalar instructions of ~50 per step; the records keep the offsets for the LDS-staged kernel)

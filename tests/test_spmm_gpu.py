@@ -1157,6 +1157,54 @@ def test_sparse_row_path_16bit(_sparse_row_mode, dtype, n):
     _check(Ch, Co, bound, "16-bit sparse rows, host pointers")
 
 
+@pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("win,min_steps,n", [(1024, 4, 256), (512, 1, 128), (4096, 16, 512)])
+def test_16bit_window_plan_of_64_row_tiles(monkeypatch, _sparse_row_mode, dtype, win, min_steps, n):
+    """SPARTA_TILE_WINDOW_COLS (an experiment, off by default: DESIGN.md section 10): the 64-row tiles of a 16-bit handle are cut into (tile, column window) pieces,
+    the pieces dealt whole to the workers window by window, every piece of a cut tile a partial image that the fix-up adds in k order.  Same product as the oracle's on the
+    rounded inputs (both layouts of C, accumulate) and as the default plan's up to the rounding of the regrouped sums; a partial last block column and a ragged last tile."""
+    torch = _torch()
+    w, rows, cols = 64, 1000, 8000 + 37
+    m = sa.gen.uniform_random(rows, cols, 400000, seed=win + n)
+    g = np.arange(rows) // 64
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=6)
+    mab_r, B_r = _round16(v.mab, dtype), _round16(B, dtype)
+    Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n, None)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n)
+    tdt = torch.float16 if dtype == sa.F16 else torch.bfloat16
+    ldb = (v.cols + 7) // 8 * 8
+    Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    Bt.view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
+    outs = []
+    for on in (True, False):
+        if on:
+            monkeypatch.setenv("SPARTA_TILE_WINDOW_COLS", str(win))
+            monkeypatch.setenv("SPARTA_TILE_WINDOW_MIN", str(min_steps))
+        else:
+            monkeypatch.delenv("SPARTA_TILE_WINDOW_COLS")
+        d = v.to_device(0, dtype=dtype)
+        info = d.info()
+        if _sparse_row_mode == "mfma-only":
+            assert info["tiles64"] > 0
+            if on:
+                assert info["split_tiles"] >= info["tiles64"] - 1, info        # every tile (all of them span several windows) goes through the fix-up
+        for cl in (sa.COL_MAJOR, sa.ROW_MAJOR):
+            for acc in (False, True):
+                C0 = sa.gen.dense_rhs(rows, n, seed=33)
+                Ct = torch.from_numpy(C0 if cl == sa.COL_MAJOR else np.ascontiguousarray(C0.reshape(n, rows).T).reshape(-1)).cuda()
+                d.spmm(Bt, Ct, n, ldb=ldb, c_layout=cl, accumulate=acc)
+                torch.cuda.synchronize()
+                got = Ct.cpu().numpy()
+                if cl == sa.ROW_MAJOR:
+                    got = np.ascontiguousarray(got.reshape(rows, n).T).reshape(-1)
+                _check(got, Co + (C0 if acc else 0), bound + (np.abs(C0) if acc else 0), "window plan %s, c_layout %d acc %d" % (on, cl, acc))
+                if cl == sa.COL_MAJOR and not acc:
+                    outs.append(got)
+        d.close()
+    assert np.max(np.abs(outs[0] - outs[1])) <= 1e-5 * np.max(bound)
+
+
 @pytest.mark.parametrize("dtype", [sa.F32, sa.BF16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("win,long_,minseg", [(512, 16, 4), (2048, 64, 16), (64, 8, 1)])
 def test_sparse_rows_cut_at_column_windows_and_taken_window_by_window(monkeypatch, _sparse_row_mode, dtype, win, long_, minseg):
