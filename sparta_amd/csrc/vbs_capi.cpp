@@ -866,7 +866,8 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     // by 3-10 %.  2-byte loads (one bf16 per lane) are slow whatever the size (6.6 ms) and never chosen.  SPARTA_SP_VEC caps the width.
     static const int vec_cap = [] { const char* e = std::getenv("SPARTA_SP_VEC"); return e ? atoi(e) : 4; }();
     const double b_bytes = (double)A->cols * (double)n_cols * (double)esz;
-    const int row_bytes = b_bytes > 384e6 ? 256 : (b_bytes > 96e6 ? 512 : 1024);
+    static const int row_bytes_env = [] { const char* e = std::getenv("SPARTA_SP_ROW_BYTES"); return e ? atoi(e) : 0; }();
+    const int row_bytes = row_bytes_env > 0 ? row_bytes_env : (b_bytes > 384e6 ? 256 : (b_bytes > 96e6 ? 512 : 1024));
     const int vec_want = std::max(esz == 2 ? 2 : 1, std::min(vec_cap, (int)(row_bytes / (64 * (int)esz))));
     const int vec = in_place ? 1 : (vec_want >= 4 && aligned(4) ? 4 : (vec_want >= 2 && aligned(2) ? 2 : 1));
     const unsigned gy = (unsigned)((n_cols + 64 * vec - 1) / (64 * vec));
