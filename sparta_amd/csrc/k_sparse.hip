@@ -159,13 +159,12 @@ __device__ __forceinline__ void sp_cm_flush(const SparseParams& p, const float* 
 // rows of one column (kCmRows * 4 contiguous bytes where the C rows are consecutive).  Replaces "row-major scratch + scatter launch": the product
 // is written once instead of written, read back and written again.
 template <int VEC, int BK, int kCmRows, int NW>
-__global__ __launch_bounds__(64 * NW) void sparse_rows_cm_kernel(SparseParams p) {
+__device__ __forceinline__ void sparse_rows_cm_body(const SparseParams& p, float* tile, int bx) {      // tile: VEC * kCmRows * 65 floats of LDS
     typedef typename SpVec<VEC>::T V;
     constexpr int RPW = kCmRows / NW;                            // rows a wave walks one after the other
     static_assert(RPW >= 1 && RPW * NW == kCmRows, "rows per workgroup must be a multiple of the waves");
-    __shared__ float tile[VEC * kCmRows * 65];                   // 64 * VEC columns of kCmRows rows, layout in sp_cm_flush
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slot0 = blockIdx.x * kCmRows;
+    const int slot0 = bx * kCmRows;
     const int n0 = (blockIdx.y * 64 + lane) * VEC;
     // the wave's rows: lane i holds the nonzero range of row j = wave + NW i (one chain of dependent loads for all of them, not one per row)
     int mlo = 0, mhi = 0, mcnt = 0;
@@ -208,13 +207,19 @@ __global__ __launch_bounds__(64 * NW) void sparse_rows_cm_kernel(SparseParams p)
     sp_cm_flush<VEC, kCmRows, 64 * NW>(p, tile, valid, valid ? p.crow[p.list[slot0 + fj]] : 0);
 }
 
+template <int VEC, int BK, int kCmRows, int NW>
+__global__ __launch_bounds__(64 * NW) void sparse_rows_cm_kernel(SparseParams p) {
+    __shared__ float tile[VEC * kCmRows * 65];                   // 64 * VEC columns of kCmRows rows, layout in sp_cm_flush
+    sparse_rows_cm_body<VEC, BK, kCmRows, NW>(p, tile, blockIdx.x);
+}
+
 // long rows (hubs): cut into segments of <= kSpSeg nonzeros, one wave per segment writes a partial row; a second launch adds
 // the partial rows of every long row in segment order (deterministic) and stores the row
 
 template <int VEC, int BK>
-__global__ __launch_bounds__(kThreads) void sparse_segments_kernel(SparseParams p, const SpSegRec* segs, int32_t n_segs, float* part) {
+__device__ __forceinline__ void sparse_segments_body(const SparseParams& p, const SpSegRec* segs, int32_t n_segs, float* part, int bx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slot = blockIdx.x * 4 + wave;
+    const int slot = bx * 4 + wave;
     if (slot >= n_segs) return;
     const SpSegRec sg = segs[slot];
     const int n0 = (blockIdx.y * 64 + lane) * VEC;
@@ -226,6 +231,38 @@ __global__ __launch_bounds__(kThreads) void sparse_segments_kernel(SparseParams 
     *reinterpret_cast<typename SpVec<VEC>::T*>(part + (int64_t)sg.pad * p.N + n0) = acc;
 }
 
+template <int VEC, int BK>
+__global__ __launch_bounds__(kThreads) void sparse_segments_kernel(SparseParams p, const SpSegRec* segs, int32_t n_segs, float* part) {
+    sparse_segments_body<VEC, BK>(p, segs, n_segs, part, blockIdx.x);
+}
+
+// small sparse parts, column-major C: the rows of ordinary length (4 or 16 per workgroup, as in the separate launch) and the segments of the long rows in ONE launch - workgroups
+// [0, n_row_wgs) take rows, the rest segments (a launch costs 5-8 us whatever it does: wiki-Vote 33.7 us = rows 13.0 + segments 6.7 + reduce 10.7 + transpose 5.8)
+template <int VEC, int BK, int kCmRows>
+__global__ __launch_bounds__(kThreads) void sparse_small_cm_kernel(SparseParams p, int32_t n_row_wgs, const SpSegRec* segs, int32_t n_segs, float* part) {
+    __shared__ float tile[VEC * kCmRows * 65];
+    if ((int)blockIdx.x < n_row_wgs) sparse_rows_cm_body<VEC, BK, kCmRows, 4>(p, tile, blockIdx.x);       // (workgroup-uniform branch: the barrier inside is reached by all or none)
+    else sparse_segments_body<VEC, BK>(p, segs, n_segs, part, (int)blockIdx.x - n_row_wgs);
+}
+
+// the partial rows of one long row, added in segment order - eight loads in flight at a time (the order of the additions is what fixes the bits, not the
+// order of the loads: one load + one add per iteration made the reduction a chain of memory latencies, 52 us for the hub rows of ia-wikiquote)
+template <int VEC>
+__device__ __forceinline__ typename SpVec<VEC>::T sp_sum_partials(const float* first, int n_seg, int64_t stride) {
+    typedef typename SpVec<VEC>::T V;
+    V acc = (V)(0.0f);
+    int sgi = 0;
+    for (; sgi + 8 <= n_seg; sgi += 8) {
+        V t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = *reinterpret_cast<const V*>(first + (int64_t)(sgi + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += t[u];
+    }
+    for (; sgi < n_seg; sgi++) acc += *reinterpret_cast<const V*>(first + (int64_t)sgi * stride);
+    return acc;
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void sparse_reduce_kernel(SparseParams p, const SpLongRec* rows, int32_t n_rows, const float* part) {
     typedef typename SpVec<VEC>::T V;
@@ -235,8 +272,7 @@ __global__ __launch_bounds__(kThreads) void sparse_reduce_kernel(SparseParams p,
     const SpLongRec r = rows[slot];
     const int n0 = (blockIdx.y * 64 + lane) * VEC;
     if (VEC == 1 && n0 >= p.N) return;
-    V acc = (V)(0.0f);
-    for (int sgi = 0; sgi < r.n_seg; sgi++) acc += *reinterpret_cast<const V*>(part + (int64_t)(r.seg_begin + sgi) * p.N + n0);
+    const V acc = sp_sum_partials<VEC>(part + (int64_t)r.seg_begin * p.N + n0, r.n_seg, p.N);
     sparse_row_store<VEC>(p, r.ord, acc, n0);
 }
 
@@ -256,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void sparse_reduce_cm_kernel(SparseParams
         V acc = (V)(0.0f);
         if (slot0 + j < n_rows && in) {
             const SpLongRec r = rows[slot0 + j];
-            for (int sgi = 0; sgi < r.n_seg; sgi++) acc += *reinterpret_cast<const V*>(part + (int64_t)(r.seg_begin + sgi) * p.N + n0);
+            acc = sp_sum_partials<VEC>(part + (int64_t)r.seg_begin * p.N + n0, r.n_seg, p.N);
         }
 #pragma unroll
         for (int e = 0; e < VEC; e++) {
@@ -338,7 +374,17 @@ namespace {
 template <int VEC, int BK>
 void launch_sparse_t(SparseParams q, unsigned gy, hipStream_t st, const int32_t* list, int64_t n_short, const SpSegRec* segs, int64_t n_segs,
                      const SpLongRec* longs, int64_t n_long, float* part) {
-    if (n_short > 0) {
+    const bool fused_small = q.out_is_c == 2 && n_short > 0 && n_short < 262144 && n_long > 0 && n_segs > 0 && n_segs < 65536;
+    if (fused_small) {
+        q.list = list; q.n_list = (int32_t)n_short;
+        if (n_short < 16384) {
+            const int32_t n_row_wgs = (int32_t)((n_short + 3) / 4);
+            hipLaunchKernelGGL((sparse_small_cm_kernel<VEC, BK, 4>), dim3((unsigned)(n_row_wgs + (n_segs + 3) / 4), gy), dim3(kThreads), 0, st, q, n_row_wgs, segs, (int32_t)n_segs, part);
+        } else {
+            const int32_t n_row_wgs = (int32_t)((n_short + 15) / 16);
+            hipLaunchKernelGGL((sparse_small_cm_kernel<VEC, BK, 16>), dim3((unsigned)(n_row_wgs + (n_segs + 3) / 4), gy), dim3(kThreads), 0, st, q, n_row_wgs, segs, (int32_t)n_segs, part);
+        }
+    } else if (n_short > 0) {
         q.list = list; q.n_list = (int32_t)n_short;
         // column-major C: 16 rows per workgroup (64-byte pieces of a column; 32 rows = 128-byte pieces but half the workgroups: measured 0-25 %
         // slower from R-MAT 2^14 to 2^20), 4 waves walking 4 rows each (8 / 16 waves with 2 / 1 rows each: 15-45 % slower on R-MAT 2^20; 1 wave
@@ -350,7 +396,7 @@ void launch_sparse_t(SparseParams q, unsigned gy, hipStream_t st, const int32_t*
         else hipLaunchKernelGGL((sparse_rows_kernel<VEC, BK>), dim3((unsigned)((n_short + 3) / 4), gy), dim3(kThreads), 0, st, q);
     }
     if (n_long > 0) {
-        hipLaunchKernelGGL((sparse_segments_kernel<VEC, BK>), dim3((unsigned)((n_segs + 3) / 4), gy), dim3(kThreads), 0, st, q, segs, (int32_t)n_segs, part);
+        if (!fused_small) hipLaunchKernelGGL((sparse_segments_kernel<VEC, BK>), dim3((unsigned)((n_segs + 3) / 4), gy), dim3(kThreads), 0, st, q, segs, (int32_t)n_segs, part);
         if (q.out_is_c == 2) hipLaunchKernelGGL((sparse_reduce_cm_kernel<VEC, 16>), dim3((unsigned)((n_long + 15) / 16), gy), dim3(kThreads), 0, st, q, longs, (int32_t)n_long, (const float*)part);
         else hipLaunchKernelGGL(sparse_reduce_kernel<VEC>, dim3((unsigned)((n_long + 3) / 4), gy), dim3(kThreads), 0, st, q, longs, (int32_t)n_long, (const float*)part);
     }
