@@ -278,15 +278,16 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     int64_t kSpLong = 2 * kSpSeg;
     // Column windows.  The rows of B a launch gathers at any one time should lie close together: on a power-law matrix with millions of columns the nonzeros of the
     // rows in flight are spread over all of B (GBs), every gather is an HBM access (measured with FETCH_SIZE: 327 of 336 GB gathered came from HBM on a part of
-    // the 8 M-row R-MAT) and the kernels run at the random-row rate of HBM.  So the columns are cut into windows of win_cols columns (~64 MB of B at N = 256..512
+    // the 8 M-row R-MAT) and the kernels run at the random-row rate of HBM.  So the columns are cut into windows of win_w columns (16-32 MB of B at N = 256..512
     // in 16 bits), a row of more than 128 nonzeros is cut into segments that also end where its columns cross into another window (once a segment holds sp_minseg
     // nonzeros), and the segments are PROCESSED window by window -- all rows' segments of window 0, then of window 1, ... (workgroups start in the order of the
     // list).  What is in flight then gathers from one window, which the Infinity Cache and the L2s hold: the same part 62.4 -> 35.1 ms, R-MAT 2^20 at 0.1 %
     // (B = 512, bf16) 11.6 -> 8.1 ms per part.  A row's partial rows are still added in segment order (the sum does not depend on the processing order).
-    // SPARTA_SP_WINDOW_COLS: unset = automatic (on from 4 windows and 4 M nonzeros on this path), 0 = off, > 0 = the window width in columns;
+    // Width / segment minimum 65536 / 64 -> 32768 / 128 (the defaults): another 3 % on both configs (34.8 -> 33.9 ms, 8.05 -> 7.80).
+    // SPARTA_SP_WINDOW_COLS: unset = automatic (on from 262144 columns and 4 M nonzeros on this path), 0 = off, > 0 = the window width in columns;
     // SPARTA_SP_LONG / SPARTA_SP_MINSEG: the row length above which a row is cut / the nonzeros a segment holds before a window boundary ends it.
     const int64_t sp_total = sp_rowptr.empty() ? 0 : sp_rowptr.back();
-    int64_t win_w = (cols >= 4 * 65536 && sp_total >= ((int64_t)4 << 20)) ? 65536 : 0, sp_minseg = 64;
+    int64_t win_w = (cols >= 4 * 65536 && sp_total >= ((int64_t)4 << 20)) ? 32768 : 0, sp_minseg = 128;
     if (const char* e = std::getenv("SPARTA_SP_WINDOW_COLS")) win_w = std::max(0, atoi(e));
     if (win_w > 0) kSpLong = 128;
     if (const char* e = std::getenv("SPARTA_SP_LONG")) kSpLong = std::max(8, atoi(e));

@@ -73,7 +73,7 @@ class DeviceVBS:
         """Predicted time of one product of the handle from_csr would build (plan_stats x measured rates on one MI355X): the dense tiles at
         the executed rate of the stream kernels on power-law hubs (16-bit: 220 TFLOP/s = 13.6 ms for 5.8e9 stored elements x 256 columns;
         fp32: 100), the sparse rows at the gather rate (one n_cols-wide row of B per nonzero: 5.9 TB/s when every gather goes to HBM, 9.5 TB/s
-        where the library takes the long rows column window by column window -- from 4 windows of 65536 columns and 4 M nonzeros, vbs_capi.cpp)
+        where the library takes the long rows column window by column window -- from 262144 columns and 4 M nonzeros, vbs_capi.cpp)
         + their rows of C.  Good to ~10 % on R-MAT parts (profiles/r3): enough to choose between two blockings of one matrix, which is all it is for."""
         st = DeviceVBS.plan_stats(cmat, grouping, col_block_size, row_block_size, force_fixed_size, dtype)
         esz = 4.0 if dtype == _lib.F32 else 2.0
