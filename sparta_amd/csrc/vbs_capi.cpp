@@ -66,6 +66,11 @@ void destroy_impl(sparta_vbs* v) {
         if (v->d_wrange[ty]) (void)hipFree(v->d_wrange[ty]);
     }
     if (v->d_a_frag) (void)hipFree(v->d_a_frag);
+    if (v->d_hub_steps) (void)hipFree(v->d_hub_steps);
+    if (v->d_hub_steps_g) (void)hipFree(v->d_hub_steps_g);
+    if (v->d_hub_tiles) (void)hipFree(v->d_hub_tiles);
+    if (v->d_hub_wrange) (void)hipFree(v->d_hub_wrange);
+    if (v->d_hub_A) (void)hipFree(v->d_hub_A);
     if (v->d_fix) (void)hipFree(v->d_fix);
     if (v->d_fix_slots) (void)hipFree(v->d_fix_slots);
     if (v->d_big_fix) (void)hipFree(v->d_big_fix);
@@ -510,7 +515,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         CREATE_TRY(hipMalloc((void**)&v->d_brows, brows.size() * sizeof(BlockRowDesc)));
         CREATE_TRY(hipMemcpy(v->d_brows, brows.data(), brows.size() * sizeof(BlockRowDesc), hipMemcpyHostToDevice));
     }
-    if (!steps[0].empty() || !steps[1].empty() || !fix.empty() || !plan.zero_ranges.empty()) {
+    if (!steps[0].empty() || !steps[1].empty() || !fix.empty() || !plan.zero_ranges.empty() || plan.n_hub_steps > 0) {
         v->has_tail = (cols % w) != 0;
         v->n_workers = n_workers; v->n_fix = (int32_t)fix.size(); v->n_split = n_split; v->n_slots = (int32_t)fix_slots.size();
         std::vector<int32_t> big_fix;
@@ -548,6 +553,22 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
                 (void)hipGetLastError();
                 v->d_a_frag = nullptr;
             }
+        }
+        if (plan.n_hub_steps > 0) {
+            v->hub_g = plan.hub_g; v->hub_workers = plan.hub_workers; v->n_hub_steps = plan.n_hub_steps; v->hub_area = plan.hub_area;
+            v->hub_union_area = plan.hub_union_area; v->n_hub_tiles = plan.n_hub_tiles; v->n_hub_groups = plan.n_hub_groups;
+            CREATE_TRY(hipMalloc((void**)&v->d_hub_steps, plan.hub_steps.size() * sizeof(HubStep)));
+            CREATE_TRY(hipMemcpy(v->d_hub_steps, plan.hub_steps.data(), plan.hub_steps.size() * sizeof(HubStep), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc((void**)&v->d_hub_tiles, plan.hub_tiles.size() * sizeof(HubTile)));
+            CREATE_TRY(hipMemcpy(v->d_hub_tiles, plan.hub_tiles.data(), plan.hub_tiles.size() * sizeof(HubTile), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc((void**)&v->d_hub_wrange, plan.hub_wrange.size() * sizeof(int32_t)));
+            CREATE_TRY(hipMemcpy(v->d_hub_wrange, plan.hub_wrange.data(), plan.hub_wrange.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            const size_t a_elems = plan.hub_a16.size();
+            CREATE_TRY(hipMalloc((void**)&v->d_hub_A, (a_elems + 64) * sizeof(uint16_t)));
+            if (a_elems > 0) CREATE_TRY(hipMemcpy(v->d_hub_A, plan.hub_a16.data(), a_elems * sizeof(uint16_t), hipMemcpyHostToDevice));
+            v->a_bytes += (int64_t)(a_elems * sizeof(uint16_t));
+            v->exec_area += plan.hub_union_area;
+            v->h_hub_steps.swap(plan.hub_steps);
         }
         if (!fix.empty()) {
             CREATE_TRY(hipMalloc((void**)&v->d_fix, fix.size() * sizeof(FixRec)));
@@ -749,6 +770,13 @@ int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info) {
     return SPARTA_OK;
 }
 
+int sparta_vbs_hub_info(const sparta_vbs_t* A, int64_t* info) {
+    if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_hub_info: NULL argument");
+    info[0] = A->n_hub_steps; info[1] = A->n_hub_tiles; info[2] = A->n_hub_groups; info[3] = A->n_hub_steps > 0 ? A->hub_g : 0;
+    info[4] = A->hub_area; info[5] = A->hub_union_area; info[6] = A->n_hub_steps > 0 ? A->hub_workers : 0; info[7] = 0;
+    return SPARTA_OK;
+}
+
 int sparta_vbs_sparse_info(const sparta_vbs_t* A, int64_t* info) {
     if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_sparse_info: NULL argument");
     info[0] = A->n_sp_rows; info[1] = A->sp_nnz; info[2] = A->n_sp_short; info[3] = A->n_sp_long;
@@ -823,6 +851,13 @@ int ensure_gathered_steps(sparta_vbs_t* A, int64_t shard_rows, hipStream_t st) {
         if (!A->d_steps_g[ty]) HIP_TRY(hipMalloc((void**)&A->d_steps_g[ty], g.size() * sizeof(StepRec)));
         HIP_TRY(hipMemcpyAsync(A->d_steps_g[ty], g.data(), g.size() * sizeof(StepRec), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));                       // g goes out of scope
+    }
+    if (!A->h_hub_steps.empty()) {
+        std::vector<HubStep> g = A->h_hub_steps;
+        for (HubStep& r : g) if (!(r.flags & STEP_TAIL)) { r.shard = (int32_t)(r.b_row / shard_rows); r.b_row = (int32_t)(r.b_row % shard_rows); }
+        if (!A->d_hub_steps_g) HIP_TRY(hipMalloc((void**)&A->d_hub_steps_g, g.size() * sizeof(HubStep)));
+        HIP_TRY(hipMemcpyAsync(A->d_hub_steps_g, g.data(), g.size() * sizeof(HubStep), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
     }
     A->g_shard_rows = shard_rows;
     return SPARTA_OK;
@@ -933,7 +968,7 @@ int spmm16_core(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
         if (int rc = ensure_gathered_steps(A, shard_rows, st)) return rc;
     sp.ws_slab_stride = (int64_t)slab; sp.accumulate = accumulate != 0; sp.c_row_major = c_layout == SPARTA_ROW_MAJOR;
     sp.N = n_cols; sp.w = (int32_t)A->w; sp.B_tail = nullptr; sp.clk = nullptr; sp.stagger = 0;
-    if (A->n_steps[0] + A->n_steps[1] > 0) {
+    if (A->n_steps[0] + A->n_steps[1] + A->n_hub_steps > 0) {
         if (prof) HIP_TRY(hipEventRecord(A->cev[0][0], st));
         if (A->has_tail && shard_rows == 0) {
             if (int rc = ensure_scratch(&A->d_btail, &A->d_btail_bytes, (size_t)A->w * n_cols * sizeof(uint16_t))) return rc;
@@ -970,6 +1005,19 @@ int spmm16_core(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
                 sp.sub_ranges = 0;
             } else
                 launch_h16_stream(A->kp16, ty != 0, bf16, gth, c_stage, ty == 0 && A->wide16, grid, st, sp);
+        }
+        // the hub plan: group tiles of 2 / 4 long 64-row tiles through the GEMM-shaped kernel (k_hub16.hip), 256-column slabs (the last one may be a half slab)
+        if (A->n_hub_steps > 0) {
+            HubParams hp;
+            hp.steps = shard_rows > 0 ? A->d_hub_steps_g : A->d_hub_steps; hp.worker_range = A->d_hub_wrange; hp.tiles = A->d_hub_tiles; hp.A = A->d_hub_A;
+            hp.B = dB; hp.B_tail = (const uint16_t*)sp.B_tail; hp.C = dC; hp.ws = (float*)A->d_ws;
+            hp.ldb = ldb16; hp.ldc = ldc; hp.shard_stride = shard_stride; hp.ws_slab_stride = (int64_t)slab;
+            hp.accumulate = accumulate != 0; hp.c_row_major = c_layout == SPARTA_ROW_MAJOR; hp.c_nt = 1; hp.w = (int32_t)A->w;
+            hp.n_slabs = (n_cols + 255) / 256; hp.n_workers = A->hub_workers; hp.n_cols = n_cols; hp.pad0 = 0;
+            static const int hub_variant_env = [] { const char* e = std::getenv("SPARTA_HUB_VARIANT"); return e ? atoi(e) : -1; }();
+            int variant = A->hub_g == 4 ? 10 : 0;                        // KP 64: G = 4 two stages (eight waves), G = 2 three stages
+            if (hub_variant_env >= 0 && hub_variant_kp(hub_variant_env) == 64 && hub_variant_g(hub_variant_env) == A->hub_g) variant = hub_variant_env;
+            launch_h16_hub(variant, bf16, shard_rows > 0, st, hp);
         }
         if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
     }

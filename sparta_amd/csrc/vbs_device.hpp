@@ -109,6 +109,40 @@ struct StreamParams {
     int32_t sub_ranges = 0;               // 1: worker_range holds two adjacent sub-worker ranges per workgroup (16-bit `wide16` plans)
 };
 
+// ---- the GEMM-shaped hub kernel of 16-bit handles (k_hub16.hip): group tiles of G = 2 or 4 sub-tiles of <= 64 rows (block-rows of the fixed 64 x 64 grid that
+// share most of their block columns -- not necessarily neighbours), walked over the UNION of their block columns; a workgroup owns the group's rows x one
+// 256-column slab of C and stages A and B once through LDS for all its waves
+constexpr int kHubGMax = 4;               // most 64-row sub-tiles per group tile (the kernel has a two- and a four-sub-tile form)
+struct HubStep {                          // 32 bytes, one per (group tile, KP-deep k slice), in execution order
+    uint32_t a_lo, a_hi;                  // element offset into the 16-bit image of A of this step's first PRESENT slice (present slices back to back)
+    int32_t b_row;                        // first row of B of the step's panel (row inside its slab for a gathered B; k offset into B_tail for STEP_TAIL)
+    int32_t shard;                        // gathered B: index of the slab that holds b_row; else 0
+    int32_t flags;                        // bits 0..3: which sub-tiles have a block in this block column; STEP_LAST / STEP_SPLIT / STEP_TAIL
+    int32_t slot;                         // STEP_LAST | STEP_SPLIT: first of the segment's G consecutive workspace images (one per sub-tile), else -1
+    int32_t tile;                         // index into HubTile
+    int32_t pad;
+};
+static_assert(sizeof(HubStep) == 32, "HubStep must stay 32 bytes");
+struct HubTile { int32_t c_row[4]; int32_t mt[4]; };      // per sub-tile: first row of C, rows (<= 64; 0: no such sub-tile)
+struct HubParams {
+    const HubStep* steps;
+    const int32_t* worker_range;          // [2 * n_workers]: begin, end step of every worker
+    const HubTile* tiles;
+    const uint16_t* A;                    // slices of 64 rows x KP, [row][16-byte chunk c ^ swizzle(row)] (the LDS image, see k_hub16.hip)
+    const uint16_t* B;
+    const uint16_t* B_tail;               // zero-padded copy of B's last (partial) block row: w x N, ld = w; or nullptr
+    float* C;
+    float* ws;                            // partial images, as StreamParams::ws
+    int64_t ldb, ldc;
+    int64_t shard_stride;
+    int64_t ws_slab_stride;               // floats between the workspaces of consecutive 128-column slabs
+    int32_t accumulate, c_row_major, c_nt, w;
+    int32_t n_slabs;                      // 256-column slabs of this launch: grid = n_workers x n_slabs workgroups (the slabs of a worker adjacent on one XCD)
+    int32_t n_workers;
+    int32_t n_cols;                       // columns of B / C (a multiple of 128): the last slab may be a half slab
+    int32_t pad0;
+};
+
 constexpr int kFixGroup = 16;   // partial images per group of the fix-up group stage (k_f32_stream.hip)
 
 struct SparseParams {
@@ -194,6 +228,15 @@ struct sparta_vbs {
     bool tiles_row_aligned[2] = {true, true};
     bool wide16 = false;                      // the 16-bit one-tile plan holds two sub-worker ranges per workgroup (vbs_spmm_h16_direct_kernel, WC = 64)
     float* d_a_frag = nullptr;                    // A of the one-tile plan in fragment order (k_f32_direct.hip) or nullptr
+    // hub plan (16-bit handles of 64-wide blocks; vbs_plan.cpp, k_hub16.hip)
+    sparta_dev::HubStep* d_hub_steps = nullptr;
+    sparta_dev::HubStep* d_hub_steps_g = nullptr; // step list for sparta_vbs_spmm_gathered with shard_rows == g_shard_rows
+    std::vector<sparta_dev::HubStep> h_hub_steps; // host copy (padded), source of the gathered variant
+    sparta_dev::HubTile* d_hub_tiles = nullptr;
+    int32_t* d_hub_wrange = nullptr;
+    uint16_t* d_hub_A = nullptr;
+    int hub_g = 0, hub_workers = 0;
+    int64_t n_hub_steps = 0, hub_area = 0, hub_union_area = 0, n_hub_tiles = 0, n_hub_groups = 0;
     bool has_tail = false;                 // cols % w != 0: the stream path needs B_tail
     void* d_btail = nullptr;
     size_t d_btail_bytes = 0;
@@ -253,6 +296,10 @@ void launch_h16_stream(int kp, bool mi2, bool bf16, bool gathered, bool c_stage,
 void launch_h16_slab256(bool bf16, dim3 grid, hipStream_t st, const StreamParams& sp);   // one-tile plans of 32-wide blocks, 256-column slabs (grid.y = N / 256), no split tile
 bool h16_uses_direct_kernel(int kp, bool mi2);
 void launch_h16_quad(int kp, bool bf16, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
+// k_hub16.hip
+void launch_h16_hub(int variant, bool bf16, bool gathered, hipStream_t st, const HubParams& p);
+int hub_variant_kp(int variant);
+int hub_variant_g(int variant);
 void launch_tail_copy_h16(hipStream_t st, const uint16_t* B, int64_t ldb, int64_t row0, int64_t cols, int w, int N, uint16_t* B_tail);
 void launch_convert_h16(bool bf16, hipStream_t st, const float* src, int64_t ld_in, int64_t rows, int64_t n_cols, uint16_t* dst, int64_t ld_out);
 // C[:, col0 + j] (+)= Ct[:, j] for j < n_t: the column tail of a 16-bit product (Ct column-major, ld = rows)
@@ -286,6 +333,16 @@ struct StreamPlanHost {
     int64_t n_plan_tiles[2] = {0, 0};         // tiles (with at least one block) per plan: steps per tile decides the cache policy of the C stores
     bool tiles_row_aligned[2] = {true, true}; // every tile of the plan starts at a multiple of 32 rows of C (whole 128-byte lines of a column-major C)
     std::vector<float> a_frag;                // fp32 one-tile plan: A per step in MFMA fragment order (vbs_spmm_f32_direct_kernel), or empty
+    // hub plan (16-bit handles of 64-wide blocks): the long tiles of 33..64 rows, grouped by the similarity of their block columns into group tiles for
+    // vbs_spmm_h16_hub_kernel (k_hub16.hip); their block-rows are in none of the two plans above
+    std::vector<HubStep> hub_steps;           // in execution order, padded by 32 harmless copies
+    std::vector<HubTile> hub_tiles;
+    std::vector<int32_t> hub_wrange;          // [2 * hub_workers]
+    std::vector<uint16_t> hub_a16;            // slices of 64 rows x 64 k in the kernel's LDS image, present sub-tiles of a step back to back, steps in execution order
+    int hub_g = 0;                            // sub-tiles per group tile (2 or 4); 0: no hub plan
+    int hub_workers = 0;
+    int64_t n_hub_steps = 0, hub_area = 0, hub_union_area = 0;    // steps; stored elements of the hub tiles; elements the kernel multiplies (absent sub-tiles included)
+    int64_t n_hub_tiles = 0, n_hub_groups = 0;
 };
 constexpr int64_t kZeroRangeRows = 2048;    // block-rows without blocks at least this tall are zero-filled by vbs_zero_rows_kernel
 int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P);

@@ -103,6 +103,71 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                 }
             }
         }
+        // ---- HUB PLAN, part 1: which block-rows leave the 64-row plan for the GEMM-shaped kernel (k_hub16.hip), and in which groups --------------------------
+        // 16-bit handles of 64-wide blocks.  Candidates: block-rows of 33..64 rows with at least hub_min steps (the dense hub of a power-law matrix under the
+        // fixed 64 x 64 grid: 10^3..10^4 blocks per block-row).  A workgroup of that kernel multiplies G sub-tiles against ONE panel of B per step, walking the union
+        // of their block columns, so the members of a group should own (nearly) the same block columns: candidates are sorted by length and a seed takes, among the
+        // next `window` candidates, the ones whose block-column sets are most similar to its own (Jaccard, the reference's own measure -- one level up: blocks
+        // instead of nonzeros); they need NOT be neighbours (in an R-MAT graph the block columns of a block-row follow the popcount of its index, not its position).
+        // SPARTA_HUB=0: off.  SPARTA_HUB_G = 2 | 4 sub-tiles per group; SPARTA_HUB_MIN_STEPS (per tile), SPARTA_HUB_MIN_TOTAL (all groups); SPARTA_HUB_TAU (least
+        // similarity, default 0.5); SPARTA_HUB_RANGES (K ranges of the step order, part 2).
+        std::vector<uint8_t> hub_role((size_t)(br1 - br0), 0);
+        struct HubGroup { int64_t ib[kHubGMax]; int n; };
+        std::vector<HubGroup> hub_groups;
+        int hub_G = 4;
+        {
+            const char* e0 = std::getenv("SPARTA_HUB");
+            const bool hub_on = h16 && kp == 64 && !(e0 && atoi(e0) == 0) && [] { const char* e = std::getenv("SPARTA_H16_PATH"); return !(e && e[0] == 'l'); }();
+            if (const char* e = std::getenv("SPARTA_HUB_G")) hub_G = atoi(e) == 2 ? 2 : 4;
+            int64_t hub_min = 64;
+            if (const char* e = std::getenv("SPARTA_HUB_MIN_STEPS")) hub_min = std::max<int64_t>(1, atoll(e));
+            double tau = 0.5;
+            if (const char* e = std::getenv("SPARTA_HUB_TAU")) tau = atof(e);
+            const int window = 48;
+            if (hub_on) {
+                std::vector<int64_t> cand;
+                for (int64_t ib = br0; ib < br1; ib++) {
+                    const int64_t h = row_part[ib + 1] - row_part[ib], nb = nzcount[ib];
+                    if ((in.skip && in.skip[ib - br0]) || pair_role[(size_t)(ib - br0)] != 0) continue;
+                    if (h > 32 && h <= 64 && nb * (w / 64) >= hub_min) cand.push_back(ib);
+                }
+                std::stable_sort(cand.begin(), cand.end(), [&](int64_t a, int64_t b) { return nzcount[a] > nzcount[b]; });
+                auto jaccard = [&](int64_t a, int64_t b) {
+                    const int64_t* pa = jab + jab_lo + jo_of[(size_t)(a - br0)]; const int64_t na = nzcount[a];
+                    const int64_t* pb = jab + jab_lo + jo_of[(size_t)(b - br0)]; const int64_t nb2 = nzcount[b];
+                    int64_t i = 0, j = 0, both = 0;
+                    while (i < na && j < nb2) { if (pa[i] == pb[j]) { both++; i++; j++; } else if (pa[i] < pb[j]) i++; else j++; }
+                    return (double)both / (double)(na + nb2 - both);
+                };
+                std::vector<uint8_t> used(cand.size(), 0);
+                int64_t hub_steps_total = 0;
+                for (size_t q = 0; q < cand.size(); q++) {
+                    if (used[q]) continue;
+                    used[q] = 1;
+                    HubGroup g{{cand[q], 0, 0, 0}, 1};
+                    std::vector<std::pair<double, size_t>> sim;
+                    int seen = 0;
+                    for (size_t r = q + 1; r < cand.size() && seen < window; r++) {
+                        if (used[r]) continue;
+                        seen++;
+                        if ((double)nzcount[cand[r]] < tau * (double)nzcount[cand[q]]) break;          // (sorted by length: nothing similar enough further on)
+                        const double js = jaccard(cand[q], cand[r]);
+                        if (js >= tau) sim.emplace_back(-js, r);
+                    }
+                    std::sort(sim.begin(), sim.end());
+                    for (size_t k = 0; k < sim.size() && g.n < hub_G; k++) { g.ib[g.n++] = cand[sim[k].second]; used[sim[k].second] = 1; }
+                    if (g.n < 2) continue;                              // a tile on its own stays in the 64-row plan
+                    std::sort(g.ib, g.ib + g.n);
+                    hub_groups.push_back(g);
+                    hub_steps_total += nzcount[cand[q]] * (w / 64);
+                }
+                // not worth a launch of its own below a few steps per worker (SPARTA_HUB_MIN_TOTAL overrides: tests)
+                int64_t hub_min_total = 8 * (int64_t)n_workers;
+                if (const char* e = std::getenv("SPARTA_HUB_MIN_TOTAL")) hub_min_total = atoll(e);
+                if (hub_steps_total < hub_min_total) hub_groups.clear();
+                for (const HubGroup& g : hub_groups) for (int u = 0; u < g.n; u++) hub_role[(size_t)(g.ib[u] - br0)] = 1;
+            }
+        }
         for (int ty = 0; ty < 2; ty++) {
             std::vector<StepRec>& st = steps[ty];
             struct TileSpan { int64_t first, last; int32_t c_row, mt; };     // step range of a tile
@@ -160,7 +225,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                         st[(size_t)sp.last].mt_flags |= STEP_LAST;
                         spans.push_back(sp);
                     }
-                    if (role != 0) { jo2 += nb; mo2 += nb * h * w; continue; }   // block-rows of a pair: no tiles of their own
+                    if (role != 0 || hub_role[(size_t)(ib - br0)]) { jo2 += nb; mo2 += nb * h * w; continue; }   // block-rows of a pair / of the hub plan: no tiles of their own
                     for (int64_t r0 = 0; r0 < h && !skipped && !zero_range; r0 += SK_TM) {
                         const int32_t mt = (int32_t)std::min<int64_t>(SK_TM, h - r0);
                         if ((mt > 32 ? 1 : 0) != ty) continue;
@@ -565,6 +630,135 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                     }
                 }
             }
+        }
+        // ---- HUB PLAN, part 2: step list over the unions, K-range-major order, worker ranges, split segments, the slices of A ---------------------------------
+        if (!hub_groups.empty()) {
+            const int G = hub_G;
+            const int64_t block_cols = (cols - 1) / w + 1, spb = w / 64;                    // steps per block
+            const int hub_workers = P.n_workers;                                            // one workgroup per CU and 256-column slab
+            int64_t n_ranges = 16;                                                          // K ranges (SPARTA_HUB_RANGES): the step list is ordered (range, group, k), so that
+            if (const char* e = std::getenv("SPARTA_HUB_RANGES")) n_ranges = atoll(e);      // the workers of an XCD walk the same rows of B at about the same time
+            n_ranges = std::max<int64_t>(1, std::min(n_ranges, block_cols));
+            struct UStep { int32_t jb; int8_t mask; int32_t bidx[kHubGMax]; };              // one block column of a group's union: who has a block there, and which
+            std::vector<std::vector<UStep>> un(hub_groups.size());
+            sparta::parallel_for_dynamic((int64_t)hub_groups.size(), 1, [&](int64_t lo, int64_t hi, int) {
+                for (int64_t gi = lo; gi < hi; gi++) {
+                    const HubGroup& g = hub_groups[(size_t)gi];
+                    int64_t pos[kHubGMax] = {0, 0, 0, 0};
+                    std::vector<UStep>& u = un[(size_t)gi];
+                    for (;;) {
+                        int64_t jb = INT64_MAX;
+                        for (int k = 0; k < g.n; k++) if (pos[k] < nzcount[g.ib[k]]) jb = std::min(jb, jab[jab_lo + jo_of[(size_t)(g.ib[k] - br0)] + pos[k]]);
+                        if (jb == INT64_MAX) break;
+                        UStep x{(int32_t)jb, 0, {-1, -1, -1, -1}};
+                        for (int k = 0; k < g.n; k++)
+                            if (pos[k] < nzcount[g.ib[k]] && jab[jab_lo + jo_of[(size_t)(g.ib[k] - br0)] + pos[k]] == jb) { x.mask |= (int8_t)(1 << k); x.bidx[k] = (int32_t)pos[k]; pos[k]++; }
+                        u.push_back(x);
+                    }
+                }
+            });
+            // order: (K range, group, block column, k slice)
+            struct ORef { int32_t g, u, ks; };
+            std::vector<ORef> order;
+            {
+                std::vector<size_t> cur(hub_groups.size(), 0);
+                for (int64_t r = 0; r < n_ranges; r++) {
+                    const int64_t jb_end = (r + 1) * block_cols / n_ranges;
+                    for (size_t gi = 0; gi < hub_groups.size(); gi++) {
+                        size_t& c = cur[gi];
+                        while (c < un[gi].size() && un[gi][c].jb < jb_end) { for (int64_t k = 0; k < spb; k++) order.push_back(ORef{(int32_t)gi, (int32_t)c, (int32_t)(k * 64)}); c++; }
+                    }
+                }
+            }
+            const int64_t S = (int64_t)order.size();
+            if (S > INT32_MAX - 64) return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: matrix too large for 32-bit step indexing");
+            P.hub_g = G; P.hub_workers = hub_workers; P.n_hub_steps = S; P.n_hub_groups = (int64_t)hub_groups.size();
+            const int64_t row0 = row_part[br0];
+            P.hub_tiles.resize(hub_groups.size());
+            for (size_t gi = 0; gi < hub_groups.size(); gi++) {
+                HubTile t{{0, 0, 0, 0}, {0, 0, 0, 0}};
+                for (int k = 0; k < hub_groups[gi].n; k++) {
+                    const int64_t ib = hub_groups[gi].ib[k];
+                    t.c_row[k] = (int32_t)(row_part[ib] - row0); t.mt[k] = (int32_t)(row_part[ib + 1] - row_part[ib]);
+                    P.hub_area += nzcount[ib] * (row_part[ib + 1] - row_part[ib]) * w;
+                    P.n_hub_tiles++;
+                }
+                P.hub_union_area += (int64_t)un[gi].size() * w * 64 * hub_groups[gi].n;
+                P.hub_tiles[gi] = t;
+            }
+            std::vector<HubStep>& hs = P.hub_steps;
+            hs.resize((size_t)S + 32);
+            std::vector<int64_t> a_at((size_t)S + 1, 0);                                    // element offset of every step's first slice
+            for (int64_t q = 0; q < S; q++) a_at[(size_t)q + 1] = a_at[(size_t)q] + (int64_t)__builtin_popcount((unsigned)(uint8_t)un[(size_t)order[(size_t)q].g][(size_t)order[(size_t)q].u].mask) * 64 * 64;
+            for (int64_t q = 0; q < S; q++) {
+                const ORef& o = order[(size_t)q];
+                const UStep& x = un[(size_t)o.g][(size_t)o.u];
+                HubStep h;
+                h.a_lo = (uint32_t)a_at[(size_t)q]; h.a_hi = (uint32_t)(a_at[(size_t)q] >> 32);
+                h.b_row = (int32_t)((int64_t)x.jb * w + o.ks); h.shard = 0; h.flags = (int32_t)(uint8_t)x.mask; h.slot = -1; h.tile = o.g; h.pad = 0;
+                if (((int64_t)x.jb + 1) * w > cols) { h.flags |= STEP_TAIL; h.b_row = o.ks; }
+                hs[(size_t)q] = h;
+            }
+            // worker ranges: equal step counts, contiguous; position pos = XCD (pos / per_x) x place -> worker id x + 8 place
+            const int per_x = hub_workers / 8;
+            P.hub_wrange.assign((size_t)hub_workers * 2, 0);
+            std::vector<std::vector<std::pair<int64_t, int32_t>>> segs_of(hub_groups.size());       // per group: (first step of the segment in the group's own order, slot base)
+            int32_t next_id = (int32_t)fix_slots.size();
+            auto own_index = [&](int64_t q) { const ORef& o = order[(size_t)q]; return (int64_t)o.u * spb + o.ks / 64; };     // place of step q in its group's k order
+            for (int pos = 0; pos < hub_workers; pos++) {
+                const int64_t s0 = S * pos / hub_workers, s1 = S * (pos + 1) / hub_workers;
+                const int wid = (pos / per_x) + 8 * (pos % per_x);
+                P.hub_wrange[(size_t)wid * 2] = (int32_t)s0; P.hub_wrange[(size_t)wid * 2 + 1] = (int32_t)s1;
+                int64_t a = s0;
+                while (a < s1) {
+                    int64_t b = a;                                           // the run of consecutive steps of one group that starts at a
+                    while (b + 1 < s1 && order[(size_t)b + 1].g == order[(size_t)a].g && own_index(b + 1) == own_index(b) + 1) b++;
+                    const size_t gi = (size_t)order[(size_t)a].g;
+                    const bool whole = own_index(a) == 0 && own_index(b) == (int64_t)un[gi].size() * spb - 1;
+                    hs[(size_t)b].flags |= STEP_LAST;
+                    if (!whole) {
+                        hs[(size_t)b].flags |= STEP_SPLIT;
+                        hs[(size_t)b].slot = next_id;
+                        segs_of[gi].emplace_back(own_index(a), next_id);
+                        next_id += G;
+                    }
+                    a = b + 1;
+                }
+            }
+            for (size_t gi = 0; gi < hub_groups.size(); gi++) {
+                if (segs_of[gi].empty()) continue;
+                std::sort(segs_of[gi].begin(), segs_of[gi].end());           // a tile's images are added in k order, whatever worker made them
+                for (int k = 0; k < hub_groups[gi].n; k++) {
+                    fix.push_back(FixRec{P.hub_tiles[gi].c_row[k], P.hub_tiles[gi].mt[k], (int32_t)fix_slots.size(), (int32_t)segs_of[gi].size()});
+                    for (const auto& sg : segs_of[gi]) fix_slots.push_back(sg.second + k);
+                    n_split++;
+                }
+                for (int k = hub_groups[gi].n; k < G; k++)                   // (the images of the places a short group leaves empty: written by the kernel, read by nobody)
+                    for (const auto& sg : segs_of[gi]) fix_slots.push_back(sg.second + k);
+            }
+            for (int k = 0; k < 32; k++) { HubStep d = hs[(size_t)S - 1]; d.flags &= ~(STEP_LAST | STEP_SPLIT); d.slot = -1; hs[(size_t)S + k] = d; }
+            // the slices of A, in execution order: 64 rows x 64 k, element (row, k) at row * 64 + (((k / 8) ^ ((row / 2) & 7)) * 8 + k % 8 -- the LDS image of
+            // vbs_spmm_h16_hub_kernel (a ds_read_b128 of 16 rows covers all 64 banks); rows past the sub-tile's height zero
+            P.hub_a16.assign((size_t)a_at[(size_t)S], 0);
+            const bool bf = dtype == SPARTA_BF16;
+            uint16_t* all = P.hub_a16.data();
+            sparta::parallel_for_dynamic(S, 64, [&](int64_t lo, int64_t hi, int) {
+                for (int64_t q = lo; q < hi; q++) {
+                    const ORef& o = order[(size_t)q];
+                    const UStep& x = un[(size_t)o.g][(size_t)o.u];
+                    uint16_t* dst = all + a_at[(size_t)q];
+                    for (int k = 0; k < hub_groups[(size_t)o.g].n; k++) {
+                        if (!((x.mask >> k) & 1)) continue;
+                        const int64_t ib = hub_groups[(size_t)o.g].ib[k], hh = row_part[ib + 1] - row_part[ib];
+                        const float* blk = mab + mab_lo + mo_of[(size_t)(ib - br0)] + ((int64_t)x.bidx[k] * w + o.ks) * hh;     // column-major hh x w block, k slice o.ks
+                        for (int64_t kk = 0; kk < 64; kk++) {
+                            const float* colp = blk + kk * hh;
+                            for (int64_t rr = 0; rr < hh; rr++) dst[rr * 64 + ((((kk >> 3) ^ ((rr >> 1) & 7)) << 3) | (kk & 7))] = to_h16(colp[rr], bf);
+                        }
+                        dst += 64 * 64;
+                    }
+                }
+            });
         }
     }
 

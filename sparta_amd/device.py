@@ -124,6 +124,13 @@ class DeviceVBS:
         check(lib.sparta_vbs_sparse_info(self.h, a.ctypes.data_as(_i64p)))
         return {"rows": int(a[0]), "nnz": int(a[1]), "short_rows": int(a[2]), "hub_rows": int(a[3])}
 
+    def hub_info(self):
+        """the hub part of a 16-bit plan (group tiles of long 64-row tiles for the GEMM-shaped kernel): see sparta_vbs_hub_info"""
+        a = np.zeros(8, np.int64)
+        check(lib.sparta_vbs_hub_info(self.h, a.ctypes.data_as(_i64p)))
+        keys = ["steps", "tiles", "groups", "tiles_per_group", "stored_area", "union_area", "workers"]
+        return {k: int(a[i]) for i, k in enumerate(keys)}
+
     def spmm_host(self, B, n_cols, C_out, accumulate=True, algo=_lib.SPMM_MFMA, b_layout=_lib.COL_MAJOR,
                   c_layout=_lib.COL_MAJOR):
         """Host buffers in, host buffers out (the reference back-ends' contract). Returns kernel ms."""

@@ -1751,3 +1751,85 @@ def test_16bit_handles_take_leading_dimensions_of_2_to_the_23(monkeypatch, _spar
         d.spmm(Bt, Ct, n, ldb=ldb, ldc=ldc)
     del Bt, Ct
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("G", ["2", "4"])
+@pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("rows,cols,nnz,n,drop", [(640, 6400, 260000, 256, 0.0), (1000, 8191, 800000, 384, 0.3), (300, 12800, 400000, 512, 0.15), (832, 4096, 300000, 200, 0.5)])
+def test_16bit_hub_group_tiles_against_the_oracle(monkeypatch, _sparse_row_mode, G, dtype, rows, cols, nnz, n, drop):
+    """The hub plan of 16-bit handles of 64-wide blocks (vbs_plan.cpp, k_hub16.hip): long tiles of 33..64 rows grouped by the Jaccard similarity of their block
+    columns into group tiles of G, multiplied by the GEMM-shaped kernel over the UNION of the group's block columns -- a member without a block in a column is a
+    slice that is not fetched.  Against the oracle's product on the rounded inputs: groups of 2 and of 4 (and the short groups a count not divisible by G leaves),
+    blocks missing from some members (`drop`: whole blocks removed at random, so that the unions differ from their members), a partial last block-row (rows % 64),
+    a partial last block column (cols % 64: B_tail), N % 256 == 128 (a half slab), N % 128 != 0 (tail slab), both layouts of C, accumulate, a gathered B, split
+    segments (every plan here has them: the step list is ordered by K range) -- and the plan with the hub switched off gives the same product within the tolerance."""
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_HUB_G", G)
+    monkeypatch.setenv("SPARTA_HUB_MIN_TOTAL", "0")
+    monkeypatch.setenv("SPARTA_HUB_MIN_STEPS", "16")
+    monkeypatch.setenv("SPARTA_HUB_RANGES", "4")
+    monkeypatch.setenv("SPARTA_HUB_TAU", "0.25")        # (random halves of the block columns are a third alike)
+    w = 64
+    m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + cols + n)
+    if drop > 0.0:                                       # remove whole 64 x 64 blocks: the members of a group then own different block columns
+        rng = np.random.Generator(np.random.PCG64(rows + n))
+        keep_blk = rng.random(((rows + 63) // 64, (cols + 63) // 64)) >= drop
+        r_of = np.repeat(np.arange(m.rows), np.diff(m.rowptr))
+        keep = keep_blk[r_of // 64, m.colidx // 64]
+        rowptr = np.zeros(m.rows + 1, np.int64)
+        np.add.at(rowptr, r_of[keep] + 1, 1)
+        m = sa.CSR(m.rows, m.cols, np.cumsum(rowptr), m.colidx[keep].copy(), m.vals[keep].copy())
+    g = np.arange(rows) // 64
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    B = sa.gen.dense_rhs(v.cols, n, seed=5)
+    tdt = torch.float16 if dtype == sa.F16 else torch.bfloat16
+    ldb = (v.cols + 7) // 8 * 8
+    Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    Bt.view(n, ldb)[:, :v.cols] = torch.from_numpy(B.reshape(n, v.cols)).cuda().to(tdt)
+    world = 2
+    shard_rows = v.cols // world if v.cols % (world * w) == 0 else 0
+    Bg = None
+    if shard_rows:
+        Bg = torch.zeros(world * shard_rows * n, dtype=tdt, device="cuda")
+        for s_ in range(world):
+            Bg[s_ * shard_rows * n:(s_ + 1) * shard_rows * n].view(n, shard_rows)[:] = Bt.view(n, ldb)[:, s_ * shard_rows:(s_ + 1) * shard_rows]
+    outs = {}
+    for hub in ("1", "0"):
+        monkeypatch.setenv("SPARTA_HUB", hub)
+        d = v.to_device(0, dtype=dtype)
+        hi = d.hub_info()
+        if hub == "1":
+            assert hi["steps"] > 0 and hi["tiles_per_group"] == int(G) and hi["groups"] >= 1 and hi["tiles"] >= 2 * hi["groups"], hi
+            assert hi["union_area"] >= hi["stored_area"] > 0
+            if drop == 0.0 and rows % 64 == 0 and _sparse_row_mode == "mfma-only":
+                assert hi["tiles"] >= rows // 64 - 1, hi       # identical block columns: every tile finds a partner (one may be left over when G does not divide)
+        else:
+            assert hi["steps"] == 0
+        res = []
+        for cl, acc in ((sa.COL_MAJOR, False), (sa.ROW_MAJOR, False), (sa.COL_MAJOR, True)):
+            Ct = torch.full((v.rows * n,), 0.5, dtype=torch.float32, device="cuda")
+            d.spmm(Bt, Ct, n, ldb=ldb, c_layout=cl, accumulate=acc)
+            torch.cuda.synchronize()
+            res.append(Ct.cpu().numpy())
+        if Bg is not None:
+            Ct = torch.full((v.rows * n,), 0.5, dtype=torch.float32, device="cuda")
+            d.spmm_gathered(Bg, shard_rows, Ct, n)
+            torch.cuda.synchronize()
+            res.append(Ct.cpu().numpy())
+        # twice the same bits (no atomics, fixed order of the partial images)
+        Ct = torch.full((v.rows * n,), 0.5, dtype=torch.float32, device="cuda")
+        d.spmm(Bt, Ct, n, ldb=ldb)
+        torch.cuda.synchronize()
+        assert np.array_equal(Ct.cpu().numpy(), res[0])
+        outs[hub] = res
+        d.close()
+    mab_r, B_r = _round16(v.mab, dtype), _round16(B, dtype)
+    Co = O.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n, None)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, mab_r, B_r, n)
+    for hub in ("1", "0"):
+        o = outs[hub]
+        _check(o[0], Co, bound, "hub %s, column-major C" % hub)
+        _check(np.ascontiguousarray(o[1].reshape(v.rows, n).T).reshape(-1), Co, bound, "hub %s, row-major C" % hub)
+        _check(o[2], Co + 0.5, bound + 0.5, "hub %s, accumulate" % hub)
+        if Bg is not None:
+            _check(o[3], Co, bound, "hub %s, gathered B" % hub)
