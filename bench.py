@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--slabs", type=int, default=8,
                     help="rmat-part on ONE GPU: the P parts of the P-rank job one after the other (the N = 1 comparator of --gpus P; a power of two)")
     ap.add_argument("--slab-sample", type=int, default=0, help="rmat-part on one GPU: run only this many of the --slabs parts (part 0 + a seeded choice), total extrapolated by cost")
+    ap.add_argument("--pad-b", type=int, default=1,
+                    help="rmat-part: 1 (default) = the columns of a rank's slab of B lie shard_rows + 64 elements apart when shard_rows is a multiple of 4 KB (columns a large power of two "
+                         "apart share cache sets and memory channels: sparta_vbs_spmm_gathered_ld); 0 = the plain all-gather layout")
     ap.add_argument("--ag-chunks", type=int, default=1,
                     help="rmat-part, N > 1: all-gather + product in this many column chunks, the collective of the next chunk overlapped with the kernels of this one "
                          "(1 = north_star's single all-gather per step; the chunked step is checked bit for bit against it)")

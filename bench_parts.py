@@ -79,15 +79,22 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
     my_parts = [rank] if distributed else choose_parts(P, args.slab_sample, part_cost)
 
     # ---- B: canonical rows, held as the all-gather of P ranks leaves it (P column-major slabs of shard_rows x N) ------------
-    B_gath = torch.empty(P * shard_rows * N, dtype=tdt, device=dev)
+    # The columns of a slab lie shard_ld = shard_rows + 64 elements apart when shard_rows is a multiple of a large power of two (columns exactly 256 KB .. 2 MB
+    # apart share cache sets and memory channels: the hub kernel 0.80 -> 1.05 PFLOP/s with the padding); the padding travels with the shards.
+    shard_ld = sa.dist.padded_shard_ld(shard_rows, esz) if getattr(args, "pad_b", 1) else shard_rows
+    B_gath = torch.zeros(P * shard_ld * N, dtype=tdt, device=dev)
+
+    def shard_of(s_):
+        t_ = torch.zeros(N * shard_ld, dtype=tdt, device=dev)
+        t_.view(N, shard_ld)[:, :shard_rows] = gen.dense_rhs_rows(s_ * shard_rows, (s_ + 1) * shard_rows, N, seed=7, dtype=tdt, device=local_rank).view(N, shard_rows)
+        return t_
     B_shard = None
     if distributed:
-        B_shard = gen.dense_rhs_rows(rank * shard_rows, (rank + 1) * shard_rows, N, seed=7, dtype=tdt, device=local_rank)
+        B_shard = shard_of(rank)
         dist.all_gather_into_tensor(B_gath, B_shard)
     else:
         for s_ in range(P):
-            B_gath[s_ * shard_rows * N:(s_ + 1) * shard_rows * N] = gen.dense_rhs_rows(s_ * shard_rows, (s_ + 1) * shard_rows, N, seed=7, dtype=tdt,
-                                                                                       device=local_rank)
+            B_gath[s_ * shard_ld * N:(s_ + 1) * shard_ld * N] = shard_of(s_)
     gather_pick, gather_mode = None, "all_gather"
     if distributed and world > 1:
         if args.gather == "auto" and args.backend == "nccl":
@@ -145,27 +152,27 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
         if K_ag > 1 and (N % (128 * K_ag) != 0 or gather_mode == "peer_copies"):
             K_ag = 1
         Nc = N // K_ag
-        B_gath_c = [torch.empty(P * shard_rows * Nc, dtype=tdt, device=dev) for _ in range(K_ag)] if K_ag > 1 else None
+        B_gath_c = [torch.empty(P * shard_ld * Nc, dtype=tdt, device=dev) for _ in range(K_ag)] if K_ag > 1 else None
 
         def step():
             if K_ag > 1:
-                works = [dist.all_gather_into_tensor(B_gath_c[c_], B_shard[c_ * Nc * shard_rows:(c_ + 1) * Nc * shard_rows], async_op=True) for c_ in range(K_ag)]
+                works = [dist.all_gather_into_tensor(B_gath_c[c_], B_shard[c_ * Nc * shard_ld:(c_ + 1) * Nc * shard_ld], async_op=True) for c_ in range(K_ag)]
                 for c_ in range(K_ag):
                     works[c_].wait()                                  # the compute stream waits for chunk c_ only
-                    d.spmm_gathered(B_gath_c[c_], shard_rows, C[c_ * Nc * rows_c:(c_ + 1) * Nc * rows_c], Nc, accumulate=False)
+                    d.spmm_gathered(B_gath_c[c_], shard_rows, C[c_ * Nc * rows_c:(c_ + 1) * Nc * rows_c], Nc, accumulate=False, shard_ld=shard_ld)
                 return
             if distributed and world > 1:
                 if gather_mode == "peer_copies":
                     sa.dist.allgather_B_peer_copies(B_shard, B_gath, rank, world)
                 else:
                     dist.all_gather_into_tensor(B_gath, B_shard)
-            d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False)
+            d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False, shard_ld=shard_ld)
 
         step()                                   # plan time (autotune of the MFMA path, scratch sizing): not a timed step
         fence()
         if K_ag > 1:                             # the chunked step must give the bits of the one-collective step
             C_one = torch.empty_like(C)
-            d.spmm_gathered(B_gath, shard_rows, C_one, N, accumulate=False)
+            d.spmm_gathered(B_gath, shard_rows, C_one, N, accumulate=False, shard_ld=shard_ld)
             torch.cuda.synchronize()
             same = torch.tensor([1.0 if torch.equal(C_one, C) else 0.0], device=dev)
             dist.all_reduce(same, op=dist.ReduceOp.MIN)
@@ -188,7 +195,7 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
                     worst = max(worst, float(np.abs(got).max()))
                     continue
                 a = torch.from_numpy(np.ascontiguousarray(m.vals[m.rowptr[i]:m.rowptr[i + 1]])).to(tdt).float().numpy().astype(np.float64)
-                bb = sa.dist.gathered_rows(B_gath, cols_i, P, shard_rows, N)
+                bb = sa.dist.gathered_rows(B_gath, cols_i, P, shard_rows, N, shard_ld)
                 want = bb @ a
                 scale_ = np.abs(bb) @ np.abs(a) + 1e-30
                 worst = max(worst, float((np.abs(got - want) / scale_).max()))
@@ -228,7 +235,7 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
         d.set_class_timing(True)
         kt = {}
         for _ in range(min(max(args.steps, 3), 10)):
-            d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False)
+            d.spmm_gathered(B_gath, shard_rows, C, N, accumulate=False, shard_ld=shard_ld)
             for k_, v_ in d.class_times().items():
                 kt.setdefault(k_, []).append(v_)
         d.set_class_timing(False)
@@ -299,7 +306,9 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
     if not args.no_cpu_baseline and last is not None:
         m, grouping, rbs = last
         try:
-            cpu = cpu_baseline(sa, args, m, grouping, None, w, rbs, False, N, None, n, B_gath, P, shard_rows, True, h16, torch)
+            B_plain = B_gath if shard_ld == shard_rows else B_gath.view(P, N, shard_ld)[:, :, :shard_rows].contiguous().view(-1)     # (the CPU baseline reads the unpadded layout)
+            cpu = cpu_baseline(sa, args, m, grouping, None, w, rbs, False, N, None, n, B_plain, P, shard_rows, True, h16, torch)
+            del B_plain
         except Exception as e:
             cpu = {"value": None, "unit": "GFLOP/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
     comparator = None
@@ -316,7 +325,7 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
            "warmup": args.warmup, "ms_per_step": round(ms_job, 5), "higher_is_better": True, "scaling": "strong" if distributed else None,
            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": wl + (", 1 all-gather of B per step" if distributed else ", %d parts streamed through one GPU" % P),
-                      "density": args.rmat_density, "n_cols": N, "col_block_size": w, "parts": P, "raw_edges": int(E),
+                      "density": args.rmat_density, "n_cols": N, "col_block_size": w, "parts": P, "raw_edges": int(E), "b_shard_ld": int(shard_ld), "b_shard_rows": int(shard_rows),
                       "reorder": {"off": "fixed height %d per part (reference flags -a 2 -F 1)" % (args.fixed_height or 64),
                                   "on": "LSH-bucketed Jaccard clustering per part (blocking_algo 7, tau %.2f)" % args.tau,
                                   "auto": "clustering per part, kept only where its predicted product time beats the fixed grid's"}[args.reorder],

@@ -314,6 +314,13 @@ int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layou
  * No reference counterpart (the reference is single-GPU: SURVEY.md section 2.1). */
 int sparta_vbs_spmm_gathered(sparta_vbs_t* A, const void* B_gathered, int64_t shard_rows, int64_t shard_stride, int32_t n_cols,
                              void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, void* stream, int32_t algo, float* dt_ms);
+/* the same with the columns of a slab `shard_ld` >= shard_rows elements apart (sparta_vbs_spmm_gathered: shard_ld = shard_rows; 16-bit handles: shard_ld even).
+ * Why: a leading dimension that is a multiple of a large power of two -- 2^20 rows of a 16-bit B: columns exactly 2 MB apart -- maps the columns of a panel of B
+ * onto the same cache sets and memory channels: the hub kernel of a 16-bit handle measured 0.80 PFLOP/s with such a B and 1.05 with 64 elements of padding per
+ * column (MI355X).  Pad the ranks' shard buffers before the all-gather (bench_parts.py does); for sparta_vbs_spmm the same advice holds for
+ * ldb.  No reference counterpart (single-GPU). */
+int sparta_vbs_spmm_gathered_ld(sparta_vbs_t* A, const void* B_gathered, int64_t shard_rows, int64_t shard_ld, int64_t shard_stride, int32_t n_cols,
+                                void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, void* stream, int32_t algo, float* dt_ms);
 
 /* Multi-GPU, sparsity-aware exchange: gathers chunks of `block_bytes` bytes (a multiple of 16; one chunk = one
  * block_col_size x n_cols tile of B in the row-block-tiled layout) from `src` into consecutive chunks of `dst`:

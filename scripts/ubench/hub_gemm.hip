@@ -34,10 +34,10 @@ __global__ void fill_a(uint16_t* A, int64_t n_el, int S, int G) {        // imag
         A[e] = to_bf16(a_val((uint32_t)((G * t + u) * 64 + row), (uint32_t)(s * KP + 8 * c + kk)));
     }
 }
-__global__ void fill_b(uint16_t* B, int64_t K, int N) {
+__global__ void fill_b(uint16_t* B, int64_t K, int N, int64_t ldb) {
     const int64_t n_el = K * N;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_el; e += (int64_t)gridDim.x * blockDim.x)
-        B[e] = to_bf16(b_val((uint32_t)(e % K), (uint32_t)(e / K)));
+        B[(e % K) + (e / K) * ldb] = to_bf16(b_val((uint32_t)(e % K), (uint32_t)(e / K)));
 }
 // C[rows of sub-tile][128-column slab] = sum of its images (in order), the layout of SK_SLOT_FLOATS images
 __global__ void naive_fix(const int32_t* fix, const int32_t* slots, const float* ws, int64_t ws_slab_stride, float* C, int64_t ldc) {
@@ -69,11 +69,12 @@ int main(int argc, char** argv) {
     float *dC, *dWs = nullptr;
     CK(hipMalloc(&dA, (n_a + pad_a) * 2));
     CK(hipMemset(dA, 0, (n_a + pad_a) * 2));
-    CK(hipMalloc(&dB, K * N * 2));
+    const int64_t ldb = getenv("HUB_LDB") ? atoll(getenv("HUB_LDB")) : K;      // developer: a leading dimension larger than K (the page pattern of a taller B)
+    CK(hipMalloc(&dB, ldb * N * 2));
     CK(hipMalloc(&dC, rows * N * 4));
     if (KP == 64) hipLaunchKernelGGL(fill_a<64>, dim3(4096), dim3(256), 0, 0, dA, n_a, S, G);
     else hipLaunchKernelGGL(fill_a<32>, dim3(4096), dim3(256), 0, 0, dA, n_a, S, G);
-    hipLaunchKernelGGL(fill_b, dim3(4096), dim3(256), 0, 0, dB, K, N);
+    hipLaunchKernelGGL(fill_b, dim3(4096), dim3(256), 0, 0, dB, K, N, ldb);
     CK(hipDeviceSynchronize());
 
     // developer: every step reads one of 64 panels of B / one of 256 slices of A (cache-hot operands: what do the loads cost when nothing misses?); results wrong
@@ -94,7 +95,7 @@ int main(int argc, char** argv) {
         h.b_row = same_b ? (ts.second % 64) * KP : ts.second * KP; h.shard = 0; h.flags = (1 << G) - 1; h.slot = -1; h.tile = ts.first; h.pad = 0;
         steps[(size_t)q] = h;
     }
-    // worker ranges: position pos = XCD (pos / (P / 8)) x place -> worker id xcd + 8 place; equal contiguous cut
+    // worker ranges in plan order (the kernel maps workgroup ids to it); equal contiguous cut
     std::vector<int32_t> wr((size_t)P * 2);
     std::vector<int64_t> bnd((size_t)P + 1);
     for (int k = 0; k <= P; k++) bnd[(size_t)k] = U * k / P;
@@ -103,8 +104,7 @@ int main(int argc, char** argv) {
     std::vector<std::vector<int32_t>> tile_slots((size_t)T);
     int32_t n_slots = 0;
     for (int pos = 0; pos < P; pos++) {
-        const int x = pos / (P / 8), j = pos % (P / 8);
-        wr[(size_t)(x + 8 * j) * 2] = (int32_t)bnd[(size_t)pos]; wr[(size_t)(x + 8 * j) * 2 + 1] = (int32_t)bnd[(size_t)pos + 1];
+        wr[(size_t)pos * 2] = (int32_t)bnd[(size_t)pos]; wr[(size_t)pos * 2 + 1] = (int32_t)bnd[(size_t)pos + 1];
         int64_t a = bnd[(size_t)pos];
         while (a < bnd[(size_t)pos + 1]) {
             // the run of steps of one tile with consecutive step numbers that starts at a
@@ -142,7 +142,7 @@ int main(int argc, char** argv) {
     }
     HubParams p{};
     p.steps = dS; p.worker_range = dW; p.tiles = dT; p.A = dA; p.B = dB; p.B_tail = nullptr; p.C = dC; p.ws = dWs;
-    p.ldb = K; p.ldc = rows; p.shard_stride = 0; p.ws_slab_stride = slab_stride; p.accumulate = 0; p.c_row_major = 0; p.c_nt = 1; p.w = 64;
+    p.ldb = ldb; p.ldc = rows; p.shard_stride = 0; p.ws_slab_stride = slab_stride; p.accumulate = 0; p.c_row_major = 0; p.c_nt = 1; p.w = 64;
     p.n_slabs = N / 256; p.n_workers = P; p.n_cols = N;
 
     hipEvent_t e0, e1;

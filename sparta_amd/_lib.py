@@ -31,7 +31,7 @@ SYMBOLS = [
     "sparta_reorder_cfg_default", "sparta_reorder", "sparta_get_permutation", "sparta_get_partition",
     "sparta_get_fixed_size_grouping", "sparta_row_distance", "sparta_merge_rows", "sparta_vbs_build",
     "sparta_vbs_host_free", "sparta_blocking_info", "sparta_vbs_create", "sparta_vbs_create_range", "sparta_vbs_create_from_csr",
-    "sparta_vbs_spmm", "sparta_vbs_spmm_gathered", "sparta_pack_blocks", "sparta_vbs_create_transposed", "sparta_vbs_spmm_ba", "sparta_vbs_set_class_timing",
+    "sparta_vbs_spmm", "sparta_vbs_spmm_gathered", "sparta_vbs_spmm_gathered_ld", "sparta_pack_blocks", "sparta_vbs_create_transposed", "sparta_vbs_spmm_ba", "sparta_vbs_set_class_timing",
     "sparta_vbs_class_times", "sparta_vbs_clock_mhz", "sparta_vbs_destroy", "sparta_vbs_info", "sparta_vbs_sparse_info", "sparta_vbs_hub_info", "sparta_device_count", "sparta_last_error",
     "sparta_version",
     "sparta_csr_read", "sparta_csr_read_buffer", "sparta_csr_host_free", "sparta_csr_write_edgelist", "sparta_grouping_write", "sparta_grouping_read",
@@ -124,6 +124,7 @@ def _load():
     L.sparta_vbs_spmm.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp,
                                   C.c_int32, f32p]
     L.sparta_vbs_spmm_gathered.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int32, vp, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int32, f32p]
+    L.sparta_vbs_spmm_gathered_ld.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, vp, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int32, f32p]
     L.sparta_pack_blocks.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, vp]
     L.sparta_vbs_set_class_timing.argtypes = [vp, C.c_int32]
     L.sparta_vbs_class_times.argtypes = [vp, f32p]

@@ -69,10 +69,17 @@ __global__ __launch_bounds__(64 * 2 * G * (LW ? 2 : 1), (G / 2) * (LW ? 2 : 1) *
     const int wave = wave_id % NWV;                      // place among the compute (or the loader) waves
     const int wr = wave >> 1, wc = wave & 1;
     const int lm = lane & 31, g = lane >> 5;
-    // workgroup id -> (worker, slab): the slabs of a worker are neighbours on ONE XCD (ids 8 apart), so that they start together and the second one finds
-    // the slices of A in that XCD's L2
+    // workgroup id -> (worker, slab).  Workgroups are dealt round-robin over the 8 XCDs (id & 7) and start in id order, one per CU.  (1) the slabs of a worker are
+    // neighbours on ONE XCD (ids 8 apart): they start together and the second one finds the slices of A in that XCD's L2; (2) the workers that run at the SAME TIME are
+    // a contiguous block of the plan's worker order -- the plan puts the workers that walk the same rows of B next to each other (vbs_plan.cpp, chunk-major units) --
+    // and inside the block an XCD holds consecutive ones: round r of the dispatch = workers [r * 8 rq, (r + 1) * 8 rq), XCD x the rq = (CUs per XCD) / slabs from x * rq on
     const int xcd = (int)blockIdx.x & 7, jj = (int)blockIdx.x >> 3;
-    const int slab = jj % p.n_slabs, worker = (jj / p.n_slabs) * 8 + xcd;
+    const int slab = jj % p.n_slabs, qx = jj / p.n_slabs;                    // qx: this worker's place among its XCD's workers, in dispatch order
+    const int per_x = p.n_workers >> 3;
+    const int rq = per_x / p.n_slabs > 0 ? per_x / p.n_slabs : 1;
+    const int round = qx / rq;
+    const int rq_here = per_x - round * rq < rq ? per_x - round * rq : rq;   // (the last round may be short)
+    const int worker = round * 8 * rq + xcd * rq_here + (qx - round * rq);
     const int s_begin = p.worker_range[2 * worker];
     const int n = p.worker_range[2 * worker + 1] - s_begin;
     if (n <= 0) return;

@@ -1097,9 +1097,13 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
     if (int rc = ensure_scratch(&A->d_Bt, &A->d_Bt_bytes, bt_elems * sizeof(uint16_t))) return rc;
     if (int rc = ensure_scratch(&A->d_Ct, &A->d_Ct_bytes, (size_t)A->rows * kTN * sizeof(float))) return rc;
     HIP_TRY(hipMemsetAsync(A->d_Bt, 0, bt_elems * sizeof(uint16_t), st));
-    if (shard_rows > 0)
+    if (shard_rows > 0 && ldb16 == shard_rows)
         HIP_TRY(hipMemcpy2DAsync(A->d_Bt, (size_t)shard_rows * kTN * sizeof(uint16_t), dB + (size_t)n_main * shard_rows, (size_t)shard_stride * sizeof(uint16_t),
                                  (size_t)n_t * shard_rows * sizeof(uint16_t), (size_t)n_shards, hipMemcpyDeviceToDevice, st));
+    else if (shard_rows > 0)                                  // columns of a slab ldb16 > shard_rows apart (sparta_vbs_spmm_gathered_ld): one 2-D copy per slab
+        for (int64_t sh = 0; sh < n_shards; sh++)
+            HIP_TRY(hipMemcpy2DAsync((uint16_t*)A->d_Bt + (size_t)sh * shard_rows * kTN, (size_t)shard_rows * sizeof(uint16_t), dB + (size_t)sh * shard_stride + (size_t)n_main * ldb16,
+                                     (size_t)ldb16 * sizeof(uint16_t), (size_t)shard_rows * sizeof(uint16_t), (size_t)n_t, hipMemcpyDeviceToDevice, st));
     else
         HIP_TRY(hipMemcpyAsync(A->d_Bt, dB + (size_t)n_main * ldb16, (size_t)n_t * ldb16 * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
     if (int rc = spmm16_core(A, A->d_Bt, ld_t, b_layout, shard_rows, shard_rows > 0 ? shard_rows * kTN : 0, kTN, A->d_Ct, A->rows, SPARTA_COL_MAJOR, 0,
@@ -1331,18 +1335,25 @@ int sparta_vbs_spmm(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layou
     SPARTA_GUARD_END("sparta_vbs_spmm")
 }
 
-int sparta_vbs_spmm_gathered(sparta_vbs_t* A, const void* B_gathered, int64_t shard_rows, int64_t shard_stride, int32_t n_cols,
-                             void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, void* stream, int32_t algo, float* dt_ms) {
+int sparta_vbs_spmm_gathered_ld(sparta_vbs_t* A, const void* B_gathered, int64_t shard_rows, int64_t shard_ld, int64_t shard_stride, int32_t n_cols,
+                                void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, void* stream, int32_t algo, float* dt_ms) {
     using sparta::fail;
     if (!A) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: NULL handle");
     if (shard_rows <= 0 || shard_rows % A->w != 0)
         return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: shard_rows must be a positive multiple of block_col_size");
-    if (shard_stride < shard_rows * (int64_t)n_cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: shard_stride too small");
+    if (shard_ld < shard_rows) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: shard_ld must be >= shard_rows");
+    if (shard_stride < shard_ld * (int64_t)(n_cols - 1) + shard_rows) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: shard_stride too small");
     if (A->cols % shard_rows != 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: cols must be n_shards * shard_rows");
     SPARTA_GUARD_BEGIN
-    return spmm_impl(A, B_gathered, shard_rows, SPARTA_COL_MAJOR, shard_rows, shard_stride, n_cols, C, ldc, c_layout, accumulate,
+    return spmm_impl(A, B_gathered, shard_ld, SPARTA_COL_MAJOR, shard_rows, shard_stride, n_cols, C, ldc, c_layout, accumulate,
                      SPARTA_PTR_DEVICE, stream, algo, dt_ms);
     SPARTA_GUARD_END("sparta_vbs_spmm_gathered")
+}
+
+int sparta_vbs_spmm_gathered(sparta_vbs_t* A, const void* B_gathered, int64_t shard_rows, int64_t shard_stride, int32_t n_cols,
+                             void* C, int64_t ldc, int32_t c_layout, int32_t accumulate, void* stream, int32_t algo, float* dt_ms) {
+    if (shard_rows > 0 && shard_stride < shard_rows * (int64_t)n_cols) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_gathered: shard_stride too small");
+    return sparta_vbs_spmm_gathered_ld(A, B_gathered, shard_rows, shard_rows, shard_stride, n_cols, C, ldc, c_layout, accumulate, stream, algo, dt_ms);
 }
 
 // ---- a B that does not change between products, prepared once ------------------------------------------------------------

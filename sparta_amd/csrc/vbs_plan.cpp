@@ -636,9 +636,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             const int G = hub_G;
             const int64_t block_cols = (cols - 1) / w + 1, spb = w / 64;                    // steps per block
             const int hub_workers = P.n_workers;                                            // one workgroup per CU and 256-column slab
-            int64_t n_ranges = 16;                                                          // K ranges (SPARTA_HUB_RANGES): the step list is ordered (range, group, k), so that
-            if (const char* e = std::getenv("SPARTA_HUB_RANGES")) n_ranges = atoll(e);      // the workers of an XCD walk the same rows of B at about the same time
-            n_ranges = std::max<int64_t>(1, std::min(n_ranges, block_cols));
+            int64_t n_ranges = 16;                                                          // K chunks of the step order, chosen below
             struct UStep { int32_t jb; int8_t mask; int32_t bidx[kHubGMax]; };              // one block column of a group's union: who has a block there, and which
             std::vector<std::vector<UStep>> un(hub_groups.size());
             sparta::parallel_for_dynamic((int64_t)hub_groups.size(), 1, [&](int64_t lo, int64_t hi, int) {
@@ -657,9 +655,68 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                     }
                 }
             });
-            // order: (K range, group, block column, k slice)
+            // ---- the order of the step list and the cut into worker ranges.  Units = (K chunk, group): the steps of one group tile whose block columns lie in one
+            // of C equal ranges of block columns.  The list is chunk-major -- (chunk, group, block column, k slice) -- and the workers take WHOLE units, in that order:
+            // the workgroups that run at the same time then walk the same rows of B from the same place on, one group each: the first to touch a panel takes the miss,
+            // the others hit in the L2s / the Infinity Cache (a panel is 32 KB per 64 rows of B; the B of the power-law configs is 1-4 GB).  C is chosen so that whole
+            // units balance (each worker close to 1 / P of the steps); when no C does (makespan more than 10 % above the mean) the cut is by step count anywhere.
+            // SPARTA_HUB_RANGES = C forces the chunk count AND the cut by step count (the first form of this plan, kept for A/B runs).
+            int64_t total_union = 0;
+            for (const auto& u : un) total_union += (int64_t)u.size();
+            const int64_t S_all = total_union * spb;
+            auto unit_sizes = [&](int64_t C, std::vector<int64_t>& cost) {          // steps of unit (chunk c, group g) at [c * groups + g]
+                cost.assign((size_t)(C * (int64_t)hub_groups.size()), 0);
+                for (size_t gi = 0; gi < hub_groups.size(); gi++) {
+                    size_t c0 = 0;
+                    for (int64_t c = 0; c < C; c++) {
+                        const int64_t jb_end = (c + 1) * block_cols / C;
+                        size_t c1 = c0;
+                        while (c1 < un[gi].size() && un[gi][c1].jb < jb_end) c1++;
+                        cost[(size_t)(c * (int64_t)hub_groups.size()) + gi] = (int64_t)(c1 - c0) * spb;
+                        c0 = c1;
+                    }
+                }
+            };
+            auto aligned_cut = [&](const std::vector<int64_t>& cost, std::vector<int64_t>* bnd_out) -> int64_t {      // greedy: consecutive whole units per worker
+                const double T = (double)S_all / (double)hub_workers;
+                int64_t worst = 0, load = 0, at = 0;
+                int wk = 0;
+                if (bnd_out) { bnd_out->assign((size_t)hub_workers + 1, S_all); (*bnd_out)[0] = 0; }
+                for (size_t q = 0; q < cost.size(); q++) {
+                    if (cost[q] == 0) continue;
+                    if (load > 0 && (double)load + 0.5 * (double)cost[q] > T && wk + 1 < hub_workers) {
+                        worst = std::max(worst, load); load = 0; wk++;
+                        if (bnd_out) (*bnd_out)[(size_t)wk] = at;
+                    }
+                    load += cost[q]; at += cost[q];
+                }
+                return std::max(worst, load);
+            };
+            int64_t forced_ranges = -1;
+            if (const char* e = std::getenv("SPARTA_HUB_RANGES")) forced_ranges = std::max<int64_t>(1, atoll(e));
+            int64_t best_C = 16;
+            bool cut_aligned = false;
+            std::vector<int64_t> wbnd;                                       // worker boundaries in steps (aligned cut)
+            if (forced_ranges > 0) best_C = std::min(forced_ranges, block_cols);
+            else {
+                int64_t best_span = INT64_MAX;
+                std::vector<int64_t> cost;
+                for (int64_t C = 1; C <= std::min<int64_t>(64, block_cols); C++) {
+                    unit_sizes(C, cost);
+                    const int64_t span = aligned_cut(cost, nullptr);
+                    if (span < best_span) { best_span = span; best_C = C; }
+                }
+                if ((double)best_span <= 1.10 * (double)S_all / (double)hub_workers + 1.0) {
+                    cut_aligned = true;
+                    unit_sizes(best_C, cost);
+                    aligned_cut(cost, &wbnd);
+                } else best_C = std::min<int64_t>(16, block_cols);
+            }
+            n_ranges = best_C;
+            // order: (K chunk, group, block column, k slice)
             struct ORef { int32_t g, u, ks; };
             std::vector<ORef> order;
+            order.reserve((size_t)S_all);
             {
                 std::vector<size_t> cur(hub_groups.size(), 0);
                 for (int64_t r = 0; r < n_ranges; r++) {
@@ -699,15 +756,14 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                 if (((int64_t)x.jb + 1) * w > cols) { h.flags |= STEP_TAIL; h.b_row = o.ks; }
                 hs[(size_t)q] = h;
             }
-            // worker ranges: equal step counts, contiguous; position pos = XCD (pos / per_x) x place -> worker id x + 8 place
-            const int per_x = hub_workers / 8;
+            // worker ranges, in plan order (the kernel maps workgroup ids to this order so that the workers that run at the same time are neighbours here)
             P.hub_wrange.assign((size_t)hub_workers * 2, 0);
             std::vector<std::vector<std::pair<int64_t, int32_t>>> segs_of(hub_groups.size());       // per group: (first step of the segment in the group's own order, slot base)
             int32_t next_id = (int32_t)fix_slots.size();
             auto own_index = [&](int64_t q) { const ORef& o = order[(size_t)q]; return (int64_t)o.u * spb + o.ks / 64; };     // place of step q in its group's k order
             for (int pos = 0; pos < hub_workers; pos++) {
-                const int64_t s0 = S * pos / hub_workers, s1 = S * (pos + 1) / hub_workers;
-                const int wid = (pos / per_x) + 8 * (pos % per_x);
+                const int64_t s0 = cut_aligned ? wbnd[(size_t)pos] : S * pos / hub_workers, s1 = cut_aligned ? wbnd[(size_t)pos + 1] : S * (pos + 1) / hub_workers;
+                const int wid = pos;
                 P.hub_wrange[(size_t)wid * 2] = (int32_t)s0; P.hub_wrange[(size_t)wid * 2 + 1] = (int32_t)s1;
                 int64_t a = s0;
                 while (a < s1) {

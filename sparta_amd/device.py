@@ -172,16 +172,18 @@ class DeviceVBS:
         return dt.value if timed else None
 
     def spmm_gathered(self, B_gathered, shard_rows, C_out, n_cols, accumulate=False, algo=_lib.SPMM_MFMA,
-                      c_layout=_lib.COL_MAJOR, shard_stride=None, timed=False, stream=None):
-        """Multi-GPU entry: B_gathered is the all-gather result (n_shards column-major slabs of shard_rows x n_cols)."""
+                      c_layout=_lib.COL_MAJOR, shard_stride=None, timed=False, stream=None, shard_ld=None):
+        """Multi-GPU entry: B_gathered is the all-gather result (n_shards column-major slabs of shard_rows x n_cols; shard_ld: elements between the columns of a
+        slab, default shard_rows -- pad it when shard_rows is a multiple of a large power of two: sparta_vbs_spmm_gathered_ld)."""
         import torch
         want_b = {_lib.F32: torch.float32, _lib.F16: torch.float16, _lib.BF16: torch.bfloat16}[self.dtype]
         if not (B_gathered.is_cuda and C_out.is_cuda and B_gathered.dtype == want_b and C_out.dtype == torch.float32):
             raise ValueError("B_gathered must be a %s tensor and C a float32 tensor, both on the GPU" % want_b)
         if B_gathered.device.index != self.device or C_out.device.index != self.device:
             raise ValueError("B_gathered and C must live on device %d" % self.device)
-        shard_stride = shard_rows * n_cols if shard_stride is None else shard_stride
-        if B_gathered.numel() < (self.cols // shard_rows) * shard_stride:
+        shard_ld = shard_rows if shard_ld is None else int(shard_ld)
+        shard_stride = shard_ld * n_cols if shard_stride is None else shard_stride
+        if B_gathered.numel() < (self.cols // shard_rows - 1) * shard_stride + shard_ld * (n_cols - 1) + shard_rows:
             raise ValueError("B_gathered too small")
         ldc = self.rows if c_layout == _lib.COL_MAJOR else n_cols
         need_c = ldc * (n_cols if c_layout == _lib.COL_MAJOR else self.rows)
@@ -189,9 +191,9 @@ class DeviceVBS:
             raise ValueError("C too small / B_gathered or C not contiguous")
         st = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
         dt = C.c_float(0)
-        check(lib.sparta_vbs_spmm_gathered(self.h, C.c_void_p(B_gathered.data_ptr()), int(shard_rows), int(shard_stride), int(n_cols),
-                                           C.c_void_p(C_out.data_ptr()), int(ldc), c_layout, int(bool(accumulate)), C.c_void_p(st),
-                                           int(algo), C.byref(dt) if timed else None))
+        check(lib.sparta_vbs_spmm_gathered_ld(self.h, C.c_void_p(B_gathered.data_ptr()), int(shard_rows), int(shard_ld), int(shard_stride), int(n_cols),
+                                              C.c_void_p(C_out.data_ptr()), int(ldc), c_layout, int(bool(accumulate)), C.c_void_p(st),
+                                              int(algo), C.byref(dt) if timed else None))
         return dt.value if timed else None
 
     def prepare_b(self, B, n_cols, ldb=None, shard_rows=0, shard_stride=None, stream=None):

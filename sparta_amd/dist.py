@@ -64,13 +64,20 @@ def row_slab(cmat, rows, n_cols=None):
     return CSR(len(rows), int(cmat.cols if n_cols is None else n_cols), rowptr, colidx, vals)
 
 
-def gathered_rows(B_gathered, row_ids, world_size, shard_rows, n_cols):
+def gathered_rows(B_gathered, row_ids, world_size, shard_rows, n_cols, shard_ld=None):
     """(checks) rows `row_ids` of B out of the gathered device buffer: returns an n_cols x len(row_ids) float64 numpy array"""
     import torch
     ids = torch.as_tensor(np.asarray(row_ids, np.int64), device=B_gathered.device)
-    g = B_gathered.view(world_size, n_cols, shard_rows)                      # slab s, column j, local row
+    shard_ld = shard_rows if shard_ld is None else shard_ld
+    g = B_gathered.view(world_size, n_cols, shard_ld)                        # slab s, column j, local row (rows past shard_rows: padding)
     out = g[ids // shard_rows, :, ids % shard_rows]                          # len(ids) x n_cols
     return out.float().cpu().numpy().astype(np.float64).T
+
+
+def padded_shard_ld(shard_rows, elem_bytes):
+    """elements between the columns of a rank's slab of B: shard_rows, plus 64 when the columns would lie a multiple of 4 KB apart -- columns a large power of
+    two apart fall onto the same cache sets and memory channels (a panel of B is 8..16 columns per load instruction): sparta_vbs_spmm_gathered_ld, DESIGN.md 12"""
+    return int(shard_rows) + (64 if (int(shard_rows) * int(elem_bytes)) % 4096 == 0 else 0)
 
 
 def padded_shard_rows(n_local, block_col_size):
