@@ -397,6 +397,8 @@ def main():
     elif not distributed:
         B32 = None
         ldb = (cols_a + 7) // 8 * 8 if h16 else cols_a        # 16-bit B: leading dimension padded to a multiple of 8 elements
+        if h16 and (ldb * 2) % 4096 == 0 and getattr(args, "pad_b", 1):
+            ldb += 64                                           # columns a multiple of 4 KB apart share cache sets / channels (sparta_vbs_spmm_gathered_ld's comment)
         if cols_a * N <= (1 << 28):
             B32 = (torch.rand(cols_a * N, generator=g, dtype=torch.float32) - 0.5).to(dev)      # column-major, ld = cols
         else:                                                   # large B: generated on the device

@@ -161,7 +161,7 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
                     works[c_].wait()                                  # the compute stream waits for chunk c_ only
                     d.spmm_gathered(B_gath_c[c_], shard_rows, C[c_ * Nc * rows_c:(c_ + 1) * Nc * rows_c], Nc, accumulate=False, shard_ld=shard_ld)
                 return
-            if distributed and world > 1:
+            if distributed:                      # (one rank under --dist-path too: the collective is then a copy, but it is RCCL's, and in the timed step)
                 if gather_mode == "peer_copies":
                     sa.dist.allgather_B_peer_copies(B_shard, B_gath, rank, world)
                 else:
@@ -222,7 +222,7 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
         ev_ms = ev0.elapsed_time(ev1) / args.steps
         # the all-gather alone (same stream, same fences)
         ag_ms = 0.0
-        if distributed and world > 1:
+        if distributed:
             fence()
             t1 = time.perf_counter()
             for _ in range(min(args.steps, 5)):

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -30,18 +31,32 @@ void parallel_for_dynamic(int64_t n, int64_t grain, F&& f) {
     grain = std::max<int64_t>(1, grain);
     const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(host_threads(), (n + grain - 1) / grain));
     if (nt <= 1) { f((int64_t)0, n, 0); return; }
+    // An exception inside a worker (bad_alloc on inputs of 1e8..1e9 nonzeros is plausible) must reach the caller's handlers, not std::terminate: the first one is
+    // kept, the cursor is pushed past the end so that the others stop, every started thread is joined -- also when a thread cannot be created -- and it is rethrown
     std::atomic<int64_t> cursor{0};
-    std::vector<std::thread> th;
-    th.reserve((size_t)nt);
-    for (int64_t t = 0; t < nt; t++)
-        th.emplace_back([&f, &cursor, n, grain, t] {
+    std::exception_ptr first_error;
+    std::atomic<bool> failed{false};
+    auto work = [&](int t) {
+        try {
             for (;;) {
                 const int64_t lo = cursor.fetch_add(grain, std::memory_order_relaxed);
                 if (lo >= n) break;
-                f(lo, std::min(n, lo + grain), (int)t);
+                f(lo, std::min(n, lo + grain), t);
             }
-        });
+        } catch (...) {
+            if (!failed.exchange(true)) first_error = std::current_exception();
+            cursor.store(n, std::memory_order_relaxed);
+        }
+    };
+    std::vector<std::thread> th;
+    th.reserve((size_t)nt);
+    try {
+        for (int64_t t = 1; t < nt; t++) th.emplace_back(work, (int)t);
+    } catch (...) {                                      // (std::system_error: no more threads) the caller's thread and the ones that started do the work
+    }
+    work(0);
     for (auto& x : th) x.join();
+    if (failed.load()) std::rethrow_exception(first_error);
 }
 
 // SPARTA_BUILD_TRACE=1: phase timings of the host builders on stderr (developer aid)

@@ -202,13 +202,16 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
         // ca-HepPh (118 k nonzeros, 11 tile blocks): 110 -> ~40 us per product, bcsstk18 (80 k nonzeros in 3002 thin blocks): 48 -> ~25 us.
         {
             const double launch_nnz = [] { const char* e = std::getenv("SPARTA_LAUNCH_NNZ"); return e ? atof(e) : 50000.0; }();
-            double tile_steps = 0.0, tile_nnz = 0.0;
+            double tile_steps = 0.0, tile_nnz = 0.0, tile_area = 0.0;
             for (int64_t ib = 0; ib < block_rows; ib++) {
                 if (mode[(size_t)ib] == 1) continue;
                 tile_steps += (double)out->nzcount[ib] * spb_of(part[(size_t)ib + 1] - part[(size_t)ib]);
                 tile_nnz += (double)(nnz_all[(size_t)ib] - sp_ent_of[(size_t)ib]);
+                tile_area += (double)out->nzcount[ib] * (double)(part[(size_t)ib + 1] - part[(size_t)ib]) * (double)w;
             }
-            if (tile_steps > 0.0 && tile_nnz < K * tile_steps + 3.0 * launch_nnz) {
+            // ... and only when the tiles ARE sparse (fill below an eighth): a small DENSE matrix stays on the MFMA kernels (and keeps its dense image: the
+            // exact-order kernel, SPARTA_SPMM_EXACT, has nothing to walk on a handle whose blocks are all sparse rows)
+            if (tile_steps > 0.0 && tile_nnz < K * tile_steps + 3.0 * launch_nnz && tile_nnz < 0.125 * tile_area) {
                 for (int64_t ib = 0; ib < block_rows; ib++) {
                     const int64_t h = part[(size_t)ib + 1] - part[(size_t)ib];
                     if (mode[(size_t)ib] == 1 || h <= 0) continue;

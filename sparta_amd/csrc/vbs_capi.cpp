@@ -877,7 +877,7 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     const bool in_place = !(b_row_major && shard_rows == 0) && A->sp_nnz * 8 < A->cols;
     if (b_row_major && shard_rows == 0) { q.B = dB; q.ldb = ldb; }
     else if (in_place) { q.B = dB; q.ldb = 0; q.b_col_stride = ldb; q.shard_rows = shard_rows; q.shard_stride = shard_stride; }
-    else if (A->prepared_brm) { q.B = A->prepared_brm; q.ldb = n_cols; }        // sparta_vbs_prepare_b: transposed once, not per product
+    else if (A->prepared_brm) { q.B = A->prepared_brm; q.ldb = A->prepared_ld; }   // sparta_vbs_prepare_b: transposed once, not per product (row stride: the n_cols it was prepared for)
     else {
         if (int rc = ensure_scratch(&A->d_Brm, &A->d_Brm_bytes, (size_t)A->cols * (size_t)n_cols * esz)) return rc;
         const int64_t n_wg = ((A->cols + 63) / 64) * (int64_t)((n_cols + 63) / 64);
@@ -1105,9 +1105,14 @@ int spmm16_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
             HIP_TRY(hipMemcpy2DAsync((uint16_t*)A->d_Bt + (size_t)sh * shard_rows * kTN, (size_t)shard_rows * sizeof(uint16_t), dB + (size_t)sh * shard_stride + (size_t)n_main * ldb16,
                                      (size_t)ldb16 * sizeof(uint16_t), (size_t)shard_rows * sizeof(uint16_t), (size_t)n_t, hipMemcpyDeviceToDevice, st));
     else
-        HIP_TRY(hipMemcpyAsync(A->d_Bt, dB + (size_t)n_main * ldb16, (size_t)n_t * ldb16 * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
-    if (int rc = spmm16_core(A, A->d_Bt, ld_t, b_layout, shard_rows, shard_rows > 0 ? shard_rows * kTN : 0, kTN, A->d_Ct, A->rows, SPARTA_COL_MAJOR, 0,
-                             SPARTA_PTR_DEVICE, st, algo, nullptr)) return rc;
+        HIP_TRY(hipMemcpyAsync(A->d_Bt, dB + (size_t)n_main * ldb16, ((size_t)(n_t - 1) * ldb16 + (size_t)A->cols) * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));   // (not past the last column's rows: a caller may have allocated ldb * (n_cols - 1) + cols)
+    {
+        // the tail slab is a B of its own (zero-padded copy of the last columns): a prepared row-major copy of the caller's B does not describe it
+        struct Unprepare { sparta_vbs_t* a; const void* keep; ~Unprepare() { a->prepared_brm = keep; } } unprep{A, A->prepared_brm};
+        A->prepared_brm = nullptr;
+        if (int rc = spmm16_core(A, A->d_Bt, ld_t, b_layout, shard_rows, shard_rows > 0 ? shard_rows * kTN : 0, kTN, A->d_Ct, A->rows, SPARTA_COL_MAJOR, 0,
+                                 SPARTA_PTR_DEVICE, st, algo, nullptr)) return rc;
+    }
     launch_col_tail_merge(st, (const float*)A->d_Ct, A->rows, dC, ldc, (int)(c_layout == SPARTA_ROW_MAJOR), n_main, n_t, (int)(accumulate != 0));
     HIP_TRY(hipGetLastError());
     if (dt_ms) {
@@ -1403,11 +1408,11 @@ int sparta_vbs_spmm_prepared(sparta_vbs_t* A, const sparta_b_t* Bp, void* C, int
     if (Bp->cols != A->cols || Bp->dtype != A->dtype || Bp->device != A->device)
         return fail(SPARTA_ERR_INVALID, "sparta_vbs_spmm_prepared: this B was prepared for another handle shape / type / device");
     SPARTA_GUARD_BEGIN
-    A->prepared_brm = Bp->d_Brm;
-    const int rc = spmm_impl(A, Bp->B, Bp->ldb, SPARTA_COL_MAJOR, Bp->shard_rows, Bp->shard_stride, Bp->n_cols, C, ldc, c_layout, accumulate,
-                             SPARTA_PTR_DEVICE, stream, SPARTA_SPMM_MFMA, dt_ms);
-    A->prepared_brm = nullptr;
-    return rc;
+    // (cleared on every way out, exceptions included: a stale pointer would make a later plain product gather from this B)
+    struct Prepared { sparta_vbs_t* a; ~Prepared() { a->prepared_brm = nullptr; a->prepared_ld = 0; } } guard{A};
+    A->prepared_brm = Bp->d_Brm; A->prepared_ld = Bp->n_cols;
+    return spmm_impl(A, Bp->B, Bp->ldb, SPARTA_COL_MAJOR, Bp->shard_rows, Bp->shard_stride, Bp->n_cols, C, ldc, c_layout, accumulate,
+                     SPARTA_PTR_DEVICE, stream, SPARTA_SPMM_MFMA, dt_ms);
     SPARTA_GUARD_END("sparta_vbs_spmm_prepared")
 }
 

@@ -269,6 +269,7 @@ struct sparta_vbs {
     void* d_Brm = nullptr;                 // row-major copy of a column-major / gathered B
     size_t d_Brm_bytes = 0;
     const void* prepared_brm = nullptr;    // set for the duration of a sparta_vbs_spmm_prepared call: the caller's row-major copy, made once
+    int64_t prepared_ld = 0;               // ... and its row stride (the n_cols it was prepared for: a 16-bit call with n_cols % 128 != 0 is cut into sub-calls)
     void* d_B = nullptr;
     size_t d_B_bytes = 0;
     void* d_C = nullptr;

@@ -285,24 +285,36 @@ def test_rmat_row_slab_is_sampled_without_the_rest_of_the_graph():
 
 
 # ---- round 3: the stated densities / sizes through the canonical piece-wise graph (bench.py --workload rmat-part) ----------------------
-def _gathered_view(torch, B_gath, P, shard_rows, n):
-    """the gathered layout (P column-major slabs of shard_rows x n) as one n x cols view for the checks: (n, P, shard_rows) -> (n, P * shard_rows)"""
-    return B_gath.view(P, n, shard_rows).permute(1, 0, 2).reshape(n, P * shard_rows)
+def _gathered_view(torch, B_gath, P, shard_rows, n, shard_ld=None):
+    """the gathered layout (P column-major slabs of shard_rows x n, columns shard_ld apart) as one n x cols view for the checks: (n, P, shard_rows) -> (n, P * shard_rows)"""
+    shard_ld = shard_rows if shard_ld is None else shard_ld
+    return B_gath.view(P, n, shard_ld)[:, :, :shard_rows].permute(1, 0, 2).reshape(n, P * shard_rows)
 
 
-def _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed):
+def _gathered_b(torch, P, shard_rows, n, tdt, padded):
+    """B of the canonical graph in the layout the all-gather of P ranks leaves; padded: the columns of a slab shard_rows + 64 apart, as bench_parts.py allocates
+    them (columns a power of two apart share cache sets and channels: sparta_vbs_spmm_gathered_ld)"""
+    shard_ld = sa.dist.padded_shard_ld(shard_rows, 2 if tdt != torch.float32 else 4) if padded else shard_rows
+    B_gath = torch.zeros(P * n * shard_ld, dtype=tdt, device="cuda")
+    for s in range(P):
+        B_gath.view(P, n, shard_ld)[s, :, :shard_rows] = sa.gen.dense_rhs_rows(s * shard_rows, (s + 1) * shard_rows, n, seed=7, dtype=tdt, device=0).view(n, shard_rows)
+    return B_gath, shard_ld
+
+
+def _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed, shard_ld=None, keep=False):
     C = torch.full((d.rows * n,), 2.5, dtype=torch.float32, device="cuda")
-    d.spmm_gathered(B_gath, shard_rows, C, n)
+    d.spmm_gathered(B_gath, shard_rows, C, n, shard_ld=shard_ld)
     C2 = torch.full((d.rows * n,), -7.0, dtype=torch.float32, device="cuda")
-    d.spmm_gathered(B_gath, shard_rows, C2, n)
+    d.spmm_gathered(B_gath, shard_rows, C2, n, shard_ld=shard_ld)
     torch.cuda.synchronize()
     assert torch.equal(C, C2), "a second product into a dirty buffer must give the same bits"
     del C2
-    Bflat = _gathered_view(torch, B_gath, P, shard_rows, n).contiguous().view(-1)      # column-major, ld = cols: what the check helpers read
+    Bflat = _gathered_view(torch, B_gath, P, shard_rows, n, shard_ld).contiguous().view(-1)      # column-major, ld = cols: what the check helpers read
     ldb = P * shard_rows
     assert _sampled_rows_check(torch, m, g, C, n, Bflat, ldb, tdt, n_rows=64, seed=seed) <= 1e-5
     assert _column_checksum_check(torch, m, C, n, Bflat, ldb, tdt) <= 1e-5
-    del Bflat, C
+    del Bflat
+    return C if keep else None
 
 
 def test_config3_rmat20_at_the_stated_density_0p1_percent_slab_streamed():
@@ -358,4 +370,81 @@ def test_config4_one_full_size_slab_of_the_8m_row_graph():
     d = sa.DeviceVBS.from_csr(m, g, w, 64, False, device=0, dtype=sa.F16)
     assert d.info()["tiles64"] > 0 and d.sparse_info()["nnz"] > 0          # hub blocks on MFMA tiles, the tail on the sparse-row kernels
     _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed=41)
+    d.close()
+
+
+# ---- round 4: the parts of the power-law configs that no test had reached ("configs not exercised") ------------------------------------------
+def _canonical_part(scale, dens, P, ip):
+    E = sa.gen.rmat_raw_edges_for_density(scale, dens)
+    r0, r1 = sa.gen.rmat_cuts(scale, E, P)[ip]
+    return sa.gen.rmat_rows(scale, E, r0, r1, seed=3, device=0), (r0, r1)
+
+
+@pytest.mark.parametrize("dens,P,ip", [(5e-2, 64, 0), (5e-2, 64, 63), (1e-2, 16, 0), (1e-2, 16, 15)], ids=["5pct-hub", "5pct-tail", "1pct-hub", "1pct-tail"])
+def test_config3_rmat20_at_1_and_5_percent_hub_and_tail_parts(dens, P, ip):
+    """configs[3] at its stated 1 % and 5 %: part 0 -- the hub: at 5 % 9216 rows of which 2048+ are fully dense, 8.7e9 stored elements in 16-bit tiles, the one
+    place a dense tile stream of that size occurs (it runs on the hub plan: group tiles of four 64-row tiles through the GEMM-shaped kernel, k_hub16.hip) -- and the
+    LAST part (the all-sparse end of the graph) of the 64 / 16 parts of equal expected cost that bench.py --workload rmat-part --rmat-density 0.05 / 0.01 streams,
+    reorder OFF (-a 2 -F 1: src/scripts/run_multiplication_experiments_fixed_cluster.sh:14-16), B = 512 columns bf16 in the (padded) all-gather layout."""
+    torch = _torch()
+    scale, n, w, tdt = 20, 512, 64, torch.bfloat16
+    m, (r0, r1) = _canonical_part(scale, dens, P, ip)
+    shard_rows = (1 << scale) // P
+    B_gath, shard_ld = _gathered_b(torch, P, shard_rows, n, tdt, padded=True)
+    assert shard_ld == shard_rows + 64
+    g = np.arange(m.rows, dtype=np.int64) // 64
+    d = sa.DeviceVBS.from_csr(m, g, w, 64, False, device=0, dtype=sa.BF16)
+    info, sp, hub = d.info(), d.sparse_info(), d.hub_info()
+    if ip == 0:
+        assert hub["steps"] > 100000 and hub["tiles_per_group"] == 4 and hub["tiles"] >= 0.9 * info["tiles64"], (hub, info)
+        assert hub["union_area"] <= 1.15 * hub["stored_area"], hub          # the Jaccard grouping of the block-rows: the unions hold few blocks their members lack
+        if dens == 5e-2:
+            assert hub["stored_area"] > 8e9 and m.rows == 9216
+    else:
+        assert sp["nnz"] > 0.5 * m.nztot()                                   # the tail: carried by the sparse rows
+    _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed=50 + ip, shard_ld=shard_ld)
+    d.close()
+
+
+@pytest.mark.parametrize("ip", [1, 6])
+def test_config3_rmat20_at_0p1_percent_reorder_on_equals_off_on_a_part(ip):
+    """configs[3] at its stated 0.1 %, BOTH arms of the reference's experiment (-a 2 -F 1 against the clustering arm) on parts 1 and 6 of the 8 that the bench
+    streams: each arm through the property checks, and the two products are the same rows of the same product -- row inv_on[i] of C_on equals row inv_off[i] of
+    C_off for every original row i sampled."""
+    torch = _torch()
+    scale, dens, P, n, w, tdt = 20, 1e-3, 8, 512, 64, torch.bfloat16
+    m, _ = _canonical_part(scale, dens, P, ip)
+    shard_rows = (1 << scale) // P
+    B_gath, shard_ld = _gathered_b(torch, P, shard_rows, n, tdt, padded=True)
+    g_off = np.arange(m.rows, dtype=np.int64) // 64
+    d_off = sa.DeviceVBS.from_csr(m, g_off, w, 64, False, device=0, dtype=sa.BF16)
+    C_off = _part_checks(torch, m, g_off, d_off, B_gath, P, shard_rows, n, tdt, seed=60 + ip, shard_ld=shard_ld, keep=True)
+    d_off.close()
+    g_on = sa.BlockingEngine(blocking_algo=7, tau=0.4, col_block_size=w, row_block_size=64, force_fixed_size=False, sim_measure=1).GetGrouping(m)
+    d_on = sa.DeviceVBS.from_csr(m, g_on, w, 64, False, device=0, dtype=sa.BF16)
+    C_on = _part_checks(torch, m, g_on, d_on, B_gath, P, shard_rows, n, tdt, seed=70 + ip, shard_ld=shard_ld, keep=True)
+    d_on.close()
+    p_on, p_off = sa.get_permutation(g_on), sa.get_permutation(g_off)
+    inv_on = np.empty(m.rows, np.int64); inv_on[p_on] = np.arange(m.rows)
+    inv_off = np.empty(m.rows, np.int64); inv_off[p_off] = np.arange(m.rows)
+    rows = np.random.Generator(np.random.PCG64(4 + ip)).integers(0, m.rows, 4096)
+    a = C_on.view(n, -1)[:, torch.from_numpy(inv_on[rows]).cuda()]
+    b = C_off.view(n, -1)[:, torch.from_numpy(inv_off[rows]).cuda()]
+    scale_ = b.abs().max().clamp_min(1e-30)
+    assert float((a - b).abs().max() / scale_) <= 2e-5                       # the same exact products summed in fp32, in two orders
+
+
+def test_config4_the_last_slab_of_the_8m_row_graph():
+    """configs[4] at full size, part 7 of 8: 3.1 M rows, the all-sparse end of the 8.4 M x 8.4 M R-MAT at 0.01 % (what rank 7 of `bench.py --gpus 8` runs),
+    B = 256 columns fp16 in the padded all-gather layout of 8 ranks."""
+    torch = _torch()
+    scale, dens, P, n, w, tdt = 23, 1e-4, 8, 256, 64, torch.float16
+    m, (r0, r1) = _canonical_part(scale, dens, P, 7)
+    assert r1 == 1 << scale and r1 - r0 > 2500000
+    shard_rows = (1 << scale) // P
+    B_gath, shard_ld = _gathered_b(torch, P, shard_rows, n, tdt, padded=True)
+    g = np.arange(m.rows, dtype=np.int64) // 64
+    d = sa.DeviceVBS.from_csr(m, g, w, 64, False, device=0, dtype=sa.F16)
+    assert d.sparse_info()["nnz"] > 0.8 * m.nztot()
+    _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed=47, shard_ld=shard_ld)
     d.close()

@@ -754,12 +754,14 @@ def test_16bit_four_accumulator_slabs_give_the_bits_of_the_128_column_launch(mon
         _check(outs["1"][3].cpu().numpy(), Co, bound, "four accumulators, gathered B")
 
 
+@pytest.mark.parametrize("n", [256, 200, 72])
 @pytest.mark.parametrize("dtype", [sa.F32, sa.F16, sa.BF16], ids=["f32", "f16", "bf16"])
-def test_a_constant_b_prepared_once_gives_the_bits_of_the_plain_product(dtype):
+def test_a_constant_b_prepared_once_gives_the_bits_of_the_plain_product(dtype, n):
     """sparta_vbs_prepare_b / sparta_vbs_spmm_prepared: the row-major copy of B the sparse-row kernels read is made once instead of per product; everything
-    else is the same call -- the same bits, column-major B and the gathered layout; a B prepared for one handle is refused by another shape."""
+    else is the same call -- the same bits, column-major B and the gathered layout; a B prepared for one handle is refused by another shape.  n = 200 / 72: a 16-bit
+    call is cut into whole 128-column slabs (which gather from the prepared copy, rows n elements apart) and a zero-padded tail slab (which must not)."""
     torch = _torch()
-    n, w = 256, 64
+    w = 64
     m = sa.gen.rmat(13, 60000, seed=5, symmetrize=True, pattern_only=False)
     g = sa.BlockingEngine(blocking_algo=7, tau=0.4, col_block_size=w, row_block_size=32).GetGrouping(m)
     d = sa.DeviceVBS.from_csr(m, g, w, device=0, dtype=dtype)
