@@ -391,8 +391,9 @@ int sparta_vbs_sparse_info(const sparta_vbs_t* A, int64_t* info_out);
 /* the hub part of the plan of a 16-bit handle of 64-wide blocks (no reference counterpart: the reference multiplies every block-row the same way,
  * vbr.cpp:323-372 / cuda_utilities.cpp:828-875).  The long tiles of 33..64 rows -- the dense hub of a power-law matrix under the fixed 64 x 64 grid -- are grouped
  * by the Jaccard similarity of their block-column sets into group tiles of 2 or 4 and multiplied by a GEMM-shaped kernel that stages A and B once per workgroup.
- * info_out (int64[8]): [0] steps (one 64-deep k slice of one group tile) [1] 64-row tiles in the hub plan [2] group tiles [3] tiles per group tile (2 or 4; 0: no
- * hub plan) [4] stored elements of those tiles [5] elements the kernel multiplies (the union of a group's block columns x its tiles) [6] workers [7] 0.
+ * info_out (int64[10]): [0] steps (one 64-deep k slice of one group tile) [1] 64-row tiles in the hub plan [2] group tiles [3] tiles per group tile (2 or 4; 0: no
+ * hub plan) [4] stored elements of those tiles [5] elements the kernel multiplies (the union of a group's block columns x its tiles) [6] workers [7] K chunks of
+ * the step order [8] segments (runs of one group tile on one worker: each one that is not a whole tile leaves partial images for the fix-up) [9] 0.
  * SPARTA_HUB=0 switches the hub plan off (every tile then runs on the 64-row plan as before). */
 int sparta_vbs_hub_info(const sparta_vbs_t* A, int64_t* info_out);
 

@@ -557,6 +557,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         if (plan.n_hub_steps > 0) {
             v->hub_g = plan.hub_g; v->hub_workers = plan.hub_workers; v->n_hub_steps = plan.n_hub_steps; v->hub_area = plan.hub_area;
             v->hub_union_area = plan.hub_union_area; v->n_hub_tiles = plan.n_hub_tiles; v->n_hub_groups = plan.n_hub_groups;
+            v->hub_chunks = plan.hub_chunks; v->hub_segments = plan.hub_segments;
             CREATE_TRY(hipMalloc((void**)&v->d_hub_steps, plan.hub_steps.size() * sizeof(HubStep)));
             CREATE_TRY(hipMemcpy(v->d_hub_steps, plan.hub_steps.data(), plan.hub_steps.size() * sizeof(HubStep), hipMemcpyHostToDevice));
             CREATE_TRY(hipMalloc((void**)&v->d_hub_tiles, plan.hub_tiles.size() * sizeof(HubTile)));
@@ -773,7 +774,7 @@ int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info) {
 int sparta_vbs_hub_info(const sparta_vbs_t* A, int64_t* info) {
     if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_hub_info: NULL argument");
     info[0] = A->n_hub_steps; info[1] = A->n_hub_tiles; info[2] = A->n_hub_groups; info[3] = A->n_hub_steps > 0 ? A->hub_g : 0;
-    info[4] = A->hub_area; info[5] = A->hub_union_area; info[6] = A->n_hub_steps > 0 ? A->hub_workers : 0; info[7] = 0;
+    info[4] = A->hub_area; info[5] = A->hub_union_area; info[6] = A->n_hub_steps > 0 ? A->hub_workers : 0; info[7] = A->hub_chunks; info[8] = A->hub_segments; info[9] = 0;
     return SPARTA_OK;
 }
 

@@ -236,7 +236,7 @@ struct sparta_vbs {
     int32_t* d_hub_wrange = nullptr;
     uint16_t* d_hub_A = nullptr;
     int hub_g = 0, hub_workers = 0;
-    int64_t n_hub_steps = 0, hub_area = 0, hub_union_area = 0, n_hub_tiles = 0, n_hub_groups = 0;
+    int64_t n_hub_steps = 0, hub_area = 0, hub_union_area = 0, n_hub_tiles = 0, n_hub_groups = 0, hub_chunks = 0, hub_segments = 0;
     bool has_tail = false;                 // cols % w != 0: the stream path needs B_tail
     void* d_btail = nullptr;
     size_t d_btail_bytes = 0;
@@ -343,7 +343,7 @@ struct StreamPlanHost {
     int hub_g = 0;                            // sub-tiles per group tile (2 or 4); 0: no hub plan
     int hub_workers = 0;
     int64_t n_hub_steps = 0, hub_area = 0, hub_union_area = 0;    // steps; stored elements of the hub tiles; elements the kernel multiplies (absent sub-tiles included)
-    int64_t n_hub_tiles = 0, n_hub_groups = 0;
+    int64_t n_hub_tiles = 0, n_hub_groups = 0, hub_chunks = 0, hub_segments = 0;    // K chunks of the step order; segments (runs of one group on one worker)
 };
 constexpr int64_t kZeroRangeRows = 2048;    // block-rows without blocks at least this tall are zero-filled by vbs_zero_rows_kernel
 int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P);

@@ -703,7 +703,9 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                 std::vector<int64_t> cost;
                 for (int64_t C = 1; C <= std::min<int64_t>(64, block_cols); C++) {
                     unit_sizes(C, cost);
-                    const int64_t span = aligned_cut(cost, nullptr);
+                    // every unit that is not a whole tile leaves partial images for the fix-up (G x N / 128 images of 32 KB, written and read once): measured
+                    // 0.11 us per unit at N = 512 against 4.8 us per step of the makespan (part 0 of configs[3] at 1 %: 54 chunks x 89 groups, fix-up 0.53 ms)
+                    const int64_t span = aligned_cut(cost, nullptr) + (C > 1 ? (int64_t)(0.025 * (double)C * (double)hub_groups.size()) : 0);
                     if (span < best_span) { best_span = span; best_C = C; }
                 }
                 if ((double)best_span <= 1.10 * (double)S_all / (double)hub_workers + 1.0) {
@@ -713,6 +715,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                 } else best_C = std::min<int64_t>(16, block_cols);
             }
             n_ranges = best_C;
+            P.hub_chunks = best_C;
             // order: (K chunk, group, block column, k slice)
             struct ORef { int32_t g, u, ks; };
             std::vector<ORef> order;
@@ -772,6 +775,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                     const size_t gi = (size_t)order[(size_t)a].g;
                     const bool whole = own_index(a) == 0 && own_index(b) == (int64_t)un[gi].size() * spb - 1;
                     hs[(size_t)b].flags |= STEP_LAST;
+                    P.hub_segments++;
                     if (!whole) {
                         hs[(size_t)b].flags |= STEP_SPLIT;
                         hs[(size_t)b].slot = next_id;

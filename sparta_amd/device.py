@@ -126,9 +126,9 @@ class DeviceVBS:
 
     def hub_info(self):
         """the hub part of a 16-bit plan (group tiles of long 64-row tiles for the GEMM-shaped kernel): see sparta_vbs_hub_info"""
-        a = np.zeros(8, np.int64)
+        a = np.zeros(10, np.int64)
         check(lib.sparta_vbs_hub_info(self.h, a.ctypes.data_as(_i64p)))
-        keys = ["steps", "tiles", "groups", "tiles_per_group", "stored_area", "union_area", "workers"]
+        keys = ["steps", "tiles", "groups", "tiles_per_group", "stored_area", "union_area", "workers", "chunks", "segments"]
         return {k: int(a[i]) for i, k in enumerate(keys)}
 
     def spmm_host(self, B, n_cols, C_out, accumulate=True, algo=_lib.SPMM_MFMA, b_layout=_lib.COL_MAJOR,

@@ -57,10 +57,17 @@ def _sampled_rows_check(torch, m, grouping, C, n, B, ldb, tdt, n_rows=96, seed=1
 
 def _column_checksum_check(torch, m, C, n, B, ldb, tdt):
     """1^T C == (1^T A) B per column of B, in float64 on the device; returns max |diff| / (|1^T A| |B|)"""
-    vals = np.ones(m.nztot(), np.float32) if m.vals is None else m.vals
-    s = np.bincount(m.colidx, weights=_rounded(vals, torch, tdt), minlength=m.cols)          # column sums of (rounded) A
-    sa_abs = np.bincount(m.colidx, weights=np.abs(_rounded(vals, torch, tdt)), minlength=m.cols)
-    st, sat = torch.from_numpy(s).cuda(), torch.from_numpy(sa_abs).cuda()
+    # column sums of (rounded) A and of |A|, accumulated on the device in float64, a chunk of the nonzeros at a time (the hub parts hold 1e9..2.5e9 of them)
+    st = torch.zeros(m.cols, dtype=torch.float64, device="cuda")
+    sat = torch.zeros(m.cols, dtype=torch.float64, device="cuda")
+    nnz, step = m.nztot(), 1 << 27
+    for lo in range(0, nnz, step):
+        hi = min(nnz, lo + step)
+        idx = torch.from_numpy(m.colidx[lo:hi].astype(np.int64)).cuda()
+        v = torch.ones(hi - lo, dtype=torch.float64, device="cuda") if m.vals is None else torch.from_numpy(m.vals[lo:hi]).cuda().to(tdt).double()
+        st.index_add_(0, idx, v)
+        sat.index_add_(0, idx, v.abs())
+        del idx, v
     Bd = B.view(n, ldb)[:, :m.cols].double()
     want, scale = Bd @ st, Bd.abs() @ sat + 1e-30
     got = C.view(n, -1).double().sum(dim=1)
@@ -301,7 +308,7 @@ def _gathered_b(torch, P, shard_rows, n, tdt, padded):
     return B_gath, shard_ld
 
 
-def _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed, shard_ld=None, keep=False):
+def _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed, shard_ld=None, keep=False, n_rows=64):
     C = torch.full((d.rows * n,), 2.5, dtype=torch.float32, device="cuda")
     d.spmm_gathered(B_gath, shard_rows, C, n, shard_ld=shard_ld)
     C2 = torch.full((d.rows * n,), -7.0, dtype=torch.float32, device="cuda")
@@ -311,7 +318,7 @@ def _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed, shard_ld=N
     del C2
     Bflat = _gathered_view(torch, B_gath, P, shard_rows, n, shard_ld).contiguous().view(-1)      # column-major, ld = cols: what the check helpers read
     ldb = P * shard_rows
-    assert _sampled_rows_check(torch, m, g, C, n, Bflat, ldb, tdt, n_rows=64, seed=seed) <= 1e-5
+    assert _sampled_rows_check(torch, m, g, C, n, Bflat, ldb, tdt, n_rows=n_rows, seed=seed) <= 1e-5
     assert _column_checksum_check(torch, m, C, n, Bflat, ldb, tdt) <= 1e-5
     del Bflat
     return C if keep else None
@@ -401,8 +408,8 @@ def test_config3_rmat20_at_1_and_5_percent_hub_and_tail_parts(dens, P, ip):
         if dens == 5e-2:
             assert hub["stored_area"] > 8e9 and m.rows == 9216
     else:
-        assert sp["nnz"] > 0.5 * m.nztot()                                   # the tail: carried by the sparse rows
-    _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed=50 + ip, shard_ld=shard_ld)
+        assert sp["nnz"] > 0.25 * m.nztot()                                  # the tail: sparse rows carry a large share (at 5 % even the last part keeps tiles)
+    _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed=50 + ip, shard_ld=shard_ld, n_rows=16 if ip == 0 else 64)      # (a hub row holds 10^5..10^6 nonzeros)
     d.close()
 
 
