@@ -17,6 +17,14 @@ print("|---|---|---|---|---|---|---|---|---|")
 
 
 def log(r):
+    if "points" in r:                                        # a real matrix at the reference's operand widths, its two arms + blocking_algo 7
+        for p_ in r["points"]:
+            if "error" in p_:
+                print("|   %s N = %d, %s | error: %s |" % (r["name"].split(":")[0], p_["n_cols"], p_["arm"], p_["error"]), flush=True)
+            else:
+                print("|   %s N = %d, %s (%.2f s) | | | | %.4f | %.0f | %s | %.3f | check %.1e |" % (r["name"].split(":")[0], p_["n_cols"], p_["arm"], p_["host_reorder_s"], p_["ms"],
+                      p_["useful_gflops"], p_["carried_by"], p_["frac_8d"], p_["check_max_err"]), flush=True)
+        return
     if "error" in r:
         print("| %s | error: %s |" % (r["name"], r["error"]), flush=True)
         return
@@ -24,9 +32,10 @@ def log(r):
           r["useful_gflops"], r["carried_by"], r["frac_8d"], "-" if r["gather_gbs"] is None else "%.0f" % r["gather_gbs"]), flush=True)
 
 
-res = bench_suite.run(sa, torch, N=128, device=0, large=True, time_budget_s=600.0, log=log)
+res = bench_suite.run(sa, torch, N=128, device=0, large=True, time_budget_s=600.0, log=log, sweep_budget_s=600.0)
 res["device"] = torch.cuda.get_device_name(0)
 res["kernel_rev"] = sa.KERNEL_REV
 print("min frac_8d %.3f, median %.3f, %.1f s" % (res["min_frac_8d"], res["median_frac_8d"], res["seconds"]))
+print({k: v for k, v in res.items() if k.startswith("real_median") or k in ("bound_violations", "check_failures", "skipped_for_time")})
 if OUT:
     json.dump(res, open(OUT, "w"), indent=1)

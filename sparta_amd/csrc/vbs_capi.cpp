@@ -875,7 +875,9 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     q.b_col_stride = 0; q.shard_rows = 0; q.shard_stride = 0;
     // A column-major B read in place costs one 64-byte line per ELEMENT (16 x the bytes of a row-major row); transposing costs
     // 2 x |B| once.  In place wins while  nnz * 16 < 2 * cols.
-    const bool in_place = !(b_row_major && shard_rows == 0) && A->sp_nnz * 8 < A->cols;
+    // SPARTA_SP_INPLACE = 0 | 1 forces the choice (developer A/B)
+    static const int inplace_env = [] { const char* e = std::getenv("SPARTA_SP_INPLACE"); return e ? atoi(e) : -1; }();
+    const bool in_place = !(b_row_major && shard_rows == 0) && (inplace_env >= 0 ? inplace_env != 0 : A->sp_nnz * 8 < A->cols);
     if (b_row_major && shard_rows == 0) { q.B = dB; q.ldb = ldb; }
     else if (in_place) { q.B = dB; q.ldb = 0; q.b_col_stride = ldb; q.shard_rows = shard_rows; q.shard_stride = shard_stride; }
     else if (A->prepared_brm) { q.B = A->prepared_brm; q.ldb = A->prepared_ld; }   // sparta_vbs_prepare_b: transposed once, not per product (row stride: the n_cols it was prepared for)
@@ -904,7 +906,10 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     static const int vec_cap = [] { const char* e = std::getenv("SPARTA_SP_VEC"); return e ? atoi(e) : 4; }();
     const double b_bytes = (double)A->cols * (double)n_cols * (double)esz;
     static const int row_bytes_env = [] { const char* e = std::getenv("SPARTA_SP_ROW_BYTES"); return e ? atoi(e) : 0; }();
-    const int row_bytes = row_bytes_env > 0 ? row_bytes_env : (b_bytes > 384e6 ? 256 : (b_bytes > 96e6 ? 512 : 1024));
+    // (what matters is the SLICE of B one column chunk touches, cols x row_bytes: while that fits the Infinity Cache the widest chunk wins -- the reference's real
+    // matrices at its operand width N = 8192, 8-58 k columns, |B| = 0.3-1.9 GB: 1.14 -> 0.83 ms (bcsstk18), 3.37 -> 2.81 (social_location) with 1024 instead of 256)
+    const bool slice_fits = (double)A->cols * 1024.0 <= 96e6;
+    const int row_bytes = row_bytes_env > 0 ? row_bytes_env : (slice_fits ? 1024 : (b_bytes > 384e6 ? 256 : (b_bytes > 96e6 ? 512 : 1024)));
     const int vec_want = std::max(esz == 2 ? 2 : 1, std::min(vec_cap, (int)(row_bytes / (64 * (int)esz))));
     const int vec = in_place ? 1 : (vec_want >= 4 && aligned(4) ? 4 : (vec_want >= 2 && aligned(2) ? 2 : 1));
     const unsigned gy = (unsigned)((n_cols + 64 * vec - 1) / (64 * vec));
