@@ -32,6 +32,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+#ifndef SPARTA_HUB_A_AUX
+#define SPARTA_HUB_A_AUX 0          /* cache policy of the loads of A (developer A/B): 0 default, 2 non-temporal */
+#endif
 #ifndef SPARTA_HUB_PROBE
 #define SPARTA_HUB_PROBE 0        /* developer probes, TIMING ONLY (results wrong): 1 no B loads, 2 no A loads, 4 no MFMAs, 8 no fragment reads, 16 no epilogue */
 #endif
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(64 * 2 * G * (LW ? 2 : 1), (G / 2) * (LW ? 2 : 1) *
         } else {
             const int q = wc * NA + (t - NB);            // piece of the slice
             if (!(SPARTA_HUB_PROBE & 2))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rA, (lds_ptr_t)(c_st + wr * SLICE + q * 1024), 16, voffA, (uint32_t)(q * 1024), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(c_rA, (lds_ptr_t)(c_st + wr * SLICE + q * 1024), 16, voffA, (uint32_t)(q * 1024), 0, SPARTA_HUB_A_AUX);
         }
     };
     auto issue = [&](const Rec& rec, int stage) __attribute__((always_inline)) -> int32_t {       // all of a step's loads back to back (prologue)
