@@ -319,7 +319,36 @@ __global__ __launch_bounds__(kThreads, SPARTA_DIRECT_WAVES) void vbs_spmm_f32_di
 
 }  // namespace
 
+namespace {
+
+// The reference-layout image of A (column-major h x w blocks) rebuilt from the fragment image of the one-tile plan: slice q of a_frag = step q, element (row m, column k
+// of the 32-deep slice) at fragment position pos[k] (k-compaction: vbs_plan.cpp), i.e. frag[((j * 2 + g) * 32 + m) * 4 + e] with pos[k] = 16 g + 4 j + e; all-zero
+// columns hold zeros there too.  Used when a handle that dropped its reference-layout image (vbs_capi.cpp: one image of A, not two, once the no-barrier kernel has won the
+// plan-time autotune) is asked for something that reads it after all: SPARTA_SPMM_EXACT, a row-major or gathered B, the per-class kernels.  The copy is exact.
+__global__ __launch_bounds__(kThreads) void vbs_f32_legacy_from_frag_kernel(const StepRec* steps, int64_t n_steps, const float* a_frag, float* A) {
+    for (int64_t q = blockIdx.x; q < n_steps; q += gridDim.x) {
+        const int64_t a_off = steps[q].a_off, h = steps[q].h;
+        const int mt = steps[q].mt_flags & 0xffff;
+        const float* sl = a_frag + q * kAFragSlice;
+        const unsigned char* pos = reinterpret_cast<const unsigned char*>(sl);
+        const float* frag = sl + 16;
+        for (int x = threadIdx.x; x < 32 * 32; x += kThreads) {
+            const int k = x >> 5, m = x & 31;
+            if (m >= mt) continue;
+            const int kp = pos[k], g = kp >> 4, j = (kp & 15) >> 2, e = kp & 3;
+            A[a_off + (int64_t)k * h + m] = frag[((j * 2 + g) * 32 + m) * 4 + e];
+        }
+    }
+}
+
+}  // namespace
+
 namespace sparta_dev {
+
+void launch_f32_legacy_from_frag(hipStream_t st, const StepRec* steps, int64_t n_steps, const float* a_frag, float* A) {
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_steps, 65536));
+    hipLaunchKernelGGL(vbs_f32_legacy_from_frag_kernel, dim3(grid), dim3(kThreads), 0, st, steps, n_steps, a_frag, A);
+}
 
 void launch_f32_direct(bool c_stage, dim3 grid, hipStream_t st, const StreamParams& sp) {
     static const bool lean_off = [] { const char* e = std::getenv("SPARTA_F32_TAILFREE"); return e && atoi(e) == 0; }();     // (A/B runs)

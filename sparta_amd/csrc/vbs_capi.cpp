@@ -865,6 +865,29 @@ int ensure_gathered_steps(sparta_vbs_t* A, int64_t shard_rows, hipStream_t st) {
 }
 
 
+// fp32 handles whose <= 32-row tiles have a fragment image (k_f32_direct.hip) hold A twice at create time.  Once the no-barrier kernel has won the plan-time autotune on a
+// handle whose tiles are ALL in that image, the reference-layout copy is dropped (drop_legacy_image: a_bytes = one image); a later call that reads it -- SPARTA_SPMM_EXACT, a
+// row-major or gathered B, the per-class kernels -- rebuilds it on the device from the fragment image (an exact copy) and then keeps it.  SPARTA_F32_KEEP_LEGACY=1: never drop.
+int ensure_legacy_image(sparta_vbs_t* A, hipStream_t st) {
+    if (A->d_A || A->dtype != SPARTA_F32) return SPARTA_OK;
+    if (g_capturing) return capture_refusal("rebuild the reference-layout image of A");
+    const size_t bytes = (size_t)(A->nztot + 128) * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&A->d_A, bytes));
+    HIP_TRY(hipMemsetAsync(A->d_A, 0, bytes, st));
+    if (A->n_steps[0] > 0) launch_f32_legacy_from_frag(st, A->d_steps[0], A->n_steps[0], A->d_a_frag, A->d_A);
+    HIP_TRY(hipGetLastError());
+    A->a_bytes += (int64_t)bytes;
+    return SPARTA_OK;
+}
+void drop_legacy_image(sparta_vbs_t* A) {
+    static const bool keep = [] { const char* e = std::getenv("SPARTA_F32_KEEP_LEGACY"); return e && atoi(e) != 0; }();
+    if (keep || g_capturing || A->legacy_dropped || !A->d_A || !A->d_a_frag || A->dtype != SPARTA_F32 || A->n_steps[1] != 0 || A->class_timing) return;
+    (void)hipFree(A->d_A);                               // (synchronises: the autotune's launches that read it are done)
+    A->d_A = nullptr;
+    A->a_bytes -= (int64_t)((A->nztot + 128) * sizeof(float));
+    A->legacy_dropped = true;
+}
+
 int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_major, int64_t shard_rows, int64_t shard_stride, int bk,
                        int32_t n_cols, float* dC, int64_t ldc, bool c_row_major, bool accumulate, hipStream_t st) {
     const size_t esz = bk == 0 ? 4 : 2;
@@ -1174,6 +1197,7 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
         return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: SPARTA_SPMM_EXACT needs the dense image of every block-row (handle made by sparta_vbs_create_from_csr)");
     if (dt_ms) HIP_TRY(hipEventRecord(A->ev0, st));
     if (algo == SPARTA_SPMM_EXACT) {
+        if (int rc = ensure_legacy_image(A, st)) return rc;
         if (A->n_brows > 0) {
             launch_f32_exact((unsigned)A->n_brows, st, A->d_brows, A->d_jab, A->d_A, dB, dC, ldb, ldc, A->cols, (int)n_cols, (int)A->w,
                              (int)(b_layout == SPARTA_ROW_MAJOR), (int)(c_layout == SPARTA_ROW_MAJOR), (int)accumulate, shard_rows, shard_stride);
@@ -1202,6 +1226,9 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
                 if (int rc = ensure_scratch(&A->d_ws, &A->d_ws_bytes, slab * n_nt * sizeof(float))) return rc;
             if (shard_rows > 0)
                 if (int rc = ensure_gathered_steps(A, shard_rows, st)) return rc;
+            // the LDS-staged kernels (33..64-row tiles; any tile under a row-major or gathered B) read the reference-layout image; the no-barrier kernel the fragment image
+            if (A->n_steps[1] > 0 || !(A->d_a_frag && b_layout == SPARTA_COL_MAJOR && shard_rows == 0))
+                if (int rc = ensure_legacy_image(A, st)) return rc;
             StreamParams sp;
             sp.A = A->d_A; sp.B = dB; sp.C = Cout; sp.ws = (float*)A->d_ws;
             sp.ldb = ldb; sp.ldc = ldc; sp.cols = A->cols; sp.shard_rows = shard_rows; sp.shard_stride = shard_stride;
@@ -1253,6 +1280,7 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
         };
         // one launch per tile class (<=16 / <=32 / <=64 rows), one workgroup per tile
         auto run_class = [&](float* Cout, bool generic, bool prof) -> int {
+            if (int rc = ensure_legacy_image(A, st)) return rc;
             SpmmParams p;
             p.jab = A->d_jab; p.A = A->d_A; p.B = dB; p.C = Cout; p.ldb = ldb; p.ldc = ldc; p.cols = A->cols;
             p.n_ntiles = n_nt; p.N = n_cols; p.w = (int32_t)A->w;
@@ -1311,6 +1339,8 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
         if (path == 1) { if (int rc = run_stream(dC, prof)) return rc; }
         else if (int rc = run_class(dC, path == 3, prof)) return rc;
         A->last_path = path;
+        // one image of A, not two: the no-barrier kernel carries this handle's products (every tile is in the fragment image) -- see ensure_legacy_image
+        if (path == 1 && b_layout == SPARTA_COL_MAJOR && shard_rows == 0) drop_legacy_image(A);
 
         // ---- the sparse rows.  Fully sparse block-rows (flag 1) own their rows of C; rows of MIXED block-rows (flag 2, bit 31 of crow) ADD to what
         // the tile and fix-up launches stored: this launch must stay BEHIND those launches on the same stream (moving the sparse leg to a side

@@ -228,6 +228,7 @@ struct sparta_vbs {
     bool tiles_row_aligned[2] = {true, true};
     bool wide16 = false;                      // the 16-bit one-tile plan holds two sub-worker ranges per workgroup (vbs_spmm_h16_direct_kernel, WC = 64)
     float* d_a_frag = nullptr;                    // A of the one-tile plan in fragment order (k_f32_direct.hip) or nullptr
+    bool legacy_dropped = false;                  // fp32: the reference-layout image d_A was freed once the fragment image had won (rebuilt on demand, then kept)
     // hub plan (16-bit handles of 64-wide blocks; vbs_plan.cpp, k_hub16.hip)
     sparta_dev::HubStep* d_hub_steps = nullptr;
     sparta_dev::HubStep* d_hub_steps_g = nullptr; // step list for sparta_vbs_spmm_gathered with shard_rows == g_shard_rows
@@ -287,6 +288,7 @@ void launch_f32_exact(unsigned n_brows, hipStream_t st, const BlockRowDesc* rows
 // k_f32_stream.hip
 void launch_f32_stream(bool mi2, bool b_row_major, bool gathered, dim3 grid, hipStream_t st, const StreamParams& sp);
 void launch_f32_direct(bool c_stage, dim3 grid, hipStream_t st, const StreamParams& sp);
+void launch_f32_legacy_from_frag(hipStream_t st, const StepRec* steps, int64_t n_steps, const float* a_frag, float* A);
 void launch_fixup_group(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* big, const int32_t* fix_slots, float* ws_all, int64_t ws_slab_stride);
 void launch_fixup(dim3 grid, hipStream_t st, const FixRec* fix, const int32_t* fix_slots, const float* ws_all, int64_t ws_slab_stride, float* C, int64_t ldc,
                   int c_row_major, int accumulate);

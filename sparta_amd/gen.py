@@ -380,10 +380,12 @@ def rmat_block_model(scale, raw_edges, a=0.57, b=0.19, c=0.19, block=64, tile_mi
     return out
 
 
-def rmat_piece_table(scale, raw_edges, a=0.57, b=0.19, c=0.19, tile_block_cost=55.0, row_cost=1.0):
+def rmat_piece_table(scale, raw_edges, a=0.57, b=0.19, c=0.19, tile_block_cost=25.0, row_cost=34.0):
     """Per canonical piece: (raw edges it receives, expected cost of its product).  Cost unit: one nonzero on the sparse-row path (one
     gathered row of B); a well-filled 64 x 64 block kept as an MFMA tile costs `tile_block_cost` of them, a row of C `row_cost` (least
-    squares over the eight parts of configs[4] on one MI355X, fp16, N = 256: 0.102 ns per gathered nonzero, 5.6 ns per tile, rows ~ 0;
+    squares over the eight parts of configs[4] on one MI355X, fp16, N = 256.  Round 4, with the hub kernel and the column windows: 0.054 ns per gathered nonzero,
+    1.35 ns per tile, 1.85 ns per row -- the fit reproduces the eight part times within 0.6 %; round 3: 0.102 ns, 5.6 ns per tile, rows ~ 0: the parts cut with those
+    coefficients ran 34.3-42.3 ms, max / mean 1.12, once the tiles had become four times cheaper);
     the model's own counts match the builder's: part 0 predicted 432.86 M sparse nonzeros + 1.4208 M tiles, built 432.82 M + 1.4212 M).  Pure arithmetic on the R-MAT marginals: every
     rank computes the same table without seeing the graph."""
     s = int(scale)

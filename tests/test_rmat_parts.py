@@ -56,7 +56,7 @@ def test_any_row_range_is_generated_without_the_rest_of_the_graph():
 
 
 def test_cuts_by_expected_cost_balance_the_real_costs():
-    """the cost model behind the cuts (nonzeros of sparsely filled 64 x 64 blocks + 55 per well-filled block kept as an MFMA tile + rows)
+    """the cost model behind the cuts (nonzeros of sparsely filled 64 x 64 blocks + 25 per well-filled block kept as an MFMA tile + 34 per row: gen.rmat_piece_table)
     evaluated on the REAL graph: the parts cut from the marginals alone carry equal shares of it"""
     sa, E = _graph()
     full = sa.gen.rmat_rows(SCALE, E, 0, 1 << SCALE, device="cpu")
@@ -64,7 +64,7 @@ def test_cuts_by_expected_cost_balance_the_real_costs():
     blk = (rows_of // 64) * ((1 << SCALE) // 64) + full.colidx // 64
     ids, cnt = np.unique(blk, return_counts=True)
     br = ids // ((1 << SCALE) // 64)
-    cost_br = np.bincount(br, weights=np.where(cnt >= 120, 55.0, cnt.astype(np.float64)), minlength=full.rows // 64) + 64.0
+    cost_br = np.bincount(br, weights=np.where(cnt >= 120, 25.0, cnt.astype(np.float64)), minlength=full.rows // 64) + 64.0 * 34.0
     model = sa.gen.rmat_block_model(SCALE, E)
     # the model's totals against the graph's: nonzeros outside well-filled blocks, number of well-filled blocks
     from math import comb
@@ -78,7 +78,7 @@ def test_cuts_by_expected_cost_balance_the_real_costs():
         real = np.array([cost_br[r0 // 64:r1 // 64].sum() for r0, r1 in cuts], np.float64)
         assert real.max() / real.mean() < 1.3, (parts, real)           # granularity of a piece at this small scale; ~1.03 at 2^23
         # the hub: the first part has far fewer rows than the last
-        assert (cuts[0][1] - cuts[0][0]) * 2 < (cuts[-1][1] - cuts[-1][0])
+        assert (cuts[0][1] - cuts[0][0]) < (cuts[-1][1] - cuts[-1][0])           # (rows have a price of their own since round 4: less skew than by nonzeros alone)
 
 
 def test_dense_operand_rows_are_canonical():

@@ -849,6 +849,59 @@ def test_fp32_k_compaction_every_count_of_non_empty_columns(monkeypatch, rows_pe
         assert d.info()["last_path"] == 1, "the stream kernels were meant to run"
 
 
+@pytest.mark.parametrize("rows,cols,nnz,w,blk", [(2048, 2048, 60000, 32, ("keeper", 16)), (1500, 1000 - 7, 40000, 32, ("fixed", 32)), (900, 640, 30000, 64, ("fixed", 19))])
+def test_fp32_handle_keeps_one_image_of_a_and_rebuilds_the_reference_layout_on_demand(monkeypatch, _sparse_row_mode, rows, cols, nnz, w, blk):
+    """a fp32 handle whose tiles all have <= 32 rows is created with A in two layouts (the reference's mab, and the fragment image the no-barrier kernel reads); once that
+    kernel carries the products the reference-layout image is dropped (a_bytes = one image, vbs_capi.cpp: drop_legacy_image) and rebuilt on the device -- an exact copy --
+    when a later call reads it: SPARTA_SPMM_EXACT must still be bit-identical to the reference's VBR::multiply, a row-major B and the per-class kernels within the bar."""
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_PATH", "stream")
+    m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + w)
+    g = sa.BlockingEngine(tau=0.5, col_block_size=w, row_block_size=blk[1], blocking_algo=5).GetGrouping(m) if blk[0] == "keeper" else np.arange(rows) // blk[1]
+    v = sa.VBR().fill_from_CSR_inplace(m, g, w)
+    n = 128
+    B = sa.gen.dense_rhs(v.cols, n, seed=5)
+    Co = _oracle_c(v, B, n)
+    bound = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+    d = v.to_device(0)
+    two = d.info()["a_bytes"]
+    legacy = (int(v.mab.size) + 128) * 4
+    Bt = torch.from_numpy(B).cuda()
+    Ct = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
+    d.spmm(Bt, Ct, n)
+    torch.cuda.synchronize()
+    _check(Ct.cpu().numpy(), Co, bound, "first product")
+    one = d.info()["a_bytes"]
+    if d.info()["stream_steps"] > 0:
+        assert one == two - legacy, "the reference-layout image of A was meant to be dropped after the first product (%d -> %d, image %d)" % (two, one, legacy)
+    Ct.zero_()
+    d.spmm(Bt, Ct, n)                                                     # ... and the next products run without it
+    torch.cuda.synchronize()
+    _check(Ct.cpu().numpy(), Co, bound, "second product")
+    Cx = np.zeros(v.rows * n, np.float32)
+    d.spmm_host(B, n, Cx, accumulate=True, algo=sa.SPMM_EXACT)           # reads the reference layout: rebuilt from the fragment image, bit for bit
+    assert np.array_equal(Cx, Co), "exact-order kernel after the rebuild is not bit-identical to the reference's VBR::multiply"
+    assert d.info()["a_bytes"] == two
+    Brm = torch.from_numpy(np.ascontiguousarray(B.reshape(n, v.cols).T)).cuda()      # row-major B: the LDS-staged kernels, reference-layout image
+    Ct.zero_()
+    d.spmm(Brm, Ct, n, b_layout=sa.ROW_MAJOR)
+    torch.cuda.synchronize()
+    _check(Ct.cpu().numpy(), Co, bound, "row-major B after the rebuild")
+    Ct.zero_()
+    d.spmm(Bt, Ct, n)
+    torch.cuda.synchronize()
+    _check(Ct.cpu().numpy(), Co, bound, "column-major B again")
+    assert d.info()["a_bytes"] == two, "a rebuilt image stays (no free / rebuild ping-pong)"
+    # a handle whose FIRST use reads the reference layout after a drop: row-major B straight after the first product
+    d2 = v.to_device(0)
+    Ct.zero_()
+    d2.spmm(Bt, Ct, n)
+    Ct.zero_()
+    d2.spmm(Brm, Ct, n, b_layout=sa.ROW_MAJOR)
+    torch.cuda.synchronize()
+    _check(Ct.cpu().numpy(), Co, bound, "row-major B on a handle that had dropped the image")
+
+
 def test_small_matrices_whose_tiles_are_not_worth_their_launches_go_to_the_sparse_rows(monkeypatch):
     """every launch of a product costs 5-10 us whatever it does: a small matrix whose tiles hold fewer nonzeros than their steps + three launches are worth is
     multiplied by the sparse-row kernels alone (one launch chain instead of two); a small DENSE matrix keeps its tiles.  Same product either way."""
