@@ -313,12 +313,17 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
             cpu = {"value": None, "unit": "GFLOP/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
     comparator = None
     if distributed:
-        try:                                        # the one-GPU run of the same P parts (profiles/r3/slabs*.json), when one is committed for this job
-            cj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3", "slabs%d_scale%d.json" % (P, scale))))
-            if cj["config"]["n_cols"] == N and cj["dtype"] == args.dtype and abs(cj["config"]["density"] - args.rmat_density) < 1e-12 and not cj["config"].get("extrapolated"):
-                comparator = {"one_gpu_ms": cj["ms_per_step"], "speedup": round(cj["ms_per_step"] / ms_job, 3), "source": "profiles/r3/slabs%d_scale%d.json" % (P, scale)}
-        except Exception:
-            comparator = None
+        # the one-GPU run of the same P parts (profiles/rN/slabs*.json, the newest round that holds one), when one is committed for this job
+        here = os.path.dirname(os.path.abspath(__file__))
+        for rnd in sorted((d for d in os.listdir(os.path.join(here, "profiles")) if d[:1] == "r" and d[1:].isdigit()), key=lambda d: -int(d[1:])):
+            rel = "profiles/%s/slabs%d_scale%d.json" % (rnd, P, scale)
+            try:
+                cj = json.load(open(os.path.join(here, rel)))
+                if cj["config"]["n_cols"] == N and cj["dtype"] == args.dtype and abs(cj["config"]["density"] - args.rmat_density) < 1e-12 and not cj["config"].get("extrapolated"):
+                    comparator = {"one_gpu_ms": cj["ms_per_step"], "speedup": round(cj["ms_per_step"] / ms_job, 3), "source": rel, "kernel_rev": cj.get("kernel_rev")}
+                    break
+            except Exception:
+                continue
     wl = ("R-MAT 2^%d (a,b,c = 0.57,0.19,0.19; canonical graph: %d raw edges, seed 3) at density %.4g %% = %.4g distinct nnz, rows cut into %d parts of equal "
           "expected cost, B = %d cols, %s" % (scale, E, 100.0 * args.rmat_density, nnz_total, P, N, {"f32": "fp32", "f16": "fp16", "bf16": "bf16"}[args.dtype]))
     out = {"metric": "Block-sparse SpMM GFLOP/s", "value": round(useful, 2), "unit": "GFLOP/s", "n_gpus": max(args.gpus, 1), "steps": args.steps,

@@ -1,18 +1,18 @@
 #!/usr/bin/env python3
-"""gpurun_out/ (what scripts/r3_final_record.sh + scripts/r3_parts_full.sh left) -> profiles/r3/ + profiles/traffic*.json, named by kernel revision.
-    python scripts/r3_collect_profiles.py r3e"""
+"""gpurun_out/ (what scripts/profile_bench.sh + scripts/r4_parts_full.sh left) -> profiles/r3/ + profiles/traffic*.json, named by kernel revision.
+    python scripts/collect_profiles.py r4 r4a"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rev = sys.argv[1]
-G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", "r3")
+RND, rev = sys.argv[1], sys.argv[2]
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", RND)
 
 
 def last_json_line(path):
     return [l for l in open(path) if l.startswith("{")][-1]
 
 
-for tag, name, traffic in (("r3_default", "bench_default", "traffic.json"), ("r3_f16", "bench_f16", "traffic_f16.json")):
+for tag, name, traffic in ((RND + "_default", "bench_default", "traffic.json"), (RND + "_f16", "bench_f16", "traffic_f16.json")):
     src = os.path.join(G, "prof_" + tag)
     if not os.path.isdir(src):
         print("no", src)
@@ -38,7 +38,7 @@ for tag, name, traffic in (("r3_default", "bench_default", "traffic.json"), ("r3
 for src, dst in (("bench_driver_cmd.json", "bench_driver_cmd_line.json"), ("bench_default.json", "bench_default_line.json"), ("bench_f16.json", "bench_f16_line.json"),
                  ("slabs8_scale23.json", None), ("c3_0p1pct_off.json", None), ("c3_0p1pct_on.json", None), ("c3_0p1pct_auto.json", None), ("c3_1pct_off.json", None),
                  ("c3_5pct_off.json", None), ("half_of_c4.json", None), ("suite.json", None), ("suite.md", None)):
-    s = os.path.join(G, "r3", src)
+    s = os.path.join(G, RND, src)
     if not os.path.exists(s):
         print("no", s)
         continue

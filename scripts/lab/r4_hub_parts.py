@@ -17,7 +17,8 @@ cfgs = {"5": (20, 5e-2, 64, 512, sa.BF16, torch.bfloat16), "1": (20, 1e-2, 16, 5
 for key in which.split(","):
     scale, dens, P, N, sdt, tdt = cfgs[key]
     E = sa.gen.rmat_raw_edges_for_density(scale, dens)
-    r0, r1 = sa.gen.rmat_cuts(scale, E, P)[0]
+    part = int(os.environ.get("HUB_PART", "0"))
+    r0, r1 = sa.gen.rmat_cuts(scale, E, P)[part]
     t0 = time.time()
     m = sa.gen.rmat_rows(scale, E, r0, r1, device=0)
     g = np.arange(m.rows) // 64
@@ -26,7 +27,7 @@ for key in which.split(","):
     B = torch.zeros(ldb * N, dtype=tdt, device="cuda")
     B.view(N, ldb)[:, :n] = sa.gen.dense_rhs_rows(0, n, N, dtype=tdt, device=0).view(N, n)
     C = torch.zeros(m.rows * N, dtype=torch.float32, device="cuda")
-    print("config %s part 0: rows %d nnz %d (generate %.1f s)" % (key, m.rows, m.nztot(), time.time() - t0), flush=True)
+    print("config %s part %d: rows %d nnz %d (generate %.1f s)" % (key, part, m.rows, m.nztot(), time.time() - t0), flush=True)
     perm = sa.get_permutation(g)
     ref = None
     for name, env in variants:
@@ -50,7 +51,9 @@ for key in which.split(","):
         st = np.mean([t["stream"] for t in ts]); fx = np.mean([t["fixup"] for t in ts]); sp = np.mean([t["sparse"] for t in ts])
         area = info["nztot"]
         print("  %-34s build %.1f s | stream %.3f ms fixup %.3f sparse %.3f | tile area %.4g -> %.0f TFLOP/s on the stored area | hub: %s | check %.1e" %
-              (name, tb, st, fx, sp, area, 2.0 * area * N / (st * 1e-3) / 1e12, hi, worst), flush=True)
+              (name, tb, st, fx, sp, area, 2.0 * area * N / (max(st, 1e-9) * 1e-3) / 1e12, hi, worst), flush=True)
+        si = d.sparse_info()
+        print("      sparse rows: %s -> %.1f Gnnz/s" % (si, si["nnz"] / max(sp, 1e-9) / 1e6), flush=True)
         d.close()
         for k in env: os.environ.pop(k, None)
     del B, C, m

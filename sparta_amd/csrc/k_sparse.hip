@@ -90,6 +90,104 @@ __device__ __forceinline__ typename SpVec<VEC>::T sparse_row_partial(const Spars
     return acc;
 }
 
+// Round 4: the same sum for a ROW-major B with the bookkeeping moved off the vector pipe.  Measured on the hub parts of the power-law configs the gather above spent 10-12
+// vector instructions per nonzero on top of its load -- two v_readlane, a 64-bit vector add for the address, a VECTOR compare + exec mask + branch for "t < n" (n was
+// wave-uniform but lived in VGPRs), four conversions and two packed FMAs -- 24 cycles per nonzero and CU against the 8 the load path needs for 512 bytes.  Here the
+// (column, value) pairs come through SCALAR loads (constant address space: the range is wave-uniform, so a batch is two s_load_dwordx16 and no readlane), the row of B
+// is addressed as scalar base + one per-lane byte offset (global_load ... v_off, s[base:base+1]), a full batch runs without any condition and only the last, short
+// batch of a range takes wave-uniform scalar branches.  The order of the additions is the one of sparse_row_partial: bit-identical results.
+__device__ __forceinline__ int64_t sp_uniform64(int64_t x) {
+    return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x));
+}
+
+template <int VEC, int BK>
+__device__ __forceinline__ typename SpVec<VEC>::T sparse_row_partial_s(const SparseParams& p, int64_t p0v, int64_t p1v, int n0) {
+    typedef typename SpVec<VEC>::T V;
+    typedef typename std::conditional<BK == 0, float, unsigned short>::type E;
+    typedef typename std::conditional<BK == 0, V, typename SpRaw16<VEC>::T>::type L;
+    typedef const __attribute__((address_space(4))) int32_t* ccol_t;
+    typedef const __attribute__((address_space(4))) float* cval_t;
+    const int64_t p0 = sp_uniform64(p0v), p1 = sp_uniform64(p1v);
+    const ccol_t colc = (ccol_t)p.col;
+    const cval_t valc = (cval_t)p.val;
+    V acc = (V)(0.0f);
+    const bool in = VEC > 1 || n0 < p.N;
+    const uint32_t loff = (uint32_t)(in ? n0 : 0) * (uint32_t)sizeof(E);       // this lane's columns inside a row of B
+    const char* Bb = (const char*)p.B;
+    const uint32_t ldbb32 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p.ldb * (int64_t)sizeof(E)));
+    // row c of B as a SCALAR base (kept in SGPRs: the empty asm stops the compiler from folding the per-lane offset into a 64-bit vector address per nonzero)
+    typedef const __attribute__((address_space(1))) char* gptr_t;
+    typedef const __attribute__((address_space(1))) L* gl_t;
+    auto row_of = [&](int col) __attribute__((always_inline)) -> gptr_t {
+        uint64_t r = (uint64_t)Bb + (uint64_t)(uint32_t)col * (uint64_t)ldbb32;     // (a row of B is shorter than 4 GB: launch_sparse_rows checks)
+        asm("" : "+s"(r));
+        return (gptr_t)r;
+    };
+    auto fma_row = [&](float v, const L& b) __attribute__((always_inline)) {
+        if constexpr (BK == 0) {
+            if constexpr (VEC == 1) acc = __builtin_fmaf(v, b, acc);
+            else {
+#pragma unroll
+                for (int e = 0; e < VEC; e++) acc[e] = __builtin_fmaf(v, b[e], acc[e]);
+            }
+        } else if constexpr (BK == 1 && VEC > 1) {
+            // fp16: v_fma_mix_f32 widens the half inside the FMA (one instruction per element instead of a conversion and half a packed FMA); the same fused product-sum
+            const auto w = __builtin_bit_cast(typename std::conditional<VEC == 2, uint32_t, uint32_t __attribute__((ext_vector_type(2)))>::type, b);
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                uint32_t word;
+                if constexpr (VEC == 2) word = w; else word = w[e >> 1];
+                float a = acc[e];
+                if (e & 1) asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(a) : "s"(v), "v"(word));
+                else asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(a) : "s"(v), "v"(word));
+                acc[e] = a;
+            }
+        } else if constexpr (VEC == 1) acc = __builtin_fmaf(v, sp_widen(b, BK == 2), acc);
+        else {
+#pragma unroll
+            for (int e = 0; e < VEC; e++) acc[e] = __builtin_fmaf(v, sp_widen(b[e], BK == 2), acc[e]);
+        }
+    };
+    int c[SP_BATCH];
+    float v[SP_BATCH];
+#pragma unroll
+    for (int t = 0; t < SP_BATCH; t++) { c[t] = colc[p0 + t]; v[t] = valc[p0 + t]; }          // (the arrays end in 64 zero entries: vbs_capi.cpp)
+#pragma unroll 1
+    for (int64_t q = p0; q < p1; q += SP_BATCH) {
+        const int n = (int)(p1 - q < SP_BATCH ? p1 - q : SP_BATCH);
+        L b[SP_BATCH];
+        if (n == SP_BATCH) {
+#pragma unroll
+            for (int t = 0; t < SP_BATCH; t++) b[t] = *(gl_t)(row_of(c[t]) + loff);
+            float vc[SP_BATCH];
+#pragma unroll
+            for (int t = 0; t < SP_BATCH; t++) vc[t] = v[t];
+#pragma unroll
+            for (int t = 0; t < SP_BATCH; t++) { c[t] = colc[q + SP_BATCH + t]; v[t] = valc[q + SP_BATCH + t]; }      // the next batch's pairs, behind this batch's loads
+#pragma unroll
+            for (int t = 0; t < SP_BATCH; t++) fma_row(vc[t], b[t]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < SP_BATCH; t++)
+                if (t < n) b[t] = *(gl_t)(row_of(c[t]) + loff);
+#pragma unroll
+            for (int t = 0; t < SP_BATCH; t++)
+                if (t < n) fma_row(v[t], b[t]);
+        }
+    }
+    return acc;
+}
+
+// the gather of one range of nonzeros: the scalar-batch version for a row-major B, the in-place one for a column-major B
+template <int VEC, int BK>
+__device__ __forceinline__ typename SpVec<VEC>::T sparse_range(const SparseParams& p, int64_t p0, int64_t p1, int n0, int lane) {
+    if (p.scalar_gather && !(VEC == 1 && p.b_col_stride > 0)) return sparse_row_partial_s<VEC, BK>(p, p0, p1, n0);
+    int cl;
+    float vl;
+    sp_batch_load(p, p0, p1, lane, cl, vl);
+    return sparse_row_partial<VEC, BK>(p, p0, p1, n0, lane, cl, vl);
+}
+
 template <int VEC>
 __device__ __forceinline__ void sparse_row_store(const SparseParams& p, int ord, typename SpVec<VEC>::T acc, int n0) {
     typedef typename SpVec<VEC>::T V;
@@ -109,10 +207,7 @@ __global__ __launch_bounds__(kThreads) void sparse_rows_kernel(SparseParams p) {
     const int ord = p.list[slot];
     const int n0 = (blockIdx.y * 64 + lane) * VEC;
     const int64_t p0 = p.rowptr[ord], p1 = p.rowptr[ord + 1];
-    int cl;
-    float vl;
-    sp_batch_load(p, p0, p1, lane, cl, vl);
-    sparse_row_store<VEC>(p, ord, sparse_row_partial<VEC, BK>(p, p0, p1, n0, lane, cl, vl), n0);
+    sparse_row_store<VEC>(p, ord, sparse_range<VEC, BK>(p, p0, p1, n0, lane), n0);
 }
 
 // kCmRows partial rows of one chunk of columns meet in LDS (element (row j, column l * VEC + e) at ((e * kCmRows + j) * 65 + l)) and leave
@@ -176,9 +271,10 @@ __device__ __forceinline__ void sparse_rows_cm_body(const SparseParams& p, float
     auto row_p0 = [&](int i) {
         return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(mhi, i) << 32) | (uint32_t)__builtin_amdgcn_readlane(mlo, i));
     };
-    int cl;
-    float vl;
-    {
+    const bool scalar_path = p.scalar_gather && !(VEC == 1 && p.b_col_stride > 0);
+    int cl = 0;
+    float vl = 0.0f;
+    if (!scalar_path) {
         const int64_t a = row_p0(0);
         sp_batch_load(p, a, a + __builtin_amdgcn_readlane(mcnt, 0), lane, cl, vl);
     }
@@ -186,14 +282,18 @@ __device__ __forceinline__ void sparse_rows_cm_body(const SparseParams& p, float
     for (int i = 0; i < RPW; i++) {
         const int j = wave + NW * i;
         const int64_t p0 = row_p0(i), p1 = p0 + __builtin_amdgcn_readlane(mcnt, i);
-        int cn = 0;
-        float vn = 0.0f;
-        if (i + 1 < RPW) {                                       // first batch of the next row, requested before this row's rows of B
-            const int64_t a = row_p0(i + 1);
-            sp_batch_load(p, a, a + __builtin_amdgcn_readlane(mcnt, i + 1), lane, cn, vn);
+        V acc;
+        if (scalar_path) acc = sparse_row_partial_s<VEC, BK>(p, p0, p1, n0);         // an empty range (slot past the list) gives zeros
+        else {
+            int cn = 0;
+            float vn = 0.0f;
+            if (i + 1 < RPW) {                                   // first batch of the next row, requested before this row's rows of B
+                const int64_t a = row_p0(i + 1);
+                sp_batch_load(p, a, a + __builtin_amdgcn_readlane(mcnt, i + 1), lane, cn, vn);
+            }
+            acc = sparse_row_partial<VEC, BK>(p, p0, p1, n0, lane, cl, vl);
+            cl = cn; vl = vn;
         }
-        const V acc = sparse_row_partial<VEC, BK>(p, p0, p1, n0, lane, cl, vl);      // an empty range (slot past the list) gives zeros
-        cl = cn; vl = vn;
 #pragma unroll
         for (int e = 0; e < VEC; e++) {
             float x;
@@ -223,10 +323,7 @@ __device__ __forceinline__ void sparse_segments_body(const SparseParams& p, cons
     if (slot >= n_segs) return;
     const SpSegRec sg = segs[slot];
     const int n0 = (blockIdx.y * 64 + lane) * VEC;
-    int cl;
-    float vl;
-    sp_batch_load(p, sg.p0, sg.p0 + sg.cnt, lane, cl, vl);
-    typename SpVec<VEC>::T acc = sparse_row_partial<VEC, BK>(p, sg.p0, sg.p0 + sg.cnt, n0, lane, cl, vl);
+    typename SpVec<VEC>::T acc = sparse_range<VEC, BK>(p, sg.p0, sg.p0 + sg.cnt, n0, lane);
     if (VEC == 1 && n0 >= p.N) return;
     *reinterpret_cast<typename SpVec<VEC>::T*>(part + (int64_t)sg.pad * p.N + n0) = acc;
 }
@@ -234,6 +331,17 @@ __device__ __forceinline__ void sparse_segments_body(const SparseParams& p, cons
 template <int VEC, int BK>
 __global__ __launch_bounds__(kThreads) void sparse_segments_kernel(SparseParams p, const SpSegRec* segs, int32_t n_segs, float* part) {
     sparse_segments_body<VEC, BK>(p, segs, n_segs, part, blockIdx.x);
+}
+
+// XCD-affine order (round 4).  With all workgroups walking the same column window, the eight L2s of the chip hold eight copies of the same few MB of B.  Here the
+// segment list is eight STREAMS (vbs_capi.cpp: windows dealt to streams by nonzeros, each stream in column order), and workgroup b -- which the hardware places on XCD
+// b % 8 -- takes its segments from stream b % 8: every L2 holds its own window, eight different windows are cache-resident at a time.
+template <int VEC, int BK>
+__global__ __launch_bounds__(kThreads) void sparse_segments_xcd_kernel(SparseParams p, const SpSegRec* segs, const int32_t* stream_begin, float* part) {
+    const int stream = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int b0 = stream_begin[stream], b1 = stream_begin[stream + 1];
+    if (b0 + k * 4 >= b1) return;
+    sparse_segments_body<VEC, BK>(p, segs + b0, b1 - b0, part, k);
 }
 
 // small sparse parts, column-major C: the rows of ordinary length (4 or 16 per workgroup, as in the separate launch) and the segments of the long rows in ONE launch - workgroups
@@ -373,7 +481,7 @@ namespace sparta_dev {
 namespace {
 template <int VEC, int BK>
 void launch_sparse_t(SparseParams q, unsigned gy, hipStream_t st, const int32_t* list, int64_t n_short, const SpSegRec* segs, int64_t n_segs,
-                     const SpLongRec* longs, int64_t n_long, float* part) {
+                     const SpLongRec* longs, int64_t n_long, float* part, const int32_t* stream_begin, int64_t max_stream) {
     const bool fused_small = q.out_is_c == 2 && n_short > 0 && n_short < 262144 && n_long > 0 && n_segs > 0 && n_segs < 65536;
     if (fused_small) {
         q.list = list; q.n_list = (int32_t)n_short;
@@ -396,7 +504,9 @@ void launch_sparse_t(SparseParams q, unsigned gy, hipStream_t st, const int32_t*
         else hipLaunchKernelGGL((sparse_rows_kernel<VEC, BK>), dim3((unsigned)((n_short + 3) / 4), gy), dim3(kThreads), 0, st, q);
     }
     if (n_long > 0) {
-        if (!fused_small) hipLaunchKernelGGL((sparse_segments_kernel<VEC, BK>), dim3((unsigned)((n_segs + 3) / 4), gy), dim3(kThreads), 0, st, q, segs, (int32_t)n_segs, part);
+        if (!fused_small && stream_begin)
+            hipLaunchKernelGGL((sparse_segments_xcd_kernel<VEC, BK>), dim3((unsigned)(8 * ((max_stream + 3) / 4)), gy), dim3(kThreads), 0, st, q, segs, stream_begin, part);
+        else if (!fused_small) hipLaunchKernelGGL((sparse_segments_kernel<VEC, BK>), dim3((unsigned)((n_segs + 3) / 4), gy), dim3(kThreads), 0, st, q, segs, (int32_t)n_segs, part);
         if (q.out_is_c == 2) hipLaunchKernelGGL((sparse_reduce_cm_kernel<VEC, 16>), dim3((unsigned)((n_long + 15) / 16), gy), dim3(kThreads), 0, st, q, longs, (int32_t)n_long, (const float*)part);
         else hipLaunchKernelGGL(sparse_reduce_kernel<VEC>, dim3((unsigned)((n_long + 3) / 4), gy), dim3(kThreads), 0, st, q, longs, (int32_t)n_long, (const float*)part);
     }
@@ -404,12 +514,12 @@ void launch_sparse_t(SparseParams q, unsigned gy, hipStream_t st, const int32_t*
 }  // namespace
 
 void launch_sparse_kernels(int vec, int bk, const SparseParams& q, unsigned gy, hipStream_t st, const int32_t* list, int64_t n_short, const SpSegRec* segs,
-                           int64_t n_segs, const SpLongRec* longs, int64_t n_long, float* part) {
+                           int64_t n_segs, const SpLongRec* longs, int64_t n_long, float* part, const int32_t* stream_begin, int64_t max_stream) {
 #define SPARTA_SP_DISPATCH(V_)                                                                                         \
     do {                                                                                                               \
-        if (bk == 0) launch_sparse_t<V_, 0>(q, gy, st, list, n_short, segs, n_segs, longs, n_long, part);              \
-        else if (bk == 1) launch_sparse_t<V_, 1>(q, gy, st, list, n_short, segs, n_segs, longs, n_long, part);         \
-        else launch_sparse_t<V_, 2>(q, gy, st, list, n_short, segs, n_segs, longs, n_long, part);                      \
+        if (bk == 0) launch_sparse_t<V_, 0>(q, gy, st, list, n_short, segs, n_segs, longs, n_long, part, stream_begin, max_stream);              \
+        else if (bk == 1) launch_sparse_t<V_, 1>(q, gy, st, list, n_short, segs, n_segs, longs, n_long, part, stream_begin, max_stream);         \
+        else launch_sparse_t<V_, 2>(q, gy, st, list, n_short, segs, n_segs, longs, n_long, part, stream_begin, max_stream);                      \
     } while (0)
     if (vec == 4) SPARTA_SP_DISPATCH(4); else if (vec == 2) SPARTA_SP_DISPATCH(2); else SPARTA_SP_DISPATCH(1);
 #undef SPARTA_SP_DISPATCH

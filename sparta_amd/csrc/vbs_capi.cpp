@@ -89,6 +89,7 @@ void destroy_impl(sparta_vbs* v) {
     if (v->d_sp_crow) (void)hipFree(v->d_sp_crow);
     if (v->d_sp_list) (void)hipFree(v->d_sp_list);
     if (v->d_sp_segs) (void)hipFree(v->d_sp_segs);
+    if (v->d_sp_stream_begin) (void)hipFree(v->d_sp_stream_begin);
     if (v->d_sp_long) (void)hipFree(v->d_sp_long);
     if (v->d_sp_part) (void)hipFree(v->d_sp_part);
     if (v->d_Brm) (void)hipFree(v->d_Brm);
@@ -292,7 +293,13 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     // SPARTA_SP_WINDOW_COLS: unset = automatic (on from 262144 columns and 4 M nonzeros on this path), 0 = off, > 0 = the window width in columns;
     // SPARTA_SP_LONG / SPARTA_SP_MINSEG: the row length above which a row is cut / the nonzeros a segment holds before a window boundary ends it.
     const int64_t sp_total = sp_rowptr.empty() ? 0 : sp_rowptr.back();
-    int64_t win_w = (cols >= 4 * 65536 && sp_total >= ((int64_t)4 << 20)) ? 32768 : 0, sp_minseg = 128;
+    // Round 4: the windows are dealt to eight streams, one per XCD (below: every L2 then holds its OWN window instead of a copy of everybody's), and are 8192 columns wide
+    // (2 MB of B per L2 at the 256-byte row chunks the large parts run with).  Parts of configs[4] / configs[3] at 1 %, sparse-row kernels, ms: one list of 32768-column
+    // windows 25.8 / 31.5 / 10.7 -> eight streams of 8192-column windows 24.5 / 28.9 / 10.3 (4096 .. 32768 columns: within 1 %).  SPARTA_SP_XCD=0: one list, 32768 columns.
+    bool sp_xcd = true;
+    if (const char* e = std::getenv("SPARTA_SP_XCD")) sp_xcd = atoi(e) != 0;
+    int64_t win_w = (cols >= 4 * 65536 && sp_total >= ((int64_t)4 << 20)) ? (sp_xcd ? 8192 : 32768) : 0, sp_minseg = 128;
+    std::vector<int32_t> sp_stream_begin;
     if (const char* e = std::getenv("SPARTA_SP_WINDOW_COLS")) win_w = std::max(0, atoi(e));
     if (win_w > 0) kSpLong = 128;
     if (const char* e = std::getenv("SPARTA_SP_LONG")) kSpLong = std::max(8, atoi(e));
@@ -366,6 +373,34 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         std::vector<SpSegRec> sorted(sp_segs.size());
         for (const SpSegRec& g : sp_segs) sorted[(size_t)start[(size_t)(sp_col[(size_t)g.p0] / win_w)]++] = g;
         sp_segs.swap(sorted);
+        // XCD-affine order (k_sparse.hip: sparse_segments_xcd_kernel): the windows are dealt to eight streams -- heaviest first, each to the stream with the fewest
+        // nonzeros so far -- and the list becomes stream 0's windows in column order, then stream 1's, ...; workgroup b takes from stream b % 8 = its XCD.
+        if (sp_xcd && sp_segs.size() >= 64) {
+            std::vector<int64_t> w_nnz((size_t)n_win, 0), w_begin((size_t)n_win + 1, 0);
+            for (const SpSegRec& g : sp_segs) { const size_t k = (size_t)(sp_col[(size_t)g.p0] / win_w); w_nnz[k] += g.cnt; w_begin[k + 1]++; }
+            for (int64_t k = 0; k < n_win; k++) w_begin[(size_t)k + 1] += w_begin[(size_t)k];
+            std::vector<int64_t> order((size_t)n_win);
+            for (int64_t k = 0; k < n_win; k++) order[(size_t)k] = k;
+            std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return w_nnz[(size_t)a] > w_nnz[(size_t)b]; });
+            int64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            std::vector<int8_t> stream_of((size_t)n_win, 0);
+            for (int64_t k : order) {
+                int best = 0;
+                for (int x = 1; x < 8; x++) if (load[x] < load[best]) best = x;
+                stream_of[(size_t)k] = (int8_t)best;
+                load[best] += w_nnz[(size_t)k] + 16 * (w_begin[(size_t)k + 1] - w_begin[(size_t)k]);       // (a segment costs about a batch whatever it holds)
+            }
+            std::vector<SpSegRec> streamed;
+            streamed.reserve(sp_segs.size());
+            sp_stream_begin.assign(9, 0);
+            for (int x = 0; x < 8; x++) {
+                sp_stream_begin[(size_t)x] = (int32_t)streamed.size();
+                for (int64_t k = 0; k < n_win; k++)
+                    if (stream_of[(size_t)k] == x) streamed.insert(streamed.end(), sp_segs.begin() + w_begin[(size_t)k], sp_segs.begin() + w_begin[(size_t)k + 1]);
+            }
+            sp_stream_begin[8] = (int32_t)streamed.size();
+            sp_segs.swap(streamed);
+        }
     }
     n_sp_short = (int64_t)sp_list.size(); n_sp_long = (int64_t)sp_long.size();
     trace.lap("sparse rows (device form)");
@@ -600,6 +635,11 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             v->n_sp_segs = (int64_t)sp_segs.size();
             CREATE_TRY(hipMalloc(&v->d_sp_segs, sp_segs.size() * sizeof(SpSegRec)));
             CREATE_TRY(hipMemcpy(v->d_sp_segs, sp_segs.data(), sp_segs.size() * sizeof(SpSegRec), hipMemcpyHostToDevice));
+            if (!sp_stream_begin.empty()) {
+                CREATE_TRY(hipMalloc((void**)&v->d_sp_stream_begin, 9 * sizeof(int32_t)));
+                CREATE_TRY(hipMemcpy(v->d_sp_stream_begin, sp_stream_begin.data(), 9 * sizeof(int32_t), hipMemcpyHostToDevice));
+                for (int x = 0; x < 8; x++) v->sp_max_stream = std::max<int64_t>(v->sp_max_stream, sp_stream_begin[(size_t)x + 1] - sp_stream_begin[(size_t)x]);
+            }
             CREATE_TRY(hipMalloc(&v->d_sp_long, sp_long.size() * sizeof(SpLongRec)));
             CREATE_TRY(hipMemcpy(v->d_sp_long, sp_long.data(), sp_long.size() * sizeof(SpLongRec), hipMemcpyHostToDevice));
         }
@@ -866,7 +906,7 @@ int ensure_gathered_steps(sparta_vbs_t* A, int64_t shard_rows, hipStream_t st) {
 
 
 // fp32 handles whose <= 32-row tiles have a fragment image (k_f32_direct.hip) hold A twice at create time.  Once the no-barrier kernel has won the plan-time autotune on a
-// handle whose tiles are ALL in that image, the reference-layout copy is dropped (drop_legacy_image: a_bytes = one image); a later call that reads it -- SPARTA_SPMM_EXACT, a
+// handle whose blocks are ALL in that image (no 33..64-row tiles, no sparse rows), the reference-layout copy is dropped (drop_legacy_image: a_bytes = one image); a later call that reads it -- SPARTA_SPMM_EXACT, a
 // row-major or gathered B, the per-class kernels -- rebuilds it on the device from the fragment image (an exact copy) and then keeps it.  SPARTA_F32_KEEP_LEGACY=1: never drop.
 int ensure_legacy_image(sparta_vbs_t* A, hipStream_t st) {
     if (A->d_A || A->dtype != SPARTA_F32) return SPARTA_OK;
@@ -881,7 +921,7 @@ int ensure_legacy_image(sparta_vbs_t* A, hipStream_t st) {
 }
 void drop_legacy_image(sparta_vbs_t* A) {
     static const bool keep = [] { const char* e = std::getenv("SPARTA_F32_KEEP_LEGACY"); return e && atoi(e) != 0; }();
-    if (keep || g_capturing || A->legacy_dropped || !A->d_A || !A->d_a_frag || A->dtype != SPARTA_F32 || A->n_steps[1] != 0 || A->class_timing) return;
+    if (keep || g_capturing || A->legacy_dropped || !A->d_A || !A->d_a_frag || A->dtype != SPARTA_F32 || A->n_steps[1] != 0 || A->n_sp_rows != 0 || A->class_timing) return;
     (void)hipFree(A->d_A);                               // (synchronises: the autotune's launches that read it are done)
     A->d_A = nullptr;
     A->a_bytes -= (int64_t)((A->nztot + 128) * sizeof(float));
@@ -911,6 +951,12 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
         launch_b_to_row_major(bk != 0, (unsigned)n_wg, st, dB, ldb, shard_rows, shard_stride, A->cols, (int)n_cols, A->d_Brm);
         q.B = A->d_Brm; q.ldb = n_cols;
     }
+    // round 4: (column, value) pairs through scalar loads and the row of B as an SGPR base (k_sparse.hip: sparse_row_partial_s) -- rows of B shorter than 4 GB (the
+    // row offset is a 32 x 32 -> 64 bit scalar multiply); SPARTA_SP_SCALAR=0: the round-3 gather (developer A/B; read per call)
+    {
+        const char* e = std::getenv("SPARTA_SP_SCALAR");
+        q.scalar_gather = (e ? atoi(e) != 0 : true) && q.b_col_stride == 0 && q.ldb * (int64_t)esz < ((int64_t)1 << 32) ? 1 : 0;
+    }
     // the kernels write C themselves: rows of a row-major C, or 16-row pieces of the columns of the reference's column-major C
     q.out = dC; q.ldo = ldc; q.out_is_c = c_row_major ? 1 : 2;
     if (A->n_sp_long > 0)
@@ -928,7 +974,7 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     // by 3-10 %.  2-byte loads (one bf16 per lane) are slow whatever the size (6.6 ms) and never chosen.  SPARTA_SP_VEC caps the width.
     static const int vec_cap = [] { const char* e = std::getenv("SPARTA_SP_VEC"); return e ? atoi(e) : 4; }();
     const double b_bytes = (double)A->cols * (double)n_cols * (double)esz;
-    static const int row_bytes_env = [] { const char* e = std::getenv("SPARTA_SP_ROW_BYTES"); return e ? atoi(e) : 0; }();
+    const int row_bytes_env = [] { const char* e = std::getenv("SPARTA_SP_ROW_BYTES"); return e ? atoi(e) : 0; }();      // (read per call: developer A/B)
     // (what matters is the SLICE of B one column chunk touches, cols x row_bytes: while that fits the Infinity Cache the widest chunk wins -- the reference's real
     // matrices at its operand width N = 8192, 8-58 k columns, |B| = 0.3-1.9 GB: 1.14 -> 0.83 ms (bcsstk18), 3.37 -> 2.81 (social_location) with 1024 instead of 256)
     const bool slice_fits = (double)A->cols * 1024.0 <= 96e6;
@@ -937,7 +983,7 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     const int vec = in_place ? 1 : (vec_want >= 4 && aligned(4) ? 4 : (vec_want >= 2 && aligned(2) ? 2 : 1));
     const unsigned gy = (unsigned)((n_cols + 64 * vec - 1) / (64 * vec));
     launch_sparse_kernels(vec, bk, q, gy, st, A->d_sp_list, A->n_sp_short, (const SpSegRec*)A->d_sp_segs, A->n_sp_segs, (const SpLongRec*)A->d_sp_long,
-                          A->n_sp_long, (float*)A->d_sp_part);
+                          A->n_sp_long, (float*)A->d_sp_part, A->d_sp_stream_begin, A->sp_max_stream);
     HIP_TRY(hipGetLastError());
     return SPARTA_OK;
 }

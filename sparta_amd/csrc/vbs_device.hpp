@@ -159,6 +159,7 @@ struct SparseParams {
     float* out;                // out_is_c 1: row-major C (ld = ldc, row = crow); 2: COLUMN-major C (ld = ldc)
     int64_t ldo;
     int32_t out_is_c, accumulate, N;
+    int32_t scalar_gather;     // 1: (column, value) pairs through scalar loads, row base in SGPRs (k_sparse.hip: sparse_row_partial_s); 0: the round-3 gather (SPARTA_SP_SCALAR=0)
 };
 
 struct SpSegRec { int64_t p0; int32_t cnt, pad; };
@@ -265,6 +266,8 @@ struct sparta_vbs {
     void* d_sp_segs = nullptr;             // SpSegRec[n_sp_segs]: segments of the long rows
     void* d_sp_long = nullptr;             // SpLongRec[n_sp_long]
     int64_t n_sp_segs = 0;
+    int32_t* d_sp_stream_begin = nullptr;  // XCD-affine order of the segments: eight streams, [9] offsets into d_sp_segs (nullptr: one list, window-major)
+    int64_t sp_max_stream = 0;
     void* d_sp_part = nullptr;             // partial rows of the segments
     size_t d_sp_part_bytes = 0;
     void* d_Brm = nullptr;                 // row-major copy of a column-major / gathered B
@@ -309,7 +312,7 @@ void launch_convert_h16(bool bf16, hipStream_t st, const float* src, int64_t ld_
 void launch_col_tail_merge(hipStream_t st, const float* Ct, int64_t rows, float* C, int64_t ldc, int c_row_major, int col0, int n_t, int accumulate);
 // k_sparse.hip
 void launch_sparse_kernels(int vec, int bk, const SparseParams& q, unsigned gy, hipStream_t st, const int32_t* list, int64_t n_short, const SpSegRec* segs,
-                           int64_t n_segs, const SpLongRec* longs, int64_t n_long, float* part);
+                           int64_t n_segs, const SpLongRec* longs, int64_t n_long, float* part, const int32_t* stream_begin = nullptr, int64_t max_stream = 0);
 void launch_b_to_row_major(bool is16, unsigned grid, hipStream_t st, const void* B, int64_t ldb, int64_t shard_rows, int64_t shard_stride, int64_t rows, int N,
                            void* out);
 void launch_pack_blocks(dim3 grid, hipStream_t st, const void* src, const int32_t* ids, void* dst, int64_t block_vec);

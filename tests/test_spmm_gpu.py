@@ -872,7 +872,7 @@ def test_fp32_handle_keeps_one_image_of_a_and_rebuilds_the_reference_layout_on_d
     torch.cuda.synchronize()
     _check(Ct.cpu().numpy(), Co, bound, "first product")
     one = d.info()["a_bytes"]
-    if d.info()["stream_steps"] > 0:
+    if d.info()["stream_steps"] > 0 and d.info()["sparse_rows"] == 0:            # (a handle with sparse rows keeps it: their blocks are not in the fragment image)
         assert one == two - legacy, "the reference-layout image of A was meant to be dropped after the first product (%d -> %d, image %d)" % (two, one, legacy)
     Ct.zero_()
     d.spmm(Bt, Ct, n)                                                     # ... and the next products run without it
@@ -1297,7 +1297,10 @@ def test_sparse_rows_cut_at_column_windows_and_taken_window_by_window(monkeypatc
     Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
     Bt.view(n, ldb)[:, :cols] = torch.from_numpy(B.reshape(n, cols)).cuda().to(tdt)
     outs = []
-    for on in (True, False):
+    # eight streams of windows (one per XCD: sparse_segments_xcd_kernel under a row-major C, the fused small launch under a column-major one), one window-major list, no windows
+    for on in ("streams", "one-list", False):
+        if on == "one-list":
+            monkeypatch.setenv("SPARTA_SP_XCD", "0")
         if not on:
             monkeypatch.setenv("SPARTA_SP_WINDOW_COLS", "0")
         d = sa.DeviceVBS.from_csr(m, g, w, 0, False, device=0, dtype=dtype)
@@ -1315,7 +1318,8 @@ def test_sparse_rows_cut_at_column_windows_and_taken_window_by_window(monkeypatc
                 if cl == sa.COL_MAJOR and not acc:
                     outs.append(got)
         d.close()
-    assert np.max(np.abs(outs[0] - outs[1])) <= 1e-5 * np.max(bound)
+    assert np.array_equal(outs[0], outs[1]), "the order in which the segments are TAKEN must not change a bit"
+    assert np.max(np.abs(outs[0] - outs[2])) <= 1e-5 * np.max(bound)
 
 
 @pytest.mark.parametrize("dtype", [sa.F32, sa.F16], ids=["f32", "f16"])
