@@ -295,7 +295,7 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
     gbs_gather = sum_gather / (f_ex if not distributed else 1.0) / (sparse_ms_all * 1e-3) / 1e9 if sparse_ms_all > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(gbs_once, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(job_lb / (ms_job * 1e-3), 5),
                 "traffic": None, "traffic_source": None,
-                "kernel": "sparse_rows_cm_kernel + sparse_segments_kernel (gather of one row of B per nonzero) + vbs_spmm_h16_direct_kernel (hub tiles)",
+                "kernel": "sparse_rows_cm_kernel + sparse_segments_xcd_kernel (gather of one row of B per nonzero) + vbs_spmm_h16_hub_kernel / vbs_spmm_h16_direct_kernel (hub group tiles / the other 64-row tiles)",
                 "algorithmic_bytes": round(sum_alg), "gather_gbs": round(gbs_gather, 1),
                 "note": "frac = section-8(d) bound (per part: A once, B once, C once; MFMA part max(bytes, flops)) / measured time"
                         + ("; the job's bound is the slowest rank's" if distributed else "; summed over the parts")
