@@ -48,3 +48,22 @@ for src, dst in (("bench_driver_cmd.json", "bench_driver_cmd_line.json"), ("benc
     else:
         shutil.copy(s, d)
     print("copied", src)
+# round 4 extras: kernel tables of the power-law configs, the hub kernel's record, the sparse kernels' cache counters, the GPU test log, the lab notes
+for src, dst in (("kt_c4_kernel_stats.csv", "c4_kernel_stats.csv"), ("kt_c3_1pct_kernel_stats.csv", "c3_1pct_kernel_stats.csv"), ("kt_c3_0p1pct_kernel_stats.csv", "c3_0p1pct_kernel_stats.csv"),
+                 ("hub_profile_5.json", None), ("hub_profile_5_kernel_stats.csv", None), ("hub_profile_1.json", None), ("hub_profile_1_kernel_stats.csv", None),
+                 ("sp_pmc_part5.json", "sparse_pmc_c4_part5.json"), ("sp_pmc_part0.json", "sparse_pmc_c4_part0.json"), ("gputest.log", "gpu_tests.log"),
+                 ("hub_ubench.txt", "lab_hub_ubench.txt"), ("hub_g4.txt", "lab_hub_g4.txt"), ("hub_ldb.txt", "lab_hub_ldb.txt"), ("hub_ldb2.txt", "lab_hub_ldb2.txt"),
+                 ("hub_hot.txt", "lab_hub_hot.txt"), ("hub_lw.txt", "lab_hub_loader_waves.txt"), ("hub_nt.txt", "lab_hub_nt.txt"), ("hub_probe.txt", "lab_hub_probe.txt"),
+                 ("hub_big.txt", "lab_hub_big.txt"), ("glds_probe.txt", "lab_glds_probe.txt")):
+    s = os.path.join(G, RND, src)
+    if os.path.exists(s):
+        shutil.copy(s, os.path.join(P, dst or src))
+        print("copied", src)
+for src, dst in (("r4_hub_parts.txt", "lab_hub_parts.txt"), ("r4_hub_kblock.txt", "lab_hub_kblock.txt"), ("r4_sp_gather_old_f16.txt", "lab_sparse_gather_r3_f16.txt"),
+                 ("r4_sp_gather_new_f16.txt", "lab_sparse_gather_scalar_f16.txt"), ("r4_sp_gather_old_bf16.txt", "lab_sparse_gather_r3_bf16.txt"),
+                 ("r4_sp_gather_new_bf16.txt", "lab_sparse_gather_scalar_bf16.txt"), ("r4_sp_xcd_c4_0.txt", "lab_sparse_xcd_c4_part0.txt"), ("r4_sp_xcd_c4_5.txt", "lab_sparse_xcd_c4_part5.txt"),
+                 ("r4_sp_xcd2_c4_5.txt", "lab_sparse_rowbytes_c4_part5.txt"), ("r4_sp_xcd2_c3_8.txt", "lab_sparse_rowbytes_c3_1pct_part8.txt")):
+    s = os.path.join(G, src)
+    if RND == "r4" and os.path.exists(s):
+        shutil.copy(s, os.path.join(P, dst))
+        print("copied", src)

@@ -714,13 +714,77 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                     aligned_cut(cost, &wbnd);
                 } else best_C = std::min<int64_t>(16, block_cols);
             }
+            // ROUND-ROBIN DEALING (round 4, second form).  With consecutive whole units per worker the 16-32 workers that share an XCD at any one time sit in 4-8 different K chunks
+            // (worker w starts at unit w * units-per-worker): a panel of B is shared by ~2 workgroups before the L2 drops it (FETCH_SIZE on part 0 of configs[3] at 5 %:
+            // 49 GB per launch = A once + 25 x |B|).  Dealt round-robin -- unit t * W + j to worker j, odd rounds backwards so that trends in the group lengths cancel -- the
+            // workers of an XCD hold CONSECUTIVE units at every moment: the same K chunk, neighbouring groups (similar lengths: the groups are formed in order of length).
+            // The step list is laid out worker by worker, so the kernel and its worker ranges stay as they are.  MEASURED (hub parts of configs[3] at 5 % / 1 %, configs[4]):
+            // 12.76 / 12.58 / 6.87 ms against 12.27 / 12.85 / 6.86 with consecutive units, and FETCH_SIZE unchanged (50.5 against 50.3 GB): the workers of an XCD fall
+            // out of step inside their first unit (group lengths differ by more than the ~7 steps of panels an L2 holds beside the 512 KB of A slices per step), so the
+            // panels are not shared either way.  Off by default (SPARTA_HUB_DEAL=1 switches it on; tests cover both): what it needs is a step the workers of an XCD take
+            // TOGETHER at unit boundaries.
+            bool dealt = false;
+            std::vector<std::vector<int64_t>> units_of;                      // per worker: the units (index into the chunk-major cost table) it runs, in order
+            {
+                const char* de = std::getenv("SPARTA_HUB_DEAL");
+                const bool want = forced_ranges <= 0 && (de ? atoi(de) != 0 : false);
+                if (want) {
+                    int64_t best_span = INT64_MAX, best = -1;
+                    std::vector<int64_t> cost;
+                    auto deal = [&](const std::vector<int64_t>& c, std::vector<std::vector<int64_t>>* out) -> int64_t {
+                        std::vector<int64_t> load((size_t)hub_workers, 0);
+                        if (out) out->assign((size_t)hub_workers, {});
+                        int64_t k = 0;
+                        for (size_t q = 0; q < c.size(); q++) {
+                            if (c[q] == 0) continue;
+                            const int64_t t = k / hub_workers, j = k % hub_workers, wk = (t & 1) ? hub_workers - 1 - j : j;
+                            load[(size_t)wk] += c[q];
+                            if (out) (*out)[(size_t)wk].push_back((int64_t)q);
+                            k++;
+                        }
+                        return *std::max_element(load.begin(), load.end());
+                    };
+                    for (int64_t C = 1; C <= std::min<int64_t>(64, block_cols); C++) {
+                        unit_sizes(C, cost);
+                        const int64_t span = deal(cost, nullptr) + (C > 1 ? (int64_t)(0.025 * (double)C * (double)hub_groups.size()) : 0);
+                        if (span < best_span) { best_span = span; best = C; }
+                    }
+                    if (best > 0 && (double)best_span <= 1.10 * (double)S_all / (double)hub_workers + 1.0) {
+                        dealt = true; cut_aligned = true; best_C = best;
+                        unit_sizes(best_C, cost);
+                        deal(cost, &units_of);
+                    }
+                }
+            }
             n_ranges = best_C;
             P.hub_chunks = best_C;
             // order: (K chunk, group, block column, k slice)
             struct ORef { int32_t g, u, ks; };
             std::vector<ORef> order;
             order.reserve((size_t)S_all);
-            {
+            if (dealt) {
+                // the first union entry of every unit (chunk-major table), then the list worker by worker
+                const size_t NG = hub_groups.size();
+                std::vector<size_t> first((size_t)n_ranges * NG + 1, 0);
+                for (size_t gi = 0; gi < NG; gi++) {
+                    size_t c = 0;
+                    for (int64_t r = 0; r < n_ranges; r++) {
+                        first[(size_t)r * NG + gi] = c;
+                        const int64_t jb_end = (r + 1) * block_cols / n_ranges;
+                        while (c < un[gi].size() && un[gi][c].jb < jb_end) c++;
+                    }
+                }
+                wbnd.assign((size_t)hub_workers + 1, 0);
+                for (int wk = 0; wk < hub_workers; wk++) {
+                    for (int64_t q : units_of[(size_t)wk]) {
+                        const size_t gi = (size_t)q % NG;
+                        const int64_t r = q / (int64_t)NG, jb_end = (r + 1) * block_cols / n_ranges;
+                        for (size_t c = first[(size_t)q]; c < un[gi].size() && un[gi][c].jb < jb_end; c++)
+                            for (int64_t k = 0; k < spb; k++) order.push_back(ORef{(int32_t)gi, (int32_t)c, (int32_t)(k * 64)});
+                    }
+                    wbnd[(size_t)wk + 1] = (int64_t)order.size();
+                }
+            } else {
                 std::vector<size_t> cur(hub_groups.size(), 0);
                 for (int64_t r = 0; r < n_ranges; r++) {
                     const int64_t jb_end = (r + 1) * block_cols / n_ranges;

@@ -389,7 +389,7 @@ def _canonical_part(scale, dens, P, ip):
 
 @pytest.mark.parametrize("dens,P,ip", [(5e-2, 64, 0), (5e-2, 64, 63), (1e-2, 16, 0), (1e-2, 16, 15)], ids=["5pct-hub", "5pct-tail", "1pct-hub", "1pct-tail"])
 def test_config3_rmat20_at_1_and_5_percent_hub_and_tail_parts(dens, P, ip):
-    """configs[3] at its stated 1 % and 5 %: part 0 -- the hub: at 5 % 9216 rows of which 2048+ are fully dense, 8.7e9 stored elements in 16-bit tiles, the one
+    """configs[3] at its stated 1 % and 5 %: part 0 -- the hub: at 5 % ~12 k rows of which 2048+ are fully dense, 1.1e10 stored elements in 16-bit tiles, the one
     place a dense tile stream of that size occurs (it runs on the hub plan: group tiles of four 64-row tiles through the GEMM-shaped kernel, k_hub16.hip) -- and the
     LAST part (the all-sparse end of the graph) of the 64 / 16 parts of equal expected cost that bench.py --workload rmat-part --rmat-density 0.05 / 0.01 streams,
     reorder OFF (-a 2 -F 1: src/scripts/run_multiplication_experiments_fixed_cluster.sh:14-16), B = 512 columns bf16 in the (padded) all-gather layout."""
@@ -406,7 +406,7 @@ def test_config3_rmat20_at_1_and_5_percent_hub_and_tail_parts(dens, P, ip):
         assert hub["steps"] > 100000 and hub["tiles_per_group"] == 4 and hub["tiles"] >= 0.9 * info["tiles64"], (hub, info)
         assert hub["union_area"] <= 1.15 * hub["stored_area"], hub          # the Jaccard grouping of the block-rows: the unions hold few blocks their members lack
         if dens == 5e-2:
-            assert hub["stored_area"] > 8e9 and m.rows == 9216
+            assert hub["stored_area"] > 8e9 and 8192 <= m.rows <= 16384, m.rows    # (12288 rows with the cost constants of sa.gen.rmat_piece_table as of r4b)
     else:
         assert sp["nnz"] > 0.25 * m.nztot()                                  # the tail: sparse rows carry a large share (at 5 % even the last part keeps tiles)
     _part_checks(torch, m, g, d, B_gath, P, shard_rows, n, tdt, seed=50 + ip, shard_ld=shard_ld, n_rows=16 if ip == 0 else 64)      # (a hub row holds 10^5..10^6 nonzeros)

@@ -1812,10 +1812,11 @@ def test_16bit_handles_take_leading_dimensions_of_2_to_the_23(monkeypatch, _spar
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("sched", ["cut-by-steps", "dealt", "consecutive-units"])
 @pytest.mark.parametrize("G", ["2", "4"])
 @pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("rows,cols,nnz,n,drop", [(640, 6400, 260000, 256, 0.0), (1000, 8191, 800000, 384, 0.3), (300, 12800, 400000, 512, 0.15), (832, 4096, 300000, 200, 0.5)])
-def test_16bit_hub_group_tiles_against_the_oracle(monkeypatch, _sparse_row_mode, G, dtype, rows, cols, nnz, n, drop):
+def test_16bit_hub_group_tiles_against_the_oracle(monkeypatch, _sparse_row_mode, sched, G, dtype, rows, cols, nnz, n, drop):
     """The hub plan of 16-bit handles of 64-wide blocks (vbs_plan.cpp, k_hub16.hip): long tiles of 33..64 rows grouped by the Jaccard similarity of their block
     columns into group tiles of G, multiplied by the GEMM-shaped kernel over the UNION of the group's block columns -- a member without a block in a column is a
     slice that is not fetched.  Against the oracle's product on the rounded inputs: groups of 2 and of 4 (and the short groups a count not divisible by G leaves),
@@ -1826,7 +1827,13 @@ def test_16bit_hub_group_tiles_against_the_oracle(monkeypatch, _sparse_row_mode,
     monkeypatch.setenv("SPARTA_HUB_G", G)
     monkeypatch.setenv("SPARTA_HUB_MIN_TOTAL", "0")
     monkeypatch.setenv("SPARTA_HUB_MIN_STEPS", "16")
-    monkeypatch.setenv("SPARTA_HUB_RANGES", "4")
+    # the three schedules of the step list (vbs_plan.cpp, HUB PLAN part 2): four K ranges cut by step count anywhere (split segments inside units), whole (K chunk, group)
+    # units dealt round-robin to the workers (SPARTA_HUB_DEAL=1), consecutive whole units per worker (the default)
+    if sched == "cut-by-steps":
+        monkeypatch.setenv("SPARTA_HUB_RANGES", "4")
+    monkeypatch.setenv("SPARTA_HUB_DEAL", "1" if sched == "dealt" else "0")
+    if sched != "cut-by-steps" and _sparse_row_mode != "mfma-only":
+        pytest.skip("the schedules differ in the hub plan only: one sparse-row mode is enough")
     monkeypatch.setenv("SPARTA_HUB_TAU", "0.25")        # (random halves of the block columns are a third alike)
     w = 64
     m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + cols + n)
