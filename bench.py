@@ -755,7 +755,7 @@ def main():
             "vbs_area": vbs_area_ref, "fill": round(nnz_local / max(vbs_area_ref, 1), 6),
             "mean_block_row_height": round(mean_h, 2),
             "device_image": {"mfma_tile_area": int(info["nztot"]), "mfma_blocks": int(info["nblocks"]), "sparse_rows": sp["rows"], "sparse_nnz": sp["nnz"],
-                             "a_bytes": int(info["a_bytes"])},
+                             "a_bytes": int(dmain.info()["a_bytes"]), "a_bytes_at_create": int(info["a_bytes"])},      # (fp32: one image of A once the no-barrier kernel carries the products)
             "tiles": {"16": info["tiles16"], "32": info["tiles32"], "64": info["tiles64"]}, "kernel_path": path,
             "executed_gflops": round(flops_exec * (world if not strong else 1) / (ms_per_step * 1e-3) / 1e9, 1),
             "host_seconds": {"generate": round(t_gen, 2), "reorder": round(t_reorder, 2), "vbs_build": round(t_build, 2)},
@@ -884,7 +884,7 @@ def cpu_baseline(sa, args, m, grouping, vb, w, rbs, ff, N, B, ldb, B_gath, world
         t_csr = time.perf_counter() - t1
         csr_ref = {"value": round(2.0 * sub.nztot() * N / t_csr / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
                    "sample": "CSR::multiply on a seeded random %.2f %% of the rows (%d rows, %d nnz), %.2f s" % (100.0 * sub.rows / m.rows, sub.rows, sub.nztot(), t_csr)}
-    elif total_rows == m.rows and m.rows == m.cols and 2.0 * m.nztot() * N <= 4.0e10:
+    elif 0 <= total_rows - m.rows < 1024 and m.rows == m.cols and 2.0 * m.nztot() * N <= 4.0e10:      # (the VBS pads the rows to whole blocks: 62 451 -> 62 464)
         # the headline matrix (square, a few million nonzeros): the reference's OTHER CPU SpMM, CSR::multiply (src/general/csr.cpp:49-65), on the WHOLE matrix --
         # the compiled reference where it is present (oracle/_ref), else the oracle's restatement (BASELINE.md section 3 promises both loops)
         t_csr, csr_kind, n_rep = 0.0, "port", 0
