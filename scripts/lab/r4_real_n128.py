@@ -8,4 +8,4 @@ for name, kind, make, eng_kw, w in bench_suite.cases(sa, False):
     if not kind.startswith("real"): continue
     for N in (128, 512):
         r = bench_suite.run_one(sa, torch, name, kind, make, eng_kw, w, N=N, budget_ms=100.0)
-        print("%-28s N %4d | %.4f ms frac %.3f kernels %s check %.1e" % (name.split(":")[0], N, r["ms"], r["frac_8d"], r["kernels_ms"], r["check_max_err"]), flush=True)
+        print("%-28s N %4d | %.4f ms (prepared B %s) frac %.3f kernels %s check %.1e" % (name.split(":")[0], N, r["ms"], r.get("ms_prepared_b"), r["frac_8d"], r["kernels_ms"], r["check_max_err"]), flush=True)

@@ -12,8 +12,8 @@ import sparta_amd as sa  # noqa: E402
 import bench_suite  # noqa: E402
 
 OUT = sys.argv[1] if len(sys.argv) > 1 else None
-print("| matrix | rows | nnz | blocking (host s) | ms | useful GFLOP/s | carried by | frac_8d | gather GB/s |")
-print("|---|---|---|---|---|---|---|---|---|")
+print("| matrix | rows | nnz | blocking (host s) | ms | useful GFLOP/s | carried by | frac_8d | gather GB/s | ms behind a prepared B |")
+print("|---|---|---|---|---|---|---|---|---|---|")
 
 
 def log(r):
@@ -28,8 +28,9 @@ def log(r):
     if "error" in r:
         print("| %s | error: %s |" % (r["name"], r["error"]), flush=True)
         return
-    print("| %s | %d | %d | %s (%.2f) | %.4f | %.0f | %s | %.3f | %s |" % (r["name"], r["rows"], r["nnz"], r["blocking"], r["host_seconds"]["reorder"], r["ms"],
-          r["useful_gflops"], r["carried_by"], r["frac_8d"], "-" if r["gather_gbs"] is None else "%.0f" % r["gather_gbs"]), flush=True)
+    print("| %s | %d | %d | %s (%.2f) | %.4f | %.0f | %s | %.3f | %s | %s |" % (r["name"], r["rows"], r["nnz"], r["blocking"], r["host_seconds"]["reorder"], r["ms"],
+          r["useful_gflops"], r["carried_by"], r["frac_8d"], "-" if r["gather_gbs"] is None else "%.0f" % r["gather_gbs"],
+          "-" if r.get("ms_prepared_b") is None else "%.4f" % r["ms_prepared_b"]), flush=True)
 
 
 res = bench_suite.run(sa, torch, N=128, device=0, large=True, time_budget_s=600.0, log=log, sweep_budget_s=600.0)
