@@ -63,8 +63,9 @@ def run(args, torch, sa, dist, rank, local_rank, world, dev, emit, cpu_baseline)
     shard_rows = n // P
     gen = sa.gen
     E = gen.rmat_raw_edges_for_density(scale, args.rmat_density)
-    raw_tab, cost_tab = gen.rmat_piece_table(scale, E)
-    cuts = gen.rmat_cuts(scale, E, P)
+    tb_cost, row_cost = gen.rmat_cost_constants(N)
+    raw_tab, cost_tab = gen.rmat_piece_table(scale, E, tile_block_cost=tb_cost, row_cost=row_cost)
+    cuts = gen.rmat_cuts(scale, E, P, n_cols=N)
     rpp = 1 << (scale - gen.rmat_piece_bits(scale))
     part_cost = np.array([cost_tab[r0 // rpp:r1 // rpp].sum() for r0, r1 in cuts])
     if distributed and world > 1:

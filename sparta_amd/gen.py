@@ -380,11 +380,19 @@ def rmat_block_model(scale, raw_edges, a=0.57, b=0.19, c=0.19, block=64, tile_mi
     return out
 
 
-def rmat_piece_table(scale, raw_edges, a=0.57, b=0.19, c=0.19, tile_block_cost=25.0, row_cost=34.0):
+def rmat_cost_constants(n_cols=256):
+    """(tile_block_cost, row_cost) of rmat_piece_table for a product with n_cols columns of B, in units of one nonzero on the sparse-row path.  Least squares over the part
+    times of the round-4 records (profiles/r4, one MI355X, hub kernel + scalar gather + XCD streams): configs[4] (fp16, N = 256, 8 parts) 0.0425 ns per gathered nonzero,
+    41.6 / 92.0 nonzero-equivalents per tile block / row of C (the eight part times within 4.8 %); configs[3] (bf16, N = 512, its 30 parts at 0.1 / 1 / 5 % jointly) 0.0805 ns,
+    68.5 / 106.4 (within 4.2 %).  The parts those records ran on were cut with 25 / 34 (the first fit of the round): max / mean 1.16 (configs[4]), 1.11 / 1.19 / 1.30."""
+    return (42.0, 92.0) if int(n_cols) <= 256 else (68.0, 106.0)
+
+
+def rmat_piece_table(scale, raw_edges, a=0.57, b=0.19, c=0.19, tile_block_cost=42.0, row_cost=92.0):
     """Per canonical piece: (raw edges it receives, expected cost of its product).  Cost unit: one nonzero on the sparse-row path (one
     gathered row of B); a well-filled 64 x 64 block kept as an MFMA tile costs `tile_block_cost` of them, a row of C `row_cost` (least
-    squares over the eight parts of configs[4] on one MI355X, fp16, N = 256.  Round 4, with the hub kernel and the column windows: 0.054 ns per gathered nonzero,
-    1.35 ns per tile, 1.85 ns per row -- the fit reproduces the eight part times within 0.6 %; round 3: 0.102 ns, 5.6 ns per tile, rows ~ 0: the parts cut with those
+    squares over part times on one MI355X: rmat_cost_constants holds the current fits, the defaults here are those of configs[4].  First fit of round 4: 0.054 ns per gathered nonzero,
+    1.35 ns per tile, 1.85 ns per row = 25 / 34; round 3: 0.102 ns, 5.6 ns per tile, rows ~ 0: the parts cut with those
     coefficients ran 34.3-42.3 ms, max / mean 1.12, once the tiles had become four times cheaper);
     the model's own counts match the builder's: part 0 predicted 432.86 M sparse nonzeros + 1.4208 M tiles, built 432.82 M + 1.4212 M).  Pure arithmetic on the R-MAT marginals: every
     rank computes the same table without seeing the graph."""
@@ -453,10 +461,12 @@ def rmat_piece_is_cellwise(scale, raw_of_piece):
     return np.asarray(raw_of_piece, np.float64) * 2.0 >= float(rpp) * float(1 << s)
 
 
-def rmat_cuts(scale, raw_edges, parts, a=0.57, b=0.19, c=0.19):
-    """`parts` contiguous row ranges [(row0, row1), ...] of equal expected cost (distinct entries + rows), cut at piece boundaries."""
+def rmat_cuts(scale, raw_edges, parts, a=0.57, b=0.19, c=0.19, n_cols=256):
+    """`parts` contiguous row ranges [(row0, row1), ...] of equal expected cost (sparse nonzeros + tile blocks + rows, priced for a product with n_cols columns of B:
+    rmat_cost_constants), cut at piece boundaries."""
     from .dist import partition_by_cost
-    _, cost = rmat_piece_table(scale, raw_edges, a, b, c)
+    tb, rc = rmat_cost_constants(n_cols)
+    _, cost = rmat_piece_table(scale, raw_edges, a, b, c, tile_block_cost=tb, row_cost=rc)
     rows_per_piece = 1 << (int(scale) - rmat_piece_bits(scale))
     return [(p0 * rows_per_piece, p1 * rows_per_piece) for p0, p1 in partition_by_cost(cost, parts)]
 

@@ -64,7 +64,8 @@ def test_cuts_by_expected_cost_balance_the_real_costs():
     blk = (rows_of // 64) * ((1 << SCALE) // 64) + full.colidx // 64
     ids, cnt = np.unique(blk, return_counts=True)
     br = ids // ((1 << SCALE) // 64)
-    cost_br = np.bincount(br, weights=np.where(cnt >= 120, 25.0, cnt.astype(np.float64)), minlength=full.rows // 64) + 64.0 * 34.0
+    tb_cost, row_cost = sa.gen.rmat_cost_constants(256)                  # (what rmat_cuts prices a tile block / a row of C at by default)
+    cost_br = np.bincount(br, weights=np.where(cnt >= 120, tb_cost, cnt.astype(np.float64)), minlength=full.rows // 64) + 64.0 * row_cost
     model = sa.gen.rmat_block_model(SCALE, E)
     # the model's totals against the graph's: nonzeros outside well-filled blocks, number of well-filled blocks
     from math import comb
