@@ -599,9 +599,9 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             CREATE_TRY(hipMemcpy(v->d_hub_tiles, plan.hub_tiles.data(), plan.hub_tiles.size() * sizeof(HubTile), hipMemcpyHostToDevice));
             CREATE_TRY(hipMalloc((void**)&v->d_hub_wrange, plan.hub_wrange.size() * sizeof(int32_t)));
             CREATE_TRY(hipMemcpy(v->d_hub_wrange, plan.hub_wrange.data(), plan.hub_wrange.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            const size_t a_elems = plan.hub_a16.size();
+            const size_t a_elems = plan.hub_a16_elems;
             CREATE_TRY(hipMalloc((void**)&v->d_hub_A, (a_elems + 64) * sizeof(uint16_t)));
-            if (a_elems > 0) CREATE_TRY(hipMemcpy(v->d_hub_A, plan.hub_a16.data(), a_elems * sizeof(uint16_t), hipMemcpyHostToDevice));
+            if (a_elems > 0) CREATE_TRY(hipMemcpy(v->d_hub_A, plan.hub_a16.get(), a_elems * sizeof(uint16_t), hipMemcpyHostToDevice));
             v->a_bytes += (int64_t)(a_elems * sizeof(uint16_t));
             v->exec_area += plan.hub_union_area;
             v->h_hub_steps.swap(plan.hub_steps);

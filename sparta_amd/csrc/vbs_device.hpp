@@ -17,6 +17,7 @@
 #include <string>
 #include <type_traits>
 #include <utility>
+#include <memory>
 #include <vector>
 
 #include "host_core.hpp"
@@ -344,7 +345,8 @@ struct StreamPlanHost {
     std::vector<HubStep> hub_steps;           // in execution order, padded by 32 harmless copies
     std::vector<HubTile> hub_tiles;
     std::vector<int32_t> hub_wrange;          // [2 * hub_workers]
-    std::vector<uint16_t> hub_a16;            // slices of 64 rows x 64 k in the kernel's LDS image, present sub-tiles of a step back to back, steps in execution order
+    std::unique_ptr<uint16_t[]> hub_a16;      // slices of 64 rows x 64 k in the kernel's LDS image, present sub-tiles of a step back to back, steps in execution order
+    size_t hub_a16_elems = 0;                 // (uninitialised storage: 10^10 elements on a dense hub part -- the packing loop writes every element, zeros included)
     int hub_g = 0;                            // sub-tiles per group tile (2 or 4); 0: no hub plan
     int hub_workers = 0;
     int64_t n_hub_steps = 0, hub_area = 0, hub_union_area = 0;    // steps; stored elements of the hub tiles; elements the kernel multiplies (absent sub-tiles included)

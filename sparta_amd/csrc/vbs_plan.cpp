@@ -863,9 +863,11 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
             for (int k = 0; k < 32; k++) { HubStep d = hs[(size_t)S - 1]; d.flags &= ~(STEP_LAST | STEP_SPLIT); d.slot = -1; hs[(size_t)S + k] = d; }
             // the slices of A, in execution order: 64 rows x 64 k, element (row, k) at row * 64 + (((k / 8) ^ ((row / 2) & 7)) * 8 + k % 8 -- the LDS image of
             // vbs_spmm_h16_hub_kernel (a ds_read_b128 of 16 rows covers all 64 banks); rows past the sub-tile's height zero
-            P.hub_a16.assign((size_t)a_at[(size_t)S], 0);
+            P.hub_a16_elems = (size_t)a_at[(size_t)S];
+            P.hub_a16.reset(new (std::nothrow) uint16_t[std::max<size_t>(P.hub_a16_elems, 1)]);      // NOT zero-filled (22 GB on the hub part of configs[3] at 5 %: 2 s on one thread)
+            if (!P.hub_a16) return fail(SPARTA_ERR_ALLOC, "sparta_vbs_create: out of host memory for the hub slices");
             const bool bf = dtype == SPARTA_BF16;
-            uint16_t* all = P.hub_a16.data();
+            uint16_t* all = P.hub_a16.get();
             sparta::parallel_for_dynamic(S, 64, [&](int64_t lo, int64_t hi, int) {
                 for (int64_t q = lo; q < hi; q++) {
                     const ORef& o = order[(size_t)q];
@@ -875,6 +877,7 @@ int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P) {
                         if (!((x.mask >> k) & 1)) continue;
                         const int64_t ib = hub_groups[(size_t)o.g].ib[k], hh = row_part[ib + 1] - row_part[ib];
                         const float* blk = mab + mab_lo + mo_of[(size_t)(ib - br0)] + ((int64_t)x.bidx[k] * w + o.ks) * hh;     // column-major hh x w block, k slice o.ks
+                        if (hh < 64) std::memset(dst + hh * 64, 0, (size_t)(64 - hh) * 64 * sizeof(uint16_t));              // rows past the sub-tile's height
                         for (int64_t kk = 0; kk < 64; kk++) {
                             const float* colp = blk + kk * hh;
                             for (int64_t rr = 0; rr < hh; rr++) dst[rr * 64 + ((((kk >> 3) ^ ((rr >> 1) & 7)) << 3) | (kk & 7))] = to_h16(colp[rr], bf);
