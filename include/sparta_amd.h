@@ -388,6 +388,22 @@ int sparta_vbs_info(const sparta_vbs_t* A, int64_t* info_out);
  * [2] rows handled one wave each [3] hub rows (cut into segments) */
 int sparta_vbs_sparse_info(const sparta_vbs_t* A, int64_t* info_out);
 
+/* the resident-column image of a small fp32 handle (no reference counterpart: the reference multiplies every matrix block by block, vbr.cpp:323-372; this is the
+ * product path of its real matrices -- 8-22 k rows, no dense blocks at any block size it sweeps -- at its operand widths B_COLs = 1024 / 8192,
+ * scripts/run_multiplication_experiments_fixed_cluster.sh:6-7).  Built when every row of the handle is on the sparse-row path and a column of B and of C
+ * fits LDS (rows, columns <= 40 960); taken by sparta_vbs_spmm when B and C are column-major (the reference's layouts) device or host pointers: NC columns of
+ * B are copied into LDS, A (length-sorted rows, 64 to a slice, long rows cut into chunks) streams past them from L2, one launch, B and C cross HBM once; a row's
+ * nonzeros are added in ascending column order as in CSR::multiply (csr.cpp:49-65).  SPARTA_COLRES=0 at create time: not built (the row gather takes the product).
+ * info_out (int64[8]): [0] slices of 64 slots (0: no image) [1] stored entries, padding included [2] rows cut into chunks [3] cells per column of the staging
+ * image (rows + extra cells of the chunks) [4] longest slot [5] columns per workgroup of the last product on this path (0: the last product took another path)
+ * [6] nonzeros [7] 0 */
+int sparta_vbs_colres_info(const sparta_vbs_t* A, int64_t* info_out);
+/* HOST-side walk of that image for one column x of B (y = A x; rows of C through crow, NULL = identity; info_out as above, [0] = 0 and y untouched when the matrix
+ * gets no image): slots in slice order, a slot's entries in order, the chunks of a long row added in chunk order -- the arithmetic of the kernel, for the CPU suite
+ * to check the builder with.  Not a product path (and not a fallback: sparta_vbs_spmm never calls it). */
+int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals, const int64_t* crow, const float* x,
+                             float* y, int64_t* info_out);
+
 /* the hub part of the plan of a 16-bit handle of 64-wide blocks (no reference counterpart: the reference multiplies every block-row the same way,
  * vbr.cpp:323-372 / cuda_utilities.cpp:828-875).  The long tiles of 33..64 rows -- the dense hub of a power-law matrix under the fixed 64 x 64 grid -- are grouped
  * by the Jaccard similarity of their block-column sets into group tiles of 2 or 4 and multiplied by a GEMM-shaped kernel that stages A and B once per workgroup.

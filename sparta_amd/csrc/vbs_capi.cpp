@@ -92,6 +92,10 @@ void destroy_impl(sparta_vbs* v) {
     if (v->d_sp_stream_begin) (void)hipFree(v->d_sp_stream_begin);
     if (v->d_sp_long) (void)hipFree(v->d_sp_long);
     if (v->d_sp_part) (void)hipFree(v->d_sp_part);
+    if (v->d_cr_ent) (void)hipFree(v->d_cr_ent);
+    if (v->d_cr_soff) (void)hipFree(v->d_cr_soff);
+    if (v->d_cr_dest) (void)hipFree(v->d_cr_dest);
+    if (v->d_cr_longs) (void)hipFree(v->d_cr_longs);
     if (v->d_Brm) (void)hipFree(v->d_Brm);
     if (v->d_B) (void)hipFree(v->d_B);
     if (v->d_C) (void)hipFree(v->d_C);
@@ -101,6 +105,88 @@ void destroy_impl(sparta_vbs* v) {
         for (int e = 0; e < 2; e++)
             if (v->cev[c][e]) (void)hipEventDestroy(v->cev[c][e]);
     delete v;
+}
+
+
+
+
+// ---- resident-column product (k_colres.hip): A as length-sorted slots, 64 to a slice -----------------------------------------------------------
+// Only for handles whose rows of C are ALL sparse rows (nothing for a tile launch to store first) and small enough that a column of B (and of C, with the
+// extra cells of the long rows) fits LDS.  SPARTA_COLRES=0: never built.  SPARTA_COLRES_LMAX: longest slot (default max(32, nnz / 2048): at 1024 lanes per
+// workgroup a slot of twice the average load per lane is not the critical path).
+constexpr int64_t kColresCells = 160 * 1024 / 4;                  // floats of LDS a workgroup may hold
+struct ColresHost {
+    std::vector<int32_t> ent;                                     // (column, value bits) pairs
+    std::vector<int32_t> soff, dest;
+    std::vector<ColresLong> longs;
+    int32_t n_slices = 0, plane = 0, lmax = 0;
+};
+bool build_colres(int64_t rows, int64_t cols, const std::vector<int64_t>& rowptr, const std::vector<int32_t>& col, const std::vector<float>& val,
+                  const std::vector<int32_t>& crow, ColresHost& H) {
+    if (const char* e = std::getenv("SPARTA_COLRES")) if (atoi(e) == 0) return false;
+    const int64_t n = (int64_t)crow.size(), nnz = rowptr.empty() ? 0 : rowptr.back();
+    if (n != rows || nnz == 0 || rows > kColresCells || cols > kColresCells - 1) return false;
+    std::vector<uint8_t> seen((size_t)rows, 0);
+    for (int64_t t = 0; t < n; t++) {
+        const int32_t r = crow[(size_t)t];
+        if (r < 0 || r >= rows || seen[(size_t)r]) return false;                     // bit 31 (the row also has tiles), or not a permutation of the rows of C
+        seen[(size_t)r] = 1;
+    }
+    int64_t lmax = std::max<int64_t>(32, nnz / 2048);
+    if (const char* e = std::getenv("SPARTA_COLRES_LMAX")) lmax = std::max(1, atoi(e));
+    struct Slot { int64_t p0; int32_t len, dest; };
+    std::vector<Slot> slots;
+    slots.reserve((size_t)rows + (size_t)(nnz / lmax) + 1);
+    int64_t n_extra = 0;
+    for (int64_t t = 0; t < n; t++) {
+        const int64_t p0 = rowptr[(size_t)t], len = rowptr[(size_t)t + 1] - p0;
+        const int64_t chunks = std::max<int64_t>(1, (len + lmax - 1) / lmax);
+        if (chunks > 1) H.longs.push_back(ColresLong{crow[(size_t)t], (int32_t)n_extra, (int32_t)(chunks - 1), 0});      // `first` made absolute below
+        for (int64_t c = 0; c < chunks; c++) {
+            const int64_t o = c * lmax;
+            slots.push_back(Slot{p0 + o, (int32_t)std::min<int64_t>(lmax, len - o), c == 0 ? crow[(size_t)t] : (int32_t)(-2 - (n_extra + c - 1))});
+        }
+        n_extra += chunks - 1;
+    }
+    const int64_t rows_pad = (rows + 3) / 4 * 4, plane = (rows_pad + n_extra + 3) / 4 * 4;
+    if (plane > kColresCells || (int64_t)slots.size() > (int64_t)colres_max_slices(1) * 64) return false;
+    for (ColresLong& lr : H.longs) lr.first += (int32_t)rows_pad;
+    std::stable_sort(slots.begin(), slots.end(), [](const Slot& a, const Slot& b) { return a.len > b.len; });
+    const int64_t n_slices = ((int64_t)slots.size() + 63) / 64;
+    H.soff.assign((size_t)n_slices + 1, 0);
+    H.dest.assign((size_t)n_slices * 64, -1);
+    int64_t total = 0;
+    for (int64_t s = 0; s < n_slices; s++) {
+        const int64_t wd = std::max<int32_t>(1, slots[(size_t)s * 64].len);            // sorted: the first slot of a slice is its longest; never an empty slice (the kernel clamps k to wd - 1)
+        H.soff[(size_t)s] = (int32_t)total;
+        total += wd * 64;
+        if (total > (int64_t)INT32_MAX / 2) return false;
+    }
+    H.soff[(size_t)n_slices] = (int32_t)total;
+    H.ent.assign((size_t)total * 2, 0);
+    for (int64_t q = 0; q < (int64_t)slots.size(); q++) {
+        const Slot& sl = slots[(size_t)q];
+        const int64_t s = q / 64, l = q % 64;
+        H.dest[(size_t)q] = sl.dest >= 0 ? sl.dest : (int32_t)(rows_pad + (-2 - sl.dest));
+        const int32_t wd = (H.soff[(size_t)s + 1] - H.soff[(size_t)s]) / 64;
+        for (int32_t k = 0; k < wd; k++) {                                             // past the slot's end: a column of its own row with the value 0.0f (no per-lane condition in the kernel)
+            const size_t at = ((size_t)H.soff[(size_t)s] + (size_t)k * 64 + (size_t)l) * 2;
+            if (k < sl.len) { H.ent[at] = col[(size_t)(sl.p0 + k)]; std::memcpy(&H.ent[at + 1], &val[(size_t)(sl.p0 + k)], 4); }
+            else H.ent[at] = sl.len > 0 ? col[(size_t)(sl.p0 + sl.len - 1)] : 0;
+        }
+    }
+    H.n_slices = (int32_t)n_slices; H.plane = (int32_t)plane; H.lmax = (int32_t)lmax;
+    return true;
+}
+// columns of B per workgroup: as many as LDS holds next to each other (columns of B first, the staging image of C after them, in the same cells)
+int colres_columns(const sparta_vbs_t* A, int n_cols) {
+    if (A->cr_slices == 0) return 0;
+    const int64_t span = (A->cols + 1) / 2 * 2, cells = std::max<int64_t>(span, A->cr_plane);
+    int nc = (int)std::min<int64_t>(4, kColresCells / cells);
+    if (const char* e = std::getenv("SPARTA_COLRES_NC")) nc = std::min(nc, std::max(1, atoi(e)));
+    nc = std::min(nc, n_cols);
+    while (nc > 1 && A->cr_slices > colres_max_slices(nc)) nc--;
+    return nc;
 }
 
 }  // namespace
@@ -644,6 +730,25 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             CREATE_TRY(hipMemcpy(v->d_sp_long, sp_long.data(), sp_long.size() * sizeof(SpLongRec), hipMemcpyHostToDevice));
         }
     }
+    // resident-column image (k_colres.hip): every row of C is a sparse row, nothing else launches, a column of B fits LDS
+    if (!h16 && !sp_crow.empty() && v->n_steps[0] + v->n_steps[1] == 0 && v->n_hub_steps == 0) {
+        ColresHost H;
+        if (build_colres(v->rows, cols, sp_rowptr, sp_col, sp_val, sp_crow, H)) {
+            CREATE_TRY(hipMalloc(&v->d_cr_ent, H.ent.size() * sizeof(int32_t)));
+            CREATE_TRY(hipMemcpy(v->d_cr_ent, H.ent.data(), H.ent.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc((void**)&v->d_cr_soff, H.soff.size() * sizeof(int32_t)));
+            CREATE_TRY(hipMemcpy(v->d_cr_soff, H.soff.data(), H.soff.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc((void**)&v->d_cr_dest, H.dest.size() * sizeof(int32_t)));
+            CREATE_TRY(hipMemcpy(v->d_cr_dest, H.dest.data(), H.dest.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            if (!H.longs.empty()) {
+                CREATE_TRY(hipMalloc(&v->d_cr_longs, H.longs.size() * sizeof(ColresLong)));
+                CREATE_TRY(hipMemcpy(v->d_cr_longs, H.longs.data(), H.longs.size() * sizeof(ColresLong), hipMemcpyHostToDevice));
+            }
+            v->cr_slices = H.n_slices; v->cr_long = (int32_t)H.longs.size(); v->cr_plane = H.plane; v->cr_lmax = H.lmax;
+            v->cr_entries = (int64_t)H.ent.size() / 2;
+            v->a_bytes += (int64_t)(H.ent.size() * sizeof(int32_t));
+        }
+    }
     CREATE_TRY(hipEventCreate(&v->ev0));
     CREATE_TRY(hipEventCreate(&v->ev1));
     CREATE_TRY(hipEventCreate(&v->tev0));
@@ -824,6 +929,50 @@ int sparta_vbs_sparse_info(const sparta_vbs_t* A, int64_t* info) {
     return SPARTA_OK;
 }
 
+// the resident-column image of a CSR matrix, built and walked on the HOST exactly as k_colres.hip walks it (slots in slice order, the sums of a slot in entry order,
+// extra cells added to their row in chunk order) for ONE column x of B: what the CPU suite checks the builder with (no GPU involved; not a product path)
+int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals, const int64_t* crow, const float* x, float* y,
+                             int64_t* info) {
+    using sparta::fail;
+    SPARTA_GUARD_BEGIN
+    if (rows <= 0 || cols <= 0 || !rowptr || !colidx || !vals || !x || !y || !info) return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: bad argument");
+    std::vector<int64_t> rp(rowptr, rowptr + rows + 1);
+    std::vector<int32_t> ci(colidx, colidx + rowptr[rows]), cr((size_t)rows);
+    std::vector<float> va(vals, vals + rowptr[rows]);
+    for (int64_t i = 0; i < rows; i++) cr[(size_t)i] = crow ? (int32_t)crow[i] : (int32_t)i;
+    ColresHost H;
+    for (int k = 0; k < 8; k++) info[k] = 0;
+    if (!build_colres(rows, cols, rp, ci, va, cr, H)) return SPARTA_OK;                 // info[0] = 0: this matrix gets no image
+    std::vector<float> cell((size_t)H.plane, 0.0f);
+    for (int32_t s = 0; s < H.n_slices; s++) {
+        const int32_t off = H.soff[(size_t)s], wd = (H.soff[(size_t)s + 1] - off) / 64;
+        for (int l = 0; l < 64; l++) {
+            float acc = 0.0f;
+            for (int32_t k = 0; k < wd; k++) {
+                const size_t at = ((size_t)off + (size_t)k * 64 + (size_t)l) * 2;
+                float a; std::memcpy(&a, &H.ent[at + 1], 4);
+                if (H.ent[at] < 0 || H.ent[at] >= cols) return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: column out of range in the image");
+                acc = std::fma(a, x[H.ent[at]], acc);
+            }
+            const int32_t d = H.dest[(size_t)s * 64 + (size_t)l];
+            if (d >= H.plane) return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: cell out of range in the image");
+            if (d >= 0) cell[(size_t)d] = acc;
+        }
+    }
+    for (const ColresLong& lr : H.longs) { float sum = cell[(size_t)lr.row]; for (int32_t i = 0; i < lr.n; i++) sum += cell[(size_t)lr.first + (size_t)i]; cell[(size_t)lr.row] = sum; }
+    for (int64_t i = 0; i < rows; i++) y[i] = cell[(size_t)i];
+    info[0] = H.n_slices; info[1] = (int64_t)H.ent.size() / 2; info[2] = (int64_t)H.longs.size(); info[3] = H.plane; info[4] = H.lmax; info[6] = rp.back();
+    return SPARTA_OK;
+    SPARTA_GUARD_END("sparta_colres_host_check")
+}
+
+int sparta_vbs_colres_info(const sparta_vbs_t* A, int64_t* info) {
+    if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_colres_info: NULL argument");
+    info[0] = A->cr_slices; info[1] = A->cr_entries; info[2] = A->cr_long; info[3] = A->cr_plane; info[4] = A->cr_lmax; info[5] = A->last_colres_nc;
+    info[6] = A->cr_slices > 0 ? A->sp_nnz : 0; info[7] = 0;
+    return SPARTA_OK;
+}
+
 #ifdef SPARTA_TIMELINE
 // developer build only: the raw timeline words (4 waves x 64 steps x 8)
 int sparta_debug_timeline(sparta_vbs_t* A, long long* out) {
@@ -931,6 +1080,26 @@ void drop_legacy_image(sparta_vbs_t* A) {
 int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_major, int64_t shard_rows, int64_t shard_stride, int bk,
                        int32_t n_cols, float* dC, int64_t ldc, bool c_row_major, bool accumulate, hipStream_t st) {
     const size_t esz = bk == 0 ? 4 : 2;
+    A->last_colres_nc = 0;
+    // Small A, the reference's own layouts (column-major B and C): the resident-column product -- NC columns of B in LDS, A streamed past them from L2, one launch
+    // (k_colres.hip).  No transpose of B, no partial rows, B and C cross HBM once.
+    if (bk == 0 && A->cr_slices > 0 && !b_row_major && !c_row_major && shard_rows == 0) {
+        const int nc = colres_columns(A, n_cols);
+        if (nc > 0) {
+            ColresParams cp;
+            cp.ent = (const int2*)A->d_cr_ent; cp.soff = A->d_cr_soff; cp.dest = A->d_cr_dest; cp.longs = (const ColresLong*)A->d_cr_longs;
+            cp.B = (const float*)dB; cp.ldb = ldb; cp.C = dC; cp.ldc = ldc;
+            cp.n_slices = A->cr_slices; cp.n_long = A->cr_long; cp.rows = (int32_t)A->rows; cp.cols = (int32_t)A->cols; cp.N = n_cols; cp.accumulate = accumulate ? 1 : 0;
+            cp.vec_out = ldc % 4 == 0 && ((uintptr_t)dC % 16) == 0 ? 1 : 0;
+            cp.plane = A->cr_plane;
+            const int64_t span = (A->cols + 1) / 2 * 2;
+            const size_t lds_bytes = (size_t)std::max<int64_t>(span, A->cr_plane) * (size_t)nc * sizeof(float);
+            if (int hrc = launch_colres(nc, cp, lds_bytes, st)) return sparta::fail(SPARTA_ERR_HIP, "sparta_vbs_spmm: the resident-column kernel could not be launched (hipError_t " + std::to_string(hrc) + ")");
+            HIP_TRY(hipGetLastError());
+            A->last_colres_nc = nc;
+            return SPARTA_OK;
+        }
+    }
     SparseParams q;
     q.rowptr = A->d_sp_rowptr; q.col = A->d_sp_col; q.val = A->d_sp_val; q.crow = A->d_sp_crow;
     q.list = nullptr; q.n_list = 0;
@@ -1469,7 +1638,9 @@ int sparta_vbs_prepare_b(sparta_vbs_t* A, const void* B, int64_t ldb, int64_t sh
     p->n_cols = n_cols; p->dtype = A->dtype; p->device = A->device;
     const size_t esz = A->dtype == SPARTA_F32 ? 4 : 2;
     // the sparse-row kernels of this handle would transpose this B per product (launch_sparse_rows: not when a handful of rows reads it in place)
-    const bool needs_copy = A->n_sp_rows > 0 && !(A->sp_nnz * 8 < A->cols);
+    // (nor when the resident-column kernel carries the products of a plain column-major B: it reads the columns where they are; a later product into a ROW-major C
+    // then transposes per call as sparta_vbs_spmm does)
+    const bool needs_copy = A->n_sp_rows > 0 && !(A->sp_nnz * 8 < A->cols) && !(A->cr_slices > 0 && shard_rows == 0);
     if (needs_copy) {
         hipStream_t st = (hipStream_t)stream;
         const int64_t n_wg = ((A->cols + 63) / 64) * (int64_t)((n_cols + 63) / 64);

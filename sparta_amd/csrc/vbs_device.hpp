@@ -163,6 +163,21 @@ struct SparseParams {
     int32_t scalar_gather;     // 1: (column, value) pairs through scalar loads, row base in SGPRs (k_sparse.hip: sparse_row_partial_s); 0: the round-3 gather (SPARTA_SP_SCALAR=0)
 };
 
+// resident-column product (k_colres.hip): A as slots (rows, the long ones cut into chunks) sorted by length, 64 to a slice, entry k of a slice's slots contiguous
+struct ColresLong { int32_t row, first, n, pad; };   // a row cut into chunks: its cell in the staging image, the first of its extra cells, how many
+struct ColresParams {
+    const int2* ent;           // (column, value bits); slice s, step k, lane l at soff[s] + 64 k + l; a slot shorter than its slice ends in (a column of its row, 0.0f)
+    const int32_t* soff;       // [n_slices + 1], in entries
+    const int32_t* dest;       // [64 n_slices] cell of the staging image the slot's sum goes to (row of C, or an extra cell >= rows); -1: padding slot
+    const ColresLong* longs;
+    const float* B;            // column-major, ld = ldb
+    int64_t ldb;
+    float* C;                  // column-major, ld = ldc
+    int64_t ldc;
+    int32_t n_slices, n_long, rows, cols, N, accumulate, vec_out;
+    int32_t plane;             // cells per column of the staging image (rows + extra cells, a multiple of 4)
+};
+
 struct SpSegRec { int64_t p0; int32_t cnt, pad; };
 struct SpLongRec { int32_t ord, seg_begin, n_seg, pad; };
 
@@ -271,6 +286,14 @@ struct sparta_vbs {
     int64_t sp_max_stream = 0;
     void* d_sp_part = nullptr;             // partial rows of the segments
     size_t d_sp_part_bytes = 0;
+    // resident-column product (k_colres.hip): fp32 handles whose rows are ALL sparse rows and whose columns of B fit LDS
+    void* d_cr_ent = nullptr;
+    int32_t* d_cr_soff = nullptr;
+    int32_t* d_cr_dest = nullptr;
+    void* d_cr_longs = nullptr;
+    int32_t cr_slices = 0, cr_long = 0, cr_plane = 0, cr_lmax = 0;
+    int64_t cr_entries = 0;                // stored entries, padding included
+    int last_colres_nc = 0;                // columns per workgroup of the last product on this path (0: the product took another path)
     void* d_Brm = nullptr;                 // row-major copy of a column-major / gathered B
     size_t d_Brm_bytes = 0;
     const void* prepared_brm = nullptr;    // set for the duration of a sparta_vbs_spmm_prepared call: the caller's row-major copy, made once
@@ -316,6 +339,9 @@ void launch_sparse_kernels(int vec, int bk, const SparseParams& q, unsigned gy, 
                            int64_t n_segs, const SpLongRec* longs, int64_t n_long, float* part, const int32_t* stream_begin = nullptr, int64_t max_stream = 0);
 void launch_b_to_row_major(bool is16, unsigned grid, hipStream_t st, const void* B, int64_t ldb, int64_t shard_rows, int64_t shard_stride, int64_t rows, int N,
                            void* out);
+// k_colres.hip
+int launch_colres(int nc, const ColresParams& p, size_t lds_bytes, hipStream_t st);     // nc = 1..4 columns per workgroup; 0 or a hipError_t
+int colres_max_slices(int nc);                                                          // slices the nc-column kernel holds sums for
 void launch_pack_blocks(dim3 grid, hipStream_t st, const void* src, const int32_t* ids, void* dst, int64_t block_vec);
 
 // vbs_plan.cpp

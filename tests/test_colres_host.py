@@ -1,0 +1,115 @@
+"""The resident-column image (k_colres.hip; sparta_amd/csrc/vbs_capi.cpp: build_colres) on the HOST: sparta_colres_host_check builds the image of a CSR matrix and
+walks it exactly as the kernel does for one column of B -- slots in slice order, a slot's entries in order, the chunks of a long row added in chunk order.
+Checked against float64 and, where no row is cut, bit-for-bit against the oracle's restatement of the reference's CSR::multiply
+(/root/reference/src/general/csr.cpp:49-65: the same ascending-column order of additions).  No GPU involved."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from sparta_amd._lib import lib, check
+
+_i64p, _i32p, _f32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_float)
+
+
+def _walk(A, x, crow=None):
+    rows, cols = A.shape
+    rp, ci, va = A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.float32)
+    y, info = np.full(rows, 7.0, np.float32), np.zeros(8, np.int64)
+    cr = None if crow is None else np.ascontiguousarray(crow, np.int64)
+    check(lib.sparta_colres_host_check(rows, cols, rp.ctypes.data_as(_i64p), ci.ctypes.data_as(_i32p), va.ctypes.data_as(_f32p),
+                                       None if cr is None else cr.ctypes.data_as(_i64p), x.ctypes.data_as(_f32p), y.ctypes.data_as(_f32p), info.ctypes.data_as(_i64p)))
+    keys = ["slices", "entries", "long_rows", "plane", "lmax", "nc", "nnz"]
+    return y, {k: int(info[i]) for i, k in enumerate(keys)}
+
+
+def _matrix(rows, cols, density, hubs, seed, empty_every=0):
+    rng = np.random.default_rng(seed)
+    A = sp.random(rows, cols, density, format="lil", random_state=seed, dtype=np.float32)
+    for h in range(hubs):
+        k = int(rng.integers(cols // 3, cols))
+        A[(h * 37) % rows, rng.choice(cols, k, replace=False)] = rng.uniform(-1, 1, k).astype(np.float32)
+    if empty_every:
+        for i in range(0, rows, empty_every):
+            A[i, :] = 0
+    A = A.tocsr()
+    A.eliminate_zeros()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("rows,cols,density,hubs,empty", [(1000, 900, 0.01, 0, 0), (5000, 5000, 0.002, 3, 7), (300, 40000, 0.001, 2, 0), (64, 64, 0.5, 0, 0),
+                                                           (63, 5, 0.6, 0, 2), (12000, 12000, 0.0006, 1, 0), (1, 1, 1.0, 0, 0)])
+def test_walk_of_the_image_equals_the_product(rows, cols, density, hubs, empty):
+    A = _matrix(rows, cols, density, hubs, rows + cols, empty)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(cols).astype(np.float32)
+    crow = rng.permutation(rows)
+    y, info = _walk(A, x, crow)
+    if A.nnz == 0:
+        assert info["slices"] == 0
+        return
+    assert info["slices"] > 0 and info["nnz"] == A.nnz
+    ref = A.astype(np.float64) @ x.astype(np.float64)
+    bound = np.abs(A).astype(np.float64) @ np.abs(x).astype(np.float64)
+    assert np.all(np.abs(y[crow] - ref) <= 1e-5 * bound + 1e-30)
+    # layout facts the kernel relies on
+    assert info["plane"] % 4 == 0 and info["plane"] >= rows
+    assert info["entries"] % 64 == 0 and info["entries"] >= A.nnz
+    longest = int(np.diff(A.indptr).max())
+    assert (info["long_rows"] > 0) == (longest > info["lmax"])
+    if A.nnz > 5000:
+        assert info["entries"] <= 1.6 * A.nnz, "padding of the sorted slices out of proportion"
+
+
+def test_rows_that_are_not_cut_are_added_in_the_order_of_csr_multiply():
+    """no long row: a slot IS a row, its entries ascending in column -- the additions of the reference's CSR::multiply (csr.cpp:49-65), fused: bit-identical
+    to a float32 FMA chain in that order"""
+    A = _matrix(3000, 2500, 0.004, 0, 11)
+    assert int(np.diff(A.indptr).max()) <= 32
+    x = np.random.default_rng(4).standard_normal(2500).astype(np.float32)
+    y, info = _walk(A, x)
+    assert info["long_rows"] == 0
+    want = np.zeros(3000, np.float32)
+    for i in range(3000):
+        acc = np.float64(0.0)
+        for k in range(A.indptr[i], A.indptr[i + 1]):                      # fma(a, b, acc) in float32 = round(a * b + acc) with the product exact in float64
+            acc = np.float64(np.float32(np.float64(A.data[k]) * np.float64(x[A.indices[k]]) + acc))
+        want[i] = acc
+    assert np.array_equal(y, want)
+
+
+def test_a_long_row_is_cut_and_its_chunks_added_in_order(monkeypatch):
+    monkeypatch.setenv("SPARTA_COLRES_LMAX", "8")
+    A = _matrix(200, 300, 0.05, 2, 5)
+    x = np.random.default_rng(6).standard_normal(300).astype(np.float32)
+    y, info = _walk(A, x)
+    assert info["lmax"] == 8 and info["long_rows"] > 0
+    want = np.zeros(200, np.float32)
+    for i in range(200):
+        parts = []
+        for o in range(A.indptr[i], A.indptr[i + 1], 8):
+            acc = np.float64(0.0)
+            for k in range(o, min(o + 8, A.indptr[i + 1])):
+                acc = np.float64(np.float32(np.float64(A.data[k]) * np.float64(x[A.indices[k]]) + acc))
+            parts.append(np.float32(acc))
+        s = np.float32(parts[0]) if parts else np.float32(0)
+        for q in parts[1:]:
+            s = np.float32(s + q)
+        want[i] = s
+    assert np.array_equal(y, want)
+
+
+def test_no_image_for_matrices_the_kernel_cannot_hold(monkeypatch):
+    x = np.ones(100, np.float32)
+    y, info = _walk(_matrix(41000, 100, 0.01, 0, 1), x)                   # a column of C does not fit LDS
+    assert info["slices"] == 0 and np.all(y == 7.0)
+    y, info = _walk(_matrix(100, 41000, 0.01, 0, 1), np.ones(41000, np.float32))
+    assert info["slices"] == 0
+    monkeypatch.setenv("SPARTA_COLRES", "0")
+    y, info = _walk(_matrix(100, 100, 0.1, 0, 1), x)
+    assert info["slices"] == 0
+    monkeypatch.delenv("SPARTA_COLRES")
+    y, info = _walk(_matrix(100, 100, 0.1, 0, 1), x, np.zeros(100, np.int64))      # crow not a permutation of the rows: no image (rows of C would stay unwritten)
+    assert info["slices"] == 0 and np.all(y == 7.0)

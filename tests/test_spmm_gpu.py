@@ -25,6 +25,9 @@ def _sparse_row_mode(request, monkeypatch):
     # ... and sends a SMALL matrix to the sparse-row kernels altogether when its tiles are not worth their launches (vbs_build.cpp, SPARTA_LAUNCH_NNZ): the test
     # matrices are all small, and these tests are about the tiles (tests/test_real_matrices.py and test_small_matrices_* run with the library's own rule)
     monkeypatch.setenv("SPARTA_LAUNCH_NNZ", "0")
+    # ... and multiplies a small all-sparse fp32 matrix by the resident-column kernel (k_colres.hip): these tests are about the tiles and the row gather
+    # (tests/test_colres_gpu.py, test_real_matrices.py run that kernel)
+    monkeypatch.setenv("SPARTA_COLRES", "0")
     return request.param
 TOL = 1e-5
 
