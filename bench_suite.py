@@ -130,6 +130,7 @@ def run_one(sa, torch, name, kind, make, eng_kw, w, N=128, device=0, budget_ms=4
     d.set_class_timing(False)
     check = _spot_check(sa, torch, m, g, C, B, N)
     info, sp = d.info(), d.sparse_info()
+    cr = d.colres_info()                                         # nc > 0: the last product was the resident-column kernel's (small all-sparse matrix, k_colres.hip), ONE launch
     # the reference's experiment multiplies the SAME B again and again: behind sparta_vbs_prepare_b the sparse rows' row-major copy of B is made once, and a small
     # product is one launch (rows + segments, the last-arriving segment of a long row reduces it).  Reported beside `ms` (a fresh B per product), never instead of it.
     ms_prepared = None
@@ -153,7 +154,7 @@ def run_one(sa, torch, name, kind, make, eng_kw, w, N=128, device=0, budget_ms=4
     bytes_b = float(info["cols"]) * N * 4.0
     t_lb = max(bytes_dense / (PEAK_HBM_GBS * 1e9), flops_dense / (PEAK_MFMA_F32_TFLOPS * 1e12)) + (bytes_sparse + bytes_b) / (PEAK_HBM_GBS * 1e9)
     gather = None
-    if sp["nnz"] > 0 and ct.get("sparse", 0.0) > 0:
+    if sp["nnz"] > 0 and ct.get("sparse", 0.0) > 0 and cr["nc"] == 0:
         gather = (float(sp["nnz"]) * (N * 4.0 + 8.0) + float(sp["rows"]) * N * 4.0) / (ct["sparse"] * 1e-3) / 1e9
     rec = {"name": name, "kind": kind, "rows": int(m.rows), "cols": int(m.cols), "nnz": int(m.nztot()),
            "n_cols": int(N), "check_max_err": float(check),
@@ -162,7 +163,8 @@ def run_one(sa, torch, name, kind, make, eng_kw, w, N=128, device=0, budget_ms=4
                                              eng_kw.get("tau", 0.0), w),
            "ms": round(ms, 5), "ms_prepared_b": None if ms_prepared is None else round(ms_prepared, 5), "useful_gflops": round(2.0 * m.nztot() * N / ms / 1e6, 1), "frac_8d": round(t_lb / (ms * 1e-3), 4),
            "gather_gbs": None if gather is None else round(gather, 1),
-           "carried_by": ("sparse rows %.0f %%" % (100.0 * sp["nnz"] / max(m.nztot(), 1))) if sp["nnz"] * 2 > m.nztot() else
+           "carried_by": ("resident columns (%d per workgroup%s), 1 launch" % (cr["nc"], ", unit image" if cr["unit"] else "")) if cr["nc"] > 0 else
+                         ("sparse rows %.0f %%" % (100.0 * sp["nnz"] / max(m.nztot(), 1))) if sp["nnz"] * 2 > m.nztot() else
                          ("MFMA tiles %.0f %%" % (100.0 * (1 - sp["nnz"] / max(m.nztot(), 1)))),
            "mfma_tile_area": int(info["nztot"]), "sparse_nnz": int(sp["nnz"]), "kernels_ms": {k: round(float(v), 5) for k, v in ct.items()},
            "host_seconds": {"reorder": round(t_r, 3), "vbs_build": round(t_b, 3)}, "reps": reps}

@@ -396,7 +396,7 @@ int sparta_vbs_sparse_info(const sparta_vbs_t* A, int64_t* info_out);
  * nonzeros are added in ascending column order as in CSR::multiply (csr.cpp:49-65).  SPARTA_COLRES=0 at create time: not built (the row gather takes the product).
  * info_out (int64[8]): [0] slices of 64 slots (0: no image) [1] stored entries, padding included [2] rows cut into chunks [3] cells per column of the staging
  * image (rows + extra cells of the chunks) [4] longest slot [5] columns per workgroup of the last product on this path (0: the last product took another path)
- * [6] nonzeros [7] 0 */
+ * [6] nonzeros [7] 1: every stored value is 1.0f and the image holds columns only (the reference's pattern-only runs, -P 1) */
 int sparta_vbs_colres_info(const sparta_vbs_t* A, int64_t* info_out);
 /* HOST-side walk of that image for one column x of B (y = A x; rows of C through crow, NULL = identity; info_out as above, [0] = 0 and y untouched when the matrix
  * gets no image): slots in slice order, a slot's entries in order, the chunks of a long row added in chunk order -- the arithmetic of the kernel, for the CPU suite

@@ -6,15 +6,18 @@
 // The row gather of k_sparse.hip moves one N-wide row of B per NONZERO (d x |B| through the caches for d nonzeros per row, plus 2 x |B| for the transpose of
 // the reference's column-major B, plus partial rows and a reduction for the long rows: three launches).  Here the roles are swapped: a workgroup owns NC
 // COLUMNS of B / C, copies them whole into LDS (a column of the reference's layout is contiguous: no transpose), and streams A -- a few hundred KB, resident
-// in every L2 -- past them: lane = row, one 8-byte (column, value) entry and one LDS read of NC values per nonzero.  B is read from HBM once, C written once,
+// in every L2 -- past them: lane = row, one (column, value) entry and one LDS read of NC values per nonzero.  B is read from HBM once, C written once,
 // both coalesced; what is re-read is A, N / NC times, from L2.  One launch, no scratch.
 //
 // A's layout (built at create time, vbs_capi.cpp: build_colres): "slots" = rows, the long ones cut into chunks of at most Lmax nonzeros (a row of 10^4 nonzeros on one lane
-// would be the whole kernel's critical path), sorted by length and packed 64 to a slice, entry k of the slice's 64 slots contiguous (sliced ELLPACK: a wave's
-// load of step k is one 512-byte line).  A slot accumulates its nonzeros in ascending column order -- the order of the reference's CSR::multiply
-// (/root/reference/src/general/csr.cpp:49-65) and, zeros of the blocks aside, of VBR::multiply -- into registers; every slot then writes its sum to its
-// `dest` in a staging image that REPLACES the columns of B in LDS (first chunk of a row: the row of C; later chunks: extra cells behind the rows), the owner of a long row adds
-// its extra cells in chunk order (fixed order: bit-reproducible), and the staging image goes to C in whole lines.
+// would be the whole kernel's critical path), sorted by length and packed 64 to a slice of a multiple of 4 steps.  The slices of wave w (w, w + 16, ... of the sorted list: equally long
+// streams; 16 waves per workgroup) lie back to back, in BATCHES of 4 steps: per batch and lane four 16-bit columns (8 bytes; 512 per wave) and, unless every value is 1.0f -- the reference's
+// experiments read their matrices pattern-only, `-P 1`, run_multiplication_experiments_fixed_cluster.sh:27 -- four fp32 values (16 bytes).  The stream of A is bound by what the L2s
+// deliver to 256 CUs at once (~15 TB/s: measured 12 us per workgroup with 8-byte (column, value) entries whatever the arithmetic around them), hence the narrow entries.
+// A slot accumulates its nonzeros in ascending column order -- the order of the reference's CSR::multiply (/root/reference/src/general/csr.cpp:49-65) and, zeros of the blocks
+// aside, of VBR::multiply -- into registers; every slot then writes its sum to its `dest` in a staging image that REPLACES the columns of B in LDS (first chunk of a row: the
+// row of C; later chunks: extra cells behind the rows), the owner of a long row adds its extra cells in chunk order (fixed order: bit-reproducible), and the staging image goes
+// to C in whole lines.
 #include "vbs_kernel_common.hpp"
 
 using namespace sparta_dev;
@@ -23,6 +26,7 @@ namespace {
 
 typedef float cr_f2 __attribute__((ext_vector_type(2)));
 typedef float cr_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned cr_u2 __attribute__((ext_vector_type(2)));
 
 // NC values per column index c.  NC = 3 keeps a pair plane and a single plane (a 12-byte LDS read needs 16-byte alignment and takes 8 cycles: MI355X_MICROARCH.md, LDS)
 template <int NC> __device__ __forceinline__ void cr_put(float* lds, int span, int c, const float (&v)[NC]) {
@@ -37,89 +41,187 @@ template <int NC> __device__ __forceinline__ void cr_get(const float* lds, int s
     else if constexpr (NC == 3) { const cr_f2 t = *reinterpret_cast<const cr_f2*>(lds + 2 * c); v[0] = t.x; v[1] = t.y; v[2] = lds[2 * span + c]; }
     else { const cr_f4 t = *reinterpret_cast<const cr_f4*>(lds + 4 * c); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
 }
+// rows c .. c + 3 of the NC columns (x[jj] = four consecutive rows of column jj; c a multiple of 4) -> LDS in whole 16-byte writes
+template <int NC> __device__ __forceinline__ void cr_put4(float* lds, int span, int c, const cr_f4 (&x)[NC]) {
+    if constexpr (NC == 1) *reinterpret_cast<cr_f4*>(lds + c) = x[0];
+    else if constexpr (NC == 2 || NC == 3) {
+        *reinterpret_cast<cr_f4*>(lds + 2 * c) = cr_f4{x[0].x, x[1].x, x[0].y, x[1].y};
+        *reinterpret_cast<cr_f4*>(lds + 2 * c + 4) = cr_f4{x[0].z, x[1].z, x[0].w, x[1].w};
+        if constexpr (NC == 3) *reinterpret_cast<cr_f4*>(lds + 2 * span + c) = x[2];
+    } else {
+        *reinterpret_cast<cr_f4*>(lds + 4 * c) = cr_f4{x[0].x, x[1].x, x[2].x, x[3].x};
+        *reinterpret_cast<cr_f4*>(lds + 4 * c + 4) = cr_f4{x[0].y, x[1].y, x[2].y, x[3].y};
+        *reinterpret_cast<cr_f4*>(lds + 4 * c + 8) = cr_f4{x[0].z, x[1].z, x[2].z, x[3].z};
+        *reinterpret_cast<cr_f4*>(lds + 4 * c + 12) = cr_f4{x[0].w, x[1].w, x[2].w, x[3].w};
+    }
+}
 
-constexpr int kCrThreads = 1024, kCrWaves = kCrThreads / 64;
+// 1024 threads, one workgroup per CU.  (512 threads with two or three workgroups sharing a CU -- one's loads of B / stores of C under another's stream of A -- was built and
+// measured: the phases' times still ADD UP, start offsets between the co-resident workgroups or not, and the shorter workgroups hide less latency: bcsstk18 at N = 8192
+// 0.32-0.37 ms against 0.26, wiki-Vote 0.245 against 0.217; profiles/r4/lab_colres_stagger.txt.)
+constexpr int kCrWaves = kColresWaves, kCrThreads = 64 * kCrWaves;
 
-// SL: slices a wave may own (slice s belongs to wave s % 16; the sums of all of them stay in registers until the columns of B are no longer needed)
-template <int NC, int SL>
+// SL: slices a wave may own (slice s of the length-sorted list belongs to wave s % 16; the sums of all of them stay in registers until the columns of B are no longer needed)
+// UNIT: every stored value is 1.0f (no value array: the sums are sums of elements of B)
+template <int NC, int SL, bool UNIT>
 __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j0 = (int)blockIdx.x * NC;
     const int nc = p.N - j0 < NC ? p.N - j0 : NC;                 // columns of this workgroup that exist (the last workgroup of a ragged N)
-    const int span = (p.cols + 1) & ~1;
+    const int span = (p.cols + 4) & ~3;                           // cells per column of B: its rows + the zero cell the padding of A points at
+
+    // Every CU starts its first workgroup at the same time, and all of them then load B together, stream A together, store C together: HBM idles while the LDS works and the
+    // other way round.  The CUs of the first dispatch round are therefore started in p.share groups, a share of a workgroup's time apart (developer knob SPARTA_COLRES_STAGGER_US).
+    if (p.stagger_ticks > 0 && (int)blockIdx.x < p.n_cus) {
+        const int slot = ((int)blockIdx.x >> 3) % p.share;                             // (consecutive workgroups go to the 8 XCDs in turn: >> 3 = the CU within its XCD)
+        if (slot > 0) {
+            const long long t_end = wall_clock64() + (long long)slot * p.stagger_ticks;      // 100 MHz
+            while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8);
+        }
+    }
 
     // ---- 1. the NC columns of B -> LDS, interleaved per row of B -------------------------------------------------------------------------------
-    {
-        // (branch-free: a lane past the last row reads the last row and stores nothing; a column past the last one repeats the last one and is never written to C)
+    // (branch-free: a lane past the last row reads the last row(s) and stores nothing; a column past the last one repeats the last one and is never written to C)
+    if (!(p.probe & 1)) {
         const float* Bj = p.B + (int64_t)j0 * p.ldb;
-        constexpr int U = 4;
-        for (int c0 = tid; c0 < p.cols; c0 += U * kCrThreads) {
-            float v[U][NC];
+        if (p.vec_in) {                                           // 16-byte aligned columns: four rows per lane and load, whole 16-byte LDS writes, every load of a round in flight at once
+            constexpr int R = 3;                                  // 4096-row rounds in flight (12 288 rows: what NC >= 3 can hold)
+            const int full = p.cols >> 2;                         // whole groups of four rows
+            for (int q0 = tid; q0 < full; q0 += R * kCrThreads) {
+                cr_f4 x[R][NC];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int c = c0 + u * kCrThreads, cc = c < p.cols ? c : p.cols - 1;
+                for (int r = 0; r < R; r++) {
+                    const int q = q0 + r * kCrThreads, qq = q < full ? q : full - 1;
 #pragma unroll
-                for (int jj = 0; jj < NC; jj++) v[u][jj] = Bj[(int64_t)(jj < nc ? jj : nc - 1) * p.ldb + cc];
+                    for (int jj = 0; jj < NC; jj++) x[r][jj] = *reinterpret_cast<const cr_f4*>(Bj + (int64_t)(jj < nc ? jj : nc - 1) * p.ldb + 4 * qq);
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int q = q0 + r * kCrThreads;
+                    if (q < full) cr_put4<NC>(lds, span, 4 * q, x[r]);
+                }
             }
+            for (int c = 4 * full + tid; c < p.cols; c += kCrThreads) {          // the last cols % 4 rows
+                float v[NC];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int c = c0 + u * kCrThreads;
-                if (c < p.cols) cr_put<NC>(lds, span, c, v[u]);
+                for (int jj = 0; jj < NC; jj++) v[jj] = Bj[(int64_t)(jj < nc ? jj : nc - 1) * p.ldb + c];
+                cr_put<NC>(lds, span, c, v);
+            }
+        } else {
+            constexpr int U = 4;
+            for (int c0 = tid; c0 < p.cols; c0 += U * kCrThreads) {
+                float v[U][NC];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int c = c0 + u * kCrThreads, cc = c < p.cols ? c : p.cols - 1;
+#pragma unroll
+                    for (int jj = 0; jj < NC; jj++) v[u][jj] = Bj[(int64_t)(jj < nc ? jj : nc - 1) * p.ldb + cc];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int c = c0 + u * kCrThreads;
+                    if (c < p.cols) cr_put<NC>(lds, span, c, v[u]);
+                }
             }
         }
     }
+    if (tid == 0) {                                               // the cell behind the last row: what a padding entry of A (column = cols) reads
+        const float z[NC] = {};
+        cr_put<NC>(lds, span, p.cols, z);
+    }
     __syncthreads();
 
-    // ---- 2. A streams past: lane = slot, entry k of the slice's 64 slots is one 512-byte line ------------------------------------------------------
+    // ---- 2. A streams past: lane = slot, a batch (4 steps) of the wave's stream is one 512-byte line of columns (+ 1 KB of values) -------------------------
+    // ONE stream per wave, read D batches ahead whatever slice they belong to (a loop per slice exposed a scalar load, a global load and an LDS read, one after the
+    // other, at every one of the 12 slices of a wave).  Where a slice ends (wave-uniform: a scalar compare per batch) the running sums are parked in the registers of
+    // that slice -- they cannot go to LDS before the last wave is done with the columns of B.
     float acc[SL][NC];
 #pragma unroll
     for (int i = 0; i < SL; i++) {
 #pragma unroll
         for (int jj = 0; jj < NC; jj++) acc[i][jj] = 0.0f;
     }
-    constexpr int U = NC >= 3 ? 4 : 8;
-    static_for<0, SL>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const int s = wave + i * kCrWaves;
-        if (s < p.n_slices) {
-            const int off = __builtin_amdgcn_readfirstlane(p.soff[s]);
-            const int wd = __builtin_amdgcn_readfirstlane(p.soff[s + 1] - off) >> 6;       // entries per slot of this slice
-            const int2* e = p.ent + off + lane;
-            // (a slot shorter than its slice is padded with (a column of its own row, 0.0f): no per-lane condition; the steps past the slice's end re-read its last
-            // entry with the value replaced by zero -- one scalar-conditioned select per entry instead of a tail loop)
-            for (int k0 = 0; k0 < wd; k0 += U) {
-                int2 cv[U];
+    const int sl0 = __builtin_amdgcn_readfirstlane(p.wslice[wave]);
+    const int n_w = __builtin_amdgcn_readfirstlane(p.wslice[wave + 1]) - sl0;      // slices of this wave (<= SL: checked by the host)
+    {
+        const int off = __builtin_amdgcn_readfirstlane(p.woff[wave]);             // in batches
+        const int T = (p.probe & 2) ? 0 : __builtin_amdgcn_readfirstlane(p.woff[wave + 1]) - off;
+        const cr_u2* ec = reinterpret_cast<const cr_u2*>(p.col4) + (size_t)off * 64 + lane;
+        const cr_f4* ev = UNIT ? nullptr : reinterpret_cast<const cr_f4*>(p.val4) + (size_t)off * 64 + lane;
+        const int32_t* bnd = p.bnd + sl0;                          // bnd[i]: the batch behind the last one of the wave's i-th slice
+        int i = 0;
+        int nb = T > 0 ? __builtin_amdgcn_readfirstlane(bnd[0]) : -1;
+        float cur[NC];
 #pragma unroll
-                for (int u = 0; u < U; u++) { const int k = k0 + u < wd ? k0 + u : wd - 1; cv[u] = e[k * 64]; }
-                float b[U][NC];
+        for (int jj = 0; jj < NC; jj++) cur[jj] = 0.0f;
+        constexpr int D = 4;                                       // batches in flight (an L2 hit is ~700 cycles away): the loop body is written D times, each copy consuming the
+        cr_u2 rc[D];                                               // register buffer it then refills for D batches later
+        cr_f4 rv[D];
 #pragma unroll
-                for (int u = 0; u < U; u++) cr_get<NC>(lds, span, cv[u].x, b[u]);
+        for (int q = 0; q < D; q++) {
+            const int t = q < T ? q : (T > 0 ? T - 1 : 0);         // (past the end: the last line again, never used)
+            rc[q] = ec[(size_t)t * 64];
+            if constexpr (!UNIT) rv[q] = ev[(size_t)t * 64];
+            else rv[q] = cr_f4{1.0f, 1.0f, 1.0f, 1.0f};
+            __builtin_amdgcn_sched_barrier(0);                     // issue order = consumption order (vmcnt counts loads in order).  NOT an asm memory clobber: behind one the
+        }                                                          // slice boundaries are no longer scalar loads, and their vector loads drain the ring at every slice end
+        auto batch = [&](cr_u2& bc, cr_f4& bv, int t0) __attribute__((always_inline)) {
+            const unsigned w0 = bc.x, w1 = bc.y;
+            const int c[4] = {(int)(w0 & 0xffffu), (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16)};
+            float b[4][NC];
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const float a = k0 + u < wd ? __builtin_bit_cast(float, cv[u].y) : 0.0f;
-#pragma unroll
-                    for (int jj = 0; jj < NC; jj++) acc[i][jj] = __builtin_fmaf(a, b[u][jj], acc[i][jj]);
-                }
+            for (int u = 0; u < 4; u++) cr_get<NC>(lds, span, c[u], b[u]);
+            const float a[4] = {bv.x, bv.y, bv.z, bv.w};
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int t = t0 + D < T ? t0 + D : T - 1;         // refilled behind its last use: no copies
+                bc = ec[(size_t)t * 64];
+                if constexpr (!UNIT) bv = ev[(size_t)t * 64];
             }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+#pragma unroll
+                for (int jj = 0; jj < NC; jj++) cur[jj] = UNIT ? cur[jj] + b[u][jj] : __builtin_fmaf(a[u], b[u][jj], cur[jj]);
+            }
+            if (t0 + 1 == nb) {                                    // (wave-uniform) the slice ends with this batch: park its sums in ITS registers -- scalar branches, NC moves
+#pragma unroll
+                for (int I = 0; I < SL; I++) {
+                    if (i == I) {                                  // (a plain conditional store: the chain becomes ONE indexed store and the array moves to scratch)
+#pragma unroll
+                        for (int jj = 0; jj < NC; jj++) asm volatile("v_mov_b32 %0, %1" : "=v"(acc[I][jj]) : "v"(cur[jj]));
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < NC; jj++) cur[jj] = 0.0f;
+                i++;
+                nb = i < n_w ? __builtin_amdgcn_readfirstlane(bnd[i]) : -1;
+            }
+        };
+        for (int t0 = 0; t0 < T; t0 += D) {
+            static_for<0, D>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value;
+                if (t0 + q < T) batch(rc[q], rv[q], t0 + q);
+            });
         }
-    });
+    }
     __syncthreads();                                              // nobody reads the columns of B any more
 
     // ---- 3. sums -> staging image (NC planes of P cells), long rows add their extra cells in chunk order ---------------------------------------------
     const int P = p.plane;
-    static_for<0, SL>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const int s = wave + i * kCrWaves;
-        if (s < p.n_slices) {
-            const int d = p.dest[s * 64 + lane];
-            if (d >= 0) {
+    {
+        int dst[SL];
 #pragma unroll
-                for (int jj = 0; jj < NC; jj++) lds[jj * P + d] = acc[i][jj];
+        for (int I = 0; I < SL; I++) dst[I] = p.dest[(sl0 + (I < n_w ? I : 0)) * 64 + lane];      // (all loads first: one latency, not SL)
+#pragma unroll
+        for (int I = 0; I < SL; I++) {
+            if (I < n_w && dst[I] >= 0) {
+#pragma unroll
+                for (int jj = 0; jj < NC; jj++) lds[jj * P + dst[I]] = acc[I][jj];
             }
         }
-    });
+    }
     __syncthreads();
     if (p.n_long > 0) {
         for (int t = tid; t < p.n_long * NC; t += kCrThreads) {
@@ -144,6 +246,7 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
 
     // ---- 4. staging image -> the NC columns of C, whole lines --------------------------------------------------------------------------------------
     float* Cj = p.C + (int64_t)j0 * p.ldc;
+    if (p.probe & 4) return;
     if (p.vec_out) {
         const int r4 = p.rows >> 2;
         for (int jj = 0; jj < nc; jj++) {
@@ -165,15 +268,15 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
     }
 }
 
-template <int NC, int SL>
+template <int NC, int SL, bool UNIT>
 int colres_launch(const ColresParams& p, size_t lds_bytes, hipStream_t st) {
     static int attr_rc = -1;                                      // once per instantiation: allow more than 64 KB of dynamic LDS
     if (attr_rc != 0) {
-        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&colres_kernel<NC, SL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&colres_kernel<NC, SL, UNIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (attr_rc != 0) return attr_rc;
     }
     const unsigned grid = (unsigned)((p.N + NC - 1) / NC);
-    hipLaunchKernelGGL((colres_kernel<NC, SL>), dim3(grid), dim3(kCrThreads), lds_bytes, st, p);
+    hipLaunchKernelGGL((colres_kernel<NC, SL, UNIT>), dim3(grid), dim3(kCrThreads), lds_bytes, st, p);
     return 0;
 }
 
@@ -181,14 +284,15 @@ int colres_launch(const ColresParams& p, size_t lds_bytes, hipStream_t st) {
 
 namespace sparta_dev {
 
-int colres_max_slices(int nc) { return (nc == 1 ? 40 : nc == 2 ? 20 : nc == 3 ? 14 : 10) * kCrWaves; }
+int colres_max_slices(int nc) { return (40 / nc) * kCrWaves; }
 
 int launch_colres(int nc, const ColresParams& p, size_t lds_bytes, hipStream_t st) {
+    const bool unit = p.val4 == nullptr;
     switch (nc) {
-        case 1: return colres_launch<1, 40>(p, lds_bytes, st);
-        case 2: return colres_launch<2, 20>(p, lds_bytes, st);
-        case 3: return colres_launch<3, 14>(p, lds_bytes, st);
-        case 4: return colres_launch<4, 10>(p, lds_bytes, st);
+        case 1: return unit ? colres_launch<1, 40, true>(p, lds_bytes, st) : colres_launch<1, 40, false>(p, lds_bytes, st);
+        case 2: return unit ? colres_launch<2, 20, true>(p, lds_bytes, st) : colres_launch<2, 20, false>(p, lds_bytes, st);
+        case 3: return unit ? colres_launch<3, 13, true>(p, lds_bytes, st) : colres_launch<3, 13, false>(p, lds_bytes, st);
+        case 4: return unit ? colres_launch<4, 10, true>(p, lds_bytes, st) : colres_launch<4, 10, false>(p, lds_bytes, st);
     }
     return -1;
 }

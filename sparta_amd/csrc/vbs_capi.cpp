@@ -92,8 +92,9 @@ void destroy_impl(sparta_vbs* v) {
     if (v->d_sp_stream_begin) (void)hipFree(v->d_sp_stream_begin);
     if (v->d_sp_long) (void)hipFree(v->d_sp_long);
     if (v->d_sp_part) (void)hipFree(v->d_sp_part);
-    if (v->d_cr_ent) (void)hipFree(v->d_cr_ent);
-    if (v->d_cr_soff) (void)hipFree(v->d_cr_soff);
+    if (v->d_cr_col) (void)hipFree(v->d_cr_col);
+    if (v->d_cr_val) (void)hipFree(v->d_cr_val);
+    if (v->d_cr_meta) (void)hipFree(v->d_cr_meta);
     if (v->d_cr_dest) (void)hipFree(v->d_cr_dest);
     if (v->d_cr_longs) (void)hipFree(v->d_cr_longs);
     if (v->d_Brm) (void)hipFree(v->d_Brm);
@@ -116,16 +117,18 @@ void destroy_impl(sparta_vbs* v) {
 // workgroup a slot of twice the average load per lane is not the critical path).
 constexpr int64_t kColresCells = 160 * 1024 / 4;                  // floats of LDS a workgroup may hold
 struct ColresHost {
-    std::vector<int32_t> ent;                                     // (column, value bits) pairs
-    std::vector<int32_t> soff, dest;
+    std::vector<uint16_t> col;                                    // per batch of 4 steps and lane: four columns ...
+    std::vector<float> val;                                       // ... and four values (empty: every stored value is 1.0f -- a unit image, the reference's -P 1)
+    std::vector<int32_t> woff, wslice, bnd, dest;
     std::vector<ColresLong> longs;
     int32_t n_slices = 0, plane = 0, lmax = 0;
+    int64_t entries = 0;
 };
 bool build_colres(int64_t rows, int64_t cols, const std::vector<int64_t>& rowptr, const std::vector<int32_t>& col, const std::vector<float>& val,
                   const std::vector<int32_t>& crow, ColresHost& H) {
     if (const char* e = std::getenv("SPARTA_COLRES")) if (atoi(e) == 0) return false;
     const int64_t n = (int64_t)crow.size(), nnz = rowptr.empty() ? 0 : rowptr.back();
-    if (n != rows || nnz == 0 || rows > kColresCells || cols > kColresCells - 1) return false;
+    if (n != rows || nnz == 0 || rows > kColresCells || cols > kColresCells - 4) return false;                // (columns fit 16 bits; one more LDS cell holds the zero the padding points at)
     std::vector<uint8_t> seen((size_t)rows, 0);
     for (int64_t t = 0; t < n; t++) {
         const int32_t r = crow[(size_t)t];
@@ -153,40 +156,55 @@ bool build_colres(int64_t rows, int64_t cols, const std::vector<int64_t>& rowptr
     for (ColresLong& lr : H.longs) lr.first += (int32_t)rows_pad;
     std::stable_sort(slots.begin(), slots.end(), [](const Slot& a, const Slot& b) { return a.len > b.len; });
     const int64_t n_slices = ((int64_t)slots.size() + 63) / 64;
-    H.soff.assign((size_t)n_slices + 1, 0);
+    constexpr int64_t kWaves = kColresWaves;                                          // waves of a workgroup of k_colres.hip
+    // wave-major order: wave w owns the slices w, w + 16, ... of the sorted list (equally long streams), stored back to back
+    H.woff.assign(17, 0); H.wslice.assign(17, 0);                                       // (room for 16 waves: [kWaves] is what the kernel reads last)
+    H.bnd.assign((size_t)n_slices, 0);
     H.dest.assign((size_t)n_slices * 64, -1);
-    int64_t total = 0;
-    for (int64_t s = 0; s < n_slices; s++) {
-        const int64_t wd = std::max<int32_t>(1, slots[(size_t)s * 64].len);            // sorted: the first slot of a slice is its longest; never an empty slice (the kernel clamps k to wd - 1)
-        H.soff[(size_t)s] = (int32_t)total;
-        total += wd * 64;
-        if (total > (int64_t)INT32_MAX / 2) return false;
+    bool unit = true;
+    for (int64_t k = 0; k < nnz && unit; k++) unit = val[(size_t)k] == 1.0f;
+    if (const char* e = std::getenv("SPARTA_COLRES_UNIT")) unit = unit && atoi(e) != 0;      // (0: keep the value array of a pattern matrix -- developer A/B)
+    std::vector<int64_t> where((size_t)n_slices, 0), wdth((size_t)n_slices, 0), at_slice((size_t)n_slices, 0);      // per sorted slice: first batch, batches, wave-major index
+    int64_t total = 0, k_slice = 0;                               // batches
+    for (int64_t w = 0; w < kWaves; w++) {
+        H.woff[(size_t)w] = (int32_t)total; H.wslice[(size_t)w] = (int32_t)k_slice;
+        int64_t first = total;
+        for (int64_t s = w; s < n_slices; s += kWaves) {
+            const int64_t wb = std::max<int64_t>(1, ((int64_t)slots[(size_t)s * 64].len + 3) / 4);      // sorted: the first slot of a slice is its longest; never an empty slice
+            where[(size_t)s] = total; wdth[(size_t)s] = wb; at_slice[(size_t)s] = k_slice;
+            total += wb;
+            H.bnd[(size_t)k_slice++] = (int32_t)(total - first);
+            if (total * 256 > (int64_t)INT32_MAX / 2) return false;
+        }
     }
-    H.soff[(size_t)n_slices] = (int32_t)total;
-    H.ent.assign((size_t)total * 2, 0);
+    H.woff[(size_t)kWaves] = (int32_t)total; H.wslice[(size_t)kWaves] = (int32_t)k_slice;
+    // past a slot's end: the column `cols` -- one more cell of LDS, which the kernel clears -- with the value 0.0f: no per-lane condition, and nothing of B is multiplied by a padding zero
+    H.col.assign((size_t)(total + 1) * 256, (uint16_t)cols);                            // + one batch: a wave without slices still reads the first line of its (empty) stream
+    if (!unit) H.val.assign((size_t)(total + 1) * 256, 0.0f);
+    H.entries = total * 256;
     for (int64_t q = 0; q < (int64_t)slots.size(); q++) {
         const Slot& sl = slots[(size_t)q];
         const int64_t s = q / 64, l = q % 64;
-        H.dest[(size_t)q] = sl.dest >= 0 ? sl.dest : (int32_t)(rows_pad + (-2 - sl.dest));
-        const int32_t wd = (H.soff[(size_t)s + 1] - H.soff[(size_t)s]) / 64;
-        for (int32_t k = 0; k < wd; k++) {                                             // past the slot's end: a column of its own row with the value 0.0f (no per-lane condition in the kernel)
-            const size_t at = ((size_t)H.soff[(size_t)s] + (size_t)k * 64 + (size_t)l) * 2;
-            if (k < sl.len) { H.ent[at] = col[(size_t)(sl.p0 + k)]; std::memcpy(&H.ent[at + 1], &val[(size_t)(sl.p0 + k)], 4); }
-            else H.ent[at] = sl.len > 0 ? col[(size_t)(sl.p0 + sl.len - 1)] : 0;
+        H.dest[(size_t)(at_slice[(size_t)s] * 64 + l)] = sl.dest >= 0 ? sl.dest : (int32_t)(rows_pad + (-2 - sl.dest));
+        for (int64_t k = 0; k < sl.len; k++) {
+            const size_t at = ((size_t)(where[(size_t)s] + k / 4) * 64 + (size_t)l) * 4 + (size_t)(k % 4);
+            H.col[at] = (uint16_t)col[(size_t)(sl.p0 + k)];
+            if (!unit) H.val[at] = val[(size_t)(sl.p0 + k)];
         }
     }
     H.n_slices = (int32_t)n_slices; H.plane = (int32_t)plane; H.lmax = (int32_t)lmax;
     return true;
 }
 // columns of B per workgroup: as many as LDS holds next to each other (columns of B first, the staging image of C after them, in the same cells)
+// ... as many as fit: with one workgroup per CU the phases (columns of B in, stream of A, columns of C out) take the sum of their times, and the stream of A costs the same
+// per workgroup whatever NC (measured): fewer passes win.  SPARTA_COLRES_NC caps it (read per call: developer A/B, tests).
 int colres_columns(const sparta_vbs_t* A, int n_cols) {
     if (A->cr_slices == 0) return 0;
-    const int64_t span = (A->cols + 1) / 2 * 2, cells = std::max<int64_t>(span, A->cr_plane);
-    int nc = (int)std::min<int64_t>(4, kColresCells / cells);
+    const int64_t span = (A->cols + 4) / 4 * 4, cells = std::max<int64_t>(span, A->cr_plane);           // (+ the zero cell behind the last row of B)
+    int nc = (int)std::min<int64_t>(std::min<int64_t>(4, kColresCells / cells), n_cols);
     if (const char* e = std::getenv("SPARTA_COLRES_NC")) nc = std::min(nc, std::max(1, atoi(e)));
-    nc = std::min(nc, n_cols);
     while (nc > 1 && A->cr_slices > colres_max_slices(nc)) nc--;
-    return nc;
+    return nc >= 1 && A->cr_slices <= colres_max_slices(nc) ? nc : 0;
 }
 
 }  // namespace
@@ -734,10 +752,17 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
     if (!h16 && !sp_crow.empty() && v->n_steps[0] + v->n_steps[1] == 0 && v->n_hub_steps == 0) {
         ColresHost H;
         if (build_colres(v->rows, cols, sp_rowptr, sp_col, sp_val, sp_crow, H)) {
-            CREATE_TRY(hipMalloc(&v->d_cr_ent, H.ent.size() * sizeof(int32_t)));
-            CREATE_TRY(hipMemcpy(v->d_cr_ent, H.ent.data(), H.ent.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            CREATE_TRY(hipMalloc((void**)&v->d_cr_soff, H.soff.size() * sizeof(int32_t)));
-            CREATE_TRY(hipMemcpy(v->d_cr_soff, H.soff.data(), H.soff.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc(&v->d_cr_col, H.col.size() * sizeof(uint16_t)));
+            CREATE_TRY(hipMemcpy(v->d_cr_col, H.col.data(), H.col.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            if (!H.val.empty()) {
+                CREATE_TRY(hipMalloc(&v->d_cr_val, H.val.size() * sizeof(float)));
+                CREATE_TRY(hipMemcpy(v->d_cr_val, H.val.data(), H.val.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
+            std::vector<int32_t> meta(H.woff);
+            meta.insert(meta.end(), H.wslice.begin(), H.wslice.end());
+            meta.insert(meta.end(), H.bnd.begin(), H.bnd.end());
+            CREATE_TRY(hipMalloc((void**)&v->d_cr_meta, meta.size() * sizeof(int32_t)));
+            CREATE_TRY(hipMemcpy(v->d_cr_meta, meta.data(), meta.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             CREATE_TRY(hipMalloc((void**)&v->d_cr_dest, H.dest.size() * sizeof(int32_t)));
             CREATE_TRY(hipMemcpy(v->d_cr_dest, H.dest.data(), H.dest.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             if (!H.longs.empty()) {
@@ -745,8 +770,9 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
                 CREATE_TRY(hipMemcpy(v->d_cr_longs, H.longs.data(), H.longs.size() * sizeof(ColresLong), hipMemcpyHostToDevice));
             }
             v->cr_slices = H.n_slices; v->cr_long = (int32_t)H.longs.size(); v->cr_plane = H.plane; v->cr_lmax = H.lmax;
-            v->cr_entries = (int64_t)H.ent.size() / 2;
-            v->a_bytes += (int64_t)(H.ent.size() * sizeof(int32_t));
+            v->cr_entries = H.entries;
+            v->a_bytes += (int64_t)(H.col.size() * sizeof(uint16_t) + H.val.size() * sizeof(float));
+            v->cr_unit = H.val.empty();
         }
     }
     CREATE_TRY(hipEventCreate(&v->ev0));
@@ -944,24 +970,32 @@ int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, 
     for (int k = 0; k < 8; k++) info[k] = 0;
     if (!build_colres(rows, cols, rp, ci, va, cr, H)) return SPARTA_OK;                 // info[0] = 0: this matrix gets no image
     std::vector<float> cell((size_t)H.plane, 0.0f);
-    for (int32_t s = 0; s < H.n_slices; s++) {
-        const int32_t off = H.soff[(size_t)s], wd = (H.soff[(size_t)s + 1] - off) / 64;
-        for (int l = 0; l < 64; l++) {
-            float acc = 0.0f;
-            for (int32_t k = 0; k < wd; k++) {
-                const size_t at = ((size_t)off + (size_t)k * 64 + (size_t)l) * 2;
-                float a; std::memcpy(&a, &H.ent[at + 1], 4);
-                if (H.ent[at] < 0 || H.ent[at] >= cols) return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: column out of range in the image");
-                acc = std::fma(a, x[H.ent[at]], acc);
+    for (int w = 0; w < kColresWaves; w++) {
+        for (int32_t i = H.wslice[(size_t)w]; i < H.wslice[(size_t)w + 1]; i++) {
+            const int32_t t0 = i == H.wslice[(size_t)w] ? 0 : H.bnd[(size_t)i - 1], t1 = H.bnd[(size_t)i];      // batches of 4 steps
+            for (int l = 0; l < 64; l++) {
+                float acc = 0.0f;
+                for (int32_t t = t0; t < t1; t++) {
+                    for (int u = 0; u < 4; u++) {
+                        const size_t at = ((size_t)(H.woff[(size_t)w] + t) * 64 + (size_t)l) * 4 + (size_t)u;
+                        const int64_t c = H.col[at];
+                        if (c > cols) return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: column out of range in the image");
+                        const float b = c == cols ? 0.0f : x[c];                       // the zero cell behind the last row of B
+                        acc = H.val.empty() ? acc + b : std::fma(H.val[at], b, acc);
+                    }
+                }
+                const int32_t d = H.dest[(size_t)i * 64 + (size_t)l];
+                if (d >= H.plane) return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: cell out of range in the image");
+                if (d >= 0) cell[(size_t)d] = acc;
             }
-            const int32_t d = H.dest[(size_t)s * 64 + (size_t)l];
-            if (d >= H.plane) return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: cell out of range in the image");
-            if (d >= 0) cell[(size_t)d] = acc;
         }
+        if (H.bnd.size() && H.wslice[(size_t)w + 1] > H.wslice[(size_t)w] &&
+            (int64_t)H.bnd[(size_t)H.wslice[(size_t)w + 1] - 1] != (int64_t)H.woff[(size_t)w + 1] - H.woff[(size_t)w])
+            return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: a wave's stream and its slice boundaries disagree");
     }
     for (const ColresLong& lr : H.longs) { float sum = cell[(size_t)lr.row]; for (int32_t i = 0; i < lr.n; i++) sum += cell[(size_t)lr.first + (size_t)i]; cell[(size_t)lr.row] = sum; }
     for (int64_t i = 0; i < rows; i++) y[i] = cell[(size_t)i];
-    info[0] = H.n_slices; info[1] = (int64_t)H.ent.size() / 2; info[2] = (int64_t)H.longs.size(); info[3] = H.plane; info[4] = H.lmax; info[6] = rp.back();
+    info[0] = H.n_slices; info[1] = H.entries; info[2] = (int64_t)H.longs.size(); info[3] = H.plane; info[4] = H.lmax; info[6] = rp.back(); info[7] = H.val.empty() ? 1 : 0;
     return SPARTA_OK;
     SPARTA_GUARD_END("sparta_colres_host_check")
 }
@@ -969,7 +1003,7 @@ int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, 
 int sparta_vbs_colres_info(const sparta_vbs_t* A, int64_t* info) {
     if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_colres_info: NULL argument");
     info[0] = A->cr_slices; info[1] = A->cr_entries; info[2] = A->cr_long; info[3] = A->cr_plane; info[4] = A->cr_lmax; info[5] = A->last_colres_nc;
-    info[6] = A->cr_slices > 0 ? A->sp_nnz : 0; info[7] = 0;
+    info[6] = A->cr_slices > 0 ? A->sp_nnz : 0; info[7] = A->cr_slices > 0 && A->cr_unit ? 1 : 0;
     return SPARTA_OK;
 }
 
@@ -1087,13 +1121,30 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
         const int nc = colres_columns(A, n_cols);
         if (nc > 0) {
             ColresParams cp;
-            cp.ent = (const int2*)A->d_cr_ent; cp.soff = A->d_cr_soff; cp.dest = A->d_cr_dest; cp.longs = (const ColresLong*)A->d_cr_longs;
+            cp.col4 = (const uint2*)A->d_cr_col; cp.val4 = (const float4*)A->d_cr_val; cp.woff = A->d_cr_meta; cp.wslice = A->d_cr_meta + 17; cp.bnd = A->d_cr_meta + 34; cp.dest = A->d_cr_dest; cp.longs = (const ColresLong*)A->d_cr_longs;
             cp.B = (const float*)dB; cp.ldb = ldb; cp.C = dC; cp.ldc = ldc;
             cp.n_slices = A->cr_slices; cp.n_long = A->cr_long; cp.rows = (int32_t)A->rows; cp.cols = (int32_t)A->cols; cp.N = n_cols; cp.accumulate = accumulate ? 1 : 0;
             cp.vec_out = ldc % 4 == 0 && ((uintptr_t)dC % 16) == 0 ? 1 : 0;
+            cp.vec_in = ldb % 4 == 0 && ((uintptr_t)dB % 16) == 0 ? 1 : 0;
             cp.plane = A->cr_plane;
-            const int64_t span = (A->cols + 1) / 2 * 2;
+            cp.probe = [] { const char* e = std::getenv("SPARTA_COLRES_PROBE"); return e ? atoi(e) : 0; }();        // (read per call: developer A/B)
+            const int64_t span = (A->cols + 4) / 4 * 4;
             const size_t lds_bytes = (size_t)std::max<int64_t>(span, A->cr_plane) * (size_t)nc * sizeof(float);
+            {
+                static const int n_cus = [] { hipDeviceProp_t pr; return hipGetDeviceProperties(&pr, 0) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }();
+                cp.n_cus = n_cus;
+                // start the CUs in three groups, a quarter of a workgroup's time apart (its stream of A: LDS-bound, ~7 / 7 / 14 / 13 cycles per step of 64 slots with 1..4 columns;
+                // its columns of B and C at HBM speed).  Measured at N = 8192 (profiles/r4/lab_colres_stagger2.txt): bcsstk18 0.262 -> 0.234 ms, wiki-Vote 0.217 -> 0.189,
+                // ca-HepPh 0.326 -> 0.294; two groups or four, or offsets of half a workgroup's time: less or nothing.  SPARTA_COLRES_STAGGER_US / SPARTA_COLRES_GROUPS:
+                // developer A/B, read per call; 0 = everybody at once
+                static const double step_cycles[5] = {0.0, 7.0, 7.0, 14.0, 13.0};
+                const double t_wg = (double)A->cr_entries / 64.0 * step_cycles[nc] / 2.4e9 + (double)(A->rows + A->cols) * nc * 4.0 / (6.0e12 / n_cus) + 3.0e-6;
+                const char* e = std::getenv("SPARTA_COLRES_STAGGER_US");
+                const char* eg = std::getenv("SPARTA_COLRES_GROUPS");
+                cp.share = eg ? std::max(1, atoi(eg)) : 3;
+                const double stagger = e ? atof(e) * 1e-6 : t_wg / 4.0;
+                cp.stagger_ticks = cp.share > 1 && (int64_t)((n_cols + nc - 1) / nc) > 2 * (int64_t)n_cus ? (int32_t)std::min(stagger * 1e8, 1.0e5) : 0;
+            }
             if (int hrc = launch_colres(nc, cp, lds_bytes, st)) return sparta::fail(SPARTA_ERR_HIP, "sparta_vbs_spmm: the resident-column kernel could not be launched (hipError_t " + std::to_string(hrc) + ")");
             HIP_TRY(hipGetLastError());
             A->last_colres_nc = nc;

@@ -164,18 +164,26 @@ struct SparseParams {
 };
 
 // resident-column product (k_colres.hip): A as slots (rows, the long ones cut into chunks) sorted by length, 64 to a slice, entry k of a slice's slots contiguous
+constexpr int kColresWaves = 16;        // waves of a workgroup of k_colres.hip (host layout and kernel agree on it)
 struct ColresLong { int32_t row, first, n, pad; };   // a row cut into chunks: its cell in the staging image, the first of its extra cells, how many
 struct ColresParams {
-    const int2* ent;           // (column, value bits); slice s, step k, lane l at soff[s] + 64 k + l; a slot shorter than its slice ends in (a column of its row, 0.0f)
-    const int32_t* soff;       // [n_slices + 1], in entries
-    const int32_t* dest;       // [64 n_slices] cell of the staging image the slot's sum goes to (row of C, or an extra cell >= rows); -1: padding slot
+    // The slices of wave w (w, w + 16, ... of the length-sorted list; widths multiples of 4 steps) back to back, in batches of 4 steps: batch t of wave w, lane l at (woff[w] + t) * 64 + l;
+    // a slot shorter than its slice ends in (a column of its row, 0.0f) -- (the row's column, whatever value) where every value is 1.0f ... see build_colres
+    const uint2* col4;         // four 16-bit columns per batch and lane
+    const float4* val4;        // four values per batch and lane; nullptr: every stored value is 1.0f AND no slot is padded inside a slice with a nonzero (unit image)
+    const int32_t* woff;       // [17] in batches
+    const int32_t* wslice;     // [17] first slice of every wave in the wave-major order of bnd / dest
+    const int32_t* bnd;        // [n_slices] the batch of its wave's stream behind the slice's last one
+    const int32_t* dest;       // [64 n_slices] (wave-major) cell of the staging image the slot's sum goes to (row of C, or an extra cell >= rows); -1: padding slot
     const ColresLong* longs;
     const float* B;            // column-major, ld = ldb
     int64_t ldb;
     float* C;                  // column-major, ld = ldc
     int64_t ldc;
-    int32_t n_slices, n_long, rows, cols, N, accumulate, vec_out;
+    int32_t n_slices, n_long, rows, cols, N, accumulate, vec_out, vec_in;
     int32_t plane;             // cells per column of the staging image (rows + extra cells, a multiple of 4)
+    int32_t n_cus, share, stagger_ticks;      // CUs of the device, workgroups that share one (LDS), and the start offset between them in 10 ns ticks (0: none) -- see the kernel
+    int32_t probe;             // developer probe (SPARTA_COLRES_PROBE, wrong products): 1 skip the loads of B, 2 skip the stream of A, 4 skip the stores of C, 8 conflict-free LDS addresses, 16 no loads of A
 };
 
 struct SpSegRec { int64_t p0; int32_t cnt, pad; };
@@ -287,11 +295,13 @@ struct sparta_vbs {
     void* d_sp_part = nullptr;             // partial rows of the segments
     size_t d_sp_part_bytes = 0;
     // resident-column product (k_colres.hip): fp32 handles whose rows are ALL sparse rows and whose columns of B fit LDS
-    void* d_cr_ent = nullptr;
-    int32_t* d_cr_soff = nullptr;
+    void* d_cr_col = nullptr;               // 16-bit columns
+    void* d_cr_val = nullptr;               // values (nullptr: unit image)
+    int32_t* d_cr_meta = nullptr;          // woff[17], wslice[17], bnd[n_slices]
     int32_t* d_cr_dest = nullptr;
     void* d_cr_longs = nullptr;
     int32_t cr_slices = 0, cr_long = 0, cr_plane = 0, cr_lmax = 0;
+    bool cr_unit = false;                  // every value 1.0f: no value array
     int64_t cr_entries = 0;                // stored entries, padding included
     int last_colres_nc = 0;                // columns per workgroup of the last product on this path (0: the product took another path)
     void* d_Brm = nullptr;                 // row-major copy of a column-major / gathered B

@@ -20,7 +20,7 @@ def _walk(A, x, crow=None):
     cr = None if crow is None else np.ascontiguousarray(crow, np.int64)
     check(lib.sparta_colres_host_check(rows, cols, rp.ctypes.data_as(_i64p), ci.ctypes.data_as(_i32p), va.ctypes.data_as(_f32p),
                                        None if cr is None else cr.ctypes.data_as(_i64p), x.ctypes.data_as(_f32p), y.ctypes.data_as(_f32p), info.ctypes.data_as(_i64p)))
-    keys = ["slices", "entries", "long_rows", "plane", "lmax", "nc", "nnz"]
+    keys = ["slices", "entries", "long_rows", "plane", "lmax", "nc", "nnz", "unit"]
     return y, {k: int(info[i]) for i, k in enumerate(keys)}
 
 
@@ -56,11 +56,11 @@ def test_walk_of_the_image_equals_the_product(rows, cols, density, hubs, empty):
     assert np.all(np.abs(y[crow] - ref) <= 1e-5 * bound + 1e-30)
     # layout facts the kernel relies on
     assert info["plane"] % 4 == 0 and info["plane"] >= rows
-    assert info["entries"] % 64 == 0 and info["entries"] >= A.nnz
+    assert info["entries"] % 256 == 0 and info["entries"] >= A.nnz and info["unit"] == 0
     longest = int(np.diff(A.indptr).max())
     assert (info["long_rows"] > 0) == (longest > info["lmax"])
     if A.nnz > 5000:
-        assert info["entries"] <= 1.6 * A.nnz, "padding of the sorted slices out of proportion"
+        assert info["entries"] <= 1.9 * A.nnz, "padding of the sorted slices (whole batches of 4 steps) out of proportion"
 
 
 def test_rows_that_are_not_cut_are_added_in_the_order_of_csr_multiply():
@@ -113,3 +113,25 @@ def test_no_image_for_matrices_the_kernel_cannot_hold(monkeypatch):
     monkeypatch.delenv("SPARTA_COLRES")
     y, info = _walk(_matrix(100, 100, 0.1, 0, 1), x, np.zeros(100, np.int64))      # crow not a permutation of the rows: no image (rows of C would stay unwritten)
     assert info["slices"] == 0 and np.all(y == 7.0)
+
+
+def test_pattern_matrices_get_a_unit_image(monkeypatch):
+    """every value 1.0f (the reference's -P 1 runs): columns only, the sums are sums of elements of x in ascending column order; padding reads the zero cell"""
+    A = _matrix(3000, 2500, 0.004, 2, 21, empty_every=9)
+    A.data[:] = 1.0
+    x = np.random.default_rng(5).standard_normal(2500).astype(np.float32)
+    y, info = _walk(A, x)
+    assert info["unit"] == 1 and info["slices"] > 0
+    ref = A.astype(np.float64) @ x.astype(np.float64)
+    bound = np.abs(A).astype(np.float64) @ np.abs(x).astype(np.float64)
+    assert np.all(np.abs(y - ref) <= 1e-5 * bound + 1e-30)
+    assert np.all(y[np.diff(A.indptr) == 0] == 0.0)
+    monkeypatch.setenv("SPARTA_COLRES_UNIT", "0")
+    y2, info2 = _walk(A, x)
+    assert info2["unit"] == 0 and np.array_equal(y2, y)               # fma(1, b, acc) = acc + b
+    # a matrix with infinities in x: a padding entry must not turn them into NaN in OTHER rows (it reads the zero cell, not a column of its row)
+    x2 = x.copy()
+    x2[7] = np.inf
+    y3, _ = _walk(A, x2)
+    touched = np.asarray((A[:, 7] != 0).todense()).reshape(-1)
+    assert np.all(np.isfinite(y3[~touched])) and np.all(np.isinf(y3[touched]))
