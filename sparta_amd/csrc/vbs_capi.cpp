@@ -202,7 +202,10 @@ int colres_columns(const sparta_vbs_t* A, int n_cols) {
     if (A->cr_slices == 0) return 0;
     const int64_t span = (A->cols + 4) / 4 * 4, cells = std::max<int64_t>(span, A->cr_plane);           // (+ the zero cell behind the last row of B)
     int nc = (int)std::min<int64_t>(std::min<int64_t>(4, kColresCells / cells), n_cols);
-    if (const char* e = std::getenv("SPARTA_COLRES_NC")) nc = std::min(nc, std::max(1, atoi(e)));
+    // (a product of fewer workgroups than CUs is ONE round whatever NC: the stream of A with three or four columns per cell costs twice the LDS time of one or two --
+    // bcsstk18 at N = 128: 16.5 / 14.7 / 17.9 us with 1 / 2 / 3 columns)
+    if (nc > 2 && (n_cols + nc - 1) / nc <= 256) nc = 2;
+    if (const char* e = std::getenv("SPARTA_COLRES_NC")) nc = std::min((int)std::min<int64_t>(std::min<int64_t>(4, kColresCells / cells), n_cols), std::max(1, atoi(e)));
     while (nc > 1 && A->cr_slices > colres_max_slices(nc)) nc--;
     return nc >= 1 && A->cr_slices <= colres_max_slices(nc) ? nc : 0;
 }
