@@ -394,9 +394,11 @@ int sparta_vbs_sparse_info(const sparta_vbs_t* A, int64_t* info_out);
  * fits LDS (rows, columns <= 40 960); taken by sparta_vbs_spmm when B and C are column-major (the reference's layouts) device or host pointers: NC columns of
  * B are copied into LDS, A (length-sorted rows, 64 to a slice, long rows cut into chunks) streams past them from L2, one launch, B and C cross HBM once; a row's
  * nonzeros are added in ascending column order as in CSR::multiply (csr.cpp:49-65).  SPARTA_COLRES=0 at create time: not built (the row gather takes the product).
- * info_out (int64[8]): [0] slices of 64 slots (0: no image) [1] stored entries, padding included [2] rows cut into chunks [3] cells per column of the staging
- * image (rows + extra cells of the chunks) [4] longest slot [5] columns per workgroup of the last product on this path (0: the last product took another path)
- * [6] nonzeros [7] 1: every stored value is 1.0f and the image holds columns only (the reference's pattern-only runs, -P 1) */
+ * info_out (int64[10]): [0] slices of 64 slots of the part with most (0: no image) [1] stored entries, padding included [2] rows cut into chunks [3] cells a column set
+ * needs in LDS (the largest range of B + 4, or the largest staging image: rows + extra cells of the chunks) [4] longest slot [5] columns per workgroup of the last product on this path (0: the last product took another path)
+ * [6] nonzeros [7] 1: every stored value is 1.0f and the image holds columns only (the reference's pattern-only runs, -P 1)
+ * [8] parts the rows of C are cut into, [9] K ranges the columns of A are cut into (1, 1: a column of B and of C fits LDS whole; up to 4 x 4: rows, columns <= 163 k --
+ * the workgroup of a part walks the ranges one after the other with its sums in registers, B is read once per part) */
 int sparta_vbs_colres_info(const sparta_vbs_t* A, int64_t* info_out);
 /* HOST-side walk of that image for one column x of B (y = A x; rows of C through crow, NULL = identity; info_out as above, [0] = 0 and y untouched when the matrix
  * gets no image): slots in slice order, a slot's entries in order, the chunks of a long row added in chunk order -- the arithmetic of the kernel, for the CPU suite

@@ -70,92 +70,109 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j0 = (int)blockIdx.x * NC;
     const int nc = p.N - j0 < NC ? p.N - j0 : NC;                 // columns of this workgroup that exist (the last workgroup of a ragged N)
-    const int span = (p.cols + 4) & ~3;                           // cells per column of B: its rows + the zero cell the padding of A points at
+    // the part of the rows of C this workgroup owns (grid y); its tables
+    const ColresPartDev* pdp = p.parts + blockIdx.y;
+    const int part_r0 = __builtin_amdgcn_readfirstlane(pdp->r0), part_rows = __builtin_amdgcn_readfirstlane(pdp->rows);
+    const int n_slices = __builtin_amdgcn_readfirstlane(pdp->n_slices), n_long = __builtin_amdgcn_readfirstlane(pdp->n_long), P = __builtin_amdgcn_readfirstlane(pdp->plane);
+    const int32_t* wslice = p.meta + __builtin_amdgcn_readfirstlane(pdp->meta);
+    const int32_t* woff = wslice + 17;
+    const int32_t* bnd_all = woff + p.n_ranges * 17;
+    const int32_t* dest = p.dest + __builtin_amdgcn_readfirstlane(pdp->dest);
+    const ColresLong* longs = p.longs + __builtin_amdgcn_readfirstlane(pdp->longs);
 
     // Every CU starts its first workgroup at the same time, and all of them then load B together, stream A together, store C together: HBM idles while the LDS works and the
     // other way round.  The CUs of the first dispatch round are therefore started in p.share groups, a share of a workgroup's time apart (developer knob SPARTA_COLRES_STAGGER_US).
-    if (p.stagger_ticks > 0 && (int)blockIdx.x < p.n_cus) {
-        const int slot = ((int)blockIdx.x >> 3) % p.share;                             // (consecutive workgroups go to the 8 XCDs in turn: >> 3 = the CU within its XCD)
-        if (slot > 0) {
-            const long long t_end = wall_clock64() + (long long)slot * p.stagger_ticks;      // 100 MHz
-            while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8);
-        }
-    }
-
-    // ---- 1. the NC columns of B -> LDS, interleaved per row of B -------------------------------------------------------------------------------
-    // (branch-free: a lane past the last row reads the last row(s) and stores nothing; a column past the last one repeats the last one and is never written to C)
-    if (!(p.probe & 1)) {
-        const float* Bj = p.B + (int64_t)j0 * p.ldb;
-        if (p.vec_in) {                                           // 16-byte aligned columns: four rows per lane and load, whole 16-byte LDS writes, every load of a round in flight at once
-            constexpr int R = 3;                                  // 4096-row rounds in flight (12 288 rows: what NC >= 3 can hold)
-            const int full = p.cols >> 2;                         // whole groups of four rows
-            for (int q0 = tid; q0 < full; q0 += R * kCrThreads) {
-                cr_f4 x[R][NC];
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int q = q0 + r * kCrThreads, qq = q < full ? q : full - 1;
-#pragma unroll
-                    for (int jj = 0; jj < NC; jj++) x[r][jj] = *reinterpret_cast<const cr_f4*>(Bj + (int64_t)(jj < nc ? jj : nc - 1) * p.ldb + 4 * qq);
-                }
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int q = q0 + r * kCrThreads;
-                    if (q < full) cr_put4<NC>(lds, span, 4 * q, x[r]);
-                }
-            }
-            for (int c = 4 * full + tid; c < p.cols; c += kCrThreads) {          // the last cols % 4 rows
-                float v[NC];
-#pragma unroll
-                for (int jj = 0; jj < NC; jj++) v[jj] = Bj[(int64_t)(jj < nc ? jj : nc - 1) * p.ldb + c];
-                cr_put<NC>(lds, span, c, v);
-            }
-        } else {
-            constexpr int U = 4;
-            for (int c0 = tid; c0 < p.cols; c0 += U * kCrThreads) {
-                float v[U][NC];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int c = c0 + u * kCrThreads, cc = c < p.cols ? c : p.cols - 1;
-#pragma unroll
-                    for (int jj = 0; jj < NC; jj++) v[u][jj] = Bj[(int64_t)(jj < nc ? jj : nc - 1) * p.ldb + cc];
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int c = c0 + u * kCrThreads;
-                    if (c < p.cols) cr_put<NC>(lds, span, c, v[u]);
-                }
+    {
+        const int wg = (int)(blockIdx.x + blockIdx.y * gridDim.x);
+        if (p.stagger_ticks > 0 && wg < p.n_cus) {
+            const int slot = (wg >> 3) % p.share;                                      // (consecutive workgroups go to the 8 XCDs in turn: >> 3 = the CU within its XCD)
+            if (slot > 0) {
+                const long long t_end = wall_clock64() + (long long)slot * p.stagger_ticks;      // 100 MHz
+                while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8);
             }
         }
     }
-    if (tid == 0) {                                               // the cell behind the last row: what a padding entry of A (column = cols) reads
-        const float z[NC] = {};
-        cr_put<NC>(lds, span, p.cols, z);
-    }
-    __syncthreads();
 
-    // ---- 2. A streams past: lane = slot, a batch (4 steps) of the wave's stream is one 512-byte line of columns (+ 1 KB of values) -------------------------
-    // ONE stream per wave, read D batches ahead whatever slice they belong to (a loop per slice exposed a scalar load, a global load and an LDS read, one after the
-    // other, at every one of the 12 slices of a wave).  Where a slice ends (wave-uniform: a scalar compare per batch) the running sums are parked in the registers of
-    // that slice -- they cannot go to LDS before the last wave is done with the columns of B.
+    // the sums of the slices of this wave (slice s of the part's length-sorted list belongs to wave s % 16): in registers from the first K range to the last
     float acc[SL][NC];
 #pragma unroll
     for (int i = 0; i < SL; i++) {
 #pragma unroll
         for (int jj = 0; jj < NC; jj++) acc[i][jj] = 0.0f;
     }
-    const int sl0 = __builtin_amdgcn_readfirstlane(p.wslice[wave]);
-    const int n_w = __builtin_amdgcn_readfirstlane(p.wslice[wave + 1]) - sl0;      // slices of this wave (<= SL: checked by the host)
-    {
-        const int off = __builtin_amdgcn_readfirstlane(p.woff[wave]);             // in batches
-        const int T = (p.probe & 2) ? 0 : __builtin_amdgcn_readfirstlane(p.woff[wave + 1]) - off;
+    const int sl0 = __builtin_amdgcn_readfirstlane(wslice[wave]);
+    const int n_w = __builtin_amdgcn_readfirstlane(wslice[wave + 1]) - sl0;       // slices of this wave (<= SL: checked by the host)
+
+    for (int rg = 0; rg < p.n_ranges; rg++) {
+        const int k0 = p.krange[rg], klen = p.krange[rg + 1] - k0;               // this range's rows of B
+        const int span = (klen + 4) & ~3;                             // cells per column of B: the rows + the zero cell the padding of A points at
+        if (rg > 0) __syncthreads();                                  // the last wave is done with the previous range
+
+        // ---- 1. rows k0 .. k0 + klen of the NC columns of B -> LDS, interleaved per row of B ---------------------------------------------------------------
+        // (branch-free: a lane past the last row reads the last row(s) and stores nothing; a column past the last one repeats the last one and is never written to C)
+        if (!(p.probe & 1)) {
+            const float* Bj = p.B + (int64_t)j0 * p.ldb + k0;
+            if (p.vec_in) {                                           // 16-byte aligned columns: four rows per lane and load, whole 16-byte LDS writes, every load of a round in flight at once
+                constexpr int R = 3;                                  // 4096-row rounds in flight (12 288 rows: what NC >= 3 can hold)
+                const int full = klen >> 2;                           // whole groups of four rows
+                for (int q0 = tid; q0 < full; q0 += R * kCrThreads) {
+                    cr_f4 x[R][NC];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int q = q0 + r * kCrThreads, qq = q < full ? q : full - 1;
+#pragma unroll
+                        for (int jj = 0; jj < NC; jj++) x[r][jj] = *reinterpret_cast<const cr_f4*>(Bj + (int64_t)(jj < nc ? jj : nc - 1) * p.ldb + 4 * qq);
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int q = q0 + r * kCrThreads;
+                        if (q < full) cr_put4<NC>(lds, span, 4 * q, x[r]);
+                    }
+                }
+                for (int c = 4 * full + tid; c < klen; c += kCrThreads) {              // the last klen % 4 rows
+                    float v[NC];
+#pragma unroll
+                    for (int jj = 0; jj < NC; jj++) v[jj] = Bj[(int64_t)(jj < nc ? jj : nc - 1) * p.ldb + c];
+                    cr_put<NC>(lds, span, c, v);
+                }
+            } else {
+                constexpr int U = 4;
+                for (int c0 = tid; c0 < klen; c0 += U * kCrThreads) {
+                    float v[U][NC];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int c = c0 + u * kCrThreads, cc = c < klen ? c : klen - 1;
+#pragma unroll
+                        for (int jj = 0; jj < NC; jj++) v[u][jj] = Bj[(int64_t)(jj < nc ? jj : nc - 1) * p.ldb + cc];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int c = c0 + u * kCrThreads;
+                        if (c < klen) cr_put<NC>(lds, span, c, v[u]);
+                    }
+                }
+            }
+        }
+        if (tid == 0) {                                               // the cell behind the last row: what a padding entry of A (column = klen) reads
+            const float z[NC] = {};
+            cr_put<NC>(lds, span, klen, z);
+        }
+        __syncthreads();
+
+        // ---- 2. A streams past: lane = slot, a batch (4 steps) of the wave's stream is one 512-byte line of columns (+ 1 KB of values) -------------------------
+        // ONE stream per wave and range, read D batches ahead whatever slice they belong to (a loop per slice exposed a scalar load, a global load and an LDS read, one after
+        // the other, at every one of the 12 slices of a wave).  Where a slice ends (wave-uniform: a scalar compare per batch) the running sums are parked in the registers of
+        // that slice -- they cannot go to LDS before the last wave is done with the columns of B -- and the next slice's are taken up (zeros in the first range).
+        const int off = __builtin_amdgcn_readfirstlane(woff[rg * 17 + wave]);        // in batches
+        const int T = (p.probe & 2) ? 0 : __builtin_amdgcn_readfirstlane(woff[rg * 17 + wave + 1]) - off;
         const cr_u2* ec = reinterpret_cast<const cr_u2*>(p.col4) + (size_t)off * 64 + lane;
         const cr_f4* ev = UNIT ? nullptr : reinterpret_cast<const cr_f4*>(p.val4) + (size_t)off * 64 + lane;
-        const int32_t* bnd = p.bnd + sl0;                          // bnd[i]: the batch behind the last one of the wave's i-th slice
+        const int32_t* bnd = bnd_all + rg * n_slices + sl0;        // bnd[i]: the batch behind the last one of the wave's i-th slice
         int i = 0;
         int nb = T > 0 ? __builtin_amdgcn_readfirstlane(bnd[0]) : -1;
         float cur[NC];
 #pragma unroll
-        for (int jj = 0; jj < NC; jj++) cur[jj] = 0.0f;
+        for (int jj = 0; jj < NC; jj++) cur[jj] = acc[0][jj];
         constexpr int D = 4;                                       // batches in flight (an L2 hit is ~700 cycles away): the loop body is written D times, each copy consuming the
         cr_u2 rc[D];                                               // register buffer it then refills for D batches later
         cr_f4 rv[D];
@@ -185,17 +202,19 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
 #pragma unroll
                 for (int jj = 0; jj < NC; jj++) cur[jj] = UNIT ? cur[jj] + b[u][jj] : __builtin_fmaf(a[u], b[u][jj], cur[jj]);
             }
-            if (t0 + 1 == nb) {                                    // (wave-uniform) the slice ends with this batch: park its sums in ITS registers -- scalar branches, NC moves
-#pragma unroll
+            if (t0 + 1 == nb) {                                    // (wave-uniform) the slice ends with this batch: park its sums in ITS registers, take up the next slice's --
+                i++;                                               // scalar branches and 2 NC moves (plain conditional stores: the chain becomes ONE indexed store and the
+#pragma unroll                                                     // array moves to scratch)
                 for (int I = 0; I < SL; I++) {
-                    if (i == I) {                                  // (a plain conditional store: the chain becomes ONE indexed store and the array moves to scratch)
+                    if (i == I + 1) {
 #pragma unroll
                         for (int jj = 0; jj < NC; jj++) asm volatile("v_mov_b32 %0, %1" : "=v"(acc[I][jj]) : "v"(cur[jj]));
+                        if (I + 1 < SL) {
+#pragma unroll
+                            for (int jj = 0; jj < NC; jj++) asm volatile("v_mov_b32 %0, %1" : "=v"(cur[jj]) : "v"(acc[I + 1 < SL ? I + 1 : I][jj]));
+                        }
                     }
                 }
-#pragma unroll
-                for (int jj = 0; jj < NC; jj++) cur[jj] = 0.0f;
-                i++;
                 nb = i < n_w ? __builtin_amdgcn_readfirstlane(bnd[i]) : -1;
             }
         };
@@ -209,11 +228,10 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
     __syncthreads();                                              // nobody reads the columns of B any more
 
     // ---- 3. sums -> staging image (NC planes of P cells), long rows add their extra cells in chunk order ---------------------------------------------
-    const int P = p.plane;
     {
         int dst[SL];
 #pragma unroll
-        for (int I = 0; I < SL; I++) dst[I] = p.dest[(sl0 + (I < n_w ? I : 0)) * 64 + lane];      // (all loads first: one latency, not SL)
+        for (int I = 0; I < SL; I++) dst[I] = dest[(sl0 + (I < n_w ? I : 0)) * 64 + lane];      // (all loads first: one latency, not SL)
 #pragma unroll
         for (int I = 0; I < SL; I++) {
             if (I < n_w && dst[I] >= 0) {
@@ -223,10 +241,10 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
         }
     }
     __syncthreads();
-    if (p.n_long > 0) {
-        for (int t = tid; t < p.n_long * NC; t += kCrThreads) {
-            const int jj = t / p.n_long, q = t - jj * p.n_long;
-            const ColresLong lr = p.longs[q];
+    if (n_long > 0) {
+        for (int t = tid; t < n_long * NC; t += kCrThreads) {
+            const int jj = t / n_long, q = t - jj * n_long;
+            const ColresLong lr = longs[q];
             float* cell = lds + jj * P;
             float sum = cell[lr.row];
             const float* x = cell + lr.first;
@@ -244,11 +262,11 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
         __syncthreads();
     }
 
-    // ---- 4. staging image -> the NC columns of C, whole lines --------------------------------------------------------------------------------------
-    float* Cj = p.C + (int64_t)j0 * p.ldc;
+    // ---- 4. staging image -> the part's rows of the NC columns of C, whole lines ----------------------------------------------------------------------
+    float* Cj = p.C + (int64_t)j0 * p.ldc + part_r0;
     if (p.probe & 4) return;
     if (p.vec_out) {
-        const int r4 = p.rows >> 2;
+        const int r4 = part_rows >> 2;
         for (int jj = 0; jj < nc; jj++) {
             float* Cc = Cj + (int64_t)jj * p.ldc;
             const float* src = lds + jj * P;
@@ -257,13 +275,13 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
                 if (p.accumulate) x += *reinterpret_cast<const cr_f4*>(Cc + 4 * q);
                 *reinterpret_cast<cr_f4*>(Cc + 4 * q) = x;
             }
-            for (int r = 4 * r4 + tid; r < p.rows; r += kCrThreads) Cc[r] = p.accumulate ? Cc[r] + src[r] : src[r];
+            for (int r = 4 * r4 + tid; r < part_rows; r += kCrThreads) Cc[r] = p.accumulate ? Cc[r] + src[r] : src[r];
         }
     } else {
         for (int jj = 0; jj < nc; jj++) {
             float* Cc = Cj + (int64_t)jj * p.ldc;
             const float* src = lds + jj * P;
-            for (int r = tid; r < p.rows; r += kCrThreads) Cc[r] = p.accumulate ? Cc[r] + src[r] : src[r];
+            for (int r = tid; r < part_rows; r += kCrThreads) Cc[r] = p.accumulate ? Cc[r] + src[r] : src[r];
         }
     }
 }
@@ -276,7 +294,7 @@ int colres_launch(const ColresParams& p, size_t lds_bytes, hipStream_t st) {
         if (attr_rc != 0) return attr_rc;
     }
     const unsigned grid = (unsigned)((p.N + NC - 1) / NC);
-    hipLaunchKernelGGL((colres_kernel<NC, SL, UNIT>), dim3(grid), dim3(kCrThreads), lds_bytes, st, p);
+    hipLaunchKernelGGL((colres_kernel<NC, SL, UNIT>), dim3(grid, (unsigned)p.n_parts), dim3(kCrThreads), lds_bytes, st, p);
     return 0;
 }
 

@@ -95,6 +95,7 @@ void destroy_impl(sparta_vbs* v) {
     if (v->d_cr_col) (void)hipFree(v->d_cr_col);
     if (v->d_cr_val) (void)hipFree(v->d_cr_val);
     if (v->d_cr_meta) (void)hipFree(v->d_cr_meta);
+    if (v->d_cr_parts) (void)hipFree(v->d_cr_parts);
     if (v->d_cr_dest) (void)hipFree(v->d_cr_dest);
     if (v->d_cr_longs) (void)hipFree(v->d_cr_longs);
     if (v->d_Brm) (void)hipFree(v->d_Brm);
@@ -117,82 +118,158 @@ void destroy_impl(sparta_vbs* v) {
 // workgroup a slot of twice the average load per lane is not the critical path).
 constexpr int64_t kColresCells = 160 * 1024 / 4;                  // floats of LDS a workgroup may hold
 struct ColresHost {
-    std::vector<uint16_t> col;                                    // per batch of 4 steps and lane: four columns ...
+    std::vector<uint16_t> col;                                    // per batch of 4 steps and lane: four columns (relative to their K range) ...
     std::vector<float> val;                                       // ... and four values (empty: every stored value is 1.0f -- a unit image, the reference's -P 1)
-    std::vector<int32_t> woff, wslice, bnd, dest;
+    std::vector<ColresPartDev> parts;
+    std::vector<int32_t> meta, dest;                              // per part: see ColresPartDev
     std::vector<ColresLong> longs;
-    int32_t n_slices = 0, plane = 0, lmax = 0;
+    std::vector<int32_t> krange;                                  // [n_ranges + 1]
+    int32_t max_slices = 0, max_cells = 0, lmax = 0;              // slices of the part with most; cells a column set needs in LDS (largest range of B + its zero cell / largest staging image)
     int64_t entries = 0;
 };
 bool build_colres(int64_t rows, int64_t cols, const std::vector<int64_t>& rowptr, const std::vector<int32_t>& col, const std::vector<float>& val,
                   const std::vector<int32_t>& crow, ColresHost& H) {
     if (const char* e = std::getenv("SPARTA_COLRES")) if (atoi(e) == 0) return false;
     const int64_t n = (int64_t)crow.size(), nnz = rowptr.empty() ? 0 : rowptr.back();
-    if (n != rows || nnz == 0 || rows > kColresCells || cols > kColresCells - 4) return false;                // (columns fit 16 bits; one more LDS cell holds the zero the padding points at)
-    std::vector<uint8_t> seen((size_t)rows, 0);
+    if (n != rows || nnz == 0 || rows > kColresMaxParts * kColresCells || cols > kColresMaxRanges * (kColresCells - 8)) return false;
+    std::vector<int32_t> ord_of((size_t)rows, -1);                                    // sparse row of every row of C
     for (int64_t t = 0; t < n; t++) {
         const int32_t r = crow[(size_t)t];
-        if (r < 0 || r >= rows || seen[(size_t)r]) return false;                     // bit 31 (the row also has tiles), or not a permutation of the rows of C
-        seen[(size_t)r] = 1;
+        if (r < 0 || r >= rows || ord_of[(size_t)r] >= 0) return false;               // bit 31 (the row also has tiles), or not a permutation of the rows of C
+        ord_of[(size_t)r] = (int32_t)t;
     }
     int64_t lmax = std::max<int64_t>(32, nnz / 2048);
     if (const char* e = std::getenv("SPARTA_COLRES_LMAX")) lmax = std::max(1, atoi(e));
-    struct Slot { int64_t p0; int32_t len, dest; };
-    std::vector<Slot> slots;
-    slots.reserve((size_t)rows + (size_t)(nnz / lmax) + 1);
-    int64_t n_extra = 0;
-    for (int64_t t = 0; t < n; t++) {
-        const int64_t p0 = rowptr[(size_t)t], len = rowptr[(size_t)t + 1] - p0;
-        const int64_t chunks = std::max<int64_t>(1, (len + lmax - 1) / lmax);
-        if (chunks > 1) H.longs.push_back(ColresLong{crow[(size_t)t], (int32_t)n_extra, (int32_t)(chunks - 1), 0});      // `first` made absolute below
-        for (int64_t c = 0; c < chunks; c++) {
-            const int64_t o = c * lmax;
-            slots.push_back(Slot{p0 + o, (int32_t)std::min<int64_t>(lmax, len - o), c == 0 ? crow[(size_t)t] : (int32_t)(-2 - (n_extra + c - 1))});
+    constexpr int64_t kWaves = kColresWaves;
+    // ---- K ranges: the rows of B a workgroup holds at a time (+ the zero cell), equal, multiples of 4 ----
+    int64_t max_range = kColresCells - 8;
+    if (const char* e = std::getenv("SPARTA_COLRES_RANGE")) max_range = std::max<int64_t>(64, std::min<int64_t>(max_range, atoi(e)) / 4 * 4);      // (tests: small matrices in several ranges)
+    const int64_t n_ranges = (cols + max_range - 1) / max_range;
+    if (n_ranges > kColresMaxRanges) return false;
+    const int64_t range_len = ((cols + n_ranges - 1) / n_ranges + 3) / 4 * 4;
+    H.krange.assign((size_t)n_ranges + 1, 0);
+    for (int64_t r = 0; r <= n_ranges; r++) H.krange[(size_t)r] = (int32_t)std::min(cols, r * range_len);
+    // ---- parts: contiguous ranges of the rows of C whose staging image (rows + the extra cells of their chunked rows) fits ----
+    int64_t max_plane = kColresCells;
+    if (const char* e = std::getenv("SPARTA_COLRES_PLANE")) max_plane = std::max<int64_t>(64, std::min<int64_t>(max_plane, atoi(e)) / 4 * 4);
+    auto chunks_of = [&](int64_t r) { const int64_t t = ord_of[(size_t)r], len = rowptr[(size_t)t + 1] - rowptr[(size_t)t]; return std::max<int64_t>(1, (len + lmax - 1) / lmax); };
+    std::vector<int64_t> part_begin{0};
+    {
+        int64_t cells = 0;
+        for (int64_t r = 0; r < rows; r += 4) {                                       // (four rows at a time: every part starts at a multiple of 4 -- 16-byte stores of C)
+            int64_t add = 4;
+            for (int64_t q = r; q < std::min(rows, r + 4); q++) add += chunks_of(q) - 1;
+            if (add > max_plane) return false;
+            if (cells + add > max_plane) { part_begin.push_back(r); cells = 0; }
+            cells += add;
         }
-        n_extra += chunks - 1;
+        part_begin.push_back(rows);
     }
-    const int64_t rows_pad = (rows + 3) / 4 * 4, plane = (rows_pad + n_extra + 3) / 4 * 4;
-    if (plane > kColresCells || (int64_t)slots.size() > (int64_t)colres_max_slices(1) * 64) return false;
-    for (ColresLong& lr : H.longs) lr.first += (int32_t)rows_pad;
-    std::stable_sort(slots.begin(), slots.end(), [](const Slot& a, const Slot& b) { return a.len > b.len; });
-    const int64_t n_slices = ((int64_t)slots.size() + 63) / 64;
-    constexpr int64_t kWaves = kColresWaves;                                          // waves of a workgroup of k_colres.hip
-    // wave-major order: wave w owns the slices w, w + 16, ... of the sorted list (equally long streams), stored back to back
-    H.woff.assign(17, 0); H.wslice.assign(17, 0);                                       // (room for 16 waves: [kWaves] is what the kernel reads last)
-    H.bnd.assign((size_t)n_slices, 0);
-    H.dest.assign((size_t)n_slices * 64, -1);
+    const int64_t n_parts = (int64_t)part_begin.size() - 1;
+    if (n_parts > kColresMaxParts) return false;
+    // Several parts / ranges are built only on request (SPARTA_COLRES_CUTS=1; tested, bit-identical to the uncut image): measured on the reference's two larger real matrices at N = 8192
+    // they LOSE to the windowed row gather -- social_location (58 k x 58 k, 3.7 nonzeros per row: 2 parts x 2 ranges) 4.26 against 2.60 ms, ia-wikiquote (21.6 k x 94 k: 3 ranges) 3.25
+    // against 2.75: one column per workgroup (4-byte LDS reads, A streamed N times), and rows of 2-4 nonzeros spread over the ranges pad every slice to a batch per range (3.3 x the nonzeros).
+    {
+        const char* e = std::getenv("SPARTA_COLRES_CUTS");
+        if (n_parts * n_ranges > 1 && !(e && atoi(e) != 0)) return false;
+    }
     bool unit = true;
     for (int64_t k = 0; k < nnz && unit; k++) unit = val[(size_t)k] == 1.0f;
     if (const char* e = std::getenv("SPARTA_COLRES_UNIT")) unit = unit && atoi(e) != 0;      // (0: keep the value array of a pattern matrix -- developer A/B)
-    std::vector<int64_t> where((size_t)n_slices, 0), wdth((size_t)n_slices, 0), at_slice((size_t)n_slices, 0);      // per sorted slice: first batch, batches, wave-major index
-    int64_t total = 0, k_slice = 0;                               // batches
-    for (int64_t w = 0; w < kWaves; w++) {
-        H.woff[(size_t)w] = (int32_t)total; H.wslice[(size_t)w] = (int32_t)k_slice;
-        int64_t first = total;
-        for (int64_t s = w; s < n_slices; s += kWaves) {
-            const int64_t wb = std::max<int64_t>(1, ((int64_t)slots[(size_t)s * 64].len + 3) / 4);      // sorted: the first slot of a slice is its longest; never an empty slice
-            where[(size_t)s] = total; wdth[(size_t)s] = wb; at_slice[(size_t)s] = k_slice;
-            total += wb;
-            H.bnd[(size_t)k_slice++] = (int32_t)(total - first);
-            if (total * 256 > (int64_t)INT32_MAX / 2) return false;
+    struct Slot { int64_t p0; int32_t len, dest; };
+    int64_t total = 0;                                                                // batches so far (all parts, ranges, waves)
+    struct Fill { int64_t batch0; int32_t wb; };                                      // where a (sorted slice, range) starts and how wide it is
+    for (int64_t p = 0; p < n_parts; p++) {
+        const int64_t r0 = part_begin[(size_t)p], r1 = part_begin[(size_t)p + 1], prow = r1 - r0, rows_pad = (prow + 3) / 4 * 4;
+        std::vector<Slot> slots;
+        const size_t longs0 = H.longs.size();
+        int64_t n_extra = 0;
+        for (int64_t r = r0; r < r1; r++) {
+            const int64_t t = ord_of[(size_t)r], p0 = rowptr[(size_t)t], len = rowptr[(size_t)t + 1] - p0, chunks = chunks_of(r);
+            if (chunks > 1) H.longs.push_back(ColresLong{(int32_t)(r - r0), (int32_t)(rows_pad + n_extra), (int32_t)(chunks - 1), 0});
+            for (int64_t c = 0; c < chunks; c++) {
+                const int64_t o = c * lmax;
+                slots.push_back(Slot{p0 + o, (int32_t)std::max<int64_t>(0, std::min<int64_t>(lmax, len - o)), c == 0 ? (int32_t)(r - r0) : (int32_t)(rows_pad + n_extra + c - 1)});
+            }
+            n_extra += chunks - 1;
         }
+        const int64_t plane = (rows_pad + n_extra + 3) / 4 * 4;
+        if (plane > kColresCells || (int64_t)slots.size() > (int64_t)colres_max_slices(1) * 64) return false;
+        std::stable_sort(slots.begin(), slots.end(), [](const Slot& a, const Slot& b) { return a.len > b.len; });
+        const int64_t n_slices = ((int64_t)slots.size() + 63) / 64;
+        // where the entries of a slot fall into the K ranges
+        std::vector<int32_t> cut((size_t)slots.size() * (size_t)(n_ranges + 1), 0);
+        for (size_t q = 0; q < slots.size(); q++) {
+            const int32_t* c0 = col.data() + slots[q].p0;
+            for (int64_t r = 0; r <= n_ranges; r++)
+                cut[q * (size_t)(n_ranges + 1) + (size_t)r] = (int32_t)(std::lower_bound(c0, c0 + slots[q].len, H.krange[(size_t)r]) - c0);
+        }
+        ColresPartDev pd;
+        pd.r0 = (int32_t)r0; pd.rows = (int32_t)prow; pd.n_slices = (int32_t)n_slices; pd.n_long = (int32_t)(H.longs.size() - longs0); pd.plane = (int32_t)plane;
+        pd.meta = (int32_t)H.meta.size(); pd.dest = (int32_t)H.dest.size(); pd.longs = (int32_t)longs0;
+        const size_t m_wslice = H.meta.size(), m_woff = m_wslice + 17, m_bnd = m_woff + (size_t)n_ranges * 17;
+        H.meta.resize(m_bnd + (size_t)n_ranges * (size_t)n_slices, 0);
+        const size_t d0 = H.dest.size();
+        H.dest.resize(d0 + (size_t)n_slices * 64, -1);
+        // wave-major order: wave w owns the slices w, w + 16, ... of the sorted list (equally long streams)
+        std::vector<int64_t> at_slice((size_t)n_slices, 0);
+        {
+            int64_t k_slice = 0;
+            for (int64_t w = 0; w < kWaves; w++) {
+                H.meta[m_wslice + (size_t)w] = (int32_t)k_slice;
+                for (int64_t s = w; s < n_slices; s += kWaves) at_slice[(size_t)s] = k_slice++;
+            }
+            H.meta[m_wslice + (size_t)kWaves] = (int32_t)k_slice;
+        }
+        std::vector<Fill> fill((size_t)n_slices * (size_t)n_ranges);
+        for (int64_t r = 0; r < n_ranges; r++) {
+            for (int64_t w = 0; w < kWaves; w++) {
+                H.meta[m_woff + (size_t)r * 17 + (size_t)w] = (int32_t)total;
+                const int64_t first = total;
+                for (int64_t s = w; s < n_slices; s += kWaves) {
+                    int32_t longest = 0;
+                    for (size_t q = (size_t)s * 64; q < std::min(slots.size(), (size_t)s * 64 + 64); q++)
+                        longest = std::max(longest, cut[q * (size_t)(n_ranges + 1) + (size_t)r + 1] - cut[q * (size_t)(n_ranges + 1) + (size_t)r]);
+                    const int32_t wb = std::max(1, (longest + 3) / 4);                  // never an empty slice: the kernel parks a slice's sums behind its last batch
+                    fill[(size_t)s * (size_t)n_ranges + (size_t)r] = Fill{total, wb};
+                    total += wb;
+                    H.meta[m_bnd + (size_t)r * (size_t)n_slices + (size_t)at_slice[(size_t)s]] = (int32_t)(total - first);
+                    if (total * 256 > (int64_t)INT32_MAX / 2) return false;
+                }
+            }
+            H.meta[m_woff + (size_t)r * 17 + (size_t)kWaves] = (int32_t)total;
+        }
+        // the entries.  Past a slot's end in a range: the range's length -- one more cell of LDS, which the kernel clears -- with the value 0.0f: no per-lane condition, and nothing of B
+        // is multiplied by a padding zero
+        H.col.resize((size_t)(total + 1) * 256, 0);                                     // (+ one batch: a wave without slices still reads the first line of its empty stream)
+        if (!unit) H.val.resize((size_t)(total + 1) * 256, 0.0f);
+        for (int64_t s = 0; s < n_slices; s++) {
+            for (int64_t r = 0; r < n_ranges; r++) {
+                const Fill f = fill[(size_t)s * (size_t)n_ranges + (size_t)r];
+                const uint16_t pad = (uint16_t)(H.krange[(size_t)r + 1] - H.krange[(size_t)r]);
+                for (size_t x = (size_t)f.batch0 * 256; x < (size_t)(f.batch0 + f.wb) * 256; x++) H.col[x] = pad;
+                for (int64_t l = 0; l < 64; l++) {
+                    const size_t q = (size_t)s * 64 + (size_t)l;
+                    if (q >= slots.size()) continue;
+                    const int32_t b = cut[q * (size_t)(n_ranges + 1) + (size_t)r], e = cut[q * (size_t)(n_ranges + 1) + (size_t)r + 1];
+                    for (int32_t k = b; k < e; k++) {
+                        const size_t at = ((size_t)(f.batch0 + (k - b) / 4) * 64 + (size_t)l) * 4 + (size_t)((k - b) % 4);
+                        H.col[at] = (uint16_t)(col[(size_t)(slots[q].p0 + k)] - H.krange[(size_t)r]);
+                        if (!unit) H.val[at] = val[(size_t)(slots[q].p0 + k)];
+                    }
+                }
+            }
+        }
+        for (size_t q = 0; q < slots.size(); q++) H.dest[d0 + (size_t)at_slice[q / 64] * 64 + q % 64] = slots[q].dest;
+        H.parts.push_back(pd);
+        H.max_slices = std::max(H.max_slices, (int32_t)n_slices);
+        H.max_cells = std::max(H.max_cells, (int32_t)plane);
     }
-    H.woff[(size_t)kWaves] = (int32_t)total; H.wslice[(size_t)kWaves] = (int32_t)k_slice;
-    // past a slot's end: the column `cols` -- one more cell of LDS, which the kernel clears -- with the value 0.0f: no per-lane condition, and nothing of B is multiplied by a padding zero
-    H.col.assign((size_t)(total + 1) * 256, (uint16_t)cols);                            // + one batch: a wave without slices still reads the first line of its (empty) stream
-    if (!unit) H.val.assign((size_t)(total + 1) * 256, 0.0f);
+    for (size_t x = (size_t)total * 256; x < H.col.size(); x++) H.col[x] = (uint16_t)(H.krange[1] - H.krange[0]);
+    H.max_cells = std::max(H.max_cells, (int32_t)((range_len + 4) / 4 * 4));
     H.entries = total * 256;
-    for (int64_t q = 0; q < (int64_t)slots.size(); q++) {
-        const Slot& sl = slots[(size_t)q];
-        const int64_t s = q / 64, l = q % 64;
-        H.dest[(size_t)(at_slice[(size_t)s] * 64 + l)] = sl.dest >= 0 ? sl.dest : (int32_t)(rows_pad + (-2 - sl.dest));
-        for (int64_t k = 0; k < sl.len; k++) {
-            const size_t at = ((size_t)(where[(size_t)s] + k / 4) * 64 + (size_t)l) * 4 + (size_t)(k % 4);
-            H.col[at] = (uint16_t)col[(size_t)(sl.p0 + k)];
-            if (!unit) H.val[at] = val[(size_t)(sl.p0 + k)];
-        }
-    }
-    H.n_slices = (int32_t)n_slices; H.plane = (int32_t)plane; H.lmax = (int32_t)lmax;
+    H.lmax = (int32_t)lmax;
     return true;
 }
 // columns of B per workgroup: as many as LDS holds next to each other (columns of B first, the staging image of C after them, in the same cells)
@@ -200,12 +277,13 @@ bool build_colres(int64_t rows, int64_t cols, const std::vector<int64_t>& rowptr
 // per workgroup whatever NC (measured): fewer passes win.  SPARTA_COLRES_NC caps it (read per call: developer A/B, tests).
 int colres_columns(const sparta_vbs_t* A, int n_cols) {
     if (A->cr_slices == 0) return 0;
-    const int64_t span = (A->cols + 4) / 4 * 4, cells = std::max<int64_t>(span, A->cr_plane);           // (+ the zero cell behind the last row of B)
-    int nc = (int)std::min<int64_t>(std::min<int64_t>(4, kColresCells / cells), n_cols);
+    const int64_t cells = A->cr_plane;                             // what a column set needs in LDS: the largest range of B (+ its zero cell) or the largest staging image
+    const int fit = (int)std::min<int64_t>(std::min<int64_t>(4, kColresCells / cells), n_cols);
+    int nc = fit;
     // (a product of fewer workgroups than CUs is ONE round whatever NC: the stream of A with three or four columns per cell costs twice the LDS time of one or two --
     // bcsstk18 at N = 128: 16.5 / 14.7 / 17.9 us with 1 / 2 / 3 columns)
-    if (nc > 2 && (n_cols + nc - 1) / nc <= 256) nc = 2;
-    if (const char* e = std::getenv("SPARTA_COLRES_NC")) nc = std::min((int)std::min<int64_t>(std::min<int64_t>(4, kColresCells / cells), n_cols), std::max(1, atoi(e)));
+    if (nc > 2 && (int64_t)((n_cols + nc - 1) / nc) * A->cr_parts <= 256) nc = 2;
+    if (const char* e = std::getenv("SPARTA_COLRES_NC")) nc = std::min(fit, std::max(1, atoi(e)));
     while (nc > 1 && A->cr_slices > colres_max_slices(nc)) nc--;
     return nc >= 1 && A->cr_slices <= colres_max_slices(nc) ? nc : 0;
 }
@@ -761,18 +839,19 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
                 CREATE_TRY(hipMalloc(&v->d_cr_val, H.val.size() * sizeof(float)));
                 CREATE_TRY(hipMemcpy(v->d_cr_val, H.val.data(), H.val.size() * sizeof(float), hipMemcpyHostToDevice));
             }
-            std::vector<int32_t> meta(H.woff);
-            meta.insert(meta.end(), H.wslice.begin(), H.wslice.end());
-            meta.insert(meta.end(), H.bnd.begin(), H.bnd.end());
-            CREATE_TRY(hipMalloc((void**)&v->d_cr_meta, meta.size() * sizeof(int32_t)));
-            CREATE_TRY(hipMemcpy(v->d_cr_meta, meta.data(), meta.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc((void**)&v->d_cr_meta, H.meta.size() * sizeof(int32_t)));
+            CREATE_TRY(hipMemcpy(v->d_cr_meta, H.meta.data(), H.meta.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc(&v->d_cr_parts, H.parts.size() * sizeof(ColresPartDev)));
+            CREATE_TRY(hipMemcpy(v->d_cr_parts, H.parts.data(), H.parts.size() * sizeof(ColresPartDev), hipMemcpyHostToDevice));
             CREATE_TRY(hipMalloc((void**)&v->d_cr_dest, H.dest.size() * sizeof(int32_t)));
             CREATE_TRY(hipMemcpy(v->d_cr_dest, H.dest.data(), H.dest.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             if (!H.longs.empty()) {
                 CREATE_TRY(hipMalloc(&v->d_cr_longs, H.longs.size() * sizeof(ColresLong)));
                 CREATE_TRY(hipMemcpy(v->d_cr_longs, H.longs.data(), H.longs.size() * sizeof(ColresLong), hipMemcpyHostToDevice));
             }
-            v->cr_slices = H.n_slices; v->cr_long = (int32_t)H.longs.size(); v->cr_plane = H.plane; v->cr_lmax = H.lmax;
+            v->cr_slices = H.max_slices; v->cr_long = (int32_t)H.longs.size(); v->cr_plane = H.max_cells; v->cr_lmax = H.lmax;
+            v->cr_parts = (int32_t)H.parts.size(); v->cr_ranges = (int32_t)H.krange.size() - 1;
+            for (size_t r = 0; r < H.krange.size(); r++) v->cr_krange[r] = H.krange[r];
             v->cr_entries = H.entries;
             v->a_bytes += (int64_t)(H.col.size() * sizeof(uint16_t) + H.val.size() * sizeof(float));
             v->cr_unit = H.val.empty();
@@ -970,35 +1049,53 @@ int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, 
     std::vector<float> va(vals, vals + rowptr[rows]);
     for (int64_t i = 0; i < rows; i++) cr[(size_t)i] = crow ? (int32_t)crow[i] : (int32_t)i;
     ColresHost H;
-    for (int k = 0; k < 8; k++) info[k] = 0;
+    for (int k = 0; k < 10; k++) info[k] = 0;
     if (!build_colres(rows, cols, rp, ci, va, cr, H)) return SPARTA_OK;                 // info[0] = 0: this matrix gets no image
-    std::vector<float> cell((size_t)H.plane, 0.0f);
-    for (int w = 0; w < kColresWaves; w++) {
-        for (int32_t i = H.wslice[(size_t)w]; i < H.wslice[(size_t)w + 1]; i++) {
-            const int32_t t0 = i == H.wslice[(size_t)w] ? 0 : H.bnd[(size_t)i - 1], t1 = H.bnd[(size_t)i];      // batches of 4 steps
-            for (int l = 0; l < 64; l++) {
-                float acc = 0.0f;
-                for (int32_t t = t0; t < t1; t++) {
-                    for (int u = 0; u < 4; u++) {
-                        const size_t at = ((size_t)(H.woff[(size_t)w] + t) * 64 + (size_t)l) * 4 + (size_t)u;
-                        const int64_t c = H.col[at];
-                        if (c > cols) return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: column out of range in the image");
-                        const float b = c == cols ? 0.0f : x[c];                       // the zero cell behind the last row of B
-                        acc = H.val.empty() ? acc + b : std::fma(H.val[at], b, acc);
+    const int n_ranges = (int)H.krange.size() - 1;
+    for (const ColresPartDev& pd : H.parts) {
+        const int32_t* wslice = H.meta.data() + pd.meta;
+        const int32_t* woff = wslice + 17;
+        const int32_t* bnd = woff + (size_t)n_ranges * 17;
+        std::vector<float> acc((size_t)pd.n_slices * 64, 0.0f), cell((size_t)pd.plane, 0.0f);
+        for (int r = 0; r < n_ranges; r++) {                                          // the sums of a slot carry over from range to range, as the kernel's registers do
+            const int64_t k0 = H.krange[(size_t)r], klen = H.krange[(size_t)r + 1] - k0;
+            for (int w = 0; w < kColresWaves; w++) {
+                for (int32_t i = wslice[w]; i < wslice[w + 1]; i++) {
+                    const int32_t t0 = i == wslice[w] ? 0 : bnd[(size_t)r * pd.n_slices + i - 1], t1 = bnd[(size_t)r * pd.n_slices + i];      // batches of 4 steps
+                    if (t1 <= t0) return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: an empty slice in the image");
+                    for (int l = 0; l < 64; l++) {
+                        float a = acc[(size_t)i * 64 + (size_t)l];
+                        for (int32_t t = t0; t < t1; t++) {
+                            for (int u = 0; u < 4; u++) {
+                                const size_t at = ((size_t)(woff[(size_t)r * 17 + w] + t) * 64 + (size_t)l) * 4 + (size_t)u;
+                                const int64_t c = H.col[at];
+                                if (c > klen) return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: column out of range in the image");
+                                const float b = c == klen ? 0.0f : x[k0 + c];           // the zero cell behind the range's last row of B
+                                a = H.val.empty() ? a + b : std::fma(H.val[at], b, a);
+                            }
+                        }
+                        acc[(size_t)i * 64 + (size_t)l] = a;
                     }
                 }
-                const int32_t d = H.dest[(size_t)i * 64 + (size_t)l];
-                if (d >= H.plane) return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: cell out of range in the image");
-                if (d >= 0) cell[(size_t)d] = acc;
+                if (wslice[w + 1] > wslice[w] && (int64_t)bnd[(size_t)r * pd.n_slices + wslice[w + 1] - 1] != (int64_t)woff[(size_t)r * 17 + w + 1] - woff[(size_t)r * 17 + w])
+                    return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: a wave's stream and its slice boundaries disagree");
             }
         }
-        if (H.bnd.size() && H.wslice[(size_t)w + 1] > H.wslice[(size_t)w] &&
-            (int64_t)H.bnd[(size_t)H.wslice[(size_t)w + 1] - 1] != (int64_t)H.woff[(size_t)w + 1] - H.woff[(size_t)w])
-            return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: a wave's stream and its slice boundaries disagree");
+        for (int32_t q = 0; q < pd.n_slices * 64; q++) {
+            const int32_t d = H.dest[(size_t)pd.dest + (size_t)q];
+            if (d >= pd.plane) return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: cell out of range in the image");
+            if (d >= 0) cell[(size_t)d] = acc[(size_t)q];
+        }
+        for (int32_t q = 0; q < pd.n_long; q++) {
+            const ColresLong& lr = H.longs[(size_t)pd.longs + (size_t)q];
+            float sum = cell[(size_t)lr.row];
+            for (int32_t i = 0; i < lr.n; i++) sum += cell[(size_t)lr.first + (size_t)i];
+            cell[(size_t)lr.row] = sum;
+        }
+        for (int32_t i = 0; i < pd.rows; i++) y[pd.r0 + i] = cell[(size_t)i];
     }
-    for (const ColresLong& lr : H.longs) { float sum = cell[(size_t)lr.row]; for (int32_t i = 0; i < lr.n; i++) sum += cell[(size_t)lr.first + (size_t)i]; cell[(size_t)lr.row] = sum; }
-    for (int64_t i = 0; i < rows; i++) y[i] = cell[(size_t)i];
-    info[0] = H.n_slices; info[1] = H.entries; info[2] = (int64_t)H.longs.size(); info[3] = H.plane; info[4] = H.lmax; info[6] = rp.back(); info[7] = H.val.empty() ? 1 : 0;
+    info[0] = H.max_slices; info[1] = H.entries; info[2] = (int64_t)H.longs.size(); info[3] = H.max_cells; info[4] = H.lmax; info[6] = rp.back(); info[7] = H.val.empty() ? 1 : 0;
+    info[8] = (int64_t)H.parts.size(); info[9] = n_ranges;
     return SPARTA_OK;
     SPARTA_GUARD_END("sparta_colres_host_check")
 }
@@ -1006,7 +1103,7 @@ int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, 
 int sparta_vbs_colres_info(const sparta_vbs_t* A, int64_t* info) {
     if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_colres_info: NULL argument");
     info[0] = A->cr_slices; info[1] = A->cr_entries; info[2] = A->cr_long; info[3] = A->cr_plane; info[4] = A->cr_lmax; info[5] = A->last_colres_nc;
-    info[6] = A->cr_slices > 0 ? A->sp_nnz : 0; info[7] = A->cr_slices > 0 && A->cr_unit ? 1 : 0;
+    info[6] = A->cr_slices > 0 ? A->sp_nnz : 0; info[7] = A->cr_slices > 0 && A->cr_unit ? 1 : 0; info[8] = A->cr_parts; info[9] = A->cr_ranges;
     return SPARTA_OK;
 }
 
@@ -1124,15 +1221,15 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
         const int nc = colres_columns(A, n_cols);
         if (nc > 0) {
             ColresParams cp;
-            cp.col4 = (const uint2*)A->d_cr_col; cp.val4 = (const float4*)A->d_cr_val; cp.woff = A->d_cr_meta; cp.wslice = A->d_cr_meta + 17; cp.bnd = A->d_cr_meta + 34; cp.dest = A->d_cr_dest; cp.longs = (const ColresLong*)A->d_cr_longs;
+            cp.col4 = (const uint2*)A->d_cr_col; cp.val4 = (const float4*)A->d_cr_val; cp.parts = (const ColresPartDev*)A->d_cr_parts; cp.meta = A->d_cr_meta;
+            cp.dest = A->d_cr_dest; cp.longs = (const ColresLong*)A->d_cr_longs;
             cp.B = (const float*)dB; cp.ldb = ldb; cp.C = dC; cp.ldc = ldc;
-            cp.n_slices = A->cr_slices; cp.n_long = A->cr_long; cp.rows = (int32_t)A->rows; cp.cols = (int32_t)A->cols; cp.N = n_cols; cp.accumulate = accumulate ? 1 : 0;
+            for (int r = 0; r <= kColresMaxRanges; r++) cp.krange[r] = A->cr_krange[r];
+            cp.n_parts = A->cr_parts; cp.n_ranges = A->cr_ranges; cp.N = n_cols; cp.accumulate = accumulate ? 1 : 0;
             cp.vec_out = ldc % 4 == 0 && ((uintptr_t)dC % 16) == 0 ? 1 : 0;
             cp.vec_in = ldb % 4 == 0 && ((uintptr_t)dB % 16) == 0 ? 1 : 0;
-            cp.plane = A->cr_plane;
             cp.probe = [] { const char* e = std::getenv("SPARTA_COLRES_PROBE"); return e ? atoi(e) : 0; }();        // (read per call: developer A/B)
-            const int64_t span = (A->cols + 4) / 4 * 4;
-            const size_t lds_bytes = (size_t)std::max<int64_t>(span, A->cr_plane) * (size_t)nc * sizeof(float);
+            const size_t lds_bytes = (size_t)A->cr_plane * (size_t)nc * sizeof(float);
             {
                 static const int n_cus = [] { hipDeviceProp_t pr; return hipGetDeviceProperties(&pr, 0) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }();
                 cp.n_cus = n_cus;
@@ -1146,7 +1243,7 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
                 const char* eg = std::getenv("SPARTA_COLRES_GROUPS");
                 cp.share = eg ? std::max(1, atoi(eg)) : 3;
                 const double stagger = e ? atof(e) * 1e-6 : t_wg / 4.0;
-                cp.stagger_ticks = cp.share > 1 && (int64_t)((n_cols + nc - 1) / nc) > 2 * (int64_t)n_cus ? (int32_t)std::min(stagger * 1e8, 1.0e5) : 0;
+                cp.stagger_ticks = cp.share > 1 && (int64_t)((n_cols + nc - 1) / nc) * A->cr_parts > 2 * (int64_t)n_cus ? (int32_t)std::min(stagger * 1e8, 1.0e5) : 0;
             }
             if (int hrc = launch_colres(nc, cp, lds_bytes, st)) return sparta::fail(SPARTA_ERR_HIP, "sparta_vbs_spmm: the resident-column kernel could not be launched (hipError_t " + std::to_string(hrc) + ")");
             HIP_TRY(hipGetLastError());

@@ -166,24 +166,36 @@ struct SparseParams {
 // resident-column product (k_colres.hip): A as slots (rows, the long ones cut into chunks) sorted by length, 64 to a slice, entry k of a slice's slots contiguous
 constexpr int kColresWaves = 16;        // waves of a workgroup of k_colres.hip (host layout and kernel agree on it)
 struct ColresLong { int32_t row, first, n, pad; };   // a row cut into chunks: its cell in the staging image, the first of its extra cells, how many
+// A matrix whose columns of B or of C do not fit LDS whole is cut: the rows of C into PARTS (a workgroup owns NC columns of one part: grid y), the columns of A into K RANGES (a workgroup
+// walks them one after the other, its sums staying in registers: the rows of B of a range in LDS at a time).
+constexpr int kColresMaxParts = 4, kColresMaxRanges = 4;
+struct ColresPartDev {
+    int32_t r0, rows;          // the part's rows of C: [r0, r0 + rows), r0 a multiple of 4
+    int32_t n_slices, n_long;
+    int32_t plane;             // cells per column of the staging image (rows + extra cells, a multiple of 4)
+    int32_t meta;              // offset (int32) of the part's block in `meta`: wslice[17], woff[n_ranges][17], bnd[n_ranges][n_slices]
+    int32_t dest;              // offset (int32) of its dest[64 n_slices] in `dest`
+    int32_t longs;             // offset (records) of its list in `longs`
+};
 struct ColresParams {
-    // The slices of wave w (w, w + 16, ... of the length-sorted list; widths multiples of 4 steps) back to back, in batches of 4 steps: batch t of wave w, lane l at (woff[w] + t) * 64 + l;
-    // a slot shorter than its slice ends in (a column of its row, 0.0f) -- (the row's column, whatever value) where every value is 1.0f ... see build_colres
+    // Per part and K range: the slices of wave w (w, w + 16, ... of the part's length-sorted slots; per range a multiple of 4 steps wide, at least 4) back to back, in batches of 4 steps:
+    // batch t of wave w, lane l at (woff[range][w] + t) * 64 + l.  Columns are relative to the range's first; a slot shorter than its slice (in that range) ends in (the range's length, 0.0f):
+    // the cell behind the range's last row of B in LDS, which the kernel clears.
     const uint2* col4;         // four 16-bit columns per batch and lane
-    const float4* val4;        // four values per batch and lane; nullptr: every stored value is 1.0f AND no slot is padded inside a slice with a nonzero (unit image)
-    const int32_t* woff;       // [17] in batches
-    const int32_t* wslice;     // [17] first slice of every wave in the wave-major order of bnd / dest
-    const int32_t* bnd;        // [n_slices] the batch of its wave's stream behind the slice's last one
-    const int32_t* dest;       // [64 n_slices] (wave-major) cell of the staging image the slot's sum goes to (row of C, or an extra cell >= rows); -1: padding slot
+    const float4* val4;        // four values per batch and lane; nullptr: every stored value is 1.0f (unit image)
+    const ColresPartDev* parts;
+    const int32_t* meta;       // per part: wslice[17] (first slice of every wave in the wave-major order of bnd / dest), woff[range][17] (batches), bnd[range][slice] (the batch of
+                               // its wave's stream of that range behind the slice's last one)
+    const int32_t* dest;       // per part [64 n_slices] (wave-major): cell of the staging image the slot's sum goes to (row of C - r0, or an extra cell >= rows); -1: padding slot
     const ColresLong* longs;
     const float* B;            // column-major, ld = ldb
     int64_t ldb;
     float* C;                  // column-major, ld = ldc
     int64_t ldc;
-    int32_t n_slices, n_long, rows, cols, N, accumulate, vec_out, vec_in;
-    int32_t plane;             // cells per column of the staging image (rows + extra cells, a multiple of 4)
-    int32_t n_cus, share, stagger_ticks;      // CUs of the device, workgroups that share one (LDS), and the start offset between them in 10 ns ticks (0: none) -- see the kernel
-    int32_t probe;             // developer probe (SPARTA_COLRES_PROBE, wrong products): 1 skip the loads of B, 2 skip the stream of A, 4 skip the stores of C, 8 conflict-free LDS addresses, 16 no loads of A
+    int32_t krange[kColresMaxRanges + 1];      // first column of every K range (multiples of 4), then cols
+    int32_t n_parts, n_ranges, N, accumulate, vec_out, vec_in;
+    int32_t n_cus, share, stagger_ticks;      // CUs of the device, groups the CUs of the first dispatch round start in, and the offset between the groups in 10 ns ticks (0: none) -- see the kernel
+    int32_t probe;             // developer probe (SPARTA_COLRES_PROBE, wrong products): 1 skip the loads of B, 2 skip the stream of A, 4 skip the stores of C
 };
 
 struct SpSegRec { int64_t p0; int32_t cnt, pad; };
@@ -300,7 +312,10 @@ struct sparta_vbs {
     int32_t* d_cr_meta = nullptr;          // woff[17], wslice[17], bnd[n_slices]
     int32_t* d_cr_dest = nullptr;
     void* d_cr_longs = nullptr;
-    int32_t cr_slices = 0, cr_long = 0, cr_plane = 0, cr_lmax = 0;
+    int32_t cr_slices = 0, cr_long = 0, cr_plane = 0, cr_lmax = 0;       // slices of the part with most; rows cut into chunks; cells of the largest staging image / range of B; longest slot
+    int32_t cr_parts = 0, cr_ranges = 0, cr_span = 0;
+    int32_t cr_krange[sparta_dev::kColresMaxRanges + 1] = {0, 0, 0, 0, 0};
+    void* d_cr_parts = nullptr;
     bool cr_unit = false;                  // every value 1.0f: no value array
     int64_t cr_entries = 0;                // stored entries, padding included
     int last_colres_nc = 0;                // columns per workgroup of the last product on this path (0: the product took another path)

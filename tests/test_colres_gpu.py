@@ -171,6 +171,61 @@ def test_unit_image_of_a_pattern_matrix(monkeypatch):
     d.close(); d2.close()
 
 
+@pytest.mark.parametrize("rng_cols,plane_cells", [(2048, 0), (0, 2048), (1500, 2500)])
+def test_parts_of_rows_and_k_ranges_give_the_bits_of_the_whole_image(monkeypatch, rng_cols, plane_cells):
+    """columns of B / of C that do not fit LDS whole: K ranges walked one after the other with the sums in registers, parts of the rows of C on grid y.  Forced on a small
+    matrix (SPARTA_COLRES_RANGE / SPARTA_COLRES_PLANE): the same additions in the same order as the uncut image -- the same bits -- and float64 within the tolerance"""
+    torch = _torch()
+    A = _matrix(6100, 5900, 0.003, 3, 51, empty_every=13)
+    d0, perm = _handle(A)
+    assert (d0.colres_info()["parts"], d0.colres_info()["ranges"]) == (1, 1)
+    monkeypatch.setenv("SPARTA_COLRES_CUTS", "1")
+    if rng_cols:
+        monkeypatch.setenv("SPARTA_COLRES_RANGE", str(rng_cols))
+    if plane_cells:
+        monkeypatch.setenv("SPARTA_COLRES_PLANE", str(plane_cells))
+    d, _ = _handle(A)
+    info = d.colres_info()
+    assert info["ranges"] == (-(-5900 // rng_cols) if rng_cols else 1) and info["parts"] >= (2 if plane_cells else 1)
+    for n, ldb, ldc in ((7, 5900, 6100), (64, 5904, 6104), (130, 5901, 6101)):
+        B = sa.gen.dense_rhs(5900, n, seed=n)
+        C0 = sa.gen.dense_rhs(6100, n, seed=n + 1)
+        want, bound = _want(A, perm, B, n, C0)
+        got = _product(torch, d, B, n, ldb=ldb, ldc=ldc, C0=C0)
+        assert d.colres_info()["nc"] >= 1
+        assert np.all(np.abs(got - want) <= TOL * bound + 1e-30)
+        assert np.array_equal(got, _product(torch, d0, B, n, ldb=ldb, ldc=ldc, C0=C0)), "the cut image adds in another order"
+    d.close(); d0.close()
+
+
+@pytest.mark.parametrize("name", ["social_location.el", "ia-wikiquote-user-edits-nodup.el"])
+def test_the_two_larger_real_matrices_in_parts_and_ranges(monkeypatch, name):
+    """58 k x 58 k and 21.6 k x 94 k: two parts x two ranges / one part x three ranges, one launch; the reference's fixed-grid arm against float64 (on request only,
+    SPARTA_COLRES_CUTS=1: measured slower than the row gather on exactly these two)"""
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_COLRES_CUTS", "1")
+    m0 = sa.CSR.read_from_edgelist(os.path.join(HERE, "golden", "ref_data", "minitest", name), pattern_only=True)
+    r = np.repeat(np.arange(m0.rows), np.diff(m0.rowptr))
+    key = np.unique(r.astype(np.int64) * m0.cols + m0.colidx)
+    rp = np.concatenate([[0], np.cumsum(np.bincount(key // m0.cols, minlength=m0.rows))])
+    m = sa.CSR(m0.rows, m0.cols, rp, (key % m0.cols).astype(np.int32), None)
+    g = np.arange(m.rows, dtype=np.int64) // 64
+    d = sa.DeviceVBS.from_csr(m, g, 64, 64, True, device=0)
+    info = d.colres_info()
+    assert info["slices"] > 0 and info["parts"] * info["ranges"] > 1 and info["unit"] == 1
+    A = sp.csr_matrix((np.ones(len(key), np.float32), m.colidx, m.rowptr), shape=(m.rows, d.cols))
+    perm = np.asarray(sa.get_permutation(g), np.int64)
+    n = 256
+    B = sa.gen.dense_rhs(d.cols, n, seed=8)
+    want, bound = _want(A, perm, B, n)
+    got = _product(torch, d, B, n).reshape(n, d.rows)
+    assert d.colres_info()["nc"] >= 1
+    assert np.all(got[:, m.rows:] == 0.0)
+    got = np.ascontiguousarray(got[:, :m.rows]).reshape(-1)
+    assert np.all(np.abs(got - want) <= TOL * bound + 1e-30)
+    d.close()
+
+
 def test_prepared_b_is_read_where_it_lies():
     """sparta_vbs_prepare_b makes no row-major copy for a handle the resident-column kernel carries; the prepared product is the plain one"""
     import ctypes as C

@@ -16,11 +16,11 @@ _i64p, _i32p, _f32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_
 def _walk(A, x, crow=None):
     rows, cols = A.shape
     rp, ci, va = A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.float32)
-    y, info = np.full(rows, 7.0, np.float32), np.zeros(8, np.int64)
+    y, info = np.full(rows, 7.0, np.float32), np.zeros(10, np.int64)
     cr = None if crow is None else np.ascontiguousarray(crow, np.int64)
     check(lib.sparta_colres_host_check(rows, cols, rp.ctypes.data_as(_i64p), ci.ctypes.data_as(_i32p), va.ctypes.data_as(_f32p),
                                        None if cr is None else cr.ctypes.data_as(_i64p), x.ctypes.data_as(_f32p), y.ctypes.data_as(_f32p), info.ctypes.data_as(_i64p)))
-    keys = ["slices", "entries", "long_rows", "plane", "lmax", "nc", "nnz", "unit"]
+    keys = ["slices", "entries", "long_rows", "plane", "lmax", "nc", "nnz", "unit", "parts", "ranges"]
     return y, {k: int(info[i]) for i, k in enumerate(keys)}
 
 
@@ -103,10 +103,20 @@ def test_a_long_row_is_cut_and_its_chunks_added_in_order(monkeypatch):
 
 def test_no_image_for_matrices_the_kernel_cannot_hold(monkeypatch):
     x = np.ones(100, np.float32)
-    y, info = _walk(_matrix(41000, 100, 0.01, 0, 1), x)                   # a column of C does not fit LDS
+    y, info = _walk(_matrix(41000, 100, 0.01, 0, 1), x)                   # a column of C does not fit LDS whole
     assert info["slices"] == 0 and np.all(y == 7.0)
-    y, info = _walk(_matrix(100, 41000, 0.01, 0, 1), np.ones(41000, np.float32))
+    y, info = _walk(_matrix(100, 41000, 0.01, 0, 1), np.ones(41000, np.float32))      # nor does a column of B
     assert info["slices"] == 0
+    monkeypatch.setenv("SPARTA_COLRES_CUTS", "1")                         # on request: parts of the rows of C, K ranges of the columns of A (up to 4 x 4)
+    y, info = _walk(_matrix(41000, 100, 0.01, 0, 1), x)
+    assert info["slices"] > 0 and info["parts"] == 2 and info["ranges"] == 1
+    y, info = _walk(_matrix(100, 41000, 0.01, 0, 1), np.ones(41000, np.float32))
+    assert info["slices"] > 0 and info["parts"] == 1 and info["ranges"] == 2
+    y, info = _walk(_matrix(170000, 100, 0.002, 0, 1), x)
+    assert info["slices"] == 0
+    y, info = _walk(_matrix(100, 170000, 0.002, 0, 1), np.ones(170000, np.float32))
+    assert info["slices"] == 0
+    monkeypatch.delenv("SPARTA_COLRES_CUTS")
     monkeypatch.setenv("SPARTA_COLRES", "0")
     y, info = _walk(_matrix(100, 100, 0.1, 0, 1), x)
     assert info["slices"] == 0
@@ -135,3 +145,44 @@ def test_pattern_matrices_get_a_unit_image(monkeypatch):
     y3, _ = _walk(A, x2)
     touched = np.asarray((A[:, 7] != 0).todense()).reshape(-1)
     assert np.all(np.isfinite(y3[~touched])) and np.all(np.isinf(y3[touched]))
+
+
+@pytest.mark.parametrize("rng_cols,plane_cells", [(512, 0), (0, 1024), (700, 900), (512, 1000)])
+def test_parts_of_rows_and_k_ranges(monkeypatch, rng_cols, plane_cells):
+    """a matrix whose columns of B / of C do not fit LDS whole: the columns of A in K ranges (a slot's sum carries over from range to range), the rows of C in parts;
+    SPARTA_COLRES_RANGE / SPARTA_COLRES_PLANE force the cuts on a small matrix.  Same sums in the same order as the uncut image: the same bits."""
+    A = _matrix(2100, 1900, 0.01, 3, 41, empty_every=13)
+    x = np.random.default_rng(8).standard_normal(1900).astype(np.float32)
+    crow = np.random.default_rng(9).permutation(2100)
+    y0, info0 = _walk(A, x, crow)
+    assert info0["parts"] == 1 and info0["ranges"] == 1
+    monkeypatch.setenv("SPARTA_COLRES_CUTS", "1")
+    if rng_cols:
+        monkeypatch.setenv("SPARTA_COLRES_RANGE", str(rng_cols))
+    if plane_cells:
+        monkeypatch.setenv("SPARTA_COLRES_PLANE", str(plane_cells))
+    y, info = _walk(A, x, crow)
+    assert info["slices"] > 0
+    assert info["ranges"] == (-(-1900 // rng_cols) if rng_cols else 1)
+    assert info["parts"] >= (2 if plane_cells else 1)
+    assert np.array_equal(y, y0)
+
+
+def test_the_two_larger_real_matrices_get_an_image_in_parts_and_ranges(monkeypatch):
+    """(on request only: measured slower than the row gather on exactly these two -- vbs_capi.cpp, build_colres)"""
+    import os
+    monkeypatch.setenv("SPARTA_COLRES_CUTS", "1")
+    import sparta_amd as sa
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name, parts, ranges in (("social_location.el", 2, 2), ("ia-wikiquote-user-edits-nodup.el", 1, 3)):
+        m0 = sa.CSR.read_from_edgelist(os.path.join(here, "golden", "ref_data", "minitest", name), pattern_only=True)
+        r = np.repeat(np.arange(m0.rows), np.diff(m0.rowptr))
+        key = np.unique(r.astype(np.int64) * m0.cols + m0.colidx)
+        A = sp.csr_matrix((np.ones(len(key), np.float32), (key % m0.cols).astype(np.int32), np.concatenate([[0], np.cumsum(np.bincount(key // m0.cols, minlength=m0.rows))])),
+                          shape=(m0.rows, m0.cols))
+        x = np.random.default_rng(3).standard_normal(m0.cols).astype(np.float32)
+        y, info = _walk(A, x)
+        assert (info["parts"], info["ranges"], info["unit"]) == (parts, ranges, 1), info
+        ref = A.astype(np.float64) @ x.astype(np.float64)
+        bound = abs(A).astype(np.float64) @ np.abs(x).astype(np.float64)
+        assert np.all(np.abs(y - ref) <= 1e-5 * bound + 1e-30)
