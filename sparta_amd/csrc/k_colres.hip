@@ -103,6 +103,10 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
     const int sl0 = __builtin_amdgcn_readfirstlane(wslice[wave]);
     const int n_w = __builtin_amdgcn_readfirstlane(wslice[wave + 1]) - sl0;       // slices of this wave (<= SL: checked by the host)
 
+    int dst[SL];                                                    // where this wave's sums go in the end: requested now, needed behind the stream of A
+#pragma unroll
+    for (int I = 0; I < SL; I++) dst[I] = dest[(sl0 + (I < n_w ? I : 0)) * 64 + lane];
+
     for (int rg = 0; rg < p.n_ranges; rg++) {
         const int k0 = p.krange[rg], klen = p.krange[rg + 1] - k0;               // this range's rows of B
         const int span = (klen + 4) & ~3;                             // cells per column of B: the rows + the zero cell the padding of A points at
@@ -157,7 +161,6 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
             const float z[NC] = {};
             cr_put<NC>(lds, span, klen, z);
         }
-        __syncthreads();
 
         // ---- 2. A streams past: lane = slot, a batch (4 steps) of the wave's stream is one 512-byte line of columns (+ 1 KB of values) -------------------------
         // ONE stream per wave and range, read D batches ahead whatever slice they belong to (a loop per slice exposed a scalar load, a global load and an LDS read, one after
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
             else rv[q] = cr_f4{1.0f, 1.0f, 1.0f, 1.0f};
             __builtin_amdgcn_sched_barrier(0);                     // issue order = consumption order (vmcnt counts loads in order).  NOT an asm memory clobber: behind one the
         }                                                          // slice boundaries are no longer scalar loads, and their vector loads drain the ring at every slice end
+        __syncthreads();                                           // the columns of B are in LDS (the first batches of A were requested in front of this wait)
         auto batch = [&](cr_u2& bc, cr_f4& bv, int t0) __attribute__((always_inline)) {
             const unsigned w0 = bc.x, w1 = bc.y;
             const int c[4] = {(int)(w0 & 0xffffu), (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16)};
@@ -229,9 +233,6 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
 
     // ---- 3. sums -> staging image (NC planes of P cells), long rows add their extra cells in chunk order ---------------------------------------------
     {
-        int dst[SL];
-#pragma unroll
-        for (int I = 0; I < SL; I++) dst[I] = dest[(sl0 + (I < n_w ? I : 0)) * 64 + lane];      // (all loads first: one latency, not SL)
 #pragma unroll
         for (int I = 0; I < SL; I++) {
             if (I < n_w && dst[I] >= 0) {
