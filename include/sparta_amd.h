@@ -390,8 +390,8 @@ int sparta_vbs_sparse_info(const sparta_vbs_t* A, int64_t* info_out);
 
 /* the resident-column image of a small fp32 handle (no reference counterpart: the reference multiplies every matrix block by block, vbr.cpp:323-372; this is the
  * product path of its real matrices -- 8-22 k rows, no dense blocks at any block size it sweeps -- at its operand widths B_COLs = 1024 / 8192,
- * scripts/run_multiplication_experiments_fixed_cluster.sh:6-7).  Built when every row of the handle is on the sparse-row path and a column of B and of C
- * fits LDS (rows, columns <= 40 960); taken by sparta_vbs_spmm when B and C are column-major (the reference's layouts) device or host pointers: NC columns of
+ * scripts/run_multiplication_experiments_fixed_cluster.sh:6-7).  Built when at least half the rows of the handle are on the sparse-row path -- the launches of its MFMA
+ * tiles, if it has any, come first; the sparse part of a mixed block-row ADDS to what they stored -- and a column of B and of C fits LDS (rows, columns <= 40 960); taken by sparta_vbs_spmm when B and C are column-major (the reference's layouts) device or host pointers: NC columns of
  * B are copied into LDS, A (length-sorted rows, 64 to a slice, long rows cut into chunks) streams past them from L2, one launch, B and C cross HBM once; a row's
  * nonzeros are added in ascending column order as in CSR::multiply (csr.cpp:49-65).  SPARTA_COLRES=0 at create time: not built (the row gather takes the product).
  * info_out (int64[10]): [0] slices of 64 slots of the part with most (0: no image) [1] stored entries, padding included [2] rows cut into chunks [3] cells a column set
@@ -400,7 +400,8 @@ int sparta_vbs_sparse_info(const sparta_vbs_t* A, int64_t* info_out);
  * [8] parts the rows of C are cut into, [9] K ranges the columns of A are cut into (1, 1: a column of B and of C fits LDS whole; up to 4 x 4: rows, columns <= 163 k --
  * the workgroup of a part walks the ranges one after the other with its sums in registers, B is read once per part) */
 int sparta_vbs_colres_info(const sparta_vbs_t* A, int64_t* info_out);
-/* HOST-side walk of that image for one column x of B (y = A x; rows of C through crow, NULL = identity; info_out as above, [0] = 0 and y untouched when the matrix
+/* HOST-side walk of that image for one column x of B (y = A x; rows of C through crow, NULL = identity; crow[i] + 2^31: row i ADDS to y -- the sparse part of a mixed block-row --,
+ * crow[i] = -1: CSR row i is not a sparse row and y[i] is left alone -- a block-row of tiles; info_out as above, [0] = 0 and y untouched when the matrix
  * gets no image): slots in slice order, a slot's entries in order, the chunks of a long row added in chunk order -- the arithmetic of the kernel, for the CPU suite
  * to check the builder with.  Not a product path (and not a fallback: sparta_vbs_spmm never calls it). */
 int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals, const int64_t* crow, const float* x,

@@ -266,23 +266,38 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
     // ---- 4. staging image -> the part's rows of the NC columns of C, whole lines ----------------------------------------------------------------------
     float* Cj = p.C + (int64_t)j0 * p.ldc + part_r0;
     if (p.probe & 4) return;
+    const uint8_t* mode = p.mode + part_r0;                       // per row: 0 not ours (a block-row of tiles: left alone), 1 store, 2 add to what the tile launches stored
     if (p.vec_out) {
         const int r4 = part_rows >> 2;
         for (int jj = 0; jj < nc; jj++) {
             float* Cc = Cj + (int64_t)jj * p.ldc;
             const float* src = lds + jj * P;
             for (int q = tid; q < r4; q += kCrThreads) {
+                const unsigned m4 = *reinterpret_cast<const unsigned*>(mode + 4 * q);
+                if (m4 == 0u) continue;
                 cr_f4 x = *reinterpret_cast<const cr_f4*>(src + 4 * q);
-                if (p.accumulate) x += *reinterpret_cast<const cr_f4*>(Cc + 4 * q);
+                if (m4 == 0x01010101u && !p.accumulate) { *reinterpret_cast<cr_f4*>(Cc + 4 * q) = x; continue; }
+                const cr_f4 c = *reinterpret_cast<const cr_f4*>(Cc + 4 * q);
+                const bool acc_all = p.accumulate != 0;
+                x.x = (m4 & 0xffu) == 0u ? c.x : ((m4 & 0xffu) == 2u || acc_all ? c.x + x.x : x.x);
+                x.y = ((m4 >> 8) & 0xffu) == 0u ? c.y : (((m4 >> 8) & 0xffu) == 2u || acc_all ? c.y + x.y : x.y);
+                x.z = ((m4 >> 16) & 0xffu) == 0u ? c.z : (((m4 >> 16) & 0xffu) == 2u || acc_all ? c.z + x.z : x.z);
+                x.w = (m4 >> 24) == 0u ? c.w : ((m4 >> 24) == 2u || acc_all ? c.w + x.w : x.w);
                 *reinterpret_cast<cr_f4*>(Cc + 4 * q) = x;
             }
-            for (int r = 4 * r4 + tid; r < part_rows; r += kCrThreads) Cc[r] = p.accumulate ? Cc[r] + src[r] : src[r];
+            for (int r = 4 * r4 + tid; r < part_rows; r += kCrThreads) {
+                const unsigned m = mode[r];
+                if (m != 0u) Cc[r] = (p.accumulate || m == 2u) ? Cc[r] + src[r] : src[r];
+            }
         }
     } else {
         for (int jj = 0; jj < nc; jj++) {
             float* Cc = Cj + (int64_t)jj * p.ldc;
             const float* src = lds + jj * P;
-            for (int r = tid; r < part_rows; r += kCrThreads) Cc[r] = p.accumulate ? Cc[r] + src[r] : src[r];
+            for (int r = tid; r < part_rows; r += kCrThreads) {
+                const unsigned m = mode[r];
+                if (m != 0u) Cc[r] = (p.accumulate || m == 2u) ? Cc[r] + src[r] : src[r];
+            }
         }
     }
 }

@@ -96,6 +96,7 @@ void destroy_impl(sparta_vbs* v) {
     if (v->d_cr_val) (void)hipFree(v->d_cr_val);
     if (v->d_cr_meta) (void)hipFree(v->d_cr_meta);
     if (v->d_cr_parts) (void)hipFree(v->d_cr_parts);
+    if (v->d_cr_mode) (void)hipFree(v->d_cr_mode);
     if (v->d_cr_dest) (void)hipFree(v->d_cr_dest);
     if (v->d_cr_longs) (void)hipFree(v->d_cr_longs);
     if (v->d_Brm) (void)hipFree(v->d_Brm);
@@ -122,6 +123,7 @@ struct ColresHost {
     std::vector<float> val;                                       // ... and four values (empty: every stored value is 1.0f -- a unit image, the reference's -P 1)
     std::vector<ColresPartDev> parts;
     std::vector<int32_t> meta, dest;                              // per part: see ColresPartDev
+    std::vector<uint8_t> mode;                                    // per row of C (padded to 4): 0 not this kernel's, 1 store, 2 add
     std::vector<ColresLong> longs;
     std::vector<int32_t> krange;                                  // [n_ranges + 1]
     int32_t max_slices = 0, max_cells = 0, lmax = 0;              // slices of the part with most; cells a column set needs in LDS (largest range of B + its zero cell / largest staging image)
@@ -131,12 +133,17 @@ bool build_colres(int64_t rows, int64_t cols, const std::vector<int64_t>& rowptr
                   const std::vector<int32_t>& crow, ColresHost& H) {
     if (const char* e = std::getenv("SPARTA_COLRES")) if (atoi(e) == 0) return false;
     const int64_t n = (int64_t)crow.size(), nnz = rowptr.empty() ? 0 : rowptr.back();
-    if (n != rows || nnz == 0 || rows > kColresMaxParts * kColresCells || cols > kColresMaxRanges * (kColresCells - 8)) return false;
-    std::vector<int32_t> ord_of((size_t)rows, -1);                                    // sparse row of every row of C
+    // The sparse rows may be SOME of the rows of C (the others belong to block-rows of MFMA tiles, whose launches come first and which this kernel leaves alone), and a sparse row may belong to
+    // a MIXED block-row (bit 31 of crow: its well-filled blocks are tiles, this kernel ADDS the rest): H.mode says per row of C.  Not worth a second image and B / C through LDS for a
+    // handful of sparse rows: at least half the rows.
+    if (n > rows || 2 * n < rows || nnz == 0 || rows > kColresMaxParts * kColresCells || cols > kColresMaxRanges * (kColresCells - 8)) return false;
+    std::vector<int32_t> ord_of((size_t)rows, -1);                                    // sparse row of every row of C (-1: none)
+    H.mode.assign((size_t)((rows + 3) / 4 * 4), 0);                                    // 0: not this kernel's row, 1: store, 2: add to what the tile launches stored
     for (int64_t t = 0; t < n; t++) {
-        const int32_t r = crow[(size_t)t];
-        if (r < 0 || r >= rows || ord_of[(size_t)r] >= 0) return false;               // bit 31 (the row also has tiles), or not a permutation of the rows of C
+        const int32_t r = crow[(size_t)t] & 0x7fffffff;
+        if (r >= rows || ord_of[(size_t)r] >= 0) return false;                         // not distinct rows of C
         ord_of[(size_t)r] = (int32_t)t;
+        H.mode[(size_t)r] = crow[(size_t)t] < 0 ? 2 : 1;
     }
     int64_t lmax = std::max<int64_t>(32, nnz / 2048);
     if (const char* e = std::getenv("SPARTA_COLRES_LMAX")) lmax = std::max(1, atoi(e));
@@ -152,7 +159,11 @@ bool build_colres(int64_t rows, int64_t cols, const std::vector<int64_t>& rowptr
     // ---- parts: contiguous ranges of the rows of C whose staging image (rows + the extra cells of their chunked rows) fits ----
     int64_t max_plane = kColresCells;
     if (const char* e = std::getenv("SPARTA_COLRES_PLANE")) max_plane = std::max<int64_t>(64, std::min<int64_t>(max_plane, atoi(e)) / 4 * 4);
-    auto chunks_of = [&](int64_t r) { const int64_t t = ord_of[(size_t)r], len = rowptr[(size_t)t + 1] - rowptr[(size_t)t]; return std::max<int64_t>(1, (len + lmax - 1) / lmax); };
+    auto chunks_of = [&](int64_t r) -> int64_t {
+        const int64_t t = ord_of[(size_t)r];
+        if (t < 0) return 1;                                                           // (a row of another kernel: a cell of the staging image nobody writes or reads)
+        return std::max<int64_t>(1, (rowptr[(size_t)t + 1] - rowptr[(size_t)t] + lmax - 1) / lmax);
+    };
     std::vector<int64_t> part_begin{0};
     {
         int64_t cells = 0;
@@ -186,7 +197,9 @@ bool build_colres(int64_t rows, int64_t cols, const std::vector<int64_t>& rowptr
         const size_t longs0 = H.longs.size();
         int64_t n_extra = 0;
         for (int64_t r = r0; r < r1; r++) {
-            const int64_t t = ord_of[(size_t)r], p0 = rowptr[(size_t)t], len = rowptr[(size_t)t + 1] - p0, chunks = chunks_of(r);
+            const int64_t t = ord_of[(size_t)r];
+            if (t < 0) continue;
+            const int64_t p0 = rowptr[(size_t)t], len = rowptr[(size_t)t + 1] - p0, chunks = chunks_of(r);
             if (chunks > 1) H.longs.push_back(ColresLong{(int32_t)(r - r0), (int32_t)(rows_pad + n_extra), (int32_t)(chunks - 1), 0});
             for (int64_t c = 0; c < chunks; c++) {
                 const int64_t o = c * lmax;
@@ -829,8 +842,8 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             CREATE_TRY(hipMemcpy(v->d_sp_long, sp_long.data(), sp_long.size() * sizeof(SpLongRec), hipMemcpyHostToDevice));
         }
     }
-    // resident-column image (k_colres.hip): every row of C is a sparse row, nothing else launches, a column of B fits LDS
-    if (!h16 && !sp_crow.empty() && v->n_steps[0] + v->n_steps[1] == 0 && v->n_hub_steps == 0) {
+    // resident-column image (k_colres.hip): at least half the rows of C are sparse rows (the tile launches, if any, come first on the stream), a column of B fits LDS
+    if (!h16 && !sp_crow.empty()) {
         ColresHost H;
         if (build_colres(v->rows, cols, sp_rowptr, sp_col, sp_val, sp_crow, H)) {
             CREATE_TRY(hipMalloc(&v->d_cr_col, H.col.size() * sizeof(uint16_t)));
@@ -841,6 +854,8 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             }
             CREATE_TRY(hipMalloc((void**)&v->d_cr_meta, H.meta.size() * sizeof(int32_t)));
             CREATE_TRY(hipMemcpy(v->d_cr_meta, H.meta.data(), H.meta.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMalloc(&v->d_cr_mode, H.mode.size()));
+            CREATE_TRY(hipMemcpy(v->d_cr_mode, H.mode.data(), H.mode.size(), hipMemcpyHostToDevice));
             CREATE_TRY(hipMalloc(&v->d_cr_parts, H.parts.size() * sizeof(ColresPartDev)));
             CREATE_TRY(hipMemcpy(v->d_cr_parts, H.parts.data(), H.parts.size() * sizeof(ColresPartDev), hipMemcpyHostToDevice));
             CREATE_TRY(hipMalloc((void**)&v->d_cr_dest, H.dest.size() * sizeof(int32_t)));
@@ -1044,10 +1059,17 @@ int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, 
     using sparta::fail;
     SPARTA_GUARD_BEGIN
     if (rows <= 0 || cols <= 0 || !rowptr || !colidx || !vals || !x || !y || !info) return fail(SPARTA_ERR_INVALID, "sparta_colres_host_check: bad argument");
-    std::vector<int64_t> rp(rowptr, rowptr + rows + 1);
-    std::vector<int32_t> ci(colidx, colidx + rowptr[rows]), cr((size_t)rows);
-    std::vector<float> va(vals, vals + rowptr[rows]);
-    for (int64_t i = 0; i < rows; i++) cr[(size_t)i] = crow ? (int32_t)crow[i] : (int32_t)i;
+    // crow[i] = the row of C of CSR row i (NULL: i); + 2^31: the row ADDS to y (a mixed block-row's sparse part); -1: CSR row i is not a sparse row (its row of C belongs to tiles: y untouched)
+    std::vector<int64_t> rp{0};
+    std::vector<int32_t> ci, cr;
+    std::vector<float> va;
+    for (int64_t i = 0; i < rows; i++) {
+        if (crow && crow[i] == -1) continue;
+        ci.insert(ci.end(), colidx + rowptr[i], colidx + rowptr[i + 1]);
+        va.insert(va.end(), vals + rowptr[i], vals + rowptr[i + 1]);
+        rp.push_back((int64_t)ci.size());
+        cr.push_back(crow ? (int32_t)(uint32_t)(crow[i] & 0xffffffffll) : (int32_t)i);
+    }
     ColresHost H;
     for (int k = 0; k < 10; k++) info[k] = 0;
     if (!build_colres(rows, cols, rp, ci, va, cr, H)) return SPARTA_OK;                 // info[0] = 0: this matrix gets no image
@@ -1092,7 +1114,10 @@ int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, 
             for (int32_t i = 0; i < lr.n; i++) sum += cell[(size_t)lr.first + (size_t)i];
             cell[(size_t)lr.row] = sum;
         }
-        for (int32_t i = 0; i < pd.rows; i++) y[pd.r0 + i] = cell[(size_t)i];
+        for (int32_t i = 0; i < pd.rows; i++) {
+            const uint8_t m = H.mode[(size_t)(pd.r0 + i)];
+            if (m == 1) y[pd.r0 + i] = cell[(size_t)i]; else if (m == 2) y[pd.r0 + i] += cell[(size_t)i];
+        }
     }
     info[0] = H.max_slices; info[1] = H.entries; info[2] = (int64_t)H.longs.size(); info[3] = H.max_cells; info[4] = H.lmax; info[6] = rp.back(); info[7] = H.val.empty() ? 1 : 0;
     info[8] = (int64_t)H.parts.size(); info[9] = n_ranges;
@@ -1222,7 +1247,7 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
         if (nc > 0) {
             ColresParams cp;
             cp.col4 = (const uint2*)A->d_cr_col; cp.val4 = (const float4*)A->d_cr_val; cp.parts = (const ColresPartDev*)A->d_cr_parts; cp.meta = A->d_cr_meta;
-            cp.dest = A->d_cr_dest; cp.longs = (const ColresLong*)A->d_cr_longs;
+            cp.dest = A->d_cr_dest; cp.longs = (const ColresLong*)A->d_cr_longs; cp.mode = (const uint8_t*)A->d_cr_mode;
             cp.B = (const float*)dB; cp.ldb = ldb; cp.C = dC; cp.ldc = ldc;
             for (int r = 0; r <= kColresMaxRanges; r++) cp.krange[r] = A->cr_krange[r];
             cp.n_parts = A->cr_parts; cp.n_ranges = A->cr_ranges; cp.N = n_cols; cp.accumulate = accumulate ? 1 : 0;

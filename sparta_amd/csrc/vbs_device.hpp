@@ -188,6 +188,7 @@ struct ColresParams {
                                // its wave's stream of that range behind the slice's last one)
     const int32_t* dest;       // per part [64 n_slices] (wave-major): cell of the staging image the slot's sum goes to (row of C - r0, or an extra cell >= rows); -1: padding slot
     const ColresLong* longs;
+    const uint8_t* mode;       // per row of C (padded to a multiple of 4): 0 the row is not this kernel's (a block-row of tiles), 1 store its sum, 2 add it to what the tile launches stored
     const float* B;            // column-major, ld = ldb
     int64_t ldb;
     float* C;                  // column-major, ld = ldc
@@ -316,6 +317,7 @@ struct sparta_vbs {
     int32_t cr_parts = 0, cr_ranges = 0, cr_span = 0;
     int32_t cr_krange[sparta_dev::kColresMaxRanges + 1] = {0, 0, 0, 0, 0};
     void* d_cr_parts = nullptr;
+    void* d_cr_mode = nullptr;
     bool cr_unit = false;                  // every value 1.0f: no value array
     int64_t cr_entries = 0;                // stored entries, padding included
     int last_colres_nc = 0;                // columns per workgroup of the last product on this path (0: the product took another path)

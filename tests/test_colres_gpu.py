@@ -250,19 +250,43 @@ def test_prepared_b_is_read_where_it_lies():
     d.close()
 
 
-def test_mixed_and_tiled_handles_keep_their_kernels():
-    """a handle with MFMA tiles has no resident-column image (its sparse rows ADD to what the tile launches stored)"""
-    _torch()
+def test_handles_with_tiles_take_the_kernel_for_their_sparse_rows(monkeypatch):
+    """a handle with MFMA tiles: the tile launches come first, the resident-column kernel then stores the rows of the all-sparse block-rows, ADDS the sparse part of the mixed
+    block-rows and leaves the rows of pure tile block-rows alone.  Against float64, against the same handle on the row gather, with and without accumulate; a handle with only
+    a handful of sparse rows gets no image"""
+    torch = _torch()
+    monkeypatch.setenv("SPARTA_LAUNCH_NNZ", "0")                              # (the library sends a SMALL matrix to the sparse-row kernels altogether: this test wants its tiles ...
+    monkeypatch.setenv("SPARTA_SPARSE_MIN_STEPS", "0")                        # ... and leaves a handful of nearly empty block-rows with the tiles: this test wants them as sparse rows)
     rng = np.random.default_rng(1)
-    dense = np.zeros((512, 2048), np.float32)
-    dense[:256, :640] = rng.uniform(-1, 1, (256, 640))                        # full blocks: tiles
-    dense[256:, :] = (rng.random((256, 2048)) < 0.002) * rng.uniform(-1, 1, (256, 2048))
+    dense = np.zeros((1024, 4096), np.float32)
+    dense[:256, :640] = rng.uniform(-1, 1, (256, 640))                        # full blocks: block-rows of tiles only
+    dense[256:320, 1024:1088] = rng.uniform(-1, 1, (64, 64))                  # a full block inside block-rows that are otherwise scattered: mixed
+    dense[256:, :] += (rng.random((768, 4096)) < 0.002) * rng.uniform(-1, 1, (768, 4096)).astype(np.float32)
     A = sp.csr_matrix(dense)
-    d, _ = _handle(A, np.arange(512, dtype=np.int64) // 32, w=32)
+    g = np.arange(1024, dtype=np.int64) // 32
+    d, perm = _handle(A, g, w=32)
     info = d.info()
-    assert info["tiles16"] + info["tiles32"] + info["tiles64"] > 0
-    assert d.colres_info()["slices"] == 0
-    d.close()
+    assert info["tiles16"] + info["tiles32"] + info["tiles64"] + info["stream_steps"] > 0 and 0 < d.sparse_info()["rows"] < 1024, (info, d.sparse_info())
+    assert d.colres_info()["slices"] > 0
+    monkeypatch.setenv("SPARTA_COLRES", "0")
+    d0, _ = _handle(A, g, w=32)
+    monkeypatch.delenv("SPARTA_COLRES")
+    assert d0.colres_info()["slices"] == 0
+    for n, acc in ((128, False), (128, True), (200, False)):
+        B = sa.gen.dense_rhs(4096, n, seed=n)
+        C0 = sa.gen.dense_rhs(1024, n, seed=n + 1) if acc else None
+        want, bound = _want(A, perm, B, n, C0)
+        got = _product(torch, d, B, n, C0=C0)
+        assert d.colres_info()["nc"] >= 1
+        assert np.all(np.abs(got - want) <= TOL * bound + 1e-30), (n, acc)
+        got0 = _product(torch, d0, B, n, C0=C0)
+        assert d0.colres_info()["nc"] == 0
+        assert np.all(np.abs(got0 - want) <= TOL * bound + 1e-30)
+    d.close(); d0.close()
+    dense[300:, :] = 0                                                         # 44 sparse rows of 1024: the row gather keeps them
+    d1, _ = _handle(sp.csr_matrix(dense), g, w=32)
+    assert d1.colres_info()["slices"] == 0
+    d1.close()
 
 
 @pytest.mark.parametrize("name", ["bcsstk18_r.el", "wiki-Vote_r.el", "ca-HepPh_r.el"])

@@ -121,8 +121,39 @@ def test_no_image_for_matrices_the_kernel_cannot_hold(monkeypatch):
     y, info = _walk(_matrix(100, 100, 0.1, 0, 1), x)
     assert info["slices"] == 0
     monkeypatch.delenv("SPARTA_COLRES")
-    y, info = _walk(_matrix(100, 100, 0.1, 0, 1), x, np.zeros(100, np.int64))      # crow not a permutation of the rows: no image (rows of C would stay unwritten)
+    y, info = _walk(_matrix(100, 100, 0.1, 0, 1), x, np.zeros(100, np.int64))      # two sparse rows for one row of C: no image
     assert info["slices"] == 0 and np.all(y == 7.0)
+    few = np.full(100, -1, np.int64)                                        # a handful of sparse rows among rows of tiles: not worth an image
+    few[:20] = np.arange(20)
+    A = _matrix(100, 100, 0.1, 0, 1).tolil()
+    A[20:, :] = 0
+    y, info = _walk(A.tocsr(), x, few)
+    assert info["slices"] == 0
+
+
+def test_sparse_rows_among_tile_rows_and_mixed_rows():
+    """a handle with MFMA tiles: some rows of C are not this kernel's (crow -1: left alone), the sparse part of a mixed block-row ADDS (crow + 2^31) to what the tiles stored"""
+    rng = np.random.default_rng(12)
+    A = _matrix(3000, 2600, 0.004, 2, 61).tolil()
+    tile_rows = rng.choice(3000, 900, replace=False)
+    A[tile_rows, :] = 0                                                      # those rows of the CSR are not sparse rows: their rows of C belong to tiles
+    A = A.tocsr()
+    perm = rng.permutation(3000).astype(np.int64)
+    crow = perm.copy()
+    add_rows = np.setdiff1d(np.arange(3000), tile_rows)[::5]
+    crow[add_rows] += 1 << 31
+    crow[tile_rows] = -1
+    x = rng.standard_normal(2600).astype(np.float32)
+    y, info = _walk(A, x, crow)                                              # y arrives filled with 7.0
+    assert info["slices"] > 0
+    ref = A.astype(np.float64) @ x.astype(np.float64)
+    bound = abs(A).astype(np.float64) @ np.abs(x).astype(np.float64)
+    is_tile = np.zeros(3000, bool); is_tile[tile_rows] = True
+    is_add = np.zeros(3000, bool); is_add[add_rows] = True
+    assert np.all(y[perm[is_tile]] == 7.0), "a row of tiles was written"
+    store = ~is_tile & ~is_add
+    assert np.all(np.abs(y[perm[store]] - ref[store]) <= 1e-5 * bound[store] + 1e-30)
+    assert np.all(np.abs(y[perm[is_add]] - (7.0 + ref[is_add])) <= 1e-5 * (bound[is_add] + 7.0) + 1e-30)
 
 
 def test_pattern_matrices_get_a_unit_image(monkeypatch):
