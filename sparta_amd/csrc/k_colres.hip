@@ -74,6 +74,7 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
     const ColresPartDev* pdp = p.parts + blockIdx.y;
     const int part_r0 = __builtin_amdgcn_readfirstlane(pdp->r0), part_rows = __builtin_amdgcn_readfirstlane(pdp->rows);
     const int n_slices = __builtin_amdgcn_readfirstlane(pdp->n_slices), n_long = __builtin_amdgcn_readfirstlane(pdp->n_long), P = __builtin_amdgcn_readfirstlane(pdp->plane);
+    const bool all_store = __builtin_amdgcn_readfirstlane(pdp->all_store) != 0;
     const int32_t* wslice = p.meta + __builtin_amdgcn_readfirstlane(pdp->meta);
     const int32_t* woff = wslice + 17;
     const int32_t* bnd_all = woff + p.n_ranges * 17;
@@ -269,12 +270,23 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
     const uint8_t* mode = p.mode + part_r0;                       // per row: 0 not ours (a block-row of tiles: left alone), 1 store, 2 add to what the tile launches stored
     if (p.vec_out) {
         const int r4 = part_rows >> 2;
+        // the modes of this thread's groups of four rows, all requested before the first is needed (a load -> wait -> store chain per group cost 3-5 us per workgroup); a part
+        // whose rows are ALL stored (no tiles in the handle) reads none
+        constexpr int MQ = kColresCellsPerPlane / (4 * kCrThreads);            // groups per thread at most
+        unsigned m4v[MQ];
+#pragma unroll
+        for (int k = 0; k < MQ; k++) {
+            const int q = tid + k * kCrThreads;
+            m4v[k] = all_store ? 0x01010101u : (q < r4 ? *reinterpret_cast<const unsigned*>(mode + 4 * q) : 0u);
+        }
         for (int jj = 0; jj < nc; jj++) {
             float* Cc = Cj + (int64_t)jj * p.ldc;
             const float* src = lds + jj * P;
-            for (int q = tid; q < r4; q += kCrThreads) {
-                const unsigned m4 = *reinterpret_cast<const unsigned*>(mode + 4 * q);
-                if (m4 == 0u) continue;
+#pragma unroll
+            for (int k = 0; k < MQ; k++) {
+                const int q = tid + k * kCrThreads;
+                const unsigned m4 = m4v[k];
+                if (q >= r4 || m4 == 0u) continue;
                 cr_f4 x = *reinterpret_cast<const cr_f4*>(src + 4 * q);
                 if (m4 == 0x01010101u && !p.accumulate) { *reinterpret_cast<cr_f4*>(Cc + 4 * q) = x; continue; }
                 const cr_f4 c = *reinterpret_cast<const cr_f4*>(Cc + 4 * q);
@@ -286,7 +298,7 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
                 *reinterpret_cast<cr_f4*>(Cc + 4 * q) = x;
             }
             for (int r = 4 * r4 + tid; r < part_rows; r += kCrThreads) {
-                const unsigned m = mode[r];
+                const unsigned m = all_store ? 1u : mode[r];
                 if (m != 0u) Cc[r] = (p.accumulate || m == 2u) ? Cc[r] + src[r] : src[r];
             }
         }
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
             float* Cc = Cj + (int64_t)jj * p.ldc;
             const float* src = lds + jj * P;
             for (int r = tid; r < part_rows; r += kCrThreads) {
-                const unsigned m = mode[r];
+                const unsigned m = all_store ? 1u : mode[r];
                 if (m != 0u) Cc[r] = (p.accumulate || m == 2u) ? Cc[r] + src[r] : src[r];
             }
         }

@@ -221,6 +221,8 @@ bool build_colres(int64_t rows, int64_t cols, const std::vector<int64_t>& rowptr
         ColresPartDev pd;
         pd.r0 = (int32_t)r0; pd.rows = (int32_t)prow; pd.n_slices = (int32_t)n_slices; pd.n_long = (int32_t)(H.longs.size() - longs0); pd.plane = (int32_t)plane;
         pd.meta = (int32_t)H.meta.size(); pd.dest = (int32_t)H.dest.size(); pd.longs = (int32_t)longs0;
+        pd.all_store = 1; pd.pad = 0;
+        for (int64_t r = r0; r < r1; r++) if (H.mode[(size_t)r] != 1) pd.all_store = 0;
         const size_t m_wslice = H.meta.size(), m_woff = m_wslice + 17, m_bnd = m_woff + (size_t)n_ranges * 17;
         H.meta.resize(m_bnd + (size_t)n_ranges * (size_t)n_slices, 0);
         const size_t d0 = H.dest.size();

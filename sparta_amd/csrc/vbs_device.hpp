@@ -169,6 +169,7 @@ struct ColresLong { int32_t row, first, n, pad; };   // a row cut into chunks: i
 // A matrix whose columns of B or of C do not fit LDS whole is cut: the rows of C into PARTS (a workgroup owns NC columns of one part: grid y), the columns of A into K RANGES (a workgroup
 // walks them one after the other, its sums staying in registers: the rows of B of a range in LDS at a time).
 constexpr int kColresMaxParts = 4, kColresMaxRanges = 4;
+constexpr int kColresCellsPerPlane = 160 * 1024 / 4;      // floats of LDS: the most cells a column's staging image can have
 struct ColresPartDev {
     int32_t r0, rows;          // the part's rows of C: [r0, r0 + rows), r0 a multiple of 4
     int32_t n_slices, n_long;
@@ -176,6 +177,8 @@ struct ColresPartDev {
     int32_t meta;              // offset (int32) of the part's block in `meta`: wslice[17], woff[n_ranges][17], bnd[n_ranges][n_slices]
     int32_t dest;              // offset (int32) of its dest[64 n_slices] in `dest`
     int32_t longs;             // offset (records) of its list in `longs`
+    int32_t all_store;         // 1: every row of the part is stored by this kernel (no row of tiles, no mixed row: `mode` is not read)
+    int32_t pad;
 };
 struct ColresParams {
     // Per part and K range: the slices of wave w (w, w + 16, ... of the part's length-sorted slots; per range a multiple of 4 steps wide, at least 4) back to back, in batches of 4 steps:
