@@ -316,10 +316,13 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
 
 template <int NC, int SL, bool UNIT>
 int colres_launch(const ColresParams& p, size_t lds_bytes, hipStream_t st) {
-    static int attr_rc = -1;                                      // once per instantiation: allow more than 64 KB of dynamic LDS
-    if (attr_rc != 0) {
-        attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&colres_kernel<NC, SL, UNIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (attr_rc != 0) return attr_rc;
+    static int attr_rc[64];                                       // once per instantiation and device: allow more than 64 KB of dynamic LDS (0: not yet, 1: done)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (attr_rc[dev] != 1) {
+        const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&colres_kernel<NC, SL, UNIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (rc != 0) return rc;
+        attr_rc[dev] = 1;
     }
     const unsigned grid = (unsigned)((p.N + NC - 1) / NC);
     hipLaunchKernelGGL((colres_kernel<NC, SL, UNIT>), dim3(grid, (unsigned)p.n_parts), dim3(kCrThreads), lds_bytes, st, p);
