@@ -297,7 +297,19 @@ int colres_columns(const sparta_vbs_t* A, int n_cols) {
     int nc = fit;
     // (a product of fewer workgroups than CUs is ONE round whatever NC: the stream of A with three or four columns per cell costs twice the LDS time of one or two --
     // bcsstk18 at N = 128: 16.5 / 14.7 / 17.9 us with 1 / 2 / 3 columns)
-    if (nc > 2 && (int64_t)((n_cols + nc - 1) / nc) * A->cr_parts <= 256) nc = 2;
+    if (nc > 2 && (int64_t)((n_cols + 1) / 2) * A->cr_parts <= 256) nc = 2;             // (one round with two columns as well)
+    else if (nc > 1) {
+        // several rounds of workgroups: a round costs ~13 us + 3.4 us per column (measured per workgroup on the reference's real matrices: 16.5 / 18.7 / 23.4 / 27 us with 1..4
+        // columns), and a last round is paid in full however few workgroups it has: N = 1024 on 256 CUs is 2 full rounds with two columns, 1.34 -> 2 with three
+        // (bcsstk18 0.045 against 0.052 ms)
+        int best = nc;
+        double best_t = 1e300;
+        for (int c = 1; c <= fit; c++) {
+            const double rounds = std::ceil(std::ceil((double)n_cols / c) * A->cr_parts / 256.0), t = rounds * (13.0 + 3.4 * c);
+            if (t <= best_t) { best_t = t; best = c; }
+        }
+        nc = best;
+    }
     if (const char* e = std::getenv("SPARTA_COLRES_NC")) nc = std::min(fit, std::max(1, atoi(e)));
     while (nc > 1 && A->cr_slices > colres_max_slices(nc)) nc--;
     return nc >= 1 && A->cr_slices <= colres_max_slices(nc) ? nc : 0;
