@@ -129,3 +129,16 @@ def test_steady_state_of_the_one_tile_kernels_keeps_its_prefetch_and_its_valu_bu
         # the waits in front of the LDS writes of a step leave at least one step's loads in flight
         waits = [int(m.group(1)) for i in ins for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", i)] if m]
         assert sum(w >= loads_per_step for w in waits) >= 4 * steps, (waits, steps)
+
+
+def test_resident_column_kernels_keep_their_sums_in_registers(tmp_path):
+    """k_colres.hip: the sums of a wave's slices live in a statically indexed register array (`acc[SL][NC]`) through the stream of A.  Written the obvious way -- conditional stores
+    at a slice's end, or the next set's columns of B held next to them -- the compiler moves the array to scratch: eight instantiations (1..4 columns x
+    values / unit image), no private segment, no spills, at most 128 registers (four waves per SIMD: one 1024-thread workgroup per CU), no static LDS (the launch sizes it)."""
+    kernels = _kernel_metadata(tmp_path)
+    cr = {n: m for n, m in kernels.items() if "colres_kernel" in n}
+    assert len(cr) == 8, sorted(cr)
+    for name, m in cr.items():
+        assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, (name, m)
+        assert m["vgpr_count"] <= 128, (name, m)
+        assert m["group_segment_fixed_size"] == 0, (name, m)
