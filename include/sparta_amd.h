@@ -394,11 +394,13 @@ int sparta_vbs_sparse_info(const sparta_vbs_t* A, int64_t* info_out);
  * tiles, if it has any, come first; the sparse part of a mixed block-row ADDS to what they stored -- and a column of B and of C fits LDS (rows, columns <= 40 960); taken by sparta_vbs_spmm when B and C are column-major (the reference's layouts) device or host pointers: NC columns of
  * B are copied into LDS, A (length-sorted rows, 64 to a slice, long rows cut into chunks) streams past them from L2, one launch, B and C cross HBM once; a row's
  * nonzeros are added in ascending column order as in CSR::multiply (csr.cpp:49-65).  SPARTA_COLRES=0 at create time: not built (the row gather takes the product).
- * info_out (int64[10]): [0] slices of 64 slots of the part with most (0: no image) [1] stored entries, padding included [2] rows cut into chunks [3] cells a column set
+ * info_out (int64[12]): [0] slices of 64 slots of the part with most (0: no image) [1] stored entries, padding included [2] rows cut into chunks [3] cells a column set
  * needs in LDS (the largest range of B + 4, or the largest staging image: rows + extra cells of the chunks) [4] longest slot [5] columns per workgroup of the last product on this path (0: the last product took another path)
  * [6] nonzeros [7] 1: every stored value is 1.0f and the image holds columns only (the reference's pattern-only runs, -P 1)
  * [8] parts the rows of C are cut into, [9] K ranges the columns of A are cut into (1, 1: a column of B and of C fits LDS whole; up to 4 x 4: rows, columns <= 163 k --
- * the workgroup of a part walks the ranges one after the other with its sums in registers, B is read once per part) */
+ * the workgroup of a part walks the ranges one after the other with its sums in registers, B is read once per part)
+ * [10] parts of the SECOND image a handle keeps for products of few column sets (4; 0: none -- fewer than 2048 rows, or SPARTA_COLRES_SMALL=0): with at most 64 column sets the
+ * product is one round of 4 x the workgroups, each streaming a quarter of A; [11] 1: the last product used it */
 int sparta_vbs_colres_info(const sparta_vbs_t* A, int64_t* info_out);
 /* HOST-side walk of that image for one column x of B (y = A x; rows of C through crow, NULL = identity; crow[i] + 2^31: row i ADDS to y -- the sparse part of a mixed block-row --,
  * crow[i] = -1: CSR row i is not a sparse row and y[i] is left alone -- a block-row of tiles; info_out as above, [0] = 0 and y untouched when the matrix

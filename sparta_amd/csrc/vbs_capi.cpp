@@ -97,6 +97,12 @@ void destroy_impl(sparta_vbs* v) {
     if (v->d_cr_meta) (void)hipFree(v->d_cr_meta);
     if (v->d_cr_parts) (void)hipFree(v->d_cr_parts);
     if (v->d_cr_mode) (void)hipFree(v->d_cr_mode);
+    if (v->cr_small.col) (void)hipFree(v->cr_small.col);
+    if (v->cr_small.val) (void)hipFree(v->cr_small.val);
+    if (v->cr_small.meta) (void)hipFree(v->cr_small.meta);
+    if (v->cr_small.dest) (void)hipFree(v->cr_small.dest);
+    if (v->cr_small.longs) (void)hipFree(v->cr_small.longs);
+    if (v->cr_small.parts) (void)hipFree(v->cr_small.parts);
     if (v->d_cr_dest) (void)hipFree(v->d_cr_dest);
     if (v->d_cr_longs) (void)hipFree(v->d_cr_longs);
     if (v->d_Brm) (void)hipFree(v->d_Brm);
@@ -129,8 +135,9 @@ struct ColresHost {
     int32_t max_slices = 0, max_cells = 0, lmax = 0;              // slices of the part with most; cells a column set needs in LDS (largest range of B + its zero cell / largest staging image)
     int64_t entries = 0;
 };
+// force_parts > 1: that many parts of the rows of C (about equal staging images), one K range -- the image for products of few column sets
 bool build_colres(int64_t rows, int64_t cols, const std::vector<int64_t>& rowptr, const std::vector<int32_t>& col, const std::vector<float>& val,
-                  const std::vector<int32_t>& crow, ColresHost& H) {
+                  const std::vector<int32_t>& crow, ColresHost& H, int force_parts = 0) {
     if (const char* e = std::getenv("SPARTA_COLRES")) if (atoi(e) == 0) return false;
     const int64_t n = (int64_t)crow.size(), nnz = rowptr.empty() ? 0 : rowptr.back();
     // The sparse rows may be SOME of the rows of C (the others belong to block-rows of MFMA tiles, whose launches come first and which this kernel leaves alone), and a sparse row may belong to
@@ -164,6 +171,11 @@ bool build_colres(int64_t rows, int64_t cols, const std::vector<int64_t>& rowptr
         if (t < 0) return 1;                                                           // (a row of another kernel: a cell of the staging image nobody writes or reads)
         return std::max<int64_t>(1, (rowptr[(size_t)t + 1] - rowptr[(size_t)t] + lmax - 1) / lmax);
     };
+    if (force_parts > 1) {
+        int64_t total_cells = 0;
+        for (int64_t r = 0; r < rows; r++) total_cells += chunks_of(r);
+        max_plane = std::min<int64_t>(max_plane, ((total_cells + force_parts - 1) / force_parts + 256 + 3) / 4 * 4);
+    }
     std::vector<int64_t> part_begin{0};
     {
         int64_t cells = 0;
@@ -183,7 +195,8 @@ bool build_colres(int64_t rows, int64_t cols, const std::vector<int64_t>& rowptr
     // against 2.75: one column per workgroup (4-byte LDS reads, A streamed N times), and rows of 2-4 nonzeros spread over the ranges pad every slice to a batch per range (3.3 x the nonzeros).
     {
         const char* e = std::getenv("SPARTA_COLRES_CUTS");
-        if (n_parts * n_ranges > 1 && !(e && atoi(e) != 0)) return false;
+        if (force_parts > 1) { if (n_ranges != 1 || n_parts < 2) return false; }
+        else if (n_parts * n_ranges > 1 && !(e && atoi(e) != 0)) return false;
     }
     bool unit = true;
     for (int64_t k = 0; k < nnz && unit; k++) unit = val[(size_t)k] == 1.0f;
@@ -884,6 +897,32 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
             v->cr_entries = H.entries;
             v->a_bytes += (int64_t)(H.col.size() * sizeof(uint16_t) + H.val.size() * sizeof(float));
             v->cr_unit = H.val.empty();
+            // the four-part image for products of few column sets (SPARTA_COLRES_SMALL=0: not built)
+            const char* es = std::getenv("SPARTA_COLRES_SMALL");
+            if (v->cr_parts == 1 && v->cr_ranges == 1 && v->rows >= 2048 && !(es && atoi(es) == 0)) {
+                ColresHost S;
+                if (build_colres(v->rows, cols, sp_rowptr, sp_col, sp_val, sp_crow, S, 4) && S.val.empty() == H.val.empty()) {
+                    auto& cs = v->cr_small;
+                    CREATE_TRY(hipMalloc(&cs.col, S.col.size() * sizeof(uint16_t)));
+                    CREATE_TRY(hipMemcpy(cs.col, S.col.data(), S.col.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+                    if (!S.val.empty()) {
+                        CREATE_TRY(hipMalloc(&cs.val, S.val.size() * sizeof(float)));
+                        CREATE_TRY(hipMemcpy(cs.val, S.val.data(), S.val.size() * sizeof(float), hipMemcpyHostToDevice));
+                    }
+                    CREATE_TRY(hipMalloc((void**)&cs.meta, S.meta.size() * sizeof(int32_t)));
+                    CREATE_TRY(hipMemcpy(cs.meta, S.meta.data(), S.meta.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                    CREATE_TRY(hipMalloc((void**)&cs.dest, S.dest.size() * sizeof(int32_t)));
+                    CREATE_TRY(hipMemcpy(cs.dest, S.dest.data(), S.dest.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                    if (!S.longs.empty()) {
+                        CREATE_TRY(hipMalloc(&cs.longs, S.longs.size() * sizeof(ColresLong)));
+                        CREATE_TRY(hipMemcpy(cs.longs, S.longs.data(), S.longs.size() * sizeof(ColresLong), hipMemcpyHostToDevice));
+                    }
+                    CREATE_TRY(hipMalloc(&cs.parts, S.parts.size() * sizeof(ColresPartDev)));
+                    CREATE_TRY(hipMemcpy(cs.parts, S.parts.data(), S.parts.size() * sizeof(ColresPartDev), hipMemcpyHostToDevice));
+                    cs.slices = S.max_slices; cs.plane = S.max_cells; cs.n_parts = (int32_t)S.parts.size();
+                    v->a_bytes += (int64_t)(S.col.size() * sizeof(uint16_t) + S.val.size() * sizeof(float));
+                }
+            }
         }
     }
     CREATE_TRY(hipEventCreate(&v->ev0));
@@ -1085,8 +1124,9 @@ int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, 
         cr.push_back(crow ? (int32_t)(uint32_t)(crow[i] & 0xffffffffll) : (int32_t)i);
     }
     ColresHost H;
-    for (int k = 0; k < 10; k++) info[k] = 0;
-    if (!build_colres(rows, cols, rp, ci, va, cr, H)) return SPARTA_OK;                 // info[0] = 0: this matrix gets no image
+    for (int k = 0; k < 12; k++) info[k] = 0;
+    const int force_parts = [] { const char* e = std::getenv("SPARTA_COLRES_FORCE_PARTS"); return e ? atoi(e) : 0; }();      // (4: the image a handle keeps for products of few column sets)
+    if (!build_colres(rows, cols, rp, ci, va, cr, H, force_parts)) return SPARTA_OK;    // info[0] = 0: this matrix gets no image
     const int n_ranges = (int)H.krange.size() - 1;
     for (const ColresPartDev& pd : H.parts) {
         const int32_t* wslice = H.meta.data() + pd.meta;
@@ -1142,7 +1182,7 @@ int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, 
 int sparta_vbs_colres_info(const sparta_vbs_t* A, int64_t* info) {
     if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_colres_info: NULL argument");
     info[0] = A->cr_slices; info[1] = A->cr_entries; info[2] = A->cr_long; info[3] = A->cr_plane; info[4] = A->cr_lmax; info[5] = A->last_colres_nc;
-    info[6] = A->cr_slices > 0 ? A->sp_nnz : 0; info[7] = A->cr_slices > 0 && A->cr_unit ? 1 : 0; info[8] = A->cr_parts; info[9] = A->cr_ranges;
+    info[6] = A->cr_slices > 0 ? A->sp_nnz : 0; info[7] = A->cr_slices > 0 && A->cr_unit ? 1 : 0; info[8] = A->cr_parts; info[9] = A->cr_ranges; info[10] = A->cr_small.n_parts; info[11] = A->last_colres_small ? 1 : 0;
     return SPARTA_OK;
 }
 
@@ -1259,6 +1299,8 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     if (bk == 0 && A->cr_slices > 0 && !b_row_major && !c_row_major && shard_rows == 0) {
         const int nc = colres_columns(A, n_cols);
         if (nc > 0) {
+            int nc_used = nc;
+            bool used_small = false;
             ColresParams cp;
             cp.col4 = (const uint2*)A->d_cr_col; cp.val4 = (const float4*)A->d_cr_val; cp.parts = (const ColresPartDev*)A->d_cr_parts; cp.meta = A->d_cr_meta;
             cp.dest = A->d_cr_dest; cp.longs = (const ColresLong*)A->d_cr_longs; cp.mode = (const uint8_t*)A->d_cr_mode;
@@ -1268,7 +1310,22 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
             cp.vec_out = ldc % 4 == 0 && ((uintptr_t)dC % 16) == 0 ? 1 : 0;
             cp.vec_in = ldb % 4 == 0 && ((uintptr_t)dB % 16) == 0 ? 1 : 0;
             cp.probe = [] { const char* e = std::getenv("SPARTA_COLRES_PROBE"); return e ? atoi(e) : 0; }();        // (read per call: developer A/B)
-            const size_t lds_bytes = (size_t)A->cr_plane * (size_t)nc * sizeof(float);
+            size_t lds_bytes = (size_t)A->cr_plane * (size_t)nc * sizeof(float);
+            // few column sets: the four-part image, the fewest columns per workgroup that keep the product one round of workgroups (read per call: SPARTA_COLRES_SMALL=0 keeps the whole image)
+            if (A->cr_small.slices > 0) {
+                const char* es = std::getenv("SPARTA_COLRES_SMALL");
+                const char* en = std::getenv("SPARTA_COLRES_NC");
+                const int fit = (int)std::min<int64_t>(std::min<int64_t>(4, kColresCells / A->cr_plane), n_cols);
+                int ncs = 0;
+                for (int c = 1; c <= fit && ncs == 0; c++) if ((int64_t)((n_cols + c - 1) / c) * A->cr_small.n_parts <= 256 && A->cr_small.slices <= colres_max_slices(c)) ncs = c;
+                if (ncs > 0 && !en && !(es && atoi(es) == 0)) {
+                    nc_used = ncs; used_small = true;
+                    cp.col4 = (const uint2*)A->cr_small.col; cp.val4 = (const float4*)A->cr_small.val; cp.parts = (const ColresPartDev*)A->cr_small.parts; cp.meta = A->cr_small.meta;
+                    cp.dest = A->cr_small.dest; cp.longs = (const ColresLong*)A->cr_small.longs;
+                    cp.n_parts = A->cr_small.n_parts;
+                    lds_bytes = (size_t)A->cr_plane * (size_t)ncs * sizeof(float);
+                }
+            }
             {
                 static const int n_cus = [] { hipDeviceProp_t pr; return hipGetDeviceProperties(&pr, 0) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }();
                 cp.n_cus = n_cus;
@@ -1282,11 +1339,11 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
                 const char* eg = std::getenv("SPARTA_COLRES_GROUPS");
                 cp.share = eg ? std::max(1, atoi(eg)) : 3;
                 const double stagger = e ? atof(e) * 1e-6 : t_wg / 4.0;
-                cp.stagger_ticks = cp.share > 1 && (int64_t)((n_cols + nc - 1) / nc) * A->cr_parts > 2 * (int64_t)n_cus ? (int32_t)std::min(stagger * 1e8, 1.0e5) : 0;
+                cp.stagger_ticks = cp.share > 1 && (int64_t)((n_cols + nc_used - 1) / nc_used) * cp.n_parts > 2 * (int64_t)n_cus ? (int32_t)std::min(stagger * 1e8, 1.0e5) : 0;
             }
-            if (int hrc = launch_colres(nc, cp, lds_bytes, st)) return sparta::fail(SPARTA_ERR_HIP, "sparta_vbs_spmm: the resident-column kernel could not be launched (hipError_t " + std::to_string(hrc) + ")");
+            if (int hrc = launch_colres(nc_used, cp, lds_bytes, st)) return sparta::fail(SPARTA_ERR_HIP, "sparta_vbs_spmm: the resident-column kernel could not be launched (hipError_t " + std::to_string(hrc) + ")");
             HIP_TRY(hipGetLastError());
-            A->last_colres_nc = nc;
+            A->last_colres_nc = nc_used; A->last_colres_small = used_small;
             return SPARTA_OK;
         }
     }

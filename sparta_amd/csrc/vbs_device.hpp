@@ -322,6 +322,13 @@ struct sparta_vbs {
     void* d_cr_parts = nullptr;
     void* d_cr_mode = nullptr;
     bool cr_unit = false;                  // every value 1.0f: no value array
+    // ... and the same matrix once more in FOUR parts of the rows of C, for products of few column sets (N <= 128 with two columns per workgroup): 4 x the workgroups, each with a
+    // quarter of the stream of A -- with fewer workgroups than CUs one workgroup's stream IS the product's time
+    struct ColresSmall {
+        void* col = nullptr; void* val = nullptr; int32_t* meta = nullptr; int32_t* dest = nullptr; void* longs = nullptr; void* parts = nullptr;
+        int32_t slices = 0, plane = 0, n_parts = 0;
+    } cr_small;
+    bool last_colres_small = false;        // the last product on this path used the four-part image
     int64_t cr_entries = 0;                // stored entries, padding included
     int last_colres_nc = 0;                // columns per workgroup of the last product on this path (0: the product took another path)
     void* d_Brm = nullptr;                 // row-major copy of a column-major / gathered B

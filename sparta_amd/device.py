@@ -126,10 +126,10 @@ class DeviceVBS:
 
     def colres_info(self):
         """the resident-column image of a small fp32 handle (k_colres.hip): see sparta_vbs_colres_info; "nc" = columns per workgroup of the last product on that path"""
-        a = np.zeros(10, np.int64)
+        a = np.zeros(12, np.int64)
         check(lib.sparta_vbs_colres_info(self.h, a.ctypes.data_as(_i64p)))
         return {"slices": int(a[0]), "entries": int(a[1]), "long_rows": int(a[2]), "plane": int(a[3]), "lmax": int(a[4]), "nc": int(a[5]), "nnz": int(a[6]), "unit": int(a[7]),
-                "parts": int(a[8]), "ranges": int(a[9])}
+                "parts": int(a[8]), "ranges": int(a[9]), "small_parts": int(a[10]), "used_small": int(a[11])}
 
     def hub_info(self):
         """the hub part of a 16-bit plan (group tiles of long 64-row tiles for the GEMM-shaped kernel): see sparta_vbs_hub_info"""

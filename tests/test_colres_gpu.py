@@ -226,6 +226,34 @@ def test_the_two_larger_real_matrices_in_parts_and_ranges(monkeypatch, name):
     d.close()
 
 
+def test_few_column_sets_take_the_four_part_image(monkeypatch):
+    """N <= 128: the product is fewer workgroups than CUs and one workgroup's stream of A is its time -- the handle keeps a second image in four parts of the rows of C
+    (4 x the workgroups, a quarter of the stream each).  Same slots, same order of additions: the bits of the whole image; wide products keep the whole image"""
+    torch = _torch()
+    A = _matrix(9000, 8000, 0.002, 3, 71, empty_every=17)
+    d, perm = _handle(A)
+    assert d.colres_info()["small_parts"] == 4
+    for n in (1, 2, 64, 100, 128):
+        B = sa.gen.dense_rhs(8000, n, seed=n)
+        C0 = sa.gen.dense_rhs(9000, n, seed=n + 1)
+        want, bound = _want(A, perm, B, n, C0)
+        got = _product(torch, d, B, n, C0=C0)
+        assert d.colres_info()["used_small"] == 1 and d.colres_info()["nc"] >= 1, n
+        assert np.all(np.abs(got - want) <= TOL * bound + 1e-30)
+        monkeypatch.setenv("SPARTA_COLRES_SMALL", "0")
+        whole = _product(torch, d, B, n, C0=C0)
+        assert d.colres_info()["used_small"] == 0
+        monkeypatch.delenv("SPARTA_COLRES_SMALL")
+        assert np.array_equal(got, whole), (n, "the four-part image adds in another order")
+    B = sa.gen.dense_rhs(8000, 1024, seed=5)
+    _product(torch, d, B, 1024)
+    assert d.colres_info()["used_small"] == 0
+    d.close()
+    d1, _ = _handle(_matrix(1000, 900, 0.01, 0, 1))                           # a matrix this small keeps one image
+    assert d1.colres_info()["small_parts"] == 0
+    d1.close()
+
+
 def test_prepared_b_is_read_where_it_lies():
     """sparta_vbs_prepare_b makes no row-major copy for a handle the resident-column kernel carries; the prepared product is the plain one"""
     import ctypes as C

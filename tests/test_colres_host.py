@@ -16,7 +16,7 @@ _i64p, _i32p, _f32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_
 def _walk(A, x, crow=None):
     rows, cols = A.shape
     rp, ci, va = A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.float32)
-    y, info = np.full(rows, 7.0, np.float32), np.zeros(10, np.int64)
+    y, info = np.full(rows, 7.0, np.float32), np.zeros(12, np.int64)
     cr = None if crow is None else np.ascontiguousarray(crow, np.int64)
     check(lib.sparta_colres_host_check(rows, cols, rp.ctypes.data_as(_i64p), ci.ctypes.data_as(_i32p), va.ctypes.data_as(_f32p),
                                        None if cr is None else cr.ctypes.data_as(_i64p), x.ctypes.data_as(_f32p), y.ctypes.data_as(_f32p), info.ctypes.data_as(_i64p)))
@@ -217,3 +217,17 @@ def test_the_two_larger_real_matrices_get_an_image_in_parts_and_ranges(monkeypat
         ref = A.astype(np.float64) @ x.astype(np.float64)
         bound = abs(A).astype(np.float64) @ np.abs(x).astype(np.float64)
         assert np.all(np.abs(y - ref) <= 1e-5 * bound + 1e-30)
+
+
+def test_the_four_part_image_for_few_column_sets(monkeypatch):
+    """a handle keeps a second image in four parts of the rows of C for products of at most 64 column sets (4 x the workgroups, a quarter of the stream of A each):
+    SPARTA_COLRES_FORCE_PARTS=4 walks that image on the host -- the same slots, chunks and order of additions per row: the bits of the whole image"""
+    A = _matrix(9000, 8000, 0.002, 3, 71, empty_every=17)
+    x = np.random.default_rng(2).standard_normal(8000).astype(np.float32)
+    crow = np.random.default_rng(3).permutation(9000)
+    y0, info0 = _walk(A, x, crow)
+    monkeypatch.setenv("SPARTA_COLRES_FORCE_PARTS", "4")
+    y, info = _walk(A, x, crow)
+    assert info0["parts"] == 1 and info["parts"] == 4 and info["ranges"] == 1
+    assert info["plane"] <= info0["plane"] and info["long_rows"] == info0["long_rows"]
+    assert np.array_equal(y, y0)
