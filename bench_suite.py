@@ -163,7 +163,7 @@ def run_one(sa, torch, name, kind, make, eng_kw, w, N=128, device=0, budget_ms=4
                                              eng_kw.get("tau", 0.0), w),
            "ms": round(ms, 5), "ms_prepared_b": None if ms_prepared is None else round(ms_prepared, 5), "useful_gflops": round(2.0 * m.nztot() * N / ms / 1e6, 1), "frac_8d": round(t_lb / (ms * 1e-3), 4),
            "gather_gbs": None if gather is None else round(gather, 1),
-           "carried_by": ("resident columns (%d per workgroup%s)%s" % (cr["nc"], ", unit image" if cr["unit"] else "",
+           "carried_by": ("resident columns (%d per workgroup%s)%s" % (cr["nc"], (", unit image" if cr["unit"] else "") + (", four-part image" if cr.get("used_small") else ""),
                                                                         ", 1 launch" if info["nztot"] == 0 else " behind MFMA tiles (%.0f %% of the nonzeros)" % (100.0 * (1 - sp["nnz"] / max(m.nztot(), 1))))) if cr["nc"] > 0 else
                          ("sparse rows %.0f %%" % (100.0 * sp["nnz"] / max(m.nztot(), 1))) if sp["nnz"] * 2 > m.nztot() else
                          ("MFMA tiles %.0f %%" % (100.0 * (1 - sp["nnz"] / max(m.nztot(), 1)))),
