@@ -348,7 +348,7 @@ int sparta_vbs_spmm_ba(sparta_vbs_t* At, const void* B, int64_t ldb, int32_t M, 
  * or gathered B is otherwise transposed into per-handle scratch on EVERY product (11 % of a power-law product).
  * sparta_vbs_prepare_b makes that copy once, on `stream`, into memory the returned object owns; B itself is not copied and must stay
  * valid and unchanged while the object is used.  shard_rows = 0: B is column-major cols x n_cols with leading dimension ldb; shard_rows >
- * 0: the gathered layout of sparta_vbs_spmm_gathered (ldb ignored).  Device pointers only.  sparta_vbs_spmm_prepared is sparta_vbs_spmm /
+ * 0: the gathered layout of sparta_vbs_spmm_gathered_ld with ldb = the column stride inside a slab (shard_ld; 0 = unpadded = shard_rows).  Device pointers only.  sparta_vbs_spmm_prepared is sparta_vbs_spmm /
  * sparta_vbs_spmm_gathered on that B (SPARTA_SPMM_MFMA; the exception state of a failed call is a plain status code: the handle is usable
  * again).  The implicit per-call transpose of sparta_vbs_spmm stays the default: nothing changes for a caller that never prepares. */
 typedef struct sparta_b sparta_b_t;

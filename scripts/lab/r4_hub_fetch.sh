@@ -5,6 +5,8 @@ cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 out=gpurun_out/r4/hub_fetch
 rm -rf $out; mkdir -p $out
 H=scripts/ubench/hub_gemm
+# built here from the source beside it (no binaries in the tree): the numbers belong to this hub_gemm.hip
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I sparta_amd/csrc scripts/ubench/hub_gemm.hip -o $H || exit 1
 export HUB_LDB=1048640
 i=0
 for args in "36 1048576 256 10 1 8 256 2" "36 1048576 512 10 1 8 256 2" "36 1048576 512 10 1 64 256 2" "36 1048576 512 10 0 8 256 2"; do

@@ -18,7 +18,7 @@ for key in which.split(","):
     scale, dens, P, N, sdt, tdt = cfgs[key]
     E = sa.gen.rmat_raw_edges_for_density(scale, dens)
     part = int(os.environ.get("HUB_PART", "0"))
-    r0, r1 = sa.gen.rmat_cuts(scale, E, P)[part]
+    r0, r1 = sa.gen.rmat_cuts(scale, E, P, n_cols=N)[part]          # the cuts bench_parts.py runs (cost constants per operand width)
     t0 = time.time()
     m = sa.gen.rmat_rows(scale, E, r0, r1, device=0)
     g = np.arange(m.rows) // 64

@@ -6,6 +6,8 @@ out=gpurun_out/r4/hub_pmc
 mkdir -p $out
 rocprofv3 -L > $out/counters.txt 2>&1
 H=scripts/ubench/hub_gemm
+# built here from the source beside it (no binaries in the tree): the numbers belong to this hub_gemm.hip
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I sparta_amd/csrc scripts/ubench/hub_gemm.hip -o $H || exit 1
 for cfg in "0 36x2" "10 36"; do
   set -- $cfg; v=$1
   if [ $v = 0 ]; then T=72; else T=36; fi

@@ -295,6 +295,9 @@ bool build_colres(int64_t rows, int64_t cols, const std::vector<int64_t>& rowptr
         H.max_cells = std::max(H.max_cells, (int32_t)plane);
     }
     for (size_t x = (size_t)total * 256; x < H.col.size(); x++) H.col[x] = (uint16_t)(H.krange[1] - H.krange[0]);
+    // a wave that owns no slice of a part (every part of fewer than 16 slices has such waves) still prefetches the destination cells of "its first slice" = one
+    // slice behind the part's last (k_colres.hip: dst[I] = dest[(sl0 + ...) * 64 + lane]); behind the LAST part that is past the table: one padding slice of -1
+    H.dest.resize(H.dest.size() + 64, -1);
     H.max_cells = std::max(H.max_cells, (int32_t)((range_len + 4) / 4 * 4));
     H.entries = total * 256;
     H.lmax = (int32_t)lmax;
@@ -1508,6 +1511,9 @@ int spmm16_core(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
             static const int hub_variant_env = [] { const char* e = std::getenv("SPARTA_HUB_VARIANT"); return e ? atoi(e) : -1; }();
             int variant = A->hub_g == 4 ? 10 : 0;                        // KP 64: G = 4 two stages (eight waves), G = 2 three stages
             if (hub_variant_env >= 0 && hub_variant_kp(hub_variant_env) == 64 && hub_variant_g(hub_variant_env) == A->hub_g) variant = hub_variant_env;
+            // a wave's panel loads span 64 (G = 2) or 32 (G = 4) columns of B in 32-bit buffer offsets: the leading dimension must keep them inside the descriptor's 2 GB
+            if (ldb16 * (int64_t)(hub_variant_g(variant) == 2 ? 64 : 32) * 2 >= ((int64_t)1 << 31) - 65536)
+                return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: leading dimension of B too large for the 16-bit hub kernel (32-bit panel offsets)");
             launch_h16_hub(variant, bf16, shard_rows > 0, st, hp);
         }
         if (prof) { HIP_TRY(hipEventRecord(A->cev[0][1], st)); A->class_ran[0] = true; }
@@ -1875,13 +1881,16 @@ int sparta_vbs_prepare_b(sparta_vbs_t* A, const void* B, int64_t ldb, int64_t sh
     *out = nullptr;
     if (n_cols <= 0) return fail(SPARTA_ERR_INVALID, "sparta_vbs_prepare_b: n_cols must be > 0");
     if (shard_rows == 0 && ldb < A->cols) return fail(SPARTA_ERR_INVALID, "sparta_vbs_prepare_b: ldb too small");
-    if (shard_rows != 0 && (shard_rows < 0 || shard_rows % A->w != 0 || A->cols % shard_rows != 0 || shard_stride < shard_rows * (int64_t)n_cols))
+    // a gathered B: `ldb` is the column stride inside a slab (sparta_vbs_spmm_gathered_ld's shard_ld; 0 = unpadded, shard_rows)
+    const int64_t shard_ld = shard_rows != 0 ? (ldb > 0 ? ldb : shard_rows) : 0;
+    if (shard_rows != 0 && (shard_rows < 0 || shard_rows % A->w != 0 || A->cols % shard_rows != 0 || shard_ld < shard_rows ||
+                            shard_stride < shard_ld * (int64_t)(n_cols - 1) + shard_rows))
         return fail(SPARTA_ERR_INVALID, "sparta_vbs_prepare_b: bad gathered layout");
     if (g_capturing) return capture_refusal("prepare a copy of B");
     DeviceGuard guard(A->device);
     sparta_b* p = new (std::nothrow) sparta_b;
     if (!p) return fail(SPARTA_ERR_ALLOC, "sparta_vbs_prepare_b: out of host memory");
-    p->B = B; p->ldb = shard_rows ? shard_rows : ldb; p->shard_rows = shard_rows; p->shard_stride = shard_stride; p->cols = A->cols;
+    p->B = B; p->ldb = shard_rows ? shard_ld : ldb; p->shard_rows = shard_rows; p->shard_stride = shard_stride; p->cols = A->cols;
     p->n_cols = n_cols; p->dtype = A->dtype; p->device = A->device;
     const size_t esz = A->dtype == SPARTA_F32 ? 4 : 2;
     // the sparse-row kernels of this handle would transpose this B per product (launch_sparse_rows: not when a handful of rows reads it in place)

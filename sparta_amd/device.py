@@ -210,11 +210,12 @@ class DeviceVBS:
         want_b = {_lib.F32: torch.float32, _lib.F16: torch.float16, _lib.BF16: torch.bfloat16}[self.dtype]
         if not (B.is_cuda and B.dtype == want_b and B.device.index == self.device and B.is_contiguous()):
             raise ValueError("B must be a contiguous %s tensor on device %d" % (want_b, self.device))
-        ldb = self.cols if ldb is None else int(ldb)
         if shard_rows:
-            shard_stride = shard_rows * n_cols if shard_stride is None else int(shard_stride)
-            need = (self.cols // shard_rows) * shard_stride
+            ldb = shard_rows if ldb is None else int(ldb)                      # gathered B: ldb = shard_ld, the column stride inside a slab (padded slabs: > shard_rows)
+            shard_stride = ldb * n_cols if shard_stride is None else int(shard_stride)
+            need = (self.cols // shard_rows - 1) * shard_stride + ldb * (n_cols - 1) + shard_rows
         else:
+            ldb = self.cols if ldb is None else int(ldb)
             shard_stride, need = 0, ldb * n_cols
         if B.numel() < need:
             raise ValueError("B too small for the stated layout")
