@@ -130,6 +130,7 @@ def run_one(sa, torch, name, kind, make, eng_kw, w, N=128, device=0, budget_ms=4
     d.set_class_timing(False)
     check = _spot_check(sa, torch, m, g, C, B, N)
     info, sp = d.info(), d.sparse_info()
+    ui = d.union_info()                                          # column-compacted tiles (k_union.hip): clusters whose rows share columns, as dense rows x |union| tiles
     cr = d.colres_info()                                         # nc > 0: the last product was the resident-column kernel's (small all-sparse matrix, k_colres.hip), ONE launch
     # the reference's experiment multiplies the SAME B again and again: behind sparta_vbs_prepare_b the sparse rows' row-major copy of B is made once, and a small
     # product is one launch (rows + segments, the last-arriving segment of a long row reduces it).  Reported beside `ms` (a fresh B per product), never instead of it.
@@ -146,9 +147,11 @@ def run_one(sa, torch, name, kind, make, eng_kw, w, N=128, device=0, budget_ms=4
         ms_prepared = e0.elapsed_time(e1) / reps
         Bp.close()
     # section-8(d) bound of what the device holds
-    dense_area = float(info["nztot"])
+    # (column-compacted tiles count as what they are: stored elements x 4 bytes + list entries, flops on the stored elements.  Rows of C: every row is written once by
+    #  whoever owns it -- rows x N x 4 bytes in all, split here as (rows - sparse rows) + sparse rows; a sparse row that ADDS to a tile's row is charged only once)
+    dense_area = float(info["nztot"]) + float(ui["area"])
     dense_rows = info["rows"] - sp["rows"]
-    bytes_dense = dense_area * 4.0 + info["nblocks"] * 4.0 + dense_rows * N * 4.0
+    bytes_dense = dense_area * 4.0 + info["nblocks"] * 4.0 + ui["list_entries"] * 4.0 + dense_rows * N * 4.0
     flops_dense = 2.0 * dense_area * N
     bytes_sparse = float(sp["nnz"]) * 8.0 + float(sp["rows"]) * (N * 4.0 + 8.0)
     bytes_b = float(info["cols"]) * N * 4.0
@@ -163,7 +166,10 @@ def run_one(sa, torch, name, kind, make, eng_kw, w, N=128, device=0, budget_ms=4
                                              eng_kw.get("tau", 0.0), w),
            "ms": round(ms, 5), "ms_prepared_b": None if ms_prepared is None else round(ms_prepared, 5), "useful_gflops": round(2.0 * m.nztot() * N / ms / 1e6, 1), "frac_8d": round(t_lb / (ms * 1e-3), 4),
            "gather_gbs": None if gather is None else round(gather, 1),
-           "carried_by": ("resident columns (%d per workgroup%s)%s" % (cr["nc"], (", unit image" if cr["unit"] else "") + (", four-part image" if cr.get("used_small") else ""),
+           "union_info": ui if ui["area"] > 0 else None,
+           "carried_by": ("column-compacted MFMA tiles %.0f %% of the nonzeros (%d + %d tiles, fill %.2f)%s" % (100.0 * ui["nnz"] / max(m.nztot(), 1), ui["tiles32"], ui["tiles64"], ui["nnz"] / max(ui["area"], 1),
+                                                                                                     ", rest: resident columns" if cr["nc"] > 0 else (", rest: sparse rows" if sp["nnz"] > 0 else ""))) if ui["nnz"] * 2 > m.nztot() else
+                         ("resident columns (%d per workgroup%s)%s" % (cr["nc"], (", unit image" if cr["unit"] else "") + (", four-part image" if cr.get("used_small") else ""),
                                                                         ", 1 launch" if info["nztot"] == 0 else " behind MFMA tiles (%.0f %% of the nonzeros)" % (100.0 * (1 - sp["nnz"] / max(m.nztot(), 1))))) if cr["nc"] > 0 else
                          ("sparse rows %.0f %%" % (100.0 * sp["nnz"] / max(m.nztot(), 1))) if sp["nnz"] * 2 > m.nztot() else
                          ("MFMA tiles %.0f %%" % (100.0 * (1 - sp["nnz"] / max(m.nztot(), 1)))),

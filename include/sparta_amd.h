@@ -409,6 +409,24 @@ int sparta_vbs_colres_info(const sparta_vbs_t* A, int64_t* info_out);
 int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals, const int64_t* crow, const float* x,
                              float* y, int64_t* info_out);
 
+/* the column-compacted ("union-pattern") tiles of an fp32 handle made by sparta_vbs_create_from_csr.  They replace what the reference's builder stores for a cluster at
+ * SMALL block widths -- VBR::fill_from_CSR_inplace flags, per block-row, exactly the column blocks its rows touch and stores them back to back
+ * (src/general/vbr.cpp:177-228; at -b 1 that is a dense rows x |union| tile plus the ascending column list, the ids its Jaccard distance is defined on,
+ * src/general/blocking.cpp:923-994) -- and what VBR::multiply does with it (vbr.cpp:323-372): a block-row whose rows share columns but whose w-wide blocks would be
+ * nearly empty is kept as tiles of <= 64 consecutive reordered rows x the columns at least 2-3 of those rows use, multiplied on the matrix cores against the
+ * gathered rows of a row-major B (k_union.hip; a column-major B is transposed once per product, or once per sparta_vbs_prepare_b); the nonzeros of the other
+ * columns are sparse rows that add.  SPARTA_UNION=0 at create time: not built.  SPARTA_SPMM_EXACT is not available on such a handle (as for any handle with sparse rows).
+ * info_out (int64[8]): [0] tiles of <= 32 rows [1] tiles of 33..64 rows [2], [3] their 32-deep steps [4] stored elements (tile rows x list entries)
+ * [5] list entries [6] nonzeros the tiles hold [7] persistent workgroups (both launches) */
+int sparta_vbs_union_info(const sparta_vbs_t* A, int64_t* info_out);
+/* HOST-side check of that builder and its device plan for the CPU suite (no GPU; not a product path, and not a fallback: sparta_vbs_spmm never calls it): the hybrid
+ * image of the CSR matrix under `grouping` -- w-wide tiles, column-compacted tiles, sparse rows, decided as sparta_vbs_create_from_csr decides them for an fp32 handle --
+ * multiplied with ONE column x; the column-compacted tiles are walked in their DEVICE form (step records, list entries, MFMA-fragment-order slices, dealt to
+ * `max_workers` workers).  y (double, [rows padded as force_fixed_size pads them], reordered order).  info_out (int64[12]): [0..6] as sparta_vbs_union_info,
+ * [7] nonzeros left to the sparse rows [8] stored elements of the w-wide tiles [9] padded rows [10], [11] workers of the two step lists */
+int sparta_union_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals, const int64_t* grouping, int64_t col_block_size,
+                            int64_t row_block_size, int32_t force_fixed_size, int32_t max_workers, const float* x, double* y, int64_t* info_out);
+
 /* the hub part of the plan of a 16-bit handle of 64-wide blocks (no reference counterpart: the reference multiplies every block-row the same way,
  * vbr.cpp:323-372 / cuda_utilities.cpp:828-875).  The long tiles of 33..64 rows -- the dense hub of a power-law matrix under the fixed 64 x 64 grid -- are grouped
  * by the Jaccard similarity of their block-column sets into group tiles of 2 or 4 and multiplied by a GEMM-shaped kernel that stages A and B once per workgroup.

@@ -9,12 +9,12 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/sparta_asan
 mkdir -p "$OUT"
 CXX=/opt/rocm/lib/llvm/bin/clang++                              # (g++ 11 has no _Float16 in C++: vbs_plan.cpp / vbs_capi.cpp need clang)
-for f in capi reorder vbs_build io vbs_plan vbs_capi; do
+for f in capi reorder vbs_build io vbs_plan vbs_union vbs_capi; do
   $CXX -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -I"$ROOT/include" -I"$ROOT/sparta_amd/csrc" -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ \
       -c "$ROOT/sparta_amd/csrc/$f.cpp" -o "$OUT/$f.o"
 done
 make -s -C "$ROOT/sparta_amd/csrc"                             # the kernel objects (k_*.o, not instrumented: device code)
-$CXX -shared -fPIC -fsanitize=address,undefined -shared-libsan -o "$OUT/libsparta_amd_asan.so" "$OUT"/{capi,reorder,vbs_build,io,vbs_plan,vbs_capi}.o "$ROOT"/sparta_amd/csrc/k_*.o \
+$CXX -shared -fPIC -fsanitize=address,undefined -shared-libsan -o "$OUT/libsparta_amd_asan.so" "$OUT"/{capi,reorder,vbs_build,io,vbs_plan,vbs_union,vbs_capi}.o "$ROOT"/sparta_amd/csrc/k_*.o \
     -L/opt/rocm/lib -lamdhip64 -lpthread
 cd "$ROOT"
 LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 SPARTA_AMD_LIB="$OUT/libsparta_amd_asan.so" \

@@ -32,7 +32,7 @@ SYMBOLS = [
     "sparta_get_fixed_size_grouping", "sparta_row_distance", "sparta_merge_rows", "sparta_vbs_build",
     "sparta_vbs_host_free", "sparta_blocking_info", "sparta_vbs_create", "sparta_vbs_create_range", "sparta_vbs_create_from_csr",
     "sparta_vbs_spmm", "sparta_vbs_spmm_gathered", "sparta_vbs_spmm_gathered_ld", "sparta_pack_blocks", "sparta_vbs_create_transposed", "sparta_vbs_spmm_ba", "sparta_vbs_set_class_timing",
-    "sparta_vbs_class_times", "sparta_vbs_clock_mhz", "sparta_vbs_destroy", "sparta_vbs_info", "sparta_vbs_sparse_info", "sparta_vbs_colres_info", "sparta_colres_host_check", "sparta_vbs_hub_info", "sparta_device_count", "sparta_last_error",
+    "sparta_vbs_class_times", "sparta_vbs_clock_mhz", "sparta_vbs_destroy", "sparta_vbs_info", "sparta_vbs_sparse_info", "sparta_vbs_colres_info", "sparta_colres_host_check", "sparta_vbs_union_info", "sparta_union_host_check", "sparta_vbs_hub_info", "sparta_device_count", "sparta_last_error",
     "sparta_version",
     "sparta_csr_read", "sparta_csr_read_buffer", "sparta_csr_host_free", "sparta_csr_write_edgelist", "sparta_grouping_write", "sparta_grouping_read",
     "sparta_blocking_csv_row", "sparta_degree_permutation", "sparta_vbs_save", "sparta_vbs_load", "sparta_vbs_to_blocked_ell",
@@ -144,6 +144,8 @@ def _load():
     L.sparta_vbs_hub_info.argtypes = [vp, i64p]
     L.sparta_vbs_colres_info.argtypes = [vp, i64p]
     L.sparta_colres_host_check.argtypes = [C.c_int64, C.c_int64, i64p, i32p, f32p, i64p, f32p, f32p, i64p]
+    L.sparta_vbs_union_info.argtypes = [vp, i64p]
+    L.sparta_union_host_check.argtypes = [C.c_int64, C.c_int64, i64p, i32p, f32p, i64p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, f32p, C.POINTER(C.c_double), i64p]
     L.sparta_device_count.argtypes = []
     L.sparta_last_error.restype = C.c_char_p
     L.sparta_version.restype = C.c_char_p

@@ -103,8 +103,25 @@ std::vector<int64_t> merge_rows(const int64_t* a, int64_t na, const int64_t* b, 
 // ---- VBS builder (vbs_build.cpp) -------------------------------------------------------------
 int vbs_build(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t row_block_size,
               bool force_fixed_size, sparta_vbs_host* out);
+// Column-compacted ("union-pattern") tiles: what the reference's builder stores for a cluster at SMALL block widths -- exactly the columns its rows touch, back to
+// back (src/general/vbr.cpp:177-228 at -b 1) -- kept as ONE dense (rows x |U|) tile + the ascending column list U per group of <= 64 consecutive reordered rows.
+// The device multiplies a tile with the |U| gathered rows of B on the matrix cores (k_union.hip).  Built by vbs_build_hybrid for the block-rows whose rows share
+// columns (mode 3), consumed by create_core (vbs_union.cpp lays the tiles out per worker in MFMA fragment order).
+struct UnionPlanHost {
+    // ty 0: tiles of <= 32 rows (one 32-row MFMA tile per wave and step), ty 1: tiles of 33..64 rows (two)
+    struct Tile { int32_t c_row, mt; int64_t k0; int32_t nk, pad; };   // first reordered row (= row of C), rows, offset of its column list in cols[ty], columns
+    std::vector<Tile> tiles[2];
+    std::vector<int32_t> cols[2];      // column ids, tile after tile; a tile's list is the concatenation of its parts' ascending lists (a part = the rows of ONE block-row in the tile)
+    std::vector<float> a[2];           // values, tile after tile, tile t at a_off[ty][t]: element (row i, list position k) at k * (32 * (ty + 1)) + i; zeros where a row lacks the column
+    std::vector<int64_t> a_off[2];
+    int64_t nnz = 0;                   // nonzeros held by the tiles
+    bool empty() const { return tiles[0].empty() && tiles[1].empty(); }
+};
+
 // hybrid build (sparta_vbs_create_from_csr): the block-rows left to the device's sparse-row path, as rows of (column, value)
 struct HybridSparse {
+    UnionPlanHost uni;                // flag 3 block-rows: their column-compacted tiles (the nonzeros of thinly used columns are sparse rows that ADD, as for flag 2)
+    bool want_union = false;          // in: build them (fp32 handles; SPARTA_UNION=0 switches the path off)
     std::vector<uint8_t> flag;        // per block-row: 1 = not in the dense image at all; 2 = mixed: its well-filled blocks are in the dense image,
                                       // the nonzeros of the others are sparse rows that ADD to what the tiles wrote (row_add)
     std::vector<uint8_t> row_add;     // per sparse row: 1 = its block-row also has tiles: the sparse-row kernels add to C instead of storing
@@ -119,7 +136,11 @@ struct HybridStats {
     double mfma_steps = 0.0;                  // steps those tiles cost (one <= 32-row tile x kdep columns of a block)
     int64_t sparse_nnz = 0, sparse_rows = 0;  // entries / rows left to the sparse-row kernels
     int64_t block_rows = 0, rows = 0;
+    int64_t union_block_rows = 0, union_cols = 0, union_nnz = 0;   // block-rows kept as column-compacted tiles, their list entries (k columns), the nonzeros those hold
+    double union_steps = 0.0;                 // 32-deep steps of 32-row MFMA tiles they cost
 };
+double union_col_cost(int mi);      // a list entry of a column-compacted tile (mi = 1: tiles of <= 32 rows, 2: of 33..64) in nonzeros of the sparse-row path
+int32_t union_min_count(int mi);    // fewest nonzeros of a part's rows that keep a column in its tile
 int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, bool force_fixed_size,
                      double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp, bool keep_order = false, HybridStats* stats_only = nullptr);
 // fewest MFMA steps the nearly empty block-rows of a matrix must be worth before they leave the tiles for the sparse-row kernels

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kThreads) void sparse_reduce_cm_kernel(SparseParams
 // consecutive rows of one column (256 contiguous bytes) and writes 64 consecutive columns of one row (256 contiguous bytes)
 template <class E>
 __global__ __launch_bounds__(kThreads) void b_to_row_major_kernel(const E* __restrict__ B, int64_t ldb, int64_t shard_rows, int64_t shard_stride,
-                                                                  int64_t rows, int N, E* __restrict__ out) {
+                                                                  int64_t rows, int N, E* __restrict__ out, int64_t ld_out) {
     __shared__ E tile[64][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // 1-D grid, column tile fastest: the workgroups that run together complete whole rows of the row-major copy (and read the same
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(kThreads) void b_to_row_major_kernel(const E* __res
     for (int q = 0; q < 16; q++) {                               // write: lanes along the columns (contiguous in a row)
         const int j = wave + 4 * q;
         const int64_t rr = r0 + j;
-        if (rr < rows && n < N) out[rr * N + n] = tile[lane][j];
+        if (rr < rows && n < N) out[rr * ld_out + n] = tile[lane][j];
     }
 }
 
@@ -526,9 +526,9 @@ void launch_sparse_kernels(int vec, int bk, const SparseParams& q, unsigned gy, 
 }
 
 void launch_b_to_row_major(bool is16, unsigned grid, hipStream_t st, const void* B, int64_t ldb, int64_t shard_rows, int64_t shard_stride, int64_t rows, int N,
-                           void* out) {
-    if (!is16) hipLaunchKernelGGL(b_to_row_major_kernel<float>, dim3(grid), dim3(kThreads), 0, st, (const float*)B, ldb, shard_rows, shard_stride, rows, N, (float*)out);
-    else hipLaunchKernelGGL(b_to_row_major_kernel<unsigned short>, dim3(grid), dim3(kThreads), 0, st, (const unsigned short*)B, ldb, shard_rows, shard_stride, rows, N, (unsigned short*)out);
+                           void* out, int64_t ld_out) {
+    if (!is16) hipLaunchKernelGGL(b_to_row_major_kernel<float>, dim3(grid), dim3(kThreads), 0, st, (const float*)B, ldb, shard_rows, shard_stride, rows, N, (float*)out, ld_out);
+    else hipLaunchKernelGGL(b_to_row_major_kernel<unsigned short>, dim3(grid), dim3(kThreads), 0, st, (const unsigned short*)B, ldb, shard_rows, shard_stride, rows, N, (unsigned short*)out, ld_out);
 }
 
 void launch_pack_blocks(dim3 grid, hipStream_t st, const void* src, const int32_t* ids, void* dst, int64_t block_vec) {

@@ -1,0 +1,213 @@
+// k_union.hip -- the MFMA kernel of the column-compacted ("union-pattern") tiles of an fp32 handle: vbs_union_f32_kernel.  Part of the device side of
+// libsparta_amd.so; see vbs_device.hpp (UnionRec / UnionParams), vbs_union.cpp (the plan) and DESIGN.md section 3.2 (6).
+//
+// What it multiplies.  At small block widths the reference's VBS of a cluster IS a dense (rows x |U|) tile over the union U of the columns its rows touch, stored back
+// to back, plus the ascending column list (src/general/vbr.cpp:177-228 at -b 1; its Jaccard distance is defined on those ids: src/general/blocking.cpp:923-994).  The
+// hybrid builder keeps such block-rows in exactly that form (vbs_build.cpp, mode 3): tiles of <= 64 consecutive reordered rows, 32 columns of the list per step.
+// C[tile rows, :] (+)= Atile . B[U, :] is then a GEMM whose B operand is GATHERED by row: B must be ROW-major here (one contiguous 512-byte piece per list entry and
+// 128-column slab; the host transposes the reference's column-major B once per product, or once per sparta_vbs_prepare_b -- the sparse-row kernels read the same copy).
+//
+// How.  A workgroup (four waves) owns a tile x one 128-column slab of C; wave v owns columns [32 v, 32 v + 32) x all the tile's rows: MI (1 or 2) accumulators of
+// 32 x 32, D = Bpanel^T . Atile^T as in the other kernels (a register holds 32 consecutive rows of one column of C).  A step's operands go HBM / L2 -> LDS with
+// LDS-direct loads (no staging registers), 1 KB per wave instruction:
+//   * the slice of A (32 MI rows x 32 k) is stored in HBM as the LDS image, in MFMA fragment order [rt][j][g][row][4] = A[32 rt + row][k = 16 g + 4 j + e]: a fragment
+//     read is one conflict-free ds_read_b128 per lane;
+//   * the panel of B is 32 rows of 512 bytes, LDS image Bs[k][128]: wave v fetches rows 8 v .. 8 v + 7, each through its OWN buffer descriptor (a 64-bit scalar base:
+//     row id x ldb -- B may be larger than the 4 GB a 32-bit offset spans), two rows per 1 KB piece: lanes 0..31 the even row, lanes 32..63 the odd one (the LDS-direct
+//     load writes lane l at base + 16 l whatever the exec mask).  Rows 16..31 are stored with their 16-byte chunks permuted (chunk c at position c ^ 8: the swizzle is
+//     on the SOURCE side, a lane fetches the chunk that belongs at its position), so that the MFMA-shaped read -- lanes 0..31 row k, lanes 32..63 row k + 16, one float
+//     each -- covers all 64 banks;
+//   * list positions behind the tile's last column get a descriptor of zero records: zeros in LDS without a memory access (no 0 x inf from a padding row).
+// One barrier per step: wait (counted vmcnt) for this wave's loads of step i, barrier, issue the loads of step i + NS - 1 into the stage step i - 1 has left, multiply
+// step i.  A worker walks WHOLE tiles (vbs_union.cpp deals them longest first); a tile's last step stores its rows of C (or adds to them: accumulate).
+#include "vbs_kernel_common.hpp"
+
+using namespace sparta_dev;
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#ifndef SPARTA_UNION_PROBE
+#define SPARTA_UNION_PROBE 0      /* developer probes, TIMING ONLY (results wrong): 1 no B loads, 2 no A loads, 4 no MFMAs, 16 no epilogue */
+#endif
+
+template <int MI, int NS>
+__global__ __launch_bounds__(256, 2) void vbs_union_f32_kernel(const UnionParams p) {
+    static_assert(MI == 1 || MI == 2, "one or two 32-row MFMA tiles per wave and step");
+    constexpr int A_BYTES = MI * 4096, B_BYTES = 32 * 512, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = MI;                               // 1 KB pieces of the slice of A per wave and step (4 MI pieces, four waves)
+    constexpr int LPS = 8 + NA;                          // vector-memory instructions per wave and step
+    constexpr int AHEAD = NS - 1;                        // steps between a step's loads and its MFMAs
+    static_assert((AHEAD - 1) * LPS <= 63, "vmcnt holds 6 bits");
+    static_assert(NS * STAGE * 2 <= 160 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 31, g = lane >> 5;
+    const int worker = (int)blockIdx.x, n0 = (int)blockIdx.y * kTN;
+    const int s_begin = p.worker_range[2 * worker];
+    const int n = p.worker_range[2 * worker + 1] - s_begin;
+    if (n <= 0) return;
+
+    // step records and list entries through the constant address space (scalar loads): per step this wave needs the record (two dwords) and ITS eight row ids
+    typedef const __attribute__((address_space(4))) int32_t* cptr_t;
+    const cptr_t srec = (cptr_t)(reinterpret_cast<const int32_t*>(p.rec + s_begin));
+    const cptr_t sids = (cptr_t)(p.ids + (int64_t)s_begin * 32 + 8 * wave);
+    struct Rec { int32_t c_row, info, id[8]; };
+    auto load_rec = [&](int j) __attribute__((always_inline)) -> Rec {
+        Rec r;
+        r.c_row = srec[(int64_t)j * 2]; r.info = srec[(int64_t)j * 2 + 1];
+#pragma unroll
+        for (int q = 0; q < 8; q++) r.id[q] = sids[(int64_t)j * 32 + q];
+        return r;
+    };
+
+    // ---- per-lane / per-wave constants ----
+    const int ncv = p.n_cols - n0;                                               // columns of this slab that exist (the last slab of a call may be narrower than 128)
+    const uint32_t row_bytes = ncv >= kTN ? 512u : (uint32_t)((ncv * 4 + 15) & ~15);   // (whole 16-byte chunks: ldb % 4 == 0, so the chunk is inside the row's allocation)
+    const uint32_t voffB = (uint32_t)(((lane & 31) ^ (wave >= 2 ? 8 : 0)) * 16);       // rows 16..31 (waves 2, 3): chunk c at position c ^ 8
+    const uint32_t voffA = (uint32_t)lane * 16u;
+    const float* const Bs0 = p.B + n0;
+    const float* const A0 = p.A + (int64_t)s_begin * (MI * 1024);
+    // fragment reads of B: row k = 16 g + kk, column 32 wave + lm at float position (32 wave + lm) ^ (32 g) of the row
+    const uint32_t rdB = (uint32_t)(16 * g * 512 + (((32 * wave + lm) ^ (32 * g)) * 4));
+    char* const lds0 = lds;
+
+    // the loads of one step (its record already in scalar registers) into `stage`
+    auto issue = [&](const Rec& rec, int j, int stage) __attribute__((always_inline)) {
+        char* const stp = lds0 + stage * STAGE;
+        const int nvalid = (rec.info >> 8) & 63;
+        if (!(SPARTA_UNION_PROBE & 2)) {
+            const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A0 + (int64_t)j * (MI * 1024)), 0, MI * 4096, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < NA; t++) {
+                const int q = wave * NA + t;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(stp + q * 1024), 16, voffA, (uint32_t)(q * 1024), 0, 0);
+            }
+        }
+        if (!(SPARTA_UNION_PROBE & 1)) {
+            // lanes 0..31 fetch the four even rows, lanes 32..63 the four odd ones: two divergent regions per step, every load in them under half an exec mask
+            auto half = [&](int odd) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r2 = 0; r2 < 4; r2++) {
+                    const int r = 2 * r2 + odd;
+                    const float* rp = Bs0 + (int64_t)rec.id[r] * p.ldb;
+                    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rp), 0, 8 * wave + r < nvalid ? row_bytes : 0u, 0x00020000);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(stp + A_BYTES + (4 * wave + r2) * 1024), 16, voffB, 0, 0, 0);
+                }
+            };
+            if (lane < 32) half(0); else half(1);
+        }
+    };
+
+    f32x16 acc[MI];
+#pragma unroll
+    for (int rt = 0; rt < MI; rt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[rt][r] = 0.0f;
+
+    // records of the steps in flight: info / c_row of step i are needed at its epilogue, long after its loads were issued
+    int32_t iq[NS], cq[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) { iq[k] = 0; cq[k] = 0; }
+#pragma unroll
+    for (int k = 0; k < AHEAD; k++) {                    // prologue: steps 0 .. AHEAD - 1
+        const Rec r = load_rec(k);
+        iq[k] = r.info; cq[k] = r.c_row;
+        issue(r, k, k);
+    }
+    Rec nxt = load_rec(AHEAD);                           // the record of the step whose loads the next iteration issues
+
+    const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 4 * g) * 4) : (uint32_t)((lm + (4 * g) * p.ldc) * 4);
+    const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;            // bytes per output column
+    const uint32_t mistep = p.c_row_major ? (uint32_t)p.ldc * 128u : 128u;       // bytes per 32 rows
+    const int ncw = ncv - 32 * wave;                                             // columns of this wave that exist
+
+    int stage = 0;
+    for (int i = 0; i < n; i++) {
+        // (1) this wave's loads of step i have landed: all but those of the AHEAD - 1 younger steps
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"((AHEAD - 1) * LPS) : "memory");
+        // (2) everybody's have, and everybody is done with the stage of step i - 1
+        __builtin_amdgcn_s_barrier();
+        // (3) the loads of step i + AHEAD go into that stage; the record of step i + AHEAD + 1 is requested for the next iteration
+        const Rec rec = nxt;
+        nxt = load_rec(i + AHEAD + 1);
+        int jstage = stage + AHEAD; if (jstage >= NS) jstage -= NS;
+        iq[AHEAD] = rec.info; cq[AHEAD] = rec.c_row;
+        issue(rec, i + AHEAD, jstage);
+        // (4) multiply step i
+        if (!(SPARTA_UNION_PROBE & 4)) {
+            const char* const sa = lds0 + stage * STAGE;
+            const char* const sb = sa + A_BYTES + rdB;
+            f32x4 af[MI][4];
+#pragma unroll
+            for (int rt = 0; rt < MI; rt++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) af[rt][j] = *reinterpret_cast<const f32x4*>(sa + (rt * 4 + j) * 1024 + lane * 16);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float bv = *reinterpret_cast<const float*>(sb + (4 * j + e) * 512);
+#pragma unroll
+                    for (int rt = 0; rt < MI; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, af[rt][j][e], acc[rt], 0, 0, 0);
+                }
+        }
+        const int32_t info = iq[0];
+        if ((info & UREC_LAST) && !(SPARTA_UNION_PROBE & 16)) {
+            const int mt = info & 127;
+            const int64_t c_row = cq[0];
+            float* cbase = p.c_row_major ? p.C + c_row * p.ldc + (n0 + 32 * wave) : p.C + c_row + (int64_t)(n0 + 32 * wave) * p.ldc;
+            const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+            for (int rt = 0; rt < MI; rt++) {
+                if (rt * 32 + lm < mt) {
+                    float v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) v[q] = acc[rt][q];
+                    if (p.accumulate) {
+                        uint32_t old[16];
+#pragma unroll
+                        for (int q = 0; q < 16; q++) {
+                            const int col = (q & 3) + 8 * (q >> 2);
+                            old[q] = col + 4 * g < ncw ? __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)col * jstep + (uint32_t)rt * mistep, 0) : 0u;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const int col = (q & 3) + 8 * (q >> 2);
+                        if (col + 4 * g < ncw) {
+                            if (p.c_nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)col * jstep + (uint32_t)rt * mistep, 2);
+                            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)col * jstep + (uint32_t)rt * mistep, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < MI; rt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[rt][r] = 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < AHEAD; k++) { iq[k] = iq[k + 1]; cq[k] = cq[k + 1]; }
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    // the loads issued past the end of the range (into LDS nobody reads any more) must land before the workgroup's LDS is handed on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace
+
+namespace sparta_dev {
+
+// mi = 1: the plan of the tiles of <= 32 rows; mi = 2: of the tiles of 33..64 rows.  grid = (workers, 128-column slabs)
+void launch_union_f32(int mi, dim3 grid, hipStream_t st, const UnionParams& p) {
+    if (mi == 2) hipLaunchKernelGGL((vbs_union_f32_kernel<2, 3>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((vbs_union_f32_kernel<1, 3>), grid, dim3(256), 0, st, p);
+}
+
+}  // namespace sparta_dev

@@ -7,6 +7,7 @@
 // table, O(nnz + touched blocks * log) instead of the reference's std::count over a bit-vector per
 // nonzero (:222, O(nnz * block_cols)); both passes run on all host cores (block-rows are independent).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -60,7 +61,41 @@ struct BlockCollector {
     }
 };
 
+// per-COLUMN nonzero counts of a run of reordered rows: a "part" of a column-compacted tile (UnionPlanHost) -- the rows of one block-row inside one tile
+struct ColCounter {
+    std::vector<int32_t> cnt;       // per column: stored nonzeros of the counted rows; all zero between uses
+    std::vector<int32_t> touched;   // the columns with cnt > 0, in order of first appearance
+    explicit ColCounter(int64_t cols) : cnt((size_t)cols, 0) {}
+    void count(const CsrView& a, const int64_t* perm, int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; r++) {
+            const int64_t i = perm[r];
+            if (i >= a.rows) continue;
+            const int32_t* cj = a.row(i);
+            const float* v = a.vals ? a.vals + a.rowptr[i] : nullptr;
+            const int64_t n = a.nnz_of(i);
+            for (int64_t k = 0; k < n; k++) {
+                if (v && v[k] == 0.0f) continue;
+                if (cnt[(size_t)cj[k]]++ == 0) touched.push_back(cj[k]);
+            }
+        }
+    }
+    void reset() { for (int32_t c : touched) cnt[(size_t)c] = 0; touched.clear(); }
+};
+
+// the parts of a block-row of h rows that becomes column-compacted tiles: chunks of 64 rows; a chunk of <= 32 rows is multiplied as ONE 32-row MFMA tile per step (MI = 1), a taller one as two
+inline int64_t union_parts(int64_t h) { return (h + 63) / 64; }
+inline int64_t union_part_rows(int64_t h, int64_t q) { return std::min<int64_t>(64, h - 64 * q); }
+
 }  // namespace
+
+// what a column of a column-compacted tile costs, in nonzeros of the sparse-row path: a 32-deep step of a 32-row tile is worth K_union of them (SPARTA_UNION_K, default 36:
+// the 24 of a w-wide block step + the list entry, the gathered row of B and 128 bytes of A per column); a column is kept in the tile when its rows hold at least that
+// many nonzeros (never fewer than 2: a column one row uses is a sparse-row entry)
+double union_col_cost(int mi) {
+    static const double K_union = [] { const char* e = std::getenv("SPARTA_UNION_K"); return e ? std::max(1.0, atof(e)) : 36.0; }();
+    return K_union * (double)mi / 32.0;
+}
+int32_t union_min_count(int mi) { return std::max<int32_t>(2, (int32_t)std::ceil(union_col_cost(mi))); }
 
 int vbs_build(const CsrView& a, const int64_t* grouping, int64_t w, int64_t row_block_size, bool force_fixed,
               sparta_vbs_host* out) {
@@ -126,10 +161,10 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
     // per step, not the ~15-24 of rows of B that come from HBM (scripts/sparse_k_sweep.py)
     const double K_block = [] { const char* e = std::getenv("SPARTA_SPARSE_K_BLOCK"); return e ? atof(e) : 60.0; }();
     auto spb_of = [&](int64_t h) { return (double)((w + kdep - 1) / kdep) * (double)((h + 31) / 32); };
-    struct RowMode { uint8_t mode; int64_t n_dense; double saved; };
+    struct RowMode { uint8_t mode; int64_t n_dense; double saved; double cost, c_dense; };
     auto decide = [&](const BlockCollector& bc, int64_t h) {
         const int64_t nb = (int64_t)bc.touched.size();
-        RowMode r{0, nb, 0.0};
+        RowMode r{0, nb, 0.0, 0.0, 0.0};
         if (!hybrid || nb == 0 || h <= 0) return r;
         const double spb = spb_of(h), kb = K * spb, kbb = K_block * spb;
         int64_t n_dense = 0;
@@ -140,9 +175,43 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
             if (c >= kbb) n_dense++; else nnz_rest += c;
         }
         const double c_dense = (double)nb * kb, c_sparse = nnz, c_mixed = (double)n_dense * kb + nnz_rest + (double)h * rmw_cost;
-        if (c_sparse < c_dense && c_sparse <= c_mixed) { r.mode = 1; r.n_dense = 0; r.saved = (c_dense - c_sparse) / K; }
-        else if (n_dense > 0 && n_dense < nb && c_mixed < c_dense) { r.mode = 2; r.n_dense = n_dense; r.saved = (c_dense - c_mixed) / K; }
+        r.cost = r.c_dense = c_dense;
+        if (c_sparse < c_dense && c_sparse <= c_mixed) { r.mode = 1; r.n_dense = 0; r.saved = (c_dense - c_sparse) / K; r.cost = c_sparse; }
+        else if (n_dense > 0 && n_dense < nb && c_mixed < c_dense) { r.mode = 2; r.n_dense = n_dense; r.saved = (c_dense - c_mixed) / K; r.cost = c_mixed; }
         return r;
+    };
+    // mode 3 (sp->want_union): the block-row as column-compacted tiles -- per part (chunk of <= 64 rows) the columns at least union_min_count of its rows use, as one dense
+    // tile + the column list; the nonzeros of the other columns are sparse rows that ADD (as in mode 2).   cost  sum_parts |U| * union_col_cost + nnz_rest + rows_rest * rmw
+    // Chosen when that is below SPARTA_UNION_MARGIN (default 0.8) x the best of the three modes above.
+    const bool want_union = hybrid && sp->want_union && [] { const char* e = std::getenv("SPARTA_UNION"); return !(e && atoi(e) == 0); }();
+    const double union_margin = [] { const char* e = std::getenv("SPARTA_UNION_MARGIN"); return e ? atof(e) : 0.8; }();
+    struct UnionEval { double cost; int64_t rows_rest, ent_rest, nnz_in; std::vector<int32_t> nu; };
+    auto eval_union = [&](ColCounter& cc, int64_t r0, int64_t r1) {
+        UnionEval u{0.0, 0, 0, 0, {}};
+        const int64_t h = r1 - r0;
+        for (int64_t q = 0; q < union_parts(h); q++) {
+            const int64_t p0 = r0 + 64 * q, p1 = p0 + union_part_rows(h, q);
+            const int mi = p1 - p0 > 32 ? 2 : 1;
+            const int32_t cmin = union_min_count(mi);
+            cc.count(a, perm.data(), p0, p1);
+            int64_t nu = 0;
+            for (int32_t c : cc.touched) if (cc.cnt[(size_t)c] >= cmin) { nu++; u.nnz_in += cc.cnt[(size_t)c]; }
+            u.nu.push_back((int32_t)nu);
+            u.cost += (double)nu * union_col_cost(mi);
+            for (int64_t rr = p0; rr < p1; rr++) {                   // the rows' nonzeros in thinly used columns
+                const int64_t i = perm[(size_t)rr];
+                if (i >= a.rows) continue;
+                const int32_t* cj = a.row(i);
+                const float* v = a.vals ? a.vals + a.rowptr[i] : nullptr;
+                const int64_t n = a.nnz_of(i);
+                int64_t mine = 0;
+                for (int64_t k = 0; k < n; k++) mine += (!v || v[k] != 0.0f) && cc.cnt[(size_t)cj[k]] < cmin;
+                u.ent_rest += mine; u.rows_rest += mine > 0;
+            }
+            cc.reset();
+        }
+        u.cost += (double)u.ent_rest + (double)u.rows_rest * rmw_cost;
+        return u;
     };
 
     BuildTrace trace("vbs_build");
@@ -151,9 +220,12 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
     std::vector<double> saved_row((size_t)block_rows, 0.0);           // MFMA steps the chosen mode saves against "all tiles"
     std::vector<int64_t> sp_rows_of(hybrid ? (size_t)block_rows : 0, 0), sp_ent_of(hybrid ? (size_t)block_rows : 0, 0), nb_all(hybrid ? (size_t)block_rows : 0, 0);
     std::vector<int64_t> nnz_all(hybrid ? (size_t)block_rows : 0, 0);  // stored nonzeros of the block-row (all blocks)
+    std::vector<std::vector<int32_t>> nu_parts(want_union ? (size_t)block_rows : 0);   // mode 3: columns kept per part
+    std::vector<int64_t> union_nnz_of(want_union ? (size_t)block_rows : 0, 0);
     const int64_t grain = std::max<int64_t>(1, std::min<int64_t>(64, block_rows / (8 * (int64_t)host_threads()) + 1));
     parallel_for_dynamic(block_rows, grain, [&](int64_t lo, int64_t hi, int) {
         BlockCollector bc(block_cols, hybrid);
+        ColCounter cc(want_union ? cols : 0);
         for (int64_t ib = lo; ib < hi; ib++) {
             const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
             bc.collect(a, perm.data(), r0, r1, w, bc.next_tag());
@@ -164,6 +236,22 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
             if (!hybrid) continue;
             nb_all[(size_t)ib] = (int64_t)bc.touched.size();
             for (int32_t jb : bc.touched) nnz_all[(size_t)ib] += bc.count[(size_t)jb];
+            // column-compacted tiles?  Only where they CAN win: every column holds at most h nonzeros, so the tiles cost at least nnz / h columns
+            if (want_union && h >= 2 && !bc.touched.empty()) {
+                const double lower = (double)nnz_all[(size_t)ib] / (double)h * union_col_cost(h > 32 ? 2 : 1);
+                if (lower < union_margin * r.cost) {
+                    UnionEval u = eval_union(cc, r0, r1);
+                    if (u.nnz_in > 0 && u.cost < union_margin * r.cost) {
+                        mode[(size_t)ib] = 3;
+                        out->nzcount[ib] = 0;
+                        saved_row[(size_t)ib] = (r.c_dense - u.cost) / K;
+                        sp_rows_of[(size_t)ib] = u.rows_rest; sp_ent_of[(size_t)ib] = u.ent_rest;
+                        nu_parts[(size_t)ib].swap(u.nu);
+                        union_nnz_of[(size_t)ib] = u.nnz_in;
+                        continue;
+                    }
+                }
+            }
             if (r.mode == 1) {                                            // every row of the block-row is a sparse row (padded and empty ones too)
                 int64_t ent = 0;
                 for (int32_t jb : bc.touched) ent += bc.count[(size_t)jb];
@@ -200,8 +288,22 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                 mode[(size_t)ib] = 0;
                 out->nzcount[ib] = nb_all[(size_t)ib];
                 sp_rows_of[(size_t)ib] = sp_ent_of[(size_t)ib] = 0;
+                if (want_union) { nu_parts[(size_t)ib].clear(); union_nnz_of[(size_t)ib] = 0; }
             }
         }
+        // steps / stored elements of the column-compacted tiles of block-row ib (mode 3)
+        auto union_steps_of = [&](int64_t ib) {
+            double st = 0.0;
+            const int64_t h = part[(size_t)ib + 1] - part[(size_t)ib];
+            for (size_t q = 0; q < nu_parts[(size_t)ib].size(); q++) st += (double)((nu_parts[(size_t)ib][q] + 31) / 32) * (union_part_rows(h, (int64_t)q) > 32 ? 2.0 : 1.0);
+            return st;
+        };
+        auto union_area_of = [&](int64_t ib) {
+            double ar = 0.0;
+            const int64_t h = part[(size_t)ib + 1] - part[(size_t)ib];
+            for (size_t q = 0; q < nu_parts[(size_t)ib].size(); q++) ar += (double)nu_parts[(size_t)ib][q] * (double)union_part_rows(h, (int64_t)q);
+            return ar;
+        };
         // SMALL matrices: every launch of a product costs ~5-10 us whatever it does, and the MFMA part needs up to five (panel tail copy, one per tile
         // type, fix-up, zero fill) where the sparse-row kernels need the ones they run anyway.  When the tiles of the whole matrix hold fewer nonzeros than
         // their steps + those launches are worth (a launch ~ SPARTA_LAUNCH_NNZ = 50 000 gathered nonzeros ~ 5 us), EVERYTHING goes to the sparse rows:
@@ -211,8 +313,9 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
             double tile_steps = 0.0, tile_nnz = 0.0, tile_area = 0.0;
             for (int64_t ib = 0; ib < block_rows; ib++) {
                 if (mode[(size_t)ib] == 1) continue;
-                tile_steps += (double)out->nzcount[ib] * spb_of(part[(size_t)ib + 1] - part[(size_t)ib]);
                 tile_nnz += (double)(nnz_all[(size_t)ib] - sp_ent_of[(size_t)ib]);
+                if (mode[(size_t)ib] == 3) { tile_steps += union_steps_of(ib); tile_area += union_area_of(ib); continue; }
+                tile_steps += (double)out->nzcount[ib] * spb_of(part[(size_t)ib + 1] - part[(size_t)ib]);
                 tile_area += (double)out->nzcount[ib] * (double)(part[(size_t)ib + 1] - part[(size_t)ib]) * (double)w;
             }
             // ... and only when the tiles are not DENSE (fill below a half): a small dense matrix stays on the MFMA kernels (and keeps its dense image: the
@@ -227,6 +330,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                     out->nzcount[ib] = 0;
                     sp_rows_of[(size_t)ib] = h;
                     sp_ent_of[(size_t)ib] = nnz_all[(size_t)ib];
+                    if (want_union) { nu_parts[(size_t)ib].clear(); union_nnz_of[(size_t)ib] = 0; }
                 }
             }
         }
@@ -240,6 +344,10 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                 st.mfma_steps += (double)out->nzcount[ib] * spb_of(h);
                 st.sparse_nnz += sp_ent_of[(size_t)ib];
                 st.sparse_rows += sp_rows_of[(size_t)ib];
+                if (mode[(size_t)ib] == 3) {
+                    st.union_block_rows++; st.union_steps += union_steps_of(ib); st.union_nnz += union_nnz_of[(size_t)ib];
+                    for (int32_t nu : nu_parts[(size_t)ib]) st.union_cols += nu;
+                }
             }
             *stats_only = st;
             return SPARTA_OK;
@@ -257,7 +365,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
         parallel_for_dynamic(block_rows, grain, [&](int64_t lo, int64_t hi, int) {
             BlockCollector bc(block_cols, true);
             for (int64_t ib = lo; ib < hi; ib++) {
-                if (!mode[(size_t)ib]) continue;
+                if (!mode[(size_t)ib] || mode[(size_t)ib] == 3) continue;     // (mode 3: filled with its tiles, below)
                 const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
                 const bool mixed = mode[(size_t)ib] == 2;
                 double kbb = 0.0;
@@ -285,6 +393,88 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
             }
         });
         trace.lap("sparse rows (collect)");
+
+        // ---- mode 3: the column-compacted tiles.  Parts become tiles in row order: a part of 33..64 rows is a tile of its own (ty 1); parts of <= 32 rows are packed --
+        // consecutive rows only -- into tiles of <= 32 rows (ty 0), each part with its own columns (a tile of several parts is block-diagonal: the parts' column lists
+        // back to back).  Then every block-row fills its parts: ascending column list, dense values, and the nonzeros of the thinly used columns as sparse rows that ADD.
+        if (want_union) {
+            UnionPlanHost& U = sp->uni;
+            struct PartAt { int8_t ty; int32_t tile, ro; int64_t ko; };
+            std::vector<int64_t> part_base((size_t)block_rows + 1, 0);
+            for (int64_t ib = 0; ib < block_rows; ib++) part_base[(size_t)ib + 1] = part_base[(size_t)ib] + (int64_t)nu_parts[(size_t)ib].size();
+            std::vector<PartAt> at((size_t)part_base[(size_t)block_rows]);
+            for (int64_t ib = 0; ib < block_rows; ib++) {
+                if (mode[(size_t)ib] != 3) continue;
+                const int64_t r0 = part[(size_t)ib], h = part[(size_t)ib + 1] - r0;
+                for (size_t q = 0; q < nu_parts[(size_t)ib].size(); q++) {
+                    const int64_t p0 = r0 + 64 * (int64_t)q, len = union_part_rows(h, (int64_t)q);
+                    const int ty = len > 32 ? 1 : 0;
+                    const int32_t nu = nu_parts[(size_t)ib][q];
+                    std::vector<UnionPlanHost::Tile>& T = U.tiles[ty];
+                    const bool join = ty == 0 && !T.empty() && (int64_t)T.back().c_row + T.back().mt == p0 && T.back().mt + len <= 32;
+                    if (!join) T.push_back(UnionPlanHost::Tile{(int32_t)p0, 0, (int64_t)U.cols[ty].size(), 0, 0});
+                    UnionPlanHost::Tile& t = T.back();
+                    at[(size_t)part_base[(size_t)ib] + q] = PartAt{(int8_t)ty, (int32_t)(T.size() - 1), t.mt, (int64_t)t.nk};
+                    t.mt += (int32_t)len; t.nk += nu;
+                    U.cols[ty].resize(U.cols[ty].size() + (size_t)nu);
+                }
+                U.nnz += union_nnz_of[(size_t)ib];
+            }
+            for (int ty = 0; ty < 2; ty++) {
+                int64_t o = 0;
+                U.a_off[ty].assign(U.tiles[ty].size() + 1, 0);
+                for (size_t t = 0; t < U.tiles[ty].size(); t++) { U.a_off[ty][t] = o; o += (int64_t)U.tiles[ty][t].nk * 32 * (ty + 1); }
+                U.a_off[ty][U.tiles[ty].size()] = o;
+                U.a[ty].assign((size_t)o, 0.0f);
+            }
+            parallel_for_dynamic(block_rows, grain, [&](int64_t lo, int64_t hi, int) {
+                ColCounter cc(cols);
+                std::vector<int32_t> list;
+                for (int64_t ib = lo; ib < hi; ib++) {
+                    if (mode[(size_t)ib] != 3) continue;
+                    const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
+                    int64_t t = row_base[(size_t)ib], e = ent_base[(size_t)ib];
+                    for (size_t q = 0; q < nu_parts[(size_t)ib].size(); q++) {
+                        const int64_t p0 = r0 + 64 * (int64_t)q, p1 = p0 + union_part_rows(h, (int64_t)q);
+                        const PartAt pa = at[(size_t)part_base[(size_t)ib] + q];
+                        const int mi = pa.ty + 1;
+                        const int32_t cmin = union_min_count(mi);
+                        const UnionPlanHost::Tile& tl = U.tiles[pa.ty][(size_t)pa.tile];
+                        cc.count(a, perm.data(), p0, p1);
+                        list.clear();
+                        for (int32_t c : cc.touched) if (cc.cnt[(size_t)c] >= cmin) list.push_back(c);
+                        std::sort(list.begin(), list.end());
+                        // (cnt doubles as the position table: a kept column -> -(position + 1); the others keep their small positive count)
+                        for (size_t k = 0; k < list.size(); k++) { U.cols[pa.ty][(size_t)(tl.k0 + pa.ko) + k] = list[k]; cc.cnt[(size_t)list[k]] = -(int32_t)(k + 1); }
+                        float* img = U.a[pa.ty].data() + U.a_off[pa.ty][(size_t)pa.tile];
+                        const int64_t ldt = 32 * mi;
+                        for (int64_t r = p0; r < p1; r++) {
+                            const int64_t i = perm[(size_t)r];
+                            const int64_t before = e;
+                            if (i < a.rows) {
+                                const int32_t* cj = a.row(i);
+                                const float* v = a.vals ? a.vals + a.rowptr[i] : nullptr;
+                                const int64_t n = a.nnz_of(i);
+                                for (int64_t k = 0; k < n; k++) {
+                                    const float x = v ? v[k] : 1.0f;
+                                    if (x == 0.0f) continue;
+                                    const int32_t c = cc.cnt[(size_t)cj[k]];
+                                    if (c < 0) img[(pa.ko + (int64_t)(-c - 1)) * ldt + pa.ro + (r - p0)] = x;
+                                    else { sp->col[(size_t)e] = cj[k]; sp->val[(size_t)e] = x; e++; }
+                                }
+                            }
+                            if (e == before) continue;                            // the tile writes all of this row
+                            sp->crow[(size_t)t] = (int32_t)r;
+                            sp->row_add[(size_t)t] = 1;
+                            sp->rowptr[(size_t)t + 1] = e;
+                            t++;
+                        }
+                        cc.reset();
+                    }
+                }
+            });
+            trace.lap("column-compacted tiles");
+        }
     }
 
     // offsets
@@ -306,7 +496,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
         BlockCollector bc(block_cols, hybrid);
         for (int64_t ib = lo; ib < hi; ib++) {
             const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
-            if (mode[(size_t)ib] == 1) continue;                          // not materialised
+            if (mode[(size_t)ib] == 1 || mode[(size_t)ib] == 3) continue;  // not materialised as w-wide blocks
             bc.collect(a, perm.data(), r0, r1, w, bc.next_tag());
             const bool mixed = mode[(size_t)ib] == 2;
             if (mixed) {                                                  // keep the well-filled blocks only; slot = -1 marks the others

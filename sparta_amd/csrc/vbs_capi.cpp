@@ -105,6 +105,12 @@ void destroy_impl(sparta_vbs* v) {
     if (v->cr_small.parts) (void)hipFree(v->cr_small.parts);
     if (v->d_cr_dest) (void)hipFree(v->d_cr_dest);
     if (v->d_cr_longs) (void)hipFree(v->d_cr_longs);
+    for (int ty = 0; ty < 2; ty++) {
+        if (v->d_u_rec[ty]) (void)hipFree(v->d_u_rec[ty]);
+        if (v->d_u_ids[ty]) (void)hipFree(v->d_u_ids[ty]);
+        if (v->d_u_a[ty]) (void)hipFree(v->d_u_a[ty]);
+        if (v->d_u_wrange[ty]) (void)hipFree(v->d_u_wrange[ty]);
+    }
     if (v->d_Brm) (void)hipFree(v->d_Brm);
     if (v->d_B) (void)hipFree(v->d_B);
     if (v->d_C) (void)hipFree(v->d_C);
@@ -413,7 +419,8 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         // (nzcount / jab hold only those), the nonzeros of its other blocks are sparse rows that ADD to C (bit 31 of their crow entry)
         sparse_flag.assign(ext->flag.size(), 0);
         bool any = false;
-        for (size_t q = 0; q < ext->flag.size(); q++) { sparse_flag[q] = ext->flag[q] == 1; any = any || sparse_flag[q]; }
+        // (flag 3: column-compacted tiles, UnionPlanHost -- no w-wide block either; their thinly used columns are sparse rows that add, as for flag 2)
+        for (size_t q = 0; q < ext->flag.size(); q++) { sparse_flag[q] = ext->flag[q] == 1 || ext->flag[q] == 3; any = any || sparse_flag[q]; }
         if (!any) sparse_flag.clear();
         // the entries that survive the storage type (a value that rounds to zero is a zero) and lie inside the matrix: counted, then
         // copied, on all host threads (10^8..10^9 entries on the power-law configs)
@@ -718,6 +725,13 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         if (int rc = build_stream_plans(pin, plan)) return rc;
         trace.lap("stream plans");
     }
+    UnionDevPlan uplan;
+    if (ext && !ext->uni.empty()) {
+        int n_cus = 256;
+        if (!plan_debug) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) n_cus = pr.multiProcessorCount; }
+        if (int rc = build_union_plan(ext->uni, 2 * n_cus, uplan)) return rc;
+        trace.lap("column-compacted tiles (plan)");
+    }
     std::vector<StepRec>(&steps)[2] = plan.steps;
     std::vector<int32_t>(&wrange)[2] = plan.wrange;
     std::vector<FixRec>& fix = plan.fix;
@@ -841,6 +855,21 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         CREATE_TRY(hipMalloc((void**)&v->d_fix_slots, std::max<size_t>(fix_slots.size(), 1) * sizeof(int32_t)));
         if (!fix_slots.empty()) CREATE_TRY(hipMemcpy(v->d_fix_slots, fix_slots.data(), fix_slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    for (int ty = 0; ty < 2; ty++) {
+        if (uplan.n_steps[ty] == 0) continue;
+        v->u_workers[ty] = uplan.n_workers[ty]; v->u_steps[ty] = uplan.n_steps[ty]; v->u_tiles[ty] = (int64_t)ext->uni.tiles[ty].size();
+        CREATE_TRY(hipMalloc((void**)&v->d_u_rec[ty], uplan.rec[ty].size() * sizeof(UnionRec)));
+        CREATE_TRY(hipMemcpy(v->d_u_rec[ty], uplan.rec[ty].data(), uplan.rec[ty].size() * sizeof(UnionRec), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc((void**)&v->d_u_ids[ty], uplan.ids[ty].size() * sizeof(int32_t)));
+        CREATE_TRY(hipMemcpy(v->d_u_ids[ty], uplan.ids[ty].data(), uplan.ids[ty].size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc((void**)&v->d_u_a[ty], uplan.a[ty].size() * sizeof(float)));
+        CREATE_TRY(hipMemcpy(v->d_u_a[ty], uplan.a[ty].data(), uplan.a[ty].size() * sizeof(float), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc((void**)&v->d_u_wrange[ty], uplan.wrange[ty].size() * sizeof(int32_t)));
+        CREATE_TRY(hipMemcpy(v->d_u_wrange[ty], uplan.wrange[ty].data(), uplan.wrange[ty].size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        v->a_bytes += (int64_t)(uplan.a[ty].size() * sizeof(float) + uplan.ids[ty].size() * sizeof(int32_t));
+        v->exec_area += uplan.n_steps[ty] * 32 * 32 * (ty + 1);
+    }
+    if (ext) { v->u_area = uplan.area; v->u_cols = uplan.cols; v->u_nnz = ext->uni.nnz; }
     if (!sp_crow.empty()) {
         v->n_sp_rows = (int64_t)sp_crow.size(); v->n_sp_short = n_sp_short; v->n_sp_long = n_sp_long; v->sp_nnz = sp_rowptr.back();
         CREATE_TRY(hipMalloc((void**)&v->d_sp_rowptr, sp_rowptr.size() * sizeof(int64_t)));
@@ -964,6 +993,7 @@ static int create_from_csr_impl(sparta_vbs_t** out, int64_t rows, int64_t cols, 
         const int64_t kdep = (dtype != SPARTA_F32 && col_block_size % 64 == 0) ? 64 : 32;
         sparta::HybridSparse sp;
         sp.esz = dtype == SPARTA_F32 ? 4.0 : 2.0;
+        sp.want_union = dtype == SPARTA_F32;                               // column-compacted tiles: fp32 handles (k_union.hip)
         rc = sparta::vbs_build_hybrid(a, grouping, col_block_size, row_block_size, force_fixed_size != 0, K, kdep, &h, K > 0.0 ? &sp : nullptr, keep_order);
         if (rc == SPARTA_OK)
             rc = create_core(out, h.rows, h.cols, h.block_rows, col_block_size, h.row_part, h.nzcount, h.jab, h.mab, 0, h.block_rows, dtype, device,
@@ -992,6 +1022,7 @@ int sparta_vbs_plan_stats(int64_t rows, int64_t cols, const int64_t* rowptr, con
     const int64_t kdep = (dtype != SPARTA_F32 && col_block_size % 64 == 0) ? 64 : 32;
     sparta::HybridSparse sp;
     sp.esz = dtype == SPARTA_F32 ? 4.0 : 2.0;
+    sp.want_union = dtype == SPARTA_F32;
     sparta::HybridStats st;
     sparta_vbs_host h;
     std::memset(&h, 0, sizeof(h));
@@ -999,7 +1030,7 @@ int sparta_vbs_plan_stats(int64_t rows, int64_t cols, const int64_t* rowptr, con
     sparta_vbs_host_free(&h);
     if (rc != SPARTA_OK) return rc;
     stats[0] = st.tile_blocks; stats[1] = st.tile_area; stats[2] = (int64_t)(st.mfma_steps + 0.5); stats[3] = st.sparse_nnz; stats[4] = st.sparse_rows;
-    stats[5] = st.block_rows; stats[6] = st.rows; stats[7] = 0;
+    stats[5] = st.block_rows; stats[6] = st.rows; stats[7] = (int64_t)(st.union_steps + 0.5);     // [7]: 32 x 32 steps of the column-compacted tiles (k_union.hip), not in [2]
     return SPARTA_OK;
     SPARTA_GUARD_END("sparta_vbs_plan_stats")
 }
@@ -1102,6 +1133,13 @@ int sparta_vbs_hub_info(const sparta_vbs_t* A, int64_t* info) {
     return SPARTA_OK;
 }
 
+int sparta_vbs_union_info(const sparta_vbs_t* A, int64_t* info) {
+    if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_union_info: NULL argument");
+    info[0] = A->u_tiles[0]; info[1] = A->u_tiles[1]; info[2] = A->u_steps[0]; info[3] = A->u_steps[1];
+    info[4] = A->u_area; info[5] = A->u_cols; info[6] = A->u_nnz; info[7] = A->u_workers[0] + A->u_workers[1];
+    return SPARTA_OK;
+}
+
 int sparta_vbs_sparse_info(const sparta_vbs_t* A, int64_t* info) {
     if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_sparse_info: NULL argument");
     info[0] = A->n_sp_rows; info[1] = A->sp_nnz; info[2] = A->n_sp_short; info[3] = A->n_sp_long;
@@ -1180,6 +1218,48 @@ int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, 
     info[8] = (int64_t)H.parts.size(); info[9] = n_ranges;
     return SPARTA_OK;
     SPARTA_GUARD_END("sparta_colres_host_check")
+}
+
+// the hybrid image of a CSR matrix under `grouping`, built exactly as sparta_vbs_create_from_csr builds it for an fp32 handle -- w-wide tiles, column-compacted tiles,
+// sparse rows -- and multiplied with ONE column x on the HOST: the w-wide tiles from the reference-layout image, the column-compacted tiles by walking their DEVICE
+// form (per-worker step records, list entries, fragment-order slices: vbs_union.cpp), the sparse rows entry by entry.  What the CPU suite checks the mode-3 builder
+// and the plan with (no GPU involved; not a product path).  y: [padded rows], reordered order, double.
+int sparta_union_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals, const int64_t* grouping, int64_t col_block_size,
+                            int64_t row_block_size, int32_t force_fixed_size, int32_t max_workers, const float* x, double* y, int64_t* info) {
+    using sparta::fail;
+    SPARTA_GUARD_BEGIN
+    if (!rowptr || !colidx || !grouping || !x || !y || !info || max_workers <= 0) return fail(SPARTA_ERR_INVALID, "sparta_union_host_check: bad argument");
+    sparta::CsrView a;
+    a.rows = rows; a.cols = cols; a.rowptr = rowptr; a.colidx = colidx; a.vals = vals;
+    double K = 24.0;
+    if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
+    if (!(K > 0.0)) return fail(SPARTA_ERR_INVALID, "sparta_union_host_check: the hybrid builder is switched off (SPARTA_SPARSE_K=0)");
+    sparta::HybridSparse sp;
+    sp.esz = 4.0; sp.want_union = true;
+    sparta_vbs_host h;
+    std::memset(&h, 0, sizeof(h));
+    struct Free { sparta_vbs_host* p; ~Free() { sparta_vbs_host_free(p); } } guard{&h};
+    if (int rc = sparta::vbs_build_hybrid(a, grouping, col_block_size, row_block_size, force_fixed_size != 0, K, 32, &h, &sp)) return rc;
+    for (int64_t r = 0; r < h.rows; r++) y[r] = 0.0;
+    int64_t jo = 0, mo = 0;
+    for (int64_t ib = 0; ib < h.block_rows; ib++) {                       // the w-wide tiles
+        const int64_t r0 = h.row_part[ib], hh = h.row_part[ib + 1] - r0;
+        for (int64_t b = 0; b < h.nzcount[ib]; b++, jo++, mo += hh * col_block_size)
+            for (int64_t k = 0; k < col_block_size && h.jab[jo] * col_block_size + k < cols; k++)
+                for (int64_t i = 0; i < hh; i++) y[r0 + i] += (double)h.mab[mo + k * hh + i] * (double)x[h.jab[jo] * col_block_size + k];
+    }
+    UnionDevPlan P;
+    if (!sp.uni.empty()) {
+        if (int rc = build_union_plan(sp.uni, max_workers, P)) return rc;
+        union_plan_host_apply(P, x, y);
+    }
+    for (size_t t = 0; t < sp.crow.size(); t++)                           // the sparse rows (they own their row or add to it: y started at zero either way)
+        for (int64_t k = sp.rowptr[t]; k < sp.rowptr[t + 1]; k++) y[sp.crow[t]] += (double)sp.val[(size_t)k] * (double)x[sp.col[(size_t)k]];
+    info[0] = (int64_t)sp.uni.tiles[0].size(); info[1] = (int64_t)sp.uni.tiles[1].size(); info[2] = P.n_steps[0]; info[3] = P.n_steps[1];
+    info[4] = P.area; info[5] = P.cols; info[6] = sp.uni.nnz; info[7] = sp.rowptr.empty() ? 0 : sp.rowptr.back();
+    info[8] = h.nztot; info[9] = h.rows; info[10] = P.n_workers[0]; info[11] = P.n_workers[1];
+    return SPARTA_OK;
+    SPARTA_GUARD_END("sparta_union_host_check")
 }
 
 int sparta_vbs_colres_info(const sparta_vbs_t* A, int64_t* info) {
@@ -1293,6 +1373,55 @@ void drop_legacy_image(sparta_vbs_t* A) {
     A->legacy_dropped = true;
 }
 
+// The ROW-major B of the product in flight (A->brm_ready / brm_ld; cleared when the product returns): B itself when the call's B is row-major, the caller's prepared
+// copy (sparta_vbs_prepare_b), or a transposed copy made now -- ONCE per product, whoever asks first (the column-compacted tiles, then the sparse rows).  `aligned16`:
+// rows must start on 16-byte boundaries (k_union.hip loads them 16 bytes per lane); the copies made here always do (row stride rounded up to 16 bytes).
+int ensure_brm(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_major, int64_t shard_rows, int64_t shard_stride, int bk, int32_t n_cols, hipStream_t st,
+               bool aligned16) {
+    if (A->brm_ready) return SPARTA_OK;
+    const size_t esz = bk == 0 ? 4 : 2;
+    const int64_t per16 = 16 / (int64_t)esz;
+    if (b_row_major && shard_rows == 0 && (!aligned16 || (ldb % per16 == 0 && ((uintptr_t)dB % 16) == 0))) { A->brm_ready = dB; A->brm_ld = ldb; return SPARTA_OK; }
+    if (A->prepared_brm && !b_row_major) { A->brm_ready = A->prepared_brm; A->brm_ld = A->prepared_ld; return SPARTA_OK; }
+    if (g_capturing && A->d_Brm_bytes < (size_t)A->cols * (size_t)((n_cols + per16 - 1) / per16 * per16) * esz) return capture_refusal("allocate the row-major copy of B");
+    const int64_t ld = (n_cols + per16 - 1) / per16 * per16;
+    if (int rc = ensure_scratch(&A->d_Brm, &A->d_Brm_bytes, (size_t)A->cols * (size_t)ld * esz)) return rc;
+    if (b_row_major) {                                   // (a row-major B whose rows are not 16-byte aligned: an aligned copy)
+        HIP_TRY(hipMemcpy2DAsync(A->d_Brm, (size_t)ld * esz, dB, (size_t)ldb * esz, (size_t)n_cols * esz, (size_t)A->cols, hipMemcpyDeviceToDevice, st));
+    } else {
+        const int64_t n_wg = ((A->cols + 63) / 64) * (int64_t)((n_cols + 63) / 64);
+        if (n_wg > INT32_MAX) return sparta::fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: B too large for the transpose grid");
+        launch_b_to_row_major(bk != 0, (unsigned)n_wg, st, dB, ldb, shard_rows, shard_stride, A->cols, (int)n_cols, A->d_Brm, ld);
+    }
+    A->brm_ready = A->d_Brm; A->brm_ld = ld;
+    return SPARTA_OK;
+}
+
+// the column-compacted tiles (k_union.hip): C[tile rows, :] (+)= Atile . B[list, :] on the matrix cores, B row-major.  Stores (or adds to) every row of its tiles;
+// the sparse rows of those block-rows (their thinly used columns) add behind it on the same stream.
+int launch_union_tiles(sparta_vbs_t* A, const float* dB, int64_t ldb, bool b_row_major, int64_t shard_rows, int64_t shard_stride, int32_t n_cols, float* dC,
+                       int64_t ldc, bool c_row_major, bool accumulate, hipStream_t st) {
+    if (A->u_steps[0] + A->u_steps[1] == 0) return SPARTA_OK;
+    // 32-bit byte offsets inside a tile's 64 rows x 32 columns of C
+    if ((c_row_major ? 64 * ldc + 128 : 32 * ldc + 128) * 4 >= ((int64_t)1 << 31) - 65536)
+        return sparta::fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: leading dimension of C too large for the column-compacted tile kernel (32-bit offsets inside a tile)");
+    if (int rc = ensure_brm(A, dB, ldb, b_row_major, shard_rows, shard_stride, 0, n_cols, st, true)) return rc;
+    UnionParams up;
+    up.B = (const float*)A->brm_ready; up.ldb = A->brm_ld; up.C = dC; up.ldc = ldc;
+    up.n_cols = n_cols; up.accumulate = accumulate ? 1 : 0; up.c_row_major = c_row_major ? 1 : 0;
+    const unsigned n_slabs = (unsigned)((n_cols + kTN - 1) / kTN);
+    for (int ty = 1; ty >= 0; ty--) {
+        if (A->u_steps[ty] == 0) continue;
+        up.rec = A->d_u_rec[ty]; up.ids = A->d_u_ids[ty]; up.A = A->d_u_a[ty]; up.worker_range = A->d_u_wrange[ty];
+        // C is written once and never read back: non-temporal stores where tiles are long (as the stream kernels: vbs_kernel_common.hpp); SPARTA_C_NT=0|1 forces one
+        const char* e = std::getenv("SPARTA_C_NT");
+        up.c_nt = e ? (atoi(e) != 0) : (A->u_steps[ty] >= 6 * A->u_tiles[ty] ? 1 : 0);
+        launch_union_f32(ty + 1, dim3((unsigned)A->u_workers[ty], n_slabs), st, up);
+    }
+    HIP_TRY(hipGetLastError());
+    return SPARTA_OK;
+}
+
 int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_major, int64_t shard_rows, int64_t shard_stride, int bk,
                        int32_t n_cols, float* dC, int64_t ldc, bool c_row_major, bool accumulate, hipStream_t st) {
     const size_t esz = bk == 0 ? 4 : 2;
@@ -1359,16 +1488,13 @@ int launch_sparse_rows(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     // 2 x |B| once.  In place wins while  nnz * 16 < 2 * cols.
     // SPARTA_SP_INPLACE = 0 | 1 forces the choice (developer A/B)
     static const int inplace_env = [] { const char* e = std::getenv("SPARTA_SP_INPLACE"); return e ? atoi(e) : -1; }();
-    const bool in_place = !(b_row_major && shard_rows == 0) && (inplace_env >= 0 ? inplace_env != 0 : A->sp_nnz * 8 < A->cols);
+    // (a row-major copy the column-compacted tiles of this product already made is used, whatever the count)
+    const bool in_place = !(b_row_major && shard_rows == 0) && !A->brm_ready && (inplace_env >= 0 ? inplace_env != 0 : A->sp_nnz * 8 < A->cols);
     if (b_row_major && shard_rows == 0) { q.B = dB; q.ldb = ldb; }
     else if (in_place) { q.B = dB; q.ldb = 0; q.b_col_stride = ldb; q.shard_rows = shard_rows; q.shard_stride = shard_stride; }
-    else if (A->prepared_brm) { q.B = A->prepared_brm; q.ldb = A->prepared_ld; }   // sparta_vbs_prepare_b: transposed once, not per product (row stride: the n_cols it was prepared for)
-    else {
-        if (int rc = ensure_scratch(&A->d_Brm, &A->d_Brm_bytes, (size_t)A->cols * (size_t)n_cols * esz)) return rc;
-        const int64_t n_wg = ((A->cols + 63) / 64) * (int64_t)((n_cols + 63) / 64);
-        if (n_wg > INT32_MAX) return sparta::fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: B too large for the transpose grid");
-        launch_b_to_row_major(bk != 0, (unsigned)n_wg, st, dB, ldb, shard_rows, shard_stride, A->cols, (int)n_cols, A->d_Brm);
-        q.B = A->d_Brm; q.ldb = n_cols;
+    else {                                               // sparta_vbs_prepare_b: transposed once; else now, once per product (ensure_brm)
+        if (int rc = ensure_brm(A, dB, ldb, b_row_major, shard_rows, shard_stride, bk, n_cols, st, false)) return rc;
+        q.B = A->brm_ready; q.ldb = A->brm_ld;
     }
     // round 4: (column, value) pairs through scalar loads and the row of B as an SGPR base (k_sparse.hip: sparse_row_partial_s) -- rows of B shorter than 4 GB (the
     // row offset is a 32 x 32 -> 64 bit scalar multiply); SPARTA_SP_SCALAR=0: the round-3 gather (developer A/B; read per call)
@@ -1533,7 +1659,10 @@ int spmm16_core(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
     }
     if (A->n_sp_rows > 0) {                  // nearly empty block-rows: sparse rows over a row-major 16-bit copy of B
         if (prof) HIP_TRY(hipEventRecord(A->cev[3][0], st));
-        if (int rc = launch_sparse_rows(A, dB, ldb16, false, shard_rows, shard_stride, bf16 ? 2 : 1, n_cols, dC, ldc, c_layout == SPARTA_ROW_MAJOR, accumulate != 0, st)) return rc;
+        A->brm_ready = nullptr; A->brm_ld = 0;            // (a 16-bit product runs this core once per piece of B: each piece has its own row-major copy)
+        const int rc_sp = launch_sparse_rows(A, dB, ldb16, false, shard_rows, shard_stride, bf16 ? 2 : 1, n_cols, dC, ldc, c_layout == SPARTA_ROW_MAJOR, accumulate != 0, st);
+        A->brm_ready = nullptr; A->brm_ld = 0;
+        if (rc_sp) return rc_sp;
         if (prof) { HIP_TRY(hipEventRecord(A->cev[3][1], st)); A->class_ran[3] = true; }
     }
     A->last_path = 1;
@@ -1661,7 +1790,9 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
         dC = (float*)A->d_C;
     }
 
-    if (algo == SPARTA_SPMM_EXACT && A->ext_sparse && A->n_sp_rows > 0)
+    struct BrmScope { sparta_vbs_t* a; ~BrmScope() { a->brm_ready = nullptr; a->brm_ld = 0; } } brm_scope{A};     // (the row-major B belongs to this product only)
+    A->brm_ready = nullptr; A->brm_ld = 0;
+    if (algo == SPARTA_SPMM_EXACT && A->ext_sparse && (A->n_sp_rows > 0 || A->u_steps[0] + A->u_steps[1] > 0))
         return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: SPARTA_SPMM_EXACT needs the dense image of every block-row (handle made by sparta_vbs_create_from_csr)");
     if (dt_ms) HIP_TRY(hipEventRecord(A->ev0, st));
     if (algo == SPARTA_SPMM_EXACT) {
@@ -1813,6 +1944,14 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
         // ---- the sparse rows.  Fully sparse block-rows (flag 1) own their rows of C; rows of MIXED block-rows (flag 2, bit 31 of crow) ADD to what
         // the tile and fix-up launches stored: this launch must stay BEHIND those launches on the same stream (moving the sparse leg to a side
         // stream for overlap needs an event wait for the mixed rows) ----
+        // ---- the column-compacted tiles (fp32 handles made from a CSR): they store every row of their block-rows; those block-rows' sparse rows add, below ----
+        if (A->u_steps[0] + A->u_steps[1] > 0) {
+            const bool rec = prof && !A->class_ran[2];
+            if (rec) HIP_TRY(hipEventRecord(A->cev[2][0], st));
+            if (int rc = launch_union_tiles(A, dB, ldb, b_layout == SPARTA_ROW_MAJOR, shard_rows, shard_stride, n_cols, dC, ldc, c_layout == SPARTA_ROW_MAJOR,
+                                            accumulate != 0, st)) return rc;
+            if (rec) { HIP_TRY(hipEventRecord(A->cev[2][1], st)); A->class_ran[2] = true; }
+        }
         if (A->n_sp_rows > 0) {
             if (prof) HIP_TRY(hipEventRecord(A->cev[3][0], st));
             if (int rc = launch_sparse_rows(A, dB, ldb, b_layout == SPARTA_ROW_MAJOR, shard_rows, shard_stride, 0, n_cols, dC, ldc,
@@ -1870,7 +2009,8 @@ struct sparta_b {
     const void* B = nullptr;
     int64_t ldb = 0, shard_rows = 0, shard_stride = 0, cols = 0;
     int32_t n_cols = 0, dtype = 0, device = 0;
-    void* d_Brm = nullptr;                 // row-major copy for the sparse-row kernels (nullptr: this handle / shape does not need one)
+    void* d_Brm = nullptr;                 // row-major copy for the sparse-row kernels and the column-compacted tiles (nullptr: this handle / shape does not need one)
+    int64_t ld_brm = 0;                    // its row stride in elements (n_cols rounded up to 16 bytes)
 };
 
 int sparta_vbs_prepare_b(sparta_vbs_t* A, const void* B, int64_t ldb, int64_t shard_rows, int64_t shard_stride, int32_t n_cols, void* stream,
@@ -1896,13 +2036,15 @@ int sparta_vbs_prepare_b(sparta_vbs_t* A, const void* B, int64_t ldb, int64_t sh
     // the sparse-row kernels of this handle would transpose this B per product (launch_sparse_rows: not when a handful of rows reads it in place)
     // (nor when the resident-column kernel carries the products of a plain column-major B: it reads the columns where they are; a later product into a ROW-major C
     // then transposes per call as sparta_vbs_spmm does)
-    const bool needs_copy = A->n_sp_rows > 0 && !(A->sp_nnz * 8 < A->cols) && !(A->cr_slices > 0 && shard_rows == 0);
+    const bool needs_copy = (A->n_sp_rows > 0 && !(A->sp_nnz * 8 < A->cols) && !(A->cr_slices > 0 && shard_rows == 0)) || A->u_steps[0] + A->u_steps[1] > 0;
     if (needs_copy) {
         hipStream_t st = (hipStream_t)stream;
         const int64_t n_wg = ((A->cols + 63) / 64) * (int64_t)((n_cols + 63) / 64);
         if (n_wg > INT32_MAX) { delete p; return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_prepare_b: B too large for the transpose grid"); }
-        if (hipMalloc(&p->d_Brm, (size_t)A->cols * (size_t)n_cols * esz) != hipSuccess) { delete p; return fail(SPARTA_ERR_ALLOC, "sparta_vbs_prepare_b: out of device memory"); }
-        launch_b_to_row_major(A->dtype != SPARTA_F32, (unsigned)n_wg, st, B, p->ldb, shard_rows, shard_stride, A->cols, (int)n_cols, p->d_Brm);
+        const int64_t per16 = 16 / (int64_t)esz;
+        p->ld_brm = (n_cols + per16 - 1) / per16 * per16;
+        if (hipMalloc(&p->d_Brm, (size_t)A->cols * (size_t)p->ld_brm * esz) != hipSuccess) { delete p; return fail(SPARTA_ERR_ALLOC, "sparta_vbs_prepare_b: out of device memory"); }
+        launch_b_to_row_major(A->dtype != SPARTA_F32, (unsigned)n_wg, st, B, p->ldb, shard_rows, shard_stride, A->cols, (int)n_cols, p->d_Brm, p->ld_brm);
         if (hipGetLastError() != hipSuccess) { (void)hipFree(p->d_Brm); delete p; return fail(SPARTA_ERR_HIP, "sparta_vbs_prepare_b: launch failed"); }
     }
     *out = p;
@@ -1919,7 +2061,7 @@ int sparta_vbs_spmm_prepared(sparta_vbs_t* A, const sparta_b_t* Bp, void* C, int
     SPARTA_GUARD_BEGIN
     // (cleared on every way out, exceptions included: a stale pointer would make a later plain product gather from this B)
     struct Prepared { sparta_vbs_t* a; ~Prepared() { a->prepared_brm = nullptr; a->prepared_ld = 0; } } guard{A};
-    A->prepared_brm = Bp->d_Brm; A->prepared_ld = Bp->n_cols;
+    A->prepared_brm = Bp->d_Brm; A->prepared_ld = Bp->ld_brm;
     return spmm_impl(A, Bp->B, Bp->ldb, SPARTA_COL_MAJOR, Bp->shard_rows, Bp->shard_stride, Bp->n_cols, C, ldc, c_layout, accumulate,
                      SPARTA_PTR_DEVICE, stream, SPARTA_SPMM_MFMA, dt_ms);
     SPARTA_GUARD_END("sparta_vbs_spmm_prepared")

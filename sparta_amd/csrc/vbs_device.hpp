@@ -202,6 +202,22 @@ struct ColresParams {
     int32_t probe;             // developer probe (SPARTA_COLRES_PROBE, wrong products): 1 skip the loads of B, 2 skip the stream of A, 4 skip the stores of C
 };
 
+// ---- column-compacted ("union-pattern") tiles of fp32 handles (k_union.hip, vbs_union.cpp; host form: sparta::UnionPlanHost) ----
+struct UnionRec { int32_t c_row; int32_t info; };        // per step: first row of C of its tile; info = rows of the tile (bits 0..6) | valid list positions of this step, 0..32 (bits 8..13) | UREC_LAST
+constexpr int32_t UREC_LAST = 1 << 16;                   // the tile's last step: store its rows of C
+constexpr int kUnionPadSteps = 4;                        // records / list entries / slices behind the last step (the pipeline requests up to three steps past a worker's range)
+struct UnionParams {
+    const UnionRec* rec;          // per step, in execution order (worker after worker)
+    const int32_t* ids;           // [step][32]: the rows of B (= columns of A) of the step's list positions; 0 behind the valid ones (never fetched)
+    const float* A;               // [step][MI x 1024]: the step's slice in MFMA fragment order [rt][j][g][row][4] = A[32 rt + row][k = 16 g + 4 j + e]
+    const int32_t* worker_range;  // [2 x workers]: begin, end step
+    const float* B;               // ROW-major cols x n_cols, ld = ldb (a multiple of 4 elements, 16-byte aligned base)
+    int64_t ldb;
+    float* C;
+    int64_t ldc;
+    int32_t n_cols, accumulate, c_row_major, c_nt;
+};
+
 struct SpSegRec { int64_t p0; int32_t cnt, pad; };
 struct SpLongRec { int32_t ord, seg_begin, n_seg, pad; };
 
@@ -331,6 +347,16 @@ struct sparta_vbs {
     bool last_colres_small = false;        // the last product on this path used the four-part image
     int64_t cr_entries = 0;                // stored entries, padding included
     int last_colres_nc = 0;                // columns per workgroup of the last product on this path (0: the product took another path)
+    // column-compacted tiles (fp32 handles made from a CSR: vbs_build.cpp mode 3): per tile type [0] <= 32 rows, [1] 33..64 rows
+    sparta_dev::UnionRec* d_u_rec[2] = {nullptr, nullptr};
+    int32_t* d_u_ids[2] = {nullptr, nullptr};
+    float* d_u_a[2] = {nullptr, nullptr};
+    int32_t* d_u_wrange[2] = {nullptr, nullptr};
+    int32_t u_workers[2] = {0, 0};
+    int64_t u_steps[2] = {0, 0}, u_tiles[2] = {0, 0};
+    int64_t u_area = 0, u_cols = 0, u_nnz = 0;      // stored elements (rows x list entries), list entries, nonzeros held
+    const void* brm_ready = nullptr;       // the row-major B of the product in flight (set by the first launch that needs it, cleared when the product returns)
+    int64_t brm_ld = 0;
     void* d_Brm = nullptr;                 // row-major copy of a column-major / gathered B
     size_t d_Brm_bytes = 0;
     const void* prepared_brm = nullptr;    // set for the duration of a sparta_vbs_spmm_prepared call: the caller's row-major copy, made once
@@ -375,7 +401,9 @@ void launch_col_tail_merge(hipStream_t st, const float* Ct, int64_t rows, float*
 void launch_sparse_kernels(int vec, int bk, const SparseParams& q, unsigned gy, hipStream_t st, const int32_t* list, int64_t n_short, const SpSegRec* segs,
                            int64_t n_segs, const SpLongRec* longs, int64_t n_long, float* part, const int32_t* stream_begin = nullptr, int64_t max_stream = 0);
 void launch_b_to_row_major(bool is16, unsigned grid, hipStream_t st, const void* B, int64_t ldb, int64_t shard_rows, int64_t shard_stride, int64_t rows, int N,
-                           void* out);
+                           void* out, int64_t ld_out);
+// k_union.hip
+void launch_union_f32(int mi, dim3 grid, hipStream_t st, const UnionParams& p);
 // k_colres.hip
 int launch_colres(int nc, const ColresParams& p, size_t lds_bytes, hipStream_t st);     // nc = 1..4 columns per workgroup; 0 or a hipError_t
 int colres_max_slices(int nc);                                                          // slices the nc-column kernel holds sums for
@@ -415,6 +443,20 @@ struct StreamPlanHost {
     int64_t n_hub_steps = 0, hub_area = 0, hub_union_area = 0;    // steps; stored elements of the hub tiles; elements the kernel multiplies (absent sub-tiles included)
     int64_t n_hub_tiles = 0, n_hub_groups = 0, hub_chunks = 0, hub_segments = 0;    // K chunks of the step order; segments (runs of one group on one worker)
 };
+// vbs_union.cpp: the device form of the column-compacted tiles -- tiles dealt to workers longest first, a worker's steps back to back
+struct UnionDevPlan {
+    std::vector<UnionRec> rec[2];
+    std::vector<int32_t> ids[2];
+    std::vector<float> a[2];
+    std::vector<int32_t> wrange[2];
+    int32_t n_workers[2] = {0, 0};
+    int64_t n_steps[2] = {0, 0};
+    int64_t area = 0, cols = 0;               // stored elements (tile rows x list entries); list entries
+};
+int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPlan& P);
+// y (+)= the tiles' part of A . x, walked on the HOST from the device form (test aid for the CPU suite: the layout of plan and slices without a GPU)
+void union_plan_host_apply(const UnionDevPlan& P, const float* x, double* y);
+
 constexpr int64_t kZeroRangeRows = 2048;    // block-rows without blocks at least this tall are zero-filled by vbs_zero_rows_kernel
 int build_stream_plans(const StreamPlanIn& in, StreamPlanHost& P);
 uint16_t to_h16(float v, bool bf16);   // fp32 -> fp16 / bf16 bits, round to nearest even (what the device conversion kernel does too)

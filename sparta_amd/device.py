@@ -65,7 +65,7 @@ class DeviceVBS:
         check(lib.sparta_vbs_plan_stats(cmat.rows, cmat.cols, rp.ctypes.data_as(_i64p), ci.ctypes.data_as(C.POINTER(C.c_int32)),
                                         None if vals is None else vals.ctypes.data_as(_f32p), g.ctypes.data_as(_i64p), int(col_block_size),
                                         int(row_block_size), int(bool(force_fixed_size)), int(dtype), st.ctypes.data_as(_i64p)))
-        keys = ["tile_blocks", "tile_area", "mfma_steps", "sparse_nnz", "sparse_rows", "block_rows", "rows"]
+        keys = ["tile_blocks", "tile_area", "mfma_steps", "sparse_nnz", "sparse_rows", "block_rows", "rows", "union_steps"]
         return {k: int(st[i]) for i, k in enumerate(keys)}
 
     @staticmethod
@@ -130,6 +130,13 @@ class DeviceVBS:
         check(lib.sparta_vbs_colres_info(self.h, a.ctypes.data_as(_i64p)))
         return {"slices": int(a[0]), "entries": int(a[1]), "long_rows": int(a[2]), "plane": int(a[3]), "lmax": int(a[4]), "nc": int(a[5]), "nnz": int(a[6]), "unit": int(a[7]),
                 "parts": int(a[8]), "ranges": int(a[9]), "small_parts": int(a[10]), "used_small": int(a[11])}
+
+    def union_info(self):
+        """the column-compacted ("union-pattern") tiles of an fp32 handle made from a CSR (k_union.hip): see sparta_vbs_union_info"""
+        a = np.zeros(8, np.int64)
+        check(lib.sparta_vbs_union_info(self.h, a.ctypes.data_as(_i64p)))
+        keys = ["tiles32", "tiles64", "steps32", "steps64", "area", "list_entries", "nnz", "workers"]
+        return {k: int(a[i]) for i, k in enumerate(keys)}
 
     def hub_info(self):
         """the hub part of a 16-bit plan (group tiles of long 64-row tiles for the GEMM-shaped kernel): see sparta_vbs_hub_info"""
@@ -250,7 +257,9 @@ class DeviceVBS:
         a = np.zeros(4, np.float32)
         check(lib.sparta_vbs_class_times(self.h, a.ctypes.data_as(_f32p)))
         if self.info()["last_path"] == 1:
-            return {"stream": float(a[0]), "fixup": float(a[1]), "sparse": float(a[3])}
+            return {"stream": float(a[0]), "fixup": float(a[1]), "union": float(a[2]), "sparse": float(a[3])}      # 'union': the column-compacted tiles (k_union.hip; + the transpose of B when they ask for it first)
+        if self.union_info()["area"] > 0 and self.info()["tiles64"] == 0:                     # (slot 2 is the column-compacted tiles' when no 64-row class ran)
+            return {"class16": float(a[0]), "class32": float(a[1]), "union": float(a[2]), "sparse": float(a[3])}
         return {"class16": float(a[0]), "class32": float(a[1]), "class64": float(a[2]), "sparse": float(a[3])}
 
     def clock_mhz(self):

@@ -1,0 +1,207 @@
+"""The column-compacted ("union-pattern") tiles on the GPU (sparta_amd/csrc/k_union.hip): clusters whose rows share columns, kept as dense (rows x |union|) tiles + column
+lists -- the VBS the reference builds at small block widths (/root/reference/src/general/vbr.cpp:177-228) -- and multiplied on the matrix cores against the gathered rows
+of B.  Through the C-ABI (sparta_vbs_create_from_csr / sparta_vbs_spmm / sparta_vbs_prepare_b) against
+  * the oracle's restatement of the reference's VBR::multiply (vbr.cpp:323-372) at -b 1, 2, 4, 8, EVERY element, bit for bit on small-integer data (every order of
+    additions gives the same bits there), and within 1e-5 * sum|a||b| on real data (the tolerance of the MFMA kernels' tests: the matrix cores add in another order);
+  * float64 over shapes x operand widths x layouts x leading dimensions x accumulate x pointer spaces."""
+import numpy as np
+import pytest
+
+import sparta_amd as sa
+from oracle import oracle
+from test_union_host import clustered, true_grouping, reference_product
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch
+
+
+@pytest.fixture(autouse=True)
+def small_matrices_keep_their_decisions(monkeypatch):
+    monkeypatch.setenv("SPARTA_SPARSE_MIN_STEPS", "0")
+    monkeypatch.setenv("SPARTA_LAUNCH_NNZ", "0")
+    monkeypatch.setenv("SPARTA_COLRES", "0")          # the sparse remainder through the row gather (test_colres_gpu.py covers the resident-column kernel behind tiles)
+
+
+def _dense(m):
+    import scipy.sparse as sp
+    v = np.ones(len(m.colidx), np.float32) if m.vals is None else m.vals
+    return sp.csr_matrix((v, m.colidx, m.rowptr), shape=(m.rows, m.cols))
+
+
+def _want(m, g, B, n, C0=None, rows_pad=None):
+    """float64 product in the handle's row order, column-major flat, and its absolute bound"""
+    A = _dense(m)
+    perm = np.asarray(sa.get_permutation(g), np.int64)
+    rows_pad = m.rows if rows_pad is None else rows_pad
+    Bm = B.reshape(n, m.cols).T.astype(np.float64)
+    Ap = A[perm].astype(np.float64)
+    C, bound = np.zeros((rows_pad, n)), np.zeros((rows_pad, n))
+    C[:m.rows], bound[:m.rows] = np.asarray(Ap @ Bm), np.asarray(abs(Ap) @ np.abs(Bm))
+    if C0 is not None:
+        C0m = C0.reshape(n, rows_pad).T.astype(np.float64)
+        C, bound = C + C0m, bound + np.abs(C0m)
+    return C.T.reshape(-1), bound.T.reshape(-1)
+
+
+def _product(torch, d, B, n, ldb=None, ldc=None, C0=None, **kw):
+    rows, cols = d.rows, d.cols
+    ldb, ldc = ldb or cols, ldc or rows
+    Bp = np.full((n, ldb), 3.0e38, np.float32)                              # padding of the leading dimensions: never read / never written
+    Bp[:, :cols] = B.reshape(n, cols)
+    Cp = np.full((n, ldc), -5.0, np.float32)
+    if C0 is not None:
+        Cp[:, :rows] = C0.reshape(n, rows)
+    Bt, Ct = torch.from_numpy(Bp.reshape(-1)).cuda(), torch.from_numpy(Cp.reshape(-1)).cuda()
+    d.spmm(Bt, Ct, n, accumulate=C0 is not None, ldb=ldb, ldc=ldc, **kw)
+    torch.cuda.synchronize()
+    got = Ct.cpu().numpy().reshape(n, ldc)
+    assert np.all(got[:, rows:] == -5.0), "the product wrote into the padding of C"
+    return np.ascontiguousarray(got[:, :rows]).reshape(-1)
+
+
+@pytest.mark.parametrize("w", [1, 2, 4, 8])
+@pytest.mark.parametrize("rows_per", [5, 48, 70])
+def test_small_block_widths_every_element_against_the_reference_product(w, rows_per):
+    torch = _torch()
+    m, order = clustered(40, rows_per, 5000, 100, 3, seed=3 * rows_per + w, integer=True)
+    g = true_grouping(order, rows_per)
+    d = sa.DeviceVBS.from_csr(m, g, w, device=0)
+    ui = d.union_info()
+    assert ui["tiles32"] + ui["tiles64"] > 0 and ui["nnz"] > 0.7 * m.nztot(), ui
+    n = 128
+    B = np.random.default_rng(w).integers(-3, 4, m.cols * n).astype(np.float32)
+    got = _product(torch, d, B, n)
+    v = oracle.OracleVBR(m.rows, m.cols, m.rowptr, m.colidx, m.vals, g, w)
+    ref = oracle.vbr_multiply(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+    assert np.array_equal(got, ref)                                          # bit for bit: the reference's VBR::multiply on the VBS it builds at this block width
+    d.close()
+
+
+@pytest.mark.parametrize("n", [128, 256, 72, 5, 384])
+@pytest.mark.parametrize("layouts", [(sa.COL_MAJOR, sa.COL_MAJOR), (sa.ROW_MAJOR, sa.COL_MAJOR), (sa.COL_MAJOR, sa.ROW_MAJOR), (sa.ROW_MAJOR, sa.ROW_MAJOR)])
+def test_against_float64_over_widths_and_layouts(n, layouts):
+    torch = _torch()
+    bl, cl = layouts
+    m, order = clustered(60, 48, 9000, 150, 5, seed=n)
+    g = true_grouping(order, 48)
+    d = sa.DeviceVBS.from_csr(m, g, 32, device=0)
+    assert d.union_info()["tiles64"] == 60
+    rng = np.random.default_rng(n + 1)
+    B = rng.uniform(-1, 1, m.cols * n).astype(np.float32)                    # column-major image; the row-major operand is its transpose
+    want, bound = _want(m, g, B, n)
+    Bt = torch.from_numpy(B if bl == sa.COL_MAJOR else np.ascontiguousarray(B.reshape(n, m.cols).T).reshape(-1)).cuda()
+    for acc in (False, True):
+        C0 = rng.uniform(-1, 1, m.rows * n).astype(np.float32)
+        Ct = torch.from_numpy(C0 if cl == sa.COL_MAJOR else np.ascontiguousarray(C0.reshape(n, m.rows).T).reshape(-1)).cuda()
+        d.spmm(Bt, Ct, n, accumulate=acc, b_layout=bl, c_layout=cl)
+        torch.cuda.synchronize()
+        got = Ct.cpu().numpy()
+        got = got if cl == sa.COL_MAJOR else np.ascontiguousarray(got.reshape(m.rows, n).T).reshape(-1)
+        w_, b_ = (want + C0, bound + np.abs(C0)) if acc else (want, bound)
+        assert np.max(np.abs(got - w_) / (b_ + 1e-30)) < TOL, (n, layouts, acc)
+    d.close()
+
+
+@pytest.mark.parametrize("rows_per,n_groups", [(3, 400), (17, 90), (32, 50), (33, 40), (64, 30), (100, 20), (200, 9)])
+def test_cluster_heights_and_padded_leading_dimensions(rows_per, n_groups):
+    torch = _torch()
+    m, order = clustered(n_groups, rows_per, 7000, 120, 4, seed=rows_per)
+    g = true_grouping(order, rows_per)
+    d = sa.DeviceVBS.from_csr(m, g, 64, device=0)
+    ui = d.union_info()
+    assert ui["nnz"] > 0.5 * m.nztot(), ui
+    n = 200
+    rng = np.random.default_rng(rows_per)
+    B = rng.uniform(-1, 1, m.cols * n).astype(np.float32)
+    want, bound = _want(m, g, B, n)
+    got = _product(torch, d, B, n, ldb=m.cols + 13, ldc=m.rows + 7)
+    assert np.max(np.abs(got - want) / (bound + 1e-30)) < TOL
+    C0 = rng.uniform(-1, 1, m.rows * n).astype(np.float32)
+    want2, bound2 = _want(m, g, B, n, C0)
+    got = _product(torch, d, B, n, ldc=m.rows + 64, C0=C0)
+    assert np.max(np.abs(got - want2) / (bound2 + 1e-30)) < TOL
+    d.close()
+
+
+def test_mixed_image_tiles_union_tiles_and_sparse_rows_in_one_product():
+    torch = _torch()
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3)
+    m1, order = clustered(60, 40, 4096, 120, 4, seed=11, scatter=False)
+    A = _dense(m1).tolil()
+    A[1000:1040, 512:1536] = rng.uniform(-1, 1, (40, 1024)).astype(np.float32)          # a dense cluster: stays w-wide MFMA tiles (a list of 1024 columns costs more than 32 blocks)
+    A[2000:2040, :] = 0                                                               # an empty cluster
+    A = A.tocsr(); A.eliminate_zeros(); A.sort_indices()
+    m = sa.CSR(A.shape[0], A.shape[1], A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.float32))
+    g = np.arange(m.rows) // 40 * 40
+    d = sa.DeviceVBS.from_csr(m, g, 32, device=0)
+    ui, si, info = d.union_info(), d.sparse_info(), d.info()
+    assert ui["tiles64"] > 0 and si["nnz"] > 0 and info["nztot"] > 0, (ui, si, info)
+    for n in (128, 130):
+        B = rng.uniform(-1, 1, m.cols * n).astype(np.float32)
+        want, bound = _want(m, g, B, n)
+        got = _product(torch, d, B, n)
+        assert np.max(np.abs(got - want) / (bound + 1e-30)) < TOL
+        # host pointers (the reference back-ends' contract), C += A B
+        C0 = rng.uniform(-1, 1, m.rows * n).astype(np.float32)
+        Ch = C0.copy()
+        d.spmm_host(B, n, Ch, accumulate=True)
+        want2, bound2 = _want(m, g, B, n, C0)
+        assert np.max(np.abs(Ch - want2) / (bound2 + 1e-30)) < TOL
+    d.close()
+
+
+def test_prepared_b_gives_the_same_bits_and_force_fixed_padding():
+    torch = _torch()
+    m, order = clustered(50, 24, 3000, 80, 3, seed=9)
+    g = true_grouping(order, 24)
+    d = sa.DeviceVBS.from_csr(m, g, 16, 32, True, device=0)                  # -F 1: rows padded to multiples of 32
+    assert d.rows == (m.rows + 31) // 32 * 32 and d.union_info()["nnz"] > 0
+    n = 136
+    rng = np.random.default_rng(5)
+    B = np.zeros((n, d.cols), np.float32)
+    B[:, :m.cols] = rng.uniform(-1, 1, (n, m.cols)).astype(np.float32)
+    Bt = torch.from_numpy(B.reshape(-1)).cuda()
+    C1, C2 = torch.zeros(d.rows * n, device="cuda"), torch.full((d.rows * n,), 9.0, device="cuda")
+    d.spmm(Bt, C1, n)
+    Bp = d.prepare_b(Bt, n)
+    d.spmm_prepared(Bp, C2)
+    torch.cuda.synchronize()
+    assert torch.equal(C1, C2)
+    want, bound = _want(m, g, np.ascontiguousarray(B[:, :m.cols]).reshape(-1), n, rows_pad=d.rows)
+    assert np.max(np.abs(C1.cpu().numpy() - want) / (bound + 1e-30)) < TOL
+    Bp.close(); d.close()
+
+
+def test_clustering_found_by_the_library_on_the_suite_family():
+    """the benchmark set's `clustered` family in small: rows of a group scattered, blocking_algo 7 finds them, the product is the tiles' (bench_suite.py)"""
+    torch = _torch()
+    import bench_suite
+    m = bench_suite._clustered(sa, 150, 48, 20000, 300, 6, 5)
+    g = sa.BlockingEngine(col_block_size=32, blocking_algo=7, tau=0.6).GetGrouping(m)
+    d = sa.DeviceVBS.from_csr(m, g, 32, device=0)
+    ui = d.union_info()
+    assert ui["nnz"] > 0.8 * m.nztot(), ui
+    n = 128
+    B = np.random.default_rng(1).uniform(-1, 1, m.cols * n).astype(np.float32)
+    want, bound = _want(m, g, B, n)
+    got = _product(torch, d, B, n)
+    assert np.max(np.abs(got - want) / (bound + 1e-30)) < TOL
+    # switched off: the same product from the sparse rows, same tolerance
+    import os
+    os.environ["SPARTA_UNION"] = "0"
+    try:
+        d0 = sa.DeviceVBS.from_csr(m, g, 32, device=0)
+    finally:
+        os.environ.pop("SPARTA_UNION")
+    assert d0.union_info()["nnz"] == 0
+    got0 = _product(torch, d0, B, n)
+    assert np.max(np.abs(got0 - want) / (bound + 1e-30)) < TOL
+    d.close(); d0.close()
