@@ -416,14 +416,16 @@ int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, 
  * nearly empty is kept as tiles of <= 64 consecutive reordered rows x the columns at least 2-3 of those rows use, multiplied on the matrix cores against the
  * gathered rows of a row-major B (k_union.hip; a column-major B is transposed once per product, or once per sparta_vbs_prepare_b); the nonzeros of the other
  * columns are sparse rows that add.  SPARTA_UNION=0 at create time: not built.  SPARTA_SPMM_EXACT is not available on such a handle (as for any handle with sparse rows).
- * info_out (int64[8]): [0] tiles of <= 32 rows [1] tiles of 33..64 rows [2], [3] their 32-deep steps [4] stored elements (tile rows x list entries)
- * [5] list entries [6] nonzeros the tiles hold [7] persistent workgroups (both launches) */
+ * A row's nonzeros in columns too thinly used for the list ride in the tile's TAIL (at most SPARTA_UNION_TAIL = 16 per row) and are added in the tile's epilogue; only what
+ * exceeds that is left to the sparse-row kernels.
+ * info_out (int64[10]): [0] tiles of <= 32 rows [1] tiles of 33..64 rows [2], [3] their 32-deep steps [4] stored elements (tile rows x list entries)
+ * [5] list entries [6] nonzeros the tiles hold (lists + tails) [7] persistent workgroups of the launch [8] rows of C the tiles own [9] nonzeros in the tails */
 int sparta_vbs_union_info(const sparta_vbs_t* A, int64_t* info_out);
 /* HOST-side check of that builder and its device plan for the CPU suite (no GPU; not a product path, and not a fallback: sparta_vbs_spmm never calls it): the hybrid
  * image of the CSR matrix under `grouping` -- w-wide tiles, column-compacted tiles, sparse rows, decided as sparta_vbs_create_from_csr decides them for an fp32 handle --
  * multiplied with ONE column x; the column-compacted tiles are walked in their DEVICE form (step records, list entries, MFMA-fragment-order slices, dealt to
- * `max_workers` workers).  y (double, [rows padded as force_fixed_size pads them], reordered order).  info_out (int64[12]): [0..6] as sparta_vbs_union_info,
- * [7] nonzeros left to the sparse rows [8] stored elements of the w-wide tiles [9] padded rows [10], [11] workers of the two step lists */
+ * `max_workers` workers).  y (double, [rows padded as force_fixed_size pads them], reordered order).  info_out (int64[14]): [0..6] as sparta_vbs_union_info,
+ * [7] nonzeros left to the sparse rows [8] stored elements of the w-wide tiles [9] padded rows [10], [11] workers of the two step lists [12] nonzeros in the tails [13] rows the tiles own */
 int sparta_union_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals, const int64_t* grouping, int64_t col_block_size,
                             int64_t row_block_size, int32_t force_fixed_size, int32_t max_workers, const float* x, double* y, int64_t* info_out);
 

@@ -109,12 +109,18 @@ int vbs_build(const CsrView& a, const int64_t* grouping, int64_t col_block_size,
 // columns (mode 3), consumed by create_core (vbs_union.cpp lays the tiles out per worker in MFMA fragment order).
 struct UnionPlanHost {
     // ty 0: tiles of <= 32 rows (one 32-row MFMA tile per wave and step), ty 1: tiles of 33..64 rows (two)
-    struct Tile { int32_t c_row, mt; int64_t k0; int32_t nk, pad; };   // first reordered row (= row of C), rows, offset of its column list in cols[ty], columns
+    struct Tile { int32_t c_row, mt; int64_t k0; int32_t nk, tail_e; int64_t tail0; };   // first reordered row (= row of C), rows, offset of its column list in cols[ty], columns; tail: below
     std::vector<Tile> tiles[2];
-    std::vector<int32_t> cols[2];      // column ids, tile after tile; a tile's list is the concatenation of its parts' ascending lists (a part = the rows of ONE block-row in the tile)
+    std::vector<int32_t> cols[2];      // column ids, tile after tile, ascending inside a tile (a tile = the rows of ONE block-row: a chunk of <= 64 of them)
     std::vector<float> a[2];           // values, tile after tile, tile t at a_off[ty][t]: element (row i, list position k) at k * (32 * (ty + 1)) + i; zeros where a row lacks the column
     std::vector<int64_t> a_off[2];
-    int64_t nnz = 0;                   // nonzeros held by the tiles
+    // the TAIL of a tile: up to union_tail_cap() nonzeros per row in columns too thinly used for the list -- a cluster's rows have a few columns of their own.  The kernel adds
+    // them in the tile's epilogue, straight into the accumulators (one 128-byte piece of a row of B per entry and wave), instead of a sparse-row launch that re-reads and
+    // re-writes the rows of C.  tail_e = entries per row (the longest row's, 0: none), entry e of row i at tail0 + e * (32 * (ty + 1)) + i; rows with fewer hold (col, 0.0f).
+    std::vector<int32_t> tail_col[2];
+    std::vector<float> tail_val[2];
+    int64_t nnz = 0;                   // nonzeros held by the tiles (lists + tails)
+    int64_t tail_nnz = 0;              // ... of which in the tails
     bool empty() const { return tiles[0].empty() && tiles[1].empty(); }
 };
 
@@ -141,6 +147,7 @@ struct HybridStats {
 };
 double union_col_cost(int mi);      // a list entry of a column-compacted tile (mi = 1: tiles of <= 32 rows, 2: of 33..64) in nonzeros of the sparse-row path
 int32_t union_min_count(int mi);    // fewest nonzeros of a part's rows that keep a column in its tile
+int32_t union_tail_cap();           // most tail entries per row of a tile (SPARTA_UNION_TAIL, default 16; 0: no tails)
 int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, bool force_fixed_size,
                      double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp, bool keep_order = false, HybridStats* stats_only = nullptr);
 // fewest MFMA steps the nearly empty block-rows of a matrix must be worth before they leave the tiles for the sparse-row kernels

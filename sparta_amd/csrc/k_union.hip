@@ -19,7 +19,10 @@
 //     each -- covers all 64 banks;
 //   * list positions behind the tile's last column get a descriptor of zero records: zeros in LDS without a memory access (no 0 x inf from a padding row).
 // One barrier per step: wait (counted vmcnt) for this wave's loads of step i, barrier, issue the loads of step i + NS - 1 into the stage step i - 1 has left, multiply
-// step i.  A worker walks WHOLE tiles (vbs_union.cpp deals them longest first); a tile's last step stores its rows of C (or adds to them: accumulate).
+// step i.  A worker walks WHOLE tiles (vbs_union.cpp deals them longest first).  A tile's last step first adds its TAIL -- up to 16 nonzeros per row in columns too
+// thinly used for the list (a cluster's rows have a few columns of their own): lane (row, g) holds the row's accumulators of 16 of the wave's 32 columns, so per entry
+// it fetches 4 x 16 bytes of ITS row of B and multiplies them in; no sparse-row launch, no second pass over the rows of C -- then stores the tile's rows of C (or adds
+// to them: accumulate).  ONE launch carries both tile types: workgroups [0, n2) walk the 33..64-row tiles (two accumulators), the others the <= 32-row tiles.
 #include "vbs_kernel_common.hpp"
 
 using namespace sparta_dev;
@@ -28,37 +31,38 @@ namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-#ifndef SPARTA_UNION_PROBE
-#define SPARTA_UNION_PROBE 0      /* developer probes, TIMING ONLY (results wrong): 1 no B loads, 2 no A loads, 4 no MFMAs, 16 no epilogue */
-#endif
+// developer probes, TIMING ONLY (results wrong), UnionParams::pad = SPARTA_UNION_PROBE read per call: 1 no B loads, 2 no A loads, 4 no MFMAs, 8 no tails, 16 no epilogue
+
+constexpr int kUnionStages = 3;
+constexpr int kUnionLds = kUnionStages * (2 * 4096 + 32 * 512);      // the taller type's stages
 
 template <int MI, int NS>
-__global__ __launch_bounds__(256, 2) void vbs_union_f32_kernel(const UnionParams p) {
+__device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide& sd, const int worker, char* const lds) {
     static_assert(MI == 1 || MI == 2, "one or two 32-row MFMA tiles per wave and step");
     constexpr int A_BYTES = MI * 4096, B_BYTES = 32 * 512, STAGE = A_BYTES + B_BYTES;
     constexpr int NA = MI;                               // 1 KB pieces of the slice of A per wave and step (4 MI pieces, four waves)
     constexpr int LPS = 8 + NA;                          // vector-memory instructions per wave and step
     constexpr int AHEAD = NS - 1;                        // steps between a step's loads and its MFMAs
     static_assert((AHEAD - 1) * LPS <= 63, "vmcnt holds 6 bits");
-    static_assert(NS * STAGE * 2 <= 160 * 1024, "two workgroups per CU");
-    __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
+    static_assert(NS * STAGE <= kUnionLds, "LDS");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 31, g = lane >> 5;
-    const int worker = (int)blockIdx.x, n0 = (int)blockIdx.y * kTN;
-    const int s_begin = p.worker_range[2 * worker];
-    const int n = p.worker_range[2 * worker + 1] - s_begin;
+    const int n0 = (int)blockIdx.y * kTN;
+    const int probe = p.pad;
+    const int s_begin = sd.worker_range[2 * worker];
+    const int n = sd.worker_range[2 * worker + 1] - s_begin;
     if (n <= 0) return;
 
     // step records and list entries through the constant address space (scalar loads): per step this wave needs the record (two dwords) and ITS eight row ids
     typedef const __attribute__((address_space(4))) int32_t* cptr_t;
-    const cptr_t srec = (cptr_t)(reinterpret_cast<const int32_t*>(p.rec + s_begin));
-    const cptr_t sids = (cptr_t)(p.ids + (int64_t)s_begin * 32 + 8 * wave);
-    struct Rec { int32_t c_row, info, id[8]; };
+    const cptr_t srec = (cptr_t)(reinterpret_cast<const int32_t*>(sd.rec + s_begin));
+    const cptr_t sids = (cptr_t)(sd.ids + (int64_t)s_begin * 32 + 8 * wave);
+    struct Rec { int32_t c_row, info, tail_off, id[8]; };
     auto load_rec = [&](int j) __attribute__((always_inline)) -> Rec {
         Rec r;
-        r.c_row = srec[(int64_t)j * 2]; r.info = srec[(int64_t)j * 2 + 1];
+        r.c_row = srec[(int64_t)j * 4]; r.info = srec[(int64_t)j * 4 + 1]; r.tail_off = srec[(int64_t)j * 4 + 2];
 #pragma unroll
         for (int q = 0; q < 8; q++) r.id[q] = sids[(int64_t)j * 32 + q];
         return r;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void vbs_union_f32_kernel(const UnionParams
     const uint32_t voffB = (uint32_t)(((lane & 31) ^ (wave >= 2 ? 8 : 0)) * 16);       // rows 16..31 (waves 2, 3): chunk c at position c ^ 8
     const uint32_t voffA = (uint32_t)lane * 16u;
     const float* const Bs0 = p.B + n0;
-    const float* const A0 = p.A + (int64_t)s_begin * (MI * 1024);
+    const float* const A0 = sd.A + (int64_t)s_begin * (MI * 1024);
     // fragment reads of B: row k = 16 g + kk, column 32 wave + lm at float position (32 wave + lm) ^ (32 g) of the row
     const uint32_t rdB = (uint32_t)(16 * g * 512 + (((32 * wave + lm) ^ (32 * g)) * 4));
     char* const lds0 = lds;
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void vbs_union_f32_kernel(const UnionParams
     auto issue = [&](const Rec& rec, int j, int stage) __attribute__((always_inline)) {
         char* const stp = lds0 + stage * STAGE;
         const int nvalid = (rec.info >> 8) & 63;
-        if (!(SPARTA_UNION_PROBE & 2)) {
+        if (!(probe & 2)) {
             const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A0 + (int64_t)j * (MI * 1024)), 0, MI * 4096, 0x00020000);
 #pragma unroll
             for (int t = 0; t < NA; t++) {
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void vbs_union_f32_kernel(const UnionParams
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(stp + q * 1024), 16, voffA, (uint32_t)(q * 1024), 0, 0);
             }
         }
-        if (!(SPARTA_UNION_PROBE & 1)) {
+        if (!(probe & 1)) {
             // lanes 0..31 fetch the four even rows, lanes 32..63 the four odd ones: two divergent regions per step, every load in them under half an exec mask
             auto half = [&](int odd) __attribute__((always_inline)) {
 #pragma unroll
@@ -109,13 +113,13 @@ __global__ __launch_bounds__(256, 2) void vbs_union_f32_kernel(const UnionParams
         for (int r = 0; r < 16; r++) acc[rt][r] = 0.0f;
 
     // records of the steps in flight: info / c_row of step i are needed at its epilogue, long after its loads were issued
-    int32_t iq[NS], cq[NS];
+    int32_t iq[NS], cq[NS], tq[NS];
 #pragma unroll
-    for (int k = 0; k < NS; k++) { iq[k] = 0; cq[k] = 0; }
+    for (int k = 0; k < NS; k++) { iq[k] = 0; cq[k] = 0; tq[k] = 0; }
 #pragma unroll
     for (int k = 0; k < AHEAD; k++) {                    // prologue: steps 0 .. AHEAD - 1
         const Rec r = load_rec(k);
-        iq[k] = r.info; cq[k] = r.c_row;
+        iq[k] = r.info; cq[k] = r.c_row; tq[k] = r.tail_off;
         issue(r, k, k);
     }
     Rec nxt = load_rec(AHEAD);                           // the record of the step whose loads the next iteration issues
@@ -135,10 +139,10 @@ __global__ __launch_bounds__(256, 2) void vbs_union_f32_kernel(const UnionParams
         const Rec rec = nxt;
         nxt = load_rec(i + AHEAD + 1);
         int jstage = stage + AHEAD; if (jstage >= NS) jstage -= NS;
-        iq[AHEAD] = rec.info; cq[AHEAD] = rec.c_row;
+        iq[AHEAD] = rec.info; cq[AHEAD] = rec.c_row; tq[AHEAD] = rec.tail_off;
         issue(rec, i + AHEAD, jstage);
         // (4) multiply step i
-        if (!(SPARTA_UNION_PROBE & 4)) {
+        if (!(probe & 4)) {
             const char* const sa = lds0 + stage * STAGE;
             const char* const sb = sa + A_BYTES + rdB;
             f32x4 af[MI][4];
@@ -156,9 +160,44 @@ __global__ __launch_bounds__(256, 2) void vbs_union_f32_kernel(const UnionParams
                 }
         }
         const int32_t info = iq[0];
-        if ((info & UREC_LAST) && !(SPARTA_UNION_PROBE & 16)) {
+        if ((info & UREC_LAST) && !(probe & 16)) {
             const int mt = info & 127;
             const int64_t c_row = cq[0];
+            // the tail: per entry and row 4 x 16 bytes of the row of B -- the 16 columns whose accumulators this lane holds (register q: column (q & 3) + 8 (q >> 2) + 4 g)
+            const int tail_e = (info >> UREC_TAIL_SHIFT) & 31;
+            if (tail_e > 0 && !(probe & 8)) {
+                const uint2* tp = sd.tail + tq[0] + lm;
+                const float* brow = p.B + n0 + 32 * wave + 4 * g;
+                // four entries at a time: their (column, value) pairs in one round trip, their 4 x MI x 4 pieces of B in a second one (an entry at a time is two round
+                // trips per entry with the matrix pipe idle: 89 of 277 us on the benchmark set's clustered family)
+                constexpr int CH = 4;
+                for (int e0 = 0; e0 < tail_e; e0 += CH) {
+                    uint2 cv[CH][MI];
+#pragma unroll
+                    for (int c = 0; c < CH; c++)
+#pragma unroll
+                        for (int rt = 0; rt < MI; rt++) cv[c][rt] = e0 + c < tail_e ? tp[((e0 + c) * MI + rt) * 32] : uint2{0u, 0u};      // (behind the last entry: nothing is fetched)
+                    f32x4 bv[CH][MI][4];
+#pragma unroll
+                    for (int c = 0; c < CH; c++)
+#pragma unroll
+                        for (int rt = 0; rt < MI; rt++) {
+                            const float* bp = brow + (int64_t)cv[c][rt].x * p.ldb;
+#pragma unroll
+                            for (int qq = 0; qq < 4; qq++) bv[c][rt][qq] = (e0 + c < tail_e && 8 * qq + 4 * g < ncw) ? *reinterpret_cast<const f32x4*>(bp + 8 * qq) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        }
+#pragma unroll
+                    for (int c = 0; c < CH; c++)
+#pragma unroll
+                        for (int rt = 0; rt < MI; rt++) {
+                            const float av = __uint_as_float(cv[c][rt].y);
+#pragma unroll
+                            for (int qq = 0; qq < 4; qq++)
+#pragma unroll
+                                for (int i2 = 0; i2 < 4; i2++) acc[rt][4 * qq + i2] = __builtin_fmaf(av, bv[c][rt][qq][i2], acc[rt][4 * qq + i2]);
+                        }
+                }
+            }
             float* cbase = p.c_row_major ? p.C + c_row * p.ldc + (n0 + 32 * wave) : p.C + c_row + (int64_t)(n0 + 32 * wave) * p.ldc;
             const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
@@ -181,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void vbs_union_f32_kernel(const UnionParams
                     for (int q = 0; q < 16; q++) {
                         const int col = (q & 3) + 8 * (q >> 2);
                         if (col + 4 * g < ncw) {
-                            if (p.c_nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)col * jstep + (uint32_t)rt * mistep, 2);
+                            if (sd.c_nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)col * jstep + (uint32_t)rt * mistep, 2);
                             else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)col * jstep + (uint32_t)rt * mistep, 0);
                         }
                     }
@@ -193,21 +232,28 @@ __global__ __launch_bounds__(256, 2) void vbs_union_f32_kernel(const UnionParams
                 for (int r = 0; r < 16; r++) acc[rt][r] = 0.0f;
         }
 #pragma unroll
-        for (int k = 0; k < AHEAD; k++) { iq[k] = iq[k + 1]; cq[k] = cq[k + 1]; }
+        for (int k = 0; k < AHEAD; k++) { iq[k] = iq[k + 1]; cq[k] = cq[k + 1]; tq[k] = tq[k + 1]; }
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
     // the loads issued past the end of the range (into LDS nobody reads any more) must land before the workgroup's LDS is handed on
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+__global__ __launch_bounds__(256, 2) void vbs_union_f32_kernel(const UnionParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[kUnionLds];
+    static_assert(kUnionLds * 2 <= 160 * 1024, "two workgroups per CU");
+    const int n2 = p.side[1].n_workers;                  // (wave-uniform: the two bodies are two programs behind one scalar branch)
+    if ((int)blockIdx.x < n2) union_body<2, kUnionStages>(p, p.side[1], (int)blockIdx.x, lds);
+    else union_body<1, kUnionStages>(p, p.side[0], (int)blockIdx.x - n2, lds);
+}
+
 }  // namespace
 
 namespace sparta_dev {
 
-// mi = 1: the plan of the tiles of <= 32 rows; mi = 2: of the tiles of 33..64 rows.  grid = (workers, 128-column slabs)
-void launch_union_f32(int mi, dim3 grid, hipStream_t st, const UnionParams& p) {
-    if (mi == 2) hipLaunchKernelGGL((vbs_union_f32_kernel<2, 3>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((vbs_union_f32_kernel<1, 3>), grid, dim3(256), 0, st, p);
+// ONE launch: grid = (workers of the 33..64-row tiles + workers of the <= 32-row tiles, 128-column slabs)
+void launch_union_f32(unsigned n_slabs, hipStream_t st, const UnionParams& p) {
+    hipLaunchKernelGGL(vbs_union_f32_kernel, dim3((unsigned)(p.side[0].n_workers + p.side[1].n_workers), n_slabs), dim3(256), 0, st, p);
 }
 
 }  // namespace sparta_dev

@@ -96,6 +96,10 @@ double union_col_cost(int mi) {
     return K_union * (double)mi / 32.0;
 }
 int32_t union_min_count(int mi) { return std::max<int32_t>(2, (int32_t)std::ceil(union_col_cost(mi))); }
+int32_t union_tail_cap() {
+    static const int32_t cap = [] { const char* e = std::getenv("SPARTA_UNION_TAIL"); return e ? std::max(0, std::min(31, atoi(e))) : 16; }();
+    return cap;
+}
 
 int vbs_build(const CsrView& a, const int64_t* grouping, int64_t w, int64_t row_block_size, bool force_fixed,
               sparta_vbs_host* out) {
@@ -185,9 +189,10 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
     // Chosen when that is below SPARTA_UNION_MARGIN (default 0.8) x the best of the three modes above.
     const bool want_union = hybrid && sp->want_union && [] { const char* e = std::getenv("SPARTA_UNION"); return !(e && atoi(e) == 0); }();
     const double union_margin = [] { const char* e = std::getenv("SPARTA_UNION_MARGIN"); return e ? atof(e) : 0.8; }();
-    struct UnionEval { double cost; int64_t rows_rest, ent_rest, nnz_in; std::vector<int32_t> nu; };
+    struct UnionEval { double cost; int64_t rows_rest, ent_rest, nnz_in, tail_ent; std::vector<int32_t> nu, te; };    // nu / te: per part, list entries / tail entries per row
+    const int64_t tail_cap = union_tail_cap();
     auto eval_union = [&](ColCounter& cc, int64_t r0, int64_t r1) {
-        UnionEval u{0.0, 0, 0, 0, {}};
+        UnionEval u{0.0, 0, 0, 0, 0, {}, {}};
         const int64_t h = r1 - r0;
         for (int64_t q = 0; q < union_parts(h); q++) {
             const int64_t p0 = r0 + 64 * q, p1 = p0 + union_part_rows(h, q);
@@ -198,6 +203,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
             for (int32_t c : cc.touched) if (cc.cnt[(size_t)c] >= cmin) { nu++; u.nnz_in += cc.cnt[(size_t)c]; }
             u.nu.push_back((int32_t)nu);
             u.cost += (double)nu * union_col_cost(mi);
+            int64_t te = 0;
             for (int64_t rr = p0; rr < p1; rr++) {                   // the rows' nonzeros in thinly used columns
                 const int64_t i = perm[(size_t)rr];
                 if (i >= a.rows) continue;
@@ -206,11 +212,15 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                 const int64_t n = a.nnz_of(i);
                 int64_t mine = 0;
                 for (int64_t k = 0; k < n; k++) mine += (!v || v[k] != 0.0f) && cc.cnt[(size_t)cj[k]] < cmin;
-                u.ent_rest += mine; u.rows_rest += mine > 0;
+                const int64_t in_tail = std::min(mine, tail_cap);                 // the first tail_cap of them ride in the tile's tail, the others are sparse-row entries
+                u.tail_ent += in_tail; u.ent_rest += mine - in_tail; u.rows_rest += mine > in_tail;
+                te = std::max(te, in_tail);
             }
+            u.te.push_back((int32_t)te);
             cc.reset();
         }
-        u.cost += (double)u.ent_rest + (double)u.rows_rest * rmw_cost;
+        u.nnz_in += u.tail_ent;
+        u.cost += (double)u.ent_rest + (double)u.rows_rest * rmw_cost + 0.5 * (double)u.tail_ent;     // (a tail entry: 128 bytes of B per wave, no row of C re-read)
         return u;
     };
 
@@ -221,6 +231,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
     std::vector<int64_t> sp_rows_of(hybrid ? (size_t)block_rows : 0, 0), sp_ent_of(hybrid ? (size_t)block_rows : 0, 0), nb_all(hybrid ? (size_t)block_rows : 0, 0);
     std::vector<int64_t> nnz_all(hybrid ? (size_t)block_rows : 0, 0);  // stored nonzeros of the block-row (all blocks)
     std::vector<std::vector<int32_t>> nu_parts(want_union ? (size_t)block_rows : 0);   // mode 3: columns kept per part
+    std::vector<std::vector<int32_t>> te_parts(want_union ? (size_t)block_rows : 0);   // ... and tail entries per row of the part's tile
     std::vector<int64_t> union_nnz_of(want_union ? (size_t)block_rows : 0, 0);
     const int64_t grain = std::max<int64_t>(1, std::min<int64_t>(64, block_rows / (8 * (int64_t)host_threads()) + 1));
     parallel_for_dynamic(block_rows, grain, [&](int64_t lo, int64_t hi, int) {
@@ -247,6 +258,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                         saved_row[(size_t)ib] = (r.c_dense - u.cost) / K;
                         sp_rows_of[(size_t)ib] = u.rows_rest; sp_ent_of[(size_t)ib] = u.ent_rest;
                         nu_parts[(size_t)ib].swap(u.nu);
+                        te_parts[(size_t)ib].swap(u.te);
                         union_nnz_of[(size_t)ib] = u.nnz_in;
                         continue;
                     }
@@ -288,7 +300,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                 mode[(size_t)ib] = 0;
                 out->nzcount[ib] = nb_all[(size_t)ib];
                 sp_rows_of[(size_t)ib] = sp_ent_of[(size_t)ib] = 0;
-                if (want_union) { nu_parts[(size_t)ib].clear(); union_nnz_of[(size_t)ib] = 0; }
+                if (want_union) { nu_parts[(size_t)ib].clear(); te_parts[(size_t)ib].clear(); union_nnz_of[(size_t)ib] = 0; }
             }
         }
         // steps / stored elements of the column-compacted tiles of block-row ib (mode 3)
@@ -330,7 +342,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                     out->nzcount[ib] = 0;
                     sp_rows_of[(size_t)ib] = h;
                     sp_ent_of[(size_t)ib] = nnz_all[(size_t)ib];
-                    if (want_union) { nu_parts[(size_t)ib].clear(); union_nnz_of[(size_t)ib] = 0; }
+                    if (want_union) { nu_parts[(size_t)ib].clear(); te_parts[(size_t)ib].clear(); union_nnz_of[(size_t)ib] = 0; }
                 }
             }
         }
@@ -394,15 +406,14 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
         });
         trace.lap("sparse rows (collect)");
 
-        // ---- mode 3: the column-compacted tiles.  Parts become tiles in row order: a part of 33..64 rows is a tile of its own (ty 1); parts of <= 32 rows are packed --
-        // consecutive rows only -- into tiles of <= 32 rows (ty 0), each part with its own columns (a tile of several parts is block-diagonal: the parts' column lists
-        // back to back).  Then every block-row fills its parts: ascending column list, dense values, and the nonzeros of the thinly used columns as sparse rows that ADD.
+        // ---- mode 3: the column-compacted tiles.  Every part (chunk of <= 64 rows of ONE block-row) is a tile: 33..64 rows ty 1, <= 32 rows ty 0.  (Parts of different
+        // block-rows share no column by construction, so packing them into one tile would save no MFMA -- it would only make one long tile out of several short ones.)
+        // Every block-row fills its tiles: ascending column list, dense values, up to tail_cap thinly-used nonzeros per row in the tile's tail, the rest as sparse rows that ADD.
         if (want_union) {
             UnionPlanHost& U = sp->uni;
-            struct PartAt { int8_t ty; int32_t tile, ro; int64_t ko; };
             std::vector<int64_t> part_base((size_t)block_rows + 1, 0);
             for (int64_t ib = 0; ib < block_rows; ib++) part_base[(size_t)ib + 1] = part_base[(size_t)ib] + (int64_t)nu_parts[(size_t)ib].size();
-            std::vector<PartAt> at((size_t)part_base[(size_t)block_rows]);
+            std::vector<int32_t> tile_of((size_t)part_base[(size_t)block_rows]);
             for (int64_t ib = 0; ib < block_rows; ib++) {
                 if (mode[(size_t)ib] != 3) continue;
                 const int64_t r0 = part[(size_t)ib], h = part[(size_t)ib + 1] - r0;
@@ -410,13 +421,11 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                     const int64_t p0 = r0 + 64 * (int64_t)q, len = union_part_rows(h, (int64_t)q);
                     const int ty = len > 32 ? 1 : 0;
                     const int32_t nu = nu_parts[(size_t)ib][q];
-                    std::vector<UnionPlanHost::Tile>& T = U.tiles[ty];
-                    const bool join = ty == 0 && !T.empty() && (int64_t)T.back().c_row + T.back().mt == p0 && T.back().mt + len <= 32;
-                    if (!join) T.push_back(UnionPlanHost::Tile{(int32_t)p0, 0, (int64_t)U.cols[ty].size(), 0, 0});
-                    UnionPlanHost::Tile& t = T.back();
-                    at[(size_t)part_base[(size_t)ib] + q] = PartAt{(int8_t)ty, (int32_t)(T.size() - 1), t.mt, (int64_t)t.nk};
-                    t.mt += (int32_t)len; t.nk += nu;
+                    tile_of[(size_t)part_base[(size_t)ib] + q] = (int32_t)U.tiles[ty].size();
+                    const int32_t te = te_parts[(size_t)ib][q];
+                    U.tiles[ty].push_back(UnionPlanHost::Tile{(int32_t)p0, (int32_t)len, (int64_t)U.cols[ty].size(), nu, te, (int64_t)U.tail_col[ty].size()});
                     U.cols[ty].resize(U.cols[ty].size() + (size_t)nu);
+                    U.tail_col[ty].resize(U.tail_col[ty].size() + (size_t)te * (size_t)(32 * (ty + 1)), -1);          // (-1: slot not used yet)
                 }
                 U.nnz += union_nnz_of[(size_t)ib];
             }
@@ -427,6 +436,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                 U.a_off[ty][U.tiles[ty].size()] = o;
                 U.a[ty].assign((size_t)o, 0.0f);
             }
+            for (int ty = 0; ty < 2; ty++) U.tail_val[ty].assign(U.tail_col[ty].size(), 0.0f);
             parallel_for_dynamic(block_rows, grain, [&](int64_t lo, int64_t hi, int) {
                 ColCounter cc(cols);
                 std::vector<int32_t> list;
@@ -436,21 +446,25 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                     int64_t t = row_base[(size_t)ib], e = ent_base[(size_t)ib];
                     for (size_t q = 0; q < nu_parts[(size_t)ib].size(); q++) {
                         const int64_t p0 = r0 + 64 * (int64_t)q, p1 = p0 + union_part_rows(h, (int64_t)q);
-                        const PartAt pa = at[(size_t)part_base[(size_t)ib] + q];
-                        const int mi = pa.ty + 1;
+                        const int ty = p1 - p0 > 32 ? 1 : 0, mi = ty + 1;
+                        const int32_t ti = tile_of[(size_t)part_base[(size_t)ib] + q];
                         const int32_t cmin = union_min_count(mi);
-                        const UnionPlanHost::Tile& tl = U.tiles[pa.ty][(size_t)pa.tile];
+                        const UnionPlanHost::Tile& tl = U.tiles[ty][(size_t)ti];
                         cc.count(a, perm.data(), p0, p1);
                         list.clear();
                         for (int32_t c : cc.touched) if (cc.cnt[(size_t)c] >= cmin) list.push_back(c);
                         std::sort(list.begin(), list.end());
                         // (cnt doubles as the position table: a kept column -> -(position + 1); the others keep their small positive count)
-                        for (size_t k = 0; k < list.size(); k++) { U.cols[pa.ty][(size_t)(tl.k0 + pa.ko) + k] = list[k]; cc.cnt[(size_t)list[k]] = -(int32_t)(k + 1); }
-                        float* img = U.a[pa.ty].data() + U.a_off[pa.ty][(size_t)pa.tile];
+                        for (size_t k = 0; k < list.size(); k++) { U.cols[ty][(size_t)tl.k0 + k] = list[k]; cc.cnt[(size_t)list[k]] = -(int32_t)(k + 1); }
+                        float* img = U.a[ty].data() + U.a_off[ty][(size_t)ti];
                         const int64_t ldt = 32 * mi;
+                        int32_t* tc = U.tail_col[ty].data() + tl.tail0;
+                        float* tv = U.tail_val[ty].data() + tl.tail0;
+                        const int32_t fill_col = list.empty() ? 0 : list[0];   // an unused tail slot points at a column of the tile (any valid row of B) with value 0
                         for (int64_t r = p0; r < p1; r++) {
                             const int64_t i = perm[(size_t)r];
                             const int64_t before = e;
+                            int64_t in_tail = 0;
                             if (i < a.rows) {
                                 const int32_t* cj = a.row(i);
                                 const float* v = a.vals ? a.vals + a.rowptr[i] : nullptr;
@@ -459,7 +473,8 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                                     const float x = v ? v[k] : 1.0f;
                                     if (x == 0.0f) continue;
                                     const int32_t c = cc.cnt[(size_t)cj[k]];
-                                    if (c < 0) img[(pa.ko + (int64_t)(-c - 1)) * ldt + pa.ro + (r - p0)] = x;
+                                    if (c < 0) img[(int64_t)(-c - 1) * ldt + (r - p0)] = x;
+                                    else if (in_tail < tl.tail_e && in_tail < tail_cap) { tc[in_tail * ldt + (r - p0)] = cj[k]; tv[in_tail * ldt + (r - p0)] = x; in_tail++; }
                                     else { sp->col[(size_t)e] = cj[k]; sp->val[(size_t)e] = x; e++; }
                                 }
                             }
@@ -469,10 +484,12 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                             sp->rowptr[(size_t)t + 1] = e;
                             t++;
                         }
+                        for (int64_t x = 0; x < (int64_t)tl.tail_e * ldt; x++) if (tc[x] < 0) tc[x] = fill_col;
                         cc.reset();
                     }
                 }
             });
+            for (int ty = 0; ty < 2; ty++) for (float x : U.tail_val[ty]) U.tail_nnz += x != 0.0f;
             trace.lap("column-compacted tiles");
         }
     }

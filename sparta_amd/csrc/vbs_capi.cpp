@@ -110,6 +110,7 @@ void destroy_impl(sparta_vbs* v) {
         if (v->d_u_ids[ty]) (void)hipFree(v->d_u_ids[ty]);
         if (v->d_u_a[ty]) (void)hipFree(v->d_u_a[ty]);
         if (v->d_u_wrange[ty]) (void)hipFree(v->d_u_wrange[ty]);
+        if (v->d_u_tail[ty]) (void)hipFree(v->d_u_tail[ty]);
     }
     if (v->d_Brm) (void)hipFree(v->d_Brm);
     if (v->d_B) (void)hipFree(v->d_B);
@@ -866,10 +867,12 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         CREATE_TRY(hipMemcpy(v->d_u_a[ty], uplan.a[ty].data(), uplan.a[ty].size() * sizeof(float), hipMemcpyHostToDevice));
         CREATE_TRY(hipMalloc((void**)&v->d_u_wrange[ty], uplan.wrange[ty].size() * sizeof(int32_t)));
         CREATE_TRY(hipMemcpy(v->d_u_wrange[ty], uplan.wrange[ty].data(), uplan.wrange[ty].size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        v->a_bytes += (int64_t)(uplan.a[ty].size() * sizeof(float) + uplan.ids[ty].size() * sizeof(int32_t));
+        CREATE_TRY(hipMalloc(&v->d_u_tail[ty], uplan.tail[ty].size() * sizeof(uint32_t)));
+        CREATE_TRY(hipMemcpy(v->d_u_tail[ty], uplan.tail[ty].data(), uplan.tail[ty].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        v->a_bytes += (int64_t)(uplan.a[ty].size() * sizeof(float) + uplan.ids[ty].size() * sizeof(int32_t) + uplan.tail[ty].size() * sizeof(uint32_t));
         v->exec_area += uplan.n_steps[ty] * 32 * 32 * (ty + 1);
     }
-    if (ext) { v->u_area = uplan.area; v->u_cols = uplan.cols; v->u_nnz = ext->uni.nnz; }
+    if (ext) { v->u_area = uplan.area; v->u_cols = uplan.cols; v->u_nnz = ext->uni.nnz; v->u_tail_nnz = ext->uni.tail_nnz; v->u_rows = uplan.rows; }
     if (!sp_crow.empty()) {
         v->n_sp_rows = (int64_t)sp_crow.size(); v->n_sp_short = n_sp_short; v->n_sp_long = n_sp_long; v->sp_nnz = sp_rowptr.back();
         CREATE_TRY(hipMalloc((void**)&v->d_sp_rowptr, sp_rowptr.size() * sizeof(int64_t)));
@@ -1137,6 +1140,7 @@ int sparta_vbs_union_info(const sparta_vbs_t* A, int64_t* info) {
     if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_union_info: NULL argument");
     info[0] = A->u_tiles[0]; info[1] = A->u_tiles[1]; info[2] = A->u_steps[0]; info[3] = A->u_steps[1];
     info[4] = A->u_area; info[5] = A->u_cols; info[6] = A->u_nnz; info[7] = A->u_workers[0] + A->u_workers[1];
+    info[8] = A->u_rows; info[9] = A->u_tail_nnz;
     return SPARTA_OK;
 }
 
@@ -1257,7 +1261,7 @@ int sparta_union_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, c
         for (int64_t k = sp.rowptr[t]; k < sp.rowptr[t + 1]; k++) y[sp.crow[t]] += (double)sp.val[(size_t)k] * (double)x[sp.col[(size_t)k]];
     info[0] = (int64_t)sp.uni.tiles[0].size(); info[1] = (int64_t)sp.uni.tiles[1].size(); info[2] = P.n_steps[0]; info[3] = P.n_steps[1];
     info[4] = P.area; info[5] = P.cols; info[6] = sp.uni.nnz; info[7] = sp.rowptr.empty() ? 0 : sp.rowptr.back();
-    info[8] = h.nztot; info[9] = h.rows; info[10] = P.n_workers[0]; info[11] = P.n_workers[1];
+    info[8] = h.nztot; info[9] = h.rows; info[10] = P.n_workers[0]; info[11] = P.n_workers[1]; info[12] = sp.uni.tail_nnz; info[13] = P.rows;
     return SPARTA_OK;
     SPARTA_GUARD_END("sparta_union_host_check")
 }
@@ -1409,15 +1413,16 @@ int launch_union_tiles(sparta_vbs_t* A, const float* dB, int64_t ldb, bool b_row
     UnionParams up;
     up.B = (const float*)A->brm_ready; up.ldb = A->brm_ld; up.C = dC; up.ldc = ldc;
     up.n_cols = n_cols; up.accumulate = accumulate ? 1 : 0; up.c_row_major = c_row_major ? 1 : 0;
-    const unsigned n_slabs = (unsigned)((n_cols + kTN - 1) / kTN);
-    for (int ty = 1; ty >= 0; ty--) {
-        if (A->u_steps[ty] == 0) continue;
-        up.rec = A->d_u_rec[ty]; up.ids = A->d_u_ids[ty]; up.A = A->d_u_a[ty]; up.worker_range = A->d_u_wrange[ty];
+    up.pad = [] { const char* e = std::getenv("SPARTA_UNION_PROBE"); return e ? atoi(e) : 0; }();      // developer probes (timing only, wrong products; read per call)
+    for (int ty = 0; ty < 2; ty++) {
+        UnionSide& sd = up.side[ty];
+        sd.rec = A->d_u_rec[ty]; sd.ids = A->d_u_ids[ty]; sd.A = A->d_u_a[ty]; sd.worker_range = A->d_u_wrange[ty]; sd.tail = (const uint2*)A->d_u_tail[ty];
+        sd.n_workers = A->u_steps[ty] > 0 ? A->u_workers[ty] : 0;
         // C is written once and never read back: non-temporal stores where tiles are long (as the stream kernels: vbs_kernel_common.hpp); SPARTA_C_NT=0|1 forces one
         const char* e = std::getenv("SPARTA_C_NT");
-        up.c_nt = e ? (atoi(e) != 0) : (A->u_steps[ty] >= 6 * A->u_tiles[ty] ? 1 : 0);
-        launch_union_f32(ty + 1, dim3((unsigned)A->u_workers[ty], n_slabs), st, up);
+        sd.c_nt = e ? (atoi(e) != 0) : (A->u_steps[ty] >= 6 * A->u_tiles[ty] ? 1 : 0);
     }
+    launch_union_f32((unsigned)((n_cols + kTN - 1) / kTN), st, up);
     HIP_TRY(hipGetLastError());
     return SPARTA_OK;
 }

@@ -203,19 +203,27 @@ struct ColresParams {
 };
 
 // ---- column-compacted ("union-pattern") tiles of fp32 handles (k_union.hip, vbs_union.cpp; host form: sparta::UnionPlanHost) ----
-struct UnionRec { int32_t c_row; int32_t info; };        // per step: first row of C of its tile; info = rows of the tile (bits 0..6) | valid list positions of this step, 0..32 (bits 8..13) | UREC_LAST
-constexpr int32_t UREC_LAST = 1 << 16;                   // the tile's last step: store its rows of C
+struct UnionRec { int32_t c_row, info, tail_off, pad; };  // per step: first row of C of its tile; info = rows of the tile (bits 0..6) | valid list positions of this step, 0..32 (bits 8..13) | UREC_LAST
+                                                         // | tail entries per row (bits 17..21); tail_off: first (column, value) pair of the tile's tail
+static_assert(sizeof(UnionRec) == 16, "UnionRec must stay 16 bytes");
+constexpr int32_t UREC_LAST = 1 << 16;                   // the tile's last step: add the tail, store the tile's rows of C
+constexpr int UREC_TAIL_SHIFT = 17;
 constexpr int kUnionPadSteps = 4;                        // records / list entries / slices behind the last step (the pipeline requests up to three steps past a worker's range)
-struct UnionParams {
+struct UnionSide {                // one tile type: [0] tiles of <= 32 rows (MI = 1), [1] tiles of 33..64 rows (MI = 2)
     const UnionRec* rec;          // per step, in execution order (worker after worker)
     const int32_t* ids;           // [step][32]: the rows of B (= columns of A) of the step's list positions; 0 behind the valid ones (never fetched)
     const float* A;               // [step][MI x 1024]: the step's slice in MFMA fragment order [rt][j][g][row][4] = A[32 rt + row][k = 16 g + 4 j + e]
     const int32_t* worker_range;  // [2 x workers]: begin, end step
+    const uint2* tail;            // per tile (execution order) [entry][32 MI rows]: (column, value bits) added in the tile's epilogue
+    int32_t n_workers, c_nt;
+};
+struct UnionParams {              // ONE launch: workgroups [0, side[1].n_workers) walk the 33..64-row tiles, the others the <= 32-row tiles
+    UnionSide side[2];
     const float* B;               // ROW-major cols x n_cols, ld = ldb (a multiple of 4 elements, 16-byte aligned base)
     int64_t ldb;
     float* C;
     int64_t ldc;
-    int32_t n_cols, accumulate, c_row_major, c_nt;
+    int32_t n_cols, accumulate, c_row_major, pad;
 };
 
 struct SpSegRec { int64_t p0; int32_t cnt, pad; };
@@ -352,9 +360,11 @@ struct sparta_vbs {
     int32_t* d_u_ids[2] = {nullptr, nullptr};
     float* d_u_a[2] = {nullptr, nullptr};
     int32_t* d_u_wrange[2] = {nullptr, nullptr};
+    void* d_u_tail[2] = {nullptr, nullptr};
     int32_t u_workers[2] = {0, 0};
     int64_t u_steps[2] = {0, 0}, u_tiles[2] = {0, 0};
-    int64_t u_area = 0, u_cols = 0, u_nnz = 0;      // stored elements (rows x list entries), list entries, nonzeros held
+    int64_t u_area = 0, u_cols = 0, u_nnz = 0;      // stored elements (rows x list entries), list entries, nonzeros held (lists + tails)
+    int64_t u_tail_nnz = 0, u_rows = 0;             // nonzeros in the tiles' tails; rows of C the tiles own
     const void* brm_ready = nullptr;       // the row-major B of the product in flight (set by the first launch that needs it, cleared when the product returns)
     int64_t brm_ld = 0;
     void* d_Brm = nullptr;                 // row-major copy of a column-major / gathered B
@@ -403,7 +413,7 @@ void launch_sparse_kernels(int vec, int bk, const SparseParams& q, unsigned gy, 
 void launch_b_to_row_major(bool is16, unsigned grid, hipStream_t st, const void* B, int64_t ldb, int64_t shard_rows, int64_t shard_stride, int64_t rows, int N,
                            void* out, int64_t ld_out);
 // k_union.hip
-void launch_union_f32(int mi, dim3 grid, hipStream_t st, const UnionParams& p);
+void launch_union_f32(unsigned n_slabs, hipStream_t st, const UnionParams& p);
 // k_colres.hip
 int launch_colres(int nc, const ColresParams& p, size_t lds_bytes, hipStream_t st);     // nc = 1..4 columns per workgroup; 0 or a hipError_t
 int colres_max_slices(int nc);                                                          // slices the nc-column kernel holds sums for
@@ -449,9 +459,10 @@ struct UnionDevPlan {
     std::vector<int32_t> ids[2];
     std::vector<float> a[2];
     std::vector<int32_t> wrange[2];
+    std::vector<uint32_t> tail[2];            // (column, value bits) pairs, tile after tile in execution order
     int32_t n_workers[2] = {0, 0};
     int64_t n_steps[2] = {0, 0};
-    int64_t area = 0, cols = 0;               // stored elements (tile rows x list entries); list entries
+    int64_t area = 0, cols = 0, rows = 0;     // stored elements (tile rows x list entries); list entries; rows of C the tiles own
 };
 int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPlan& P);
 // y (+)= the tiles' part of A . x, walked on the HOST from the device form (test aid for the CPU suite: the layout of plan and slices without a GPU)

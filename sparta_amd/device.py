@@ -133,9 +133,9 @@ class DeviceVBS:
 
     def union_info(self):
         """the column-compacted ("union-pattern") tiles of an fp32 handle made from a CSR (k_union.hip): see sparta_vbs_union_info"""
-        a = np.zeros(8, np.int64)
+        a = np.zeros(10, np.int64)
         check(lib.sparta_vbs_union_info(self.h, a.ctypes.data_as(_i64p)))
-        keys = ["tiles32", "tiles64", "steps32", "steps64", "area", "list_entries", "nnz", "workers"]
+        keys = ["tiles32", "tiles64", "steps32", "steps64", "area", "list_entries", "nnz", "workers", "rows", "tail_nnz"]
         return {k: int(a[i]) for i, k in enumerate(keys)}
 
     def hub_info(self):

@@ -136,6 +136,7 @@ def test_mixed_image_tiles_union_tiles_and_sparse_rows_in_one_product():
     rng = np.random.default_rng(3)
     m1, order = clustered(60, 40, 4096, 120, 4, seed=11, scatter=False)
     A = _dense(m1).tolil()
+    A[1000:1040, :] = 0
     A[1000:1040, 512:1536] = rng.uniform(-1, 1, (40, 1024)).astype(np.float32)          # a dense cluster: stays w-wide MFMA tiles (a list of 1024 columns costs more than 32 blocks)
     A[2000:2040, :] = 0                                                               # an empty cluster
     A = A.tocsr(); A.eliminate_zeros(); A.sort_indices()
@@ -143,7 +144,7 @@ def test_mixed_image_tiles_union_tiles_and_sparse_rows_in_one_product():
     g = np.arange(m.rows) // 40 * 40
     d = sa.DeviceVBS.from_csr(m, g, 32, device=0)
     ui, si, info = d.union_info(), d.sparse_info(), d.info()
-    assert ui["tiles64"] > 0 and si["nnz"] > 0 and info["nztot"] > 0, (ui, si, info)
+    assert ui["tiles64"] > 0 and ui["tail_nnz"] > 0 and info["nztot"] > 0, (ui, si, info)
     for n in (128, 130):
         B = rng.uniform(-1, 1, m.cols * n).astype(np.float32)
         want, bound = _want(m, g, B, n)
@@ -155,6 +156,23 @@ def test_mixed_image_tiles_union_tiles_and_sparse_rows_in_one_product():
         d.spmm_host(B, n, Ch, accumulate=True)
         want2, bound2 = _want(m, g, B, n, C0)
         assert np.max(np.abs(Ch - want2) / (bound2 + 1e-30)) < TOL
+    d.close()
+
+
+@pytest.mark.parametrize("n", [128, 40])
+def test_tails_and_their_overflow_into_sparse_rows(n):
+    torch = _torch()
+    m, order = clustered(40, 48, 6000, 100, 20, seed=21, integer=True)      # 20 columns of their own per row: 16 in the tile's tail, the rest sparse rows that add
+    g = true_grouping(order, 48)
+    d = sa.DeviceVBS.from_csr(m, g, 1, device=0)
+    ui, si = d.union_info(), d.sparse_info()
+    assert ui["tail_nnz"] > 0 and si["nnz"] > 0 and ui["nnz"] + si["nnz"] == m.nztot(), (ui, si)
+    B = np.random.default_rng(n).integers(-3, 4, m.cols * n).astype(np.float32)
+    v = oracle.OracleVBR(m.rows, m.cols, m.rowptr, m.colidx, m.vals, g, 1)
+    ref = oracle.vbr_multiply(v.rows, v.cols, 1, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+    assert np.array_equal(_product(torch, d, B, n), ref)
+    C0 = np.random.default_rng(1).integers(-3, 4, m.rows * n).astype(np.float32)
+    assert np.array_equal(_product(torch, d, B, n, C0=C0), ref + C0)         # accumulate
     d.close()
 
 

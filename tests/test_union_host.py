@@ -54,12 +54,12 @@ def true_grouping(order, rows_per):
 
 def walk(m, g, w, x, rbs=0, ff=False, workers=7):
     rows_pad = m.rows if not ff else ((m.rows - 1) // rbs + 1) * rbs
-    y, info = np.zeros(rows_pad, np.float64), np.zeros(12, np.int64)
+    y, info = np.zeros(rows_pad, np.float64), np.zeros(14, np.int64)
     vals = None if m.vals is None else m.vals.ctypes.data_as(_f32p)
     gg = np.ascontiguousarray(g, np.int64)
     check(lib.sparta_union_host_check(m.rows, m.cols, m.rowptr.ctypes.data_as(_i64p), m.colidx.ctypes.data_as(_i32p), vals, gg.ctypes.data_as(_i64p), w, rbs, int(ff),
                                       workers, x.ctypes.data_as(_f32p), y.ctypes.data_as(_f64p), info.ctypes.data_as(_i64p)))
-    keys = ["tiles32", "tiles64", "steps32", "steps64", "area", "list_entries", "nnz", "sparse_nnz", "tile_area", "rows", "workers32", "workers64"]
+    keys = ["tiles32", "tiles64", "steps32", "steps64", "area", "list_entries", "nnz", "sparse_nnz", "tile_area", "rows", "workers32", "workers64", "tail_nnz", "tile_rows"]
     return y, {k: int(info[i]) for i, k in enumerate(keys)}
 
 
@@ -90,6 +90,7 @@ def test_every_nonzero_is_somewhere_exactly_once_on_a_mixed_matrix():
     m1, order = clustered(30, 40, 4096, 120, 4, seed=11, scatter=False)
     import scipy.sparse as sp
     A = sp.csr_matrix((m1.vals, m1.colidx, m1.rowptr), shape=(m1.rows, m1.cols)).tolil()
+    A[1000:1040, :] = 0
     A[1000:1040, 512:1536] = rng.uniform(-1, 1, (40, 1024)).astype(np.float32)                       # a dense cluster: stays w-wide tiles (a list of 1024 columns costs more than 32 blocks)
     A = A.tocsr(); A.sort_indices()
     m = sa.CSR(A.shape[0], A.shape[1], A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.float32))
@@ -101,20 +102,32 @@ def test_every_nonzero_is_somewhere_exactly_once_on_a_mixed_matrix():
         want = (A.astype(np.float64) @ x.astype(np.float64))[perm]
         scale = (abs(A).astype(np.float64) @ np.abs(x).astype(np.float64))[perm] + 1e-30
         assert np.max(np.abs(y - want) / scale) < 1e-12, info
-        assert info["tiles64"] > 0 and info["tile_area"] > 0 and info["sparse_nnz"] > 0 and info["nnz"] + info["sparse_nnz"] <= m.nztot()
+        assert info["tiles64"] > 0 and info["tile_area"] > 0 and info["tail_nnz"] > 0 and info["nnz"] + info["sparse_nnz"] <= m.nztot()
+
+
+def test_tails_hold_a_rows_own_columns_and_overflow_into_sparse_rows(monkeypatch):
+    # 20 columns of their own per row: 16 ride in the tile's tail, the others are sparse-row entries that add; with SPARTA_UNION_TAIL=0 all of them are
+    m, order = clustered(10, 48, 4000, 100, 20, seed=21, integer=True)
+    g = true_grouping(order, 48)
+    x = np.random.default_rng(3).integers(-3, 4, m.cols).astype(np.float32)
+    ref = np.asarray(reference_product(m, g, 1, x)).reshape(-1)
+    y, info = walk(m, g, 1, x)
+    assert info["tail_nnz"] >= 16 * m.rows * 0.9 and info["sparse_nnz"] > 0 and info["nnz"] + info["sparse_nnz"] == m.nztot(), info
+    assert np.array_equal(y.astype(np.float32), ref)
+    monkeypatch.setenv("SPARTA_UNION_TAIL", "0")
 
 
 def test_tiles_follow_the_parts_rules():
-    # 70-row clusters: one part of 64 rows (a 33..64-row tile) + one of 6 (packed into a <= 32-row tile); 5-row clusters pack six to a tile
+    # 70-row clusters: one part of 64 rows (a 33..64-row tile) + one of 6 (a <= 32-row tile)
     m, order = clustered(8, 70, 2000, 60, 2, seed=5, scatter=False)
     g = np.arange(m.rows) // 70 * 70
     x = np.ones(m.cols, np.float32)
     y, info = walk(m, g, 32, x)
-    assert info["tiles64"] == 8 and info["tiles32"] == 8, info
+    assert info["tiles64"] == 8 and info["tiles32"] == 8 and info["tile_rows"] == m.rows, info
     m, order = clustered(12, 5, 2000, 60, 2, seed=6, scatter=False)
     g = np.arange(m.rows) // 5 * 5
     y, info = walk(m, g, 32, np.ones(m.cols, np.float32))
-    assert info["tiles64"] == 0 and info["tiles32"] == 2, info                                     # 6 x 5 = 30 rows per tile
+    assert info["tiles64"] == 0 and info["tiles32"] == 12, info                                    # every cluster its own tile (clusters share no column: packing them would save nothing)
     assert info["steps32"] >= info["list_entries"] // 32
 
 
