@@ -220,7 +220,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
             cc.reset();
         }
         u.nnz_in += u.tail_ent;
-        u.cost += (double)u.ent_rest + (double)u.rows_rest * rmw_cost + 0.5 * (double)u.tail_ent;     // (a tail entry: 128 bytes of B per wave, no row of C re-read)
+        u.cost += (double)u.ent_rest + (double)u.rows_rest * rmw_cost + 0.8 * (double)u.tail_ent;     // (a tail entry: the same row of B as a sparse-row entry, no row of C re-read)
         return u;
     };
 
@@ -252,7 +252,8 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                 const double lower = (double)nnz_all[(size_t)ib] / (double)h * union_col_cost(h > 32 ? 2 : 1);
                 if (lower < union_margin * r.cost) {
                     UnionEval u = eval_union(cc, r0, r1);
-                    if (u.nnz_in > 0 && u.cost < union_margin * r.cost) {
+                    // (... and only where the LISTS carry the block-row: tiles that are mostly tails are a slower sparse-row kernel)
+                    if (2 * (u.nnz_in - u.tail_ent) >= nnz_all[(size_t)ib] && u.cost < union_margin * r.cost) {
                         mode[(size_t)ib] = 3;
                         out->nzcount[ib] = 0;
                         saved_row[(size_t)ib] = (r.c_dense - u.cost) / K;

@@ -13,11 +13,29 @@ import _util as U
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["mfma-only", "with-sparse-rows"])
+# the tests that ALSO run with the library's own decisions -- no override of the small-matrix rule (SPARTA_LAUNCH_NNZ), of the few-block-rows rule
+# (SPARTA_SPARSE_MIN_STEPS) or of the resident-column kernel (SPARTA_COLRES) -- and say, from the handle's own records, which kernels carried each product
+_DEFAULTS_TOO = {"test_ragged_shapes_vs_oracle", "test_accumulate_overwrite_layouts_and_pointer_spaces", "test_special_block_rows",
+                 "test_create_from_csr_gives_the_same_product", "test_sparse_row_path_mixed_matrix"}
+
+
+def pytest_generate_tests(metafunc):
+    if "_sparse_row_mode" in metafunc.fixturenames:
+        modes = ["mfma-only", "with-sparse-rows"] + (["library-defaults"] if metafunc.function.__name__ in _DEFAULTS_TOO else [])
+        metafunc.parametrize("_sparse_row_mode", modes, indirect=True)
+
+
+@pytest.fixture(autouse=True)
 def _sparse_row_mode(request, monkeypatch):
-    """every test runs twice: with the sparse-row path switched off (all block-rows on the MFMA kernels) and with the
-    library's own choice (nearly empty block-rows -- most of the small test matrices -- go to the sparse-row kernels)"""
-    if request.param == "mfma-only":
+    """every test runs twice: with the sparse-row path switched off (all block-rows on the MFMA kernels) and with the sparse-row path on and the rules that keep
+    SMALL matrices on one kind of launch switched off (nearly empty block-rows -- most of the small test matrices -- go to the sparse-row kernels); the tests of
+    _DEFAULTS_TOO a third time with nothing overridden: the decisions a caller of the library gets"""
+    mode = getattr(request, "param", "with-sparse-rows")
+    if mode == "library-defaults":
+        for k in ("SPARTA_SPARSE_K", "SPARTA_SPARSE_MIN_STEPS", "SPARTA_LAUNCH_NNZ", "SPARTA_COLRES", "SPARTA_UNION"):
+            monkeypatch.delenv(k, raising=False)
+        return mode
+    if mode == "mfma-only":
         monkeypatch.setenv("SPARTA_SPARSE_K", "0")
     else:
         monkeypatch.delenv("SPARTA_SPARSE_K", raising=False)
@@ -28,7 +46,34 @@ def _sparse_row_mode(request, monkeypatch):
     # ... and multiplies a small all-sparse fp32 matrix by the resident-column kernel (k_colres.hip): these tests are about the tiles and the row gather
     # (tests/test_colres_gpu.py, test_real_matrices.py run that kernel)
     monkeypatch.setenv("SPARTA_COLRES", "0")
-    return request.param
+    return mode
+
+
+CARRIED = {}          # library-defaults mode: test id -> which kernels carried its products (printed by the last test of the file)
+
+
+def _carrier(d, mode, what, reference_layouts=True, fp32=True):
+    """which kernels carried the LAST product of handle d, from the handle's own records; asserts that the records agree with the mode"""
+    info, sp, cr, ui = d.info(), d.sparse_info(), d.colres_info(), d.union_info()
+    tiles = info["tiles16"] + info["tiles32"] + info["tiles64"]
+    rec = {"tiles": tiles, "path": {0: "none", 1: "stream", 2: "per-class", 3: "generic"}[info["last_path"]], "sparse_rows": sp["rows"], "sparse_nnz": sp["nnz"],
+           "resident_columns": cr["nc"], "union_tiles": ui["tiles32"] + ui["tiles64"]}
+    if mode == "mfma-only":
+        assert sp["rows"] == 0 and cr["slices"] == 0 and ui["area"] == 0, rec
+    elif mode == "with-sparse-rows":
+        assert cr["slices"] == 0, rec                                      # SPARTA_COLRES=0: the sparse rows went through the row gather
+    else:
+        # the resident-column kernel carries the sparse rows of a small fp32 handle exactly when it has an image and the call uses the reference's layouts
+        if fp32 and cr["slices"] > 0 and reference_layouts:
+            assert cr["nc"] > 0, rec
+        else:
+            assert cr["nc"] == 0, rec
+        if tiles > 0:
+            assert info["last_path"] in (1, 2, 3), rec
+        CARRIED.setdefault(what, rec)
+    return rec
+
+
 TOL = 1e-5
 
 
@@ -97,7 +142,7 @@ SHAPES = [
 
 
 @pytest.mark.parametrize("rows,cols,nnz,w,blk,n", SHAPES)
-def test_ragged_shapes_vs_oracle(rows, cols, nnz, w, blk, n):
+def test_ragged_shapes_vs_oracle(_sparse_row_mode, rows, cols, nnz, w, blk, n):
     m = sa.gen.uniform_random(rows, cols, nnz, seed=rows + cols + w)
     if blk[0] == "tau":
         g = sa.BlockingEngine(tau=blk[1], col_block_size=w).GetGrouping(m)
@@ -117,6 +162,7 @@ def test_ragged_shapes_vs_oracle(rows, cols, nnz, w, blk, n):
             assert np.array_equal(C, Co)
         else:
             _check(C, Co, bound, "mfma")
+            _carrier(d, _sparse_row_mode, "ragged %dx%d w%d %s n%d" % (rows, cols, w, blk[0], n))
     # independent check through the permutation: C_vbs[r] == C_csr[perm[r]]  
     perm = sa.get_permutation(g)
     Cc = O.csr_multiply(m.rows, m.rowptr, m.colidx, m.vals, B, m.cols, n).reshape(n, m.rows)
@@ -125,7 +171,7 @@ def test_ragged_shapes_vs_oracle(rows, cols, nnz, w, blk, n):
     _check(C.reshape(n, v.rows), Cc[:, perm], bound.reshape(n, v.rows), "vs CSR through perm")
 
 
-def test_accumulate_overwrite_layouts_and_pointer_spaces():
+def test_accumulate_overwrite_layouts_and_pointer_spaces(_sparse_row_mode):
     torch = _torch()
     m = sa.gen.uniform_random(900, 700, 25000, seed=5)
     w, n = 40, 72
@@ -138,6 +184,7 @@ def test_accumulate_overwrite_layouts_and_pointer_spaces():
     Co = _oracle_c(v, B, n)
     d = v.to_device(0)
     C = C0.copy(); d.spmm_host(B, n, C, accumulate=True); _check(C, Co_acc, bound, "host accumulate")
+    _carrier(d, _sparse_row_mode, "layouts: host pointers")
     C = C0.copy(); d.spmm_host(B, n, C, accumulate=True, algo=sa.SPMM_EXACT); assert np.array_equal(C, Co_acc)
     C = np.full(v.rows * n, 3.25, np.float32); d.spmm_host(B, n, C, accumulate=False); _check(C, Co, bound, "host overwrite")
     # device pointers, all four layout combinations, both kernels
@@ -156,6 +203,8 @@ def test_accumulate_overwrite_layouts_and_pointer_spaces():
                     assert np.array_equal(got, Co), (bl, cl)
                 else:
                     _check(got, Co, bound, "layouts %d %d" % (bl, cl))
+                    _carrier(d, _sparse_row_mode, "layouts: B %s C %s" % ("col" if bl == sa.COL_MAJOR else "row", "col" if cl == sa.COL_MAJOR else "row"),
+                             reference_layouts=(bl == sa.COL_MAJOR and cl == sa.COL_MAJOR))
     # leading dimensions larger than the matrix
     ldb, ldc = v.cols + 5, v.rows + 3
     Bp = np.zeros(ldb * n, np.float32); Bp.reshape(n, ldb)[:, :v.cols] = B.reshape(n, v.cols)
@@ -173,7 +222,7 @@ def test_accumulate_overwrite_layouts_and_pointer_spaces():
     _check(Ct2.cpu().numpy(), Co, bound, "side stream")
 
 
-def test_special_block_rows():
+def test_special_block_rows(_sparse_row_mode):
     """empty block-rows (zero blocks), 1-row clusters, one huge block-row, an all-empty matrix row range"""
     torch = _torch()
     rows, cols, w, n = 300, 256, 32, 48
@@ -195,6 +244,7 @@ def test_special_block_rows():
         C = np.full(v.rows * n, 9.0, np.float32)
         d.spmm_host(B, n, C, accumulate=False)      # overwrite must zero the rows of empty block-rows
         _check(C, Co, bound)
+        _carrier(d, _sparse_row_mode, "special block-rows tau %.1f" % eng.tau)
         Cx = np.zeros(v.rows * n, np.float32)
         d.spmm_host(B, n, Cx, accumulate=True, algo=sa.SPMM_EXACT)
         assert np.array_equal(Cx, Co)
@@ -1137,8 +1187,9 @@ def _mixed_checks(torch, _sparse_row_mode, v, w, B, n):
     info = d.info()
     if _sparse_row_mode == "with-sparse-rows":
         assert 0 < info["sparse_rows"] < v.rows and info["tiles16"] + info["tiles32"] + info["tiles64"] > 0
-    else:
+    elif _sparse_row_mode == "mfma-only":
         assert info["sparse_rows"] == 0
+    # (library-defaults: whatever the library decides for a matrix this small -- _carrier records it)
     Bcm = torch.from_numpy(B).cuda()
     Brm = torch.from_numpy(np.ascontiguousarray(B.reshape(n, v.cols).T).reshape(-1)).cuda()
     for bl, Bt in ((sa.COL_MAJOR, Bcm), (sa.ROW_MAJOR, Brm)):
@@ -1153,6 +1204,8 @@ def _mixed_checks(torch, _sparse_row_mode, v, w, B, n):
                     got = np.ascontiguousarray(got.reshape(v.rows, n).T).reshape(-1)
                 want = _oracle_c(v, B, n, C0) if acc else Co
                 _check(got, want, bound + (np.abs(C0) if acc else 0), "sparse rows n=%d layouts %d %d acc %d" % (n, bl, cl, acc))
+                _carrier(d, _sparse_row_mode, "mixed n=%d B %s C %s" % (n, "col" if bl == sa.COL_MAJOR else "row", "col" if cl == sa.COL_MAJOR else "row"),
+                         reference_layouts=(bl == sa.COL_MAJOR and cl == sa.COL_MAJOR))
     # host pointers (the reference's contract: C += A * B)
     Ch = sa.gen.dense_rhs(v.rows, n, seed=13)
     want = _oracle_c(v, B, n, Ch)
@@ -1333,6 +1386,9 @@ def test_create_from_csr_gives_the_same_product(monkeypatch, _sparse_row_mode, c
     torch = _torch()
     monkeypatch.setenv("SPARTA_PATH", "stream")              # two handles compared bit for bit: same MFMA path on both (no autotune)
     monkeypatch.setenv("SPARTA_SPARSE_K_BLOCK", "1e30")      # whole-block-row decisions only, as sparta_vbs_create takes them (the per-block split has its own test below)
+    defaults = _sparse_row_mode == "library-defaults"
+    if not defaults:
+        monkeypatch.setenv("SPARTA_UNION", "0")              # ... and no column-compacted tiles (sparta_vbs_create has no CSR to make them from: tests/test_union_gpu.py)
     n = 128
     if case == "mixed":
         m, w = _mixed_matrix()
@@ -1347,9 +1403,12 @@ def test_create_from_csr_gives_the_same_product(monkeypatch, _sparse_row_mode, c
     d1 = v.to_device(0, dtype=dtype)
     d2 = sa.DeviceVBS.from_csr(m, g, w, rbs, ff, device=0, dtype=dtype)
     i1, i2 = d1.info(), d2.info()
-    assert (i1["rows"], i1["cols"], i1["sparse_rows"], i1["tiles16"], i1["tiles32"], i1["tiles64"]) == \
-           (i2["rows"], i2["cols"], i2["sparse_rows"], i2["tiles16"], i2["tiles32"], i2["tiles64"])
-    assert d1.sparse_info() == d2.sparse_info()
+    # (with the library's own decisions the two builders may differ: the small-matrix rule and the column-compacted tiles belong to the builder that sees the CSR.
+    #  Then the two products agree within the tolerance, each with the oracle; with the rules pinned they agree bit for bit)
+    if not defaults:
+        assert (i1["rows"], i1["cols"], i1["sparse_rows"], i1["tiles16"], i1["tiles32"], i1["tiles64"]) == \
+               (i2["rows"], i2["cols"], i2["sparse_rows"], i2["tiles16"], i2["tiles32"], i2["tiles64"])
+        assert d1.sparse_info() == d2.sparse_info()
     if _sparse_row_mode == "with-sparse-rows":
         assert i2["sparse_rows"] > 0 and i2["nztot"] < i1["nztot"]               # the dense image shrank
     tdt = {sa.F32: torch.float32, sa.F16: torch.float16}[dtype]
@@ -1364,14 +1423,26 @@ def test_create_from_csr_gives_the_same_product(monkeypatch, _sparse_row_mode, c
             d1.spmm(Bt, C1, n, ldb=ldb, c_layout=cl, accumulate=acc)
             d2.spmm(Bt, C2, n, ldb=ldb, c_layout=cl, accumulate=acc)
             torch.cuda.synchronize()
-            assert torch.equal(C1, C2), (case, cl, acc)
+            if not defaults:
+                assert torch.equal(C1, C2), (case, cl, acc)
+            elif dtype == sa.F32:
+                Cr = _oracle_c(v, B, n, np.full(v.rows * n, 0.25, np.float32) if acc else None)
+                bnd = U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n) + (0.25 if acc else 0.0)
+                for Cx, dd, nm in ((C1, d1, "create"), (C2, d2, "from_csr")):
+                    got = Cx.cpu().numpy()
+                    got = got if cl == sa.COL_MAJOR else np.ascontiguousarray(got.reshape(v.rows, n).T).reshape(-1)
+                    _check(got, Cr, bnd, "defaults %s %s" % (nm, case))
+                    _carrier(dd, _sparse_row_mode, "%s %s C %s" % (nm, case, "col" if cl == sa.COL_MAJOR else "row"), reference_layouts=(cl == sa.COL_MAJOR))
+            else:                                                 # 16-bit: the two handles against each other (different decisions: different rounding points -- fp32 sums of the same rounded products)
+                assert torch.allclose(C1, C2, rtol=1e-4, atol=1e-3), (case, cl, acc)
+                _carrier(d2, _sparse_row_mode, "from_csr %s f16 C %s" % (case, "col" if cl == sa.COL_MAJOR else "row"), reference_layouts=(cl == sa.COL_MAJOR), fp32=False)
     if dtype == sa.F32:
         Co = _oracle_c(v, B, n)
         C2 = torch.zeros(v.rows * n, dtype=torch.float32, device="cuda")
         d2.spmm(Bt, C2, n, ldb=ldb)
         torch.cuda.synchronize()
         _check(C2.cpu().numpy(), Co, U.abs_bound(v.rows, v.cols, w, v.row_part, v.nzcount, v.jab, v.mab, B, n), "from_csr " + case)
-        if i2["sparse_rows"] > 0:
+        if i2["sparse_rows"] > 0 or d2.union_info()["area"] > 0:
             with pytest.raises(sa.SpartaError):
                 d2.spmm(Bt, C2, n, ldb=ldb, algo=sa.SPMM_EXACT)
     # unsorted columns are refused (the sparse rows are taken as they are)
@@ -1902,3 +1973,15 @@ def test_16bit_hub_group_tiles_against_the_oracle(monkeypatch, _sparse_row_mode,
         _check(o[2], Co + 0.5, bound + 0.5, "hub %s, accumulate" % hub)
         if Bg is not None:
             _check(o[3], Co, bound, "hub %s, gathered B" % hub)
+
+
+def test_zz_library_defaults_report():
+    """(last in the file) what carried the products of the library-defaults runs above: printed into the log (pytest -s / the captured output of a failure) and
+    checked for coverage -- every kind of carrier must have been exercised by the library's OWN decisions at least once"""
+    if not CARRIED:
+        pytest.skip("the library-defaults runs were deselected")
+    for k in sorted(CARRIED):
+        print("library-defaults | %-44s | %s" % (k, CARRIED[k]))
+    kinds = {"tiles": any(r["tiles"] > 0 for r in CARRIED.values()), "sparse rows": any(r["sparse_rows"] > 0 for r in CARRIED.values()),
+             "resident columns": any(r["resident_columns"] > 0 for r in CARRIED.values())}
+    assert all(kinds.values()), kinds
