@@ -814,15 +814,21 @@ void minhash_lsh(Ctx& c, int64_t* grouping) {
         for (int t = 0; t < r; t++) h = mix64(h ^ sg[b * r + t]);
         return h;
     };
-    struct Entry { uint64_t key; int32_t u; };
+    // Inside a bucket (equal band keys) the rows are ordered by ONE MORE minhash value (the first value of the next band): two rows agree on it with probability = their
+    // similarity, so a seed's true neighbours sit right around its own place in the bucket and a look-up that scans kScanLimit entries OUTWARD from there meets them
+    // first.  (Round 5: with the bucket in row order and the scan running forward from the seed, a bucket of ~1000 rows -- 96 000 rows, 2 values per band -- gave up 3/4
+    // of a cluster's members: the benchmark set's 2000 clusters of 48 rows came back as 3417 groups, 624 of them whole.)
+    struct Entry { uint64_t key; uint32_t key2; int32_t u; };
+    auto second_key = [&](const uint32_t* sg, int b) { return sg[((b + 1) % bands) * r]; };
+    auto entry_less = [](const Entry& x, const Entry& y) { return x.key != y.key ? x.key < y.key : (x.key2 != y.key2 ? x.key2 < y.key2 : x.u < y.u); };
     std::vector<std::vector<Entry>> table((size_t)bands);
     std::vector<int32_t> slot((size_t)bands * (size_t)U);
     parallel_chunks(bands, n_threads, [&](int64_t lo, int64_t hi) {
         for (int64_t b = lo; b < hi; b++) {
             std::vector<Entry>& t = table[(size_t)b];
             t.resize((size_t)U);
-            for (int64_t u = 0; u < U; u++) t[(size_t)u] = Entry{band_key(sig.data() + (size_t)u * K, (int)b), (int32_t)u};
-            std::sort(t.begin(), t.end(), [](const Entry& x, const Entry& y) { return x.key != y.key ? x.key < y.key : x.u < y.u; });
+            for (int64_t u = 0; u < U; u++) t[(size_t)u] = Entry{band_key(sig.data() + (size_t)u * K, (int)b), second_key(sig.data() + (size_t)u * K, (int)b), (int32_t)u};
+            std::sort(t.begin(), t.end(), entry_less);
             int32_t* ps = slot.data() + (size_t)b * (size_t)U;   // where each row sits in this band's table: a seed's first look-up needs no search
             for (int64_t q = 0; q < U; q++) ps[t[(size_t)q].u] = (int32_t)q;
         }
@@ -866,15 +872,22 @@ void minhash_lsh(Ctx& c, int64_t* grouping) {
                 if (!((look >> b) & 1)) continue;
                 const std::vector<Entry>& t = table[(size_t)b];
                 const uint64_t key = keyP[(size_t)b];
-                auto it = first_round ? t.begin() + slot[(size_t)b * (size_t)U + (size_t)su] + 1
-                                      : std::lower_bound(t.begin(), t.end(), Entry{key, (int32_t)su + 1},
-                                                         [](const Entry& x, const Entry& y) { return x.key != y.key ? x.key < y.key : x.u < y.u; });
-                for (int64_t n = 0; it != t.end() && it->key == key && n < kScanLimit; ++it, ++n) {
-                    const int32_t u = it->u;
-                    if (grouping[uniq[(size_t)u]] != -1) continue;
+                // the pattern's place in the bucket (a seed's first look-up: its own slot), then outward: one entry above, one below, ... while the key matches
+                const int64_t at = first_round ? (int64_t)slot[(size_t)b * (size_t)U + (size_t)su]
+                                               : (int64_t)(std::lower_bound(t.begin(), t.end(), Entry{key, second_key(sigP.data(), b), (int32_t)su}, entry_less) - t.begin());
+                int64_t up = first_round ? at + 1 : at, dn = at - 1;
+                const int64_t tn = (int64_t)t.size();
+                auto propose = [&](int32_t u) {
+                    if (u <= (int32_t)su || grouping[uniq[(size_t)u]] != -1) return;            // (rows before the seed are all grouped already; counted against the scan all the same)
                     if (seen[(size_t)u] != (int32_t)su) { seen[(size_t)u] = (int32_t)su; hits[(size_t)u] = 0; fresh.push_back(u); }
-                    else if (hits[(size_t)u] == UINT16_MAX) continue;            // already evaluated for this seed
+                    else if (hits[(size_t)u] == UINT16_MAX) return;                              // already evaluated for this seed
                     hits[(size_t)u]++;
+                };
+                for (int64_t n = 0; n < kScanLimit;) {
+                    const bool can_up = up < tn && t[(size_t)up].key == key, can_dn = dn >= 0 && t[(size_t)dn].key == key;
+                    if (!can_up && !can_dn) break;
+                    if (can_up) { propose(t[(size_t)up].u); up++; n++; }
+                    if (can_dn && n < kScanLimit) { propose(t[(size_t)dn].u); dn--; n++; }
                 }
             }
             look = 0;
