@@ -33,7 +33,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // developer probes, TIMING ONLY (results wrong), UnionParams::pad = SPARTA_UNION_PROBE read per call: 1 no B loads, 2 no A loads, 4 no MFMAs, 8 no tails, 16 no epilogue
 
-constexpr int kUnionStages = 3;
+// Two LDS stages (one step of loads in flight across the barrier) and THREE workgroups per CU: measured on the benchmark set's clustered family (N = 128, prepared B):
+// three stages with two workgroups per CU 172 us, two stages with two 162, two stages with three 160 -- another co-resident workgroup hides a workgroup's waits
+// (barrier, tile epilogue with its tail gathers) better than a deeper pipeline of its own (profiles/r5/lab_union_stages.txt).
+constexpr int kUnionStages = 2;
 constexpr int kUnionLds = kUnionStages * (2 * 4096 + 32 * 512);      // the taller type's stages
 
 template <int MI, int NS>
@@ -168,9 +171,9 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
             if (tail_e > 0 && !(probe & 8)) {
                 const uint2* tp = sd.tail + tq[0] + lm;
                 const float* brow = p.B + n0 + 32 * wave + 4 * g;
-                // four entries at a time: their (column, value) pairs in one round trip, their 4 x MI x 4 pieces of B in a second one (an entry at a time is two round
-                // trips per entry with the matrix pipe idle: 89 of 277 us on the benchmark set's clustered family)
-                constexpr int CH = 4;
+                // two entries at a time: their (column, value) pairs in one round trip, their 2 x MI x 4 pieces of B in a second one (an entry at a time is two round
+                // trips per entry with the matrix pipe idle: 89 of 277 us on the benchmark set's clustered family; four at a time costs the third workgroup per CU its registers)
+                constexpr int CH = 2;
                 for (int e0 = 0; e0 < tail_e; e0 += CH) {
                     uint2 cv[CH][MI];
 #pragma unroll
@@ -239,9 +242,9 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(256, 2) void vbs_union_f32_kernel(const UnionParams p) {
+__global__ __launch_bounds__(256, 3) void vbs_union_f32_kernel(const UnionParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[kUnionLds];
-    static_assert(kUnionLds * 2 <= 160 * 1024, "two workgroups per CU");
+    static_assert(kUnionLds * 3 <= 160 * 1024, "three workgroups per CU");
     const int n2 = p.side[1].n_workers;                  // (wave-uniform: the two bodies are two programs behind one scalar branch)
     if ((int)blockIdx.x < n2) union_body<2, kUnionStages>(p, p.side[1], (int)blockIdx.x, lds);
     else union_body<1, kUnionStages>(p, p.side[0], (int)blockIdx.x - n2, lds);
