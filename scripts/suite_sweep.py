@@ -17,6 +17,16 @@ print("|---|---|---|---|---|---|---|---|---|---|")
 
 
 def log(r):
+    if "points" in r and any("block" in p_ for p_ in r["points"]):      # the reference's block sizes: a real matrix under the fixed grid at 128 .. 1024
+        for p_ in r["points"]:
+            print("|   %s, %d x %d blocks, N = %d, fixed grid | | | | %s | %s | %s | %s | |" % (r["name"].split(":")[0], p_["block"], p_["block"], p_["n_cols"],
+                  p_.get("ms", p_.get("error")), p_.get("useful_gflops", ""), p_.get("carried_by", ""), p_.get("frac_8d", "")), flush=True)
+        return
+    if "points" in r and "reference_csv" in r:                # the R-MAT of the reference's published row, 1024 x 1024 blocks, N = 8192
+        for p_ in r["points"]:
+            print("|   %s, %s (%.2f s) | %d | %d | | %.4f | %.0f | %s | %.3f | reference (its GPU, context only): %.2f / %.2f ms |" % (r["name"], p_["arm"], p_["host_reorder_s"], r["rows"], r["nnz"],
+                  p_["ms"], p_["useful_gflops"], p_["carried_by"], p_["frac_8d"], r["reference_csv"]["fixed_grid_ms"], r["reference_csv"]["clustered_ms"]), flush=True)
+        return
     if "points" in r:                                        # a real matrix at the reference's operand widths, its two arms + blocking_algo 7
         for p_ in r["points"]:
             if "error" in p_:
@@ -33,7 +43,7 @@ def log(r):
           "-" if r.get("ms_prepared_b") is None else "%.4f" % r["ms_prepared_b"]), flush=True)
 
 
-res = bench_suite.run(sa, torch, N=128, device=0, large=True, time_budget_s=600.0, log=log, sweep_budget_s=600.0)
+res = bench_suite.run(sa, torch, N=128, device=0, large=True, time_budget_s=600.0, log=log, sweep_budget_s=600.0, block_budget_s=600.0)
 res["device"] = torch.cuda.get_device_name(0)
 res["kernel_rev"] = sa.KERNEL_REV
 print("min frac_8d %.3f, median %.3f, %.1f s" % (res["min_frac_8d"], res["median_frac_8d"], res["seconds"]))
