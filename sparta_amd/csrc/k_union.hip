@@ -95,17 +95,32 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
             }
         }
         if (!(probe & 1)) {
-            // lanes 0..31 fetch the four even rows, lanes 32..63 the four odd ones: two divergent regions per step, every load in them under half an exec mask
-            auto half = [&](int odd) __attribute__((always_inline)) {
-#pragma unroll
-                for (int r2 = 0; r2 < 4; r2++) {
-                    const int r = 2 * r2 + odd;
-                    const float* rp = Bs0 + (int64_t)rec.id[r] * p.ldb;
-                    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rp), 0, 8 * wave + r < nvalid ? row_bytes : 0u, 0x00020000);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(stp + A_BYTES + (4 * wave + r2) * 1024), 16, voffB, 0, 0, 0);
-                }
+            // lanes 0..31 fetch the even row of a 1 KB piece, lanes 32..63 the odd one: two loads per piece under half an exec mask each, every row through its own
+            // descriptor.  Inline assembly: written as `if (lane < 32) load(even) else load(odd)` the compiler merges the two loads into ONE with a per-lane descriptor and
+            // wraps it in a waterfall loop (readfirstlane / compare / saveexec per distinct descriptor).  EXEC is all ones here (uniform control flow); M0 = the piece's LDS
+            // address (one wait state before the load that uses it), handed back as found (it is the compiler's for its own LDS-direct loads).
+            auto row_desc = [&](int r) __attribute__((always_inline)) -> u32x4 {
+                const uint64_t addr = (uint64_t)(Bs0 + (int64_t)rec.id[r] * p.ldb);
+                return u32x4{(uint32_t)addr, (uint32_t)(addr >> 32) & 0xffffu, 8 * wave + r < nvalid ? row_bytes : 0u, 0x00020000u};
             };
-            if (lane < 32) half(0); else half(1);
+#pragma unroll
+            for (int r2 = 0; r2 < 4; r2++) {
+                const u32x4 dE = row_desc(2 * r2), dO = row_desc(2 * r2 + 1);
+                const uint32_t m0v = (uint32_t)(uintptr_t)(lds_ptr_t)(stp + A_BYTES + (4 * wave + r2) * 1024);
+                uint32_t m0_keep;
+                asm volatile("s_mov_b32 %0, m0\n\t"
+                             "s_mov_b32 m0, %3\n\t"
+                             "s_mov_b32 exec_hi, 0\n\t"
+                             "s_nop 0\n\t"
+                             "buffer_load_dwordx4 %4, %1, 0 offen lds\n\t"
+                             "s_mov_b32 exec_hi, -1\n\t"
+                             "s_mov_b32 exec_lo, 0\n\t"
+                             "s_nop 0\n\t"
+                             "buffer_load_dwordx4 %4, %2, 0 offen lds\n\t"
+                             "s_mov_b32 exec_lo, -1\n\t"
+                             "s_mov_b32 m0, %0"
+                             : "=&s"(m0_keep) : "s"(dE), "s"(dO), "s"(m0v), "v"(voffB) : "memory");
+            }
         }
     };
 
