@@ -142,3 +142,22 @@ def test_resident_column_kernels_keep_their_sums_in_registers(tmp_path):
         assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, (name, m)
         assert m["vgpr_count"] <= 128, (name, m)
         assert m["group_segment_fixed_size"] == 0, (name, m)
+
+
+def test_column_compacted_tile_kernel_fits_three_workgroups_per_cu(tmp_path):
+    """k_union.hip: three workgroups per CU is the point of its two-stage pipeline (profiles/r5/lab_union_stages.txt): 48 KB of LDS (two stages of the taller tile type: 8 KB of A +
+    16 KB of B), at most 168 registers (three waves per SIMD), nothing in scratch; and its panel loads are the hand-written half-wave LDS-direct loads -- no waterfall loop
+    (`v_readfirstlane` + `s_and_saveexec` around a load with a per-lane descriptor) in the step."""
+    kernels = _kernel_metadata(tmp_path)
+    un = {n: m for n, m in kernels.items() if "vbs_union_f32_kernel" in n}
+    assert len(un) == 1, sorted(un)
+    for name, m in un.items():
+        assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, (name, m)
+        assert m["vgpr_count"] <= 168, (name, m)
+        assert m["group_segment_fixed_size"] == 2 * (2 * 4096 + 32 * 512), (name, m)
+    txt = [t for n, t in _disassemble(tmp_path).items() if "vbs_union_f32_kernel" in n]
+    assert len(txt) == 1
+    ins = [l.split("//")[0].strip() for l in txt[0].splitlines() if l.startswith(("\t", " "))]
+    lds_loads = [i for i in ins if i.startswith("buffer_load_dwordx4") and i.endswith("lds")]
+    assert len(lds_loads) >= 2 * (8 + 1) and not any(i.startswith("scratch_") for i in ins), len(lds_loads)
+    assert sum(i.startswith("v_mfma_f32_32x32x2") for i in ins) >= 16 + 32          # both tile types' step bodies

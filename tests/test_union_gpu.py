@@ -176,6 +176,37 @@ def test_tails_and_their_overflow_into_sparse_rows(n):
     d.close()
 
 
+def test_gathered_b_and_a_row_major_b_that_is_not_16_byte_aligned():
+    """the tiles read a ROW-major B in 16-byte pieces: an all-gather-shaped B is transposed into the handle's copy like a column-major one; a row-major B whose rows do not
+    start on 16-byte boundaries (odd leading dimension) is copied once per product into an aligned image"""
+    torch = _torch()
+    w, world = 32, 2
+    m, order = clustered(40, 48, 2 * 2048, 100, 4, seed=31)
+    g = true_grouping(order, 48)
+    d = sa.DeviceVBS.from_csr(m, g, w, device=0)
+    assert d.union_info()["tiles64"] == 40
+    n = 136
+    rng = np.random.default_rng(8)
+    B = rng.uniform(-1, 1, m.cols * n).astype(np.float32)
+    want, bound = _want(m, g, B, n)
+    # gathered: `world` column-major slabs of shard_rows x n back to back
+    shard_rows = m.cols // world
+    Bg = np.concatenate([np.ascontiguousarray(B.reshape(n, m.cols)[:, r * shard_rows:(r + 1) * shard_rows]).reshape(-1) for r in range(world)])
+    Ct = torch.full((m.rows * n,), 7.0, device="cuda")
+    d.spmm_gathered(torch.from_numpy(Bg).cuda(), shard_rows, Ct, n)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(Ct.cpu().numpy() - want) / (bound + 1e-30)) < TOL
+    # row-major with ldb = n + 1 (rows 4 bytes off every time)
+    ldb = n + 1
+    Brm = np.full((m.cols, ldb), 3.0e38, np.float32)
+    Brm[:, :n] = B.reshape(n, m.cols).T
+    Ct = torch.full((m.rows * n,), 7.0, device="cuda")
+    d.spmm(torch.from_numpy(Brm.reshape(-1)).cuda(), Ct, n, b_layout=sa.ROW_MAJOR, ldb=ldb)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(Ct.cpu().numpy() - want) / (bound + 1e-30)) < TOL
+    d.close()
+
+
 def test_prepared_b_gives_the_same_bits_and_force_fixed_padding():
     torch = _torch()
     m, order = clustered(50, 24, 3000, 80, 3, seed=9)
