@@ -904,8 +904,8 @@ def cpu_baseline(sa, args, m, grouping, vb, w, rbs, ff, N, B, ldb, B_gath, world
                       % (sample_what, rows_s, total_rows, 100.0 * rows_s / max(total_rows, 1), nnz_s, cpu_reps, "" if cpu_reps == 1 else "s", t_cpu,
                          exec_flops / t_cpu / 1e9),
             "all_cores": {"value": round(2.0 * nnz_s * N / t_mt / 1e9, 4), "unit": "GFLOP/s", "cores": int(n_thr), "kind": "port",
-                          "sample": "same block-rows, %d threads over block-row ranges (nproc = %d%s), %d repetitions, %.3f s each; executed %.2f GFLOP/s"
-                                    % (n_thr, os.cpu_count() or 0, "" if n_thr >= (os.cpu_count() or 1) else ": NOT an all-core figure -- the sample holds fewer block-rows than the host has cores",
+                          "sample": "same block-rows, %d threads over block-row ranges (CPUs this process may use -- affinity capped by the cgroup quota -- = %d%s), %d repetitions, %.3f s each; executed %.2f GFLOP/s"
+                                    % (n_thr, O.usable_cpus(), "" if n_thr >= O.usable_cpus() else ": NOT an all-core figure -- the sample holds fewer block-rows than the host has cores",
                                        reps_mt, t_mt, exec_flops / t_mt / 1e9)}}
 
 

@@ -159,6 +159,25 @@ def collect_blocking_info(rows, cols, rowptr, colidx, grouping, col_block_size):
                 VBR_average_height=float(avg.value))
 
 
+def usable_cpus():
+    """the CPUs this process may actually use: its affinity mask, capped by the cgroup's CPU quota (a container that sees 256 hardware threads behind a quota of 16 CPUs runs
+    16 threads' worth of work however many it starts)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def vbr_multiply_mt(rows, cols, block_col_size, row_part, nzcount, jab, mab, B, n_cols, block_row_range=None, n_threads=None, C_out=None):
     """The same restatement of VBR::multiply on several host threads: block-rows are independent (each writes its own rows of C,
     vbr.cpp:355), so contiguous ranges of them -- balanced by executed multiply-adds -- run concurrently (ctypes releases the
@@ -173,7 +192,7 @@ def vbr_multiply_mt(rows, cols, block_col_size, row_part, nzcount, jab, mab, B, 
     Cm = np.zeros(rows * n_cols, np.float32) if C_out is None else C_out
     b0, b1 = (0, len(nz)) if block_row_range is None else block_row_range
     if n_threads is None:
-        n_threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        n_threads = usable_cpus()
     n_threads = max(1, min(int(n_threads), b1 - b0))
     work = (np.diff(rp)[b0:b1] * nz[b0:b1]).astype(np.float64) + 1.0
     cum = np.concatenate([[0.0], np.cumsum(work)])

@@ -722,7 +722,7 @@ void minhash_lsh(Ctx& c, int64_t* grouping) {
     const float tau = cfg.tau;
     std::fill(grouping, grouping + rows, (int64_t)-1);
     if (rows == 0) return;
-    int n_threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    int n_threads = std::min(16, sparta::host_threads());                 // (the CPUs the process may use: host_core.hpp)
     if (const char* e = std::getenv("SPARTA_REORDER_THREADS")) n_threads = std::max(1, atoi(e));
     int64_t kScanLimit = 256;                                    // entries looked at per bucket look-up
     if (const char* e = std::getenv("SPARTA_MINHASH_SCAN")) kScanLimit = std::max(1, atoi(e));
