@@ -257,6 +257,262 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// =====================================================================================================================================================================
+// 16-bit handles (fp16 / bf16 storage of A and B, fp32 accumulation and C): the same tiles, the same pipeline, the 16-bit matrix instruction.
+//   * the panel of B is 32 rows of 256 bytes (128 columns x 2 bytes) of the ROW-major 16-bit copy of B, LDS image Bs[k][128]; wave v fetches rows 8 v .. 8 v + 7, four rows per
+//     1 KB piece: lanes 16 r' .. 16 r' + 15 the piece's row r' (quarter exec masks, every row through its own descriptor);
+//   * `v_mfma_f32_32x32x16_{f16,bf16}` wants, per lane, 8 consecutive k of ITS column of the panel -- a column of a k-major image.  gfx950's `ds_read_b64_tr_b16` is that transpose:
+//     per group of 16 lanes it reads a block of 4 rows x 16 columns and hands lane i column i of the 4 rows (lane 4 q + p supplies the address of row q, columns 4 p .. 4 p + 3);
+//     two such reads per MFMA and lane.  Bank-conflict-free with 16-byte chunk ch of row r stored at position ch ^ (((r & 3) << 2) | ((r >> 2) & 3)) (cdna_hip_programming.md
+//     T10, image (b)); the LDS-direct load writes lane-linear, so the swizzle is on the SOURCE side: lane l of a row's 16 fetches chunk l ^ s(r);
+//   * the slice of A (32 MI rows x 32 k) is stored in HBM as the LDS image [rt][m][kg][row][8] = A[32 rt + row][k = 16 m + 8 kg + e]: one `ds_read_b128` per MFMA and lane;
+//   * the tails multiply in fp32: value (the rounded 16-bit value of A, kept as fp32) x the 16-bit entries of the row of B widened in registers -- products of two 16-bit
+//     values are exact in fp32, as in the matrix instruction.
+// Three LDS stages of 12 KB (4 KB of A -- two of them unused by the <= 32-row tiles -- + 8 KB of B), three workgroups per CU.
+constexpr int kUnion16Stages = 3;
+constexpr int kUnion16Lds = kUnion16Stages * (4096 + 32 * 256);
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+template <int MI, bool BF16>
+__device__ __forceinline__ void union16_body(const UnionParams& p, const UnionSide& sd, const int worker, char* const lds) {
+    constexpr int NS = kUnion16Stages;
+    constexpr int A_BYTES = 4096, B_BYTES = 32 * 256, STAGE = A_BYTES + B_BYTES;
+    constexpr int LPS = 8 + 1;                           // vector-memory instructions per wave and step: its eight rows of B, one piece of A (waves behind the slice's pieces: zeros)
+    constexpr int AHEAD = NS - 1;
+    static_assert((AHEAD - 1) * LPS <= 63, "vmcnt holds 6 bits");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 31, g = lane >> 5;
+    const int n0 = (int)blockIdx.y * kTN;
+    const int probe = p.pad;
+    const int s_begin = sd.worker_range[2 * worker];
+    const int n = sd.worker_range[2 * worker + 1] - s_begin;
+    if (n <= 0) return;
+
+    typedef const __attribute__((address_space(4))) int32_t* cptr_t;
+    const cptr_t srec = (cptr_t)(reinterpret_cast<const int32_t*>(sd.rec + s_begin));
+    const cptr_t sids = (cptr_t)(sd.ids + (int64_t)s_begin * 32 + 8 * wave);
+    struct Rec { int32_t c_row, info, tail_off, id[8]; };
+    auto load_rec = [&](int j) __attribute__((always_inline)) -> Rec {
+        Rec r;
+        r.c_row = srec[(int64_t)j * 4]; r.info = srec[(int64_t)j * 4 + 1]; r.tail_off = srec[(int64_t)j * 4 + 2];
+#pragma unroll
+        for (int q = 0; q < 8; q++) r.id[q] = sids[(int64_t)j * 32 + q];
+        return r;
+    };
+
+    const int ncv = p.n_cols - n0;
+    const uint32_t row_bytes = ncv >= kTN ? 256u : (uint32_t)((ncv * 2 + 15) & ~15);        // (whole 16-byte chunks: ldb % 8 == 0)
+    const uint16_t* const B16 = reinterpret_cast<const uint16_t*>(p.B);
+    const uint16_t* const Bs0 = B16 + n0;
+    const uint16_t* const A0 = reinterpret_cast<const uint16_t*>(sd.A) + (int64_t)s_begin * (MI * 1024);
+    // B loads: row r of this wave's eight is panel row k = 8 wave + r; lane l of its 16 fetches source chunk l ^ s(k)
+    uint32_t voffB[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { const int k = 8 * wave + r; voffB[r] = (uint32_t)((((lane & 15) ^ (((k & 3) << 2) | ((k >> 2) & 3)))) * 16); }
+    const uint32_t voffA = (uint32_t)lane * 16u;
+    // transposed fragment reads: MFMA m (k = 16 m ..), half h (rows + 4 h): the block of rows r0 = 16 m + 8 g + 4 h .. + 3, columns 32 wave + 16 gq .. + 15 (chunks c0, c0 + 1);
+    // lane 4 q + pp of the group: row r0 + q, chunk c0 + (pp >> 1), + 8 (pp & 1) bytes
+    uint32_t rdB[2][2];
+    {
+        const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, gq = (lane >> 4) & 1;
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int row = 16 * m + 8 * g + 4 * h + q, ch = 4 * wave + 2 * gq + (pp >> 1);
+                rdB[m][h] = (uint32_t)(256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) + 8 * (pp & 1));
+            }
+    }
+    char* const lds0 = lds;
+
+    auto issue = [&](const Rec& rec, int j, int stage) __attribute__((always_inline)) {
+        char* const stp = lds0 + stage * STAGE;
+        const int nvalid = (rec.info >> 8) & 63;
+        if (!(probe & 2)) {
+            // piece `wave` of the slice (MI x 2 pieces of 1 KB; behind them: past the descriptor's end -- zeros in LDS, no access; the A area holds four pieces whatever MI)
+            const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A0 + (int64_t)j * (MI * 1024)), 0, MI * 2048, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(stp + wave * 1024), 16, voffA, (uint32_t)(wave * 1024), 0, 0);
+        }
+        if (!(probe & 1)) {
+            auto row_desc = [&](int r) __attribute__((always_inline)) -> u32x4 {
+                const uint64_t addr = (uint64_t)(Bs0 + (int64_t)rec.id[r] * p.ldb);
+                return u32x4{(uint32_t)addr, (uint32_t)(addr >> 32) & 0xffffu, 8 * wave + r < nvalid ? row_bytes : 0u, 0x00020000u};
+            };
+#pragma unroll
+            for (int pc = 0; pc < 2; pc++) {             // two pieces of four rows; lanes [16 r', 16 r' + 16) fetch the piece's row r' (EXEC all ones on entry and on exit)
+                const u32x4 d0 = row_desc(4 * pc), d1 = row_desc(4 * pc + 1), d2 = row_desc(4 * pc + 2), d3 = row_desc(4 * pc + 3);
+                const uint32_t m0v = (uint32_t)(uintptr_t)(lds_ptr_t)(stp + A_BYTES + (2 * wave + pc) * 1024);
+                uint32_t m0_keep;
+                asm volatile("s_mov_b32 %0, m0\n\t"
+                             "s_mov_b32 m0, %5\n\t"
+                             "s_mov_b32 exec_hi, 0\n\t"
+                             "s_mov_b32 exec_lo, 0xffff\n\t"
+                             "s_nop 0\n\t"
+                             "buffer_load_dwordx4 %6, %1, 0 offen lds\n\t"
+                             "s_mov_b32 exec_lo, 0xffff0000\n\t"
+                             "s_nop 0\n\t"
+                             "buffer_load_dwordx4 %7, %2, 0 offen lds\n\t"
+                             "s_mov_b32 exec_lo, 0\n\t"
+                             "s_mov_b32 exec_hi, 0xffff\n\t"
+                             "s_nop 0\n\t"
+                             "buffer_load_dwordx4 %8, %3, 0 offen lds\n\t"
+                             "s_mov_b32 exec_hi, 0xffff0000\n\t"
+                             "s_nop 0\n\t"
+                             "buffer_load_dwordx4 %9, %4, 0 offen lds\n\t"
+                             "s_mov_b32 exec_lo, -1\n\t"
+                             "s_mov_b32 exec_hi, -1\n\t"
+                             "s_mov_b32 m0, %0"
+                             : "=&s"(m0_keep)
+                             : "s"(d0), "s"(d1), "s"(d2), "s"(d3), "s"(m0v), "v"(voffB[4 * pc]), "v"(voffB[4 * pc + 1]), "v"(voffB[4 * pc + 2]), "v"(voffB[4 * pc + 3])
+                             : "memory");
+            }
+        }
+    };
+
+    f32x16 acc[MI];
+#pragma unroll
+    for (int rt = 0; rt < MI; rt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[rt][r] = 0.0f;
+
+    int32_t iq[NS], cq[NS], tq[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) { iq[k] = 0; cq[k] = 0; tq[k] = 0; }
+#pragma unroll
+    for (int k = 0; k < AHEAD; k++) {
+        const Rec r = load_rec(k);
+        iq[k] = r.info; cq[k] = r.c_row; tq[k] = r.tail_off;
+        issue(r, k, k);
+    }
+    Rec nxt = load_rec(AHEAD);
+
+    const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 4 * g) * 4) : (uint32_t)((lm + (4 * g) * p.ldc) * 4);
+    const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;
+    const uint32_t mistep = p.c_row_major ? (uint32_t)p.ldc * 128u : 128u;
+    const int ncw = ncv - 32 * wave;
+    auto widen = [](uint32_t u16) __attribute__((always_inline)) -> float {            // one 16-bit element of B -> fp32
+        if constexpr (BF16) return __uint_as_float(u16 << 16);
+        else { const uint16_t h = (uint16_t)u16; _Float16 x; __builtin_memcpy(&x, &h, 2); return (float)x; }
+    };
+
+    int stage = 0;
+    for (int i = 0; i < n; i++) {
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"((AHEAD - 1) * LPS) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const Rec rec = nxt;
+        nxt = load_rec(i + AHEAD + 1);
+        int jstage = stage + AHEAD; if (jstage >= NS) jstage -= NS;
+        iq[AHEAD] = rec.info; cq[AHEAD] = rec.c_row; tq[AHEAD] = rec.tail_off;
+        issue(rec, i + AHEAD, jstage);
+        if (!(probe & 4)) {
+            const char* const sa = lds0 + stage * STAGE;
+            typedef __attribute__((address_space(3))) s16x4* tr_ptr_t;
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(lds_ptr_t)(sa + A_BYTES + rdB[m][0]));
+                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(lds_ptr_t)(sa + A_BYTES + rdB[m][1]));
+                const s16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int rt = 0; rt < MI; rt++) {
+                    const s16x8 af = *reinterpret_cast<const s16x8*>(sa + (rt * 2 + m) * 1024 + lane * 16);
+                    if constexpr (BF16) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bf), __builtin_bit_cast(bf16x8_t, af), acc[rt], 0, 0, 0);
+                    else acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, bf), __builtin_bit_cast(f16x8_t, af), acc[rt], 0, 0, 0);
+                }
+            }
+        }
+        const int32_t info = iq[0];
+        if ((info & UREC_LAST) && !(probe & 16)) {
+            const int mt = info & 127;
+            const int64_t c_row = cq[0];
+            const int tail_e = (info >> UREC_TAIL_SHIFT) & 31;
+            if (tail_e > 0 && !(probe & 8)) {
+                const uint2* tp = sd.tail + tq[0] + lm;
+                const uint16_t* brow = B16 + n0 + 32 * wave + 4 * g;
+                constexpr int CH = 2;
+                for (int e0 = 0; e0 < tail_e; e0 += CH) {
+                    uint2 cv[CH][MI];
+#pragma unroll
+                    for (int c = 0; c < CH; c++)
+#pragma unroll
+                        for (int rt = 0; rt < MI; rt++) cv[c][rt] = e0 + c < tail_e ? tp[((e0 + c) * MI + rt) * 32] : uint2{0u, 0u};
+                    uint2 bv[CH][MI][4];                  // four consecutive 16-bit columns per piece
+#pragma unroll
+                    for (int c = 0; c < CH; c++)
+#pragma unroll
+                        for (int rt = 0; rt < MI; rt++) {
+                            const uint16_t* bp = brow + (int64_t)cv[c][rt].x * p.ldb;
+#pragma unroll
+                            for (int qq = 0; qq < 4; qq++) bv[c][rt][qq] = (e0 + c < tail_e && 8 * qq + 4 * g < ncw) ? *reinterpret_cast<const uint2*>(bp + 8 * qq) : uint2{0u, 0u};
+                        }
+#pragma unroll
+                    for (int c = 0; c < CH; c++)
+#pragma unroll
+                        for (int rt = 0; rt < MI; rt++) {
+                            const float av = __uint_as_float(cv[c][rt].y);
+#pragma unroll
+                            for (int qq = 0; qq < 4; qq++) {
+                                const uint2 w2 = bv[c][rt][qq];
+                                acc[rt][4 * qq + 0] = __builtin_fmaf(av, widen(w2.x & 0xffffu), acc[rt][4 * qq + 0]);
+                                acc[rt][4 * qq + 1] = __builtin_fmaf(av, widen(w2.x >> 16), acc[rt][4 * qq + 1]);
+                                acc[rt][4 * qq + 2] = __builtin_fmaf(av, widen(w2.y & 0xffffu), acc[rt][4 * qq + 2]);
+                                acc[rt][4 * qq + 3] = __builtin_fmaf(av, widen(w2.y >> 16), acc[rt][4 * qq + 3]);
+                            }
+                        }
+                }
+            }
+            float* cbase = p.c_row_major ? p.C + c_row * p.ldc + (n0 + 32 * wave) : p.C + c_row + (int64_t)(n0 + 32 * wave) * p.ldc;
+            const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+            for (int rt = 0; rt < MI; rt++) {
+                if (rt * 32 + lm < mt) {
+                    float v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) v[q] = acc[rt][q];
+                    if (p.accumulate) {
+                        uint32_t old[16];
+#pragma unroll
+                        for (int q = 0; q < 16; q++) {
+                            const int col = (q & 3) + 8 * (q >> 2);
+                            old[q] = col + 4 * g < ncw ? __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)col * jstep + (uint32_t)rt * mistep, 0) : 0u;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const int col = (q & 3) + 8 * (q >> 2);
+                        if (col + 4 * g < ncw) {
+                            if (sd.c_nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)col * jstep + (uint32_t)rt * mistep, 2);
+                            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)col * jstep + (uint32_t)rt * mistep, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < MI; rt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[rt][r] = 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < AHEAD; k++) { iq[k] = iq[k + 1]; cq[k] = cq[k + 1]; tq[k] = tq[k + 1]; }
+        stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256, 3) void vbs_union_h16_kernel(const UnionParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[kUnion16Lds];
+    const int n2 = p.side[1].n_workers;
+    if ((int)blockIdx.x < n2) union16_body<2, BF16>(p, p.side[1], (int)blockIdx.x, lds);
+    else union16_body<1, BF16>(p, p.side[0], (int)blockIdx.x - n2, lds);
+}
+
 __global__ __launch_bounds__(256, 3) void vbs_union_f32_kernel(const UnionParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[kUnionLds];
     static_assert(kUnionLds * 3 <= 160 * 1024, "three workgroups per CU");
@@ -272,6 +528,12 @@ namespace sparta_dev {
 // ONE launch: grid = (workers of the 33..64-row tiles + workers of the <= 32-row tiles, 128-column slabs)
 void launch_union_f32(unsigned n_slabs, hipStream_t st, const UnionParams& p) {
     hipLaunchKernelGGL(vbs_union_f32_kernel, dim3((unsigned)(p.side[0].n_workers + p.side[1].n_workers), n_slabs), dim3(256), 0, st, p);
+}
+// the same for a 16-bit handle: UnionParams::B is the ROW-major 16-bit copy of B (ld a multiple of 8 elements), UnionSide::A the 16-bit slices
+void launch_union_h16(bool bf16, unsigned n_slabs, hipStream_t st, const UnionParams& p) {
+    const dim3 grid((unsigned)(p.side[0].n_workers + p.side[1].n_workers), n_slabs);
+    if (bf16) hipLaunchKernelGGL(vbs_union_h16_kernel<true>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(vbs_union_h16_kernel<false>, grid, dim3(256), 0, st, p);
 }
 
 }  // namespace sparta_dev

@@ -732,7 +732,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         if (!plan_debug) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) n_cus = pr.multiProcessorCount; }
         // (workgroups per CU the kernel is built for: k_union.hip's launch bound and LDS; SPARTA_UNION_WPC: developer A/B)
         const int wpc = [] { const char* e = std::getenv("SPARTA_UNION_WPC"); return e ? std::max(1, atoi(e)) : 3; }();
-        if (int rc = build_union_plan(ext->uni, wpc * n_cus, uplan)) return rc;
+        if (int rc = build_union_plan(ext->uni, wpc * n_cus, uplan, dtype)) return rc;
         trace.lap("column-compacted tiles (plan)");
     }
     std::vector<StepRec>(&steps)[2] = plan.steps;
@@ -865,13 +865,14 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         CREATE_TRY(hipMemcpy(v->d_u_rec[ty], uplan.rec[ty].data(), uplan.rec[ty].size() * sizeof(UnionRec), hipMemcpyHostToDevice));
         CREATE_TRY(hipMalloc((void**)&v->d_u_ids[ty], uplan.ids[ty].size() * sizeof(int32_t)));
         CREATE_TRY(hipMemcpy(v->d_u_ids[ty], uplan.ids[ty].data(), uplan.ids[ty].size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        CREATE_TRY(hipMalloc((void**)&v->d_u_a[ty], uplan.a[ty].size() * sizeof(float)));
-        CREATE_TRY(hipMemcpy(v->d_u_a[ty], uplan.a[ty].data(), uplan.a[ty].size() * sizeof(float), hipMemcpyHostToDevice));
+        const size_t a_bytes_ty = h16 ? uplan.a16[ty].size() * sizeof(uint16_t) : uplan.a[ty].size() * sizeof(float);
+        CREATE_TRY(hipMalloc((void**)&v->d_u_a[ty], a_bytes_ty));
+        CREATE_TRY(hipMemcpy(v->d_u_a[ty], h16 ? (const void*)uplan.a16[ty].data() : (const void*)uplan.a[ty].data(), a_bytes_ty, hipMemcpyHostToDevice));
         CREATE_TRY(hipMalloc((void**)&v->d_u_wrange[ty], uplan.wrange[ty].size() * sizeof(int32_t)));
         CREATE_TRY(hipMemcpy(v->d_u_wrange[ty], uplan.wrange[ty].data(), uplan.wrange[ty].size() * sizeof(int32_t), hipMemcpyHostToDevice));
         CREATE_TRY(hipMalloc(&v->d_u_tail[ty], uplan.tail[ty].size() * sizeof(uint32_t)));
         CREATE_TRY(hipMemcpy(v->d_u_tail[ty], uplan.tail[ty].data(), uplan.tail[ty].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        v->a_bytes += (int64_t)(uplan.a[ty].size() * sizeof(float) + uplan.ids[ty].size() * sizeof(int32_t) + uplan.tail[ty].size() * sizeof(uint32_t));
+        v->a_bytes += (int64_t)(a_bytes_ty + uplan.ids[ty].size() * sizeof(int32_t) + uplan.tail[ty].size() * sizeof(uint32_t));
         v->exec_area += uplan.n_steps[ty] * 32 * 32 * (ty + 1);
     }
     if (ext) { v->u_area = uplan.area; v->u_cols = uplan.cols; v->u_nnz = ext->uni.nnz; v->u_tail_nnz = ext->uni.tail_nnz; v->u_rows = uplan.rows; }
@@ -998,7 +999,7 @@ static int create_from_csr_impl(sparta_vbs_t** out, int64_t rows, int64_t cols, 
         const int64_t kdep = (dtype != SPARTA_F32 && col_block_size % 64 == 0) ? 64 : 32;
         sparta::HybridSparse sp;
         sp.esz = dtype == SPARTA_F32 ? 4.0 : 2.0;
-        sp.want_union = dtype == SPARTA_F32;                               // column-compacted tiles: fp32 handles (k_union.hip)
+        sp.want_union = true;                                              // column-compacted tiles (k_union.hip: fp32 and 16-bit forms)
         rc = sparta::vbs_build_hybrid(a, grouping, col_block_size, row_block_size, force_fixed_size != 0, K, kdep, &h, K > 0.0 ? &sp : nullptr, keep_order);
         if (rc == SPARTA_OK)
             rc = create_core(out, h.rows, h.cols, h.block_rows, col_block_size, h.row_part, h.nzcount, h.jab, h.mab, 0, h.block_rows, dtype, device,
@@ -1027,7 +1028,7 @@ int sparta_vbs_plan_stats(int64_t rows, int64_t cols, const int64_t* rowptr, con
     const int64_t kdep = (dtype != SPARTA_F32 && col_block_size % 64 == 0) ? 64 : 32;
     sparta::HybridSparse sp;
     sp.esz = dtype == SPARTA_F32 ? 4.0 : 2.0;
-    sp.want_union = dtype == SPARTA_F32;
+    sp.want_union = true;
     sparta::HybridStats st;
     sparta_vbs_host h;
     std::memset(&h, 0, sizeof(h));
@@ -1405,13 +1406,14 @@ int ensure_brm(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_major, i
 
 // the column-compacted tiles (k_union.hip): C[tile rows, :] (+)= Atile . B[list, :] on the matrix cores, B row-major.  Stores (or adds to) every row of its tiles;
 // the sparse rows of those block-rows (their thinly used columns) add behind it on the same stream.
-int launch_union_tiles(sparta_vbs_t* A, const float* dB, int64_t ldb, bool b_row_major, int64_t shard_rows, int64_t shard_stride, int32_t n_cols, float* dC,
+int launch_union_tiles(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_major, int64_t shard_rows, int64_t shard_stride, int32_t n_cols, float* dC,
                        int64_t ldc, bool c_row_major, bool accumulate, hipStream_t st) {
     if (A->u_steps[0] + A->u_steps[1] == 0) return SPARTA_OK;
     // 32-bit byte offsets inside a tile's 64 rows x 32 columns of C
     if ((c_row_major ? 64 * ldc + 128 : 32 * ldc + 128) * 4 >= ((int64_t)1 << 31) - 65536)
         return sparta::fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: leading dimension of C too large for the column-compacted tile kernel (32-bit offsets inside a tile)");
-    if (int rc = ensure_brm(A, dB, ldb, b_row_major, shard_rows, shard_stride, 0, n_cols, st, true)) return rc;
+    const int bk = A->dtype == SPARTA_F32 ? 0 : (A->dtype == SPARTA_BF16 ? 2 : 1);
+    if (int rc = ensure_brm(A, dB, ldb, b_row_major, shard_rows, shard_stride, bk, n_cols, st, true)) return rc;
     UnionParams up;
     up.B = (const float*)A->brm_ready; up.ldb = A->brm_ld; up.C = dC; up.ldc = ldc;
     up.n_cols = n_cols; up.accumulate = accumulate ? 1 : 0; up.c_row_major = c_row_major ? 1 : 0;
@@ -1424,7 +1426,8 @@ int launch_union_tiles(sparta_vbs_t* A, const float* dB, int64_t ldb, bool b_row
         const char* e = std::getenv("SPARTA_C_NT");
         sd.c_nt = e ? (atoi(e) != 0) : (A->u_steps[ty] >= 6 * A->u_tiles[ty] ? 1 : 0);
     }
-    launch_union_f32((unsigned)((n_cols + kTN - 1) / kTN), st, up);
+    if (bk == 0) launch_union_f32((unsigned)((n_cols + kTN - 1) / kTN), st, up);
+    else launch_union_h16(bk == 2, (unsigned)((n_cols + kTN - 1) / kTN), st, up);
     HIP_TRY(hipGetLastError());
     return SPARTA_OK;
 }
@@ -1664,12 +1667,18 @@ int spmm16_core(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
         if (zero_launch) launch_zero_ranges(A, dC, ldc, c_layout == SPARTA_ROW_MAJOR, n_cols, st);
         if (prof) { HIP_TRY(hipEventRecord(A->cev[1][1], st)); A->class_ran[1] = true; }
     }
+    // (a 16-bit product runs this core once per piece of B -- the whole slabs, then the padded tail slab: each piece has its own row-major copy, made by whoever needs it first)
+    A->brm_ready = nullptr; A->brm_ld = 0;
+    struct BrmPiece { sparta_vbs_t* a; ~BrmPiece() { a->brm_ready = nullptr; a->brm_ld = 0; } } brm_piece{A};
+    if (A->u_steps[0] + A->u_steps[1] > 0) {   // column-compacted tiles (k_union.hip, 16-bit form): they store every row of their block-rows; those block-rows' sparse rows add, below
+        const bool rec = prof && !A->class_ran[2];
+        if (rec) HIP_TRY(hipEventRecord(A->cev[2][0], st));
+        if (int rc = launch_union_tiles(A, dB, ldb16, false, shard_rows, shard_stride, n_cols, dC, ldc, c_layout == SPARTA_ROW_MAJOR, accumulate != 0, st)) return rc;
+        if (rec) { HIP_TRY(hipEventRecord(A->cev[2][1], st)); A->class_ran[2] = true; }
+    }
     if (A->n_sp_rows > 0) {                  // nearly empty block-rows: sparse rows over a row-major 16-bit copy of B
         if (prof) HIP_TRY(hipEventRecord(A->cev[3][0], st));
-        A->brm_ready = nullptr; A->brm_ld = 0;            // (a 16-bit product runs this core once per piece of B: each piece has its own row-major copy)
-        const int rc_sp = launch_sparse_rows(A, dB, ldb16, false, shard_rows, shard_stride, bf16 ? 2 : 1, n_cols, dC, ldc, c_layout == SPARTA_ROW_MAJOR, accumulate != 0, st);
-        A->brm_ready = nullptr; A->brm_ld = 0;
-        if (rc_sp) return rc_sp;
+        if (int rc = launch_sparse_rows(A, dB, ldb16, false, shard_rows, shard_stride, bf16 ? 2 : 1, n_cols, dC, ldc, c_layout == SPARTA_ROW_MAJOR, accumulate != 0, st)) return rc;
         if (prof) { HIP_TRY(hipEventRecord(A->cev[3][1], st)); A->class_ran[3] = true; }
     }
     A->last_path = 1;

@@ -414,6 +414,7 @@ void launch_b_to_row_major(bool is16, unsigned grid, hipStream_t st, const void*
                            void* out, int64_t ld_out);
 // k_union.hip
 void launch_union_f32(unsigned n_slabs, hipStream_t st, const UnionParams& p);
+void launch_union_h16(bool bf16, unsigned n_slabs, hipStream_t st, const UnionParams& p);   // 16-bit handles: p.B = the row-major 16-bit B, side.A = 16-bit slices
 // k_colres.hip
 int launch_colres(int nc, const ColresParams& p, size_t lds_bytes, hipStream_t st);     // nc = 1..4 columns per workgroup; 0 or a hipError_t
 int colres_max_slices(int nc);                                                          // slices the nc-column kernel holds sums for
@@ -457,14 +458,15 @@ struct StreamPlanHost {
 struct UnionDevPlan {
     std::vector<UnionRec> rec[2];
     std::vector<int32_t> ids[2];
-    std::vector<float> a[2];
+    std::vector<float> a[2];                  // fp32 handles: slices [step][MI x 1024] floats
+    std::vector<uint16_t> a16[2];             // 16-bit handles: slices [step][MI x 1024] 16-bit elements, [rt][m][kg][row][8] = A[32 rt + row][k = 16 m + 8 kg + e] (rounded to the storage type)
     std::vector<int32_t> wrange[2];
     std::vector<uint32_t> tail[2];            // (column, value bits) pairs, tile after tile in execution order
     int32_t n_workers[2] = {0, 0};
     int64_t n_steps[2] = {0, 0};
     int64_t area = 0, cols = 0, rows = 0;     // stored elements (tile rows x list entries); list entries; rows of C the tiles own
 };
-int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPlan& P);
+int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPlan& P, int dtype = SPARTA_F32);
 // y (+)= the tiles' part of A . x, walked on the HOST from the device form (test aid for the CPU suite: the layout of plan and slices without a GPU)
 void union_plan_host_apply(const UnionDevPlan& P, const float* x, double* y);
 

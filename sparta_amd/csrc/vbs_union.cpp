@@ -15,7 +15,8 @@
 
 namespace sparta_dev {
 
-int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPlan& P) {
+int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPlan& P, int dtype) {
+    const bool h16 = dtype != SPARTA_F32, bf16 = dtype == SPARTA_BF16;
     auto steps_of = [&](int ty, size_t t) { return std::max<int64_t>(1, ((int64_t)U.tiles[ty][t].nk + 31) / 32); };   // (a tile without a kept column still stores its rows: one step of zeros)
     // workers per type: in proportion to the MFMA work (a step of a 64-row tile is two of a 32-row one), at least one each, never more than tiles
     double work[2] = {0.0, 0.0};
@@ -55,7 +56,8 @@ int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPl
         P.n_workers[ty] = Wt; P.n_steps[ty] = total;
         P.rec[ty].assign((size_t)(total + kUnionPadSteps), UnionRec{0, 0, 0, 0});
         P.ids[ty].assign((size_t)(total + kUnionPadSteps) * 32, 0);
-        P.a[ty].assign((size_t)(total + kUnionPadSteps) * 1024 * mi, 0.0f);
+        if (h16) P.a16[ty].assign((size_t)(total + kUnionPadSteps) * 1024 * mi, (uint16_t)0);
+        else P.a[ty].assign((size_t)(total + kUnionPadSteps) * 1024 * mi, 0.0f);
         P.tail[ty].assign((size_t)tail_total * 2 + 2, 0u);
         P.wrange[ty].assign((size_t)Wt * 2, 0);
         std::vector<int64_t> first((size_t)Wt + 1, 0), tfirst((size_t)Wt + 1, 0);
@@ -78,7 +80,13 @@ int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPl
                     const int64_t ns = steps_of(ty, t), ldt = 32 * mi;
                     for (int64_t x = 0; x < (int64_t)tl.tail_e * ldt; x++) {
                         uint32_t vb;
-                        std::memcpy(&vb, &U.tail_val[ty][(size_t)(tl.tail0 + x)], 4);
+                        float tv = U.tail_val[ty][(size_t)(tl.tail0 + x)];
+                        if (h16) {                                            // the value the 16-bit handle holds: rounded to the storage type, kept as fp32
+                            const uint16_t u = to_h16(tv, bf16);
+                            if (bf16) { const uint32_t w32 = (uint32_t)u << 16; std::memcpy(&tv, &w32, 4); }
+                            else { _Float16 hh; std::memcpy(&hh, &u, 2); tv = (float)hh; }
+                        }
+                        std::memcpy(&vb, &tv, 4);
                         P.tail[ty][(size_t)(to + x) * 2] = (uint32_t)U.tail_col[ty][(size_t)(tl.tail0 + x)];
                         P.tail[ty][(size_t)(to + x) * 2 + 1] = vb;
                     }
@@ -86,6 +94,17 @@ int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPl
                         const int nvalid = (int)std::min<int64_t>(32, std::max<int64_t>(0, (int64_t)tl.nk - 32 * q));
                         P.rec[ty][(size_t)s] = UnionRec{tl.c_row, tl.mt | (nvalid << 8) | (q == ns - 1 ? UREC_LAST : 0) | (tl.tail_e << UREC_TAIL_SHIFT), (int32_t)to, 0};
                         for (int k = 0; k < nvalid; k++) P.ids[ty][(size_t)s * 32 + (size_t)k] = cl[32 * q + k];
+                        if (h16) {
+                            uint16_t* d16 = P.a16[ty].data() + (size_t)s * 1024 * (size_t)mi;
+                            for (int rt = 0; rt < mi; rt++)
+                                for (int k = 0; k < nvalid; k++) {
+                                    const int m = k >> 4, kg = (k >> 3) & 1, e = k & 7;
+                                    const float* src = img + (32 * q + k) * ldt + 32 * rt;
+                                    uint16_t* d = d16 + ((size_t)((rt * 2 + m) * 2 + kg) * 32) * 8 + e;
+                                    for (int row = 0; row < 32; row++) d[row * 8] = to_h16(src[row], bf16);
+                                }
+                            continue;
+                        }
                         float* dst = P.a[ty].data() + (size_t)s * 1024 * (size_t)mi;
                         for (int rt = 0; rt < mi; rt++)
                             for (int j = 0; j < 4; j++)
@@ -108,7 +127,7 @@ int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPl
 }
 
 // the tiles' part of A . x from the DEVICE form (records, list entries, fragment-order slices, tails), the way the kernel indexes them; y[row of C] += ...
-void union_plan_host_apply(const UnionDevPlan& P, const float* x, double* y) {
+void union_plan_host_apply(const UnionDevPlan& P, const float* x, double* y) {      // (fp32 plans)
     for (int ty = 0; ty < 2; ty++) {
         const int mi = ty + 1;
         for (int w = 0; w < P.n_workers[ty]; w++)

@@ -254,3 +254,77 @@ def test_clustering_found_by_the_library_on_the_suite_family():
     got0 = _product(torch, d0, B, n)
     assert np.max(np.abs(got0 - want) / (bound + 1e-30)) < TOL
     d.close(); d0.close()
+
+
+# ---- 16-bit handles: the same tiles through `v_mfma_f32_32x32x16_{f16,bf16}` (panel of B read with the LDS transpose loads) -----------------------------------------------------
+
+def _round16(x, dtype):
+    """fp32 -> fp16 / bf16 -> fp32, round to nearest even"""
+    x = np.ascontiguousarray(x, np.float32)
+    if dtype == sa.F16:
+        return x.astype(np.float16).astype(np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+
+def _b16(torch, B, dtype, n, cols, ldb=None):
+    """column-major 16-bit device image of B (ld = ldb)"""
+    ldb = ldb or (cols + 7) // 8 * 8
+    tdt = torch.float16 if dtype == sa.F16 else torch.bfloat16
+    Bt = torch.zeros(ldb * n, dtype=tdt, device="cuda")
+    Bt.view(n, ldb)[:, :cols] = torch.from_numpy(B.reshape(n, cols)).cuda().to(tdt)
+    return Bt, ldb
+
+
+@pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("rows_per,n", [(48, 128), (20, 256), (70, 72), (5, 130)])
+def test_16bit_tiles_every_element_against_the_reference_product(dtype, rows_per, n):
+    torch = _torch()
+    m, order = clustered(40, rows_per, 5000, 100, 3, seed=rows_per + n, integer=True)      # small integers: exact in both 16-bit types, every order of additions the same bits
+    g = true_grouping(order, rows_per)
+    d = sa.DeviceVBS.from_csr(m, g, 32, device=0, dtype=dtype)                           # (16-bit handles take block widths that are multiples of 32; the tiles hold columns, not blocks:
+    ui = d.union_info()                                                                  #  the product is the one of the reference's VBS at -b 1 below)
+    assert ui["tiles32"] + ui["tiles64"] > 0 and ui["nnz"] > 0.7 * m.nztot(), ui
+    B = np.random.default_rng(n).integers(-3, 4, m.cols * n).astype(np.float32)
+    Bt, ldb = _b16(torch, B, dtype, n, m.cols)
+    v = oracle.OracleVBR(m.rows, m.cols, m.rowptr, m.colidx, m.vals, g, 1)
+    ref = oracle.vbr_multiply(v.rows, v.cols, 1, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+    for cl in (sa.COL_MAJOR, sa.ROW_MAJOR):
+        Ct = torch.full((m.rows * n,), 5.0, dtype=torch.float32, device="cuda")
+        d.spmm(Bt, Ct, n, ldb=ldb, c_layout=cl)
+        torch.cuda.synchronize()
+        got = Ct.cpu().numpy()
+        got = got if cl == sa.COL_MAJOR else np.ascontiguousarray(got.reshape(m.rows, n).T).reshape(-1)
+        assert np.array_equal(got, ref), (dtype, rows_per, n, cl)
+    d.close()
+
+
+@pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
+def test_16bit_tiles_on_real_data_with_tails_accumulate_and_prepared_b(dtype):
+    """reference = float64 on the ROUNDED inputs (products of two 16-bit values are exact in fp32; the sums differ by their order only)"""
+    torch = _torch()
+    m, order = clustered(50, 48, 8000, 150, 20, seed=77)                      # 20 columns of their own per row: tails of 16 + sparse rows that add
+    g = true_grouping(order, 48)
+    d = sa.DeviceVBS.from_csr(m, g, 32, device=0, dtype=dtype)
+    ui, si = d.union_info(), d.sparse_info()
+    assert ui["tiles64"] == 50 and ui["tail_nnz"] > 0 and si["nnz"] > 0, (ui, si)
+    n = 200
+    rng = np.random.default_rng(9)
+    B = rng.uniform(-1, 1, m.cols * n).astype(np.float32)
+    mr = sa.CSR(m.rows, m.cols, m.rowptr, m.colidx, _round16(m.vals, dtype))
+    want, bound = _want(mr, g, _round16(B, dtype), n)
+    Bt, ldb = _b16(torch, B, dtype, n, m.cols)
+    C0 = rng.uniform(-1, 1, m.rows * n).astype(np.float32)
+    for acc in (False, True):
+        Ct = torch.from_numpy(C0.copy()).cuda()
+        d.spmm(Bt, Ct, n, ldb=ldb, accumulate=acc)
+        torch.cuda.synchronize()
+        w_, b_ = (want + C0, bound + np.abs(C0)) if acc else (want, bound)
+        assert np.max(np.abs(Ct.cpu().numpy() - w_) / (b_ + 1e-30)) < TOL, (dtype, acc)
+    C1, C2 = torch.zeros(m.rows * n, device="cuda"), torch.full((m.rows * n,), 3.0, device="cuda")
+    d.spmm(Bt, C1, n, ldb=ldb)
+    Bp = d.prepare_b(Bt, n, ldb=ldb)
+    d.spmm_prepared(Bp, C2)
+    torch.cuda.synchronize()
+    assert torch.equal(C1, C2)
+    Bp.close(); d.close()
