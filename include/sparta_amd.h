@@ -409,7 +409,7 @@ int sparta_vbs_colres_info(const sparta_vbs_t* A, int64_t* info_out);
 int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, const int32_t* colidx, const float* vals, const int64_t* crow, const float* x,
                              float* y, int64_t* info_out);
 
-/* the column-compacted ("union-pattern") tiles of an fp32 handle made by sparta_vbs_create_from_csr.  They replace what the reference's builder stores for a cluster at
+/* the column-compacted ("union-pattern") tiles of a handle made by sparta_vbs_create_from_csr (fp32, and since the round's second half fp16 / bf16 storage: the same tiles through the 16-bit matrix instruction).  They replace what the reference's builder stores for a cluster at
  * SMALL block widths -- VBR::fill_from_CSR_inplace flags, per block-row, exactly the column blocks its rows touch and stores them back to back
  * (src/general/vbr.cpp:177-228; at -b 1 that is a dense rows x |union| tile plus the ascending column list, the ids its Jaccard distance is defined on,
  * src/general/blocking.cpp:923-994) -- and what VBR::multiply does with it (vbr.cpp:323-372): a block-row whose rows share columns but whose w-wide blocks would be
