@@ -269,7 +269,13 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
 //   * the tails multiply in fp32: value (the rounded 16-bit value of A, kept as fp32) x the 16-bit entries of the row of B widened in registers -- products of two 16-bit
 //     values are exact in fp32, as in the matrix instruction.
 // Three LDS stages of 12 KB (4 KB of A -- two of them unused by the <= 32-row tiles -- + 8 KB of B), three workgroups per CU.
-constexpr int kUnion16Stages = 3;
+#ifndef SPARTA_UNION16_STAGES
+#define SPARTA_UNION16_STAGES 3     /* developer A/B (with SPARTA_UNION16_WPC = workgroups per CU of the launch bound; the plan's workers: SPARTA_UNION_WPC at create time) */
+#endif
+#ifndef SPARTA_UNION16_WPC
+#define SPARTA_UNION16_WPC 3
+#endif
+constexpr int kUnion16Stages = SPARTA_UNION16_STAGES;
 constexpr int kUnion16Lds = kUnion16Stages * (4096 + 32 * 256);
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -506,7 +512,8 @@ __device__ __forceinline__ void union16_body(const UnionParams& p, const UnionSi
 }
 
 template <bool BF16>
-__global__ __launch_bounds__(256, 3) void vbs_union_h16_kernel(const UnionParams p) {
+__global__ __launch_bounds__(256, SPARTA_UNION16_WPC) void vbs_union_h16_kernel(const UnionParams p) {
+    static_assert(kUnion16Lds * SPARTA_UNION16_WPC <= 160 * 1024, "LDS per CU");
     __shared__ __attribute__((aligned(1024))) char lds[kUnion16Lds];
     const int n2 = p.side[1].n_workers;
     if ((int)blockIdx.x < n2) union16_body<2, BF16>(p, p.side[1], (int)blockIdx.x, lds);
