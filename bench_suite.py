@@ -194,6 +194,48 @@ def run(sa, torch, N=128, device=0, large=False, time_budget_s=45.0, log=None, s
         recs.append(rec)
         if log:
             log(rec)
+    # ---- the clustered family once more with 16-bit storage (bf16 A and B, fp32 accumulation and C): the same column-compacted tiles through the 16-bit matrix instruction
+    # (k_union.hip: vbs_union_h16_kernel) -- half the gathered bytes.  Reported beside the fp32 record, not in the median (the set is fp32).
+    extra16 = None
+    if time.time() - t_start <= time_budget_s:
+        try:
+            name, kind, make, eng_kw, w = [c for c in cases(sa, False) if c[0].startswith("clustered")][0]
+            m = make()
+            g = sa.BlockingEngine(col_block_size=w, **eng_kw).GetGrouping(m)
+            d = sa.DeviceVBS.from_csr(m, g, w, device=device, dtype=sa.BF16)
+            dev = torch.device("cuda", device)
+            ldb = (d.cols + 7) // 8 * 8
+            B = (torch.rand(ldb * N, device=dev) - 0.5).to(torch.bfloat16)
+            C = torch.zeros(d.rows * N, device=dev)
+            for _ in range(10):
+                d.spmm(B, C, N, ldb=ldb)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(200):
+                d.spmm(B, C, N, ldb=ldb)
+            e1.record()
+            torch.cuda.synchronize()
+            ms16 = e0.elapsed_time(e1) / 200
+            perm = sa.get_permutation(g)
+            worst = 0.0
+            for r in np.random.Generator(np.random.PCG64(1)).integers(0, m.rows, 6):
+                i = perm[r]
+                ci = m.colidx[m.rowptr[i]:m.rowptr[i + 1]]
+                a = torch.from_numpy(m.vals[m.rowptr[i]:m.rowptr[i + 1]]).to(torch.bfloat16).double().numpy()
+                bb = B.view(N, ldb)[:, torch.from_numpy(ci.astype(np.int64)).to(dev)].double().cpu().numpy()
+                got = C.view(N, -1)[:, int(r)].double().cpu().numpy()
+                worst = max(worst, float((np.abs(got - bb @ a) / (np.abs(bb) @ np.abs(a) + 1e-30)).max()))
+            ui = d.union_info()
+            extra16 = {"name": name + ", bf16 storage", "dtype": "bf16", "n_cols": int(N), "ms": round(ms16, 5), "useful_gflops": round(2.0 * m.nztot() * N / ms16 / 1e6, 1),
+                       "carried_by": "column-compacted MFMA tiles (v_mfma_f32_32x32x16_bf16) %.0f %% of the nonzeros" % (100.0 * ui["nnz"] / max(m.nztot(), 1)), "union_info": ui,
+                       "check_max_err": worst, "note": "check: rows of C against float64 on the rounded values the handle holds"}
+            d.close()
+            del B, C
+            if log:
+                log({"name": extra16["name"], "error": "%.4f ms, %.0f GFLOP/s useful, %s" % (ms16, extra16["useful_gflops"], extra16["carried_by"])})
+        except Exception as e:
+            extra16 = {"name": "clustered, bf16 storage", "error": repr(e)[:200]}
     # ---- the reference's own sweep on its real matrices: operand widths B_COLs = (1024 8192) beside 128, 64-wide blocks, its two arms -- the fixed grid (-a 2 -F 1)
     # and the clustering (-a 5 -F 1) -- beside blocking_algo 7 (src/scripts/run_multiplication_experiments_fixed_cluster.sh:6-7,14-16; batch/VBR_batch_a5:36).
     # At N = 128 these products are 1-8 us of traffic behind launches; at 8192 they are bandwidth problems (B and C 270-400 MB each).
@@ -280,6 +322,8 @@ def run(sa, torch, N=128, device=0, large=False, time_budget_s=45.0, log=None, s
             fs = sorted(max(p_["frac_8d"] for p_ in r["points"] if p_.get("n_cols") == Ns and "frac_8d" in p_) for r in sweep if any(p_.get("n_cols") == Ns and "frac_8d" in p_ for p_ in r["points"]))
             if fs:
                 out["real_median_best_frac_8d_n%d" % Ns] = fs[len(fs) // 2]
+    if extra16:
+        out["clustered_16bit"] = extra16
     if bsweep:
         out["block_size_sweep"] = bsweep
     if bad:
