@@ -18,7 +18,7 @@ $CXX -shared -fPIC -fsanitize=address,undefined -shared-libsan -o "$OUT/libspart
     -L/opt/rocm/lib -lamdhip64 -lpthread
 cd "$ROOT"
 LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 SPARTA_AMD_LIB="$OUT/libsparta_amd_asan.so" \
-  python -m pytest tests/test_host_golden.py tests/test_capi.py tests/test_io.py -q -s -p no:cacheprovider 2>&1 \
+  python -m pytest tests/test_host_golden.py tests/test_capi.py tests/test_io.py tests/test_union_host.py -q -s -p no:cacheprovider 2>&1 \
   | grep -E "runtime error|AddressSanitizer|SUMMARY|passed|failed" || true
 # the hybrid builder of sparta_vbs_create_from_csr (per-block tile / sparse-row split) runs on the host before the first device call: without a GPU the
 # call ends in SPARTA_ERR_NO_DEVICE -- after the builder has done all its work under the sanitizers

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 
 #include "host_core.hpp"
 
@@ -234,9 +235,15 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
     std::vector<std::vector<int32_t>> te_parts(want_union ? (size_t)block_rows : 0);   // ... and tail entries per row of the part's tile
     std::vector<int64_t> union_nnz_of(want_union ? (size_t)block_rows : 0, 0);
     const int64_t grain = std::max<int64_t>(1, std::min<int64_t>(64, block_rows / (8 * (int64_t)host_threads()) + 1));
-    parallel_for_dynamic(block_rows, grain, [&](int64_t lo, int64_t hi, int) {
+    // (a per-column counter is `cols` integers -- 33 MB on an 8 M-column graph: one per THREAD, made when a block-row first asks for it, not one per chunk of block-rows)
+    std::vector<std::unique_ptr<ColCounter>> col_counters((size_t)std::max(1, host_threads()));
+    auto counter_of = [&](int t) -> ColCounter& {
+        std::unique_ptr<ColCounter>& c = col_counters[(size_t)t % col_counters.size()];
+        if (!c) c.reset(new ColCounter(cols));
+        return *c;
+    };
+    parallel_for_dynamic(block_rows, grain, [&](int64_t lo, int64_t hi, int tid) {
         BlockCollector bc(block_cols, hybrid);
-        ColCounter cc(want_union ? cols : 0);
         for (int64_t ib = lo; ib < hi; ib++) {
             const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
             bc.collect(a, perm.data(), r0, r1, w, bc.next_tag());
@@ -251,7 +258,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
             if (want_union && h >= 2 && !bc.touched.empty()) {
                 const double lower = (double)nnz_all[(size_t)ib] / (double)h * union_col_cost(h > 32 ? 2 : 1);
                 if (lower < union_margin * r.cost) {
-                    UnionEval u = eval_union(cc, r0, r1);
+                    UnionEval u = eval_union(counter_of(tid), r0, r1);
                     // (... and only where the LISTS carry the block-row: tiles that are mostly tails are a slower sparse-row kernel)
                     if (2 * (u.nnz_in - u.tail_ent) >= nnz_all[(size_t)ib] && u.cost < union_margin * r.cost) {
                         mode[(size_t)ib] = 3;
@@ -438,11 +445,11 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                 U.a[ty].assign((size_t)o, 0.0f);
             }
             for (int ty = 0; ty < 2; ty++) U.tail_val[ty].assign(U.tail_col[ty].size(), 0.0f);
-            parallel_for_dynamic(block_rows, grain, [&](int64_t lo, int64_t hi, int) {
-                ColCounter cc(cols);
+            parallel_for_dynamic(block_rows, grain, [&](int64_t lo, int64_t hi, int tid) {
                 std::vector<int32_t> list;
                 for (int64_t ib = lo; ib < hi; ib++) {
                     if (mode[(size_t)ib] != 3) continue;
+                    ColCounter& cc = counter_of(tid);
                     const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
                     int64_t t = row_base[(size_t)ib], e = ent_base[(size_t)ib];
                     for (size_t q = 0; q < nu_parts[(size_t)ib].size(); q++) {
