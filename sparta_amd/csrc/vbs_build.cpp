@@ -354,6 +354,40 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                 }
             }
         }
+        // STRAGGLERS.  A clustered matrix leaves a few rows outside every cluster (the clustering missed them: 58 of 96 000 on the benchmark set's clustered family) -- fully
+        // sparse block-rows of a row or two, 14 k nonzeros in all, which alone cost the product two more launches (segments + their reduction: 12 of 167 us).  When the handle
+        // has column-compacted tiles anyway and what is left for the sparse-row kernels is that small (< 2 % of the tiles' nonzeros and < 64 k), those block-rows become tiles too,
+        // with EVERY column in the list (take_all: a list entry gathers the same row of B a sparse-row entry would, and the launches are gone).
+        std::vector<uint8_t> take_all(want_union ? (size_t)block_rows : 0, 0);
+        if (want_union) {
+            int64_t union_total = 0, sparse_total = 0, add_total = 0;
+            for (int64_t ib = 0; ib < block_rows; ib++) {
+                union_total += union_nnz_of[(size_t)ib];
+                if (mode[(size_t)ib] == 1) sparse_total += sp_ent_of[(size_t)ib];
+                else add_total += sp_ent_of[(size_t)ib];                   // (rows that ADD to tiles -- more than tail_cap thinly-used columns: they stay sparse rows)
+            }
+            const int64_t straggler_cap = [] { const char* e = std::getenv("SPARTA_UNION_STRAGGLERS"); return e ? atoll(e) : (int64_t)65536; }();      // (read per build: 0 switches the rule off)
+            if (union_total > 0 && sparse_total > 0 && sparse_total + add_total <= straggler_cap && (sparse_total + add_total) * 50 <= union_total) {
+                for (int64_t ib = 0; ib < block_rows; ib++) {
+                    if (mode[(size_t)ib] != 1) continue;
+                    const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
+                    ColCounter& cc = counter_of(0);
+                    std::vector<int32_t> nu, te;
+                    int64_t nnz_in = 0;
+                    for (int64_t q = 0; q < union_parts(h); q++) {
+                        cc.count(a, perm.data(), r0 + 64 * q, r0 + 64 * q + union_part_rows(h, q));
+                        nu.push_back((int32_t)cc.touched.size()); te.push_back(0);
+                        for (int32_t c : cc.touched) nnz_in += cc.cnt[(size_t)c];
+                        cc.reset();
+                    }
+                    mode[(size_t)ib] = 3; take_all[(size_t)ib] = 1;
+                    out->nzcount[ib] = 0;
+                    sp_rows_of[(size_t)ib] = 0; sp_ent_of[(size_t)ib] = 0;
+                    nu_parts[(size_t)ib].swap(nu); te_parts[(size_t)ib].swap(te);
+                    union_nnz_of[(size_t)ib] = nnz_in;
+                }
+            }
+        }
         if (stats_only) {                                                  // sparta_vbs_plan_stats: the decisions are all that is wanted
             HybridStats st;
             st.block_rows = block_rows; st.rows = rows;
@@ -456,7 +490,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                         const int64_t p0 = r0 + 64 * (int64_t)q, p1 = p0 + union_part_rows(h, (int64_t)q);
                         const int ty = p1 - p0 > 32 ? 1 : 0, mi = ty + 1;
                         const int32_t ti = tile_of[(size_t)part_base[(size_t)ib] + q];
-                        const int32_t cmin = union_min_count(mi);
+                        const int32_t cmin = take_all[(size_t)ib] ? 1 : union_min_count(mi);
                         const UnionPlanHost::Tile& tl = U.tiles[ty][(size_t)ti];
                         cc.count(a, perm.data(), p0, p1);
                         list.clear();

@@ -117,6 +117,22 @@ def test_tails_hold_a_rows_own_columns_and_overflow_into_sparse_rows(monkeypatch
     monkeypatch.setenv("SPARTA_UNION_TAIL", "0")
 
 
+def test_stragglers_become_tiles_when_little_else_is_left_for_the_sparse_rows(monkeypatch):
+    # 30 clusters + 5 rows outside every cluster (groups of their own): with tiles in the handle anyway, those rows become one-row tiles with every column in the list
+    m, order = clustered(30, 48, 6000, 100, 3, seed=41, integer=True)
+    g = true_grouping(order, 48)
+    loners = order[:5 * 48:48]                                     # one row of each of the first five clusters, torn out of its cluster: a group of its own
+    g[loners] = m.rows + np.arange(5)                              # (ids no other row has; ids only order the groups)
+    x = np.random.default_rng(5).integers(-3, 4, m.cols).astype(np.float32)
+    ref = np.asarray(reference_product(m, g, 1, x)).reshape(-1)
+    y, info = walk(m, g, 1, x)
+    assert info["sparse_nnz"] == 0 and info["nnz"] == m.nztot() and info["tiles32"] >= 5, info
+    assert np.array_equal(y.astype(np.float32), ref)
+    monkeypatch.setenv("SPARTA_UNION_STRAGGLERS", "0")             # switched off: they are sparse rows again
+    y, info = walk(m, g, 1, x)
+    assert info["sparse_nnz"] > 0 and np.array_equal(y.astype(np.float32), ref), info
+
+
 def test_tiles_follow_the_parts_rules():
     # 70-row clusters: one part of 64 rows (a 33..64-row tile) + one of 6 (a <= 32-row tile)
     m, order = clustered(8, 70, 2000, 60, 2, seed=5, scatter=False)
