@@ -192,7 +192,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
     const double union_margin = [] { const char* e = std::getenv("SPARTA_UNION_MARGIN"); return e ? atof(e) : 0.8; }();
     struct UnionEval { double cost; int64_t rows_rest, ent_rest, nnz_in, tail_ent; std::vector<int32_t> nu, te; };    // nu / te: per part, list entries / tail entries per row
     const int64_t tail_cap = union_tail_cap();
-    auto eval_union = [&](ColCounter& cc, int64_t r0, int64_t r1) {
+    auto eval_union = [&](ColCounter& cc, int64_t r0, int64_t r1, int64_t cap) {
         UnionEval u{0.0, 0, 0, 0, 0, {}, {}};
         const int64_t h = r1 - r0;
         for (int64_t q = 0; q < union_parts(h); q++) {
@@ -213,7 +213,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                 const int64_t n = a.nnz_of(i);
                 int64_t mine = 0;
                 for (int64_t k = 0; k < n; k++) mine += (!v || v[k] != 0.0f) && cc.cnt[(size_t)cj[k]] < cmin;
-                const int64_t in_tail = std::min(mine, tail_cap);                 // the first tail_cap of them ride in the tile's tail, the others are sparse-row entries
+                const int64_t in_tail = std::min(mine, cap);                      // the first `cap` of them ride in the tile's tail, the others are sparse-row entries
                 u.tail_ent += in_tail; u.ent_rest += mine - in_tail; u.rows_rest += mine > in_tail;
                 te = std::max(te, in_tail);
             }
@@ -258,7 +258,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
             if (want_union && h >= 2 && !bc.touched.empty()) {
                 const double lower = (double)nnz_all[(size_t)ib] / (double)h * union_col_cost(h > 32 ? 2 : 1);
                 if (lower < union_margin * r.cost) {
-                    UnionEval u = eval_union(counter_of(tid), r0, r1);
+                    UnionEval u = eval_union(counter_of(tid), r0, r1, tail_cap);
                     // (... and only where the LISTS carry the block-row: tiles that are mostly tails are a slower sparse-row kernel)
                     if (2 * (u.nnz_in - u.tail_ent) >= nnz_all[(size_t)ib] && u.cost < union_margin * r.cost) {
                         mode[(size_t)ib] = 3;
@@ -359,6 +359,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
         // has column-compacted tiles anyway and what is left for the sparse-row kernels is that small (< 2 % of the tiles' nonzeros and < 64 k), those block-rows become tiles too,
         // with EVERY column in the list (take_all: a list entry gathers the same row of B a sparse-row entry would, and the launches are gone).
         std::vector<uint8_t> take_all(want_union ? (size_t)block_rows : 0, 0);
+        std::vector<int8_t> cap_of(want_union ? (size_t)block_rows : 0, (int8_t)tail_cap);       // tail entries per row a block-row's tiles may hold
         if (want_union) {
             int64_t union_total = 0, sparse_total = 0, add_total = 0;
             for (int64_t ib = 0; ib < block_rows; ib++) {
@@ -369,6 +370,15 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
             const int64_t straggler_cap = [] { const char* e = std::getenv("SPARTA_UNION_STRAGGLERS"); return e ? atoll(e) : (int64_t)65536; }();      // (read per build: 0 switches the rule off)
             if (union_total > 0 && sparse_total > 0 && sparse_total + add_total <= straggler_cap && (sparse_total + add_total) * 50 <= union_total) {
                 for (int64_t ib = 0; ib < block_rows; ib++) {
+                    if (mode[(size_t)ib] == 3 && sp_ent_of[(size_t)ib] > 0 && tail_cap > 0 && tail_cap < 31) {
+                        // ... and a tile row with more thinly-used columns than the tail holds (the rows that ADD) gets the longest tail the step record can name (31)
+                        UnionEval u = eval_union(counter_of(0), part[(size_t)ib], part[(size_t)ib + 1], 31);
+                        cap_of[(size_t)ib] = 31;
+                        sp_rows_of[(size_t)ib] = u.rows_rest; sp_ent_of[(size_t)ib] = u.ent_rest;
+                        nu_parts[(size_t)ib].swap(u.nu); te_parts[(size_t)ib].swap(u.te);
+                        union_nnz_of[(size_t)ib] = u.nnz_in;
+                        continue;
+                    }
                     if (mode[(size_t)ib] != 1) continue;
                     const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
                     ColCounter& cc = counter_of(0);
@@ -516,7 +526,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                                     if (x == 0.0f) continue;
                                     const int32_t c = cc.cnt[(size_t)cj[k]];
                                     if (c < 0) img[(int64_t)(-c - 1) * ldt + (r - p0)] = x;
-                                    else if (in_tail < tl.tail_e && in_tail < tail_cap) { tc[in_tail * ldt + (r - p0)] = cj[k]; tv[in_tail * ldt + (r - p0)] = x; in_tail++; }
+                                    else if (in_tail < tl.tail_e && in_tail < cap_of[(size_t)ib]) { tc[in_tail * ldt + (r - p0)] = cj[k]; tv[in_tail * ldt + (r - p0)] = x; in_tail++; }
                                     else { sp->col[(size_t)e] = cj[k]; sp->val[(size_t)e] = x; e++; }
                                 }
                             }
