@@ -144,7 +144,8 @@ struct UnionPlanHost {
 // hybrid build (sparta_vbs_create_from_csr): the block-rows left to the device's sparse-row path, as rows of (column, value)
 struct HybridSparse {
     UnionPlanHost uni;                // flag 3 block-rows: their column-compacted tiles (the nonzeros of thinly used columns are sparse rows that ADD, as for flag 2)
-    bool want_union = false;          // in: build them (fp32 handles; SPARTA_UNION=0 switches the path off)
+    bool want_union = false;          // in: build them (SPARTA_UNION=0 switches the path off)
+    int union_gran = 32;              // in: rows per MFMA row tile of the kernel that will multiply them (fp32 handles 16: v_mfma_f32_16x16x4_f32; 16-bit handles 32)
     std::vector<uint8_t> flag;        // per block-row: 1 = not in the dense image at all; 2 = mixed: its well-filled blocks are in the dense image,
                                       // the nonzeros of the others are sparse rows that ADD to what the tiles wrote (row_add)
     std::vector<uint8_t> row_add;     // per sparse row: 1 = its block-row also has tiles: the sparse-row kernels add to C instead of storing
@@ -162,8 +163,9 @@ struct HybridStats {
     int64_t union_block_rows = 0, union_cols = 0, union_nnz = 0;   // block-rows kept as column-compacted tiles, their list entries (k columns), the nonzeros those hold
     double union_steps = 0.0;                 // 32-deep steps of 32-row MFMA tiles they cost
 };
-double union_col_cost(int mi);      // a list entry of a column-compacted tile (mi = 1: tiles of <= 32 rows, 2: of 33..64) in nonzeros of the sparse-row path
-int32_t union_min_count(int mi);    // fewest nonzeros of a part's rows that keep a column in its tile
+double union_tile_units(int64_t rows, int gran);   // MFMA cost of a tile of `rows` rows per 32-deep step, in 32-row tiles: rows rounded up to the kernel's row tile, / 32
+double union_col_cost(double units);  // a list entry of a column-compacted tile of `units` (union_tile_units) in nonzeros of the sparse-row path
+int32_t union_min_count(double units);  // fewest nonzeros of a part's rows that keep a column in its tile
 int32_t union_tail_cap();           // most tail entries per row of a tile (SPARTA_UNION_TAIL, default 16; 0: no tails)
 int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t col_block_size, int64_t row_block_size, bool force_fixed_size,
                      double K, int64_t kdep, sparta_vbs_host* out, HybridSparse* sp, bool keep_order = false, HybridStats* stats_only = nullptr);

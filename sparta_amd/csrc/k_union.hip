@@ -1,28 +1,33 @@
-// k_union.hip -- the MFMA kernel of the column-compacted ("union-pattern") tiles of an fp32 handle: vbs_union_f32_kernel.  Part of the device side of
-// libsparta_amd.so; see vbs_device.hpp (UnionRec / UnionParams), vbs_union.cpp (the plan) and DESIGN.md section 3.2 (6).
+// k_union.hip -- the MFMA kernels of the column-compacted ("union-pattern") tiles: vbs_union_f32_kernel (fp32 handles), vbs_union_h16_kernel (16-bit handles).  Part of
+// the device side of libsparta_amd.so; see vbs_device.hpp (UnionRec / UnionParams), vbs_union.cpp (the plan) and DESIGN.md section 3.2 (6).
 //
-// What it multiplies.  At small block widths the reference's VBS of a cluster IS a dense (rows x |U|) tile over the union U of the columns its rows touch, stored back
+// What they multiply.  At small block widths the reference's VBS of a cluster IS a dense (rows x |U|) tile over the union U of the columns its rows touch, stored back
 // to back, plus the ascending column list (src/general/vbr.cpp:177-228 at -b 1; its Jaccard distance is defined on those ids: src/general/blocking.cpp:923-994).  The
 // hybrid builder keeps such block-rows in exactly that form (vbs_build.cpp, mode 3): tiles of <= 64 consecutive reordered rows, 32 columns of the list per step.
 // C[tile rows, :] (+)= Atile . B[U, :] is then a GEMM whose B operand is GATHERED by row: B must be ROW-major here (one contiguous 512-byte piece per list entry and
 // 128-column slab; the host transposes the reference's column-major B once per product, or once per sparta_vbs_prepare_b -- the sparse-row kernels read the same copy).
 //
-// How.  A workgroup (four waves) owns a tile x one 128-column slab of C; wave v owns columns [32 v, 32 v + 32) x all the tile's rows: MI (1 or 2) accumulators of
-// 32 x 32, D = Bpanel^T . Atile^T as in the other kernels (a register holds 32 consecutive rows of one column of C).  A step's operands go HBM / L2 -> LDS with
-// LDS-direct loads (no staging registers), 1 KB per wave instruction:
-//   * the slice of A (32 MI rows x 32 k) is stored in HBM as the LDS image, in MFMA fragment order [rt][j][g][row][4] = A[32 rt + row][k = 16 g + 4 j + e]: a fragment
-//     read is one conflict-free ds_read_b128 per lane;
+// How (fp32).  A workgroup (four waves) owns a tile x one 128-column slab of C; wave v owns columns [32 v, 32 v + 32) x all the tile's rows.  The matrix instruction is
+// v_mfma_f32_16x16x4_f32 -- the same rate as the 32 x 32 x 2 form (64 flops per cycle and SIMD) at a row granularity of 16: a tile of mt rows costs ceil(mt / 16) row
+// tiles (RT = 1..4, one kernel body each), so a 48-row cluster pays for 48 rows, not 64.  D = Bpanel^T . Atile^T: the "A" operand of the instruction is the panel of B
+// (its 16 M rows are 16 columns of C), the "B" operand the slice of A (its 16 N columns are 16 rows of the tile); lane (i = lane & 15, q = lane >> 4) then holds, per
+// row tile rt and column tile ct, C[16 rt + i][32 v + 16 ct + 4 q .. + 3] -- four CONSECUTIVE columns of one row.  A step's operands go HBM / L2 -> LDS with LDS-direct
+// loads (no staging registers), 1 KB per wave instruction:
+//   * the slice of A (16 RT rows x 32 k) is stored in HBM as the LDS image [rt][h][lane][4], lane = 16 kq + i: A[16 rt + i][k = 4 (4 h + e) + kq] -- the values of four
+//     consecutive instructions (k-groups 4 h .. 4 h + 3) in one conflict-free ds_read_b128 per lane;
 //   * the panel of B is 32 rows of 512 bytes, LDS image Bs[k][128]: wave v fetches rows 8 v .. 8 v + 7, each through its OWN buffer descriptor (a 64-bit scalar base:
 //     row id x ldb -- B may be larger than the 4 GB a 32-bit offset spans), two rows per 1 KB piece: lanes 0..31 the even row, lanes 32..63 the odd one (the LDS-direct
-//     load writes lane l at base + 16 l whatever the exec mask).  Rows 16..31 are stored with their 16-byte chunks permuted (chunk c at position c ^ 8: the swizzle is
-//     on the SOURCE side, a lane fetches the chunk that belongs at its position), so that the MFMA-shaped read -- lanes 0..31 row k, lanes 32..63 row k + 16, one float
-//     each -- covers all 64 banks;
+//     load writes lane l at base + 16 l whatever the exec mask).  An instruction reads, per lane, Bs[4 s + kq][32 v + 16 ct + i]: four rows x 64 bytes, which would sit on
+//     the same 16 banks -- so row k is stored with its 16-byte chunks permuted, chunk c at position c ^ (4 (k & 3)) (the swizzle is on the SOURCE side: a lane fetches the
+//     chunk that belongs at its position), and the four rows cover all 64 banks;
 //   * list positions behind the tile's last column get a descriptor of zero records: zeros in LDS without a memory access (no 0 x inf from a padding row).
-// One barrier per step: wait (counted vmcnt) for this wave's loads of step i, barrier, issue the loads of step i + NS - 1 into the stage step i - 1 has left, multiply
-// step i.  A worker walks WHOLE tiles (vbs_union.cpp deals them longest first).  A tile's last step first adds its TAIL -- up to 16 nonzeros per row in columns too
-// thinly used for the list (a cluster's rows have a few columns of their own): lane (row, g) holds the row's accumulators of 16 of the wave's 32 columns, so per entry
-// it fetches 4 x 16 bytes of ITS row of B and multiplies them in; no sparse-row launch, no second pass over the rows of C -- then stores the tile's rows of C (or adds
-// to them: accumulate).  ONE launch carries both tile types: workgroups [0, n2) walk the 33..64-row tiles (two accumulators), the others the <= 32-row tiles.
+// One barrier per step, two LDS stages: wait for this wave's loads of step i, barrier, multiply step i with the loads of step i + 1 issued BETWEEN its MFMAs (descriptor
+// arithmetic and load issue ride in the shadow of the wave's own matrix instructions).  Measured (profiles/r5/lab_union_stats.txt): waves neither wait for loads nor at
+// the barrier -- with three workgroups per CU the multiply phase of a step takes three times its MFMA time: the matrix pipe is the bound, which is why the row
+// granularity matters.  A worker walks WHOLE tiles (vbs_union.cpp deals them longest first).  A tile's last step first adds its TAIL -- up to 16 nonzeros per row in
+// columns too thinly used for the list (a cluster's rows have a few columns of their own): lane (i, q) holds its row's accumulators of 8 of the wave's 32 columns, so per
+// entry it fetches 2 x 16 bytes of ITS row of B and multiplies them in; no sparse-row launch, no second pass over the rows of C -- then stores the tile's rows of C (or
+// adds to them: accumulate).  ONE launch carries all tile types: the workgroups of the tallest type first.
 #include "vbs_kernel_common.hpp"
 
 using namespace sparta_dev;
@@ -31,34 +36,36 @@ namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// developer probes, TIMING ONLY (results wrong), UnionParams::pad = SPARTA_UNION_PROBE read per call: 1 no B loads, 2 no A loads, 4 no MFMAs, 8 no tails, 16 no epilogue
+// developer probes, TIMING ONLY (results wrong), UnionParams::pad = SPARTA_UNION_PROBE read per call: 1 no B loads, 2 no A loads, 8 no tails, 16 no epilogue
 
 // Two LDS stages (one step of loads in flight across the barrier) and THREE workgroups per CU: measured on the benchmark set's clustered family (N = 128, prepared B):
 // three stages with two workgroups per CU 172 us, two stages with two 162, two stages with three 160 -- another co-resident workgroup hides a workgroup's waits
 // (barrier, tile epilogue with its tail gathers) better than a deeper pipeline of its own (profiles/r5/lab_union_stages.txt).
+#ifndef SPARTA_UNION_STATS
+#define SPARTA_UNION_STATS 0      /* lab build: per-wave cycle sums written over the head of C (scripts/lab/r5_union_stats.py) */
+#endif
 constexpr int kUnionStages = 2;
-constexpr int kUnionLds = kUnionStages * (2 * 4096 + 32 * 512);      // the taller type's stages
+constexpr int kUnionLds = kUnionStages * (4 * 2048 + 32 * 512);      // the tallest type's stages
 
-template <int MI, int NS>
+template <int RT, int NS>
 __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide& sd, const int worker, char* const lds) {
-    static_assert(MI == 1 || MI == 2, "one or two 32-row MFMA tiles per wave and step");
-    constexpr int A_BYTES = MI * 4096, B_BYTES = 32 * 512, STAGE = A_BYTES + B_BYTES;
-    constexpr int NA = MI;                               // 1 KB pieces of the slice of A per wave and step (4 MI pieces, four waves)
-    constexpr int LPS = 8 + NA;                          // vector-memory instructions per wave and step
+    static_assert(RT >= 1 && RT <= 4, "one to four 16-row MFMA tiles per wave and column tile");
+    static_assert(NS == 2, "the step's top wait is vmcnt(0): one step of loads in flight");
+    constexpr int A_BYTES = RT * 2048, B_BYTES = 32 * 512, STAGE = A_BYTES + B_BYTES;
+    constexpr int NPA = 2 * RT;                          // 1 KB pieces of the slice of A per step, dealt to the waves round robin
     constexpr int AHEAD = NS - 1;                        // steps between a step's loads and its MFMAs
-    static_assert((AHEAD - 1) * LPS <= 63, "vmcnt holds 6 bits");
     static_assert(NS * STAGE <= kUnionLds, "LDS");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lm = lane & 31, g = lane >> 5;
+    const int li = lane & 15, kq = lane >> 4;
     const int n0 = (int)blockIdx.y * kTN;
     const int probe = p.pad;
     const int s_begin = sd.worker_range[2 * worker];
     const int n = sd.worker_range[2 * worker + 1] - s_begin;
     if (n <= 0) return;
 
-    // step records and list entries through the constant address space (scalar loads): per step this wave needs the record (two dwords) and ITS eight row ids
+    // step records and list entries through the constant address space (scalar loads): per step this wave needs the record (three dwords) and ITS eight row ids
     typedef const __attribute__((address_space(4))) int32_t* cptr_t;
     const cptr_t srec = (cptr_t)(reinterpret_cast<const int32_t*>(sd.rec + s_begin));
     const cptr_t sids = (cptr_t)(sd.ids + (int64_t)s_begin * 32 + 8 * wave);
@@ -74,61 +81,64 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
     // ---- per-lane / per-wave constants ----
     const int ncv = p.n_cols - n0;                                               // columns of this slab that exist (the last slab of a call may be narrower than 128)
     const uint32_t row_bytes = ncv >= kTN ? 512u : (uint32_t)((ncv * 4 + 15) & ~15);   // (whole 16-byte chunks: ldb % 4 == 0, so the chunk is inside the row's allocation)
-    const uint32_t voffB = (uint32_t)(((lane & 31) ^ (wave >= 2 ? 8 : 0)) * 16);       // rows 16..31 (waves 2, 3): chunk c at position c ^ 8
+    // row k = 8 wave + 2 r2 + (lane >> 5) of the panel: the lane at position l of the row fetches chunk l ^ (4 (k & 3)); k & 3 depends on r2 & 1 and the lane's half only
+    uint32_t voffB[2];
+#pragma unroll
+    for (int par = 0; par < 2; par++) voffB[par] = (uint32_t)(((lane & 31) ^ (4 * ((2 * par + (lane >> 5)) & 3))) * 16);
     const uint32_t voffA = (uint32_t)lane * 16u;
     const float* const Bs0 = p.B + n0;
-    const float* const A0 = sd.A + (int64_t)s_begin * (MI * 1024);
-    // fragment reads of B: row k = 16 g + kk, column 32 wave + lm at float position (32 wave + lm) ^ (32 g) of the row
-    const uint32_t rdB = (uint32_t)(16 * g * 512 + (((32 * wave + lm) ^ (32 * g)) * 4));
+    const float* const A0 = reinterpret_cast<const float*>(sd.A) + (int64_t)s_begin * (RT * 512);
+    // fragment reads of B: sub-step s (k = 4 s + kq), column tile ct: column 32 wave + 16 ct + i of row k, i.e. chunk 8 wave + 4 ct + (i >> 2) at position chunk ^ (4 kq)
+    uint32_t rdB[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) rdB[ct] = (uint32_t)(kq * 512 + (((8 * wave + 4 * ct + (li >> 2)) ^ (4 * kq)) * 16) + (li & 3) * 4);
     char* const lds0 = lds;
 
-    // the loads of one step (its record already in scalar registers) into `stage`
-    auto issue = [&](const Rec& rec, int j, int stage) __attribute__((always_inline)) {
+    // the loads of one step (its record already in scalar registers) into `stage`: the wave's pieces of the slice of A, then its eight rows of B two at a time
+    auto issue_a = [&](int j, int stage) __attribute__((always_inline)) {
+        if (probe & 2) return;
         char* const stp = lds0 + stage * STAGE;
-        const int nvalid = (rec.info >> 8) & 63;
-        if (!(probe & 2)) {
-            const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A0 + (int64_t)j * (MI * 1024)), 0, MI * 4096, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A0 + (int64_t)j * (RT * 512)), 0, A_BYTES, 0x00020000);
 #pragma unroll
-            for (int t = 0; t < NA; t++) {
-                const int q = wave * NA + t;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(stp + q * 1024), 16, voffA, (uint32_t)(q * 1024), 0, 0);
-            }
-        }
-        if (!(probe & 1)) {
-            // lanes 0..31 fetch the even row of a 1 KB piece, lanes 32..63 the odd one: two loads per piece under half an exec mask each, every row through its own
-            // descriptor.  Inline assembly: written as `if (lane < 32) load(even) else load(odd)` the compiler merges the two loads into ONE with a per-lane descriptor and
-            // wraps it in a waterfall loop (readfirstlane / compare / saveexec per distinct descriptor).  EXEC is all ones here (uniform control flow); M0 = the piece's LDS
-            // address (one wait state before the load that uses it), handed back as found (it is the compiler's for its own LDS-direct loads).
-            auto row_desc = [&](int r) __attribute__((always_inline)) -> u32x4 {
-                const uint64_t addr = (uint64_t)(Bs0 + (int64_t)rec.id[r] * p.ldb);
-                return u32x4{(uint32_t)addr, (uint32_t)(addr >> 32) & 0xffffu, 8 * wave + r < nvalid ? row_bytes : 0u, 0x00020000u};
-            };
-#pragma unroll
-            for (int r2 = 0; r2 < 4; r2++) {
-                const u32x4 dE = row_desc(2 * r2), dO = row_desc(2 * r2 + 1);
-                const uint32_t m0v = (uint32_t)(uintptr_t)(lds_ptr_t)(stp + A_BYTES + (4 * wave + r2) * 1024);
-                uint32_t m0_keep;
-                asm volatile("s_mov_b32 %0, m0\n\t"
-                             "s_mov_b32 m0, %3\n\t"
-                             "s_mov_b32 exec_hi, 0\n\t"
-                             "s_nop 0\n\t"
-                             "buffer_load_dwordx4 %4, %1, 0 offen lds\n\t"
-                             "s_mov_b32 exec_hi, -1\n\t"
-                             "s_mov_b32 exec_lo, 0\n\t"
-                             "s_nop 0\n\t"
-                             "buffer_load_dwordx4 %4, %2, 0 offen lds\n\t"
-                             "s_mov_b32 exec_lo, -1\n\t"
-                             "s_mov_b32 m0, %0"
-                             : "=&s"(m0_keep) : "s"(dE), "s"(dO), "s"(m0v), "v"(voffB) : "memory");
-            }
+        for (int t = 0; t < (NPA + 3) / 4; t++) {
+            const int q = wave + 4 * t;
+            if (q < NPA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(stp + q * 1024), 16, voffA, (uint32_t)(q * 1024), 0, 0);
         }
     };
+    // lanes 0..31 fetch the even row of a 1 KB piece, lanes 32..63 the odd one: two loads per piece under half an exec mask each, every row through its own
+    // descriptor.  Inline assembly: written as `if (lane < 32) load(even) else load(odd)` the compiler merges the two loads into ONE with a per-lane descriptor and
+    // wraps it in a waterfall loop (readfirstlane / compare / saveexec per distinct descriptor).  EXEC is all ones here (uniform control flow); M0 = the piece's LDS
+    // address (one wait state before the load that uses it), handed back as found (it is the compiler's for its own LDS-direct loads).
+    auto issue_b = [&](const Rec& rec, int stage, int r2) __attribute__((always_inline)) {
+        if (probe & 1) return;
+        char* const stp = lds0 + stage * STAGE;
+        const int nvalid = (rec.info >> 8) & 63;
+        auto row_desc = [&](int r) __attribute__((always_inline)) -> u32x4 {
+            const uint64_t addr = (uint64_t)(Bs0 + (int64_t)rec.id[r] * p.ldb);
+            return u32x4{(uint32_t)addr, (uint32_t)(addr >> 32) & 0xffffu, 8 * wave + r < nvalid ? row_bytes : 0u, 0x00020000u};
+        };
+        const u32x4 dE = row_desc(2 * r2), dO = row_desc(2 * r2 + 1);
+        const uint32_t m0v = (uint32_t)(uintptr_t)(lds_ptr_t)(stp + A_BYTES + (4 * wave + r2) * 1024);
+        uint32_t m0_keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %3\n\t"
+                     "s_mov_b32 exec_hi, 0\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %4, %1, 0 offen lds\n\t"
+                     "s_mov_b32 exec_hi, -1\n\t"
+                     "s_mov_b32 exec_lo, 0\n\t"
+                     "s_nop 0\n\t"
+                     "buffer_load_dwordx4 %4, %2, 0 offen lds\n\t"
+                     "s_mov_b32 exec_lo, -1\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(m0_keep) : "s"(dE), "s"(dO), "s"(m0v), "v"(voffB[r2 & 1]) : "memory");
+    };
 
-    f32x16 acc[MI];
+    f32x4 acc[RT][2];
 #pragma unroll
-    for (int rt = 0; rt < MI; rt++)
+    for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[rt][r] = 0.0f;
+        for (int ct = 0; ct < 2; ct++) acc[rt][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     // records of the steps in flight: info / c_row of step i are needed at its epilogue, long after its loads were issued
     int32_t iq[NS], cq[NS], tq[NS];
@@ -138,121 +148,160 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
     for (int k = 0; k < AHEAD; k++) {                    // prologue: steps 0 .. AHEAD - 1
         const Rec r = load_rec(k);
         iq[k] = r.info; cq[k] = r.c_row; tq[k] = r.tail_off;
-        issue(r, k, k);
+        issue_a(k, k);
+#pragma unroll
+        for (int r2 = 0; r2 < 4; r2++) issue_b(r, k, r2);
     }
     Rec nxt = load_rec(AHEAD);                           // the record of the step whose loads the next iteration issues
 
-    const uint32_t voffC = p.c_row_major ? (uint32_t)((lm * p.ldc + 4 * g) * 4) : (uint32_t)((lm + (4 * g) * p.ldc) * 4);
+    // C: lane (i, q) owns row 16 rt + i, columns 32 wave + 16 ct + 4 q + r
+    const uint32_t voffC = p.c_row_major ? (uint32_t)((li * p.ldc + 4 * kq) * 4) : (uint32_t)((li + (4 * kq) * p.ldc) * 4);
     const uint32_t jstep = p.c_row_major ? 4u : (uint32_t)p.ldc * 4u;            // bytes per output column
-    const uint32_t mistep = p.c_row_major ? (uint32_t)p.ldc * 128u : 128u;       // bytes per 32 rows
+    const uint32_t rstep = p.c_row_major ? (uint32_t)p.ldc * 64u : 64u;          // bytes per 16 rows
     const int ncw = ncv - 32 * wave;                                             // columns of this wave that exist
 
+#if SPARTA_UNION_STATS
+    // lab build only (results WRONG: the sums overwrite the head of C): cycles this wave spent waiting for its loads / at the barrier / in the multiply phase / in epilogues
+    uint64_t st_wait = 0, st_bar = 0, st_mul = 0, st_epi = 0;
+    const uint64_t st_begin = __builtin_readcyclecounter();
+#define UNION_STAMP(var) const uint64_t var = __builtin_readcyclecounter()
+#else
+#define UNION_STAMP(var)
+#endif
     int stage = 0;
     for (int i = 0; i < n; i++) {
-        // (1) this wave's loads of step i have landed: all but those of the AHEAD - 1 younger steps
-        asm volatile("s_waitcnt vmcnt(%0)" : : "n"((AHEAD - 1) * LPS) : "memory");
+        UNION_STAMP(st0);
+        // (1) this wave's loads of step i have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        UNION_STAMP(st1);
         // (2) everybody's have, and everybody is done with the stage of step i - 1
         __builtin_amdgcn_s_barrier();
-        // (3) the loads of step i + AHEAD go into that stage; the record of step i + AHEAD + 1 is requested for the next iteration
+        UNION_STAMP(st2);
+        // (3) the record of step i + 1 (its loads go into the stage step i - 1 has left); the record of step i + 2 is requested for the next iteration
         const Rec rec = nxt;
         nxt = load_rec(i + AHEAD + 1);
-        int jstage = stage + AHEAD; if (jstage >= NS) jstage -= NS;
+        const int jstage = stage ^ 1;
         iq[AHEAD] = rec.info; cq[AHEAD] = rec.c_row; tq[AHEAD] = rec.tail_off;
-        issue(rec, i + AHEAD, jstage);
-        // (4) multiply step i
-        if (!(probe & 4)) {
+        // (4) multiply step i: the fragments first (the LDS reads of the whole step), then 16 RT matrix instructions with the loads of step i + 1 issued between them
+        {
             const char* const sa = lds0 + stage * STAGE;
-            const char* const sb = sa + A_BYTES + rdB;
-            f32x4 af[MI][4];
+            const char* const sb = sa + A_BYTES;
+            f32x4 af[RT][2];
+            float bq[8][2];
 #pragma unroll
-            for (int rt = 0; rt < MI; rt++)
+            for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) af[rt][j] = *reinterpret_cast<const f32x4*>(sa + (rt * 4 + j) * 1024 + lane * 16);
+                for (int h = 0; h < 2; h++) af[rt][h] = *reinterpret_cast<const f32x4*>(sa + (rt * 2 + h) * 1024 + lane * 16);
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int s = 0; s < 8; s++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float bv = *reinterpret_cast<const float*>(sb + (4 * j + e) * 512);
+                for (int ct = 0; ct < 2; ct++) bq[s][ct] = *reinterpret_cast<const float*>(sb + rdB[ct] + s * 2048);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int rt = 0; rt < MI; rt++) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, af[rt][j][e], acc[rt], 0, 0, 0);
+            for (int s = 0; s < 8; s++) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ct++) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[s][ct], af[rt][s >> 2][s & 3], acc[rt][ct], 0, 0, 0);
+                    const int slot = 2 * s + ct;
+                    if (slot == 0) issue_a(i + AHEAD, jstage);
+                    if (slot == 2 || slot == 5 || slot == 8 || slot == 11) issue_b(rec, jstage, (slot - 2) / 3);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            }
         }
+        UNION_STAMP(st3);
         const int32_t info = iq[0];
         if ((info & UREC_LAST) && !(probe & 16)) {
             const int mt = info & 127;
             const int64_t c_row = cq[0];
-            // the tail: per entry and row 4 x 16 bytes of the row of B -- the 16 columns whose accumulators this lane holds (register q: column (q & 3) + 8 (q >> 2) + 4 g)
+            // the tail: per entry and row 2 x 16 bytes of the row of B -- the 8 columns whose accumulators this lane holds
             const int tail_e = (info >> UREC_TAIL_SHIFT) & 31;
             if (tail_e > 0 && !(probe & 8)) {
-                const uint2* tp = sd.tail + tq[0] + lm;
-                const float* brow = p.B + n0 + 32 * wave + 4 * g;
-                // two entries at a time: their (column, value) pairs in one round trip, their 2 x MI x 4 pieces of B in a second one (an entry at a time is two round
-                // trips per entry with the matrix pipe idle: 89 of 277 us on the benchmark set's clustered family; four at a time costs the third workgroup per CU its registers)
+                const uint2* tp = sd.tail + tq[0] + li;
+                const float* brow = p.B + n0 + 32 * wave + 4 * kq;
+                // two entries at a time: their (column, value) pairs in one round trip, their 2 x RT x 2 pieces of B in a second one (an entry at a time is two round
+                // trips per entry with the matrix pipe idle; four at a time costs the third workgroup per CU its registers)
                 constexpr int CH = 2;
                 for (int e0 = 0; e0 < tail_e; e0 += CH) {
-                    uint2 cv[CH][MI];
+                    uint2 cv[CH][RT];
 #pragma unroll
                     for (int c = 0; c < CH; c++)
 #pragma unroll
-                        for (int rt = 0; rt < MI; rt++) cv[c][rt] = e0 + c < tail_e ? tp[((e0 + c) * MI + rt) * 32] : uint2{0u, 0u};      // (behind the last entry: nothing is fetched)
-                    f32x4 bv[CH][MI][4];
+                        for (int rt = 0; rt < RT; rt++) cv[c][rt] = e0 + c < tail_e ? tp[((e0 + c) * RT + rt) * 16] : uint2{0u, 0u};      // (behind the last entry: nothing is fetched)
+                    f32x4 bv[CH][RT][2];
 #pragma unroll
                     for (int c = 0; c < CH; c++)
 #pragma unroll
-                        for (int rt = 0; rt < MI; rt++) {
+                        for (int rt = 0; rt < RT; rt++) {
                             const float* bp = brow + (int64_t)cv[c][rt].x * p.ldb;
 #pragma unroll
-                            for (int qq = 0; qq < 4; qq++) bv[c][rt][qq] = (e0 + c < tail_e && 8 * qq + 4 * g < ncw) ? *reinterpret_cast<const f32x4*>(bp + 8 * qq) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                            for (int ct = 0; ct < 2; ct++) bv[c][rt][ct] = (e0 + c < tail_e && 16 * ct + 4 * kq < ncw) ? *reinterpret_cast<const f32x4*>(bp + 16 * ct) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                         }
 #pragma unroll
                     for (int c = 0; c < CH; c++)
 #pragma unroll
-                        for (int rt = 0; rt < MI; rt++) {
+                        for (int rt = 0; rt < RT; rt++) {
                             const float av = __uint_as_float(cv[c][rt].y);
 #pragma unroll
-                            for (int qq = 0; qq < 4; qq++)
+                            for (int ct = 0; ct < 2; ct++)
 #pragma unroll
-                                for (int i2 = 0; i2 < 4; i2++) acc[rt][4 * qq + i2] = __builtin_fmaf(av, bv[c][rt][qq][i2], acc[rt][4 * qq + i2]);
+                                for (int i2 = 0; i2 < 4; i2++) acc[rt][ct][i2] = __builtin_fmaf(av, bv[c][rt][ct][i2], acc[rt][ct][i2]);
                         }
                 }
             }
             float* cbase = p.c_row_major ? p.C + c_row * p.ldc + (n0 + 32 * wave) : p.C + c_row + (int64_t)(n0 + 32 * wave) * p.ldc;
             const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(cbase, 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
-            for (int rt = 0; rt < MI; rt++) {
-                if (rt * 32 + lm < mt) {
-                    float v[16];
+            for (int rt = 0; rt < RT; rt++) {
+                if (rt * 16 + li < mt) {
+                    float v[2][4];
 #pragma unroll
-                    for (int q = 0; q < 16; q++) v[q] = acc[rt][q];
+                    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) v[ct][r] = acc[rt][ct][r];
                     if (p.accumulate) {
-                        uint32_t old[16];
+                        uint32_t old[2][4];
 #pragma unroll
-                        for (int q = 0; q < 16; q++) {
-                            const int col = (q & 3) + 8 * (q >> 2);
-                            old[q] = col + 4 * g < ncw ? __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)col * jstep + (uint32_t)rt * mistep, 0) : 0u;
-                        }
+                        for (int ct = 0; ct < 2; ct++)
 #pragma unroll
-                        for (int q = 0; q < 16; q++) v[q] += __uint_as_float(old[q]);
+                            for (int r = 0; r < 4; r++)
+                                old[ct][r] = 16 * ct + 4 * kq + r < ncw ? __builtin_amdgcn_raw_buffer_load_b32(rC, voffC, (uint32_t)(16 * ct + r) * jstep + (uint32_t)rt * rstep, 0) : 0u;
+#pragma unroll
+                        for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) v[ct][r] += __uint_as_float(old[ct][r]);
                     }
 #pragma unroll
-                    for (int q = 0; q < 16; q++) {
-                        const int col = (q & 3) + 8 * (q >> 2);
-                        if (col + 4 * g < ncw) {
-                            if (sd.c_nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)col * jstep + (uint32_t)rt * mistep, 2);
-                            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), rC, voffC, (uint32_t)col * jstep + (uint32_t)rt * mistep, 0);
+                    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            if (16 * ct + 4 * kq + r < ncw) {
+                                if (sd.c_nt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[ct][r]), rC, voffC, (uint32_t)(16 * ct + r) * jstep + (uint32_t)rt * rstep, 2);
+                                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[ct][r]), rC, voffC, (uint32_t)(16 * ct + r) * jstep + (uint32_t)rt * rstep, 0);
+                            }
                         }
-                    }
                 }
             }
 #pragma unroll
-            for (int rt = 0; rt < MI; rt++)
+            for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[rt][r] = 0.0f;
+                for (int ct = 0; ct < 2; ct++) acc[rt][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
 #pragma unroll
         for (int k = 0; k < AHEAD; k++) { iq[k] = iq[k + 1]; cq[k] = cq[k + 1]; tq[k] = tq[k + 1]; }
-        stage = stage + 1 == NS ? 0 : stage + 1;
+        stage ^= 1;
+#if SPARTA_UNION_STATS
+        const uint64_t st4 = __builtin_readcyclecounter();
+        st_wait += st1 - st0; st_bar += st2 - st1; st_mul += st3 - st2; st_epi += st4 - st3;
+#endif
     }
+#if SPARTA_UNION_STATS
+    if (lane == 0) {
+        float* o = p.C + ((int64_t)(blockIdx.x * 4 + wave)) * 8;
+        o[0] = (float)st_wait; o[1] = (float)st_bar; o[2] = (float)st_mul; o[3] = (float)st_epi; o[4] = (float)(__builtin_readcyclecounter() - st_begin); o[5] = (float)n;
+    }
+#endif
     // the loads issued past the end of the range (into LDS nobody reads any more) must land before the workgroup's LDS is handed on
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -523,18 +572,23 @@ __global__ __launch_bounds__(256, SPARTA_UNION16_WPC) void vbs_union_h16_kernel(
 __global__ __launch_bounds__(256, 3) void vbs_union_f32_kernel(const UnionParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[kUnionLds];
     static_assert(kUnionLds * 3 <= 160 * 1024, "three workgroups per CU");
-    const int n2 = p.side[1].n_workers;                  // (wave-uniform: the two bodies are two programs behind one scalar branch)
-    if ((int)blockIdx.x < n2) union_body<2, kUnionStages>(p, p.side[1], (int)blockIdx.x, lds);
-    else union_body<1, kUnionStages>(p, p.side[0], (int)blockIdx.x - n2, lds);
+    // (wave-uniform: the four bodies are four programs behind scalar branches; the tallest tiles' workgroups first)
+    int b = (int)blockIdx.x;
+    if (b < p.side[3].n_workers) { union_body<4, kUnionStages>(p, p.side[3], b, lds); return; }
+    b -= p.side[3].n_workers;
+    if (b < p.side[2].n_workers) { union_body<3, kUnionStages>(p, p.side[2], b, lds); return; }
+    b -= p.side[2].n_workers;
+    if (b < p.side[1].n_workers) { union_body<2, kUnionStages>(p, p.side[1], b, lds); return; }
+    b -= p.side[1].n_workers;
+    if (b < p.side[0].n_workers) union_body<1, kUnionStages>(p, p.side[0], b, lds);
 }
 
 }  // namespace
 
 namespace sparta_dev {
 
-// ONE launch: grid = (workers of the 33..64-row tiles + workers of the <= 32-row tiles, 128-column slabs)
 void launch_union_f32(unsigned n_slabs, hipStream_t st, const UnionParams& p) {
-    hipLaunchKernelGGL(vbs_union_f32_kernel, dim3((unsigned)(p.side[0].n_workers + p.side[1].n_workers), n_slabs), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(vbs_union_f32_kernel, dim3((unsigned)(p.side[0].n_workers + p.side[1].n_workers + p.side[2].n_workers + p.side[3].n_workers), n_slabs), dim3(256), 0, st, p);
 }
 // the same for a 16-bit handle: UnionParams::B is the ROW-major 16-bit copy of B (ld a multiple of 8 elements), UnionSide::A the 16-bit slices
 void launch_union_h16(bool bf16, unsigned n_slabs, hipStream_t st, const UnionParams& p) {

@@ -83,7 +83,8 @@ struct ColCounter {
     void reset() { for (int32_t c : touched) cnt[(size_t)c] = 0; touched.clear(); }
 };
 
-// the parts of a block-row of h rows that becomes column-compacted tiles: chunks of 64 rows; a chunk of <= 32 rows is multiplied as ONE 32-row MFMA tile per step (MI = 1), a taller one as two
+// the parts of a block-row of h rows that becomes column-compacted tiles: chunks of 64 rows, each ONE tile; a tile costs its rows rounded up to the kernel's MFMA row tile
+// (16 rows for fp32 handles, 32 for 16-bit ones: HybridSparse::union_gran)
 inline int64_t union_parts(int64_t h) { return (h + 63) / 64; }
 inline int64_t union_part_rows(int64_t h, int64_t q) { return std::min<int64_t>(64, h - 64 * q); }
 
@@ -92,11 +93,12 @@ inline int64_t union_part_rows(int64_t h, int64_t q) { return std::min<int64_t>(
 // what a column of a column-compacted tile costs, in nonzeros of the sparse-row path: a 32-deep step of a 32-row tile is worth K_union of them (SPARTA_UNION_K, default 36:
 // the 24 of a w-wide block step + the list entry, the gathered row of B and 128 bytes of A per column); a column is kept in the tile when its rows hold at least that
 // many nonzeros (never fewer than 2: a column one row uses is a sparse-row entry)
-double union_col_cost(int mi) {
+double union_tile_units(int64_t rows, int gran) { return (double)((rows + gran - 1) / gran * gran) / 32.0; }
+double union_col_cost(double units) {
     static const double K_union = [] { const char* e = std::getenv("SPARTA_UNION_K"); return e ? std::max(1.0, atof(e)) : 36.0; }();
-    return K_union * (double)mi / 32.0;
+    return K_union * (2.0 * units + 1.0) / 3.0 / 32.0;       // (a third of a 32-row tile's column is the gather -- list entry, row of B -- whatever the tile's height)
 }
-int32_t union_min_count(int mi) { return std::max<int32_t>(2, (int32_t)std::ceil(union_col_cost(mi))); }
+int32_t union_min_count(double units) { return std::max<int32_t>(2, (int32_t)std::ceil(union_col_cost(units))); }
 int32_t union_tail_cap() {
     static const int32_t cap = [] { const char* e = std::getenv("SPARTA_UNION_TAIL"); return e ? std::max(0, std::min(31, atoi(e))) : 16; }();
     return cap;
@@ -197,13 +199,13 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
         const int64_t h = r1 - r0;
         for (int64_t q = 0; q < union_parts(h); q++) {
             const int64_t p0 = r0 + 64 * q, p1 = p0 + union_part_rows(h, q);
-            const int mi = p1 - p0 > 32 ? 2 : 1;
-            const int32_t cmin = union_min_count(mi);
+            const double units = union_tile_units(p1 - p0, sp->union_gran);
+            const int32_t cmin = union_min_count(units);
             cc.count(a, perm.data(), p0, p1);
             int64_t nu = 0;
             for (int32_t c : cc.touched) if (cc.cnt[(size_t)c] >= cmin) { nu++; u.nnz_in += cc.cnt[(size_t)c]; }
             u.nu.push_back((int32_t)nu);
-            u.cost += (double)nu * union_col_cost(mi);
+            u.cost += (double)nu * union_col_cost(units);
             int64_t te = 0;
             for (int64_t rr = p0; rr < p1; rr++) {                   // the rows' nonzeros in thinly used columns
                 const int64_t i = perm[(size_t)rr];
@@ -256,7 +258,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
             for (int32_t jb : bc.touched) nnz_all[(size_t)ib] += bc.count[(size_t)jb];
             // column-compacted tiles?  Only where they CAN win: every column holds at most h nonzeros, so the tiles cost at least nnz / h columns
             if (want_union && h >= 2 && !bc.touched.empty()) {
-                const double lower = (double)nnz_all[(size_t)ib] / (double)h * union_col_cost(h > 32 ? 2 : 1);
+                const double lower = (double)nnz_all[(size_t)ib] / (double)h * union_col_cost(union_tile_units(std::min<int64_t>(h, 64), sp->union_gran));
                 if (lower < union_margin * r.cost) {
                     UnionEval u = eval_union(counter_of(tid), r0, r1, tail_cap);
                     // (... and only where the LISTS carry the block-row: tiles that are mostly tails are a slower sparse-row kernel)
@@ -315,7 +317,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
         auto union_steps_of = [&](int64_t ib) {
             double st = 0.0;
             const int64_t h = part[(size_t)ib + 1] - part[(size_t)ib];
-            for (size_t q = 0; q < nu_parts[(size_t)ib].size(); q++) st += (double)((nu_parts[(size_t)ib][q] + 31) / 32) * (union_part_rows(h, (int64_t)q) > 32 ? 2.0 : 1.0);
+            for (size_t q = 0; q < nu_parts[(size_t)ib].size(); q++) st += (double)((nu_parts[(size_t)ib][q] + 31) / 32) * union_tile_units(union_part_rows(h, (int64_t)q), sp->union_gran);
             return st;
         };
         auto union_area_of = [&](int64_t ib) {
@@ -500,7 +502,7 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                         const int64_t p0 = r0 + 64 * (int64_t)q, p1 = p0 + union_part_rows(h, (int64_t)q);
                         const int ty = p1 - p0 > 32 ? 1 : 0, mi = ty + 1;
                         const int32_t ti = tile_of[(size_t)part_base[(size_t)ib] + q];
-                        const int32_t cmin = take_all[(size_t)ib] ? 1 : union_min_count(mi);
+                        const int32_t cmin = take_all[(size_t)ib] ? 1 : union_min_count(union_tile_units(p1 - p0, sp->union_gran));
                         const UnionPlanHost::Tile& tl = U.tiles[ty][(size_t)ti];
                         cc.count(a, perm.data(), p0, p1);
                         list.clear();

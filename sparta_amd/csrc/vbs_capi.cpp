@@ -105,7 +105,7 @@ void destroy_impl(sparta_vbs* v) {
     if (v->cr_small.parts) (void)hipFree(v->cr_small.parts);
     if (v->d_cr_dest) (void)hipFree(v->d_cr_dest);
     if (v->d_cr_longs) (void)hipFree(v->d_cr_longs);
-    for (int ty = 0; ty < 2; ty++) {
+    for (int ty = 0; ty < kUnionTypes; ty++) {
         if (v->d_u_rec[ty]) (void)hipFree(v->d_u_rec[ty]);
         if (v->d_u_ids[ty]) (void)hipFree(v->d_u_ids[ty]);
         if (v->d_u_a[ty]) (void)hipFree(v->d_u_a[ty]);
@@ -858,9 +858,9 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         CREATE_TRY(hipMalloc((void**)&v->d_fix_slots, std::max<size_t>(fix_slots.size(), 1) * sizeof(int32_t)));
         if (!fix_slots.empty()) CREATE_TRY(hipMemcpy(v->d_fix_slots, fix_slots.data(), fix_slots.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    for (int ty = 0; ty < 2; ty++) {
+    for (int ty = 0; ty < kUnionTypes; ty++) {
         if (uplan.n_steps[ty] == 0) continue;
-        v->u_workers[ty] = uplan.n_workers[ty]; v->u_steps[ty] = uplan.n_steps[ty]; v->u_tiles[ty] = (int64_t)ext->uni.tiles[ty].size();
+        v->u_workers[ty] = uplan.n_workers[ty]; v->u_steps[ty] = uplan.n_steps[ty]; v->u_tiles[ty] = uplan.n_tiles[ty]; v->u_steps_total += uplan.n_steps[ty];
         CREATE_TRY(hipMalloc((void**)&v->d_u_rec[ty], uplan.rec[ty].size() * sizeof(UnionRec)));
         CREATE_TRY(hipMemcpy(v->d_u_rec[ty], uplan.rec[ty].data(), uplan.rec[ty].size() * sizeof(UnionRec), hipMemcpyHostToDevice));
         CREATE_TRY(hipMalloc((void**)&v->d_u_ids[ty], uplan.ids[ty].size() * sizeof(int32_t)));
@@ -873,9 +873,12 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         CREATE_TRY(hipMalloc(&v->d_u_tail[ty], uplan.tail[ty].size() * sizeof(uint32_t)));
         CREATE_TRY(hipMemcpy(v->d_u_tail[ty], uplan.tail[ty].data(), uplan.tail[ty].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         v->a_bytes += (int64_t)(a_bytes_ty + uplan.ids[ty].size() * sizeof(int32_t) + uplan.tail[ty].size() * sizeof(uint32_t));
-        v->exec_area += uplan.n_steps[ty] * 32 * 32 * (ty + 1);
+        v->exec_area += uplan.n_steps[ty] * 32 * uplan.type_rows[ty];
     }
-    if (ext) { v->u_area = uplan.area; v->u_cols = uplan.cols; v->u_nnz = ext->uni.nnz; v->u_tail_nnz = ext->uni.tail_nnz; v->u_rows = uplan.rows; }
+    if (ext) {
+        v->u_area = uplan.area; v->u_cols = uplan.cols; v->u_nnz = ext->uni.nnz; v->u_tail_nnz = ext->uni.tail_nnz; v->u_rows = uplan.rows;
+        for (int hh = 0; hh < 2; hh++) { v->u_tiles_h[hh] = uplan.tiles_by_height[hh]; v->u_steps_h[hh] = uplan.steps_by_height[hh]; }
+    }
     if (!sp_crow.empty()) {
         v->n_sp_rows = (int64_t)sp_crow.size(); v->n_sp_short = n_sp_short; v->n_sp_long = n_sp_long; v->sp_nnz = sp_rowptr.back();
         CREATE_TRY(hipMalloc((void**)&v->d_sp_rowptr, sp_rowptr.size() * sizeof(int64_t)));
@@ -1000,6 +1003,7 @@ static int create_from_csr_impl(sparta_vbs_t** out, int64_t rows, int64_t cols, 
         sparta::HybridSparse sp;
         sp.esz = dtype == SPARTA_F32 ? 4.0 : 2.0;
         sp.want_union = true;                                              // column-compacted tiles (k_union.hip: fp32 and 16-bit forms)
+        sp.union_gran = dtype == SPARTA_F32 ? 16 : 32;
         rc = sparta::vbs_build_hybrid(a, grouping, col_block_size, row_block_size, force_fixed_size != 0, K, kdep, &h, K > 0.0 ? &sp : nullptr, keep_order);
         if (rc == SPARTA_OK)
             rc = create_core(out, h.rows, h.cols, h.block_rows, col_block_size, h.row_part, h.nzcount, h.jab, h.mab, 0, h.block_rows, dtype, device,
@@ -1029,6 +1033,7 @@ int sparta_vbs_plan_stats(int64_t rows, int64_t cols, const int64_t* rowptr, con
     sparta::HybridSparse sp;
     sp.esz = dtype == SPARTA_F32 ? 4.0 : 2.0;
     sp.want_union = true;
+    sp.union_gran = dtype == SPARTA_F32 ? 16 : 32;
     sparta::HybridStats st;
     sparta_vbs_host h;
     std::memset(&h, 0, sizeof(h));
@@ -1141,8 +1146,9 @@ int sparta_vbs_hub_info(const sparta_vbs_t* A, int64_t* info) {
 
 int sparta_vbs_union_info(const sparta_vbs_t* A, int64_t* info) {
     if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_union_info: NULL argument");
-    info[0] = A->u_tiles[0]; info[1] = A->u_tiles[1]; info[2] = A->u_steps[0]; info[3] = A->u_steps[1];
-    info[4] = A->u_area; info[5] = A->u_cols; info[6] = A->u_nnz; info[7] = A->u_workers[0] + A->u_workers[1];
+    info[0] = A->u_tiles_h[0]; info[1] = A->u_tiles_h[1]; info[2] = A->u_steps_h[0]; info[3] = A->u_steps_h[1];
+    info[4] = A->u_area; info[5] = A->u_cols; info[6] = A->u_nnz; info[7] = 0;
+    for (int ty = 0; ty < kUnionTypes; ty++) info[7] += A->u_workers[ty];
     info[8] = A->u_rows; info[9] = A->u_tail_nnz;
     return SPARTA_OK;
 }
@@ -1242,7 +1248,7 @@ int sparta_union_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, c
     if (const char* e = std::getenv("SPARTA_SPARSE_K")) K = atof(e);
     if (!(K > 0.0)) return fail(SPARTA_ERR_INVALID, "sparta_union_host_check: the hybrid builder is switched off (SPARTA_SPARSE_K=0)");
     sparta::HybridSparse sp;
-    sp.esz = 4.0; sp.want_union = true;
+    sp.esz = 4.0; sp.want_union = true; sp.union_gran = 16;
     sparta_vbs_host h;
     std::memset(&h, 0, sizeof(h));
     struct Free { sparta_vbs_host* p; ~Free() { sparta_vbs_host_free(p); } } guard{&h};
@@ -1262,9 +1268,9 @@ int sparta_union_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, c
     }
     for (size_t t = 0; t < sp.crow.size(); t++)                           // the sparse rows (they own their row or add to it: y started at zero either way)
         for (int64_t k = sp.rowptr[t]; k < sp.rowptr[t + 1]; k++) y[sp.crow[t]] += (double)sp.val[(size_t)k] * (double)x[sp.col[(size_t)k]];
-    info[0] = (int64_t)sp.uni.tiles[0].size(); info[1] = (int64_t)sp.uni.tiles[1].size(); info[2] = P.n_steps[0]; info[3] = P.n_steps[1];
+    info[0] = (int64_t)sp.uni.tiles[0].size(); info[1] = (int64_t)sp.uni.tiles[1].size(); info[2] = P.steps_by_height[0]; info[3] = P.steps_by_height[1];
     info[4] = P.area; info[5] = P.cols; info[6] = sp.uni.nnz; info[7] = sp.rowptr.empty() ? 0 : sp.rowptr.back();
-    info[8] = h.nztot; info[9] = h.rows; info[10] = P.n_workers[0]; info[11] = P.n_workers[1]; info[12] = sp.uni.tail_nnz; info[13] = P.rows;
+    info[8] = h.nztot; info[9] = h.rows; info[10] = P.n_workers[0] + P.n_workers[1]; info[11] = P.n_workers[2] + P.n_workers[3]; info[12] = sp.uni.tail_nnz; info[13] = P.rows;
     return SPARTA_OK;
     SPARTA_GUARD_END("sparta_union_host_check")
 }
@@ -1408,7 +1414,7 @@ int ensure_brm(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_major, i
 // the sparse rows of those block-rows (their thinly used columns) add behind it on the same stream.
 int launch_union_tiles(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_major, int64_t shard_rows, int64_t shard_stride, int32_t n_cols, float* dC,
                        int64_t ldc, bool c_row_major, bool accumulate, hipStream_t st) {
-    if (A->u_steps[0] + A->u_steps[1] == 0) return SPARTA_OK;
+    if (A->u_steps_total == 0) return SPARTA_OK;
     // 32-bit byte offsets inside a tile's 64 rows x 32 columns of C
     if ((c_row_major ? 64 * ldc + 128 : 32 * ldc + 128) * 4 >= ((int64_t)1 << 31) - 65536)
         return sparta::fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: leading dimension of C too large for the column-compacted tile kernel (32-bit offsets inside a tile)");
@@ -1418,7 +1424,7 @@ int launch_union_tiles(sparta_vbs_t* A, const void* dB, int64_t ldb, bool b_row_
     up.B = (const float*)A->brm_ready; up.ldb = A->brm_ld; up.C = dC; up.ldc = ldc;
     up.n_cols = n_cols; up.accumulate = accumulate ? 1 : 0; up.c_row_major = c_row_major ? 1 : 0;
     up.pad = [] { const char* e = std::getenv("SPARTA_UNION_PROBE"); return e ? atoi(e) : 0; }();      // developer probes (timing only, wrong products; read per call)
-    for (int ty = 0; ty < 2; ty++) {
+    for (int ty = 0; ty < kUnionTypes; ty++) {
         UnionSide& sd = up.side[ty];
         sd.rec = A->d_u_rec[ty]; sd.ids = A->d_u_ids[ty]; sd.A = A->d_u_a[ty]; sd.worker_range = A->d_u_wrange[ty]; sd.tail = (const uint2*)A->d_u_tail[ty];
         sd.n_workers = A->u_steps[ty] > 0 ? A->u_workers[ty] : 0;
@@ -1670,7 +1676,7 @@ int spmm16_core(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, i
     // (a 16-bit product runs this core once per piece of B -- the whole slabs, then the padded tail slab: each piece has its own row-major copy, made by whoever needs it first)
     A->brm_ready = nullptr; A->brm_ld = 0;
     struct BrmPiece { sparta_vbs_t* a; ~BrmPiece() { a->brm_ready = nullptr; a->brm_ld = 0; } } brm_piece{A};
-    if (A->u_steps[0] + A->u_steps[1] > 0) {   // column-compacted tiles (k_union.hip, 16-bit form): they store every row of their block-rows; those block-rows' sparse rows add, below
+    if (A->u_steps_total > 0) {   // column-compacted tiles (k_union.hip, 16-bit form): they store every row of their block-rows; those block-rows' sparse rows add, below
         const bool rec = prof && !A->class_ran[2];
         if (rec) HIP_TRY(hipEventRecord(A->cev[2][0], st));
         if (int rc = launch_union_tiles(A, dB, ldb16, false, shard_rows, shard_stride, n_cols, dC, ldc, c_layout == SPARTA_ROW_MAJOR, accumulate != 0, st)) return rc;
@@ -1808,7 +1814,7 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
 
     struct BrmScope { sparta_vbs_t* a; ~BrmScope() { a->brm_ready = nullptr; a->brm_ld = 0; } } brm_scope{A};     // (the row-major B belongs to this product only)
     A->brm_ready = nullptr; A->brm_ld = 0;
-    if (algo == SPARTA_SPMM_EXACT && A->ext_sparse && (A->n_sp_rows > 0 || A->u_steps[0] + A->u_steps[1] > 0))
+    if (algo == SPARTA_SPMM_EXACT && A->ext_sparse && (A->n_sp_rows > 0 || A->u_steps_total > 0))
         return fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_spmm: SPARTA_SPMM_EXACT needs the dense image of every block-row (handle made by sparta_vbs_create_from_csr)");
     if (dt_ms) HIP_TRY(hipEventRecord(A->ev0, st));
     if (algo == SPARTA_SPMM_EXACT) {
@@ -1961,7 +1967,7 @@ int spmm_impl(sparta_vbs_t* A, const void* B, int64_t ldb, int32_t b_layout, int
         // the tile and fix-up launches stored: this launch must stay BEHIND those launches on the same stream (moving the sparse leg to a side
         // stream for overlap needs an event wait for the mixed rows) ----
         // ---- the column-compacted tiles (fp32 handles made from a CSR): they store every row of their block-rows; those block-rows' sparse rows add, below ----
-        if (A->u_steps[0] + A->u_steps[1] > 0) {
+        if (A->u_steps_total > 0) {
             const bool rec = prof && !A->class_ran[2];
             if (rec) HIP_TRY(hipEventRecord(A->cev[2][0], st));
             if (int rc = launch_union_tiles(A, dB, ldb, b_layout == SPARTA_ROW_MAJOR, shard_rows, shard_stride, n_cols, dC, ldc, c_layout == SPARTA_ROW_MAJOR,
@@ -2052,7 +2058,7 @@ int sparta_vbs_prepare_b(sparta_vbs_t* A, const void* B, int64_t ldb, int64_t sh
     // the sparse-row kernels of this handle would transpose this B per product (launch_sparse_rows: not when a handful of rows reads it in place)
     // (nor when the resident-column kernel carries the products of a plain column-major B: it reads the columns where they are; a later product into a ROW-major C
     // then transposes per call as sparta_vbs_spmm does)
-    const bool needs_copy = (A->n_sp_rows > 0 && !(A->sp_nnz * 8 < A->cols) && !(A->cr_slices > 0 && shard_rows == 0)) || A->u_steps[0] + A->u_steps[1] > 0;
+    const bool needs_copy = (A->n_sp_rows > 0 && !(A->sp_nnz * 8 < A->cols) && !(A->cr_slices > 0 && shard_rows == 0)) || A->u_steps_total > 0;
     if (needs_copy) {
         hipStream_t st = (hipStream_t)stream;
         const int64_t n_wg = ((A->cols + 63) / 64) * (int64_t)((n_cols + 63) / 64);

@@ -209,16 +209,19 @@ static_assert(sizeof(UnionRec) == 16, "UnionRec must stay 16 bytes");
 constexpr int32_t UREC_LAST = 1 << 16;                   // the tile's last step: add the tail, store the tile's rows of C
 constexpr int UREC_TAIL_SHIFT = 17;
 constexpr int kUnionPadSteps = 4;                        // records / list entries / slices behind the last step (the pipeline requests up to three steps past a worker's range)
-struct UnionSide {                // one tile type: [0] tiles of <= 32 rows (MI = 1), [1] tiles of 33..64 rows (MI = 2)
+constexpr int kUnionTypes = 4;    // tile types of one handle.  fp32: type t = tiles of 16 t + 1 .. 16 (t + 1) rows (t + 1 MFMA row tiles of 16); 16-bit: types 0, 1 = tiles of <= 32 / 33..64 rows
+struct UnionSide {                // one tile type
     const UnionRec* rec;          // per step, in execution order (worker after worker)
     const int32_t* ids;           // [step][32]: the rows of B (= columns of A) of the step's list positions; 0 behind the valid ones (never fetched)
-    const float* A;               // [step][MI x 1024]: the step's slice in MFMA fragment order [rt][j][g][row][4] = A[32 rt + row][k = 16 g + 4 j + e]
+    const void* A;                // the steps' slices as the LDS image the kernel wants.  fp32, type t (R = 16 (t + 1) rows): [step][rt][h][lane][4] floats, lane = 16 kq + i:
+                                  // A[16 rt + i][k = 4 (4 h + e) + kq] (one ds_read_b128 per lane = the row's values of four consecutive 16x16x4 MFMAs);
+                                  // 16-bit, type t (32 (t + 1) rows): [step][rt][m][kg][row][8] = A[32 rt + row][k = 16 m + 8 kg + e]
     const int32_t* worker_range;  // [2 x workers]: begin, end step
-    const uint2* tail;            // per tile (execution order) [entry][32 MI rows]: (column, value bits) added in the tile's epilogue
+    const uint2* tail;            // per tile (execution order) [entry][R rows]: (column, value bits) added in the tile's epilogue
     int32_t n_workers, c_nt;
 };
-struct UnionParams {              // ONE launch: workgroups [0, side[1].n_workers) walk the 33..64-row tiles, the others the <= 32-row tiles
-    UnionSide side[2];
+struct UnionParams {              // ONE launch: the workgroups of the tallest type first, then the next ...
+    UnionSide side[kUnionTypes];
     const float* B;               // ROW-major cols x n_cols, ld = ldb (a multiple of 4 elements, 16-byte aligned base)
     int64_t ldb;
     float* C;
@@ -356,13 +359,14 @@ struct sparta_vbs {
     int64_t cr_entries = 0;                // stored entries, padding included
     int last_colres_nc = 0;                // columns per workgroup of the last product on this path (0: the product took another path)
     // column-compacted tiles (fp32 handles made from a CSR: vbs_build.cpp mode 3): per tile type [0] <= 32 rows, [1] 33..64 rows
-    sparta_dev::UnionRec* d_u_rec[2] = {nullptr, nullptr};
-    int32_t* d_u_ids[2] = {nullptr, nullptr};
-    float* d_u_a[2] = {nullptr, nullptr};
-    int32_t* d_u_wrange[2] = {nullptr, nullptr};
-    void* d_u_tail[2] = {nullptr, nullptr};
-    int32_t u_workers[2] = {0, 0};
-    int64_t u_steps[2] = {0, 0}, u_tiles[2] = {0, 0};
+    sparta_dev::UnionRec* d_u_rec[sparta_dev::kUnionTypes] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t* d_u_ids[sparta_dev::kUnionTypes] = {nullptr, nullptr, nullptr, nullptr};
+    void* d_u_a[sparta_dev::kUnionTypes] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t* d_u_wrange[sparta_dev::kUnionTypes] = {nullptr, nullptr, nullptr, nullptr};
+    void* d_u_tail[sparta_dev::kUnionTypes] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t u_workers[sparta_dev::kUnionTypes] = {0, 0, 0, 0};
+    int64_t u_steps[sparta_dev::kUnionTypes] = {0, 0, 0, 0}, u_tiles[sparta_dev::kUnionTypes] = {0, 0, 0, 0};   // per tile type of the DEVICE plan
+    int64_t u_tiles_h[2] = {0, 0}, u_steps_h[2] = {0, 0}, u_steps_total = 0;   // tiles / steps of tiles of <= 32 / 33..64 rows; all steps
     int64_t u_area = 0, u_cols = 0, u_nnz = 0;      // stored elements (rows x list entries), list entries, nonzeros held (lists + tails)
     int64_t u_tail_nnz = 0, u_rows = 0;             // nonzeros in the tiles' tails; rows of C the tiles own
     const void* brm_ready = nullptr;       // the row-major B of the product in flight (set by the first launch that needs it, cleared when the product returns)
@@ -456,14 +460,16 @@ struct StreamPlanHost {
 };
 // vbs_union.cpp: the device form of the column-compacted tiles -- tiles dealt to workers longest first, a worker's steps back to back
 struct UnionDevPlan {
-    std::vector<UnionRec> rec[2];
-    std::vector<int32_t> ids[2];
-    std::vector<float> a[2];                  // fp32 handles: slices [step][MI x 1024] floats
-    std::vector<uint16_t> a16[2];             // 16-bit handles: slices [step][MI x 1024] 16-bit elements, [rt][m][kg][row][8] = A[32 rt + row][k = 16 m + 8 kg + e] (rounded to the storage type)
-    std::vector<int32_t> wrange[2];
-    std::vector<uint32_t> tail[2];            // (column, value bits) pairs, tile after tile in execution order
-    int32_t n_workers[2] = {0, 0};
-    int64_t n_steps[2] = {0, 0};
+    std::vector<UnionRec> rec[kUnionTypes];
+    std::vector<int32_t> ids[kUnionTypes];
+    std::vector<float> a[kUnionTypes];        // fp32 handles: slices [step][R x 32] floats (R = 16 (type + 1)), the layout of UnionSide::A
+    std::vector<uint16_t> a16[kUnionTypes];   // 16-bit handles: slices [step][R x 32] 16-bit elements (R = 32 (type + 1)), rounded to the storage type
+    std::vector<int32_t> wrange[kUnionTypes];
+    std::vector<uint32_t> tail[kUnionTypes];  // (column, value bits) pairs, tile after tile in execution order
+    int32_t n_workers[kUnionTypes] = {0, 0, 0, 0};
+    int64_t n_steps[kUnionTypes] = {0, 0, 0, 0}, n_tiles[kUnionTypes] = {0, 0, 0, 0};
+    int32_t type_rows[kUnionTypes] = {0, 0, 0, 0};   // R of each type
+    int64_t tiles_by_height[2] = {0, 0}, steps_by_height[2] = {0, 0};   // tiles / steps of tiles of <= 32 rows, of 33..64 rows (what sparta_vbs_union_info reports)
     int64_t area = 0, cols = 0, rows = 0;     // stored elements (tile rows x list entries); list entries; rows of C the tiles own
 };
 int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPlan& P, int dtype = SPARTA_F32);
