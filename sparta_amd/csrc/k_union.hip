@@ -41,6 +41,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // Two LDS stages (one step of loads in flight across the barrier) and THREE workgroups per CU: measured on the benchmark set's clustered family (N = 128, prepared B):
 // three stages with two workgroups per CU 172 us, two stages with two 162, two stages with three 160 -- another co-resident workgroup hides a workgroup's waits
 // (barrier, tile epilogue with its tail gathers) better than a deeper pipeline of its own (profiles/r5/lab_union_stages.txt).
+#ifndef SPARTA_UNION_TAILPIPE
+#define SPARTA_UNION_TAILPIPE 1   /* developer A/B: 0 = every tail entry is added in the tile's epilogue */
+#endif
 #ifndef SPARTA_UNION_STATS
 #define SPARTA_UNION_STATS 0      /* lab build: per-wave cycle sums written over the head of C (scripts/lab/r5_union_stats.py) */
 #endif
@@ -160,6 +163,28 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
     const uint32_t rstep = p.c_row_major ? (uint32_t)p.ldc * 64u : 64u;          // bytes per 16 rows
     const int ncw = ncv - 32 * wave;                                             // columns of this wave that exist
 
+#if SPARTA_UNION_TAILPIPE
+    // tails in the pipeline: the tile's step t requests, per lane, the pieces of B of tail entry t (2 x 16 bytes of ITS row's column) and the (column, value) pair of
+    // entry t + 1 -- ahead of the step's panel loads, so they do not queue behind them; step t + 1 multiplies entry t in before its MFMAs (the step's top wait covers
+    // them).  A round trip per entry then hides behind a step instead of standing between the tile's last MFMA and its stores; what the steps cannot carry (entries
+    // S - 1 .. of a tile of S steps) is added in the epilogue.
+    int tstep = 0;                                       // the current step's index inside its tile
+    bool tb_live = false;                                // an entry's pieces were requested by the previous step
+    uint2 cvn[RT];
+    float tv[RT];
+    f32x4 tb[RT][2];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) {
+        cvn[rt] = uint2{0u, 0u}; tv[rt] = 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) tb[rt][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    const float* const brow_t = p.B + n0 + 32 * wave + 4 * kq;
+    if (!(probe & 8) && !(iq[0] & UREC_LAST) && ((iq[0] >> UREC_TAIL_SHIFT) & 31) > 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) cvn[rt] = sd.tail[tq[0] + rt * 16 + li];
+    }
+#endif
 #if SPARTA_UNION_STATS
     // lab build only (results WRONG: the sums overwrite the head of C): cycles this wave spent waiting for its loads / at the barrier / in the multiply phase / in epilogues
     uint64_t st_wait = 0, st_bar = 0, st_mul = 0, st_epi = 0;
@@ -182,6 +207,34 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
         nxt = load_rec(i + AHEAD + 1);
         const int jstage = stage ^ 1;
         iq[AHEAD] = rec.info; cq[AHEAD] = rec.c_row; tq[AHEAD] = rec.tail_off;
+#if SPARTA_UNION_TAILPIPE
+        {
+            const int32_t inf = iq[0];
+            if (tb_live) {                                 // the entry the previous step requested
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; i2++) acc[rt][ct][i2] = __builtin_fmaf(tv[rt], tb[rt][ct][i2], acc[rt][ct][i2]);
+            }
+            tb_live = !(probe & 8) && !(inf & UREC_LAST) && tstep < ((inf >> UREC_TAIL_SHIFT) & 31);
+            if (tb_live) {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) {
+                    tv[rt] = __uint_as_float(cvn[rt].y);
+                    const float* bp = brow_t + (int64_t)cvn[rt].x * p.ldb;
+#pragma unroll
+                    for (int ct = 0; ct < 2; ct++) tb[rt][ct] = 16 * ct + 4 * kq < ncw ? *reinterpret_cast<const f32x4*>(bp + 16 * ct) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            }
+            const int tn = (inf & UREC_LAST) ? 0 : tstep + 1;                  // the next step's index inside ITS tile
+            if (!(probe & 8) && !(rec.info & UREC_LAST) && tn < ((rec.info >> UREC_TAIL_SHIFT) & 31)) {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) cvn[rt] = sd.tail[rec.tail_off + (tn * RT + rt) * 16 + li];
+            }
+        }
+#endif
         // (4) multiply step i: the fragments first (the LDS reads of the whole step), then 16 RT matrix instructions with the loads of step i + 1 issued between them
         {
             const char* const sa = lds0 + stage * STAGE;
@@ -221,9 +274,14 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
                 const uint2* tp = sd.tail + tq[0] + li;
                 const float* brow = p.B + n0 + 32 * wave + 4 * kq;
                 // two entries at a time: their (column, value) pairs in one round trip, their 2 x RT x 2 pieces of B in a second one (an entry at a time is two round
-                // trips per entry with the matrix pipe idle; four at a time costs the third workgroup per CU its registers)
-                constexpr int CH = 2;
-                for (int e0 = 0; e0 < tail_e; e0 += CH) {
+                // trips per entry with the matrix pipe idle; more at a time -- or two for the tallest type -- costs the third workgroup per CU its registers)
+                constexpr int CH = RT == 4 ? 1 : 2;
+#if SPARTA_UNION_TAILPIPE
+                const int e_first = tstep < tail_e ? tstep : tail_e;          // entries 0 .. S - 2 rode in the steps
+#else
+                const int e_first = 0;
+#endif
+                for (int e0 = e_first; e0 < tail_e; e0 += CH) {
                     uint2 cv[CH][RT];
 #pragma unroll
                     for (int c = 0; c < CH; c++)
@@ -291,6 +349,9 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
 #pragma unroll
         for (int k = 0; k < AHEAD; k++) { iq[k] = iq[k + 1]; cq[k] = cq[k + 1]; tq[k] = tq[k + 1]; }
         stage ^= 1;
+#if SPARTA_UNION_TAILPIPE
+        tstep = (info & UREC_LAST) ? 0 : tstep + 1;
+#endif
 #if SPARTA_UNION_STATS
         const uint64_t st4 = __builtin_readcyclecounter();
         st_wait += st1 - st0; st_bar += st2 - st1; st_mul += st3 - st2; st_epi += st4 - st3;
