@@ -27,7 +27,7 @@
 // granularity matters.  A worker walks WHOLE tiles (vbs_union.cpp deals them longest first).  A tile's last step first adds its TAIL -- up to 16 nonzeros per row in
 // columns too thinly used for the list (a cluster's rows have a few columns of their own): lane (i, q) holds its row's accumulators of 8 of the wave's 32 columns, so per
 // entry it fetches 2 x 16 bytes of ITS row of B and multiplies them in; no sparse-row launch, no second pass over the rows of C -- then stores the tile's rows of C (or
-// adds to them: accumulate).  ONE launch carries all tile types: the workgroups of the tallest type first.
+// adds to them: accumulate).  ONE launch carries all tile types: a workgroup runs the body of each type over its tiles of that type, tallest first.
 #include "vbs_kernel_common.hpp"
 
 using namespace sparta_dev;
@@ -625,22 +625,24 @@ template <bool BF16>
 __global__ __launch_bounds__(256, SPARTA_UNION16_WPC) void vbs_union_h16_kernel(const UnionParams p) {
     static_assert(kUnion16Lds * SPARTA_UNION16_WPC <= 160 * 1024, "LDS per CU");
     __shared__ __attribute__((aligned(1024))) char lds[kUnion16Lds];
-    const int n2 = p.side[1].n_workers;
-    if ((int)blockIdx.x < n2) union16_body<2, BF16>(p, p.side[1], (int)blockIdx.x, lds);
-    else union16_body<1, BF16>(p, p.side[0], (int)blockIdx.x - n2, lds);
+    const int b = (int)blockIdx.x;
+    if (b < p.side[1].n_workers) union16_body<2, BF16>(p, p.side[1], b, lds);
+    __syncthreads();
+    if (b < p.side[0].n_workers) union16_body<1, BF16>(p, p.side[0], b, lds);
 }
 
 __global__ __launch_bounds__(256, 3) void vbs_union_f32_kernel(const UnionParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[kUnionLds];
     static_assert(kUnionLds * 3 <= 160 * 1024, "three workgroups per CU");
-    // (wave-uniform: the four bodies are four programs behind scalar branches; the tallest tiles' workgroups first)
-    int b = (int)blockIdx.x;
-    if (b < p.side[3].n_workers) { union_body<4, kUnionStages>(p, p.side[3], b, lds); return; }
-    b -= p.side[3].n_workers;
-    if (b < p.side[2].n_workers) { union_body<3, kUnionStages>(p, p.side[2], b, lds); return; }
-    b -= p.side[2].n_workers;
-    if (b < p.side[1].n_workers) { union_body<2, kUnionStages>(p, p.side[1], b, lds); return; }
-    b -= p.side[1].n_workers;
+    // every workgroup walks ITS tiles of each type, tallest first (vbs_union.cpp balances the workers over all types together); between two bodies every wave must be
+    // done with the stages of the first
+    const int b = (int)blockIdx.x;
+    if (b < p.side[3].n_workers) union_body<4, kUnionStages>(p, p.side[3], b, lds);
+    __syncthreads();
+    if (b < p.side[2].n_workers) union_body<3, kUnionStages>(p, p.side[2], b, lds);
+    __syncthreads();
+    if (b < p.side[1].n_workers) union_body<2, kUnionStages>(p, p.side[1], b, lds);
+    __syncthreads();
     if (b < p.side[0].n_workers) union_body<1, kUnionStages>(p, p.side[0], b, lds);
 }
 
@@ -649,11 +651,13 @@ __global__ __launch_bounds__(256, 3) void vbs_union_f32_kernel(const UnionParams
 namespace sparta_dev {
 
 void launch_union_f32(unsigned n_slabs, hipStream_t st, const UnionParams& p) {
-    hipLaunchKernelGGL(vbs_union_f32_kernel, dim3((unsigned)(p.side[0].n_workers + p.side[1].n_workers + p.side[2].n_workers + p.side[3].n_workers), n_slabs), dim3(256), 0, st, p);
+    int W = 0;
+    for (int ty = 0; ty < kUnionTypes; ty++) W = p.side[ty].n_workers > W ? p.side[ty].n_workers : W;
+    hipLaunchKernelGGL(vbs_union_f32_kernel, dim3((unsigned)W, n_slabs), dim3(256), 0, st, p);
 }
 // the same for a 16-bit handle: UnionParams::B is the ROW-major 16-bit copy of B (ld a multiple of 8 elements), UnionSide::A the 16-bit slices
 void launch_union_h16(bool bf16, unsigned n_slabs, hipStream_t st, const UnionParams& p) {
-    const dim3 grid((unsigned)(p.side[0].n_workers + p.side[1].n_workers), n_slabs);
+    const dim3 grid((unsigned)(p.side[0].n_workers > p.side[1].n_workers ? p.side[0].n_workers : p.side[1].n_workers), n_slabs);
     if (bf16) hipLaunchKernelGGL(vbs_union_h16_kernel<true>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(vbs_union_h16_kernel<false>, grid, dim3(256), 0, st, p);
 }

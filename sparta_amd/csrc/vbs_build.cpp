@@ -370,18 +370,20 @@ int vbs_build_hybrid(const CsrView& a, const int64_t* grouping, int64_t w, int64
                 else add_total += sp_ent_of[(size_t)ib];                   // (rows that ADD to tiles -- more than tail_cap thinly-used columns: they stay sparse rows)
             }
             const int64_t straggler_cap = [] { const char* e = std::getenv("SPARTA_UNION_STRAGGLERS"); return e ? atoll(e) : (int64_t)65536; }();      // (read per build: 0 switches the rule off)
-            if (union_total > 0 && sparse_total > 0 && sparse_total + add_total <= straggler_cap && (sparse_total + add_total) * 50 <= union_total) {
+            if (union_total > 0 && sparse_total + add_total > 0 && sparse_total + add_total <= straggler_cap && (sparse_total + add_total) * 50 <= union_total) {
                 for (int64_t ib = 0; ib < block_rows; ib++) {
                     if (mode[(size_t)ib] == 3 && sp_ent_of[(size_t)ib] > 0 && tail_cap > 0 && tail_cap < 31) {
                         // ... and a tile row with more thinly-used columns than the tail holds (the rows that ADD) gets the longest tail the step record can name (31)
                         UnionEval u = eval_union(counter_of(0), part[(size_t)ib], part[(size_t)ib + 1], 31);
-                        cap_of[(size_t)ib] = 31;
-                        sp_rows_of[(size_t)ib] = u.rows_rest; sp_ent_of[(size_t)ib] = u.ent_rest;
-                        nu_parts[(size_t)ib].swap(u.nu); te_parts[(size_t)ib].swap(u.te);
-                        union_nnz_of[(size_t)ib] = u.nnz_in;
-                        continue;
-                    }
-                    if (mode[(size_t)ib] != 1) continue;
+                        if (u.ent_rest == 0 || part[(size_t)ib + 1] - part[(size_t)ib] > 4) {
+                            cap_of[(size_t)ib] = 31;
+                            sp_rows_of[(size_t)ib] = u.rows_rest; sp_ent_of[(size_t)ib] = u.ent_rest;
+                            nu_parts[(size_t)ib].swap(u.nu); te_parts[(size_t)ib].swap(u.te);
+                            union_nnz_of[(size_t)ib] = u.nnz_in;
+                            continue;
+                        }
+                        // (even that tail overflows in a group of two to four rows -- grouped on a few shared columns: every column in the list, as for the loners below)
+                    } else if (mode[(size_t)ib] != 1) continue;
                     const int64_t r0 = part[(size_t)ib], r1 = part[(size_t)ib + 1], h = r1 - r0;
                     ColCounter& cc = counter_of(0);
                     std::vector<int32_t> nu, te;

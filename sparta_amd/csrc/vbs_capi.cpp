@@ -1148,7 +1148,7 @@ int sparta_vbs_union_info(const sparta_vbs_t* A, int64_t* info) {
     if (!A || !info) return sparta::fail(SPARTA_ERR_INVALID, "sparta_vbs_union_info: NULL argument");
     info[0] = A->u_tiles_h[0]; info[1] = A->u_tiles_h[1]; info[2] = A->u_steps_h[0]; info[3] = A->u_steps_h[1];
     info[4] = A->u_area; info[5] = A->u_cols; info[6] = A->u_nnz; info[7] = 0;
-    for (int ty = 0; ty < kUnionTypes; ty++) info[7] += A->u_workers[ty];
+    for (int ty = 0; ty < kUnionTypes; ty++) info[7] = std::max<int64_t>(info[7], A->u_workers[ty]);
     info[8] = A->u_rows; info[9] = A->u_tail_nnz;
     return SPARTA_OK;
 }
@@ -1270,7 +1270,7 @@ int sparta_union_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, c
         for (int64_t k = sp.rowptr[t]; k < sp.rowptr[t + 1]; k++) y[sp.crow[t]] += (double)sp.val[(size_t)k] * (double)x[sp.col[(size_t)k]];
     info[0] = (int64_t)sp.uni.tiles[0].size(); info[1] = (int64_t)sp.uni.tiles[1].size(); info[2] = P.steps_by_height[0]; info[3] = P.steps_by_height[1];
     info[4] = P.area; info[5] = P.cols; info[6] = sp.uni.nnz; info[7] = sp.rowptr.empty() ? 0 : sp.rowptr.back();
-    info[8] = h.nztot; info[9] = h.rows; info[10] = P.n_workers[0] + P.n_workers[1]; info[11] = P.n_workers[2] + P.n_workers[3]; info[12] = sp.uni.tail_nnz; info[13] = P.rows;
+    info[8] = h.nztot; info[9] = h.rows; info[10] = std::max(P.n_workers[0], P.n_workers[1]); info[11] = std::max(P.n_workers[2], P.n_workers[3]); info[12] = sp.uni.tail_nnz; info[13] = P.rows;
     return SPARTA_OK;
     SPARTA_GUARD_END("sparta_union_host_check")
 }

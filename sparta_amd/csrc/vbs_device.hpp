@@ -220,7 +220,7 @@ struct UnionSide {                // one tile type
     const uint2* tail;            // per tile (execution order) [entry][R rows]: (column, value bits) added in the tile's epilogue
     int32_t n_workers, c_nt;
 };
-struct UnionParams {              // ONE launch: the workgroups of the tallest type first, then the next ...
+struct UnionParams {              // ONE launch: workgroup b walks its range of every type (side[t].worker_range[2 b ..]), tallest type first
     UnionSide side[kUnionTypes];
     const float* B;               // ROW-major cols x n_cols, ld = ldb (a multiple of 4 elements, 16-byte aligned base)
     int64_t ldb;

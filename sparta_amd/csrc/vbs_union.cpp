@@ -4,9 +4,8 @@
 // row in columns too thinly used for the list).
 // Out: per tile TYPE one sequence of 32-deep steps in execution order.  The type is the tile's height in MFMA row tiles: fp32 handles multiply with the 16 x 16 x 4
 // instruction, so a tile of mt rows is of type ceil(mt / 16) - 1 (16, 32, 48, 64 rows: a 48-row cluster costs three row tiles, not four); 16-bit handles with the
-// 32 x 32 x 16 one (types 0, 1: <= 32, 33..64 rows).  The `max_workers` persistent workgroups of the ONE launch are split between the types by their MFMA work; inside a
-// type tiles are dealt WHOLE, longest first, each to the worker with the fewest steps so far (LPT: the makespan is within one tile of the mean); a worker walks its
-// tiles in matrix order.  Per step: a record (row of C, rows, valid list positions, last-step flag, the tile's tail), its 32 list entries and its slice of A as the
+// 32 x 32 x 16 one (types 0, 1: <= 32, 33..64 rows).  The `max_workers` persistent workgroups of the ONE launch each walk tiles of every type (the kernel runs one
+// body per type, tallest first): tiles are dealt WHOLE, costliest first, each to the worker with the least work so far.  Per step: a record (row of C, rows, valid list positions, last-step flag, the tile's tail), its 32 list entries and its slice of A as the
 // LDS image the kernel's LDS-direct loads copy verbatim (UnionSide::A in vbs_device.hpp).
 #include <algorithm>
 #include <cstring>
@@ -28,46 +27,39 @@ int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPl
         }
     auto tile_of = [&](const Ref& r) -> const sparta::UnionPlanHost::Tile& { return U.tiles[r.hty][r.t]; };
     auto steps_of = [&](const Ref& r) { return std::max<int64_t>(1, ((int64_t)tile_of(r).nk + 31) / 32); };   // (a tile without a kept column still stores its rows: one step of zeros)
-    // workers per type: in proportion to the MFMA work (a step of a type-t tile is t + 1 row tiles), at least one each, never more than tiles
-    double work[kUnionTypes], total_work = 0.0;
-    for (int ty = 0; ty < kUnionTypes; ty++) {
-        work[ty] = 0.0;
-        for (const Ref& r : of_type[ty]) work[ty] += (double)steps_of(r) * (ty + 1);
-        total_work += work[ty];
+    // ONE set of workers for all types: every tile is dealt WHOLE, costliest first, to the worker with the least work so far (LPT over all tiles: the makespan is within
+    // one tile of the mean, whatever the mix of heights); a worker walks its tiles type by type (tallest first: the kernel runs one body per type), in matrix order
+    // inside a type.  A step's cost: its row tiles on the matrix pipe + what every step pays (the gather of the panel, the barrier); + a step for a tile's epilogue.
+    auto step_cost = [&](int ty) { return h16 ? 2.0 + (ty + 1) : 0.5 + (ty + 1); };
+    struct Item { double cost; int ty; size_t t; };
+    std::vector<Item> items;
+    for (int ty = 0; ty < kUnionTypes; ty++)
+        for (size_t t = 0; t < of_type[ty].size(); t++) items.push_back(Item{(double)(steps_of(of_type[ty][t]) + 1) * step_cost(ty), ty, t});
+    const int W = (int)std::min<int64_t>(std::max(max_workers, 1), (int64_t)items.size());
+    std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.cost > y.cost; });
+    std::vector<std::vector<size_t>> mine_all[kUnionTypes];
+    for (int ty = 0; ty < kUnionTypes; ty++) mine_all[ty].resize((size_t)W);
+    {
+        typedef std::pair<double, int> Load;                                   // (work so far, worker): the lightest worker on top
+        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> pq;
+        for (int w = 0; w < W; w++) pq.push(Load(0.0, w));
+        for (const Item& it : items) {
+            Load l = pq.top(); pq.pop();
+            mine_all[it.ty][(size_t)l.second].push_back(it.t);
+            l.first += it.cost;
+            pq.push(l);
+        }
     }
-    int W[kUnionTypes] = {0, 0, 0, 0};
-    max_workers = std::max(max_workers, kUnionTypes);
-    int given = 0, biggest = -1;
-    for (int ty = 0; ty < kUnionTypes; ty++) {
-        if (work[ty] <= 0.0) continue;
-        W[ty] = (int)std::max<int64_t>(1, (int64_t)(max_workers * work[ty] / total_work + 0.5));
-        given += W[ty];
-        if (biggest < 0 || work[ty] > work[biggest]) biggest = ty;
-    }
-    if (biggest >= 0 && given > max_workers) W[biggest] = std::max(1, W[biggest] - (given - max_workers));       // (rounding: the largest type gives the excess back)
-    for (int ty = 0; ty < kUnionTypes; ty++) W[ty] = (int)std::min<int64_t>(W[ty], (int64_t)of_type[ty].size());
 
     for (int ty = 0; ty < kUnionTypes; ty++) {
         const int R = gran * (ty + 1), nrt = ty + 1;                           // rows of the type's slices and tails; row tiles
         P.type_rows[ty] = R;
         const std::vector<Ref>& T = of_type[ty];
         if (T.empty()) continue;
-        const int Wt = W[ty];
-        std::vector<size_t> order(T.size());
-        for (size_t t = 0; t < T.size(); t++) order[t] = t;
-        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return steps_of(T[x]) > steps_of(T[y]); });
-        typedef std::pair<int64_t, int> Load;                                  // (steps so far, worker): the lightest worker on top
-        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> pq;
-        for (int w = 0; w < Wt; w++) pq.push(Load(0, w));
-        std::vector<std::vector<size_t>> mine((size_t)Wt);
+        const int Wt = W;
+        std::vector<std::vector<size_t>>& mine = mine_all[ty];
         int64_t total = 0, tail_total = 0;
-        for (size_t t : order) {
-            Load l = pq.top(); pq.pop();
-            mine[(size_t)l.second].push_back(t);
-            l.first += steps_of(T[t]) + 1; total += steps_of(T[t]);            // (+ 1: the epilogue of a tile costs about a step)
-            pq.push(l);
-            tail_total += (int64_t)tile_of(T[t]).tail_e * R;
-        }
+        for (const Ref& r : T) { total += steps_of(r); tail_total += (int64_t)tile_of(r).tail_e * R; }
         if (total + kUnionPadSteps > INT32_MAX || tail_total > INT32_MAX)
             return sparta::fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: too many steps of column-compacted tiles for 32-bit step indices");
         P.n_workers[ty] = Wt; P.n_steps[ty] = total; P.n_tiles[ty] = (int64_t)T.size();

@@ -1728,6 +1728,7 @@ def test_create_from_csr_splits_a_block_row_into_tiles_and_sparse_rows(monkeypat
         monkeypatch.delenv("SPARTA_SPARSE_K_BLOCK", raising=False)
     else:
         monkeypatch.setenv("SPARTA_SPARSE_K_BLOCK", kblock)
+    monkeypatch.setenv("SPARTA_UNION", "0")                   # (the subject is the per-block split; the column-compacted tiles would take these block-rows: tests/test_union_gpu.py)
     rng = np.random.Generator(np.random.PCG64(77))
     rows, cols, w, n = 640, 4096 + 17, 32, 128
     rr, cc = [], []

@@ -106,15 +106,21 @@ def test_every_nonzero_is_somewhere_exactly_once_on_a_mixed_matrix():
 
 
 def test_tails_hold_a_rows_own_columns_and_overflow_into_sparse_rows(monkeypatch):
-    # 20 columns of their own per row: 16 ride in the tile's tail, the others are sparse-row entries that add; with SPARTA_UNION_TAIL=0 all of them are
+    # 20 columns of their own per row: 16 ride in the tile's tail, the others are sparse-row entries that add ...
     m, order = clustered(10, 48, 4000, 100, 20, seed=21, integer=True)
     g = true_grouping(order, 48)
     x = np.random.default_rng(3).integers(-3, 4, m.cols).astype(np.float32)
     ref = np.asarray(reference_product(m, g, 1, x)).reshape(-1)
+    monkeypatch.setenv("SPARTA_UNION_STRAGGLERS", "0")
     y, info = walk(m, g, 1, x)
     assert info["tail_nnz"] >= 16 * m.rows * 0.9 and info["sparse_nnz"] > 0 and info["nnz"] + info["sparse_nnz"] == m.nztot(), info
     assert np.array_equal(y.astype(np.float32), ref)
-    monkeypatch.setenv("SPARTA_UNION_TAIL", "0")
+    capped = info
+    # ... unless that overflow is all the sparse-row kernels would be launched for: then the rows get the longest tail a step record can name (31) and nothing is left
+    monkeypatch.delenv("SPARTA_UNION_STRAGGLERS")
+    y, info = walk(m, g, 1, x)
+    assert info["sparse_nnz"] == 0 and info["nnz"] == m.nztot() and info["tail_nnz"] == capped["tail_nnz"] + capped["sparse_nnz"], info
+    assert np.array_equal(y.astype(np.float32), ref)
 
 
 def test_stragglers_become_tiles_when_little_else_is_left_for_the_sparse_rows(monkeypatch):
