@@ -159,14 +159,17 @@ def test_mixed_image_tiles_union_tiles_and_sparse_rows_in_one_product():
     d.close()
 
 
+@pytest.mark.parametrize("longest_tail", [False, True], ids=["overflow-to-sparse-rows", "tails-of-31"])
 @pytest.mark.parametrize("n", [128, 40])
-def test_tails_and_their_overflow_into_sparse_rows(n):
+def test_tails_and_their_overflow_into_sparse_rows(monkeypatch, n, longest_tail):
     torch = _torch()
-    m, order = clustered(40, 48, 6000, 100, 20, seed=21, integer=True)      # 20 columns of their own per row: 16 in the tile's tail, the rest sparse rows that add
+    m, order = clustered(40, 48, 6000, 100, 20, seed=21, integer=True)      # 20 columns of their own per row: 16 in the tile's tail, the rest sparse rows that add ...
     g = true_grouping(order, 48)
+    if not longest_tail:
+        monkeypatch.setenv("SPARTA_UNION_STRAGGLERS", "0")                  # ... unless that rest is all the sparse-row kernels would run for: then tails of up to 31 (the library's default here)
     d = sa.DeviceVBS.from_csr(m, g, 1, device=0)
     ui, si = d.union_info(), d.sparse_info()
-    assert ui["tail_nnz"] > 0 and si["nnz"] > 0 and ui["nnz"] + si["nnz"] == m.nztot(), (ui, si)
+    assert ui["tail_nnz"] > 0 and (si["nnz"] == 0) == longest_tail and ui["nnz"] + si["nnz"] == m.nztot(), (ui, si)
     B = np.random.default_rng(n).integers(-3, 4, m.cols * n).astype(np.float32)
     v = oracle.OracleVBR(m.rows, m.cols, m.rowptr, m.colidx, m.vals, g, 1)
     ref = oracle.vbr_multiply(v.rows, v.cols, 1, v.row_part, v.nzcount, v.jab, v.mab, B, n)
@@ -300,11 +303,12 @@ def test_16bit_tiles_every_element_against_the_reference_product(dtype, rows_per
 
 
 @pytest.mark.parametrize("dtype", [sa.F16, sa.BF16], ids=["f16", "bf16"])
-def test_16bit_tiles_on_real_data_with_tails_accumulate_and_prepared_b(dtype):
+def test_16bit_tiles_on_real_data_with_tails_accumulate_and_prepared_b(monkeypatch, dtype):
     """reference = float64 on the ROUNDED inputs (products of two 16-bit values are exact in fp32; the sums differ by their order only)"""
     torch = _torch()
     m, order = clustered(50, 48, 8000, 150, 20, seed=77)                      # 20 columns of their own per row: tails of 16 + sparse rows that add
     g = true_grouping(order, 48)
+    monkeypatch.setenv("SPARTA_UNION_STRAGGLERS", "0")                        # (by default such a small rest rides in tails of 31: the fp32 test above runs both)
     d = sa.DeviceVBS.from_csr(m, g, 32, device=0, dtype=dtype)
     ui, si = d.union_info(), d.sparse_info()
     assert ui["tiles64"] == 50 and ui["tail_nnz"] > 0 and si["nnz"] > 0, (ui, si)
