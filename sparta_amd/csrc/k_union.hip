@@ -548,7 +548,7 @@ __device__ __forceinline__ void union16_body(const UnionParams& p, const UnionSi
             const int tail_e = (info >> UREC_TAIL_SHIFT) & 31;
             if (tail_e > 0 && !(probe & 8)) {
                 const uint2* tp = sd.tail + tq[0] + lm;
-                const uint16_t* brow = B16 + n0 + 32 * wave + 4 * g;
+                const uint16_t* brow16 = B16 + n0 + 32 * wave + 8 * g;          // (16-byte chunks: lane g fetches chunks g and 2 + g of the wave's four)
                 constexpr int CH = 2;
                 for (int e0 = 0; e0 < tail_e; e0 += CH) {
                     uint2 cv[CH][MI];
@@ -556,15 +556,31 @@ __device__ __forceinline__ void union16_body(const UnionParams& p, const UnionSi
                     for (int c = 0; c < CH; c++)
 #pragma unroll
                         for (int rt = 0; rt < MI; rt++) cv[c][rt] = e0 + c < tail_e ? tp[((e0 + c) * MI + rt) * 32] : uint2{0u, 0u};
-                    uint2 bv[CH][MI][4];                  // four consecutive 16-bit columns per piece
+                    // the lane wants four pieces of four consecutive 16-bit columns (8 bytes at 16 qq + 8 g of the wave's 64 bytes of the row).  Fetched as such, an instruction
+                    // touches 32 rows for 16 bytes each.  Instead the two lanes of a row (lane, lane + 32) fetch whole 16-byte chunks -- lane g chunk 2 hh + g -- and trade
+                    // halves with v_permlane32_swap (lanes 32..63 of one register <-> lanes 0..31 of another): half the vector-memory instructions, 32 bytes per row each
+                    u32x4 ch[CH][MI][2];
 #pragma unroll
                     for (int c = 0; c < CH; c++)
 #pragma unroll
                         for (int rt = 0; rt < MI; rt++) {
-                            const uint16_t* bp = brow + (int64_t)cv[c][rt].x * p.ldb;
+                            const uint16_t* bp = brow16 + (int64_t)cv[c][rt].x * p.ldb;
 #pragma unroll
-                            for (int qq = 0; qq < 4; qq++) bv[c][rt][qq] = (e0 + c < tail_e && 8 * qq + 4 * g < ncw) ? *reinterpret_cast<const uint2*>(bp + 8 * qq) : uint2{0u, 0u};
+                            for (int hh = 0; hh < 2; hh++)
+                                ch[c][rt][hh] = (e0 + c < tail_e && 8 * (2 * hh + g) < ncw) ? *reinterpret_cast<const u32x4*>(bp + 16 * hh) : u32x4{0u, 0u, 0u, 0u};
                         }
+                    uint2 bv[CH][MI][4];                  // four consecutive 16-bit columns per piece
+#pragma unroll
+                    for (int c = 0; c < CH; c++)
+#pragma unroll
+                        for (int rt = 0; rt < MI; rt++)
+#pragma unroll
+                            for (int hh = 0; hh < 2; hh++) {
+                                const auto s0 = __builtin_amdgcn_permlane32_swap(ch[c][rt][hh][0], ch[c][rt][hh][2], false, false);
+                                const auto s1 = __builtin_amdgcn_permlane32_swap(ch[c][rt][hh][1], ch[c][rt][hh][3], false, false);
+                                bv[c][rt][2 * hh] = uint2{s0[0], s1[0]};
+                                bv[c][rt][2 * hh + 1] = uint2{s0[1], s1[1]};
+                            }
 #pragma unroll
                     for (int c = 0; c < CH; c++)
 #pragma unroll
