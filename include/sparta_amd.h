@@ -418,8 +418,11 @@ int sparta_colres_host_check(int64_t rows, int64_t cols, const int64_t* rowptr, 
  * columns are sparse rows that add.  SPARTA_UNION=0 at create time: not built.  SPARTA_SPMM_EXACT is not available on such a handle (as for any handle with sparse rows).
  * A row's nonzeros in columns too thinly used for the list ride in the tile's TAIL (at most SPARTA_UNION_TAIL = 16 per row) and are added in the tile's epilogue; only what
  * exceeds that is left to the sparse-row kernels.
- * info_out (int64[10]): [0] tiles of <= 32 rows [1] tiles of 33..64 rows [2], [3] their 32-deep steps [4] stored elements (tile rows x list entries)
- * [5] list entries [6] nonzeros the tiles hold (lists + tails) [7] persistent workgroups of the launch [8] rows of C the tiles own [9] nonzeros in the tails */
+ * The matrix instruction works on row tiles of 16 rows (fp32 handles: v_mfma_f32_16x16x4_f32) or 32 rows (16-bit handles): a tile of mt rows is multiplied as ceil(mt / 16) resp.
+ * ceil(mt / 32) row tiles.
+ * info_out (int64[12]): [0] tiles of <= 32 rows [1] tiles of 33..64 rows [2], [3] their 32-deep steps [4] stored elements (tile rows x list entries)
+ * [5] list entries [6] nonzeros the tiles hold (lists + tails) [7] persistent workgroups of the launch [8] rows of C the tiles own [9] nonzeros in the tails
+ * [10] elements the kernel multiplies (steps x 32 x the tile's rows rounded up to whole row tiles) [11] rows per row tile (16 or 32; 0: no tiles) */
 int sparta_vbs_union_info(const sparta_vbs_t* A, int64_t* info_out);
 /* HOST-side check of that builder and its device plan for the CPU suite (no GPU; not a product path, and not a fallback: sparta_vbs_spmm never calls it): the hybrid
  * image of the CSR matrix under `grouping` -- w-wide tiles, column-compacted tiles, sparse rows, decided as sparta_vbs_create_from_csr decides them for an fp32 handle --

@@ -22,6 +22,6 @@ ui, sp = d.union_info(), d.sparse_info()
 # algorithmic bytes of the union kernel per launch: the tiles' stored elements (A once) + list entries + tails (8 bytes each) + its rows of C once + B once
 alg = ui["area"] * 4 + ui["list_entries"] * 4 + ui["tail_nnz"] * 8 + ui["rows"] * N * 4 + d.cols * N * 4
 flops_stored = 2.0 * ui["area"] * N
-flops_exec = 2.0 * (ui["steps32"] * 32 + ui["steps64"] * 64) * 32 * N
+flops_exec = 2.0 * ui["exec_area"] * N          # (steps x 32 x the tile's rows rounded up to whole MFMA row tiles)
 print(json.dumps({"matrix": name, "n_cols": N, "reps": reps, "ms_per_product": e0.elapsed_time(e1) / reps, "union_info": ui, "sparse_info": sp, "nnz": int(m.nztot()),
                   "union_kernel_algorithmic_bytes": alg, "union_kernel_flops_on_stored_elements": flops_stored, "union_kernel_flops_executed": flops_exec}))

@@ -874,6 +874,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         CREATE_TRY(hipMemcpy(v->d_u_tail[ty], uplan.tail[ty].data(), uplan.tail[ty].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         v->a_bytes += (int64_t)(a_bytes_ty + uplan.ids[ty].size() * sizeof(int32_t) + uplan.tail[ty].size() * sizeof(uint32_t));
         v->exec_area += uplan.n_steps[ty] * 32 * uplan.type_rows[ty];
+        v->u_exec_area += uplan.n_steps[ty] * 32 * uplan.type_rows[ty];
     }
     if (ext) {
         v->u_area = uplan.area; v->u_cols = uplan.cols; v->u_nnz = ext->uni.nnz; v->u_tail_nnz = ext->uni.tail_nnz; v->u_rows = uplan.rows;
@@ -1150,6 +1151,7 @@ int sparta_vbs_union_info(const sparta_vbs_t* A, int64_t* info) {
     info[4] = A->u_area; info[5] = A->u_cols; info[6] = A->u_nnz; info[7] = 0;
     for (int ty = 0; ty < kUnionTypes; ty++) info[7] = std::max<int64_t>(info[7], A->u_workers[ty]);
     info[8] = A->u_rows; info[9] = A->u_tail_nnz;
+    info[10] = A->u_exec_area; info[11] = A->u_steps_total > 0 ? (A->dtype == SPARTA_F32 ? 16 : 32) : 0;
     return SPARTA_OK;
 }
 

@@ -369,6 +369,7 @@ struct sparta_vbs {
     int64_t u_tiles_h[2] = {0, 0}, u_steps_h[2] = {0, 0}, u_steps_total = 0;   // tiles / steps of tiles of <= 32 / 33..64 rows; all steps
     int64_t u_area = 0, u_cols = 0, u_nnz = 0;      // stored elements (rows x list entries), list entries, nonzeros held (lists + tails)
     int64_t u_tail_nnz = 0, u_rows = 0;             // nonzeros in the tiles' tails; rows of C the tiles own
+    int64_t u_exec_area = 0;                        // elements the kernel multiplies: steps x 32 x rows of the tile's type
     const void* brm_ready = nullptr;       // the row-major B of the product in flight (set by the first launch that needs it, cleared when the product returns)
     int64_t brm_ld = 0;
     void* d_Brm = nullptr;                 // row-major copy of a column-major / gathered B

@@ -132,10 +132,10 @@ class DeviceVBS:
                 "parts": int(a[8]), "ranges": int(a[9]), "small_parts": int(a[10]), "used_small": int(a[11])}
 
     def union_info(self):
-        """the column-compacted ("union-pattern") tiles of an fp32 handle made from a CSR (k_union.hip): see sparta_vbs_union_info"""
-        a = np.zeros(10, np.int64)
+        """the column-compacted ("union-pattern") tiles of a handle made from a CSR (k_union.hip): see sparta_vbs_union_info"""
+        a = np.zeros(12, np.int64)
         check(lib.sparta_vbs_union_info(self.h, a.ctypes.data_as(_i64p)))
-        keys = ["tiles32", "tiles64", "steps32", "steps64", "area", "list_entries", "nnz", "workers", "rows", "tail_nnz"]
+        keys = ["tiles32", "tiles64", "steps32", "steps64", "area", "list_entries", "nnz", "workers", "rows", "tail_nnz", "exec_area", "row_tile"]
         return {k: int(a[i]) for i, k in enumerate(keys)}
 
     def hub_info(self):
