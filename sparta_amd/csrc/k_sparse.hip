@@ -507,7 +507,11 @@ void launch_sparse_t(SparseParams q, unsigned gy, hipStream_t st, const int32_t*
         if (!fused_small && stream_begin)
             hipLaunchKernelGGL((sparse_segments_xcd_kernel<VEC, BK>), dim3((unsigned)(8 * ((max_stream + 3) / 4)), gy), dim3(kThreads), 0, st, q, segs, stream_begin, part);
         else if (!fused_small) hipLaunchKernelGGL((sparse_segments_kernel<VEC, BK>), dim3((unsigned)((n_segs + 3) / 4), gy), dim3(kThreads), 0, st, q, segs, (int32_t)n_segs, part);
-        if (q.out_is_c == 2) hipLaunchKernelGGL((sparse_reduce_cm_kernel<VEC, 16>), dim3((unsigned)((n_long + 15) / 16), gy), dim3(kThreads), 0, st, q, longs, (int32_t)n_long, (const float*)part);
+        // (a few hundred long rows -- the hyper-sparse real inputs -- are a latency chain like their short rows above: one row per wave instead of four one after the other;
+        // social_location, 453 long rows: 9-14 us for this launch with 16 rows per workgroup)
+        if (q.out_is_c == 2 && n_long < 16384)
+            hipLaunchKernelGGL((sparse_reduce_cm_kernel<VEC, 4>), dim3((unsigned)((n_long + 3) / 4), gy), dim3(kThreads), 0, st, q, longs, (int32_t)n_long, (const float*)part);
+        else if (q.out_is_c == 2) hipLaunchKernelGGL((sparse_reduce_cm_kernel<VEC, 16>), dim3((unsigned)((n_long + 15) / 16), gy), dim3(kThreads), 0, st, q, longs, (int32_t)n_long, (const float*)part);
         else hipLaunchKernelGGL(sparse_reduce_kernel<VEC>, dim3((unsigned)((n_long + 3) / 4), gy), dim3(kThreads), 0, st, q, longs, (int32_t)n_long, (const float*)part);
     }
 }
