@@ -8,7 +8,7 @@ import bench_suite as bs
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 N = 128
 for name, kind, make, kw, w in bs.cases(sa):
-    if not (name.startswith("social_location") or name.startswith("ia-wikiquote") or name.startswith("uniform")):
+    if not any(name.startswith(x) for x in os.environ.get("ONLY", "social_location,ia-wikiquote,uniform").split(",")):
         continue
     m = make()
     g = sa.BlockingEngine(col_block_size=w, **kw).GetGrouping(m)
