@@ -225,6 +225,12 @@ struct Ctx : CtxBase {
                                   : intersect_count(pat.blks.data(), (int64_t)pat.blks.size(), rb.row(j), rb.n(j));
         return distance_from_counts(sim, (int64_t)pat.cols.size(), (int64_t)pat.blks.size(), gsize, a.nnz_of(j), rb.n(j), 1, inter);
     }
+    // what dist(gsize, j) is never below, from the SIZES alone: the intersection holds at most the smaller set, and both distances fall as it grows (same formula, same
+    // rounding).  A candidate whose floor is already above tau need not be intersected (blocking_algo 7: most candidates of a power-law matrix collide on a hub block only).
+    inline float dist_floor(int64_t gsize, int64_t j) const {
+        const int64_t na = (int64_t)pat.blks.size(), nb = rb.n(j);
+        return distance_from_counts(sim, (int64_t)pat.cols.size(), na, gsize, a.nnz_of(j), nb, 1, std::min(na, nb));
+    }
 };
 
 // LITERAL policy -- used when some row is NOT strictly ascending.  The reference never sorts or checks
@@ -915,6 +921,7 @@ void minhash_lsh(Ctx& c, int64_t* grouping) {
                 if (members + 1 + (dup_ptr[(size_t)u + 1] - dup_ptr[(size_t)u]) > cap) continue;   // the row and its identical copies would not fit: left to another seed
                 evals++;
                 c.comparisons++;
+                if (c.dist_floor(gsize, j) > tau) { failed++; continue; }      // (hopeless by size: the exact distance is above tau too -- same decisions, no intersection)
                 const float d = c.dist(gsize, j);
                 if (!(d <= tau)) { failed++; continue; }
                 failed = 0;
