@@ -130,6 +130,54 @@ def test_cluster_heights_and_padded_leading_dimensions(rows_per, n_groups):
     d.close()
 
 
+def _clusters_of_heights(heights, cols, shared, own, seed, integer=True):
+    """one cluster per entry of `heights` (rows in cluster order, not scattered): rows of a cluster share `shared` columns (each present with probability 0.8) + `own` of their own"""
+    rng = np.random.default_rng(seed)
+    rr, cc, g, r0 = [], [], [], 0
+    for h in heights:
+        base = rng.choice(cols, shared, replace=False)
+        for k in range(h):
+            c = np.union1d(base[rng.random(shared) < 0.8], rng.choice(cols, own, replace=False))
+            rr.append(np.full(len(c), r0 + k)); cc.append(c)
+        g += [r0] * h
+        r0 += h
+    r, c = np.concatenate(rr), np.concatenate(cc)
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=r0))]).astype(np.int64)
+    v = rng.integers(1, 4, len(c)).astype(np.float32) if integer else rng.uniform(-1, 1, len(c)).astype(np.float32)
+    return sa.CSR(r0, cols, rowptr, c.astype(np.int32), v), np.asarray(g, np.int64)
+
+
+@pytest.mark.parametrize("dtype", [sa.F32, sa.BF16], ids=["f32", "bf16"])
+def test_every_tile_height_in_one_handle(dtype):
+    """tiles of 1..4 MFMA row tiles (fp32: 16-row granularity) in ONE launch: every workgroup walks its tiles type by type, tallest first (k_union.hip: four bodies behind
+    barriers; vbs_union.cpp: one set of workers over all types).  Every element against the oracle's VBR::multiply at block width 1, bit for bit (small integers)."""
+    torch = _torch()
+    heights = [5, 16, 17, 31, 33, 40, 48, 49, 60, 64, 70, 3, 25, 57] * 6                # (70: a part of 64 + a part of 6)
+    m, g = _clusters_of_heights(heights, 5000, 90, 2, seed=13)
+    w_handle = 1 if dtype == sa.F32 else 32
+    d = sa.DeviceVBS.from_csr(m, g, w_handle, device=0, dtype=dtype)
+    ui = d.union_info()
+    assert ui["tiles32"] >= 6 * 6 and ui["tiles64"] >= 7 * 6 and ui["nnz"] > 0.9 * m.nztot(), ui
+    if dtype == sa.F32:
+        # the kernel pays for whole 16-row tiles: 5 -> 16, 17 -> 32, 33 / 40 / 48 -> 48, 49 / 60 / 64 -> 64 rows per step
+        assert ui["row_tile"] == 16 and ui["exec_area"] < 1.45 * ui["area"], ui
+    n = 136
+    B = np.random.default_rng(4).integers(-3, 4, m.cols * n).astype(np.float32)
+    v = oracle.OracleVBR(m.rows, m.cols, m.rowptr, m.colidx, m.vals, g, 1)
+    ref = oracle.vbr_multiply(v.rows, v.cols, 1, v.row_part, v.nzcount, v.jab, v.mab, B, n)
+    if dtype == sa.F32:
+        assert np.array_equal(_product(torch, d, B, n), ref)
+        C0 = np.random.default_rng(1).integers(-3, 4, m.rows * n).astype(np.float32)
+        assert np.array_equal(_product(torch, d, B, n, C0=C0), ref + C0)
+    else:
+        Bt, ldb = _b16(torch, B, dtype, n, m.cols)
+        Ct = torch.full((m.rows * n,), 7.0, device="cuda")
+        d.spmm(Bt, Ct, n, ldb=ldb)
+        torch.cuda.synchronize()
+        assert np.array_equal(Ct.cpu().numpy(), ref)
+    d.close()
+
+
 def test_mixed_image_tiles_union_tiles_and_sparse_rows_in_one_product():
     torch = _torch()
     import scipy.sparse as sp
