@@ -732,7 +732,7 @@ static int create_core(sparta_vbs_t** out, int64_t rows, int64_t cols, int64_t b
         if (!plan_debug) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) n_cus = pr.multiProcessorCount; }
         // (workgroups per CU the kernel is built for: k_union.hip's launch bound and LDS; SPARTA_UNION_WPC: developer A/B)
         const int wpc = [] { const char* e = std::getenv("SPARTA_UNION_WPC"); return e ? std::max(1, atoi(e)) : 3; }();
-        if (int rc = build_union_plan(ext->uni, wpc * n_cus, uplan, dtype)) return rc;
+        if (int rc = build_union_plan(ext->uni, wpc * n_cus, uplan, dtype, n_cus)) return rc;
         trace.lap("column-compacted tiles (plan)");
     }
     std::vector<StepRec>(&steps)[2] = plan.steps;

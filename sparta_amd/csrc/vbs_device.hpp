@@ -473,7 +473,7 @@ struct UnionDevPlan {
     int64_t tiles_by_height[2] = {0, 0}, steps_by_height[2] = {0, 0};   // tiles / steps of tiles of <= 32 rows, of 33..64 rows (what sparta_vbs_union_info reports)
     int64_t area = 0, cols = 0, rows = 0;     // stored elements (tile rows x list entries); list entries; rows of C the tiles own
 };
-int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPlan& P, int dtype = SPARTA_F32);
+int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPlan& P, int dtype = SPARTA_F32, int n_cus = 0);
 // y (+)= the tiles' part of A . x, walked on the HOST from the device form (test aid for the CPU suite: the layout of plan and slices without a GPU)
 void union_plan_host_apply(const UnionDevPlan& P, const float* x, double* y);
 

@@ -139,6 +139,25 @@ def test_stragglers_become_tiles_when_little_else_is_left_for_the_sparse_rows(mo
     assert info["sparse_nnz"] > 0 and np.array_equal(y.astype(np.float32), ref), info
 
 
+def test_tiles_cut_into_row_tile_pieces_give_the_same_product(monkeypatch):
+    # whole tiles quantise the makespan: where a CU (here: a worker) would carry a tile more than the others, a few tiles are cut into pieces of one MFMA row tile (16 rows, same list)
+    # and dealt again (vbs_union.cpp).  SPARTA_UNION_SPLIT=2 cuts whenever a worker is above the mean; =0 never.  Same product either way, bit for bit.
+    m, order = clustered(23, 48, 3000, 90, 3, seed=77, integer=True)
+    g = true_grouping(order, 48)
+    x = np.random.default_rng(5).integers(-3, 4, m.cols).astype(np.float32)
+    ref = np.asarray(reference_product(m, g, 1, x)).reshape(-1)
+    monkeypatch.setenv("SPARTA_UNION_SPLIT", "0")
+    y0, whole = walk(m, g, 1, x, workers=5)
+    monkeypatch.setenv("SPARTA_UNION_SPLIT", "2")
+    y2, cut = walk(m, g, 1, x, workers=5)
+    assert whole["tiles64"] == cut["tiles64"] == 23 and cut["steps64"] > whole["steps64"] and cut["list_entries"] > whole["list_entries"], (whole, cut)
+    assert cut["tile_rows"] == whole["tile_rows"] == m.rows and cut["area"] == whole["area"]
+    assert np.array_equal(y0.astype(np.float32), ref) and np.array_equal(y2.astype(np.float32), ref)
+    monkeypatch.delenv("SPARTA_UNION_SPLIT")                              # the default: only where the makespan falls by more than 1.5 %
+    y1, info = walk(m, g, 1, x, workers=5)
+    assert np.array_equal(y1.astype(np.float32), ref) and whole["steps64"] <= info["steps64"] <= cut["steps64"]
+
+
 def test_tiles_follow_the_parts_rules():
     # 70-row clusters: one part of 64 rows (a 33..64-row tile) + one of 6 (a <= 32-row tile)
     m, order = clustered(8, 70, 2000, 60, 2, seed=5, scatter=False)
