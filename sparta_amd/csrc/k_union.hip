@@ -47,6 +47,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #ifndef SPARTA_UNION_STATS
 #define SPARTA_UNION_STATS 0      /* lab build: per-wave cycle sums written over the head of C (scripts/lab/r5_union_stats.py) */
 #endif
+// Two LDS stages (one step of loads in flight across the barrier) and THREE workgroups per CU.  Measured on 2000 clusters x 48 rows (N = 128, prepared B; profiles/r5/lab_union_stages.txt,
+// lab_union_16.txt): three workgroups x two stages 113 us, two x three 128, two x two 124, one x six 202 -- and a launch of at most one workgroup per CU (200 tiles) runs its ten steps in
+// 23 us with two stages, 31 with six: a step is not waiting for its loads, so more of them in flight buy nothing, and another co-resident workgroup does.
 constexpr int kUnionStages = 2;
 constexpr int kUnionLds = kUnionStages * (4 * 2048 + 32 * 512);      // the tallest type's stages
 
@@ -57,6 +60,7 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
     constexpr int A_BYTES = RT * 2048, B_BYTES = 32 * 512, STAGE = A_BYTES + B_BYTES;
     constexpr int NPA = 2 * RT;                          // 1 KB pieces of the slice of A per step, dealt to the waves round robin
     constexpr int AHEAD = NS - 1;                        // steps between a step's loads and its MFMAs
+    constexpr bool TAILPIPE = SPARTA_UNION_TAILPIPE != 0;
     static_assert(NS * STAGE <= kUnionLds, "LDS");
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -163,8 +167,7 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
     const uint32_t rstep = p.c_row_major ? (uint32_t)p.ldc * 64u : 64u;          // bytes per 16 rows
     const int ncw = ncv - 32 * wave;                                             // columns of this wave that exist
 
-#if SPARTA_UNION_TAILPIPE
-    // tails in the pipeline: the tile's step t requests, per lane, the pieces of B of tail entry t (2 x 16 bytes of ITS row's column) and the (column, value) pair of
+    // tails in the pipeline (two-stage form): the tile's step t requests, per lane, the pieces of B of tail entry t (2 x 16 bytes of ITS row's column) and the (column, value) pair of
     // entry t + 1 -- ahead of the step's panel loads, so they do not queue behind them; step t + 1 multiplies entry t in before its MFMAs (the step's top wait covers
     // them).  A round trip per entry then hides behind a step instead of standing between the tile's last MFMA and its stores; what the steps cannot carry (entries
     // S - 1 .. of a tile of S steps) is added in the epilogue.
@@ -180,11 +183,10 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
         for (int ct = 0; ct < 2; ct++) tb[rt][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     const float* const brow_t = p.B + n0 + 32 * wave + 4 * kq;
-    if (!(probe & 8) && !(iq[0] & UREC_LAST) && ((iq[0] >> UREC_TAIL_SHIFT) & 31) > 0) {
+    if (TAILPIPE && !(probe & 8) && !(iq[0] & UREC_LAST) && ((iq[0] >> UREC_TAIL_SHIFT) & 31) > 0) {
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) cvn[rt] = sd.tail[tq[0] + rt * 16 + li];
     }
-#endif
 #if SPARTA_UNION_STATS
     // lab build only (results WRONG: the sums overwrite the head of C): cycles this wave spent waiting for its loads / at the barrier / in the multiply phase / in epilogues
     uint64_t st_wait = 0, st_bar = 0, st_mul = 0, st_epi = 0;
@@ -202,13 +204,19 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
         // (2) everybody's have, and everybody is done with the stage of step i - 1
         __builtin_amdgcn_s_barrier();
         UNION_STAMP(st2);
-        // (3) the record of step i + 1 (its loads go into the stage step i - 1 has left); the record of step i + 2 is requested for the next iteration
+        // (3) the record of step i + AHEAD (its loads go into the stage step i - 1 has left); the record of the step behind it is requested further down, for the next iteration
         const Rec rec = nxt;
-        nxt = load_rec(i + AHEAD + 1);
         const int jstage = stage ^ 1;
         iq[AHEAD] = rec.info; cq[AHEAD] = rec.c_row; tq[AHEAD] = rec.tail_off;
-#if SPARTA_UNION_TAILPIPE
-        {
+        if constexpr (TAILPIPE) {
+            // (the compiler counts vmcnt for the loads it emitted and does not see the wait above: without telling it that these registers have landed it waits for them
+            // in the MIDDLE of the requests below -- with loads under branches in between it cannot count, so it drains: a round trip per step, exposed)
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                asm volatile("" : : "v"(cvn[rt].x), "v"(cvn[rt].y));        // (a USE, not a redefinition: loop-carried registers that an asm redefines get copied at the back edge -- behind a wait)
+#pragma unroll
+                for (int ct = 0; ct < 2; ct++) asm volatile("" : : "v"(tb[rt][ct]));
+            }
             const int32_t inf = iq[0];
             if (tb_live) {                                 // the entry the previous step requested
 #pragma unroll
@@ -234,7 +242,6 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
                 for (int rt = 0; rt < RT; rt++) cvn[rt] = sd.tail[rec.tail_off + (tn * RT + rt) * 16 + li];
             }
         }
-#endif
         // (4) multiply step i: the fragments first (the LDS reads of the whole step), then 16 RT matrix instructions with the loads of step i + 1 issued between them
         {
             const char* const sa = lds0 + stage * STAGE;
@@ -249,6 +256,17 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
             for (int s = 0; s < 8; s++)
 #pragma unroll
                 for (int ct = 0; ct < 2; ct++) bq[s][ct] = *reinterpret_cast<const float*>(sb + rdB[ct] + s * 2048);
+            // every fragment has landed before the first MFMA, and the compiler is told so: the scalar loads of the next record go out right behind, and a later partial
+            // wait for a fragment (lgkmcnt counts LDS reads and scalar loads alike; with a scalar load outstanding every wait is a wait for all) would stand through them
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) asm volatile("" : : "v"(af[rt][h]));
+#pragma unroll
+            for (int s = 0; s < 8; s++)
+#pragma unroll
+                for (int ct = 0; ct < 2; ct++) asm volatile("" : : "v"(bq[s][ct]));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 8; s++) {
@@ -257,7 +275,9 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[s][ct], af[rt][s >> 2][s & 3], acc[rt][ct], 0, 0, 0);
                     const int slot = 2 * s + ct;
-                    if (slot == 0) issue_a(i + AHEAD, jstage);
+                    // the next record's scalar loads go out BEHIND the wait for this step's fragments: lgkmcnt counts LDS reads and scalar loads alike, and a wait with a scalar
+                    // load outstanding is a wait for everything -- requested ahead of the fragment reads, every step stood through a scalar-cache miss
+                    if (slot == 0) { nxt = load_rec(i + AHEAD + 1); issue_a(i + AHEAD, jstage); }
                     if (slot == 2 || slot == 5 || slot == 8 || slot == 11) issue_b(rec, jstage, (slot - 2) / 3);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -276,11 +296,7 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
                 // two entries at a time: their (column, value) pairs in one round trip, their 2 x RT x 2 pieces of B in a second one (an entry at a time is two round
                 // trips per entry with the matrix pipe idle; more at a time -- or two for the tallest type -- costs the third workgroup per CU its registers)
                 constexpr int CH = RT == 4 ? 1 : 2;
-#if SPARTA_UNION_TAILPIPE
-                const int e_first = tstep < tail_e ? tstep : tail_e;          // entries 0 .. S - 2 rode in the steps
-#else
-                const int e_first = 0;
-#endif
+                const int e_first = TAILPIPE ? (tstep < tail_e ? tstep : tail_e) : 0;          // entries 0 .. S - 2 rode in the steps
                 for (int e0 = e_first; e0 < tail_e; e0 += CH) {
                     uint2 cv[CH][RT];
 #pragma unroll
@@ -349,9 +365,7 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
 #pragma unroll
         for (int k = 0; k < AHEAD; k++) { iq[k] = iq[k + 1]; cq[k] = cq[k + 1]; tq[k] = tq[k + 1]; }
         stage ^= 1;
-#if SPARTA_UNION_TAILPIPE
-        tstep = (info & UREC_LAST) ? 0 : tstep + 1;
-#endif
+        if constexpr (TAILPIPE) tstep = (info & UREC_LAST) ? 0 : tstep + 1;
 #if SPARTA_UNION_STATS
         const uint64_t st4 = __builtin_readcyclecounter();
         st_wait += st1 - st0; st_bar += st2 - st1; st_mul += st3 - st2; st_epi += st4 - st3;
@@ -521,25 +535,40 @@ __device__ __forceinline__ void union16_body(const UnionParams& p, const UnionSi
         asm volatile("s_waitcnt vmcnt(%0)" : : "n"((AHEAD - 1) * LPS) : "memory");
         __builtin_amdgcn_s_barrier();
         const Rec rec = nxt;
-        nxt = load_rec(i + AHEAD + 1);
         int jstage = stage + AHEAD; if (jstage >= NS) jstage -= NS;
         iq[AHEAD] = rec.info; cq[AHEAD] = rec.c_row; tq[AHEAD] = rec.tail_off;
-        issue(rec, i + AHEAD, jstage);
-        if (!(probe & 4)) {
+        // the step's fragments first, and all of them landed (lgkmcnt counts LDS reads and scalar loads alike: with the next record's scalar loads outstanding, the wait for a
+        // fragment would be a wait for them too -- a scalar-cache miss per step); then the next record's scalar loads, this step's requests, and the MFMAs
+        s16x8 bf[2], af[MI][2];
+        {
             const char* const sa = lds0 + stage * STAGE;
             typedef __attribute__((address_space(3))) s16x4* tr_ptr_t;
 #pragma unroll
             for (int m = 0; m < 2; m++) {
                 const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(lds_ptr_t)(sa + A_BYTES + rdB[m][0]));
                 const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(lds_ptr_t)(sa + A_BYTES + rdB[m][1]));
-                const s16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bf[m] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int rt = 0; rt < MI; rt++) af[rt][m] = *reinterpret_cast<const s16x8*>(sa + (rt * 2 + m) * 1024 + lane * 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                asm volatile("" : : "v"(bf[m]));
+#pragma unroll
+                for (int rt = 0; rt < MI; rt++) asm volatile("" : : "v"(af[rt][m]));
+            }
+        }
+        nxt = load_rec(i + AHEAD + 1);
+        issue(rec, i + AHEAD, jstage);
+        if (!(probe & 4)) {
+#pragma unroll
+            for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int rt = 0; rt < MI; rt++) {
-                    const s16x8 af = *reinterpret_cast<const s16x8*>(sa + (rt * 2 + m) * 1024 + lane * 16);
-                    if constexpr (BF16) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bf), __builtin_bit_cast(bf16x8_t, af), acc[rt], 0, 0, 0);
-                    else acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, bf), __builtin_bit_cast(f16x8_t, af), acc[rt], 0, 0, 0);
+                    if constexpr (BF16) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bf[m]), __builtin_bit_cast(bf16x8_t, af[rt][m]), acc[rt], 0, 0, 0);
+                    else acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, bf[m]), __builtin_bit_cast(f16x8_t, af[rt][m]), acc[rt], 0, 0, 0);
                 }
-            }
         }
         const int32_t info = iq[0];
         if ((info & UREC_LAST) && !(probe & 16)) {
