@@ -8,10 +8,12 @@ import sparta_amd as sa
 import bench_suite as bs
 N = 128
 cols = int(os.environ.get("COLS", "60000"))
-m = bs._clustered(sa, 2000, 48, cols, 300, 6, 5)
-rng = np.random.Generator(np.random.PCG64(5)); order = rng.permutation(2000 * 48)
+NCL = int(os.environ.get("NCL", "2000"))
+os.environ.setdefault("SPARTA_SPARSE_MIN_STEPS", "0"); os.environ.setdefault("SPARTA_LAUNCH_NNZ", "0")
+m = bs._clustered(sa, NCL, 48, cols, 300, 6, 5)
+rng = np.random.Generator(np.random.PCG64(5)); order = rng.permutation(NCL * 48)
 g = np.empty(m.rows, np.int64)
-for gi in range(2000):
+for gi in range(NCL):
     rows = order[gi * 48:(gi + 1) * 48]; g[rows] = rows.min()
 d = sa.DeviceVBS.from_csr(m, g, 32, device=0)
 B = torch.rand(d.cols * N, device="cuda") - 0.5

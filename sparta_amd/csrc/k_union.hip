@@ -16,11 +16,11 @@
 //   * the slice of A (16 RT rows x 32 k) is stored in HBM as the LDS image [rt][h][lane][4], lane = 16 kq + i: A[16 rt + i][k = 4 (4 h + e) + kq] -- the values of four
 //     consecutive instructions (k-groups 4 h .. 4 h + 3) in one conflict-free ds_read_b128 per lane;
 //   * the panel of B is 32 rows of 512 bytes, LDS image Bs[k][128]: wave v fetches rows 8 v .. 8 v + 7, each through its OWN buffer descriptor (a 64-bit scalar base:
-//     row id x ldb -- B may be larger than the 4 GB a 32-bit offset spans), two rows per 1 KB piece: lanes 0..31 the even row, lanes 32..63 the odd one (the LDS-direct
-//     load writes lane l at base + 16 l whatever the exec mask).  An instruction reads, per lane, Bs[4 s + kq][32 v + 16 ct + i]: four rows x 64 bytes, which would sit on
+//     row id x ldb -- B may be larger than the 4 GB a 32-bit offset spans), two rows per 1 KB piece: lanes 0..31 the even row, lanes 32..63 the odd one (ONE LDS-direct
+//     load per piece, per-lane source addresses; it writes lane l at base + 16 l).  An instruction reads, per lane, Bs[4 s + kq][32 v + 16 ct + i]: four rows x 64 bytes, which would sit on
 //     the same 16 banks -- so row k is stored with its 16-byte chunks permuted, chunk c at position c ^ (4 (k & 3)) (the swizzle is on the SOURCE side: a lane fetches the
 //     chunk that belongs at its position), and the four rows cover all 64 banks;
-//   * list positions behind the tile's last column get a descriptor of zero records: zeros in LDS without a memory access (no 0 x inf from a padding row).
+//   * list positions behind the tile's last column name the tile's first column: a valid row of B against zeros of A (nothing a dense tile does not do anyway).
 // One barrier per step, two LDS stages: wait for this wave's loads of step i, barrier, multiply step i with the loads of step i + 1 issued BETWEEN its MFMAs (descriptor
 // arithmetic and load issue ride in the shadow of the wave's own matrix instructions).  Measured (profiles/r5/lab_union_stats.txt): waves neither wait for loads nor at
 // the barrier -- with three workgroups per CU the multiply phase of a step takes three times its MFMA time: the matrix pipe is the bound, which is why the row
@@ -112,33 +112,21 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
             if (q < NPA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(stp + q * 1024), 16, voffA, (uint32_t)(q * 1024), 0, 0);
         }
     };
-    // lanes 0..31 fetch the even row of a 1 KB piece, lanes 32..63 the odd one: two loads per piece under half an exec mask each, every row through its own
-    // descriptor.  Inline assembly: written as `if (lane < 32) load(even) else load(odd)` the compiler merges the two loads into ONE with a per-lane descriptor and
-    // wraps it in a waterfall loop (readfirstlane / compare / saveexec per distinct descriptor).  EXEC is all ones here (uniform control flow); M0 = the piece's LDS
-    // address (one wait state before the load that uses it), handed back as found (it is the compiler's for its own LDS-direct loads).
+    // lanes 0..31 fetch the even row of a 1 KB piece, lanes 32..63 the odd one -- ONE LDS-direct load per piece with a per-lane source address (global_load_lds_dwordx4:
+    // the row's base is a 64-bit scalar, row id x ldb; the lane picks its half's base and adds its chunk).  An LDS-direct load costs the issuing wave 100-185 cycles
+    // beside MFMAs and LDS reads (MI355X_MICROARCH.md, cycle constants) and the wave's MFMAs queue behind it: the earlier form -- two loads per piece under half an exec
+    // mask each, every row through its own buffer descriptor -- spent more of a step issuing its eight loads than multiplying (profiles/r5/lab_union_stages.txt).
+    // List positions behind the tile's last column name the tile's FIRST column (vbs_union.cpp): a valid row of B against zeros of A.
+    const bool full_rows = row_bytes == 512u;                    // (the last slab of a ragged N: lanes behind the row's last chunk load nothing)
+    typedef const __attribute__((address_space(1))) void* gsrc_t;
     auto issue_b = [&](const Rec& rec, int stage, int r2) __attribute__((always_inline)) {
         if (probe & 1) return;
         char* const stp = lds0 + stage * STAGE;
-        const int nvalid = (rec.info >> 8) & 63;
-        auto row_desc = [&](int r) __attribute__((always_inline)) -> u32x4 {
-            const uint64_t addr = (uint64_t)(Bs0 + (int64_t)rec.id[r] * p.ldb);
-            return u32x4{(uint32_t)addr, (uint32_t)(addr >> 32) & 0xffffu, 8 * wave + r < nvalid ? row_bytes : 0u, 0x00020000u};
-        };
-        const u32x4 dE = row_desc(2 * r2), dO = row_desc(2 * r2 + 1);
-        const uint32_t m0v = (uint32_t)(uintptr_t)(lds_ptr_t)(stp + A_BYTES + (4 * wave + r2) * 1024);
-        uint32_t m0_keep;
-        asm volatile("s_mov_b32 %0, m0\n\t"
-                     "s_mov_b32 m0, %3\n\t"
-                     "s_mov_b32 exec_hi, 0\n\t"
-                     "s_nop 0\n\t"
-                     "buffer_load_dwordx4 %4, %1, 0 offen lds\n\t"
-                     "s_mov_b32 exec_hi, -1\n\t"
-                     "s_mov_b32 exec_lo, 0\n\t"
-                     "s_nop 0\n\t"
-                     "buffer_load_dwordx4 %4, %2, 0 offen lds\n\t"
-                     "s_mov_b32 exec_lo, -1\n\t"
-                     "s_mov_b32 m0, %0"
-                     : "=&s"(m0_keep) : "s"(dE), "s"(dO), "s"(m0v), "v"(voffB[r2 & 1]) : "memory");
+        const char* const be = reinterpret_cast<const char*>(Bs0 + (int64_t)rec.id[2 * r2] * p.ldb);
+        const char* const bo = reinterpret_cast<const char*>(Bs0 + (int64_t)rec.id[2 * r2 + 1] * p.ldb);
+        const char* const src = (lane < 32 ? be : bo) + voffB[r2 & 1];
+        const lds_ptr_t dst = (lds_ptr_t)(stp + A_BYTES + (4 * wave + r2) * 1024);
+        if (full_rows || voffB[r2 & 1] < row_bytes) __builtin_amdgcn_global_load_lds((gsrc_t)src, dst, 16, 0, 0);
     };
 
     f32x4 acc[RT][2];

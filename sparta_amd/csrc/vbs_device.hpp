@@ -212,7 +212,7 @@ constexpr int kUnionPadSteps = 4;                        // records / list entri
 constexpr int kUnionTypes = 4;    // tile types of one handle.  fp32: type t = tiles of 16 t + 1 .. 16 (t + 1) rows (t + 1 MFMA row tiles of 16); 16-bit: types 0, 1 = tiles of <= 32 / 33..64 rows
 struct UnionSide {                // one tile type
     const UnionRec* rec;          // per step, in execution order (worker after worker)
-    const int32_t* ids;           // [step][32]: the rows of B (= columns of A) of the step's list positions; 0 behind the valid ones (never fetched)
+    const int32_t* ids;           // [step][32]: the rows of B (= columns of A) of the step's list positions; behind the valid ones the tile's first column (fetched: A holds zeros there)
     const void* A;                // the steps' slices as the LDS image the kernel wants.  fp32, type t (R = 16 (t + 1) rows): [step][rt][h][lane][4] floats, lane = 16 kq + i:
                                   // A[16 rt + i][k = 4 (4 h + e) + kq] (one ds_read_b128 per lane = the row's values of four consecutive 16x16x4 MFMAs);
                                   // 16-bit, type t (32 (t + 1) rows): [step][rt][m][kg][row][8] = A[32 rt + row][k = 16 m + 8 kg + e]

@@ -164,7 +164,7 @@ int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPl
                     for (int64_t q = 0; q < ns; q++, s++) {
                         const int nvalid = (int)std::min<int64_t>(32, std::max<int64_t>(0, (int64_t)tl.nk - 32 * q));
                         P.rec[ty][(size_t)s] = UnionRec{tl.c_row + ref.row0, ref.nrows | (nvalid << 8) | (q == ns - 1 ? UREC_LAST : 0) | (tl.tail_e << UREC_TAIL_SHIFT), (int32_t)to, 0};
-                        for (int k = 0; k < nvalid; k++) P.ids[ty][(size_t)s * 32 + (size_t)k] = cl[32 * q + k];
+                        for (int k = 0; k < 32; k++) P.ids[ty][(size_t)s * 32 + (size_t)k] = k < nvalid ? cl[32 * q + k] : (tl.nk > 0 ? cl[0] : 0);   // (behind the list: its first column -- fetched, against zeros of A)
                         if (h16) {
                             uint16_t* d16 = P.a16[ty].data() + (size_t)s * slice;
                             for (int rt = 0; rt < nrt; rt++)
