@@ -372,7 +372,7 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
 // =====================================================================================================================================================================
 // 16-bit handles (fp16 / bf16 storage of A and B, fp32 accumulation and C): the same tiles, the same pipeline, the 16-bit matrix instruction.
 //   * the panel of B is 32 rows of 256 bytes (128 columns x 2 bytes) of the ROW-major 16-bit copy of B, LDS image Bs[k][128]; wave v fetches rows 8 v .. 8 v + 7, four rows per
-//     1 KB piece: lanes 16 r' .. 16 r' + 15 the piece's row r' (quarter exec masks, every row through its own descriptor);
+//     1 KB piece: lanes 16 r' .. 16 r' + 15 the piece's row r' (ONE LDS-direct load per piece, per-lane source addresses);
 //   * `v_mfma_f32_32x32x16_{f16,bf16}` wants, per lane, 8 consecutive k of ITS column of the panel -- a column of a k-major image.  gfx950's `ds_read_b64_tr_b16` is that transpose:
 //     per group of 16 lanes it reads a block of 4 rows x 16 columns and hands lane i column i of the 4 rows (lane 4 q + p supplies the address of row q, columns 4 p .. 4 p + 3);
 //     two such reads per MFMA and lane.  Bank-conflict-free with 16-byte chunk ch of row r stored at position ch ^ (((r & 3) << 2) | ((r >> 2) & 3)) (cdna_hip_programming.md
@@ -398,7 +398,7 @@ template <int MI, bool BF16>
 __device__ __forceinline__ void union16_body(const UnionParams& p, const UnionSide& sd, const int worker, char* const lds) {
     constexpr int NS = kUnion16Stages;
     constexpr int A_BYTES = 4096, B_BYTES = 32 * 256, STAGE = A_BYTES + B_BYTES;
-    constexpr int LPS = 8 + 1;                           // vector-memory instructions per wave and step: its eight rows of B, one piece of A (waves behind the slice's pieces: zeros)
+    constexpr int LPS = 2 + 1;                           // vector-memory instructions per wave and step: its two pieces of B (four rows each), one piece of A (waves behind the slice's pieces: zeros)
     constexpr int AHEAD = NS - 1;
     static_assert((AHEAD - 1) * LPS <= 63, "vmcnt holds 6 bits");
 
@@ -428,10 +428,10 @@ __device__ __forceinline__ void union16_body(const UnionParams& p, const UnionSi
     const uint16_t* const B16 = reinterpret_cast<const uint16_t*>(p.B);
     const uint16_t* const Bs0 = B16 + n0;
     const uint16_t* const A0 = reinterpret_cast<const uint16_t*>(sd.A) + (int64_t)s_begin * (MI * 1024);
-    // B loads: row r of this wave's eight is panel row k = 8 wave + r; lane l of its 16 fetches source chunk l ^ s(k)
-    uint32_t voffB[8];
+    // B loads: piece pc of this wave's two holds the panel rows k = 8 wave + 4 pc + q, q = lane >> 4; lane l of a row's 16 fetches source chunk l ^ s(k)
+    uint32_t voffB[2];
 #pragma unroll
-    for (int r = 0; r < 8; r++) { const int k = 8 * wave + r; voffB[r] = (uint32_t)((((lane & 15) ^ (((k & 3) << 2) | ((k >> 2) & 3)))) * 16); }
+    for (int pc = 0; pc < 2; pc++) { const int k = 8 * wave + 4 * pc + (lane >> 4); voffB[pc] = (uint32_t)((((lane & 15) ^ (((k & 3) << 2) | ((k >> 2) & 3)))) * 16); }
     const uint32_t voffA = (uint32_t)lane * 16u;
     // transposed fragment reads: MFMA m (k = 16 m ..), half h (rows + 4 h): the block of rows r0 = 16 m + 8 g + 4 h .. + 3, columns 32 wave + 16 gq .. + 15 (chunks c0, c0 + 1);
     // lane 4 q + pp of the group: row r0 + q, chunk c0 + (pp >> 1), + 8 (pp & 1) bytes
@@ -450,44 +450,26 @@ __device__ __forceinline__ void union16_body(const UnionParams& p, const UnionSi
 
     auto issue = [&](const Rec& rec, int j, int stage) __attribute__((always_inline)) {
         char* const stp = lds0 + stage * STAGE;
-        const int nvalid = (rec.info >> 8) & 63;
         if (!(probe & 2)) {
             // piece `wave` of the slice (MI x 2 pieces of 1 KB; behind them: past the descriptor's end -- zeros in LDS, no access; the A area holds four pieces whatever MI)
             const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A0 + (int64_t)j * (MI * 1024)), 0, MI * 2048, 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(stp + wave * 1024), 16, voffA, (uint32_t)(wave * 1024), 0, 0);
         }
         if (!(probe & 1)) {
-            auto row_desc = [&](int r) __attribute__((always_inline)) -> u32x4 {
-                const uint64_t addr = (uint64_t)(Bs0 + (int64_t)rec.id[r] * p.ldb);
-                return u32x4{(uint32_t)addr, (uint32_t)(addr >> 32) & 0xffffu, 8 * wave + r < nvalid ? row_bytes : 0u, 0x00020000u};
-            };
+            // two pieces of four rows, ONE LDS-direct load each: lanes [16 q, 16 q + 16) fetch the piece's row q through a per-lane source address (the row's base is a 64-bit
+            // scalar, row id x ldb; the lane picks its row's).  An LDS-direct load costs the issuing wave 100-185 cycles: four quarter-wave descriptor loads per piece spent
+            // more of a step issuing loads than anything else.  List positions behind the tile's last column name its first column (vbs_union.cpp).
+            typedef const __attribute__((address_space(1))) void* gsrc_t;
+            const int q = lane >> 4;
 #pragma unroll
-            for (int pc = 0; pc < 2; pc++) {             // two pieces of four rows; lanes [16 r', 16 r' + 16) fetch the piece's row r' (EXEC all ones on entry and on exit)
-                const u32x4 d0 = row_desc(4 * pc), d1 = row_desc(4 * pc + 1), d2 = row_desc(4 * pc + 2), d3 = row_desc(4 * pc + 3);
-                const uint32_t m0v = (uint32_t)(uintptr_t)(lds_ptr_t)(stp + A_BYTES + (2 * wave + pc) * 1024);
-                uint32_t m0_keep;
-                asm volatile("s_mov_b32 %0, m0\n\t"
-                             "s_mov_b32 m0, %5\n\t"
-                             "s_mov_b32 exec_hi, 0\n\t"
-                             "s_mov_b32 exec_lo, 0xffff\n\t"
-                             "s_nop 0\n\t"
-                             "buffer_load_dwordx4 %6, %1, 0 offen lds\n\t"
-                             "s_mov_b32 exec_lo, 0xffff0000\n\t"
-                             "s_nop 0\n\t"
-                             "buffer_load_dwordx4 %7, %2, 0 offen lds\n\t"
-                             "s_mov_b32 exec_lo, 0\n\t"
-                             "s_mov_b32 exec_hi, 0xffff\n\t"
-                             "s_nop 0\n\t"
-                             "buffer_load_dwordx4 %8, %3, 0 offen lds\n\t"
-                             "s_mov_b32 exec_hi, 0xffff0000\n\t"
-                             "s_nop 0\n\t"
-                             "buffer_load_dwordx4 %9, %4, 0 offen lds\n\t"
-                             "s_mov_b32 exec_lo, -1\n\t"
-                             "s_mov_b32 exec_hi, -1\n\t"
-                             "s_mov_b32 m0, %0"
-                             : "=&s"(m0_keep)
-                             : "s"(d0), "s"(d1), "s"(d2), "s"(d3), "s"(m0v), "v"(voffB[4 * pc]), "v"(voffB[4 * pc + 1]), "v"(voffB[4 * pc + 2]), "v"(voffB[4 * pc + 3])
-                             : "memory");
+            for (int pc = 0; pc < 2; pc++) {
+                const char* b0 = reinterpret_cast<const char*>(Bs0 + (int64_t)rec.id[4 * pc] * p.ldb);
+                const char* b1 = reinterpret_cast<const char*>(Bs0 + (int64_t)rec.id[4 * pc + 1] * p.ldb);
+                const char* b2 = reinterpret_cast<const char*>(Bs0 + (int64_t)rec.id[4 * pc + 2] * p.ldb);
+                const char* b3 = reinterpret_cast<const char*>(Bs0 + (int64_t)rec.id[4 * pc + 3] * p.ldb);
+                const char* const src = (q == 0 ? b0 : (q == 1 ? b1 : (q == 2 ? b2 : b3))) + voffB[pc];
+                const lds_ptr_t dst = (lds_ptr_t)(stp + A_BYTES + (2 * wave + pc) * 1024);
+                if (row_bytes == 256u || voffB[pc] < row_bytes) __builtin_amdgcn_global_load_lds((gsrc_t)src, dst, 16, 0, 0);
             }
         }
     };
