@@ -146,8 +146,7 @@ def test_resident_column_kernels_keep_their_sums_in_registers(tmp_path):
 
 def test_column_compacted_tile_kernel_fits_three_workgroups_per_cu(tmp_path):
     """k_union.hip: three workgroups per CU is the point of its two-stage pipeline (profiles/r5/lab_union_stages.txt): 48 KB of LDS (two stages of the tallest tile type: 8 KB of A +
-    16 KB of B), at most 168 registers (three waves per SIMD), nothing in scratch; its panel loads are the hand-written half-wave LDS-direct loads -- no waterfall loop
-    (`v_readfirstlane` + `s_and_saveexec` around a load with a per-lane descriptor) in the step; and the matrix instruction is the 16-row one (16 RT per step of the body of
+    16 KB of B), at most 168 registers (three waves per SIMD), nothing in scratch; its panel loads are one LDS-direct load per 1 KB piece; and the matrix instruction is the 16-row one (16 RT per step of the body of
     RT row tiles, RT = 1..4: a 48-row cluster pays for three row tiles, not four)."""
     kernels = _kernel_metadata(tmp_path)
     un = {n: m for n, m in kernels.items() if "vbs_union_f32_kernel" in n}
@@ -159,7 +158,10 @@ def test_column_compacted_tile_kernel_fits_three_workgroups_per_cu(tmp_path):
     txt = [t for n, t in _disassemble(tmp_path).items() if "vbs_union_f32_kernel" in n]
     assert len(txt) == 1
     ins = [l.split("//")[0].strip() for l in txt[0].splitlines() if l.startswith(("\t", " "))]
-    lds_loads = [i for i in ins if i.startswith("buffer_load_dwordx4") and i.endswith("lds")]
-    assert len(lds_loads) >= 4 * (8 + 1) and not any(i.startswith("scratch_") for i in ins), len(lds_loads)
+    # per step and body: the wave's pieces of the slice of A (buffer loads) and its four 1 KB pieces of the panel of B -- ONE LDS-direct load each, per-lane source addresses
+    # (global_load_lds_dwordx4), not one per row under half an exec mask: an LDS-direct load costs its wave 100-185 cycles of issue
+    a_loads = [i for i in ins if i.startswith("buffer_load_dwordx4") and i.endswith("lds")]
+    b_loads = [i for i in ins if i.startswith("global_load_lds_dwordx4")]
+    assert len(a_loads) >= 4 and len(b_loads) == 4 * 4 * 2 and not any(i.startswith("scratch_") for i in ins), (len(a_loads), len(b_loads))   # (four bodies x four pieces, prologue + loop)
     assert sum(i.startswith("v_mfma_f32_16x16x4") for i in ins) == 16 * (1 + 2 + 3 + 4)          # the four tile types' step bodies
     assert not any(i.startswith("v_mfma_f32_32x32x2") for i in ins)
