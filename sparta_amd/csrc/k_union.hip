@@ -15,19 +15,20 @@
 // loads (no staging registers), 1 KB per wave instruction:
 //   * the slice of A (16 RT rows x 32 k) is stored in HBM as the LDS image [rt][h][lane][4], lane = 16 kq + i: A[16 rt + i][k = 4 (4 h + e) + kq] -- the values of four
 //     consecutive instructions (k-groups 4 h .. 4 h + 3) in one conflict-free ds_read_b128 per lane;
-//   * the panel of B is 32 rows of 512 bytes, LDS image Bs[k][128]: wave v fetches rows 8 v .. 8 v + 7, each through its OWN buffer descriptor (a 64-bit scalar base:
+//   * the panel of B is 32 rows of 512 bytes, LDS image Bs[k][128]: wave v fetches rows 8 v .. 8 v + 7 (a row's base is a 64-bit scalar:
 //     row id x ldb -- B may be larger than the 4 GB a 32-bit offset spans), two rows per 1 KB piece: lanes 0..31 the even row, lanes 32..63 the odd one (ONE LDS-direct
 //     load per piece, per-lane source addresses; it writes lane l at base + 16 l).  An instruction reads, per lane, Bs[4 s + kq][32 v + 16 ct + i]: four rows x 64 bytes, which would sit on
 //     the same 16 banks -- so row k is stored with its 16-byte chunks permuted, chunk c at position c ^ (4 (k & 3)) (the swizzle is on the SOURCE side: a lane fetches the
 //     chunk that belongs at its position), and the four rows cover all 64 banks;
 //   * list positions behind the tile's last column name the tile's first column: a valid row of B against zeros of A (nothing a dense tile does not do anyway).
-// One barrier per step, two LDS stages: wait for this wave's loads of step i, barrier, multiply step i with the loads of step i + 1 issued BETWEEN its MFMAs (descriptor
-// arithmetic and load issue ride in the shadow of the wave's own matrix instructions).  Measured (profiles/r5/lab_union_stats.txt): waves neither wait for loads nor at
-// the barrier -- with three workgroups per CU the multiply phase of a step takes three times its MFMA time: the matrix pipe is the bound, which is why the row
-// granularity matters.  A worker walks WHOLE tiles (vbs_union.cpp deals them longest first).  A tile's last step first adds its TAIL -- up to 16 nonzeros per row in
+// One barrier per step, two LDS stages: wait for this wave's loads of step i, barrier, the step's fragments out of LDS, then its MFMAs with the loads of step i + 1 issued
+// BETWEEN them (address arithmetic and load issue ride in the shadow of the wave's own matrix instructions).  Measured (profiles/r5/lab_union_stats.txt, lab_union_stages.txt):
+// waves neither wait for their loads nor at the barrier -- a step costs its wave the ISSUE of its loads (an LDS-direct load: 100-185 cycles) plus its MFMAs, one after the
+// other in the wave's in-order stream; another co-resident workgroup fills the gaps, more LDS stages do not.  Hence three workgroups per CU, as few load instructions per
+// step as the bytes allow, and the 16-row instruction.  A worker walks WHOLE tiles (vbs_union.cpp deals them costliest first).  A tile's TAIL -- up to 16 nonzeros per row in
 // columns too thinly used for the list (a cluster's rows have a few columns of their own): lane (i, q) holds its row's accumulators of 8 of the wave's 32 columns, so per
-// entry it fetches 2 x 16 bytes of ITS row of B and multiplies them in; no sparse-row launch, no second pass over the rows of C -- then stores the tile's rows of C (or
-// adds to them: accumulate).  ONE launch carries all tile types: a workgroup runs the body of each type over its tiles of that type, tallest first.
+// entry it fetches 2 x 16 bytes of ITS row of B and multiplies them in (entry t during the tile's step t + 1, what is left in the last step's epilogue); no sparse-row
+// launch, no second pass over the rows of C -- the last step then stores the tile's rows of C (or adds to them: accumulate).  ONE launch carries all tile types: a workgroup runs the body of each type over its tiles of that type, tallest first.
 #include "vbs_kernel_common.hpp"
 
 using namespace sparta_dev;
