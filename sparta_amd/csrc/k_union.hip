@@ -381,9 +381,10 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
 //   * the slice of A (32 MI rows x 32 k) is stored in HBM as the LDS image [rt][m][kg][row][8] = A[32 rt + row][k = 16 m + 8 kg + e]: one `ds_read_b128` per MFMA and lane;
 //   * the tails multiply in fp32: value (the rounded 16-bit value of A, kept as fp32) x the 16-bit entries of the row of B widened in registers -- products of two 16-bit
 //     values are exact in fp32, as in the matrix instruction.
-// Three LDS stages of 12 KB (4 KB of A -- two of them unused by the <= 32-row tiles -- + 8 KB of B), three workgroups per CU.
+// Two LDS stages of 12 KB (4 KB of A -- two of them unused by the <= 32-row tiles -- + 8 KB of B), three workgroups per CU, the tails in the pipeline (measured, N = 128 / 512 on
+// 2000 clusters: three stages with every tail entry in the epilogue 67.7 / 242.5 us, two stages with the tail pipeline 61.9 / 221.5: profiles/r5/lab_union16.txt).
 #ifndef SPARTA_UNION16_STAGES
-#define SPARTA_UNION16_STAGES 3     /* developer A/B (with SPARTA_UNION16_WPC = workgroups per CU of the launch bound; the plan's workers: SPARTA_UNION_WPC at create time) */
+#define SPARTA_UNION16_STAGES 2     /* developer A/B (with SPARTA_UNION16_WPC = workgroups per CU of the launch bound; the plan's workers: SPARTA_UNION_WPC at create time); the tail pipeline needs 2 */
 #endif
 #ifndef SPARTA_UNION16_WPC
 #define SPARTA_UNION16_WPC 3
@@ -501,6 +502,45 @@ __device__ __forceinline__ void union16_body(const UnionParams& p, const UnionSi
         else { const uint16_t h = (uint16_t)u16; _Float16 x; __builtin_memcpy(&x, &h, 2); return (float)x; }
     };
 
+    // tails in the pipeline (two-stage build only: the step's top wait is then vmcnt(0) and covers them), as in the fp32 kernel: step t of a tile requests the chunks of B of tail
+    // entry t and the (column, value) pair of entry t + 1 ahead of the step's panel loads; step t + 1 trades halves and multiplies entry t in
+    constexpr bool TAILPIPE = NS == 2 && SPARTA_UNION_TAILPIPE != 0;
+    int tstep = 0;
+    bool tb_live = false;
+    uint2 cvn[MI];
+    float tv[MI];
+    u32x4 tbc[MI][2];
+#pragma unroll
+    for (int rt = 0; rt < MI; rt++) {
+        cvn[rt] = uint2{0u, 0u}; tv[rt] = 0.0f;
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) tbc[rt][hh] = u32x4{0u, 0u, 0u, 0u};
+    }
+    const uint16_t* const brow16_t = B16 + n0 + 32 * wave + 8 * g;
+    if (TAILPIPE && !(probe & 8) && !(iq[0] & UREC_LAST) && ((iq[0] >> UREC_TAIL_SHIFT) & 31) > 0) {
+#pragma unroll
+        for (int rt = 0; rt < MI; rt++) cvn[rt] = sd.tail[tq[0] + rt * 32 + lm];
+    }
+    // one tail entry's chunks (lane g holds chunks g and 2 + g of its row's four) -> the lane's four pieces of four columns (halves traded with v_permlane32_swap) -> accumulators
+    auto tail_fma = [&](const float (&av)[MI], const u32x4 (&chunks)[MI][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rt = 0; rt < MI; rt++)
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(chunks[rt][hh][0], chunks[rt][hh][2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(chunks[rt][hh][1], chunks[rt][hh][3], false, false);
+                const uint2 w[2] = {uint2{s0[0], s1[0]}, uint2{s0[1], s1[1]}};
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int qq = 2 * hh + u;
+                    acc[rt][4 * qq + 0] = __builtin_fmaf(av[rt], widen(w[u].x & 0xffffu), acc[rt][4 * qq + 0]);
+                    acc[rt][4 * qq + 1] = __builtin_fmaf(av[rt], widen(w[u].x >> 16), acc[rt][4 * qq + 1]);
+                    acc[rt][4 * qq + 2] = __builtin_fmaf(av[rt], widen(w[u].y & 0xffffu), acc[rt][4 * qq + 2]);
+                    acc[rt][4 * qq + 3] = __builtin_fmaf(av[rt], widen(w[u].y >> 16), acc[rt][4 * qq + 3]);
+                }
+            }
+    };
+
     int stage = 0;
     for (int i = 0; i < n; i++) {
         asm volatile("s_waitcnt vmcnt(%0)" : : "n"((AHEAD - 1) * LPS) : "memory");
@@ -508,6 +548,32 @@ __device__ __forceinline__ void union16_body(const UnionParams& p, const UnionSi
         const Rec rec = nxt;
         int jstage = stage + AHEAD; if (jstage >= NS) jstage -= NS;
         iq[AHEAD] = rec.info; cq[AHEAD] = rec.c_row; tq[AHEAD] = rec.tail_off;
+        if constexpr (TAILPIPE) {
+            // (the compiler is shown that these registers have landed -- it does not see the wait above and would otherwise drain in the middle of the requests below)
+#pragma unroll
+            for (int rt = 0; rt < MI; rt++) {
+                asm volatile("" : : "v"(cvn[rt].x), "v"(cvn[rt].y));
+#pragma unroll
+                for (int hh = 0; hh < 2; hh++) asm volatile("" : : "v"(tbc[rt][hh]));
+            }
+            const int32_t inf = iq[0], inf1 = iq[1];
+            if (tb_live) tail_fma(tv, tbc);
+            tb_live = !(probe & 8) && !(inf & UREC_LAST) && tstep < ((inf >> UREC_TAIL_SHIFT) & 31);
+            if (tb_live) {
+#pragma unroll
+                for (int rt = 0; rt < MI; rt++) {
+                    tv[rt] = __uint_as_float(cvn[rt].y);
+                    const uint16_t* bp = brow16_t + (int64_t)cvn[rt].x * p.ldb;
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++) tbc[rt][hh] = 8 * (2 * hh + g) < ncw ? *reinterpret_cast<const u32x4*>(bp + 16 * hh) : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+            const int tn = (inf & UREC_LAST) ? 0 : tstep + 1;
+            if (!(probe & 8) && !(inf1 & UREC_LAST) && tn < ((inf1 >> UREC_TAIL_SHIFT) & 31)) {
+#pragma unroll
+                for (int rt = 0; rt < MI; rt++) cvn[rt] = sd.tail[tq[1] + (tn * MI + rt) * 32 + lm];
+            }
+        }
         // the step's fragments first, and all of them landed (lgkmcnt counts LDS reads and scalar loads alike: with the next record's scalar loads outstanding, the wait for a
         // fragment would be a wait for them too -- a scalar-cache miss per step); then the next record's scalar loads, this step's requests, and the MFMAs
         s16x8 bf[2], af[MI][2];
@@ -548,53 +614,31 @@ __device__ __forceinline__ void union16_body(const UnionParams& p, const UnionSi
             const int tail_e = (info >> UREC_TAIL_SHIFT) & 31;
             if (tail_e > 0 && !(probe & 8)) {
                 const uint2* tp = sd.tail + tq[0] + lm;
-                const uint16_t* brow16 = B16 + n0 + 32 * wave + 8 * g;          // (16-byte chunks: lane g fetches chunks g and 2 + g of the wave's four)
+                // the lane wants four pieces of four consecutive 16-bit columns (8 bytes at 16 qq + 8 g of the wave's 64 bytes of the row).  Fetched as such, an instruction
+                // touches 32 rows for 16 bytes each.  Instead the two lanes of a row (lane, lane + 32) fetch whole 16-byte chunks -- lane g chunk 2 hh + g -- and trade
+                // halves with v_permlane32_swap (lanes 32..63 of one register <-> lanes 0..31 of another): half the vector-memory instructions, 32 bytes per row each
                 constexpr int CH = 2;
-                for (int e0 = 0; e0 < tail_e; e0 += CH) {
+                const int e_first = TAILPIPE ? (tstep < tail_e ? tstep : tail_e) : 0;          // entries 0 .. S - 2 rode in the steps
+                for (int e0 = e_first; e0 < tail_e; e0 += CH) {
                     uint2 cv[CH][MI];
 #pragma unroll
                     for (int c = 0; c < CH; c++)
 #pragma unroll
                         for (int rt = 0; rt < MI; rt++) cv[c][rt] = e0 + c < tail_e ? tp[((e0 + c) * MI + rt) * 32] : uint2{0u, 0u};
-                    // the lane wants four pieces of four consecutive 16-bit columns (8 bytes at 16 qq + 8 g of the wave's 64 bytes of the row).  Fetched as such, an instruction
-                    // touches 32 rows for 16 bytes each.  Instead the two lanes of a row (lane, lane + 32) fetch whole 16-byte chunks -- lane g chunk 2 hh + g -- and trade
-                    // halves with v_permlane32_swap (lanes 32..63 of one register <-> lanes 0..31 of another): half the vector-memory instructions, 32 bytes per row each
                     u32x4 ch[CH][MI][2];
+                    float av[CH][MI];
 #pragma unroll
                     for (int c = 0; c < CH; c++)
 #pragma unroll
                         for (int rt = 0; rt < MI; rt++) {
-                            const uint16_t* bp = brow16 + (int64_t)cv[c][rt].x * p.ldb;
+                            av[c][rt] = __uint_as_float(cv[c][rt].y);
+                            const uint16_t* bp = brow16_t + (int64_t)cv[c][rt].x * p.ldb;
 #pragma unroll
                             for (int hh = 0; hh < 2; hh++)
                                 ch[c][rt][hh] = (e0 + c < tail_e && 8 * (2 * hh + g) < ncw) ? *reinterpret_cast<const u32x4*>(bp + 16 * hh) : u32x4{0u, 0u, 0u, 0u};
                         }
-                    uint2 bv[CH][MI][4];                  // four consecutive 16-bit columns per piece
 #pragma unroll
-                    for (int c = 0; c < CH; c++)
-#pragma unroll
-                        for (int rt = 0; rt < MI; rt++)
-#pragma unroll
-                            for (int hh = 0; hh < 2; hh++) {
-                                const auto s0 = __builtin_amdgcn_permlane32_swap(ch[c][rt][hh][0], ch[c][rt][hh][2], false, false);
-                                const auto s1 = __builtin_amdgcn_permlane32_swap(ch[c][rt][hh][1], ch[c][rt][hh][3], false, false);
-                                bv[c][rt][2 * hh] = uint2{s0[0], s1[0]};
-                                bv[c][rt][2 * hh + 1] = uint2{s0[1], s1[1]};
-                            }
-#pragma unroll
-                    for (int c = 0; c < CH; c++)
-#pragma unroll
-                        for (int rt = 0; rt < MI; rt++) {
-                            const float av = __uint_as_float(cv[c][rt].y);
-#pragma unroll
-                            for (int qq = 0; qq < 4; qq++) {
-                                const uint2 w2 = bv[c][rt][qq];
-                                acc[rt][4 * qq + 0] = __builtin_fmaf(av, widen(w2.x & 0xffffu), acc[rt][4 * qq + 0]);
-                                acc[rt][4 * qq + 1] = __builtin_fmaf(av, widen(w2.x >> 16), acc[rt][4 * qq + 1]);
-                                acc[rt][4 * qq + 2] = __builtin_fmaf(av, widen(w2.y & 0xffffu), acc[rt][4 * qq + 2]);
-                                acc[rt][4 * qq + 3] = __builtin_fmaf(av, widen(w2.y >> 16), acc[rt][4 * qq + 3]);
-                            }
-                        }
+                    for (int c = 0; c < CH; c++) tail_fma(av[c], ch[c]);
                 }
             }
             float* cbase = p.c_row_major ? p.C + c_row * p.ldc + (n0 + 32 * wave) : p.C + c_row + (int64_t)(n0 + 32 * wave) * p.ldc;
@@ -633,6 +677,7 @@ __device__ __forceinline__ void union16_body(const UnionParams& p, const UnionSi
 #pragma unroll
         for (int k = 0; k < AHEAD; k++) { iq[k] = iq[k + 1]; cq[k] = cq[k + 1]; tq[k] = tq[k + 1]; }
         stage = stage + 1 == NS ? 0 : stage + 1;
+        if constexpr (TAILPIPE) tstep = (info & UREC_LAST) ? 0 : tstep + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
