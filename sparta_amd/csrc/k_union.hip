@@ -52,14 +52,15 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // lab_union_16.txt): three workgroups x two stages 113 us, two x three 128, two x two 124, one x six 202 -- and a launch of at most one workgroup per CU (200 tiles) runs its ten steps in
 // 23 us with two stages, 31 with six: a step is not waiting for its loads, so more of them in flight buy nothing, and another co-resident workgroup does.
 constexpr int kUnionStages = 2;
-constexpr int kUnionLds = kUnionStages * (4 * 2048 + 32 * 512);      // the tallest type's stages
+constexpr int kUnionLds = kUnionStages * (4 * 2048 + kUnionPairFloats * 4 + 32 * 512);      // the tallest type's stages: rows of A, the KB of tail pairs, the panel of B
 
 template <int RT, int NS>
 __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide& sd, const int worker, char* const lds) {
     static_assert(RT >= 1 && RT <= 4, "one to four 16-row MFMA tiles per wave and column tile");
     static_assert(NS == 2, "the step's top wait is vmcnt(0): one step of loads in flight");
-    constexpr int A_BYTES = RT * 2048, B_BYTES = 32 * 512, STAGE = A_BYTES + B_BYTES;
-    constexpr int NPA = 2 * RT;                          // 1 KB pieces of the slice of A per step, dealt to the waves round robin
+    constexpr int A_BYTES = RT * 2048 + kUnionPairFloats * 4, B_BYTES = 32 * 512, STAGE = A_BYTES + B_BYTES;      // (the slice of A + the KB of tail pairs behind it)
+    constexpr int NPA = 2 * RT + 1;                      // 1 KB pieces of the slice per step, dealt to the waves round robin
+    constexpr int SLICE_F = RT * 512 + kUnionPairFloats; // floats of a step's slice in memory
     constexpr int AHEAD = NS - 1;                        // steps between a step's loads and its MFMAs
     constexpr bool TAILPIPE = SPARTA_UNION_TAILPIPE != 0;
     static_assert(NS * STAGE <= kUnionLds, "LDS");
@@ -95,7 +96,7 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
     for (int par = 0; par < 2; par++) voffB[par] = (uint32_t)(((lane & 31) ^ (4 * ((2 * par + (lane >> 5)) & 3))) * 16);
     const uint32_t voffA = (uint32_t)lane * 16u;
     const float* const Bs0 = p.B + n0;
-    const float* const A0 = reinterpret_cast<const float*>(sd.A) + (int64_t)s_begin * (RT * 512);
+    const float* const A0 = reinterpret_cast<const float*>(sd.A) + (int64_t)s_begin * SLICE_F;
     // fragment reads of B: sub-step s (k = 4 s + kq), column tile ct: column 32 wave + 16 ct + i of row k, i.e. chunk 8 wave + 4 ct + (i >> 2) at position chunk ^ (4 kq)
     uint32_t rdB[2];
 #pragma unroll
@@ -106,7 +107,7 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
     auto issue_a = [&](int j, int stage) __attribute__((always_inline)) {
         if (probe & 2) return;
         char* const stp = lds0 + stage * STAGE;
-        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A0 + (int64_t)j * (RT * 512)), 0, A_BYTES, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A0 + (int64_t)j * SLICE_F), 0, A_BYTES, 0x00020000);
 #pragma unroll
         for (int t = 0; t < (NPA + 3) / 4; t++) {
             const int q = wave + 4 * t;
@@ -156,26 +157,21 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
     const uint32_t rstep = p.c_row_major ? (uint32_t)p.ldc * 64u : 64u;          // bytes per 16 rows
     const int ncw = ncv - 32 * wave;                                             // columns of this wave that exist
 
-    // tails in the pipeline (two-stage form): the tile's step t requests, per lane, the pieces of B of tail entry t (2 x 16 bytes of ITS row's column) and the (column, value) pair of
-    // entry t + 1 -- ahead of the step's panel loads, so they do not queue behind them; step t + 1 multiplies entry t in before its MFMAs (the step's top wait covers
-    // them).  A round trip per entry then hides behind a step instead of standing between the tile's last MFMA and its stores; what the steps cannot carry (entries
+    // tails in the pipeline (two-stage form): the tile's step t requests, per lane, the pieces of B of tail entry t (2 x 16 bytes of ITS row's column; the entry's (column,
+    // value) pairs came with the step's slice of A) ahead of the step's panel loads, so they do not queue behind them; step t + 1 multiplies entry t in before its MFMAs
+    // (the step's top wait covers them).  A round trip per entry then hides behind a step instead of standing between the tile's last MFMA and its stores; what the steps cannot carry (entries
     // S - 1 .. of a tile of S steps) is added in the epilogue.
     int tstep = 0;                                       // the current step's index inside its tile
     bool tb_live = false;                                // an entry's pieces were requested by the previous step
-    uint2 cvn[RT];
     float tv[RT];
     f32x4 tb[RT][2];
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) {
-        cvn[rt] = uint2{0u, 0u}; tv[rt] = 0.0f;
+        tv[rt] = 0.0f;
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) tb[rt][ct] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     const float* const brow_t = p.B + n0 + 32 * wave + 4 * kq;
-    if (TAILPIPE && !(probe & 8) && !(iq[0] & UREC_LAST) && ((iq[0] >> UREC_TAIL_SHIFT) & 31) > 0) {
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++) cvn[rt] = sd.tail[tq[0] + rt * 16 + li];
-    }
 #if SPARTA_UNION_STATS
     // lab build only (results WRONG: the sums overwrite the head of C): cycles this wave spent waiting for its loads / at the barrier / in the multiply phase / in epilogues
     uint64_t st_wait = 0, st_bar = 0, st_mul = 0, st_epi = 0;
@@ -201,11 +197,9 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
             // (the compiler counts vmcnt for the loads it emitted and does not see the wait above: without telling it that these registers have landed it waits for them
             // in the MIDDLE of the requests below -- with loads under branches in between it cannot count, so it drains: a round trip per step, exposed)
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++) {
-                asm volatile("" : : "v"(cvn[rt].x), "v"(cvn[rt].y));        // (a USE, not a redefinition: loop-carried registers that an asm redefines get copied at the back edge -- behind a wait)
+            for (int rt = 0; rt < RT; rt++)
 #pragma unroll
-                for (int ct = 0; ct < 2; ct++) asm volatile("" : : "v"(tb[rt][ct]));
-            }
+                for (int ct = 0; ct < 2; ct++) asm volatile("" : : "v"(tb[rt][ct]));        // (a USE, not a redefinition: loop-carried registers that an asm redefines get copied at the back edge -- behind a wait)
             const int32_t inf = iq[0];
             if (tb_live) {                                 // the entry the previous step requested
 #pragma unroll
@@ -217,18 +211,16 @@ __device__ __forceinline__ void union_body(const UnionParams& p, const UnionSide
             }
             tb_live = !(probe & 8) && !(inf & UREC_LAST) && tstep < ((inf >> UREC_TAIL_SHIFT) & 31);
             if (tb_live) {
+                // the entry's (column, value) pairs came with the step's slice: [rt][row] uint2 behind the rows of A
+                const uint2* const pairs = reinterpret_cast<const uint2*>(lds0 + stage * STAGE + RT * 2048) + li;
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
-                    tv[rt] = __uint_as_float(cvn[rt].y);
-                    const float* bp = brow_t + (int64_t)cvn[rt].x * p.ldb;
+                    const uint2 cv = pairs[rt * 16];
+                    tv[rt] = __uint_as_float(cv.y);
+                    const float* bp = brow_t + (int64_t)cv.x * p.ldb;
 #pragma unroll
                     for (int ct = 0; ct < 2; ct++) tb[rt][ct] = 16 * ct + 4 * kq < ncw ? *reinterpret_cast<const f32x4*>(bp + 16 * ct) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 }
-            }
-            const int tn = (inf & UREC_LAST) ? 0 : tstep + 1;                  // the next step's index inside ITS tile
-            if (!(probe & 8) && !(rec.info & UREC_LAST) && tn < ((rec.info >> UREC_TAIL_SHIFT) & 31)) {
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++) cvn[rt] = sd.tail[rec.tail_off + (tn * RT + rt) * 16 + li];
             }
         }
         // (4) multiply step i: the fragments first (the LDS reads of the whole step), then 16 RT matrix instructions with the loads of step i + 1 issued between them

@@ -209,11 +209,12 @@ static_assert(sizeof(UnionRec) == 16, "UnionRec must stay 16 bytes");
 constexpr int32_t UREC_LAST = 1 << 16;                   // the tile's last step: add the tail, store the tile's rows of C
 constexpr int UREC_TAIL_SHIFT = 17;
 constexpr int kUnionPadSteps = 4;                        // records / list entries / slices behind the last step (the pipeline requests up to three steps past a worker's range)
+constexpr int kUnionPairFloats = 256;    // fp32 plans: floats (1 KB) behind a step's slice of A that hold the (column, value) pairs of the tail entry the step requests
 constexpr int kUnionTypes = 4;    // tile types of one handle.  fp32: type t = tiles of 16 t + 1 .. 16 (t + 1) rows (t + 1 MFMA row tiles of 16); 16-bit: types 0, 1 = tiles of <= 32 / 33..64 rows
 struct UnionSide {                // one tile type
     const UnionRec* rec;          // per step, in execution order (worker after worker)
     const int32_t* ids;           // [step][32]: the rows of B (= columns of A) of the step's list positions; behind the valid ones the tile's first column (fetched: A holds zeros there)
-    const void* A;                // the steps' slices as the LDS image the kernel wants.  fp32, type t (R = 16 (t + 1) rows): [step][rt][h][lane][4] floats, lane = 16 kq + i:
+    const void* A;                // the steps' slices as the LDS image the kernel wants.  fp32, type t (R = 16 (t + 1) rows): [step]{[rt][h][lane][4] floats, then kUnionPairFloats: the step's tail pairs [row] uint2}, lane = 16 kq + i:
                                   // A[16 rt + i][k = 4 (4 h + e) + kq] (one ds_read_b128 per lane = the row's values of four consecutive 16x16x4 MFMAs);
                                   // 16-bit, type t (32 (t + 1) rows): [step][rt][m][kg][row][8] = A[32 rt + row][k = 16 m + 8 kg + e]
     const int32_t* worker_range;  // [2 x workers]: begin, end step
@@ -463,7 +464,7 @@ struct StreamPlanHost {
 struct UnionDevPlan {
     std::vector<UnionRec> rec[kUnionTypes];
     std::vector<int32_t> ids[kUnionTypes];
-    std::vector<float> a[kUnionTypes];        // fp32 handles: slices [step][R x 32] floats (R = 16 (type + 1)), the layout of UnionSide::A
+    std::vector<float> a[kUnionTypes];        // fp32 handles: slices [step][R x 32 + kUnionPairFloats] floats (R = 16 (type + 1)), the layout of UnionSide::A
     std::vector<uint16_t> a16[kUnionTypes];   // 16-bit handles: slices [step][R x 32] 16-bit elements (R = 32 (type + 1)), rounded to the storage type
     std::vector<int32_t> wrange[kUnionTypes];
     std::vector<uint32_t> tail[kUnionTypes];  // (column, value bits) pairs, tile after tile in execution order

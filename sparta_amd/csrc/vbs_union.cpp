@@ -116,7 +116,9 @@ int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPl
         if (total + kUnionPadSteps > INT32_MAX || tail_total > INT32_MAX)
             return sparta::fail(SPARTA_ERR_UNSUPPORTED, "sparta_vbs_create: too many steps of column-compacted tiles for 32-bit step indices");
         P.n_workers[ty] = Wt; P.n_steps[ty] = total; P.n_tiles[ty] = (int64_t)T.size();
-        const size_t slice = (size_t)R * 32;                                   // elements of A per step
+        // elements of a step's slice: its rows of A x 32 k, and -- fp32 plans -- one more KB behind them: the (column, value) pairs of the tile's tail entry the step requests
+        // ([rt][row of the row tile] uint2; the kernel gets them with the slice, one LDS-direct load per workgroup, instead of one vector load per wave and row tile)
+        const size_t slice = (size_t)R * 32 + (h16 ? 0 : (size_t)kUnionPairFloats);
         P.rec[ty].assign((size_t)(total + kUnionPadSteps), UnionRec{0, 0, 0, 0});
         P.ids[ty].assign((size_t)(total + kUnionPadSteps) * 32, 0);
         if (h16) P.a16[ty].assign((size_t)(total + kUnionPadSteps) * slice, (uint16_t)0);
@@ -178,6 +180,13 @@ int build_union_plan(const sparta::UnionPlanHost& U, int max_workers, UnionDevPl
                         }
                         // fp32: [rt][h][lane = 16 kq + i][e] = A[16 rt + i][k = 4 (4 h + e) + kq]
                         float* dst = P.a[ty].data() + (size_t)s * slice;
+                        if (q < tl.tail_e && q + 1 < ns) {                    // tail entry q rides in the tile's step q (requested there, multiplied in by step q + 1): its pairs
+                            uint32_t* pr = reinterpret_cast<uint32_t*>(dst + (size_t)R * 32);
+                            for (int row = 0; row < R; row++) {
+                                const size_t at = (size_t)(to + q * R + row) * 2;      // (the tile's tail in the plan's layout, written above)
+                                pr[2 * row] = P.tail[ty][at]; pr[2 * row + 1] = P.tail[ty][at + 1];
+                            }
+                        }
                         for (int k = 0; k < nvalid; k++) {
                             const int kq = k & 3, sub = k >> 2, h = sub >> 2, e = sub & 3;
                             const float* src = img + (32 * q + k) * ldt + ref.row0;
@@ -205,7 +214,7 @@ void union_plan_host_apply(const UnionDevPlan& P, const float* x, double* y) {  
             for (int64_t s = P.wrange[ty][(size_t)w * 2]; s < P.wrange[ty][(size_t)w * 2 + 1]; s++) {
                 const UnionRec r = P.rec[ty][(size_t)s];
                 const int mt = r.info & 127, nvalid = (r.info >> 8) & 63, tail_e = (r.info >> UREC_TAIL_SHIFT) & 31;
-                const float* sl = P.a[ty].data() + (size_t)s * (size_t)R * 32;
+                const float* sl = P.a[ty].data() + (size_t)s * ((size_t)R * 32 + (size_t)kUnionPairFloats);
                 for (int row = 0; row < mt && row < R; row++) {
                     double acc = 0.0;
                     for (int k = 0; k < nvalid; k++) {

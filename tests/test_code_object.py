@@ -145,7 +145,7 @@ def test_resident_column_kernels_keep_their_sums_in_registers(tmp_path):
 
 
 def test_column_compacted_tile_kernel_fits_three_workgroups_per_cu(tmp_path):
-    """k_union.hip: three workgroups per CU is the point of its two-stage pipeline (profiles/r5/lab_union_stages.txt): 48 KB of LDS (two stages of the tallest tile type: 8 KB of A +
+    """k_union.hip: three workgroups per CU is the point of its two-stage pipeline (profiles/r5/lab_union_stages.txt): 50 KB of LDS (two stages of the tallest tile type: 8 KB of A + 1 KB of tail pairs +
     16 KB of B), at most 168 registers (three waves per SIMD), nothing in scratch; its panel loads are one LDS-direct load per 1 KB piece; and the matrix instruction is the 16-row one (16 RT per step of the body of
     RT row tiles, RT = 1..4: a 48-row cluster pays for three row tiles, not four)."""
     kernels = _kernel_metadata(tmp_path)
@@ -154,7 +154,7 @@ def test_column_compacted_tile_kernel_fits_three_workgroups_per_cu(tmp_path):
     for name, m in un.items():
         assert m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, (name, m)
         assert m["vgpr_count"] <= 168, (name, m)
-        assert m["group_segment_fixed_size"] == 2 * (2 * 4096 + 32 * 512), (name, m)
+        assert m["group_segment_fixed_size"] == 2 * (2 * 4096 + 1024 + 32 * 512) and 3 * m["group_segment_fixed_size"] <= 160 * 1024, (name, m)
     txt = [t for n, t in _disassemble(tmp_path).items() if "vbs_union_f32_kernel" in n]
     assert len(txt) == 1
     ins = [l.split("//")[0].strip() for l in txt[0].splitlines() if l.startswith(("\t", " "))]
