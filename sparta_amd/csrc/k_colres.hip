@@ -172,8 +172,12 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
         const cr_u2* ec = reinterpret_cast<const cr_u2*>(p.col4) + (size_t)off * 64 + lane;
         const cr_f4* ev = UNIT ? nullptr : reinterpret_cast<const cr_f4*>(p.val4) + (size_t)off * 64 + lane;
         const int32_t* bnd = bnd_all + rg * n_slices + sl0;        // bnd[i]: the batch behind the last one of the wave's i-th slice
+        // all of the wave's boundaries in ONE load (lane i holds bnd[i]; SL <= 64): read at every slice end they were a dependent round trip each -- a global load and the wait for
+        // it, 3 to 12 times per wave and range -- in the middle of the stream
+        static_assert(SL <= 64, "a lane per slice of the wave");
+        const int bnd_v = lane < n_w ? bnd[lane] : -1;
         int i = 0;
-        int nb = T > 0 ? __builtin_amdgcn_readfirstlane(bnd[0]) : -1;
+        int nb = T > 0 ? __builtin_amdgcn_readlane(bnd_v, 0) : -1;
         float cur[NC];
 #pragma unroll
         for (int jj = 0; jj < NC; jj++) cur[jj] = acc[0][jj];
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(kCrThreads) void colres_kernel(const ColresParams p
                         }
                     }
                 }
-                nb = i < n_w ? __builtin_amdgcn_readfirstlane(bnd[i]) : -1;
+                nb = i < n_w ? __builtin_amdgcn_readlane(bnd_v, i) : -1;
             }
         };
         for (int t0 = 0; t0 < T; t0 += D) {
